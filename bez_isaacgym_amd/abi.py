@@ -1,0 +1,120 @@
+"""ctypes mirror of include/bez_sim.h (the C ABI of libbez_sim.so).
+
+Only declarations live here: struct layout, enums, and the default `BezSimConfig` for
+`bez_kick` (values: bez_isaacgym/cfg/task/bez_kick.yaml:11-147, kick_env.py:322-329 of the
+reference).  Loading / calling the library is in `bez_isaacgym_amd.sim`.
+"""
+import ctypes as C
+import math
+
+ABI_VERSION = 1
+NUM_OBS = 54
+NUM_ACTIONS = 18
+NUM_DOFS = 18
+NUM_BODIES = 22
+NUM_ACTORS = 2
+NUM_LINKS = 19
+
+FLAG_IMU_PREV_ALIAS = 1
+
+(TENSOR_ROOT_STATE, TENSOR_DOF_STATE, TENSOR_RIGID_BODY_STATE, TENSOR_NET_CONTACT_FORCE, TENSOR_OBS,
+ TENSOR_REW, TENSOR_RESET, TENSOR_PROGRESS, TENSOR_TIMEOUT, TENSOR_DOF_TARGET, TENSOR_PREV_LIN_VEL,
+ TENSOR_FEET, TENSOR_COUNT) = range(13)
+DTYPE_F32, DTYPE_I64 = 0, 1
+PARAM_FRICTION, PARAM_KP_SCALE, PARAM_KD_SCALE, PARAM_MASS_SCALE, PARAM_GRAVITY, PARAM_COUNT = range(6)
+PARAM_WIDTH = {PARAM_FRICTION: 1, PARAM_KP_SCALE: 18, PARAM_KD_SCALE: 18, PARAM_MASS_SCALE: 19, PARAM_GRAVITY: 3}
+
+
+class BezSimConfig(C.Structure):
+    _fields_ = [
+        ("abi_version", C.c_int32),
+        ("num_envs", C.c_int32),
+        ("substeps", C.c_int32),
+        ("max_episode_length", C.c_int32),
+        ("dt", C.c_float),
+        ("gravity", C.c_float * 3),
+        ("kp", C.c_float),
+        ("kd", C.c_float),
+        ("armature", C.c_float),
+        ("effort", C.c_float),
+        ("vel_limit", C.c_float),
+        ("joint_friction", C.c_float),
+        ("plane_friction", C.c_float),
+        ("clip_actions", C.c_float),
+        ("bez_init", C.c_float * 7),
+        ("ball_init", C.c_float * 7),
+        ("goal", C.c_float * 2),
+        ("contact_kn", C.c_float),
+        ("contact_cn", C.c_float),
+        ("contact_ct", C.c_float),
+        ("contact_veps", C.c_float),
+        ("limit_k", C.c_float),
+        ("limit_d", C.c_float),
+        ("jfric_veps", C.c_float),
+        ("ball_ang_damping", C.c_float),
+        ("flags", C.c_uint32),
+        ("seed", C.c_uint64),
+        ("env_id_offset", C.c_int64),
+    ]
+
+    def as_dict(self):
+        out = {}
+        for name, _ in self._fields_:
+            v = getattr(self, name)
+            out[name] = list(v) if hasattr(v, "__len__") else v
+        return out
+
+
+# Contact / limit model constants of this build (no reference counterpart; DESIGN.md "Physics model")
+CONTACT_DEFAULTS = dict(contact_kn=2.0e4, contact_cn=20.0, contact_ct=1.0e3, contact_veps=0.01,
+                        limit_k=200.0, limit_d=2.0, jfric_veps=0.1, ball_ang_damping=0.5)
+
+
+def default_config(num_envs=4096, seed=42, env_id_offset=0):
+    """bez_kick defaults; must agree field-for-field with bez_sim_default_config() in the library."""
+    c = BezSimConfig()
+    c.abi_version = ABI_VERSION
+    c.num_envs = int(num_envs)
+    c.substeps = 2
+    c.dt = 0.01667
+    c.max_episode_length = int(15.0 / 0.01667 + 0.5)  # kick_env.py:127 -> 900
+    c.gravity[:] = [0.0, 0.0, -9.81]
+    c.kp, c.kd = 100.0, 7.5
+    c.armature = 0.001
+    c.effort = 2.5
+    c.vel_limit = 2.0 * math.pi
+    c.joint_friction = 0.1
+    c.plane_friction = 1.0
+    c.clip_actions = 3.9
+    c.bez_init[:] = [0.0, 0.0, 0.34, 0.0, 0.0, 0.0, 1.0]
+    c.ball_init[:] = [0.175, 0.0, 0.1, 0.0, 0.0, 0.0, 1.0]
+    c.goal[:] = [1.5, 0.0]
+    for k, v in CONTACT_DEFAULTS.items():
+        setattr(c, k, v)
+    c.flags = FLAG_IMU_PREV_ALIAS
+    c.seed = int(seed)
+    c.env_id_offset = int(env_id_offset)
+    return c
+
+
+def config_from_task_cfg(cfg, seed=42, env_id_offset=0, strict_reference_quirks=True):
+    """Build a BezSimConfig from the task config dict (the structure of cfg/task/bez_kick.yaml)."""
+    env, sim = cfg["env"], cfg["sim"]
+    c = default_config(int(env["numEnvs"]), seed=seed, env_id_offset=env_id_offset)
+    c.substeps = int(sim.get("substeps", 2))
+    c.dt = float(sim["dt"])
+    c.max_episode_length = int(float(env["learn"]["episodeLength_s"]) / float(sim["dt"]) + 0.5)
+    c.gravity[:] = [float(x) for x in sim["gravity"]]
+    c.kp = float(env["control"]["stiffness"])
+    c.kd = float(env["control"]["damping"])
+    c.armature = float(env["urdfAsset"]["armature"])
+    c.plane_friction = float(env["plane"]["dynamicFriction"])
+    c.clip_actions = float(env.get("clipActions", float("inf")))
+    c.bez_init[:] = [float(x) for x in env["bezInitState"]["pos"] + env["bezInitState"]["rot"]]
+    c.ball_init[:] = [float(x) for x in env["ballInitState"]["pos"] + env["ballInitState"]["rot"]]
+    c.goal[:] = [float(x) for x in env["goalState"]["goal"]]
+    for k in CONTACT_DEFAULTS:
+        if k in sim.get("bez", {}):
+            setattr(c, k, float(sim["bez"][k]))
+    c.flags = FLAG_IMU_PREV_ALIAS if strict_reference_quirks else 0
+    return c

@@ -1,0 +1,329 @@
+#!/usr/bin/env python3
+"""Offline model compiler: Bez URDF + ball URDF + bez_kick.yaml -> flat constant tables.
+
+Runs ONLY in the build container (it reads /root/reference); the GPU box never parses
+URDF.  Outputs (both committed, both pure data):
+
+  bez_isaacgym_amd/csrc/bez_model_gen.h   constant tables for the HIP kernels and the C oracle
+  bez_isaacgym_amd/model/bez_model.json   same numbers for Python-side tests (numpy CRBA/RNEA)
+
+What is baked (reference file:line each number comes from):
+  * tree, joint origins/axes/limits, link mass/COM/inertia, leg collision boxes
+      resources/assets/bez/model/soccerbot_stl.urdf:34-587
+  * ball mass/inertia/radius
+      resources/assets/objects/ball.urdf:9-28
+  * ready pose (default DOF targets), init states, goal, drive gains, sim rate
+      bez_isaacgym/cfg/task/bez_kick.yaml:11-147
+  * per-DOF overrides stiffness/damping/armature/velocity/friction/effort
+      bez_isaacgym/tasks/kick_env.py:322-329
+Body order = Isaac Gym order [ext]: depth-first from the root, children sorted by joint name
+('/' < letters so '/torso_imu' first).  It reproduces the indices the reference hard-codes:
+IMU body 1 (kick_env.py:175-177), feet 12/20 (kick_env.py:193-196), DOF order = Joints enum
+(kick_env.py:23-41).  Fixed links (/imu_link, /camera) stay output bodies but their inertia
+is merged into the parent for the dynamics.
+"""
+import json
+import math
+import os
+import sys
+import xml.etree.ElementTree as ET
+
+import numpy as np
+import yaml
+
+REF = os.environ.get("BEZ_REFERENCE_ROOT", "/root/reference")
+URDF_BEZ = os.path.join(REF, "resources/assets/bez/model/soccerbot_stl.urdf")
+URDF_BALL = os.path.join(REF, "resources/assets/objects/ball.urdf")
+YAML_TASK = os.path.join(REF, "bez_isaacgym/cfg/task/bez_kick.yaml")
+HERE = os.path.dirname(os.path.abspath(__file__))
+OUT_H = os.path.join(HERE, "..", "csrc", "bez_model_gen.h")
+OUT_JSON = os.path.join(HERE, "bez_model.json")
+
+
+def _vec(s, n=3):
+    v = [float(x) for x in s.split()]
+    assert len(v) == n, s
+    return v
+
+
+def parse_urdf(path):
+    root = ET.parse(path).getroot()
+    links = {}
+    for ln in root.findall("link"):
+        name = ln.get("name")
+        inert = ln.find("inertial")
+        mass = float(inert.find("mass").get("value"))
+        org = inert.find("origin")
+        com = _vec(org.get("xyz"))
+        assert all(abs(x) < 1e-12 for x in _vec(org.get("rpy"))), "inertial rpy must be 0"
+        I = inert.find("inertia")
+        inertia = [float(I.get(k)) for k in ("ixx", "iyy", "izz", "ixy", "ixz", "iyz")]
+        box = None
+        col = ln.find("collision")
+        sphere = None
+        if col is not None:
+            g = col.find("geometry")
+            corg = col.find("origin")
+            cxyz = _vec(corg.get("xyz")) if corg is not None else [0, 0, 0]
+            if corg is not None:
+                assert all(abs(x) < 1e-12 for x in _vec(corg.get("rpy"))), "collision rpy must be 0"
+            if g.find("box") is not None:
+                size = _vec(g.find("box").get("size"))
+                box = {"center": cxyz, "half": [0.5 * s for s in size]}
+            if g.find("sphere") is not None:
+                sphere = float(g.find("sphere").get("radius"))
+        links[name] = {"mass": mass, "com": com, "inertia": inertia, "box": box, "sphere": sphere}
+    joints = []
+    for jn in root.findall("joint"):
+        org = jn.find("origin")
+        assert all(abs(x) < 1e-12 for x in _vec(org.get("rpy"))), "joint rpy must be 0"
+        lim = jn.find("limit")
+        joints.append({
+            "name": jn.get("name"), "type": jn.get("type"),
+            "parent": jn.find("parent").get("link"), "child": jn.find("child").get("link"),
+            "xyz": _vec(org.get("xyz")),
+            "axis": _vec(jn.find("axis").get("xyz")) if jn.find("axis") is not None else [0, 0, 0],
+            "lower": float(lim.get("lower")) if lim is not None else 0.0,
+            "upper": float(lim.get("upper")) if lim is not None else 0.0,
+        })
+    return links, joints
+
+
+def inertia_mat(v):
+    xx, yy, zz, xy, xz, yz = v
+    return np.array([[xx, xy, xz], [xy, yy, yz], [xz, yz, zz]], dtype=np.float64)
+
+
+def skew(v):
+    return np.array([[0, -v[2], v[1]], [v[2], 0, -v[0]], [-v[1], v[0], 0]], dtype=np.float64)
+
+
+def merge_inertia(m1, c1, I1, m2, c2, I2):
+    """Combine two rigid bodies given (mass, com, inertia about own com), same axes."""
+    m = m1 + m2
+    c = (m1 * np.asarray(c1) + m2 * np.asarray(c2)) / m
+    def shift(mm, cc, II):
+        d = np.asarray(cc) - c
+        return II + mm * (np.dot(d, d) * np.eye(3) - np.outer(d, d))
+    return m, c, shift(m1, c1, I1) + shift(m2, c2, I2)
+
+
+def build():
+    links, joints = parse_urdf(URDF_BEZ)
+    ball_links, _ = parse_urdf(URDF_BALL)
+    cfg = yaml.safe_load(open(YAML_TASK))
+    env = cfg["env"]
+
+    children = {}
+    for j in joints:
+        children.setdefault(j["parent"], []).append(j)
+    child_names = {j["child"] for j in joints}
+    roots = [n for n in links if n not in child_names]
+    assert roots == ["/torso"], roots
+
+    # Isaac order: DFS, children sorted by joint name
+    bodies = []  # dicts: name, parent_body, joint
+    def dfs(name, parent_idx, joint):
+        idx = len(bodies)
+        bodies.append({"name": name, "parent": parent_idx, "joint": joint})
+        for j in sorted(children.get(name, []), key=lambda jj: jj["name"]):
+            dfs(j["child"], idx, j)
+    dfs("/torso", -1, None)
+    assert len(bodies) == 21
+    names = [b["name"] for b in bodies]
+    assert names[1] == "/imu_link" and names[12] == "/left_foot" and names[20] == "/right_foot", names
+
+    # dynamic links: root + revolute children; fixed children merged into parent link
+    link_of_body = [None] * len(bodies)
+    body_off = [[0.0, 0.0, 0.0] for _ in bodies]  # body origin in its link frame
+    dyn = []  # link dicts
+    for bi, b in enumerate(bodies):
+        j = b["joint"]
+        L = links[b["name"]]
+        if j is None or j["type"] == "revolute":
+            li = len(dyn)
+            link_of_body[bi] = li
+            dyn.append({
+                "name": b["name"], "body": bi,
+                "parent": -1 if j is None else link_of_body[b["parent"]],
+                "joint_name": None if j is None else j["name"],
+                "axis": [0.0, 0.0, 0.0] if j is None else j["axis"],
+                "xyz": [0.0, 0.0, 0.0] if j is None else j["xyz"],
+                "lower": 0.0 if j is None else j["lower"], "upper": 0.0 if j is None else j["upper"],
+                "mass": L["mass"], "com": np.array(L["com"]), "I": inertia_mat(L["inertia"]),
+                "box": L["box"],
+            })
+            if j is not None:
+                assert bodies[b["parent"]]["joint"] is None or bodies[b["parent"]]["joint"]["type"] == "revolute", \
+                    "revolute child of a fixed body not supported"
+        else:
+            assert j["type"] == "fixed"
+            pl = link_of_body[b["parent"]]
+            link_of_body[bi] = pl
+            off = (np.array(body_off[b["parent"]]) + np.array(j["xyz"])).tolist()
+            body_off[bi] = off
+            d = dyn[pl]
+            m, c, I = merge_inertia(d["mass"], d["com"], d["I"], L["mass"], np.array(off) + np.array(L["com"]),
+                                    inertia_mat(L["inertia"]))
+            d["mass"], d["com"], d["I"] = m, c, I
+    assert len(dyn) == 19
+    # DOF d <-> link d+1; check against the reference's Joints enum order (kick_env.py:23-41)
+    dof_names = [d["joint_name"] for d in dyn[1:]]
+    expect = (["head_motor_0", "head_motor_1", "left_arm_motor_0", "left_arm_motor_1"] +
+              ["left_leg_motor_%d" % i for i in range(6)] + ["right_arm_motor_0", "right_arm_motor_1"] +
+              ["right_leg_motor_%d" % i for i in range(6)])
+    assert dof_names == expect, dof_names
+
+    lower, upper, default = [], [], []
+    for d in dyn[1:]:
+        lo, hi = d["lower"], d["upper"]
+        if lo > hi:  # kick_env.py:393-400
+            lo, hi = hi, lo
+        lower.append(lo); upper.append(hi)
+        default.append(float(env["readyJointAngles"][d["joint_name"]]))
+
+    # leg collision boxes used for ball contact (foot, ankle, calve, thigh, hip_front per leg)
+    boxes = []
+    for li, d in enumerate(dyn):
+        if d["box"] is not None and min(d["box"]["half"]) > 1e-3:
+            boxes.append({"link": li, "center": d["box"]["center"], "half": d["box"]["half"]})
+    # ground contact points: foot box bottom corners + guard points on other bodies.
+    # Upper-body meshes are approximated by bounding-box corners measured from the .dae vertex data
+    # (torso x[-.040,.064] y[+-.0725] z[-.128,.062]; head z top .062; forearm tip z -.131).
+    points = []
+    def add(link_name, p, kind):
+        li = [i for i, d in enumerate(dyn) if d["name"] == link_name][0]
+        points.append({"link": li, "p": [float(x) for x in p], "kind": kind})
+    for side in ("left", "right"):
+        fb = links["/%s_foot" % side]["box"]
+        c, h = fb["center"], fb["half"]
+        for sx in (+1, -1):
+            for sy in (+1, -1):
+                add("/%s_foot" % side, [c[0] + sx * h[0], c[1] + sy * h[1], c[2] - h[2]], "foot")
+    for sx in (-0.040, 0.064):
+        for sy in (-0.0725, 0.0725):
+            for sz in (-0.128, 0.062):
+                add("/torso", [sx, sy, sz], "guard")
+    hc = [-0.013, 0.0, 0.025]  # head collision origin (urdf:530)
+    for sx in (-0.04775, 0.02345):
+        for sy in (-0.04555, 0.04845):
+            add("/head", [hc[0] + sx, hc[1] + sy, hc[2] + 0.0619], "guard")
+    for side, sgn in (("left", 1.0), ("right", -1.0)):
+        add("/%s_forearm" % side, [-0.0055 - 0.005, sgn * (0.005 + 0.0245), -0.131], "guard")
+        cb = links["/%s_calve" % side]["box"]
+        for sx in (+1, -1):  # knee: top edge of the calve box
+            add("/%s_calve" % side, [cb["center"][0] + sx * cb["half"][0], cb["center"][1],
+                                     cb["center"][2] + cb["half"][2]], "guard")
+
+    ball = ball_links["base_link"]
+    model = {
+        "num_bodies": 21, "num_links": 19, "num_dofs": 18,
+        "body_names": names, "dof_names": dof_names,
+        "body_link": link_of_body, "body_offset": body_off,
+        "links": [{
+            "name": d["name"], "body": d["body"], "parent": d["parent"], "axis": d["axis"], "xyz": d["xyz"],
+            "mass": d["mass"], "com": d["com"].tolist(),
+            "inertia": [d["I"][0, 0], d["I"][1, 1], d["I"][2, 2], d["I"][0, 1], d["I"][0, 2], d["I"][1, 2]],
+        } for d in dyn],
+        "dof_lower": lower, "dof_upper": upper, "dof_default": default,
+        "boxes": boxes, "ground_points": points,
+        "ball": {"mass": ball["mass"], "inertia": ball["inertia"][0], "radius": ball["sphere"]},
+        "cfg": {
+            "dt": float(cfg["sim"]["dt"]), "substeps": int(cfg["sim"]["substeps"]),
+            "gravity": [float(x) for x in cfg["sim"]["gravity"]],
+            "kp": float(env["control"]["stiffness"]), "kd": float(env["control"]["damping"]),
+            "armature": float(env["urdfAsset"]["armature"]),
+            "effort": 2.5, "vel_limit": 2.0 * math.pi, "joint_friction": 0.1,  # kick_env.py:327-329
+            "plane_friction": float(env["plane"]["dynamicFriction"]),
+            "clip_actions": float(env["clipActions"]),
+            "episode_length_s": float(env["learn"]["episodeLength_s"]),
+            "bez_init": [float(x) for x in env["bezInitState"]["pos"] + env["bezInitState"]["rot"]],
+            "ball_init": [float(x) for x in env["ballInitState"]["pos"] + env["ballInitState"]["rot"]],
+            "goal": [float(x) for x in env["goalState"]["goal"]],
+        },
+        "total_mass": float(sum(d["mass"] for d in dyn)),
+    }
+    return model
+
+
+def fmt(x):
+    return repr(float(x))
+
+
+def arr(vals):
+    return "{" + ", ".join(fmt(v) for v in vals) + "}"
+
+
+def emit_header(m):
+    L = m["links"]
+    o = []
+    o.append("/* GENERATED by bez_isaacgym_amd/model/compile_model.py -- do not edit.\n"
+             " * Flat model constants for the Bez humanoid as bez_kick loads it (soccerbot_stl.urdf,\n"
+             " * ball.urdf, bez_kick.yaml).  Pure data: shared by the HIP kernels and the C oracle. */")
+    o.append("#ifndef BEZ_MODEL_GEN_H\n#define BEZ_MODEL_GEN_H")
+    o.append("#if defined(__HIPCC__)\n#define BEZ_TBL static __device__ __host__ constexpr\n"
+             "#elif defined(__cplusplus)\n#define BEZ_TBL static constexpr\n#else\n#define BEZ_TBL static const\n#endif")
+    o.append("#define BEZ_NB 21      /* robot rigid bodies, Isaac order */")
+    o.append("#define BEZ_NBE 22     /* bodies per env incl. ball */")
+    o.append("#define BEZ_NL 19      /* dynamic links (fixed children merged) */")
+    o.append("#define BEZ_ND 18      /* actuated DOFs; DOF d drives link d+1 */")
+    o.append("#define BEZ_NBOX %d" % len(m["boxes"]))
+    o.append("#define BEZ_NPT %d" % len(m["ground_points"]))
+    o.append("#define BEZ_IMU_BODY 1\n#define BEZ_LFOOT_BODY 12\n#define BEZ_RFOOT_BODY 20")
+    o.append("#define BEZ_LFOOT_LINK %d\n#define BEZ_RFOOT_LINK %d" % (m["body_link"][12], m["body_link"][20]))
+    def axis_code(a):
+        for k in range(3):
+            if abs(abs(a[k]) - 1.0) < 1e-12:
+                return int(math.copysign(k + 1, a[k]))
+        return 0
+    o.append("BEZ_TBL int BEZ_LINK_PARENT[BEZ_NL] = {%s};" % ", ".join(str(l["parent"]) for l in L))
+    o.append("BEZ_TBL int BEZ_LINK_BODY[BEZ_NL] = {%s};" % ", ".join(str(l["body"]) for l in L))
+    o.append("/* joint axis code: +-1 = +-x, +-2 = +-y, +-3 = +-z, 0 = root */")
+    o.append("BEZ_TBL int BEZ_LINK_AXIS[BEZ_NL] = {%s};" % ", ".join(str(axis_code(l["axis"])) for l in L))
+    o.append("BEZ_TBL double BEZ_LINK_AXIS_VEC[BEZ_NL][3] = {%s};" % ", ".join(arr(l["axis"]) for l in L))
+    o.append("BEZ_TBL double BEZ_LINK_XYZ[BEZ_NL][3] = {%s};" % ", ".join(arr(l["xyz"]) for l in L))
+    o.append("BEZ_TBL double BEZ_LINK_MASS[BEZ_NL] = %s;" % arr(l["mass"] for l in L))
+    o.append("BEZ_TBL double BEZ_LINK_COM[BEZ_NL][3] = {%s};" % ", ".join(arr(l["com"]) for l in L))
+    o.append("/* inertia about COM, link axes: xx yy zz xy xz yz */")
+    o.append("BEZ_TBL double BEZ_LINK_INERTIA[BEZ_NL][6] = {%s};" % ", ".join(arr(l["inertia"]) for l in L))
+    o.append("BEZ_TBL int BEZ_BODY_LINK[BEZ_NB] = {%s};" % ", ".join(str(x) for x in m["body_link"]))
+    o.append("BEZ_TBL double BEZ_BODY_OFFSET[BEZ_NB][3] = {%s};" % ", ".join(arr(x) for x in m["body_offset"]))
+    o.append("BEZ_TBL double BEZ_DOF_LOWER[BEZ_ND] = %s;" % arr(m["dof_lower"]))
+    o.append("BEZ_TBL double BEZ_DOF_UPPER[BEZ_ND] = %s;" % arr(m["dof_upper"]))
+    o.append("BEZ_TBL double BEZ_DOF_DEFAULT[BEZ_ND] = %s;" % arr(m["dof_default"]))
+    o.append("BEZ_TBL int BEZ_BOX_LINK[BEZ_NBOX] = {%s};" % ", ".join(str(b["link"]) for b in m["boxes"]))
+    o.append("BEZ_TBL double BEZ_BOX_CENTER[BEZ_NBOX][3] = {%s};" % ", ".join(arr(b["center"]) for b in m["boxes"]))
+    o.append("BEZ_TBL double BEZ_BOX_HALF[BEZ_NBOX][3] = {%s};" % ", ".join(arr(b["half"]) for b in m["boxes"]))
+    o.append("/* ground contact points (link-local); the first 8 are the foot-box bottom corners (4 left, 4 right) */")
+    o.append("BEZ_TBL int BEZ_PT_LINK[BEZ_NPT] = {%s};" % ", ".join(str(p["link"]) for p in m["ground_points"]))
+    o.append("BEZ_TBL double BEZ_PT_POS[BEZ_NPT][3] = {%s};" % ", ".join(arr(p["p"]) for p in m["ground_points"]))
+    o.append("#define BEZ_BALL_MASS %s\n#define BEZ_BALL_INERTIA %s\n#define BEZ_BALL_RADIUS %s" % (
+        fmt(m["ball"]["mass"]), fmt(m["ball"]["inertia"]), fmt(m["ball"]["radius"])))
+    c = m["cfg"]
+    o.append("/* bez_kick.yaml / kick_env.py defaults (runtime-overridable through BezSimConfig) */")
+    for k in ("dt", "kp", "kd", "armature", "effort", "vel_limit", "joint_friction", "plane_friction",
+              "clip_actions", "episode_length_s"):
+        o.append("#define BEZ_DEFAULT_%s %s" % (k.upper(), fmt(c[k])))
+    o.append("#define BEZ_DEFAULT_SUBSTEPS %d" % c["substeps"])
+    o.append("BEZ_TBL double BEZ_DEFAULT_GRAVITY[3] = %s;" % arr(c["gravity"]))
+    o.append("BEZ_TBL double BEZ_DEFAULT_BEZ_INIT[7] = %s;" % arr(c["bez_init"]))
+    o.append("BEZ_TBL double BEZ_DEFAULT_BALL_INIT[7] = %s;" % arr(c["ball_init"]))
+    o.append("BEZ_TBL double BEZ_DEFAULT_GOAL[2] = %s;" % arr(c["goal"]))
+    o.append("#endif /* BEZ_MODEL_GEN_H */\n")
+    return "\n".join(o)
+
+
+def main():
+    m = build()
+    with open(OUT_JSON, "w") as f:
+        json.dump(m, f, indent=1)
+    with open(OUT_H, "w") as f:
+        f.write(emit_header(m))
+    print("links:")
+    for i, l in enumerate(m["links"]):
+        print(i, l["name"], "parent", l["parent"], "axis", l["axis"], "xyz", l["xyz"], "m=%.6f" % l["mass"])
+    print("total mass %.6f kg; %d boxes; %d ground points" % (m["total_mass"], len(m["boxes"]), len(m["ground_points"])))
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -1,0 +1,175 @@
+/* bez_sim.h -- C ABI of the MI355X-native Bez `bez_kick` simulator (libbez_sim.so).
+ *
+ * This is the drop-in boundary for the hot path VecTask.step():
+ *   reference  bez_isaacgym/tasks/base/vec_task.py:303-349   (step orchestration)
+ *              bez_isaacgym/tasks/kick_env.py:410-438,749-850 (pre/post physics, obs, reset)
+ * The reference has no FFI of its own: everything below the Python `VecTask` goes into the
+ * closed Isaac Gym binary through the `gymapi` tensor API.  Each entry point therefore cites
+ * the gym call (and its call site in the reference) that it replaces.
+ *
+ * Conventions
+ *   - plain C, no torch / HIP types in signatures; `stream` is a hipStream_t passed as void*
+ *     (NULL = the null stream).  All work is enqueued on that stream; nothing synchronises
+ *     unless stated.
+ *   - every pointer named *_dev is device memory on the sim's GPU, borrowed for the call.
+ *   - every function returns 0 on success, <0 on error (message: bez_sim_last_error()).
+ *   - the sim owns all state buffers for its lifetime; bez_sim_get_tensor() exposes them
+ *     zero-copy (gymtorch.wrap_tensor equivalent, kick_env.py:155-157).
+ *   - Isaac-layout tensors (row-major AoS, fp32, per env: 2 actors, 22 bodies, 18 DOFs):
+ *       ROOT_STATE        (N*2, 13)  pos3 quat_xyzw4 linvel3 angvel3     kick_env.py:143
+ *       DOF_STATE         (N*18, 2)  pos vel                             kick_env.py:144
+ *       RIGID_BODY_STATE  (N*22, 13)                                     kick_env.py:145
+ *       NET_CONTACT_FORCE (N*22, 3)                                      kick_env.py:146
+ *     They are *materialised on demand* by bez_sim_refresh_tensor (gym.refresh_*_tensor);
+ *     the simulator's own state is SoA ([field][env], one env per lane).
+ */
+#ifndef BEZ_SIM_H
+#define BEZ_SIM_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BEZ_SIM_ABI_VERSION 1
+
+#define BEZ_NUM_OBS 54
+#define BEZ_NUM_ACTIONS 18
+#define BEZ_NUM_DOFS 18
+#define BEZ_NUM_BODIES 22 /* 21 robot + ball */
+#define BEZ_NUM_ACTORS 2
+
+/* flags */
+#define BEZ_FLAG_IMU_PREV_ALIAS 1u /* quirk Q1 (kick_env.py:930,441): prev_lin_vel aliases the live \
+                                      velocity, so the finite difference is identically 0 */
+
+typedef struct BezSimConfig {
+  int32_t abi_version; /* must be BEZ_SIM_ABI_VERSION */
+  int32_t num_envs;    /* cfg["env"]["numEnvs"]                         vec_task.py:84 */
+  int32_t substeps;    /* cfg["sim"]["substeps"]                        vec_task.py:430 */
+  int32_t max_episode_length; /* int(episodeLength_s/dt+0.5)            kick_env.py:127 */
+  float dt;            /* cfg["sim"]["dt"]                              vec_task.py:427 */
+  float gravity[3];    /* cfg["sim"]["gravity"]                         vec_task.py:439 */
+  float kp, kd;        /* control.stiffness / damping                   kick_env.py:324-325 */
+  float armature;      /* urdfAsset.armature                            kick_env.py:326 */
+  float effort;        /* 2.5 N*m all DOFs                              kick_env.py:329 */
+  float vel_limit;     /* 2*pi rad/s                                    kick_env.py:327 */
+  float joint_friction;/* 0.1                                           kick_env.py:328 */
+  float plane_friction;/* plane.dynamicFriction                         kick_env.py:254 */
+  float clip_actions;  /* env.clipActions                               vec_task.py:98,317 */
+  float bez_init[7];   /* bezInitState pos + rot(xyzw)                  kick_env.py:60-64 */
+  float ball_init[7];  /* ballInitState pos + rot                       kick_env.py:67-71 */
+  float goal[2];       /* goalState.goal                                kick_env.py:74,159 */
+  /* Contact / limit model of this build (PhysX's TGS contact solve has no source here; see
+   * DESIGN.md "Physics model").  All forces are spring-dampers integrated implicitly. */
+  float contact_kn;    /* normal stiffness per contact point  [N/m]   */
+  float contact_cn;    /* normal damping                      [N*s/m] */
+  float contact_ct;    /* max tangential (stick) viscosity    [N*s/m] */
+  float contact_veps;  /* Coulomb regularisation speed        [m/s]   */
+  float limit_k;       /* joint-limit spring                  [N*m/rad]   */
+  float limit_d;       /* joint-limit damper                  [N*m*s/rad] */
+  float jfric_veps;    /* joint-friction regularisation speed [rad/s] */
+  float ball_ang_damping; /* Isaac asset default angular_damping 0.5 [ext] for the ball actor */
+  uint32_t flags;      /* BEZ_FLAG_* */
+  uint64_t seed;       /* reset-noise stream key (config.yaml:11 seed: 42) */
+  int64_t env_id_offset; /* global id of local env 0; reset noise is keyed by GLOBAL env id so
+                            results do not depend on how envs are sharded over GPUs */
+} BezSimConfig;
+
+/* Fills `cfg` with the bez_kick.yaml / kick_env.py defaults for `num_envs` environments. */
+int bez_sim_default_config(BezSimConfig* cfg, int32_t num_envs);
+
+typedef struct BezSim BezSim;
+
+enum BezTensor {
+  BEZ_TENSOR_ROOT_STATE = 0,        /* f32 (N*2,13)   acquire_actor_root_state_tensor   kick_env.py:143 */
+  BEZ_TENSOR_DOF_STATE = 1,         /* f32 (N*18,2)   acquire_dof_state_tensor          kick_env.py:144 */
+  BEZ_TENSOR_RIGID_BODY_STATE = 2,  /* f32 (N*22,13)  acquire_rigid_body_state_tensor   kick_env.py:145 */
+  BEZ_TENSOR_NET_CONTACT_FORCE = 3, /* f32 (N*22,3)   acquire_net_contact_force_tensor  kick_env.py:146 */
+  BEZ_TENSOR_OBS = 4,               /* f32 (N,54)     obs_buf       vec_task.py:235 */
+  BEZ_TENSOR_REW = 5,               /* f32 (N)        rew_buf       vec_task.py:239 */
+  BEZ_TENSOR_RESET = 6,             /* i64 (N)        reset_buf     vec_task.py:241 (init 1) */
+  BEZ_TENSOR_PROGRESS = 7,          /* i64 (N)        progress_buf  vec_task.py:245 */
+  BEZ_TENSOR_TIMEOUT = 8,           /* i64 (N)        timeout_buf   vec_task.py:243 */
+  BEZ_TENSOR_DOF_TARGET = 9,        /* f32 (N,18)     PD position targets */
+  BEZ_TENSOR_PREV_LIN_VEL = 10,     /* f32 (N,3)      prev_lin_vel  kick_env.py:183 */
+  BEZ_TENSOR_FEET = 11,             /* f32 (N,8)      self.feet     kick_env.py:185 */
+  BEZ_TENSOR_COUNT = 12
+};
+enum BezDtype { BEZ_DTYPE_F32 = 0, BEZ_DTYPE_I64 = 1 };
+
+/* gym.create_sim + create_env/create_actor loop + prepare_sim + allocate_buffers
+ * (vec_task.py:174-193, kick_env.py:240-408).  All envs start with reset_buf = 1. */
+int bez_sim_create(const BezSimConfig* cfg, int device_id, BezSim** out);
+int bez_sim_destroy(BezSim* sim);
+const char* bez_sim_last_error(const BezSim* sim); /* sim may be NULL: last create error */
+
+/* gymtorch.wrap_tensor(gym.acquire_*_tensor(sim)): device pointer + shape of a sim-owned
+ * buffer.  shape has `*ndim` valid entries. */
+int bez_sim_get_tensor(BezSim* sim, int which, void** dev_ptr, int64_t shape[3], int* ndim, int* dtype);
+
+/* gym.refresh_{actor_root_state,dof_state,rigid_body_state,net_contact_force}_tensor
+ * (kick_env.py:750-753): materialise the Isaac-layout tensor from the SoA state. */
+int bez_sim_refresh_tensor(BezSim* sim, int which, void* stream);
+
+/* gym.set_actor_root_state_tensor_indexed (kick_env.py:831-837): teleport the actors listed in
+ * actor_ids_dev (sim-domain actor index = env*2 + {0 robot, 1 ball}) to the rows of the full
+ * (N*2,13) tensor root_states_dev. */
+int bez_sim_set_actor_root_state_tensor_indexed(BezSim* sim, const float* root_states_dev,
+                                                const int32_t* actor_ids_dev, int32_t n, void* stream);
+/* gym.set_dof_state_tensor_indexed (kick_env.py:844-847); actor ids as above (robot actors). */
+int bez_sim_set_dof_state_tensor_indexed(BezSim* sim, const float* dof_state_dev,
+                                         const int32_t* actor_ids_dev, int32_t n, void* stream);
+/* gym.set_dof_position_target_tensor (kick_env.py:419): (N,18) targets, used as given. */
+int bez_sim_set_dof_position_target_tensor(BezSim* sim, const float* targets_dev, void* stream);
+/* gym.set_dof_position_target_tensor_indexed (kick_env.py:839-842). */
+int bez_sim_set_dof_position_target_tensor_indexed(BezSim* sim, const float* targets_dev,
+                                                   const int32_t* actor_ids_dev, int32_t n, void* stream);
+/* Writes the (N*22,3) net-contact-force tensor into the sim (test hook: the reference's feet
+ * logic reads AND mutates this tensor, kick_env.py:987-990). */
+int bez_sim_set_net_contact_force_tensor(BezSim* sim, const float* forces_dev, void* stream);
+
+/* VecTask.step's clamp + KickEnv.pre_physics_step (vec_task.py:317, kick_env.py:410-419):
+ * a = clamp(actions, +-clip); a[:,0:2] = 0; target = clamp(a + default_dof_pos, lower, upper). */
+int bez_sim_pre_physics(BezSim* sim, const float* actions_dev, void* stream);
+/* gym.simulate (vec_task.py:322-324): one control step dt = `substeps` substeps of articulated
+ * dynamics (ABA, implicit PD drives, contact) for every env. */
+int bez_sim_simulate(BezSim* sim, void* stream);
+/* timeout fill + KickEnv.post_physics_step (vec_task.py:331-335, kick_env.py:426-438):
+ * timeout = progress >= max_len-1; progress += 1; reset_idx(envs with reset_buf != 0);
+ * observations; reward + reset flags. */
+int bez_sim_post_physics(BezSim* sim, void* stream);
+/* The three calls above fused into ONE kernel launch: the whole of VecTask.step
+ * (vec_task.py:303-349) for all envs.  This is the hot path. */
+int bez_sim_step(BezSim* sim, const float* actions_dev, void* stream);
+/* bez_sim_step for n_steps consecutive control steps, actions_dev = (n_steps, N, 18); the
+ * rollout inner loop without a host round trip per step (random-action benchmark). */
+int bez_sim_step_many(BezSim* sim, const float* actions_dev, int32_t n_steps, void* stream);
+
+/* KickEnv.reset_idx (kick_env.py:779-850) for the env ids in env_ids_dev. */
+int bez_sim_reset_indexed(BezSim* sim, const int32_t* env_ids_dev, int32_t n, void* stream);
+
+/* Domain randomisation parameters (vec_task.py:505-725 -> per-env arrays read by the kernel).
+ * values_dev: (N, count) fp32 where count is fixed per param; NULL restores the default. */
+enum BezEnvParam {
+  BEZ_PARAM_FRICTION = 0,   /* (N,1)  ground/ball friction coefficient      bez_kick.yaml:179-186 */
+  BEZ_PARAM_KP_SCALE = 1,   /* (N,18) stiffness scaling                     bez_kick.yaml:200-205 */
+  BEZ_PARAM_KD_SCALE = 2,   /* (N,18) damping scaling                       bez_kick.yaml:194-199 */
+  BEZ_PARAM_MASS_SCALE = 3, /* (N,19) link mass scaling (setup only)        bez_kick.yaml:170-177 */
+  BEZ_PARAM_GRAVITY = 4,    /* (N,3)  gravity vector                        bez_kick.yaml:162-167 */
+  BEZ_PARAM_COUNT = 5
+};
+int bez_sim_set_env_params(BezSim* sim, int param, const float* values_dev, void* stream);
+
+/* Re-keys the reset-noise stream (utils/utils.py:45-70 set_seed). */
+int bez_sim_seed(BezSim* sim, uint64_t seed);
+
+/* Average device time [ms] of the fused step kernel over `n_steps` launches on `stream`,
+ * measured with HIP events recorded on that same stream (bench.py roofline leg). */
+int bez_sim_time_steps(BezSim* sim, const float* actions_dev, int32_t n_steps, void* stream, float* avg_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BEZ_SIM_H */

@@ -1,0 +1,919 @@
+/* bez_oracle.c -- CPU ORACLE for the bez_kick hot path.  TEST INFRASTRUCTURE ONLY.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library,
+ * and only as the checker / reported CPU baseline -- the product path (libbez_sim.so, HIP)
+ * never links, loads or falls back to it.
+ *
+ * What it restates (reference file:line):
+ *   step orchestration        bez_isaacgym/tasks/base/vec_task.py:303-349
+ *   buffers                   bez_isaacgym/tasks/base/vec_task.py:226-249
+ *   PD targets                bez_isaacgym/tasks/kick_env.py:410-419
+ *   post-physics ordering     bez_isaacgym/tasks/kick_env.py:426-438
+ *   reset                     bez_isaacgym/tasks/kick_env.py:779-850
+ *   quaternion_to_matrix      bez_isaacgym/tasks/kick_env.py:857-885   (quirk Q2: wxyz formula on xyzw data)
+ *   compute_imu               bez_isaacgym/tasks/kick_env.py:888-930   (quirk Q1: prev aliases current)
+ *   compute_off_orn           bez_isaacgym/tasks/kick_env.py:933-962
+ *   feet sensors (no cleats)  bez_isaacgym/tasks/kick_env.py:966-1040  (quirk Q3, in-place noise filter)
+ *   compute_bez_reward        bez_isaacgym/tasks/kick_env.py:1198-1395
+ *   compute_bez_observations  bez_isaacgym/tasks/kick_env.py:1398-1417
+ * PARITY PINNING: the obs/reward/reset/target arithmetic above is pinned against golden vectors
+ * produced by the reference's own TorchScript functions (tests/golden/, generator committed).
+ * The rigid-body step (gym.simulate, vec_task.py:324) is Isaac Gym / PhysX, a closed binary that is
+ * not under /root/reference and cannot run here: for that part there is nothing to pin against --
+ * "parity unpinned".  The physics below is this build's own model (Featherstone ABA, implicit PD,
+ * implicit spring-damper contact), written here in plain textbook form (dense 6x6
+ * spatial algebra, runtime tree tables, general Rodrigues rotations) so that it is an independent
+ * check of the hand-specialised fp32 HIP kernels, and validated itself against an independent
+ * numpy CRBA/RNEA and physical invariants (tests/test_oracle_physics.py).
+ *
+ * Build: gcc -O2 -fPIC -shared [-DBEZ_REAL=float] [-fopenmp] -o libbez_oracle_{f64,f32}.so
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../bez_isaacgym_amd/csrc/bez_model_gen.h"
+#include "../include/bez_sim.h"
+
+#ifndef BEZ_REAL
+#define BEZ_REAL double
+#endif
+typedef BEZ_REAL real;
+
+#define NL BEZ_NL
+#define ND BEZ_ND
+
+/* ------------------------------------------------------------------ small linear algebra */
+typedef struct { real v[3]; } V3;
+typedef struct { real m[3][3]; } M3;
+typedef struct { real v[6]; } SV;       /* spatial vector [ang; lin] */
+typedef struct { real m[6][6]; } M6;
+
+static V3 v3(real x, real y, real z) { V3 r = {{x, y, z}}; return r; }
+static V3 v3add(V3 a, V3 b) { return v3(a.v[0] + b.v[0], a.v[1] + b.v[1], a.v[2] + b.v[2]); }
+static V3 v3sub(V3 a, V3 b) { return v3(a.v[0] - b.v[0], a.v[1] - b.v[1], a.v[2] - b.v[2]); }
+static V3 v3scale(V3 a, real s) { return v3(a.v[0] * s, a.v[1] * s, a.v[2] * s); }
+static real v3dot(V3 a, V3 b) { return a.v[0] * b.v[0] + a.v[1] * b.v[1] + a.v[2] * b.v[2]; }
+static V3 v3cross(V3 a, V3 b) {
+  return v3(a.v[1] * b.v[2] - a.v[2] * b.v[1], a.v[2] * b.v[0] - a.v[0] * b.v[2], a.v[0] * b.v[1] - a.v[1] * b.v[0]);
+}
+static V3 m3mulv(const M3* A, V3 x) {
+  V3 r;
+  for (int i = 0; i < 3; ++i) r.v[i] = A->m[i][0] * x.v[0] + A->m[i][1] * x.v[1] + A->m[i][2] * x.v[2];
+  return r;
+}
+static V3 m3Tmulv(const M3* A, V3 x) {
+  V3 r;
+  for (int i = 0; i < 3; ++i) r.v[i] = A->m[0][i] * x.v[0] + A->m[1][i] * x.v[1] + A->m[2][i] * x.v[2];
+  return r;
+}
+static M3 m3mul(const M3* A, const M3* B) {
+  M3 C;
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) {
+      real s = 0;
+      for (int k = 0; k < 3; ++k) s += A->m[i][k] * B->m[k][j];
+      C.m[i][j] = s;
+    }
+  return C;
+}
+static M3 m3T(const M3* A) {
+  M3 C;
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) C.m[i][j] = A->m[j][i];
+  return C;
+}
+static M3 skew(V3 a) {
+  M3 S = {{{0, -a.v[2], a.v[1]}, {a.v[2], 0, -a.v[0]}, {-a.v[1], a.v[0], 0}}};
+  return S;
+}
+/* proper rotation matrix of an xyzw unit quaternion (body -> world) */
+static M3 quat_to_mat(const real q[4]) {
+  real x = q[0], y = q[1], z = q[2], w = q[3];
+  M3 R = {{{1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)},
+           {2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)},
+           {2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)}}};
+  return R;
+}
+/* Rodrigues: rotation by `ang` about unit axis a */
+static M3 rot_axis(V3 a, real ang) {
+  real c = cos(ang), s = sin(ang), t = 1 - c;
+  M3 K = skew(a);
+  M3 R;
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) R.m[i][j] = (i == j ? c : 0) + t * a.v[i] * a.v[j] + s * K.m[i][j];
+  return R;
+}
+static void mat_to_quat(const M3* R, real q[4]) { /* xyzw */
+  real tr = R->m[0][0] + R->m[1][1] + R->m[2][2];
+  if (tr > 0) {
+    real s = sqrt(tr + 1) * 2;
+    q[3] = s / 4; q[0] = (R->m[2][1] - R->m[1][2]) / s; q[1] = (R->m[0][2] - R->m[2][0]) / s; q[2] = (R->m[1][0] - R->m[0][1]) / s;
+  } else if (R->m[0][0] > R->m[1][1] && R->m[0][0] > R->m[2][2]) {
+    real s = sqrt(1 + R->m[0][0] - R->m[1][1] - R->m[2][2]) * 2;
+    q[3] = (R->m[2][1] - R->m[1][2]) / s; q[0] = s / 4; q[1] = (R->m[0][1] + R->m[1][0]) / s; q[2] = (R->m[0][2] + R->m[2][0]) / s;
+  } else if (R->m[1][1] > R->m[2][2]) {
+    real s = sqrt(1 + R->m[1][1] - R->m[0][0] - R->m[2][2]) * 2;
+    q[3] = (R->m[0][2] - R->m[2][0]) / s; q[0] = (R->m[0][1] + R->m[1][0]) / s; q[1] = s / 4; q[2] = (R->m[1][2] + R->m[2][1]) / s;
+  } else {
+    real s = sqrt(1 + R->m[2][2] - R->m[0][0] - R->m[1][1]) * 2;
+    q[3] = (R->m[1][0] - R->m[0][1]) / s; q[0] = (R->m[0][2] + R->m[2][0]) / s; q[1] = (R->m[1][2] + R->m[2][1]) / s; q[2] = s / 4;
+  }
+}
+
+static SV sv(V3 a, V3 l) { SV r = {{a.v[0], a.v[1], a.v[2], l.v[0], l.v[1], l.v[2]}}; return r; }
+static V3 sv_ang(SV s) { return v3(s.v[0], s.v[1], s.v[2]); }
+static V3 sv_lin(SV s) { return v3(s.v[3], s.v[4], s.v[5]); }
+static SV sv_add(SV a, SV b) { SV r; for (int i = 0; i < 6; ++i) r.v[i] = a.v[i] + b.v[i]; return r; }
+static SV sv_scale(SV a, real s) { SV r; for (int i = 0; i < 6; ++i) r.v[i] = a.v[i] * s; return r; }
+static real sv_dot(SV a, SV b) { real s = 0; for (int i = 0; i < 6; ++i) s += a.v[i] * b.v[i]; return s; }
+static SV m6mulv(const M6* A, SV x) {
+  SV r;
+  for (int i = 0; i < 6; ++i) { real s = 0; for (int j = 0; j < 6; ++j) s += A->m[i][j] * x.v[j]; r.v[i] = s; }
+  return r;
+}
+/* motion cross product  V x S */
+static SV crm(SV V, SV S) {
+  V3 w = sv_ang(V), v = sv_lin(V), sa = sv_ang(S), sl = sv_lin(S);
+  return sv(v3cross(w, sa), v3add(v3cross(w, sl), v3cross(v, sa)));
+}
+/* force cross product  V x* F */
+static SV crf(SV V, SV F) {
+  V3 w = sv_ang(V), v = sv_lin(V), n = sv_ang(F), f = sv_lin(F);
+  return sv(v3add(v3cross(w, n), v3cross(v, f)), v3cross(w, f));
+}
+static void m6_add_outer(M6* A, SV w, real k) { /* A += k w w^T */
+  for (int i = 0; i < 6; ++i) for (int j = 0; j < 6; ++j) A->m[i][j] += k * w.v[i] * w.v[j];
+}
+/* wrench of a force f applied at point x (both about the common reference point) */
+static SV wrench_at(V3 x, V3 f) { return sv(v3cross(x, f), f); }
+/* spatial rigid-body inertia about the reference point: mass m, COM at c, rotational inertia Ic about COM */
+static M6 rb_inertia(real m, V3 c, const M3* Ic) {
+  M6 I; memset(&I, 0, sizeof(I));
+  M3 cx = skew(c);
+  M3 cxT = m3T(&cx);
+  M3 cc = m3mul(&cx, &cxT);
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) {
+      I.m[i][j] = Ic->m[i][j] + m * cc.m[i][j];
+      I.m[i][j + 3] = m * cx.m[i][j];
+      I.m[i + 3][j] = m * cxT.m[i][j];
+      I.m[i + 3][j + 3] = (i == j) ? m : 0;
+    }
+  return I;
+}
+/* solve A x = b for SPD 6x6 by Cholesky (A is destroyed) */
+static int chol6_solve(M6* A, SV* b, int nrhs) {
+  for (int j = 0; j < 6; ++j) {
+    real d = A->m[j][j];
+    for (int k = 0; k < j; ++k) d -= A->m[j][k] * A->m[j][k];
+    if (!(d > 0)) return -1;
+    d = sqrt(d);
+    A->m[j][j] = d;
+    for (int i = j + 1; i < 6; ++i) {
+      real s = A->m[i][j];
+      for (int k = 0; k < j; ++k) s -= A->m[i][k] * A->m[j][k];
+      A->m[i][j] = s / d;
+    }
+  }
+  for (int r = 0; r < nrhs; ++r) {
+    real* x = b[r].v;
+    for (int i = 0; i < 6; ++i) { real s = x[i]; for (int k = 0; k < i; ++k) s -= A->m[i][k] * x[k]; x[i] = s / A->m[i][i]; }
+    for (int i = 5; i >= 0; --i) { real s = x[i]; for (int k = i + 1; k < 6; ++k) s -= A->m[k][i] * x[k]; x[i] = s / A->m[i][i]; }
+  }
+  return 0;
+}
+/* general 3x3 inverse by cofactors */
+static M3 m3inv(const M3* A) {
+  const real (*a)[3] = A->m;
+  real c00 = a[1][1] * a[2][2] - a[1][2] * a[2][1], c01 = a[1][2] * a[2][0] - a[1][0] * a[2][2], c02 = a[1][0] * a[2][1] - a[1][1] * a[2][0];
+  real det = a[0][0] * c00 + a[0][1] * c01 + a[0][2] * c02;
+  real id = 1 / det;
+  M3 R = {{{c00 * id, (a[0][2] * a[2][1] - a[0][1] * a[2][2]) * id, (a[0][1] * a[1][2] - a[0][2] * a[1][1]) * id},
+           {c01 * id, (a[0][0] * a[2][2] - a[0][2] * a[2][0]) * id, (a[0][2] * a[1][0] - a[0][0] * a[1][2]) * id},
+           {c02 * id, (a[0][1] * a[2][0] - a[0][0] * a[2][1]) * id, (a[0][0] * a[1][1] - a[0][1] * a[1][0]) * id}}};
+  return R;
+}
+
+/* ------------------------------------------------------------------ Philox4x32-10 (reset noise) */
+static void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
+  for (int r = 0; r < 10; ++r) {
+    uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
+    uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0, n1 = (uint32_t)p1, n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1, n3 = (uint32_t)p0;
+    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+}
+/* k-th uniform in [0,1) of the reset draw of (global env id, episode) */
+static float reset_uniform(uint64_t seed, int64_t genv, uint32_t episode, int k) {
+  uint32_t c[4] = {(uint32_t)genv, (uint32_t)((uint64_t)genv >> 32), episode, (uint32_t)(k >> 2)};
+  philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+  return (float)(c[k & 3] >> 8) * (1.0f / 16777216.0f);
+}
+
+/* ------------------------------------------------------------------ per-env state */
+typedef struct {
+  real root_pos[3], root_quat[4], root_lin[3], root_ang[3];
+  real q[ND], qd[ND];
+  real ball_pos[3], ball_quat[4], ball_lin[3], ball_ang[3];
+  real target[ND];
+  real prev_lin_vel[3];
+  real contact_force[BEZ_NBE][3]; /* per body, world, last substep */
+  real feet[8];
+  real obs[BEZ_NUM_OBS];
+  real rew;
+  int64_t reset, progress, timeout;
+  uint32_t episode;
+  /* DR */
+  real friction, kp_scale[ND], kd_scale[ND], mass_scale[NL], gravity[3];
+} Env;
+
+typedef struct {
+  BezSimConfig cfg;
+  int n;
+  Env* env;
+} Oracle;
+
+/* kinematics of one env: link frames relative to O = root_pos, world axes */
+typedef struct {
+  M3 E[NL];  /* link -> world rotation */
+  V3 r[NL];  /* link origin relative to O */
+  V3 a[NL];  /* joint axis in world */
+} Kin;
+
+static void forward_kinematics(const Env* e, Kin* k) {
+  k->E[0] = quat_to_mat(e->root_quat);
+  k->r[0] = v3(0, 0, 0);
+  k->a[0] = v3(0, 0, 0);
+  for (int l = 1; l < NL; ++l) {
+    int p = BEZ_LINK_PARENT[l];
+    V3 ax = v3((real)BEZ_LINK_AXIS_VEC[l][0], (real)BEZ_LINK_AXIS_VEC[l][1], (real)BEZ_LINK_AXIS_VEC[l][2]);
+    V3 t = v3((real)BEZ_LINK_XYZ[l][0], (real)BEZ_LINK_XYZ[l][1], (real)BEZ_LINK_XYZ[l][2]);
+    k->r[l] = v3add(k->r[p], m3mulv(&k->E[p], t));
+    M3 Rj = rot_axis(ax, e->q[l - 1]);
+    k->E[l] = m3mul(&k->E[p], &Rj);
+    k->a[l] = m3mulv(&k->E[p], ax);
+  }
+}
+
+/* Result of one dynamics evaluation */
+typedef struct {
+  SV a0;         /* root spatial acceleration about O */
+  real qdd[ND];
+  V3 ball_lin_acc, ball_ang_acc; /* classical */
+  real contact_force[BEZ_NBE][3];
+} Dyn;
+
+typedef struct { int link; V3 x; real fn0, kn, ct, ftx0, fty0; } GroundHit;
+
+/* Adds the implicit ground contact of a point at x (rel. O) on a body with velocity V (about O) whose
+ * world height is z.  Returns 1 if active and fills hit.  IA/pA are the body's inertia and bias. */
+static int ground_contact(const BezSimConfig* c, real mu, real h, V3 x, real z, SV V, M6* IA, SV* pA, GroundHit* hit) {
+  real d = -z;
+  if (!(d > 0)) return 0;
+  V3 vp = v3add(sv_lin(V), v3cross(sv_ang(V), x));
+  real kd = h * (real)c->contact_kn + (real)c->contact_cn;
+  real fn0 = (real)c->contact_kn * d - kd * vp.v[2];
+  if (!(fn0 > 0)) return 0;
+  real kn = h * kd;
+  SV wn = wrench_at(x, v3(0, 0, 1));
+  m6_add_outer(IA, wn, kn);
+  *pA = sv_add(*pA, sv_scale(wn, -fn0));
+  real vt = sqrt(vp.v[0] * vp.v[0] + vp.v[1] * vp.v[1]);
+  real ct = mu * fn0 / fmax(vt, (real)c->contact_veps);
+  if (ct > (real)c->contact_ct) ct = (real)c->contact_ct;
+  real kt = h * ct;
+  SV wx = wrench_at(x, v3(1, 0, 0)), wy = wrench_at(x, v3(0, 1, 0));
+  real ftx0 = -ct * vp.v[0], fty0 = -ct * vp.v[1];
+  m6_add_outer(IA, wx, kt);
+  m6_add_outer(IA, wy, kt);
+  *pA = sv_add(*pA, sv_scale(wx, -ftx0));
+  *pA = sv_add(*pA, sv_scale(wy, -fty0));
+  hit->x = x; hit->fn0 = fn0; hit->kn = kn; hit->ct = ct; hit->ftx0 = ftx0; hit->fty0 = fty0;
+  return 1;
+}
+
+/* One evaluation of the build's dynamics model for one env at substep size h.
+ * `mode` 0 = full model; 1 = bare ABA (no PD / friction / limits / contact / armature: used by the
+ * known-answer tests, with tau_in as the applied joint torques). */
+static void dynamics(const BezSimConfig* c, const Env* e, real h, int mode, const real* tau_in, Dyn* out) {
+  Kin k;
+  forward_kinematics(e, &k);
+  V3 g = v3(e->gravity[0], e->gravity[1], e->gravity[2]);
+  SV V[NL], S[NL], cb[NL], pA[NL];
+  M6 IA[NL];
+  memset(out->contact_force, 0, sizeof(out->contact_force));
+
+  /* pass 1: velocities, bias accelerations, rigid-body inertias and bias forces */
+  V[0] = sv(v3(e->root_ang[0], e->root_ang[1], e->root_ang[2]), v3(e->root_lin[0], e->root_lin[1], e->root_lin[2]));
+  memset(&S[0], 0, sizeof(SV));
+  memset(&cb[0], 0, sizeof(SV));
+  for (int l = 0; l < NL; ++l) {
+    if (l > 0) {
+      int p = BEZ_LINK_PARENT[l];
+      S[l] = sv(k.a[l], v3cross(k.r[l], k.a[l]));
+      SV vj = sv_scale(S[l], e->qd[l - 1]);
+      V[l] = sv_add(V[p], vj);
+      cb[l] = crm(V[l], vj);
+    }
+    real m = (real)BEZ_LINK_MASS[l] * e->mass_scale[l];
+    V3 cl = v3((real)BEZ_LINK_COM[l][0], (real)BEZ_LINK_COM[l][1], (real)BEZ_LINK_COM[l][2]);
+    V3 cw = v3add(k.r[l], m3mulv(&k.E[l], cl));
+    const double* il = BEZ_LINK_INERTIA[l];
+    M3 Il = {{{(real)il[0], (real)il[3], (real)il[4]}, {(real)il[3], (real)il[1], (real)il[5]}, {(real)il[4], (real)il[5], (real)il[2]}}};
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) Il.m[i][j] *= e->mass_scale[l];
+    M3 ET = m3T(&k.E[l]);
+    M3 tmp = m3mul(&k.E[l], &Il);
+    M3 Iw = m3mul(&tmp, &ET);
+    IA[l] = rb_inertia(m, cw, &Iw);
+    SV hmom = m6mulv(&IA[l], V[l]);
+    pA[l] = crf(V[l], hmom);
+    SV fg = wrench_at(cw, v3scale(g, m));
+    pA[l] = sv_add(pA[l], sv_scale(fg, -1));
+  }
+
+  /* contacts (implicit spring-dampers folded into IA / pA) */
+  GroundHit hits[BEZ_NPT];
+  int nhit = 0;
+  real mu = e->friction;
+  /* ball as a free body about its own centre, classical accelerations */
+  M6 Mb; memset(&Mb, 0, sizeof(Mb));
+  SV pb; memset(&pb, 0, sizeof(pb));
+  GroundHit bhit; int ball_ground = 0;
+  int bl_link = -1; V3 bl_x = v3(0, 0, 0), bl_xb = v3(0, 0, 0); M3 bl_A; V3 bl_f0p = v3(0, 0, 0);
+  memset(&bl_A, 0, sizeof(bl_A));
+  if (mode == 0) {
+    for (int i = 0; i < BEZ_NPT; ++i) {
+      int l = BEZ_PT_LINK[i];
+      V3 pl = v3((real)BEZ_PT_POS[i][0], (real)BEZ_PT_POS[i][1], (real)BEZ_PT_POS[i][2]);
+      V3 x = v3add(k.r[l], m3mulv(&k.E[l], pl));
+      real z = e->root_pos[2] + x.v[2];
+      if (ground_contact(c, mu, h, x, z, V[l], &IA[l], &pA[l], &hits[nhit])) { hits[nhit].link = l; ++nhit; }
+    }
+    /* ball */
+    real R = (real)BEZ_BALL_RADIUS, mb = (real)BEZ_BALL_MASS, Ib = (real)BEZ_BALL_INERTIA;
+    for (int i = 0; i < 3; ++i) { Mb.m[i][i] = Ib; Mb.m[i + 3][i + 3] = mb; }
+    pb = sv(v3(0, 0, 0), v3scale(g, -mb));
+    SV Vb = sv(v3(e->ball_ang[0], e->ball_ang[1], e->ball_ang[2]), v3(e->ball_lin[0], e->ball_lin[1], e->ball_lin[2]));
+    ball_ground = ground_contact(c, mu, h, v3(0, 0, -R), e->ball_pos[2] - R, Vb, &Mb, &pb, &bhit);
+    /* ball vs leg boxes: deepest penetration only */
+    real best = 0;
+    V3 bc = v3(e->ball_pos[0] - e->root_pos[0], e->ball_pos[1] - e->root_pos[1], e->ball_pos[2] - e->root_pos[2]); /* rel. O */
+    V3 bn = v3(0, 0, 0), bP = v3(0, 0, 0);
+    for (int b = 0; b < BEZ_NBOX; ++b) {
+      int l = BEZ_BOX_LINK[b];
+      V3 cl = v3((real)BEZ_BOX_CENTER[b][0], (real)BEZ_BOX_CENTER[b][1], (real)BEZ_BOX_CENTER[b][2]);
+      V3 he = v3((real)BEZ_BOX_HALF[b][0], (real)BEZ_BOX_HALF[b][1], (real)BEZ_BOX_HALF[b][2]);
+      V3 ql = v3sub(m3Tmulv(&k.E[l], v3sub(bc, k.r[l])), cl); /* ball centre in box frame */
+      V3 cp; int inside = 1;
+      for (int i = 0; i < 3; ++i) {
+        real t = ql.v[i];
+        if (t > he.v[i]) { t = he.v[i]; inside = 0; }
+        if (t < -he.v[i]) { t = -he.v[i]; inside = 0; }
+        cp.v[i] = t;
+      }
+      V3 nl; real depth;
+      if (!inside) {
+        V3 dlt = v3sub(ql, cp);
+        real dist = sqrt(v3dot(dlt, dlt));
+        depth = R - dist;
+        if (!(depth > 0)) continue;
+        nl = v3scale(dlt, 1 / dist);
+      } else { /* centre inside the box: push out through the nearest face */
+        int ax = 0; real md = he.v[0] - fabs(ql.v[0]);
+        for (int i = 1; i < 3; ++i) { real di = he.v[i] - fabs(ql.v[i]); if (di < md) { md = di; ax = i; } }
+        nl = v3(0, 0, 0); nl.v[ax] = ql.v[ax] >= 0 ? 1 : -1;
+        cp = ql; cp.v[ax] = nl.v[ax] * he.v[ax];
+        depth = R + md;
+      }
+      if (depth > best) {
+        best = depth; bl_link = l;
+        bn = m3mulv(&k.E[l], nl);
+        bP = v3add(k.r[l], m3mulv(&k.E[l], v3add(cp, cl)));
+      }
+    }
+    if (bl_link >= 0) {
+      int l = bl_link;
+      V3 x = bP, xb = v3sub(bP, bc);
+      V3 u = v3sub(v3add(sv_lin(V[l]), v3cross(sv_ang(V[l]), x)), v3add(sv_lin(Vb), v3cross(sv_ang(Vb), xb)));
+      real un = v3dot(u, bn);
+      real kd = h * (real)c->contact_kn + (real)c->contact_cn;
+      real fmag = (real)c->contact_kn * best + kd * un;
+      if (fmag > 0) {
+        V3 ut = v3sub(u, v3scale(bn, un));
+        real vt = sqrt(v3dot(ut, ut));
+        real ct = mu * fmag / fmax(vt, (real)c->contact_veps);
+        if (ct > (real)c->contact_ct) ct = (real)c->contact_ct;
+        real kn = h * kd, kt = h * ct;
+        /* force on the LINK: f0 = -(fmag n + ct ut);  K = kn nn^T + kt (1 - nn^T) */
+        V3 f0 = v3scale(v3add(v3scale(bn, fmag), v3scale(ut, ct)), -1);
+        M3 K;
+        for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) K.m[i][j] = (kn - kt) * bn.v[i] * bn.v[j] + (i == j ? kt : 0);
+        /* G = Jb Mb^-1 Jb^T, gb = Jb Mb^-1 pb  with Jb = [-[xb]x  1] */
+        M6 Mc = Mb; SV rhs[4];
+        for (int j = 0; j < 3; ++j) { V3 ej = v3(j == 0, j == 1, j == 2); rhs[j] = wrench_at(xb, ej); }
+        rhs[3] = pb;
+        chol6_solve(&Mc, rhs, 4);
+        M3 G; V3 gb;
+        for (int i = 0; i < 3; ++i) {
+          V3 ei = v3(i == 0, i == 1, i == 2);
+          SV wi = wrench_at(xb, ei);
+          for (int j = 0; j < 3; ++j) G.m[i][j] = sv_dot(wi, rhs[j]);
+          gb.v[i] = sv_dot(wi, rhs[3]);
+        }
+        M3 KG = m3mul(&K, &G);
+        for (int i = 0; i < 3; ++i) KG.m[i][i] += 1;
+        M3 inv = m3inv(&KG);
+        bl_A = m3mul(&inv, &K);
+        bl_f0p = m3mulv(&inv, v3sub(f0, m3mulv(&K, gb)));
+        /* fold into the link: IA += Jl^T A Jl ; pA -= Jl^T f0' */
+        SV Jc[3];
+        for (int j = 0; j < 3; ++j) Jc[j] = wrench_at(x, v3(j == 0, j == 1, j == 2));
+        for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j)
+          for (int a = 0; a < 6; ++a) for (int b2 = 0; b2 < 6; ++b2) IA[l].m[a][b2] += Jc[i].v[a] * bl_A.m[i][j] * Jc[j].v[b2];
+        pA[l] = sv_add(pA[l], sv_scale(wrench_at(x, bl_f0p), -1));
+        bl_x = x; bl_xb = xb;
+      } else {
+        bl_link = -1;
+      }
+    }
+  }
+
+  /* pass 2: articulated inertias, leaves -> root */
+  SV U[NL]; real Dinv[NL], u[NL];
+  for (int l = NL - 1; l >= 1; --l) {
+    int p = BEZ_LINK_PARENT[l], d = l - 1;
+    U[l] = m6mulv(&IA[l], S[l]);
+    real J = sv_dot(S[l], U[l]);
+    real tau, D;
+    if (mode == 0) {
+      J += (real)c->armature;
+      real kp = (real)c->kp * e->kp_scale[d], kdm = (real)c->kd * e->kd_scale[d];
+      real tau_pd0 = kp * (e->target[d] - e->q[d] - h * e->qd[d]) - kdm * e->qd[d];
+      real k_pd = h * h * kp + h * kdm;
+      real cf = (real)c->joint_friction / fmax(fabs(e->qd[d]), (real)c->jfric_veps);
+      real k_f = h * cf, tau_f0 = -cf * e->qd[d];
+      real k_l = 0, tau_l0 = 0;
+      real lo = (real)BEZ_DOF_LOWER[d], hi = (real)BEZ_DOF_UPPER[d];
+      if (e->q[d] < lo) { tau_l0 = (real)c->limit_k * (lo - e->q[d] - h * e->qd[d]) - (real)c->limit_d * e->qd[d]; k_l = h * h * (real)c->limit_k + h * (real)c->limit_d; }
+      else if (e->q[d] > hi) { tau_l0 = (real)c->limit_k * (hi - e->q[d] - h * e->qd[d]) - (real)c->limit_d * e->qd[d]; k_l = h * h * (real)c->limit_k + h * (real)c->limit_d; }
+      /* effort-limit predictor: joint acceleration with the parent held (a_parent = 0) */
+      real bias = sv_dot(S[l], pA[l]) + sv_dot(U[l], cb[l]);
+      real qdd_est = (tau_pd0 + tau_f0 + tau_l0 - bias) / (J + k_pd + k_f + k_l);
+      real tau_drive = tau_pd0 - k_pd * qdd_est;
+      real eff = (real)c->effort;
+      if (tau_drive > eff) { tau = eff + tau_f0 + tau_l0; D = J + k_f + k_l; }
+      else if (tau_drive < -eff) { tau = -eff + tau_f0 + tau_l0; D = J + k_f + k_l; }
+      else { tau = tau_pd0 + tau_f0 + tau_l0; D = J + k_pd + k_f + k_l; }
+    } else {
+      tau = tau_in ? tau_in[d] : 0;
+      D = J;
+    }
+    Dinv[l] = 1 / D;
+    u[l] = tau - sv_dot(S[l], pA[l]);
+    M6 Ia = IA[l];
+    for (int i = 0; i < 6; ++i) for (int j = 0; j < 6; ++j) Ia.m[i][j] -= U[l].v[i] * U[l].v[j] * Dinv[l];
+    SV pa = sv_add(pA[l], sv_add(m6mulv(&Ia, cb[l]), sv_scale(U[l], u[l] * Dinv[l])));
+    for (int i = 0; i < 6; ++i) for (int j = 0; j < 6; ++j) IA[p].m[i][j] += Ia.m[i][j];
+    pA[p] = sv_add(pA[p], pa);
+  }
+  /* root */
+  M6 I0 = IA[0];
+  SV a0 = sv_scale(pA[0], -1);
+  chol6_solve(&I0, &a0, 1);
+  out->a0 = a0;
+  /* pass 3 */
+  SV acc[NL];
+  acc[0] = a0;
+  for (int l = 1; l < NL; ++l) {
+    int p = BEZ_LINK_PARENT[l];
+    SV ap = sv_add(acc[p], cb[l]);
+    real qdd = (u[l] - sv_dot(U[l], ap)) * Dinv[l];
+    out->qdd[l - 1] = qdd;
+    acc[l] = sv_add(ap, sv_scale(S[l], qdd));
+  }
+  /* contact forces actually applied (implicit part resolved with the link accelerations) */
+  out->ball_lin_acc = v3(0, 0, 0); out->ball_ang_acc = v3(0, 0, 0);
+  if (mode == 0) {
+    for (int i = 0; i < nhit; ++i) {
+      const GroundHit* hh = &hits[i];
+      SV a = acc[hh->link];
+      V3 ap = v3add(sv_lin(a), v3cross(sv_ang(a), hh->x));
+      int body = BEZ_LINK_BODY[hh->link];
+      out->contact_force[body][0] += hh->ftx0 - h * hh->ct * ap.v[0];
+      out->contact_force[body][1] += hh->fty0 - h * hh->ct * ap.v[1];
+      out->contact_force[body][2] += hh->fn0 - hh->kn * ap.v[2];
+    }
+    V3 fl = v3(0, 0, 0); /* force on the link from the ball */
+    if (bl_link >= 0) {
+      SV a = acc[bl_link];
+      V3 ap = v3add(sv_lin(a), v3cross(sv_ang(a), bl_x));
+      fl = v3sub(bl_f0p, m3mulv(&bl_A, ap));
+      int body = BEZ_LINK_BODY[bl_link];
+      for (int i = 0; i < 3; ++i) { out->contact_force[body][i] += fl.v[i]; out->contact_force[BEZ_NBE - 1][i] -= fl.v[i]; }
+    }
+    /* ball: Mb ab = -pb - Jb^T fl */
+    SV rhs = sv_add(sv_scale(pb, -1), sv_scale(wrench_at(bl_xb, fl), -1));
+    M6 Mc = Mb;
+    chol6_solve(&Mc, &rhs, 1);
+    out->ball_ang_acc = sv_ang(rhs); out->ball_lin_acc = sv_lin(rhs);
+    if (ball_ground) {
+      V3 ap = v3add(out->ball_lin_acc, v3cross(out->ball_ang_acc, bhit.x));
+      out->contact_force[BEZ_NBE - 1][0] += bhit.ftx0 - h * bhit.ct * ap.v[0];
+      out->contact_force[BEZ_NBE - 1][1] += bhit.fty0 - h * bhit.ct * ap.v[1];
+      out->contact_force[BEZ_NBE - 1][2] += bhit.fn0 - bhit.kn * ap.v[2];
+    }
+  }
+}
+
+static void quat_integrate(real q[4], const real w[3], real h) {
+  /* q <- normalize(q + h/2 * (w,0) (x) q), xyzw, world-frame angular velocity */
+  real x = q[0], y = q[1], z = q[2], s = q[3];
+  real dx = w[0] * s + w[1] * z - w[2] * y;
+  real dy = -w[0] * z + w[1] * s + w[2] * x;
+  real dz = w[0] * y - w[1] * x + w[2] * s;
+  real dw = -w[0] * x - w[1] * y - w[2] * z;
+  real hh = (real)0.5 * h;
+  x += hh * dx; y += hh * dy; z += hh * dz; s += hh * dw;
+  real n = 1 / sqrt(x * x + y * y + z * z + s * s);
+  q[0] = x * n; q[1] = y * n; q[2] = z * n; q[3] = s * n;
+}
+
+static void substep(const BezSimConfig* c, Env* e, real h) {
+  Dyn d;
+  dynamics(c, e, h, 0, NULL, &d);
+  /* joints: semi-implicit Euler + velocity clamp (kick_env.py:327 velocity limit) */
+  for (int j = 0; j < ND; ++j) {
+    real v = e->qd[j] + h * d.qdd[j];
+    real vl = (real)c->vel_limit;
+    if (v > vl) v = vl;
+    if (v < -vl) v = -vl;
+    e->qd[j] = v;
+    e->q[j] += h * v;
+  }
+  /* root: spatial -> classical acceleration of the torso origin */
+  V3 w = v3(e->root_ang[0], e->root_ang[1], e->root_ang[2]), v = v3(e->root_lin[0], e->root_lin[1], e->root_lin[2]);
+  V3 vdot = v3add(sv_lin(d.a0), v3cross(w, v));
+  V3 wdot = sv_ang(d.a0);
+  for (int i = 0; i < 3; ++i) {
+    e->root_ang[i] += h * wdot.v[i];
+    e->root_lin[i] += h * vdot.v[i];
+    e->root_pos[i] += h * e->root_lin[i];
+  }
+  quat_integrate(e->root_quat, e->root_ang, h);
+  /* ball */
+  real damp = 1 - h * (real)c->ball_ang_damping;
+  if (damp < 0) damp = 0;
+  for (int i = 0; i < 3; ++i) {
+    e->ball_lin[i] += h * d.ball_lin_acc.v[i];
+    e->ball_ang[i] = (e->ball_ang[i] + h * d.ball_ang_acc.v[i]) * damp;
+    e->ball_pos[i] += h * e->ball_lin[i];
+  }
+  quat_integrate(e->ball_quat, e->ball_ang, h);
+  memcpy(e->contact_force, d.contact_force, sizeof(d.contact_force));
+}
+
+/* ------------------------------------------------------------------ env logic (reference restatement) */
+static void env_reset(const BezSimConfig* c, Env* e, int64_t genv) {
+  /* kick_env.py:786-791: q = clamp(default + U(-.15,.15), lo, hi); qd = U(-.1,.1) */
+  for (int j = 0; j < ND; ++j) {
+    float up = reset_uniform(c->seed, genv, e->episode, j);
+    float uv = reset_uniform(c->seed, genv, e->episode, ND + j);
+    float off = 0.3f * up + (-0.15f);
+    float vel = 0.2f * uv + (-0.1f);
+    real q = (real)((float)BEZ_DOF_DEFAULT[j] + off);
+    real lo = (real)(float)BEZ_DOF_LOWER[j], hi = (real)(float)BEZ_DOF_UPPER[j];
+    if (q > hi) q = hi;
+    if (q < lo) q = lo;
+    e->q[j] = q;
+    e->qd[j] = (real)vel;
+    e->target[j] = (real)(float)BEZ_DOF_DEFAULT[j]; /* kick_env.py:839-842 */
+  }
+  e->episode += 1;
+  /* kick_env.py:163-166,831-837: root states <- initial (zero twist) */
+  for (int i = 0; i < 3; ++i) { e->root_pos[i] = c->bez_init[i]; e->ball_pos[i] = c->ball_init[i]; e->root_lin[i] = e->root_ang[i] = e->ball_lin[i] = e->ball_ang[i] = 0; }
+  for (int i = 0; i < 4; ++i) { e->root_quat[i] = c->bez_init[3 + i]; e->ball_quat[i] = c->ball_init[3 + i]; }
+  memset(e->contact_force, 0, sizeof(e->contact_force));
+  e->progress = 0; /* kick_env.py:849-850 */
+  e->reset = 0;
+}
+
+static void env_pre_physics(const BezSimConfig* c, Env* e, const float* act) {
+  /* vec_task.py:317 + kick_env.py:413-418, evaluated in fp32 like the reference */
+  for (int j = 0; j < ND; ++j) {
+    float a = act[j];
+    if (a > c->clip_actions) a = c->clip_actions;
+    if (a < -c->clip_actions) a = -c->clip_actions;
+    if (j < 2) a = 0.0f;
+    float t = a + (float)BEZ_DOF_DEFAULT[j];
+    float lo = (float)BEZ_DOF_LOWER[j], hi = (float)BEZ_DOF_UPPER[j];
+    if (t > hi) t = hi; /* tensor_clamp = max(min(t, upper), lower) */
+    if (t < lo) t = lo;
+    e->target[j] = (real)t;
+  }
+}
+
+/* yaw of get_euler_xyz (isaacgym.torch_utils [ext]), wrapped to [0, 2pi) */
+static real euler_yaw(const real q[4]) {
+  real x = q[0], y = q[1], z = q[2], w = q[3];
+  real siny = 2 * (w * z + x * y), cosy = w * w + x * x - y * y - z * z;
+  real yaw = atan2(siny, cosy);
+  real twopi = (real)6.283185307179586;
+  yaw = fmod(yaw, twopi);
+  if (yaw < 0) yaw += twopi;
+  return yaw;
+}
+
+static void feet_no_cleats(real f[3], real out[4]) {
+  /* kick_env.py:987-990: noise filter written back into the sim tensor */
+  for (int i = 0; i < 3; ++i) if (!(fabs(f[i]) > (real)0.01)) f[i] = 0;
+  /* kick_env.py:993-1006: "sign" codes never test the sign (quirk Q3) */
+  real x = (fabs(f[0]) > 0) ? 1 : 0;
+  if (f[0] == 0) x = 2;
+  real y = (fabs(f[1]) > 0) ? 1 : 3;
+  if (f[1] == 0) y = 3;
+  real sensor = (x == 1) ? 0 : 4;
+  if (x == 2) sensor = 8;
+  real cs = y + sensor;
+  static const real tab[12][4] = {{0}, {1, -1, -1, -1}, {-1, -1, 1, -1}, {1, -1, 1, -1}, {0}, {-1, 1, -1, -1}, {-1, -1, -1, 1},
+                                  {-1, 1, -1, 1}, {0}, {1, 1, -1, -1}, {-1, -1, 1, 1}, {1, 1, 1, 1}};
+  int ci = (int)cs;
+  for (int i = 0; i < 4; ++i) out[i] = -1;
+  if (ci == 1 || ci == 2 || ci == 3 || ci == 5 || ci == 6 || ci == 7 || ci == 9 || ci == 10 || ci == 11)
+    for (int i = 0; i < 4; ++i) out[i] = tab[ci][i];
+  if (f[2] < 1) for (int i = 0; i < 4; ++i) out[i] = -1; /* kick_env.py:1036-1038 */
+}
+
+static void env_observe_reward(const BezSimConfig* c, Env* e) {
+  /* IMU link (body 1) is rigidly at the torso origin with identity offset (soccerbot_stl.urdf:567-572),
+   * so its pose/twist equal the root state. */
+  const real* q = e->root_quat; /* xyzw */
+  real vimu[3] = {e->root_lin[0], e->root_lin[1], e->root_lin[2]};
+  real wimu[3] = {e->root_ang[0], e->root_ang[1], e->root_ang[2]};
+  /* compute_imu, kick_env.py:918-930 */
+  real acc[3];
+  real dt = (real)c->dt;
+  real gunit[3] = {0, 0, -1}; /* kick_env.py:217 */
+  for (int i = 0; i < 3; ++i) {
+    real prev = (c->flags & BEZ_FLAG_IMU_PREV_ALIAS) ? vimu[i] : e->prev_lin_vel[i];
+    acc[i] = (vimu[i] - prev) / dt - gunit[i];
+  }
+  /* quaternion_to_matrix with (r,i,j,k) <- (x,y,z,w): quirk Q2 */
+  real r = q[0], i_ = q[1], j_ = q[2], k_ = q[3];
+  real two_s = 2 / (r * r + i_ * i_ + j_ * j_ + k_ * k_);
+  real Rm[3][3] = {{1 - two_s * (j_ * j_ + k_ * k_), two_s * (i_ * j_ - k_ * r), two_s * (i_ * k_ + j_ * r)},
+                   {two_s * (i_ * j_ + k_ * r), 1 - two_s * (i_ * i_ + k_ * k_), two_s * (j_ * k_ - i_ * r)},
+                   {two_s * (i_ * k_ - j_ * r), two_s * (j_ * k_ + i_ * r), 1 - two_s * (i_ * i_ + j_ * j_)}};
+  real imu[6];
+  for (int a = 0; a < 3; ++a) {
+    real s = Rm[a][0] * acc[0] + Rm[a][1] * acc[1] + Rm[a][2] * acc[2];
+    real lim = (real)(2. * 9.81);
+    imu[a] = s > lim ? lim : (s < -lim ? -lim : s);
+    real wl = (real)8.7266;
+    imu[3 + a] = wimu[a] > wl ? wl : (wimu[a] < -wl ? -wl : wimu[a]);
+  }
+  for (int i = 0; i < 3; ++i) e->prev_lin_vel[i] = vimu[i]; /* kick_env.py:441,930 */
+  /* compute_off_orn, kick_env.py:941-960 */
+  real gx = (real)c->goal[0] - e->root_pos[0], gy = (real)c->goal[1] - e->root_pos[1];
+  real gn = sqrt(gx * gx + gy * gy);
+  real ux = gx / gn, uy = gy / gn;
+  real yaw = euler_yaw(q);
+  real hx = cos(yaw), hy = sin(yaw);
+  real cosv = hx * ux + hy * uy;
+  real sinv = fabs(ux * hy - uy * hx); /* || cross(u3, h3) || : unsigned (quirk Q4) */
+  /* feet, kick_env.py:538-576 */
+  real lf[4], rf[4];
+  feet_no_cleats(e->contact_force[BEZ_LFOOT_BODY], lf);
+  feet_no_cleats(e->contact_force[BEZ_RFOOT_BODY], rf);
+  for (int i = 0; i < 4; ++i) { e->feet[i] = lf[i]; e->feet[4 + i] = rf[i]; }
+  /* compute_bez_observations, kick_env.py:1409-1415 (tail = constant ball_init, quirk Q5) */
+  for (int j = 0; j < ND; ++j) { e->obs[j] = e->q[j]; e->obs[ND + j] = e->qd[j]; }
+  for (int i = 0; i < 6; ++i) e->obs[36 + i] = imu[i];
+  e->obs[42] = sinv; e->obs[43] = -cosv;
+  for (int i = 0; i < 8; ++i) e->obs[44 + i] = e->feet[i];
+  e->obs[52] = c->ball_init[0]; e->obs[53] = c->ball_init[1];
+
+  /* compute_bez_reward, kick_env.py:1224-1391 */
+  real bx = e->ball_pos[0], by = e->ball_pos[1];
+  real dbx = bx - e->root_pos[0], dby = by - e->root_pos[1];
+  real dbn = sqrt(dbx * dbx + dby * dby);
+  real vel_fwd = (dbx / dbn) * vimu[0] + (dby / dbn) * vimu[1];
+  real dgx = (real)c->goal[0] - bx, dgy = (real)c->goal[1] - by;
+  real dgn = sqrt(dgx * dgx + dgy * dgy);
+  real b2gx = dgx / dgn, b2gy = dgy / dgn;
+  real ball_fwd = b2gx * e->ball_lin[0] + b2gy * e->ball_lin[1];
+  real igx = (real)c->goal[0] - (real)c->ball_init[0], igy = (real)c->goal[1] - (real)c->ball_init[1];
+  real ign = sqrt(igx * igx + igy * igy);
+  real ang_now = atan2(b2gy, b2gx), ang_init = atan2(igy / ign, igx / ign);
+  real goal_angle_diff = fabs(ang_init - ang_now);
+  real vn = 0;
+  for (int i = 0; i < 3; ++i) vn += vimu[i] * vimu[i] + wimu[i] * wimu[i];
+  real vel_reward = sqrt(vn);
+  real pn = 0;
+  for (int j = 0; j < ND; ++j) { real d = (real)(float)BEZ_DOF_DEFAULT[j] - e->q[j]; pn += d * d; }
+  real pos_reward = sqrt(pn);
+  real height = fabs((real)0.325 - e->root_pos[2]);
+  real kx = bx - (real)c->ball_init[0], ky = by - (real)c->ball_init[1];
+  real kicked = sqrt(kx * kx + ky * ky);
+  real vel_pos = vel_reward * (real)0.05 + pos_reward * (real)0.05;
+  real height_vel_pos = height * 1 + vel_pos;
+  real r_after = ball_fwd * (real)0.1 - height_vel_pos;
+  real r_before = ball_fwd * (real)0.1 + (vel_fwd * (real)0.05 - height);
+  real reward = kicked > (real)0.3 ? r_after : r_before;
+  int64_t reset = e->reset;
+  if (e->root_pos[2] < (real)0.275) { reset = 1; reward = -1; }
+  real tx = e->root_pos[0] - (real)c->bez_init[0], ty = e->root_pos[1] - (real)c->bez_init[1];
+  if (sqrt(tx * tx + ty * ty) > (real)0.5) { reset = 1; reward = -1; }
+  if (goal_angle_diff > (real)1.5708) { reset = 1; reward = -1; }
+  if (dgn < (real)0.05) { reset = 1; reward = (real)100.0 - (real)100.0 * ((real)e->progress / (real)c->max_episode_length); }
+  if (e->progress >= c->max_episode_length) { reset = 1; reward = 0; }
+  e->rew = reward;
+  e->reset = reset;
+}
+
+static void env_post_physics(const BezSimConfig* c, Env* e, int64_t genv) {
+  e->timeout = (e->progress >= c->max_episode_length - 1) ? 1 : 0; /* vec_task.py:331-332 */
+  e->progress += 1;                                                /* kick_env.py:429 */
+  if (e->reset != 0) env_reset(c, e, genv);                        /* kick_env.py:433-435 */
+  env_observe_reward(c, e);                                        /* kick_env.py:437-438 */
+}
+
+static void env_simulate(const BezSimConfig* c, Env* e) {
+  real h = (real)c->dt / (real)c->substeps;
+  for (int s = 0; s < c->substeps; ++s) substep(c, e, h);
+}
+
+/* ------------------------------------------------------------------ exported API (ctypes) */
+void* bez_oracle_create(const BezSimConfig* cfg) {
+  Oracle* o = (Oracle*)calloc(1, sizeof(Oracle));
+  o->cfg = *cfg;
+  o->n = cfg->num_envs;
+  o->env = (Env*)calloc((size_t)o->n, sizeof(Env));
+  for (int i = 0; i < o->n; ++i) {
+    Env* e = &o->env[i];
+    e->reset = 1; /* vec_task.py:241 */
+    e->friction = cfg->plane_friction;
+    for (int j = 0; j < ND; ++j) { e->kp_scale[j] = 1; e->kd_scale[j] = 1; }
+    for (int l = 0; l < NL; ++l) e->mass_scale[l] = 1;
+    for (int k = 0; k < 3; ++k) e->gravity[k] = cfg->gravity[k];
+    for (int k = 0; k < 8; ++k) e->feet[k] = -1; /* kick_env.py:185 */
+    e->root_quat[3] = 1; e->ball_quat[3] = 1;
+    /* vec_task.py:193 allocate_buffers sets reset_buf = 1, then KickEnv.__init__ ends with
+     * reset_idx(all) (kick_env.py:238) which clears it: the first step() does NOT re-reset. */
+    env_reset(&o->cfg, e, cfg->env_id_offset + i);
+  }
+  return o;
+}
+void bez_oracle_destroy(void* h) { Oracle* o = (Oracle*)h; free(o->env); free(o); }
+int bez_oracle_real_size(void) { return (int)sizeof(real); }
+
+void bez_oracle_get_root_states(void* h, float* out) {
+  Oracle* o = (Oracle*)h;
+  for (int i = 0; i < o->n; ++i) {
+    const Env* e = &o->env[i];
+    float* r = out + (size_t)i * 26;
+    for (int k = 0; k < 3; ++k) { r[k] = (float)e->root_pos[k]; r[7 + k] = (float)e->root_lin[k]; r[10 + k] = (float)e->root_ang[k]; }
+    for (int k = 0; k < 4; ++k) r[3 + k] = (float)e->root_quat[k];
+    r += 13;
+    for (int k = 0; k < 3; ++k) { r[k] = (float)e->ball_pos[k]; r[7 + k] = (float)e->ball_lin[k]; r[10 + k] = (float)e->ball_ang[k]; }
+    for (int k = 0; k < 4; ++k) r[3 + k] = (float)e->ball_quat[k];
+  }
+}
+void bez_oracle_set_root_states(void* h, const float* in) {
+  Oracle* o = (Oracle*)h;
+  for (int i = 0; i < o->n; ++i) {
+    Env* e = &o->env[i];
+    const float* r = in + (size_t)i * 26;
+    for (int k = 0; k < 3; ++k) { e->root_pos[k] = r[k]; e->root_lin[k] = r[7 + k]; e->root_ang[k] = r[10 + k]; }
+    for (int k = 0; k < 4; ++k) e->root_quat[k] = r[3 + k];
+    r += 13;
+    for (int k = 0; k < 3; ++k) { e->ball_pos[k] = r[k]; e->ball_lin[k] = r[7 + k]; e->ball_ang[k] = r[10 + k]; }
+    for (int k = 0; k < 4; ++k) e->ball_quat[k] = r[3 + k];
+  }
+}
+void bez_oracle_get_dof_state(void* h, float* out) {
+  Oracle* o = (Oracle*)h;
+  for (int i = 0; i < o->n; ++i) for (int j = 0; j < ND; ++j) { out[((size_t)i * ND + j) * 2] = (float)o->env[i].q[j]; out[((size_t)i * ND + j) * 2 + 1] = (float)o->env[i].qd[j]; }
+}
+void bez_oracle_set_dof_state(void* h, const float* in) {
+  Oracle* o = (Oracle*)h;
+  for (int i = 0; i < o->n; ++i) for (int j = 0; j < ND; ++j) { o->env[i].q[j] = in[((size_t)i * ND + j) * 2]; o->env[i].qd[j] = in[((size_t)i * ND + j) * 2 + 1]; }
+}
+void bez_oracle_get_targets(void* h, float* out) { Oracle* o = (Oracle*)h; for (int i = 0; i < o->n; ++i) for (int j = 0; j < ND; ++j) out[(size_t)i * ND + j] = (float)o->env[i].target[j]; }
+void bez_oracle_set_targets(void* h, const float* in) { Oracle* o = (Oracle*)h; for (int i = 0; i < o->n; ++i) for (int j = 0; j < ND; ++j) o->env[i].target[j] = in[(size_t)i * ND + j]; }
+void bez_oracle_get_contact_forces(void* h, float* out) {
+  Oracle* o = (Oracle*)h;
+  for (int i = 0; i < o->n; ++i) for (int b = 0; b < BEZ_NBE; ++b) for (int k = 0; k < 3; ++k) out[((size_t)i * BEZ_NBE + b) * 3 + k] = (float)o->env[i].contact_force[b][k];
+}
+void bez_oracle_set_contact_forces(void* h, const float* in) {
+  Oracle* o = (Oracle*)h;
+  for (int i = 0; i < o->n; ++i) for (int b = 0; b < BEZ_NBE; ++b) for (int k = 0; k < 3; ++k) o->env[i].contact_force[b][k] = in[((size_t)i * BEZ_NBE + b) * 3 + k];
+}
+void bez_oracle_get_prev_lin_vel(void* h, float* out) { Oracle* o = (Oracle*)h; for (int i = 0; i < o->n; ++i) for (int k = 0; k < 3; ++k) out[(size_t)i * 3 + k] = (float)o->env[i].prev_lin_vel[k]; }
+void bez_oracle_set_prev_lin_vel(void* h, const float* in) { Oracle* o = (Oracle*)h; for (int i = 0; i < o->n; ++i) for (int k = 0; k < 3; ++k) o->env[i].prev_lin_vel[k] = in[(size_t)i * 3 + k]; }
+void bez_oracle_get_obs(void* h, float* out) { Oracle* o = (Oracle*)h; for (int i = 0; i < o->n; ++i) for (int k = 0; k < BEZ_NUM_OBS; ++k) out[(size_t)i * BEZ_NUM_OBS + k] = (float)o->env[i].obs[k]; }
+void bez_oracle_get_feet(void* h, float* out) { Oracle* o = (Oracle*)h; for (int i = 0; i < o->n; ++i) for (int k = 0; k < 8; ++k) out[(size_t)i * 8 + k] = (float)o->env[i].feet[k]; }
+void bez_oracle_get_rew(void* h, float* out) { Oracle* o = (Oracle*)h; for (int i = 0; i < o->n; ++i) out[i] = (float)o->env[i].rew; }
+void bez_oracle_get_reset(void* h, int64_t* out) { Oracle* o = (Oracle*)h; for (int i = 0; i < o->n; ++i) out[i] = o->env[i].reset; }
+void bez_oracle_set_reset(void* h, const int64_t* in) { Oracle* o = (Oracle*)h; for (int i = 0; i < o->n; ++i) o->env[i].reset = in[i]; }
+void bez_oracle_get_progress(void* h, int64_t* out) { Oracle* o = (Oracle*)h; for (int i = 0; i < o->n; ++i) out[i] = o->env[i].progress; }
+void bez_oracle_set_progress(void* h, const int64_t* in) { Oracle* o = (Oracle*)h; for (int i = 0; i < o->n; ++i) o->env[i].progress = in[i]; }
+void bez_oracle_get_timeout(void* h, int64_t* out) { Oracle* o = (Oracle*)h; for (int i = 0; i < o->n; ++i) out[i] = o->env[i].timeout; }
+void bez_oracle_set_env_params(void* h, int param, const float* v) {
+  Oracle* o = (Oracle*)h;
+  for (int i = 0; i < o->n; ++i) {
+    Env* e = &o->env[i];
+    switch (param) {
+      case BEZ_PARAM_FRICTION: e->friction = v ? v[i] : o->cfg.plane_friction; break;
+      case BEZ_PARAM_KP_SCALE: for (int j = 0; j < ND; ++j) e->kp_scale[j] = v ? v[(size_t)i * ND + j] : 1; break;
+      case BEZ_PARAM_KD_SCALE: for (int j = 0; j < ND; ++j) e->kd_scale[j] = v ? v[(size_t)i * ND + j] : 1; break;
+      case BEZ_PARAM_MASS_SCALE: for (int l = 0; l < NL; ++l) e->mass_scale[l] = v ? v[(size_t)i * NL + l] : 1; break;
+      case BEZ_PARAM_GRAVITY: for (int k = 0; k < 3; ++k) e->gravity[k] = v ? v[(size_t)i * 3 + k] : o->cfg.gravity[k]; break;
+      default: break;
+    }
+  }
+}
+/* rigid body states (N*22,13) by forward kinematics; velocities of body origins, world frame */
+void bez_oracle_get_rigid_body_states(void* h, float* out) {
+  Oracle* o = (Oracle*)h;
+  for (int i = 0; i < o->n; ++i) {
+    const Env* e = &o->env[i];
+    Kin k;
+    forward_kinematics(e, &k);
+    SV V[NL];
+    V[0] = sv(v3(e->root_ang[0], e->root_ang[1], e->root_ang[2]), v3(e->root_lin[0], e->root_lin[1], e->root_lin[2]));
+    for (int l = 1; l < NL; ++l) V[l] = sv_add(V[BEZ_LINK_PARENT[l]], sv_scale(sv(k.a[l], v3cross(k.r[l], k.a[l])), e->qd[l - 1]));
+    for (int b = 0; b < BEZ_NB; ++b) {
+      int l = BEZ_BODY_LINK[b];
+      V3 off = v3((real)BEZ_BODY_OFFSET[b][0], (real)BEZ_BODY_OFFSET[b][1], (real)BEZ_BODY_OFFSET[b][2]);
+      V3 x = v3add(k.r[l], m3mulv(&k.E[l], off));
+      V3 vel = v3add(sv_lin(V[l]), v3cross(sv_ang(V[l]), x));
+      real qq[4];
+      mat_to_quat(&k.E[l], qq);
+      float* r = out + ((size_t)i * BEZ_NBE + b) * 13;
+      for (int a = 0; a < 3; ++a) { r[a] = (float)(e->root_pos[a] + x.v[a]); r[7 + a] = (float)vel.v[a]; r[10 + a] = (float)V[l].v[a]; }
+      for (int a = 0; a < 4; ++a) r[3 + a] = (float)qq[a];
+    }
+    float* r = out + ((size_t)i * BEZ_NBE + BEZ_NB) * 13;
+    for (int a = 0; a < 3; ++a) { r[a] = (float)e->ball_pos[a]; r[7 + a] = (float)e->ball_lin[a]; r[10 + a] = (float)e->ball_ang[a]; }
+    for (int a = 0; a < 4; ++a) r[3 + a] = (float)e->ball_quat[a];
+  }
+}
+
+void bez_oracle_pre_physics(void* h, const float* actions) {
+  Oracle* o = (Oracle*)h;
+  for (int i = 0; i < o->n; ++i) env_pre_physics(&o->cfg, &o->env[i], actions + (size_t)i * ND);
+}
+void bez_oracle_simulate(void* h) {
+  Oracle* o = (Oracle*)h;
+#pragma omp parallel for schedule(static)
+  for (int i = 0; i < o->n; ++i) env_simulate(&o->cfg, &o->env[i]);
+}
+void bez_oracle_post_physics(void* h) {
+  Oracle* o = (Oracle*)h;
+  for (int i = 0; i < o->n; ++i) env_post_physics(&o->cfg, &o->env[i], o->cfg.env_id_offset + i);
+}
+/* obs + reward only (no progress increment / reset handling): golden-vector checks of the jit functions */
+void bez_oracle_observe_reward(void* h) {
+  Oracle* o = (Oracle*)h;
+  for (int i = 0; i < o->n; ++i) env_observe_reward(&o->cfg, &o->env[i]);
+}
+void bez_oracle_step(void* h, const float* actions) {
+  Oracle* o = (Oracle*)h;
+#pragma omp parallel for schedule(static)
+  for (int i = 0; i < o->n; ++i) {
+    Env* e = &o->env[i];
+    env_pre_physics(&o->cfg, e, actions + (size_t)i * ND);
+    env_simulate(&o->cfg, e);
+    env_post_physics(&o->cfg, e, o->cfg.env_id_offset + i);
+  }
+}
+void bez_oracle_reset_idx(void* h, const int32_t* ids, int n) {
+  Oracle* o = (Oracle*)h;
+  for (int k = 0; k < n; ++k) env_reset(&o->cfg, &o->env[ids[k]], o->cfg.env_id_offset + ids[k]);
+}
+void bez_oracle_seed(void* h, uint64_t seed) { ((Oracle*)h)->cfg.seed = seed; }
+
+/* Known-answer hooks: bare dynamics of env 0 in double-precision interface.
+ * mode 1: pure ABA with joint torques tau (no PD, friction, limits, armature, contact).
+ * Outputs the root spatial acceleration about the torso origin (world axes, [ang; lin], spatial not
+ * classical) and joint accelerations. */
+void bez_oracle_forward_dynamics(void* h, int env, int mode, const double* tau, double* a0, double* qdd,
+                                 double* ball_acc6, double* contact_force) {
+  Oracle* o = (Oracle*)h;
+  real t[ND];
+  for (int j = 0; j < ND; ++j) t[j] = tau ? (real)tau[j] : 0;
+  Dyn d;
+  real hstep = (real)o->cfg.dt / (real)o->cfg.substeps;
+  dynamics(&o->cfg, &o->env[env], hstep, mode, t, &d);
+  for (int i = 0; i < 6; ++i) a0[i] = d.a0.v[i];
+  for (int j = 0; j < ND; ++j) qdd[j] = d.qdd[j];
+  if (ball_acc6) for (int i = 0; i < 3; ++i) { ball_acc6[i] = d.ball_ang_acc.v[i]; ball_acc6[3 + i] = d.ball_lin_acc.v[i]; }
+  if (contact_force) for (int b = 0; b < BEZ_NBE; ++b) for (int k = 0; k < 3; ++k) contact_force[b * 3 + k] = d.contact_force[b][k];
+}
+uint32_t bez_oracle_philox_word(uint64_t seed, int64_t genv, uint32_t episode, int k) {
+  uint32_t c[4] = {(uint32_t)genv, (uint32_t)((uint64_t)genv >> 32), episode, (uint32_t)(k >> 2)};
+  philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+  return c[k & 3];
+}
