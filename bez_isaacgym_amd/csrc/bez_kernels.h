@@ -1,0 +1,817 @@
+// bez_kernels.h -- gfx950 device code of the bez_kick hot path: one environment per lane.
+//
+// Replaces, for all envs in ONE launch (include/bez_sim.h: bez_sim_step):
+//   vec_task.py:317 action clamp, kick_env.py:410-419 PD targets, vec_task.py:322-324 gym.simulate
+//   (this build's own articulated-body step), vec_task.py:331-332 timeout, kick_env.py:426-438
+//   post_physics_step incl. reset_idx (kick_env.py:779-850), compute_observations (kick_env.py:749-777)
+//   and compute_bez_reward (kick_env.py:1198-1395).
+//
+// Layout: the simulator state is SoA, state[field * N + env] (coalesced across the 64 lanes of a wave).
+// Per substep each lane runs Featherstone's ABA over the 19-link tree in world-aligned coordinates about
+// the torso origin (no inter-link spatial transforms), chain by chain so that only one chain's link data
+// is live in VGPRs; the per-joint quantities pass 3 needs (U/D, u/D, S, c) and the contact-point records
+// are staged in LDS as lds[slot * BLOCK + lane] (bank = lane: conflict-free).
+#pragma once
+#include <stdint.h>
+
+#include <utility>
+
+#include "../../include/bez_sim.h"
+#include "bez_model_gen.h"
+#include "bez_spatial.h"
+
+namespace bez {
+
+constexpr int BLOCK = 64;  // one wave per workgroup
+
+// ---- SoA state fields (floats per env)
+enum : int {
+  F_ROOT_POS = 0, F_ROOT_QUAT = 3, F_ROOT_LIN = 7, F_ROOT_ANG = 10, F_Q = 13, F_QD = 31,
+  F_BALL_POS = 49, F_BALL_QUAT = 52, F_BALL_LIN = 56, F_BALL_ANG = 59, F_TARGET = 62, F_PREV = 80,
+  F_CF = 83 /* 22 bodies x 3 */, F_FEET = 149, F_COUNT = 157
+};
+
+// ---- LDS slots per lane
+constexpr int P3_STRIDE = 19;                       // UD(6) uD(1) S(6) cb(6) per joint
+constexpr int LDS_P3 = 0;                           // 18 joints
+constexpr int LDS_HIT = LDS_P3 + BEZ_ND * P3_STRIDE;  // ground-point records, 8 floats each
+constexpr int HIT_STRIDE = 8;                       // x(3) fn0 kn ct ftx0 fty0
+constexpr int LDS_SLOTS = LDS_HIT + BEZ_NPT * HIT_STRIDE;
+
+struct Params {
+  int n, substeps, max_len, use_prev, obs_only;
+  float dt, h;
+  float g[3];
+  float kp, kd, armature, effort, vel_limit, jfric, mu, clip;
+  float bez_init[7], ball_init[7], goal[2];
+  float kn, cn, ct, veps, lim_k, lim_d, jf_veps, ball_damp;
+  uint32_t flags;
+  uint64_t seed;
+  int64_t env_off;
+  float* state;
+  float* obs;
+  float* rew;
+  int64_t* reset;
+  int64_t* progress;
+  int64_t* timeout;
+  uint32_t* episode;
+  const float* actions;
+  const float* dr_friction;  // (N)      or null
+  const float* dr_kp;        // (N,18)   or null
+  const float* dr_kd;        // (N,18)   or null
+  const float* dr_mass;      // (N,19)   or null
+  const float* dr_gravity;   // (N,3)    or null
+};
+
+// ---- compile-time model access
+BEZ_DEV constexpr int axis_index(int l) { return (BEZ_LINK_AXIS[l] < 0 ? -BEZ_LINK_AXIS[l] : BEZ_LINK_AXIS[l]) - 1; }
+BEZ_DEV constexpr float axis_sign(int l) { return BEZ_LINK_AXIS[l] < 0 ? -1.f : 1.f; }
+BEZ_DEV constexpr bool link_has_box(int l) {
+  for (int b = 0; b < BEZ_NBOX; ++b) if (BEZ_BOX_LINK[b] == l) return true;
+  return false;
+}
+BEZ_DEV constexpr int link_box(int l) {
+  for (int b = 0; b < BEZ_NBOX; ++b) if (BEZ_BOX_LINK[b] == l) return b;
+  return -1;
+}
+
+// ---- Philox4x32-10, the reset-noise stream (counter = global env id, episode, block)
+BEZ_DEV void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    uint32_t hi0 = __umulhi(0xD2511F53u, c[0]), lo0 = 0xD2511F53u * c[0];
+    uint32_t hi1 = __umulhi(0xCD9E8D57u, c[2]), lo1 = 0xCD9E8D57u * c[2];
+    uint32_t n0 = hi1 ^ c[1] ^ k0, n2 = hi0 ^ c[3] ^ k1;
+    c[0] = n0; c[1] = lo1; c[2] = n2; c[3] = lo0;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+}
+
+// Per-lane working copy of the generalized state
+struct EnvState {
+  V3 root_pos; float rq[4]; V3 root_lin, root_ang;
+  float q[BEZ_ND], qd[BEZ_ND];
+  V3 ball_pos; float bq[4]; V3 ball_lin, ball_ang;
+};
+
+BEZ_DEV void load_state(const float* __restrict__ s, int n, int e, EnvState& S) {
+  auto ld = [&](int f) { return s[(size_t)f * n + e]; };
+  S.root_pos = mk(ld(F_ROOT_POS), ld(F_ROOT_POS + 1), ld(F_ROOT_POS + 2));
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { S.rq[i] = ld(F_ROOT_QUAT + i); S.bq[i] = ld(F_BALL_QUAT + i); }
+  S.root_lin = mk(ld(F_ROOT_LIN), ld(F_ROOT_LIN + 1), ld(F_ROOT_LIN + 2));
+  S.root_ang = mk(ld(F_ROOT_ANG), ld(F_ROOT_ANG + 1), ld(F_ROOT_ANG + 2));
+#pragma unroll
+  for (int j = 0; j < BEZ_ND; ++j) { S.q[j] = ld(F_Q + j); S.qd[j] = ld(F_QD + j); }
+  S.ball_pos = mk(ld(F_BALL_POS), ld(F_BALL_POS + 1), ld(F_BALL_POS + 2));
+  S.ball_lin = mk(ld(F_BALL_LIN), ld(F_BALL_LIN + 1), ld(F_BALL_LIN + 2));
+  S.ball_ang = mk(ld(F_BALL_ANG), ld(F_BALL_ANG + 1), ld(F_BALL_ANG + 2));
+}
+BEZ_DEV void store_state(float* __restrict__ s, int n, int e, const EnvState& S) {
+  auto st = [&](int f, float v) { s[(size_t)f * n + e] = v; };
+  st(F_ROOT_POS, S.root_pos.x); st(F_ROOT_POS + 1, S.root_pos.y); st(F_ROOT_POS + 2, S.root_pos.z);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { st(F_ROOT_QUAT + i, S.rq[i]); st(F_BALL_QUAT + i, S.bq[i]); }
+  st(F_ROOT_LIN, S.root_lin.x); st(F_ROOT_LIN + 1, S.root_lin.y); st(F_ROOT_LIN + 2, S.root_lin.z);
+  st(F_ROOT_ANG, S.root_ang.x); st(F_ROOT_ANG + 1, S.root_ang.y); st(F_ROOT_ANG + 2, S.root_ang.z);
+#pragma unroll
+  for (int j = 0; j < BEZ_ND; ++j) { st(F_Q + j, S.q[j]); st(F_QD + j, S.qd[j]); }
+  st(F_BALL_POS, S.ball_pos.x); st(F_BALL_POS + 1, S.ball_pos.y); st(F_BALL_POS + 2, S.ball_pos.z);
+  st(F_BALL_LIN, S.ball_lin.x); st(F_BALL_LIN + 1, S.ball_lin.y); st(F_BALL_LIN + 2, S.ball_lin.z);
+  st(F_BALL_ANG, S.ball_ang.x); st(F_BALL_ANG + 1, S.ball_ang.y); st(F_BALL_ANG + 2, S.ball_ang.z);
+}
+
+// Per-env model parameters that domain randomisation may change
+struct EnvDyn {
+  float mu;
+  V3 g;
+  float kp_scale[BEZ_ND], kd_scale[BEZ_ND], mass_scale[BEZ_NL];
+};
+
+// ---- contact: implicit spring-damper at a point against the ground plane z = 0.
+// Folds the point's implicit stiffness into (IA, pA) of its body and returns the hit record.
+struct Hit { V3 x; float fn0, kn, ct, ftx0, fty0; };
+BEZ_DEV Hit hit_none() { Hit h; h.x = mk(0, 0, 0); h.fn0 = h.kn = h.ct = h.ftx0 = h.fty0 = 0.f; return h; }
+
+BEZ_DEV Hit ground_contact(const Params& P, float mu, V3 x, float z, SV V, Sym6& IA, SV& pA) {
+  Hit hit = hit_none();
+  float d = -z;
+  if (d > 0.f) {
+    V3 vp = point_of(V, x);
+    float kd = fmaf(P.h, P.kn, P.cn);
+    float fn0 = fmaf(P.kn, d, -kd * vp.z);
+    if (fn0 > 0.f) {
+      float kn = P.h * kd;
+      float vt = sqrtf(fmaf(vp.x, vp.x, vp.y * vp.y));
+      float ct = fminf(mu * fn0 / fmaxf(vt, P.veps), P.ct);
+      float kt = P.h * ct;
+      Sym3 K = sym3zero();
+      K.xx = kt; K.yy = kt; K.zz = kn;
+      add_point_stiffness(IA, x, K);
+      hit.x = x; hit.fn0 = fn0; hit.kn = kn; hit.ct = ct; hit.ftx0 = -ct * vp.x; hit.fty0 = -ct * vp.y;
+      pA = pA - wrench_at(x, mk(hit.ftx0, hit.fty0, fn0));
+    }
+  }
+  return hit;
+}
+BEZ_DEV V3 hit_force(const Params& P, const Hit& h, SV acc) {
+  V3 ap = point_of(acc, h.x);
+  return mk(fmaf(-P.h * h.ct, ap.x, h.ftx0), fmaf(-P.h * h.ct, ap.y, h.fty0), fmaf(-h.kn, ap.z, h.fn0));
+}
+BEZ_DEV void lds_store_hit(float* lds, int lane, int idx, const Hit& h) {
+  float* p = lds + (size_t)(LDS_HIT + idx * HIT_STRIDE) * BLOCK + lane;
+  p[0 * BLOCK] = h.x.x; p[1 * BLOCK] = h.x.y; p[2 * BLOCK] = h.x.z; p[3 * BLOCK] = h.fn0;
+  p[4 * BLOCK] = h.kn; p[5 * BLOCK] = h.ct; p[6 * BLOCK] = h.ftx0; p[7 * BLOCK] = h.fty0;
+}
+BEZ_DEV Hit lds_load_hit(const float* lds, int lane, int idx) {
+  const float* p = lds + (size_t)(LDS_HIT + idx * HIT_STRIDE) * BLOCK + lane;
+  Hit h;
+  h.x = mk(p[0 * BLOCK], p[1 * BLOCK], p[2 * BLOCK]); h.fn0 = p[3 * BLOCK];
+  h.kn = p[4 * BLOCK]; h.ct = p[5 * BLOCK]; h.ftx0 = p[6 * BLOCK]; h.fty0 = p[7 * BLOCK];
+  return h;
+}
+
+// ---- ball <-> leg-box contact bookkeeping (deepest penetration only)
+struct BallSel {
+  int link;      // -1 none
+  float depth;
+  V3 n, P;       // world normal (box -> ball), contact point rel. O
+  // filled when the selected link is visited in pass 1:
+  Sym3 A;        // effective point stiffness seen by the link  (K^-1 + G)^-1
+  V3 f0p;        // explicit force on the link
+  V3 x, xb;      // contact point rel. O / rel. ball centre
+};
+
+// sphere (centre bc rel. O) against box `b` of a link with frame (E, r)
+template <int B>
+BEZ_DEV void test_box(const M3& E, V3 r, V3 bc, BallSel& sel) {
+  constexpr int l = BEZ_BOX_LINK[B];
+  const V3 cl = mk((float)BEZ_BOX_CENTER[B][0], (float)BEZ_BOX_CENTER[B][1], (float)BEZ_BOX_CENTER[B][2]);
+  const V3 he = mk((float)BEZ_BOX_HALF[B][0], (float)BEZ_BOX_HALF[B][1], (float)BEZ_BOX_HALF[B][2]);
+  const float R = (float)BEZ_BALL_RADIUS;
+  V3 ql = mulT(E, bc - r) - cl;
+  V3 cp = mk(fminf(fmaxf(ql.x, -he.x), he.x), fminf(fmaxf(ql.y, -he.y), he.y), fminf(fmaxf(ql.z, -he.z), he.z));
+  bool inside = (cp.x == ql.x) && (cp.y == ql.y) && (cp.z == ql.z);
+  V3 nl; float depth;
+  if (!inside) {
+    V3 dlt = ql - cp;
+    float dist = sqrtf(dot(dlt, dlt));
+    depth = R - dist;
+    if (!(depth > 0.f)) return;
+    nl = dlt * (1.0f / dist);
+  } else {
+    float dx = he.x - fabsf(ql.x), dy = he.y - fabsf(ql.y), dz = he.z - fabsf(ql.z);
+    int ax = 0; float md = dx;
+    if (dy < md) { md = dy; ax = 1; }
+    if (dz < md) { md = dz; ax = 2; }
+    nl = mk(0, 0, 0);
+    if (ax == 0) { nl.x = ql.x >= 0.f ? 1.f : -1.f; cp.x = nl.x * he.x; }
+    else if (ax == 1) { nl.y = ql.y >= 0.f ? 1.f : -1.f; cp.y = nl.y * he.y; }
+    else { nl.z = ql.z >= 0.f ? 1.f : -1.f; cp.z = nl.z * he.z; }
+    depth = R + md;
+  }
+  if (depth > sel.depth) {
+    sel.depth = depth; sel.link = l;
+    sel.n = mul(E, nl);
+    sel.P = r + mul(E, cp + cl);
+  }
+}
+
+// The free ball about its own centre with its (implicit) ground contact folded in: the 6x6 "mass" is
+// block-diagonal in the pairs (wy,vx), (wx,vy) and the scalars wz, vz -> closed-form inverse.
+struct BallBody {
+  float i_wz, i_vz;             // 1/Ib, 1/(m + kn)
+  float a11, a12, a22;          // inverse of [[Ib + kt R^2, -kt R], [-kt R, m + kt]]  (wy, vx)
+  float b11, b12, b22;          // inverse of [[Ib + kt R^2, +kt R], [+kt R, m + kt]]  (wx, vy)
+  SV pb;                        // bias: M a + pb = external
+  Hit ghit; bool ground;
+};
+BEZ_DEV SV ball_minv(const BallBody& B, SV f) {
+  SV a;
+  a.a.z = f.a.z * B.i_wz; a.l.z = f.l.z * B.i_vz;
+  a.a.y = fmaf(B.a11, f.a.y, B.a12 * f.l.x); a.l.x = fmaf(B.a12, f.a.y, B.a22 * f.l.x);
+  a.a.x = fmaf(B.b11, f.a.x, B.b12 * f.l.y); a.l.y = fmaf(B.b12, f.a.x, B.b22 * f.l.y);
+  return a;
+}
+BEZ_DEV BallBody ball_setup(const Params& P, const EnvDyn& D, const EnvState& S) {
+  const float R = (float)BEZ_BALL_RADIUS, mb = (float)BEZ_BALL_MASS, Ib = (float)BEZ_BALL_INERTIA;
+  BallBody B;
+  B.pb = mksv(mk(0, 0, 0), D.g * (-mb));
+  Sym6 dummy = sym6zero();
+  SV Vb = mksv(S.ball_ang, S.ball_lin);
+  B.ghit = ground_contact(P, D.mu, mk(0, 0, -R), S.ball_pos.z - R, Vb, dummy, B.pb);
+  B.ground = B.ghit.kn > 0.f;
+  float kt = P.h * B.ghit.ct, kn = B.ghit.kn;
+  // det = (Ib + kt R^2)(m + kt) - kt^2 R^2 = Ib m + Ib kt + m kt R^2  (expanded: no cancellation)
+  float p = fmaf(kt, R * R, Ib), s = mb + kt, o = kt * R;
+  float idet = 1.0f / fmaf(Ib, mb, fmaf(Ib, kt, mb * kt * R * R));
+  B.a11 = s * idet; B.a22 = p * idet; B.a12 = o * idet;    // inverse of [[p,-o],[-o,s]] = 1/det [[s,o],[o,p]]
+  B.b11 = s * idet; B.b22 = p * idet; B.b12 = -o * idet;   // inverse of [[p, o],[ o,s]] = 1/det [[s,-o],[-o,p]]
+  B.i_wz = 1.0f / Ib; B.i_vz = 1.0f / (mb + kn);
+  return B;
+}
+
+// Evaluate the ball<->link contact when the selected link is reached in pass 1 (needs the link velocity).
+BEZ_DEV void ball_link_contact(const Params& P, const EnvDyn& D, const EnvState& S, const BallBody& B, V3 bc, SV Vl, BallSel& sel) {
+  V3 x = sel.P, xb = sel.P - bc, n = sel.n;
+  SV Vb = mksv(S.ball_ang, S.ball_lin);
+  V3 u = point_of(Vl, x) - point_of(Vb, xb);
+  float un = dot(u, n);
+  float kd = fmaf(P.h, P.kn, P.cn);
+  float fmag = fmaf(P.kn, sel.depth, kd * un);
+  if (!(fmag > 0.f)) { sel.link = -1; return; }
+  V3 ut = u - n * un;
+  float vt = sqrtf(dot(ut, ut));
+  float ct = fminf(D.mu * fmag / fmaxf(vt, P.veps), P.ct);
+  float kn = P.h * kd, kt = P.h * ct;
+  V3 f0 = -(n * fmag + ut * ct);
+  Sym3 K;  // kn nn^T + kt (1 - nn^T)
+  float dk = kn - kt;
+  K.xx = fmaf(dk * n.x, n.x, kt); K.yy = fmaf(dk * n.y, n.y, kt); K.zz = fmaf(dk * n.z, n.z, kt);
+  K.xy = dk * n.x * n.y; K.xz = dk * n.x * n.z; K.yz = dk * n.y * n.z;
+  // G = Jb Mb^-1 Jb^T, gb = Jb Mb^-1 pb with Jb^T e_j = wrench_at(xb, e_j)
+  SV w0 = wrench_at(xb, mk(1, 0, 0)), w1 = wrench_at(xb, mk(0, 1, 0)), w2 = wrench_at(xb, mk(0, 0, 1));
+  SV y0 = ball_minv(B, w0), y1 = ball_minv(B, w1), y2 = ball_minv(B, w2), yp = ball_minv(B, B.pb);
+  M3 G;
+  G.m00 = dot(w0, y0); G.m01 = dot(w0, y1); G.m02 = dot(w0, y2);
+  G.m10 = dot(w1, y0); G.m11 = dot(w1, y1); G.m12 = dot(w1, y2);
+  G.m20 = dot(w2, y0); G.m21 = dot(w2, y1); G.m22 = dot(w2, y2);
+  V3 gb = mk(dot(w0, yp), dot(w1, yp), dot(w2, yp));
+  M3 Km = to_m3(K);
+  M3 KG = matmul(Km, G);
+  KG.m00 += 1.f; KG.m11 += 1.f; KG.m22 += 1.f;
+  M3 inv = inverse(KG);
+  M3 A = matmul(inv, Km);
+  sel.A.xx = A.m00; sel.A.yy = A.m11; sel.A.zz = A.m22;
+  sel.A.xy = 0.5f * (A.m01 + A.m10); sel.A.xz = 0.5f * (A.m02 + A.m20); sel.A.yz = 0.5f * (A.m12 + A.m21);
+  sel.f0p = mul(inv, f0 - mul(Km, gb));
+  sel.x = x; sel.xb = xb;
+}
+
+// ---- one kinematic step down the tree: child frame / joint axis / velocity from the parent's
+template <int L>
+BEZ_DEV void link_kinematics(float q, float qd, M3& E, V3& r, SV& V, SV& S, SV& cb) {
+  constexpr int ax = axis_index(L);
+  constexpr float sg = axis_sign(L);
+  V3 a = col(E, ax) * sg;  // joint axis in world (parent frame column; unchanged by the joint rotation)
+  constexpr float tx = (float)BEZ_LINK_XYZ[L][0], ty = (float)BEZ_LINK_XYZ[L][1], tz = (float)BEZ_LINK_XYZ[L][2];
+  if (tx != 0.f) r = fma3(col(E, 0), tx, r);
+  if (ty != 0.f) r = fma3(col(E, 1), ty, r);
+  if (tz != 0.f) r = fma3(col(E, 2), tz, r);
+  float s, c;
+  sincosf(sg * q, &s, &c);
+  E = rotate_about(E, ax, s, c);
+  S = mksv(a, cross(r, a));
+  SV vj = S * qd;
+  V = V + vj;
+  cb = crm(V, vj);
+}
+template <int L>
+BEZ_DEV void link_frame_only(float q, M3& E, V3& r) {
+  constexpr int ax = axis_index(L);
+  constexpr float sg = axis_sign(L);
+  constexpr float tx = (float)BEZ_LINK_XYZ[L][0], ty = (float)BEZ_LINK_XYZ[L][1], tz = (float)BEZ_LINK_XYZ[L][2];
+  if (tx != 0.f) r = fma3(col(E, 0), tx, r);
+  if (ty != 0.f) r = fma3(col(E, 1), ty, r);
+  if (tz != 0.f) r = fma3(col(E, 2), tz, r);
+  float s, c;
+  sincosf(sg * q, &s, &c);
+  E = rotate_about(E, ax, s, c);
+}
+
+// rigid-body inertia of link L about O in compact form + its bias force (velocity product - gravity)
+struct LinkInertia { float m; V3 h; Sym3 Ibar; };
+template <int L>
+BEZ_DEV void link_inertia(const EnvDyn& D, const M3& E, V3 r, SV V, LinkInertia& I, SV& pA) {
+  const float ms = D.mass_scale[L];
+  const float m = (float)BEZ_LINK_MASS[L] * ms;
+  const V3 cl = mk((float)BEZ_LINK_COM[L][0], (float)BEZ_LINK_COM[L][1], (float)BEZ_LINK_COM[L][2]);
+  Sym3 Il;
+  Il.xx = (float)BEZ_LINK_INERTIA[L][0] * ms; Il.yy = (float)BEZ_LINK_INERTIA[L][1] * ms; Il.zz = (float)BEZ_LINK_INERTIA[L][2] * ms;
+  Il.xy = (float)BEZ_LINK_INERTIA[L][3] * ms; Il.xz = (float)BEZ_LINK_INERTIA[L][4] * ms; Il.yz = (float)BEZ_LINK_INERTIA[L][5] * ms;
+  V3 c = r + mul(E, cl);
+  Sym3 Iw = rotate_inertia(E, Il);
+  float cc = dot(c, c);
+  I.m = m; I.h = c * m;
+  I.Ibar.xx = fmaf(m, cc - c.x * c.x, Iw.xx); I.Ibar.yy = fmaf(m, cc - c.y * c.y, Iw.yy); I.Ibar.zz = fmaf(m, cc - c.z * c.z, Iw.zz);
+  I.Ibar.xy = fmaf(-m * c.x, c.y, Iw.xy); I.Ibar.xz = fmaf(-m * c.x, c.z, Iw.xz); I.Ibar.yz = fmaf(-m * c.y, c.z, Iw.yz);
+  // momentum  I V = [Ibar w + h x v ; m v - h x w]
+  V3 ha = mul(I.Ibar, V.a) + cross(I.h, V.l);
+  V3 hl = V.l * m - cross(I.h, V.a);
+  pA = crf(V, mksv(ha, hl)) - mksv(cross(I.h, D.g), D.g * m);
+}
+BEZ_DEV void add_link_inertia(Sym6& IA, const LinkInertia& I) {
+  add_to(IA.A, I.Ibar);
+  // B += skew(h)
+  IA.B.m01 -= I.h.z; IA.B.m02 += I.h.y; IA.B.m10 += I.h.z; IA.B.m12 -= I.h.x; IA.B.m20 -= I.h.y; IA.B.m21 += I.h.x;
+  IA.C.xx += I.m; IA.C.yy += I.m; IA.C.zz += I.m;
+}
+
+// ground points of link L (compile-time filtered), using the link's frame and velocity
+template <int L>
+BEZ_DEV void link_ground_points(const Params& P, const EnvDyn& D, float root_z, const M3& E, V3 r, SV V, Sym6& IA, SV& pA,
+                                float* lds, int lane, bool keep) {
+#pragma unroll
+  for (int i = 0; i < BEZ_NPT; ++i) {
+    if (BEZ_PT_LINK[i] == L) {
+      V3 pl = mk((float)BEZ_PT_POS[i][0], (float)BEZ_PT_POS[i][1], (float)BEZ_PT_POS[i][2]);
+      V3 x = r + mul(E, pl);
+      Hit hit = ground_contact(P, D.mu, x, root_z + x.z, V, IA, pA);
+      if (keep) lds_store_hit(lds, lane, i, hit);
+    }
+  }
+}
+template <int L>
+BEZ_DEV V3 link_ground_forces(const Params& P, SV acc, const float* lds, int lane) {
+  V3 f = mk(0, 0, 0);
+#pragma unroll
+  for (int i = 0; i < BEZ_NPT; ++i) {
+    if (BEZ_PT_LINK[i] == L) {
+      Hit hit = lds_load_hit(lds, lane, i);
+      if (hit.kn > 0.f) f = f + hit_force(P, hit, acc);
+    }
+  }
+  return f;
+}
+
+// joint drive / friction / limit terms and the ABA joint-space quantities for DOF d = L-1
+template <int L>
+BEZ_DEV void joint_terms(const Params& P, const EnvDyn& D, float q, float qd, float target, const Sym6& IA, SV pA, SV S, SV cb,
+                         SV& U, float& Dinv, float& u) {
+  constexpr int d = L - 1;
+  U = mul(IA, S);
+  float J = dot(S, U) + P.armature;
+  float kp = P.kp * D.kp_scale[d], kdm = P.kd * D.kd_scale[d];
+  float tau_pd0 = fmaf(kp, target - q - P.h * qd, -kdm * qd);
+  float k_pd = fmaf(P.h * P.h, kp, P.h * kdm);
+  float cf = P.jfric / fmaxf(fabsf(qd), P.jf_veps);
+  float k_f = P.h * cf, tau_f0 = -cf * qd;
+  float k_l = 0.f, tau_l0 = 0.f;
+  constexpr float lo = (float)BEZ_DOF_LOWER[d], hi = (float)BEZ_DOF_UPPER[d];
+  if (q < lo) { tau_l0 = fmaf(P.lim_k, lo - q - P.h * qd, -P.lim_d * qd); k_l = fmaf(P.h * P.h, P.lim_k, P.h * P.lim_d); }
+  else if (q > hi) { tau_l0 = fmaf(P.lim_k, hi - q - P.h * qd, -P.lim_d * qd); k_l = fmaf(P.h * P.h, P.lim_k, P.h * P.lim_d); }
+  float sp = dot(S, pA);
+  float bias = sp + dot(U, cb);
+  float qdd_est = (tau_pd0 + tau_f0 + tau_l0 - bias) / (J + k_pd + k_f + k_l);
+  float tau_drive = fmaf(-k_pd, qdd_est, tau_pd0);
+  float tau, Dj;
+  if (tau_drive > P.effort) { tau = P.effort + tau_f0 + tau_l0; Dj = J + k_f + k_l; }
+  else if (tau_drive < -P.effort) { tau = -P.effort + tau_f0 + tau_l0; Dj = J + k_f + k_l; }
+  else { tau = tau_pd0 + tau_f0 + tau_l0; Dj = J + k_pd + k_f + k_l; }
+  Dinv = 1.0f / Dj;
+  u = tau - sp;
+}
+
+// compile-time loop: f(std::integral_constant<int, i>) for i in [0, N)
+template <int... Is, class F>
+BEZ_DEV void static_for_impl(std::integer_sequence<int, Is...>, F&& f) { (f(std::integral_constant<int, Is>{}), ...); }
+template <int N, class F>
+BEZ_DEV void static_for(F&& f) { static_for_impl(std::make_integer_sequence<int, N>{}, f); }
+
+// ---- passes 1+2 of one serial chain FIRST..FIRST+LEN-1 hanging off the torso.  Accumulates the chain's
+// articulated inertia / bias into the torso's (IA0, pA0) and stages pass-3 data in LDS.
+template <int FIRST, int LEN>
+BEZ_DEV void chain_up(const Params& P, const EnvDyn& D, const EnvState& S, const float* target, const M3& E0, SV V0,
+                      const BallBody& ball, V3 bc, BallSel& sel, Sym6& IA0, SV& pA0, float* lds, int lane, bool keep) {
+  LinkInertia LI[LEN];
+  SV pAl[LEN], Sl[LEN], cbl[LEN];
+  M3 E = E0;
+  V3 r = mk(0, 0, 0);
+  SV V = V0;
+  // pass 1: root -> tip
+  static_for<LEN>([&](auto I) {
+    constexpr int i = decltype(I)::value;
+    constexpr int L = FIRST + i;
+    link_kinematics<L>(S.q[L - 1], S.qd[L - 1], E, r, V, Sl[i], cbl[i]);
+    link_inertia<L>(D, E, r, V, LI[i], pAl[i]);
+    if constexpr (link_has_box(L)) {
+      if (sel.link == L) ball_link_contact(P, D, S, ball, bc, V, sel);
+    }
+  });
+  // tip: ground points of the chain-end link (E, r, V are still the tip's)
+  Sym6 IA = sym6zero();
+  SV pA = svzero();
+  link_ground_points<FIRST + LEN - 1>(P, D, S.root_pos.z, E, r, V, IA, pA, lds, lane, keep);
+  // pass 2: tip -> root
+  static_for<LEN>([&](auto I) {
+    constexpr int i = LEN - 1 - decltype(I)::value;
+    constexpr int L = FIRST + i;
+    add_link_inertia(IA, LI[i]);
+    pA = pA + pAl[i];
+    if constexpr (link_has_box(L)) {
+      if (sel.link == L) {
+        add_point_stiffness(IA, sel.x, sel.A);
+        pA = pA - wrench_at(sel.x, sel.f0p);
+      }
+    }
+    SV U; float Dinv, u;
+    joint_terms<L>(P, D, S.q[L - 1], S.qd[L - 1], target[L - 1], IA, pA, Sl[i], cbl[i], U, Dinv, u);
+    SV UD = U * Dinv;
+    float uD = u * Dinv;
+    float* p3 = lds + (size_t)(LDS_P3 + (L - 1) * P3_STRIDE) * BLOCK + lane;
+    p3[0 * BLOCK] = UD.a.x; p3[1 * BLOCK] = UD.a.y; p3[2 * BLOCK] = UD.a.z; p3[3 * BLOCK] = UD.l.x; p3[4 * BLOCK] = UD.l.y; p3[5 * BLOCK] = UD.l.z;
+    p3[6 * BLOCK] = uD;
+    p3[7 * BLOCK] = Sl[i].a.x; p3[8 * BLOCK] = Sl[i].a.y; p3[9 * BLOCK] = Sl[i].a.z; p3[10 * BLOCK] = Sl[i].l.x; p3[11 * BLOCK] = Sl[i].l.y; p3[12 * BLOCK] = Sl[i].l.z;
+    p3[13 * BLOCK] = cbl[i].a.x; p3[14 * BLOCK] = cbl[i].a.y; p3[15 * BLOCK] = cbl[i].a.z; p3[16 * BLOCK] = cbl[i].l.x; p3[17 * BLOCK] = cbl[i].l.y; p3[18 * BLOCK] = cbl[i].l.z;
+    // Ia = IA - U U^T / D ;  pa = pA + Ia c + U u / D
+    add_outer(IA, U, -Dinv);
+    pA = pA + mul(IA, cbl[i]) + U * uD;
+  });
+  add_to(IA0, IA);
+  pA0 = pA0 + pA;
+}
+
+// ---- pass 3 of one chain: joint accelerations from the torso acceleration; integrates the joints in
+// place (semi-implicit Euler + velocity clamp) and resolves contact forces on the way.
+template <int FIRST, int LEN>
+BEZ_DEV void chain_down(const Params& P, EnvState& S, SV a0, BallSel& sel, V3& ball_link_force, float* cf, const float* lds, int lane, bool keep) {
+  SV a = a0;
+  static_for<LEN>([&](auto I) {
+    constexpr int i = decltype(I)::value;
+    constexpr int L = FIRST + i;
+    const float* p3 = lds + (size_t)(LDS_P3 + (L - 1) * P3_STRIDE) * BLOCK + lane;
+    SV UD = mksv(mk(p3[0 * BLOCK], p3[1 * BLOCK], p3[2 * BLOCK]), mk(p3[3 * BLOCK], p3[4 * BLOCK], p3[5 * BLOCK]));
+    float uD = p3[6 * BLOCK];
+    SV Sj = mksv(mk(p3[7 * BLOCK], p3[8 * BLOCK], p3[9 * BLOCK]), mk(p3[10 * BLOCK], p3[11 * BLOCK], p3[12 * BLOCK]));
+    SV cb = mksv(mk(p3[13 * BLOCK], p3[14 * BLOCK], p3[15 * BLOCK]), mk(p3[16 * BLOCK], p3[17 * BLOCK], p3[18 * BLOCK]));
+    SV ap = a + cb;
+    float qdd = uD - dot(UD, ap);
+    a = ap + Sj * qdd;
+    float v = fmaf(P.h, qdd, S.qd[L - 1]);
+    v = fminf(fmaxf(v, -P.vel_limit), P.vel_limit);
+    S.qd[L - 1] = v;
+    S.q[L - 1] = fmaf(P.h, v, S.q[L - 1]);
+    if constexpr (link_has_box(L)) {
+      if (sel.link == L) {
+        ball_link_force = sel.f0p - mul(sel.A, point_of(a, sel.x));
+        if (keep) {
+          constexpr int body = BEZ_LINK_BODY[L];
+          cf[body * 3 + 0] += ball_link_force.x; cf[body * 3 + 1] += ball_link_force.y; cf[body * 3 + 2] += ball_link_force.z;
+        }
+      }
+    }
+  });
+  if (keep) {
+    constexpr int Lend = FIRST + LEN - 1;
+    constexpr int body = BEZ_LINK_BODY[Lend];
+    V3 f = link_ground_forces<Lend>(P, a, lds, lane);
+    cf[body * 3 + 0] += f.x; cf[body * 3 + 1] += f.y; cf[body * 3 + 2] += f.z;
+  }
+}
+
+BEZ_DEV void quat_integrate(float q[4], V3 w, float h) {
+  float x = q[0], y = q[1], z = q[2], s = q[3];
+  float dx = fmaf(w.x, s, fmaf(w.y, z, -w.z * y));
+  float dy = fmaf(-w.x, z, fmaf(w.y, s, w.z * x));
+  float dz = fmaf(w.x, y, fmaf(-w.y, x, w.z * s));
+  float dw = -fmaf(w.x, x, fmaf(w.y, y, w.z * z));
+  float hh = 0.5f * h;
+  x = fmaf(hh, dx, x); y = fmaf(hh, dy, y); z = fmaf(hh, dz, z); s = fmaf(hh, dw, s);
+  float n = 1.0f / sqrtf(fmaf(x, x, fmaf(y, y, fmaf(z, z, s * s))));
+  q[0] = x * n; q[1] = y * n; q[2] = z * n; q[3] = s * n;
+}
+
+// ---- one substep of the articulated-body dynamics for this lane's env.  `cf` (22x3, registers/scratch)
+// receives the net contact force per body when `keep` (last substep only).
+BEZ_DEV void substep(const Params& P, const EnvDyn& D, EnvState& S, const float* target, float* cf, float* lds, int lane, bool keep) {
+  const M3 E0 = quat_to_mat(S.rq[0], S.rq[1], S.rq[2], S.rq[3]);
+  const SV V0 = mksv(S.root_ang, S.root_lin);
+  const V3 bc = S.ball_pos - S.root_pos;  // ball centre rel. O
+  // (a) which leg box, if any, does the ball penetrate deepest?  Frames only.
+  BallSel sel;
+  sel.link = -1; sel.depth = 0.f; sel.n = sel.P = sel.f0p = sel.x = sel.xb = mk(0, 0, 0); sel.A = sym3zero();
+  {
+    M3 E = E0; V3 r = mk(0, 0, 0);
+    static_for<6>([&](auto I) {
+      constexpr int L = 5 + decltype(I)::value;
+      link_frame_only<L>(S.q[L - 1], E, r);
+      if constexpr (link_has_box(L)) test_box<link_box(L)>(E, r, bc, sel);
+    });
+    E = E0; r = mk(0, 0, 0);
+    static_for<6>([&](auto I) {
+      constexpr int L = 13 + decltype(I)::value;
+      link_frame_only<L>(S.q[L - 1], E, r);
+      if constexpr (link_has_box(L)) test_box<link_box(L)>(E, r, bc, sel);
+    });
+  }
+  // (b) ball free body with its ground contact
+  BallBody ball = ball_setup(P, D, S);
+  // (c) torso: own inertia + guard points, then the five chains
+  Sym6 IA0 = sym6zero();
+  SV pA0;
+  {
+    LinkInertia I0;
+    link_inertia<0>(D, E0, mk(0, 0, 0), V0, I0, pA0);
+    add_link_inertia(IA0, I0);
+    link_ground_points<0>(P, D, S.root_pos.z, E0, mk(0, 0, 0), V0, IA0, pA0, lds, lane, keep);
+  }
+  chain_up<1, 2>(P, D, S, target, E0, V0, ball, bc, sel, IA0, pA0, lds, lane, keep);    // neck, head
+  chain_up<3, 2>(P, D, S, target, E0, V0, ball, bc, sel, IA0, pA0, lds, lane, keep);    // left arm
+  chain_up<5, 6>(P, D, S, target, E0, V0, ball, bc, sel, IA0, pA0, lds, lane, keep);    // left leg
+  chain_up<11, 2>(P, D, S, target, E0, V0, ball, bc, sel, IA0, pA0, lds, lane, keep);   // right arm
+  chain_up<13, 6>(P, D, S, target, E0, V0, ball, bc, sel, IA0, pA0, lds, lane, keep);   // right leg
+  // (d) root: I0^A a0 = -p0^A
+  SV a0 = solve_spd6(IA0, svzero() - pA0);
+  // (e) pass 3 + joint integration + contact forces
+  if (keep) {
+#pragma unroll
+    for (int i = 0; i < BEZ_NBE * 3; ++i) cf[i] = 0.f;
+    V3 f = link_ground_forces<0>(P, a0, lds, lane);
+    cf[0] = f.x; cf[1] = f.y; cf[2] = f.z;
+  }
+  V3 fl = mk(0, 0, 0);
+  chain_down<1, 2>(P, S, a0, sel, fl, cf, lds, lane, keep);
+  chain_down<3, 2>(P, S, a0, sel, fl, cf, lds, lane, keep);
+  chain_down<5, 6>(P, S, a0, sel, fl, cf, lds, lane, keep);
+  chain_down<11, 2>(P, S, a0, sel, fl, cf, lds, lane, keep);
+  chain_down<13, 6>(P, S, a0, sel, fl, cf, lds, lane, keep);
+  // (f) ball: Mb ab = -pb - Jb^T fl
+  SV ab = ball_minv(ball, svzero() - ball.pb - wrench_at(sel.xb, fl));
+  if (keep) {
+    float* cb = cf + (BEZ_NBE - 1) * 3;
+    cb[0] -= fl.x; cb[1] -= fl.y; cb[2] -= fl.z;
+    if (ball.ground) { V3 f = hit_force(P, ball.ghit, ab); cb[0] += f.x; cb[1] += f.y; cb[2] += f.z; }
+  }
+  // (g) integrate root (spatial -> classical acceleration of the torso origin) and ball
+  V3 vdot = a0.l + cross(S.root_ang, S.root_lin);
+  S.root_ang = fma3(a0.a, P.h, S.root_ang);
+  S.root_lin = fma3(vdot, P.h, S.root_lin);
+  S.root_pos = fma3(S.root_lin, P.h, S.root_pos);
+  quat_integrate(S.rq, S.root_ang, P.h);
+  float damp = fmaxf(1.0f - P.h * P.ball_damp, 0.f);
+  S.ball_lin = fma3(ab.l, P.h, S.ball_lin);
+  S.ball_ang = fma3(ab.a, P.h, S.ball_ang) * damp;
+  S.ball_pos = fma3(S.ball_lin, P.h, S.ball_pos);
+  quat_integrate(S.bq, S.ball_ang, P.h);
+}
+
+// ---- env logic ---------------------------------------------------------------------------------------
+
+// kick_env.py:779-850 for this lane's env
+BEZ_DEV void env_reset(const Params& P, EnvState& S, float* target, float* cf, uint32_t& episode, int64_t genv) {
+  uint32_t k0 = (uint32_t)P.seed, k1 = (uint32_t)(P.seed >> 32);
+  float u[36];
+#pragma unroll
+  for (int b = 0; b < 9; ++b) {
+    uint32_t c[4] = {(uint32_t)genv, (uint32_t)((uint64_t)genv >> 32), episode, (uint32_t)b};
+    philox4x32_10(c, k0, k1);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) u[b * 4 + k] = (float)(c[k] >> 8) * (1.0f / 16777216.0f);
+  }
+#pragma unroll
+  for (int j = 0; j < BEZ_ND; ++j) {
+    float off = 0.3f * u[j] + (-0.15f);
+    float vel = 0.2f * u[BEZ_ND + j] + (-0.1f);
+    float q = (float)BEZ_DOF_DEFAULT[j] + off;
+    q = fmaxf(fminf(q, (float)BEZ_DOF_UPPER[j]), (float)BEZ_DOF_LOWER[j]);
+    S.q[j] = q; S.qd[j] = vel;
+    target[j] = (float)BEZ_DOF_DEFAULT[j];
+  }
+  episode += 1;
+  S.root_pos = mk(P.bez_init[0], P.bez_init[1], P.bez_init[2]);
+  S.ball_pos = mk(P.ball_init[0], P.ball_init[1], P.ball_init[2]);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { S.rq[i] = P.bez_init[3 + i]; S.bq[i] = P.ball_init[3 + i]; }
+  S.root_lin = S.root_ang = S.ball_lin = S.ball_ang = mk(0, 0, 0);
+#pragma unroll
+  for (int i = 0; i < BEZ_NBE * 3; ++i) cf[i] = 0.f;
+}
+
+// vec_task.py:317 + kick_env.py:413-418
+BEZ_DEV void env_targets(const Params& P, const float* __restrict__ act, float* target) {
+#pragma unroll
+  for (int j = 0; j < BEZ_ND; ++j) {
+    float a = fminf(fmaxf(act[j], -P.clip), P.clip);
+    if (j < 2) a = 0.f;
+    float t = a + (float)BEZ_DOF_DEFAULT[j];
+    target[j] = fmaxf(fminf(t, (float)BEZ_DOF_UPPER[j]), (float)BEZ_DOF_LOWER[j]);
+  }
+}
+
+// kick_env.py:966-1040 on one foot's net contact force (mutated in place like the reference does)
+BEZ_DEV void feet_no_cleats(float* f, float* out) {
+#pragma unroll
+  for (int i = 0; i < 3; ++i) if (!(fabsf(f[i]) > 0.01f)) f[i] = 0.f;
+  float x = (fabsf(f[0]) > 0.f) ? 1.f : 0.f;
+  if (f[0] == 0.f) x = 2.f;
+  float y = (fabsf(f[1]) > 0.f) ? 1.f : 3.f;
+  if (f[1] == 0.f) y = 3.f;
+  float sensor = (x == 1.f) ? 0.f : 4.f;
+  if (x == 2.f) sensor = 8.f;
+  float cs = y + sensor;
+  float o0 = -1.f, o1 = -1.f, o2 = -1.f, o3 = -1.f;
+  if (cs == 1.f) { o0 = 1.f; }
+  else if (cs == 3.f) { o0 = 1.f; o2 = 1.f; }
+  else if (cs == 5.f) { o1 = 1.f; }
+  else if (cs == 7.f) { o1 = 1.f; o3 = 1.f; }
+  else if (cs == 9.f) { o0 = 1.f; o1 = 1.f; }
+  else if (cs == 11.f) { o0 = o1 = o2 = o3 = 1.f; }
+  if (f[2] < 1.f) { o0 = o1 = o2 = o3 = -1.f; }
+  out[0] = o0; out[1] = o1; out[2] = o2; out[3] = o3;
+}
+
+// compute_observations + compute_reward (kick_env.py:749-777, 724-747) for this lane's env.
+BEZ_DEV void env_observe_reward(const Params& P, const EnvState& S, float* cf, float* prev, float* feet, float* obs,
+                                float& rew, int64_t& reset, int64_t progress) {
+  // IMU link = torso origin frame (soccerbot_stl.urdf:567-572)
+  V3 v = S.root_lin, w = S.root_ang;
+  // compute_imu (kick_env.py:918-930), quaternion_to_matrix fed xyzw as (r,i,j,k) (quirk Q2)
+  float pvx = P.use_prev ? prev[0] : v.x, pvy = P.use_prev ? prev[1] : v.y, pvz = P.use_prev ? prev[2] : v.z;
+  float ax = (v.x - pvx) / P.dt - 0.f, ay = (v.y - pvy) / P.dt - 0.f, az = (v.z - pvz) / P.dt - (-1.f);
+  float r = S.rq[0], i_ = S.rq[1], j_ = S.rq[2], k_ = S.rq[3];
+  float two_s = 2.0f / (r * r + i_ * i_ + j_ * j_ + k_ * k_);
+  float m00 = 1.f - two_s * (j_ * j_ + k_ * k_), m01 = two_s * (i_ * j_ - k_ * r), m02 = two_s * (i_ * k_ + j_ * r);
+  float m10 = two_s * (i_ * j_ + k_ * r), m11 = 1.f - two_s * (i_ * i_ + k_ * k_), m12 = two_s * (j_ * k_ - i_ * r);
+  float m20 = two_s * (i_ * k_ - j_ * r), m21 = two_s * (j_ * k_ + i_ * r), m22 = 1.f - two_s * (i_ * i_ + j_ * j_);
+  const float LIN = (float)(2. * 9.81), ANG = 8.7266f;
+  float imu[6];
+  imu[0] = fminf(fmaxf(m00 * ax + m01 * ay + m02 * az, -LIN), LIN);
+  imu[1] = fminf(fmaxf(m10 * ax + m11 * ay + m12 * az, -LIN), LIN);
+  imu[2] = fminf(fmaxf(m20 * ax + m21 * ay + m22 * az, -LIN), LIN);
+  imu[3] = fminf(fmaxf(w.x, -ANG), ANG); imu[4] = fminf(fmaxf(w.y, -ANG), ANG); imu[5] = fminf(fmaxf(w.z, -ANG), ANG);
+  prev[0] = v.x; prev[1] = v.y; prev[2] = v.z;
+  // compute_off_orn (kick_env.py:941-960)
+  float gx = P.goal[0] - S.root_pos.x, gy = P.goal[1] - S.root_pos.y;
+  float gn = sqrtf(gx * gx + gy * gy);
+  float ux = gx / gn, uy = gy / gn;
+  float qx = S.rq[0], qy = S.rq[1], qz = S.rq[2], qw = S.rq[3];
+  float yaw = atan2f(2.0f * (qw * qz + qx * qy), qw * qw + qx * qx - qy * qy - qz * qz);
+  const float TWO_PI = 6.283185307179586f;
+  yaw = yaw - TWO_PI * floorf(yaw / TWO_PI);  // python-style % (2 pi)
+  float hs, hc;
+  sincosf(yaw, &hs, &hc);
+  float cosv = hc * ux + hs * uy;
+  float sinv = fabsf(ux * hs - uy * hc);
+  // feet (kick_env.py:538-576)
+  feet_no_cleats(cf + BEZ_LFOOT_BODY * 3, feet);
+  feet_no_cleats(cf + BEZ_RFOOT_BODY * 3, feet + 4);
+  // observation row (kick_env.py:1409-1415)
+#pragma unroll
+  for (int j = 0; j < BEZ_ND; ++j) { obs[j] = S.q[j]; obs[BEZ_ND + j] = S.qd[j]; }
+#pragma unroll
+  for (int i = 0; i < 6; ++i) obs[36 + i] = imu[i];
+  obs[42] = sinv; obs[43] = -cosv;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) obs[44 + i] = feet[i];
+  obs[52] = P.ball_init[0]; obs[53] = P.ball_init[1];
+  // compute_bez_reward (kick_env.py:1224-1391)
+  float bx = S.ball_pos.x, by = S.ball_pos.y;
+  float dbx = bx - S.root_pos.x, dby = by - S.root_pos.y;
+  float dbn = sqrtf(dbx * dbx + dby * dby);
+  float vel_fwd = (dbx / dbn) * v.x + (dby / dbn) * v.y;
+  float dgx = P.goal[0] - bx, dgy = P.goal[1] - by;
+  float dgn = sqrtf(dgx * dgx + dgy * dgy);
+  float b2gx = dgx / dgn, b2gy = dgy / dgn;
+  float ball_fwd = b2gx * S.ball_lin.x + b2gy * S.ball_lin.y;
+  float igx = P.goal[0] - P.ball_init[0], igy = P.goal[1] - P.ball_init[1];
+  float ign = sqrtf(igx * igx + igy * igy);
+  float goal_angle_diff = fabsf(atan2f(igy / ign, igx / ign) - atan2f(b2gy, b2gx));
+  float vel_reward = sqrtf(dot(v, v) + dot(w, w));
+  float pn = 0.f;
+#pragma unroll
+  for (int j = 0; j < BEZ_ND; ++j) { float d = (float)BEZ_DOF_DEFAULT[j] - S.q[j]; pn = fmaf(d, d, pn); }
+  float pos_reward = sqrtf(pn);
+  float height = fabsf(0.325f - S.root_pos.z);
+  float kx = bx - P.ball_init[0], ky = by - P.ball_init[1];
+  float kicked = sqrtf(kx * kx + ky * ky);
+  float height_vel_pos = height + (vel_reward * 0.05f + pos_reward * 0.05f);
+  float r_after = ball_fwd * 0.1f - height_vel_pos;
+  float r_before = ball_fwd * 0.1f + (vel_fwd * 0.05f - height);
+  float reward = kicked > 0.3f ? r_after : r_before;
+  if (S.root_pos.z < 0.275f) { reset = 1; reward = -1.f; }
+  float tx = S.root_pos.x - P.bez_init[0], ty = S.root_pos.y - P.bez_init[1];
+  if (sqrtf(tx * tx + ty * ty) > 0.5f) { reset = 1; reward = -1.f; }
+  if (goal_angle_diff > 1.5708f) { reset = 1; reward = -1.f; }
+  if (dgn < 0.05f) { reset = 1; reward = 100.0f - 100.0f * ((float)progress / (float)P.max_len); }
+  if (progress >= (int64_t)P.max_len) { reset = 1; reward = 0.f; }
+  rew = reward;
+}
+
+// ---- the fused kernel: PRE (targets) / SIM (substeps) / POST (bookkeeping, reset, obs, reward)
+template <bool PRE, bool SIM, bool POST, bool DR>
+__global__ __launch_bounds__(BLOCK) void step_kernel(Params P) {
+  __shared__ float lds[SIM ? LDS_SLOTS * BLOCK : 1];
+  const int lane = threadIdx.x;
+  const int e = blockIdx.x * BLOCK + lane;
+  if (e >= P.n) return;
+  const int n = P.n;
+  float* st = P.state;
+  EnvState S;
+  load_state(st, n, e, S);
+  float target[BEZ_ND];
+  if (PRE) {
+    float act[BEZ_ND];
+#pragma unroll
+    for (int j = 0; j < BEZ_ND; ++j) act[j] = P.actions[(size_t)e * BEZ_ND + j];
+    env_targets(P, act, target);
+    if (!SIM) {
+#pragma unroll
+      for (int j = 0; j < BEZ_ND; ++j) st[(size_t)(F_TARGET + j) * n + e] = target[j];
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < BEZ_ND; ++j) target[j] = st[(size_t)(F_TARGET + j) * n + e];
+  }
+  float cf[BEZ_NBE * 3];
+  if (SIM) {
+    EnvDyn D;
+    D.mu = P.mu; D.g = mk(P.g[0], P.g[1], P.g[2]);
+#pragma unroll
+    for (int j = 0; j < BEZ_ND; ++j) { D.kp_scale[j] = 1.f; D.kd_scale[j] = 1.f; }
+#pragma unroll
+    for (int l = 0; l < BEZ_NL; ++l) D.mass_scale[l] = 1.f;
+    if (DR) {
+      if (P.dr_friction) D.mu = P.dr_friction[e];
+      if (P.dr_gravity) D.g = mk(P.dr_gravity[(size_t)e * 3], P.dr_gravity[(size_t)e * 3 + 1], P.dr_gravity[(size_t)e * 3 + 2]);
+      if (P.dr_kp) {
+#pragma unroll
+        for (int j = 0; j < BEZ_ND; ++j) D.kp_scale[j] = P.dr_kp[(size_t)e * BEZ_ND + j];
+      }
+      if (P.dr_kd) {
+#pragma unroll
+        for (int j = 0; j < BEZ_ND; ++j) D.kd_scale[j] = P.dr_kd[(size_t)e * BEZ_ND + j];
+      }
+      if (P.dr_mass) {
+#pragma unroll
+        for (int l = 0; l < BEZ_NL; ++l) D.mass_scale[l] = P.dr_mass[(size_t)e * BEZ_NL + l];
+      }
+    }
+    for (int s = 0; s < P.substeps; ++s) substep(P, D, S, target, cf, lds, lane, s == P.substeps - 1);
+  } else if (POST) {
+#pragma unroll
+    for (int i = 0; i < BEZ_NBE * 3; ++i) cf[i] = st[(size_t)(F_CF + i) * n + e];
+  }
+  if (POST) {
+    int64_t progress = P.progress[e], reset = P.reset[e];
+    uint32_t episode = P.episode[e];
+    if (!P.obs_only) {
+      P.timeout[e] = (progress >= (int64_t)(P.max_len - 1)) ? 1 : 0;  // vec_task.py:331-332
+      progress += 1;                                                  // kick_env.py:429
+      if (reset != 0) {                                               // kick_env.py:433-435
+        env_reset(P, S, target, cf, episode, P.env_off + e);
+        progress = 0; reset = 0;
+        P.episode[e] = episode;
+      }
+    }
+    float prev[3], feet[8], obs[BEZ_NUM_OBS], rew;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) prev[i] = st[(size_t)(F_PREV + i) * n + e];
+    env_observe_reward(P, S, cf, prev, feet, obs, rew, reset, progress);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) st[(size_t)(F_PREV + i) * n + e] = prev[i];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) st[(size_t)(F_FEET + i) * n + e] = feet[i];
+#pragma unroll
+    for (int i = 0; i < BEZ_NUM_OBS; ++i) P.obs[(size_t)e * BEZ_NUM_OBS + i] = obs[i];
+    P.rew[e] = rew; P.reset[e] = reset; P.progress[e] = progress;
+  }
+  if (SIM || POST) {
+    store_state(st, n, e, S);
+#pragma unroll
+    for (int i = 0; i < BEZ_NBE * 3; ++i) st[(size_t)(F_CF + i) * n + e] = cf[i];
+#pragma unroll
+    for (int j = 0; j < BEZ_ND; ++j) st[(size_t)(F_TARGET + j) * n + e] = target[j];
+  }
+}
+
+}  // namespace bez

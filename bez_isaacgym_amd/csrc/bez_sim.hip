@@ -1,0 +1,485 @@
+// bez_sim.hip -- host side of the C ABI declared in include/bez_sim.h (libbez_sim.so) plus the small
+// layout kernels (Isaac AoS tensors <-> the simulator's SoA state).  gfx950 only.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+
+#include "bez_kernels.h"
+
+using namespace bez;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t bytes = 0;
+};
+
+}  // namespace
+
+struct BezSim {
+  BezSimConfig cfg;
+  int device = 0;
+  int n = 0;
+  int64_t obs_calls = 0;  // compute_observations passes so far (quirk Q1: only the first sees prev = zeros)
+  std::string err;
+  // sim-owned device memory
+  float* state = nullptr;       // SoA [F_COUNT][N]
+  float* obs = nullptr;         // (N,54)
+  float* rew = nullptr;         // (N)
+  int64_t* reset = nullptr;     // (N)
+  int64_t* progress = nullptr;  // (N)
+  int64_t* timeout = nullptr;   // (N)
+  uint32_t* episode = nullptr;  // (N)
+  // Isaac-layout tensors, materialised by bez_sim_refresh_tensor
+  float* root_states = nullptr;  // (N*2,13)
+  float* dof_state = nullptr;    // (N*18,2)
+  float* rigid_body = nullptr;   // (N*22,13)
+  float* contact = nullptr;      // (N*22,3)
+  float* targets_aos = nullptr;  // (N,18)
+  float* prev_aos = nullptr;     // (N,3)
+  float* feet_aos = nullptr;     // (N,8)
+  float* dr[BEZ_PARAM_COUNT] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+
+namespace {
+
+int fail(BezSim* s, int code, const char* what, hipError_t e = hipSuccess) {
+  char buf[512];
+  if (e != hipSuccess) snprintf(buf, sizeof(buf), "%s: %s", what, hipGetErrorString(e));
+  else snprintf(buf, sizeof(buf), "%s", what);
+  if (s) s->err = buf; else g_create_error = buf;
+  return code;
+}
+#define HIP_TRY(s, call)                                              \
+  do {                                                                \
+    hipError_t _e = (call);                                           \
+    if (_e != hipSuccess) return fail((s), -2, #call, _e);            \
+  } while (0)
+
+Params make_params(const BezSim* s, const float* actions) {
+  const BezSimConfig& c = s->cfg;
+  Params P;
+  std::memset(&P, 0, sizeof(P));
+  P.n = s->n; P.substeps = c.substeps; P.max_len = c.max_episode_length;
+  P.use_prev = (!(c.flags & BEZ_FLAG_IMU_PREV_ALIAS) || s->obs_calls == 0) ? 1 : 0;
+  P.dt = c.dt; P.h = c.dt / (float)c.substeps;
+  for (int i = 0; i < 3; ++i) P.g[i] = c.gravity[i];
+  P.kp = c.kp; P.kd = c.kd; P.armature = c.armature; P.effort = c.effort; P.vel_limit = c.vel_limit;
+  P.jfric = c.joint_friction; P.mu = c.plane_friction; P.clip = c.clip_actions;
+  for (int i = 0; i < 7; ++i) { P.bez_init[i] = c.bez_init[i]; P.ball_init[i] = c.ball_init[i]; }
+  P.goal[0] = c.goal[0]; P.goal[1] = c.goal[1];
+  P.kn = c.contact_kn; P.cn = c.contact_cn; P.ct = c.contact_ct; P.veps = c.contact_veps;
+  P.lim_k = c.limit_k; P.lim_d = c.limit_d; P.jf_veps = c.jfric_veps; P.ball_damp = c.ball_ang_damping;
+  P.flags = c.flags; P.seed = c.seed; P.env_off = c.env_id_offset;
+  P.state = s->state; P.obs = s->obs; P.rew = s->rew; P.reset = s->reset; P.progress = s->progress;
+  P.timeout = s->timeout; P.episode = s->episode; P.actions = actions;
+  P.dr_friction = s->dr[BEZ_PARAM_FRICTION]; P.dr_kp = s->dr[BEZ_PARAM_KP_SCALE]; P.dr_kd = s->dr[BEZ_PARAM_KD_SCALE];
+  P.dr_mass = s->dr[BEZ_PARAM_MASS_SCALE]; P.dr_gravity = s->dr[BEZ_PARAM_GRAVITY];
+  return P;
+}
+bool has_dr(const BezSim* s) {
+  for (int i = 0; i < BEZ_PARAM_COUNT; ++i) if (s->dr[i]) return true;
+  return false;
+}
+int grid_for(int n) { return (n + BLOCK - 1) / BLOCK; }
+
+// ---------------------------------------------------------------- layout kernels
+constexpr int TB = 256;
+
+// KickEnv.reset_idx for listed envs (or all when ids == nullptr)
+__global__ void reset_kernel(Params P, const int32_t* ids, int count) {
+  int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= count) return;
+  int e = ids ? ids[t] : t;
+  if (e < 0 || e >= P.n) return;
+  EnvState S;
+  float target[BEZ_ND], cf[BEZ_NBE * 3];
+  uint32_t episode = P.episode[e];
+  env_reset(P, S, target, cf, episode, P.env_off + e);
+  P.episode[e] = episode;
+  store_state(P.state, P.n, e, S);
+  for (int j = 0; j < BEZ_ND; ++j) P.state[(size_t)(F_TARGET + j) * P.n + e] = target[j];
+  for (int i = 0; i < BEZ_NBE * 3; ++i) P.state[(size_t)(F_CF + i) * P.n + e] = 0.f;
+  P.progress[e] = 0;  // kick_env.py:849-850
+  P.reset[e] = 0;
+}
+
+__global__ void init_misc_kernel(float* state, int n) {
+  int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n) return;
+  for (int i = 0; i < 3; ++i) state[(size_t)(F_PREV + i) * n + e] = 0.f;  // kick_env.py:183
+  for (int i = 0; i < 8; ++i) state[(size_t)(F_FEET + i) * n + e] = -1.f; // kick_env.py:185
+}
+
+__global__ void refresh_root_kernel(const float* __restrict__ st, float* __restrict__ out, int n) {
+  int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n * 26) return;
+  int e = t / 26, k = t % 26;
+  int f = (k < 13) ? (F_ROOT_POS + k) : (F_BALL_POS + (k - 13));
+  out[t] = st[(size_t)f * n + e];
+}
+__global__ void refresh_dof_kernel(const float* __restrict__ st, float* __restrict__ out, int n) {
+  int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n * BEZ_ND * 2) return;
+  int e = t / (BEZ_ND * 2), k = t % (BEZ_ND * 2);
+  int j = k >> 1;
+  out[t] = st[(size_t)((k & 1) ? (F_QD + j) : (F_Q + j)) * n + e];
+}
+__global__ void refresh_rows_kernel(const float* __restrict__ st, float* __restrict__ out, int n, int field0, int width) {
+  int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n * width) return;
+  int e = t / width, k = t % width;
+  out[t] = st[(size_t)(field0 + k) * n + e];
+}
+__global__ void scatter_rows_kernel(float* __restrict__ st, const float* __restrict__ in, int n, int field0, int width) {
+  int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n * width) return;
+  int e = t / width, k = t % width;
+  st[(size_t)(field0 + k) * n + e] = in[t];
+}
+
+BEZ_DEV void mat_to_quat(const M3& R, float q[4]) {
+  float tr = R.m00 + R.m11 + R.m22;
+  if (tr > 0.f) {
+    float s = sqrtf(tr + 1.f) * 2.f;
+    q[3] = 0.25f * s; q[0] = (R.m21 - R.m12) / s; q[1] = (R.m02 - R.m20) / s; q[2] = (R.m10 - R.m01) / s;
+  } else if (R.m00 > R.m11 && R.m00 > R.m22) {
+    float s = sqrtf(1.f + R.m00 - R.m11 - R.m22) * 2.f;
+    q[3] = (R.m21 - R.m12) / s; q[0] = 0.25f * s; q[1] = (R.m01 + R.m10) / s; q[2] = (R.m02 + R.m20) / s;
+  } else if (R.m11 > R.m22) {
+    float s = sqrtf(1.f + R.m11 - R.m00 - R.m22) * 2.f;
+    q[3] = (R.m02 - R.m20) / s; q[0] = (R.m01 + R.m10) / s; q[1] = 0.25f * s; q[2] = (R.m12 + R.m21) / s;
+  } else {
+    float s = sqrtf(1.f + R.m22 - R.m00 - R.m11) * 2.f;
+    q[3] = (R.m10 - R.m01) / s; q[0] = (R.m02 + R.m20) / s; q[1] = (R.m12 + R.m21) / s; q[2] = 0.25f * s;
+  }
+}
+
+// gym.refresh_rigid_body_state_tensor: forward kinematics of all 21 robot bodies + the ball row
+__global__ void refresh_rigid_body_kernel(const float* __restrict__ st, float* __restrict__ out, int n) {
+  int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n) return;
+  EnvState S;
+  load_state(st, n, e, S);
+  M3 E[BEZ_NL]; V3 r[BEZ_NL]; SV V[BEZ_NL];
+  E[0] = quat_to_mat(S.rq[0], S.rq[1], S.rq[2], S.rq[3]);
+  r[0] = mk(0, 0, 0);
+  V[0] = mksv(S.root_ang, S.root_lin);
+  static_for<BEZ_NL - 1>([&](auto I) {
+    constexpr int L = 1 + decltype(I)::value;
+    constexpr int p = BEZ_LINK_PARENT[L];
+    E[L] = E[p]; r[L] = r[p]; V[L] = V[p];
+    SV Sj, cb;
+    link_kinematics<L>(S.q[L - 1], S.qd[L - 1], E[L], r[L], V[L], Sj, cb);
+  });
+  static_for<BEZ_NB>([&](auto I) {
+    constexpr int b = decltype(I)::value;
+    constexpr int l = BEZ_BODY_LINK[b];
+    V3 off = mk((float)BEZ_BODY_OFFSET[b][0], (float)BEZ_BODY_OFFSET[b][1], (float)BEZ_BODY_OFFSET[b][2]);
+    V3 x = r[l] + mul(E[l], off);
+    V3 vel = point_of(V[l], x);
+    float q[4];
+    mat_to_quat(E[l], q);
+    float* o = out + ((size_t)e * BEZ_NBE + b) * 13;
+    o[0] = S.root_pos.x + x.x; o[1] = S.root_pos.y + x.y; o[2] = S.root_pos.z + x.z;
+    o[3] = q[0]; o[4] = q[1]; o[5] = q[2]; o[6] = q[3];
+    o[7] = vel.x; o[8] = vel.y; o[9] = vel.z; o[10] = V[l].a.x; o[11] = V[l].a.y; o[12] = V[l].a.z;
+  });
+  float* o = out + ((size_t)e * BEZ_NBE + BEZ_NB) * 13;
+  o[0] = S.ball_pos.x; o[1] = S.ball_pos.y; o[2] = S.ball_pos.z;
+  o[3] = S.bq[0]; o[4] = S.bq[1]; o[5] = S.bq[2]; o[6] = S.bq[3];
+  o[7] = S.ball_lin.x; o[8] = S.ball_lin.y; o[9] = S.ball_lin.z; o[10] = S.ball_ang.x; o[11] = S.ball_ang.y; o[12] = S.ball_ang.z;
+}
+
+// gym.set_actor_root_state_tensor_indexed
+__global__ void set_root_indexed_kernel(float* __restrict__ st, const float* __restrict__ src, const int32_t* __restrict__ ids, int count, int n) {
+  int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= count * 13) return;
+  int a = ids[t / 13], k = t % 13;
+  if (a < 0 || a >= n * 2) return;
+  int e = a >> 1;
+  int f = (a & 1) ? (F_BALL_POS + k) : (F_ROOT_POS + k);
+  st[(size_t)f * n + e] = src[(size_t)a * 13 + k];
+}
+// gym.set_dof_state_tensor_indexed (actor ids of robot actors: env*2)
+__global__ void set_dof_indexed_kernel(float* __restrict__ st, const float* __restrict__ src, const int32_t* __restrict__ ids, int count, int n) {
+  int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= count * BEZ_ND * 2) return;
+  int a = ids[t / (BEZ_ND * 2)], k = t % (BEZ_ND * 2);
+  if (a < 0 || a >= n * 2 || (a & 1)) return;
+  int e = a >> 1, j = k >> 1;
+  st[(size_t)((k & 1) ? (F_QD + j) : (F_Q + j)) * n + e] = src[((size_t)e * BEZ_ND + j) * 2 + (k & 1)];
+}
+__global__ void set_target_indexed_kernel(float* __restrict__ st, const float* __restrict__ src, const int32_t* __restrict__ ids, int count, int n) {
+  int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= count * BEZ_ND) return;
+  int a = ids[t / BEZ_ND], j = t % BEZ_ND;
+  if (a < 0 || a >= n * 2 || (a & 1)) return;
+  int e = a >> 1;
+  st[(size_t)(F_TARGET + j) * n + e] = src[(size_t)e * BEZ_ND + j];
+}
+
+template <bool PRE, bool SIM, bool POST>
+int launch_step(BezSim* s, const float* actions, hipStream_t stream) {
+  Params P = make_params(s, actions);
+  dim3 grid(grid_for(s->n)), block(BLOCK);
+  if (has_dr(s)) hipLaunchKernelGGL((step_kernel<PRE, SIM, POST, true>), grid, block, 0, stream, P);
+  else hipLaunchKernelGGL((step_kernel<PRE, SIM, POST, false>), grid, block, 0, stream, P);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(s, -2, "step kernel launch", e);
+  if (POST) s->obs_calls += 1;
+  return 0;
+}
+
+}  // namespace
+
+// =============================================================================================== C ABI
+extern "C" {
+
+int bez_sim_default_config(BezSimConfig* c, int32_t num_envs) {
+  if (!c) return -1;
+  std::memset(c, 0, sizeof(*c));
+  c->abi_version = BEZ_SIM_ABI_VERSION;
+  c->num_envs = num_envs;
+  c->substeps = BEZ_DEFAULT_SUBSTEPS;
+  c->dt = (float)BEZ_DEFAULT_DT;
+  c->max_episode_length = (int32_t)(BEZ_DEFAULT_EPISODE_LENGTH_S / BEZ_DEFAULT_DT + 0.5);
+  for (int i = 0; i < 3; ++i) c->gravity[i] = (float)BEZ_DEFAULT_GRAVITY[i];
+  c->kp = (float)BEZ_DEFAULT_KP; c->kd = (float)BEZ_DEFAULT_KD; c->armature = (float)BEZ_DEFAULT_ARMATURE;
+  c->effort = (float)BEZ_DEFAULT_EFFORT; c->vel_limit = (float)BEZ_DEFAULT_VEL_LIMIT;
+  c->joint_friction = (float)BEZ_DEFAULT_JOINT_FRICTION; c->plane_friction = (float)BEZ_DEFAULT_PLANE_FRICTION;
+  c->clip_actions = (float)BEZ_DEFAULT_CLIP_ACTIONS;
+  for (int i = 0; i < 7; ++i) { c->bez_init[i] = (float)BEZ_DEFAULT_BEZ_INIT[i]; c->ball_init[i] = (float)BEZ_DEFAULT_BALL_INIT[i]; }
+  c->goal[0] = (float)BEZ_DEFAULT_GOAL[0]; c->goal[1] = (float)BEZ_DEFAULT_GOAL[1];
+  c->contact_kn = 2.0e4f; c->contact_cn = 20.0f; c->contact_ct = 1.0e3f; c->contact_veps = 0.01f;
+  c->limit_k = 200.0f; c->limit_d = 2.0f; c->jfric_veps = 0.1f; c->ball_ang_damping = 0.5f;
+  c->flags = BEZ_FLAG_IMU_PREV_ALIAS;
+  c->seed = 42;
+  c->env_id_offset = 0;
+  return 0;
+}
+
+const char* bez_sim_last_error(const BezSim* sim) { return sim ? sim->err.c_str() : g_create_error.c_str(); }
+
+int bez_sim_destroy(BezSim* s) {
+  if (!s) return 0;
+  (void)hipSetDevice(s->device);
+  void* bufs[] = {s->state, s->obs, s->rew, s->reset, s->progress, s->timeout, s->episode, s->root_states, s->dof_state,
+                  s->rigid_body, s->contact, s->targets_aos, s->prev_aos, s->feet_aos};
+  for (void* b : bufs) if (b) (void)hipFree(b);
+  for (int i = 0; i < BEZ_PARAM_COUNT; ++i) if (s->dr[i]) (void)hipFree(s->dr[i]);
+  if (s->ev0) (void)hipEventDestroy(s->ev0);
+  if (s->ev1) (void)hipEventDestroy(s->ev1);
+  delete s;
+  return 0;
+}
+
+int bez_sim_create(const BezSimConfig* cfg, int device_id, BezSim** out) {
+  if (!cfg || !out) return fail(nullptr, -1, "bez_sim_create: null argument");
+  *out = nullptr;
+  if (cfg->abi_version != BEZ_SIM_ABI_VERSION) return fail(nullptr, -1, "bez_sim_create: BezSimConfig.abi_version mismatch");
+  if (cfg->num_envs <= 0) return fail(nullptr, -1, "bez_sim_create: num_envs must be > 0");
+  if (cfg->substeps <= 0 || !(cfg->dt > 0.f)) return fail(nullptr, -1, "bez_sim_create: substeps and dt must be > 0");
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev <= 0) return fail(nullptr, -3, "bez_sim_create: no HIP device available (the HIP path has no CPU fallback)", e);
+  if (device_id < 0 || device_id >= ndev) return fail(nullptr, -1, "bez_sim_create: bad device id");
+  e = hipSetDevice(device_id);
+  if (e != hipSuccess) return fail(nullptr, -2, "hipSetDevice", e);
+  BezSim* s = new (std::nothrow) BezSim();
+  if (!s) return fail(nullptr, -4, "out of host memory");
+  s->cfg = *cfg; s->device = device_id; s->n = cfg->num_envs;
+  const size_t n = (size_t)s->n;
+  struct { void** p; size_t bytes; } allocs[] = {
+      {(void**)&s->state, n * F_COUNT * sizeof(float)}, {(void**)&s->obs, n * BEZ_NUM_OBS * sizeof(float)},
+      {(void**)&s->rew, n * sizeof(float)}, {(void**)&s->reset, n * sizeof(int64_t)}, {(void**)&s->progress, n * sizeof(int64_t)},
+      {(void**)&s->timeout, n * sizeof(int64_t)}, {(void**)&s->episode, n * sizeof(uint32_t)},
+      {(void**)&s->root_states, n * 26 * sizeof(float)}, {(void**)&s->dof_state, n * BEZ_ND * 2 * sizeof(float)},
+      {(void**)&s->rigid_body, n * BEZ_NBE * 13 * sizeof(float)}, {(void**)&s->contact, n * BEZ_NBE * 3 * sizeof(float)},
+      {(void**)&s->targets_aos, n * BEZ_ND * sizeof(float)}, {(void**)&s->prev_aos, n * 3 * sizeof(float)},
+      {(void**)&s->feet_aos, n * 8 * sizeof(float)}};
+  for (auto& a : allocs) {
+    e = hipMalloc(a.p, a.bytes);
+    if (e == hipSuccess) e = hipMemset(*a.p, 0, a.bytes);
+    if (e != hipSuccess) { int rc = fail(nullptr, -4, "hipMalloc", e); bez_sim_destroy(s); return rc; }
+  }
+  (void)hipEventCreate(&s->ev0);
+  (void)hipEventCreate(&s->ev1);
+  // state after KickEnv.__init__: allocate_buffers (vec_task.py:226-249) then reset_idx(all) (kick_env.py:238)
+  Params P = make_params(s, nullptr);
+  hipLaunchKernelGGL(init_misc_kernel, dim3((s->n + TB - 1) / TB), dim3(TB), 0, 0, s->state, s->n);
+  hipLaunchKernelGGL(reset_kernel, dim3((s->n + TB - 1) / TB), dim3(TB), 0, 0, P, (const int32_t*)nullptr, s->n);
+  e = hipDeviceSynchronize();
+  if (e != hipSuccess) { int rc = fail(nullptr, -2, "init kernels", e); bez_sim_destroy(s); return rc; }
+  *out = s;
+  return 0;
+}
+
+int bez_sim_get_tensor(BezSim* s, int which, void** dev_ptr, int64_t shape[3], int* ndim, int* dtype) {
+  if (!s || !dev_ptr || !shape || !ndim || !dtype) return fail(s, -1, "bez_sim_get_tensor: null argument");
+  const int64_t n = s->n;
+  *dtype = BEZ_DTYPE_F32;
+  switch (which) {
+    case BEZ_TENSOR_ROOT_STATE: *dev_ptr = s->root_states; shape[0] = n * 2; shape[1] = 13; *ndim = 2; break;
+    case BEZ_TENSOR_DOF_STATE: *dev_ptr = s->dof_state; shape[0] = n * BEZ_ND; shape[1] = 2; *ndim = 2; break;
+    case BEZ_TENSOR_RIGID_BODY_STATE: *dev_ptr = s->rigid_body; shape[0] = n * BEZ_NBE; shape[1] = 13; *ndim = 2; break;
+    case BEZ_TENSOR_NET_CONTACT_FORCE: *dev_ptr = s->contact; shape[0] = n * BEZ_NBE; shape[1] = 3; *ndim = 2; break;
+    case BEZ_TENSOR_OBS: *dev_ptr = s->obs; shape[0] = n; shape[1] = BEZ_NUM_OBS; *ndim = 2; break;
+    case BEZ_TENSOR_REW: *dev_ptr = s->rew; shape[0] = n; *ndim = 1; break;
+    case BEZ_TENSOR_RESET: *dev_ptr = s->reset; shape[0] = n; *ndim = 1; *dtype = BEZ_DTYPE_I64; break;
+    case BEZ_TENSOR_PROGRESS: *dev_ptr = s->progress; shape[0] = n; *ndim = 1; *dtype = BEZ_DTYPE_I64; break;
+    case BEZ_TENSOR_TIMEOUT: *dev_ptr = s->timeout; shape[0] = n; *ndim = 1; *dtype = BEZ_DTYPE_I64; break;
+    case BEZ_TENSOR_DOF_TARGET: *dev_ptr = s->targets_aos; shape[0] = n; shape[1] = BEZ_ND; *ndim = 2; break;
+    case BEZ_TENSOR_PREV_LIN_VEL: *dev_ptr = s->prev_aos; shape[0] = n; shape[1] = 3; *ndim = 2; break;
+    case BEZ_TENSOR_FEET: *dev_ptr = s->feet_aos; shape[0] = n; shape[1] = 8; *ndim = 2; break;
+    default: return fail(s, -1, "bez_sim_get_tensor: unknown tensor id");
+  }
+  return 0;
+}
+
+int bez_sim_refresh_tensor(BezSim* s, int which, void* stream_) {
+  if (!s) return -1;
+  hipStream_t stream = (hipStream_t)stream_;
+  const int n = s->n;
+  auto blocks = [](size_t total) { return dim3((unsigned)((total + TB - 1) / TB)); };
+  switch (which) {
+    case BEZ_TENSOR_ROOT_STATE: hipLaunchKernelGGL(refresh_root_kernel, blocks((size_t)n * 26), dim3(TB), 0, stream, s->state, s->root_states, n); break;
+    case BEZ_TENSOR_DOF_STATE: hipLaunchKernelGGL(refresh_dof_kernel, blocks((size_t)n * BEZ_ND * 2), dim3(TB), 0, stream, s->state, s->dof_state, n); break;
+    case BEZ_TENSOR_RIGID_BODY_STATE: hipLaunchKernelGGL(refresh_rigid_body_kernel, dim3((n + 63) / 64), dim3(64), 0, stream, s->state, s->rigid_body, n); break;
+    case BEZ_TENSOR_NET_CONTACT_FORCE: hipLaunchKernelGGL(refresh_rows_kernel, blocks((size_t)n * BEZ_NBE * 3), dim3(TB), 0, stream, s->state, s->contact, n, (int)F_CF, BEZ_NBE * 3); break;
+    case BEZ_TENSOR_DOF_TARGET: hipLaunchKernelGGL(refresh_rows_kernel, blocks((size_t)n * BEZ_ND), dim3(TB), 0, stream, s->state, s->targets_aos, n, (int)F_TARGET, BEZ_ND); break;
+    case BEZ_TENSOR_PREV_LIN_VEL: hipLaunchKernelGGL(refresh_rows_kernel, blocks((size_t)n * 3), dim3(TB), 0, stream, s->state, s->prev_aos, n, (int)F_PREV, 3); break;
+    case BEZ_TENSOR_FEET: hipLaunchKernelGGL(refresh_rows_kernel, blocks((size_t)n * 8), dim3(TB), 0, stream, s->state, s->feet_aos, n, (int)F_FEET, 8); break;
+    case BEZ_TENSOR_OBS: case BEZ_TENSOR_REW: case BEZ_TENSOR_RESET: case BEZ_TENSOR_PROGRESS: case BEZ_TENSOR_TIMEOUT: break;  // always live
+    default: return fail(s, -1, "bez_sim_refresh_tensor: unknown tensor id");
+  }
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(s, -2, "refresh kernel launch", e);
+  return 0;
+}
+
+int bez_sim_set_actor_root_state_tensor_indexed(BezSim* s, const float* root_states_dev, const int32_t* ids, int32_t count, void* stream) {
+  if (!s || !root_states_dev || (!ids && count > 0) || count < 0) return fail(s, -1, "set_actor_root_state_tensor_indexed: bad argument");
+  if (count == 0) return 0;
+  hipLaunchKernelGGL(set_root_indexed_kernel, dim3(((size_t)count * 13 + TB - 1) / TB), dim3(TB), 0, (hipStream_t)stream, s->state, root_states_dev, ids, count, s->n);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : fail(s, -2, "set_root_indexed launch", e);
+}
+int bez_sim_set_dof_state_tensor_indexed(BezSim* s, const float* dof_state_dev, const int32_t* ids, int32_t count, void* stream) {
+  if (!s || !dof_state_dev || (!ids && count > 0) || count < 0) return fail(s, -1, "set_dof_state_tensor_indexed: bad argument");
+  if (count == 0) return 0;
+  hipLaunchKernelGGL(set_dof_indexed_kernel, dim3(((size_t)count * BEZ_ND * 2 + TB - 1) / TB), dim3(TB), 0, (hipStream_t)stream, s->state, dof_state_dev, ids, count, s->n);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : fail(s, -2, "set_dof_indexed launch", e);
+}
+int bez_sim_set_dof_position_target_tensor(BezSim* s, const float* targets_dev, void* stream) {
+  if (!s || !targets_dev) return fail(s, -1, "set_dof_position_target_tensor: bad argument");
+  hipLaunchKernelGGL(scatter_rows_kernel, dim3(((size_t)s->n * BEZ_ND + TB - 1) / TB), dim3(TB), 0, (hipStream_t)stream, s->state, targets_dev, s->n, (int)F_TARGET, BEZ_ND);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : fail(s, -2, "set_target launch", e);
+}
+int bez_sim_set_dof_position_target_tensor_indexed(BezSim* s, const float* targets_dev, const int32_t* ids, int32_t count, void* stream) {
+  if (!s || !targets_dev || (!ids && count > 0) || count < 0) return fail(s, -1, "set_dof_position_target_tensor_indexed: bad argument");
+  if (count == 0) return 0;
+  hipLaunchKernelGGL(set_target_indexed_kernel, dim3(((size_t)count * BEZ_ND + TB - 1) / TB), dim3(TB), 0, (hipStream_t)stream, s->state, targets_dev, ids, count, s->n);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : fail(s, -2, "set_target_indexed launch", e);
+}
+int bez_sim_set_net_contact_force_tensor(BezSim* s, const float* forces_dev, void* stream) {
+  if (!s || !forces_dev) return fail(s, -1, "set_net_contact_force_tensor: bad argument");
+  hipLaunchKernelGGL(scatter_rows_kernel, dim3(((size_t)s->n * BEZ_NBE * 3 + TB - 1) / TB), dim3(TB), 0, (hipStream_t)stream, s->state, forces_dev, s->n, (int)F_CF, BEZ_NBE * 3);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : fail(s, -2, "set_contact launch", e);
+}
+/* test hook used by the parity tests: writes prev_lin_vel (N,3) */
+int bez_sim_set_prev_lin_vel_tensor(BezSim* s, const float* prev_dev, void* stream) {
+  if (!s || !prev_dev) return fail(s, -1, "set_prev_lin_vel_tensor: bad argument");
+  hipLaunchKernelGGL(scatter_rows_kernel, dim3(((size_t)s->n * 3 + TB - 1) / TB), dim3(TB), 0, (hipStream_t)stream, s->state, prev_dev, s->n, (int)F_PREV, 3);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : fail(s, -2, "set_prev launch", e);
+}
+int bez_sim_set_flags(BezSim* s, uint32_t flags) { if (!s) return -1; s->cfg.flags = flags; return 0; }
+int bez_sim_set_obs_calls(BezSim* s, int64_t calls) { if (!s) return -1; s->obs_calls = calls; return 0; }
+
+int bez_sim_pre_physics(BezSim* s, const float* actions_dev, void* stream) {
+  if (!s || !actions_dev) return fail(s, -1, "bez_sim_pre_physics: bad argument");
+  return launch_step<true, false, false>(s, actions_dev, (hipStream_t)stream);
+}
+int bez_sim_simulate(BezSim* s, void* stream) {
+  if (!s) return -1;
+  return launch_step<false, true, false>(s, nullptr, (hipStream_t)stream);
+}
+int bez_sim_post_physics(BezSim* s, void* stream) {
+  if (!s) return -1;
+  return launch_step<false, false, true>(s, nullptr, (hipStream_t)stream);
+}
+/* test hook: compute_observations + compute_reward only (no timeout/progress/reset bookkeeping) */
+int bez_sim_observe_reward(BezSim* s, void* stream) {
+  if (!s) return -1;
+  Params P = make_params(s, nullptr);
+  P.obs_only = 1;
+  hipLaunchKernelGGL((step_kernel<false, false, true, false>), dim3(grid_for(s->n)), dim3(BLOCK), 0, (hipStream_t)stream, P);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(s, -2, "observe kernel launch", e);
+  s->obs_calls += 1;
+  return 0;
+}
+int bez_sim_step(BezSim* s, const float* actions_dev, void* stream) {
+  if (!s || !actions_dev) return fail(s, -1, "bez_sim_step: bad argument");
+  return launch_step<true, true, true>(s, actions_dev, (hipStream_t)stream);
+}
+int bez_sim_step_many(BezSim* s, const float* actions_dev, int32_t n_steps, void* stream) {
+  if (!s || !actions_dev || n_steps < 0) return fail(s, -1, "bez_sim_step_many: bad argument");
+  for (int32_t t = 0; t < n_steps; ++t) {
+    int rc = launch_step<true, true, true>(s, actions_dev + (size_t)t * s->n * BEZ_ND, (hipStream_t)stream);
+    if (rc) return rc;
+  }
+  return 0;
+}
+int bez_sim_time_steps(BezSim* s, const float* actions_dev, int32_t n_steps, void* stream_, float* avg_ms) {
+  if (!s || !actions_dev || n_steps <= 0 || !avg_ms) return fail(s, -1, "bez_sim_time_steps: bad argument");
+  hipStream_t stream = (hipStream_t)stream_;
+  HIP_TRY(s, hipEventRecord(s->ev0, stream));
+  int rc = bez_sim_step_many(s, actions_dev, n_steps, stream_);
+  if (rc) return rc;
+  HIP_TRY(s, hipEventRecord(s->ev1, stream));
+  HIP_TRY(s, hipEventSynchronize(s->ev1));
+  float ms = 0.f;
+  HIP_TRY(s, hipEventElapsedTime(&ms, s->ev0, s->ev1));
+  *avg_ms = ms / (float)n_steps;
+  return 0;
+}
+
+int bez_sim_reset_indexed(BezSim* s, const int32_t* env_ids_dev, int32_t count, void* stream) {
+  if (!s || (!env_ids_dev && count > 0) || count < 0) return fail(s, -1, "bez_sim_reset_indexed: bad argument");
+  if (count == 0) return 0;
+  Params P = make_params(s, nullptr);
+  hipLaunchKernelGGL(reset_kernel, dim3((count + TB - 1) / TB), dim3(TB), 0, (hipStream_t)stream, P, env_ids_dev, count);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : fail(s, -2, "reset launch", e);
+}
+
+int bez_sim_set_env_params(BezSim* s, int param, const float* values_dev, void* stream) {
+  if (!s || param < 0 || param >= BEZ_PARAM_COUNT) return fail(s, -1, "bez_sim_set_env_params: bad argument");
+  static const int width[BEZ_PARAM_COUNT] = {1, BEZ_ND, BEZ_ND, BEZ_NL, 3};
+  if (!values_dev) {
+    if (s->dr[param]) { HIP_TRY(s, hipStreamSynchronize((hipStream_t)stream)); (void)hipFree(s->dr[param]); s->dr[param] = nullptr; }
+    return 0;
+  }
+  size_t bytes = (size_t)s->n * width[param] * sizeof(float);
+  if (!s->dr[param]) HIP_TRY(s, hipMalloc((void**)&s->dr[param], bytes));
+  HIP_TRY(s, hipMemcpyAsync(s->dr[param], values_dev, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  return 0;
+}
+
+int bez_sim_seed(BezSim* s, uint64_t seed) { if (!s) return -1; s->cfg.seed = seed; return 0; }
+
+}  // extern "C"

@@ -187,7 +187,9 @@ def build():
     for li, d in enumerate(dyn):
         if d["box"] is not None and min(d["box"]["half"]) > 1e-3:
             boxes.append({"link": li, "center": d["box"]["center"], "half": d["box"]["half"]})
-    # ground contact points: foot box bottom corners + guard points on other bodies.
+    # ground contact points: foot box bottom corners + guard points on the torso and on the other
+    # chain-end links (head, forearms).  Mid-chain links carry no ground points: an episode ends at
+    # torso z < 0.275 (kick_env.py:1331) long before a knee could reach the floor.
     # Upper-body meshes are approximated by bounding-box corners measured from the .dae vertex data
     # (torso x[-.040,.064] y[+-.0725] z[-.128,.062]; head z top .062; forearm tip z -.131).
     points = []
@@ -210,10 +212,6 @@ def build():
             add("/head", [hc[0] + sx, hc[1] + sy, hc[2] + 0.0619], "guard")
     for side, sgn in (("left", 1.0), ("right", -1.0)):
         add("/%s_forearm" % side, [-0.0055 - 0.005, sgn * (0.005 + 0.0245), -0.131], "guard")
-        cb = links["/%s_calve" % side]["box"]
-        for sx in (+1, -1):  # knee: top edge of the calve box
-            add("/%s_calve" % side, [cb["center"][0] + sx * cb["half"][0], cb["center"][1],
-                                     cb["center"][2] + cb["half"][2]], "guard")
 
     ball = ball_links["base_link"]
     model = {
@@ -261,8 +259,7 @@ def emit_header(m):
              " * Flat model constants for the Bez humanoid as bez_kick loads it (soccerbot_stl.urdf,\n"
              " * ball.urdf, bez_kick.yaml).  Pure data: shared by the HIP kernels and the C oracle. */")
     o.append("#ifndef BEZ_MODEL_GEN_H\n#define BEZ_MODEL_GEN_H")
-    o.append("#if defined(__HIPCC__)\n#define BEZ_TBL static __device__ __host__ constexpr\n"
-             "#elif defined(__cplusplus)\n#define BEZ_TBL static constexpr\n#else\n#define BEZ_TBL static const\n#endif")
+    o.append("#if defined(__cplusplus)\n#define BEZ_TBL static constexpr\n#else\n#define BEZ_TBL static const\n#endif")
     o.append("#define BEZ_NB 21      /* robot rigid bodies, Isaac order */")
     o.append("#define BEZ_NBE 22     /* bodies per env incl. ball */")
     o.append("#define BEZ_NL 19      /* dynamic links (fixed children merged) */")
@@ -294,7 +291,7 @@ def emit_header(m):
     o.append("BEZ_TBL int BEZ_BOX_LINK[BEZ_NBOX] = {%s};" % ", ".join(str(b["link"]) for b in m["boxes"]))
     o.append("BEZ_TBL double BEZ_BOX_CENTER[BEZ_NBOX][3] = {%s};" % ", ".join(arr(b["center"]) for b in m["boxes"]))
     o.append("BEZ_TBL double BEZ_BOX_HALF[BEZ_NBOX][3] = {%s};" % ", ".join(arr(b["half"]) for b in m["boxes"]))
-    o.append("/* ground contact points (link-local); the first 8 are the foot-box bottom corners (4 left, 4 right) */")
+    o.append("/* ground contact points (link-local), only on the torso and on chain-end links; the first 8 are the foot-box bottom corners (4 left, 4 right) */")
     o.append("BEZ_TBL int BEZ_PT_LINK[BEZ_NPT] = {%s};" % ", ".join(str(p["link"]) for p in m["ground_points"]))
     o.append("BEZ_TBL double BEZ_PT_POS[BEZ_NPT][3] = {%s};" % ", ".join(arr(p["p"]) for p in m["ground_points"]))
     o.append("#define BEZ_BALL_MASS %s\n#define BEZ_BALL_INERTIA %s\n#define BEZ_BALL_RADIUS %s" % (

@@ -1,0 +1,256 @@
+"""Env / VecTask base classes with the reference's public surface (bez_isaacgym/tasks/base/vec_task.py),
+re-implemented over the HIP simulator: there is no gymapi, `gym.simulate` is libbez_sim.so.
+
+Kept from the reference: constructor signature (vec_task.py:51,150), device parsing (:61-73), spaces
+(:92-95), buffer names/dtypes/initial values (:226-249), step()/reset() return contract (:303-377),
+zero_actions (:351-359), get_state (:287-289), properties (:122-145), domain-randomisation entry point
+apply_randomizations (:505-725, here: per-env parameter arrays pushed to the kernel).
+"""
+import abc
+from typing import Any, Dict, Tuple
+
+import numpy as np
+import torch
+
+
+class Box:
+    """Minimal stand-in for gym.spaces.Box (gym is not a dependency): low/high/shape/dtype."""
+
+    def __init__(self, low, high, dtype=np.float32):
+        self.low = np.asarray(low, dtype=dtype)
+        self.high = np.asarray(high, dtype=dtype)
+        self.shape = self.low.shape
+        self.dtype = np.dtype(dtype)
+
+    def __repr__(self):
+        return "Box(%s, %s, %s, %s)" % (self.low.min(), self.high.max(), self.shape, self.dtype)
+
+
+class Env(abc.ABC):
+    def __init__(self, config: Dict[str, Any], sim_device: str, graphics_device_id: int, headless: bool):
+        split_device = sim_device.split(":")
+        self.device_type = split_device[0]
+        self.device_id = int(split_device[1]) if len(split_device) > 1 else 0
+
+        # vec_task.py:65-71.  This build has no CPU pipeline: the simulator is HIP-only.
+        self.device = "cpu"
+        if config["sim"]["use_gpu_pipeline"]:
+            if self.device_type.lower() in ("cuda", "gpu"):
+                self.device = "cuda" + ":" + str(self.device_id)
+            else:
+                print("GPU Pipeline can only be used with GPU simulation. Forcing CPU Pipeline.")
+                config["sim"]["use_gpu_pipeline"] = False
+
+        self.rl_device = config.get("rl_device", "cuda:0")
+        self.headless = headless
+        self.graphics_device_id = graphics_device_id
+        if not config.get("enableCameraSensors", False) and self.headless:
+            self.graphics_device_id = -1
+
+        self.num_environments = config["env"]["numEnvs"]
+        self.num_agents = config["env"].get("numAgents", 1)
+        self.num_observations = config["env"]["numObservations"]
+        self.num_states = config["env"].get("numStates", 0)
+        self.num_actions = config["env"]["numActions"]
+        self.control_freq_inv = config["env"].get("controlFrequencyInv", 1)
+
+        self.obs_space = Box(np.ones(self.num_obs) * -np.inf, np.ones(self.num_obs) * np.inf)
+        self.state_space = Box(np.ones(self.num_states) * -np.inf, np.ones(self.num_states) * np.inf)
+        self.act_space = Box(np.ones(self.num_actions) * -1., np.ones(self.num_actions) * 1.)
+
+        self.clip_obs = config["env"].get("clipObservations", np.inf)
+        self.clip_actions = config["env"].get("clipActions", np.inf)
+
+    @abc.abstractmethod
+    def allocate_buffers(self): ...
+
+    @abc.abstractmethod
+    def step(self, actions: torch.Tensor) -> Tuple[Dict[str, torch.Tensor], torch.Tensor, torch.Tensor, Dict[str, Any]]: ...
+
+    @abc.abstractmethod
+    def reset(self) -> Dict[str, torch.Tensor]: ...
+
+    @property
+    def observation_space(self):
+        return self.obs_space
+
+    @property
+    def action_space(self):
+        return self.act_space
+
+    @property
+    def num_envs(self) -> int:
+        return self.num_environments
+
+    @property
+    def num_acts(self) -> int:
+        return self.num_actions
+
+    @property
+    def num_obs(self) -> int:
+        return self.num_observations
+
+
+class VecTask(Env):
+    """Subclasses create `self.sim` (a bez_isaacgym_amd.sim.BezSim) in create_sim()."""
+
+    def __init__(self, config, sim_device, graphics_device_id, headless):
+        super().__init__(config, sim_device, graphics_device_id, headless)
+        if self.cfg["physics_engine"] not in ("physx", "flex"):  # vec_task.py:162-168
+            raise ValueError(f"Invalid physics engine backend: {self.cfg['physics_engine']}")
+        if self.cfg["sim"]["up_axis"] not in ["z", "y"]:        # vec_task.py:421-424
+            msg = f"Invalid physics up-axis: {self.cfg['sim']['up_axis']}"
+            print(msg)
+            raise ValueError(msg)
+        if self.device == "cpu":
+            raise RuntimeError("bez_isaacgym_amd is HIP-only: run with sim_device=cuda:<k> pipeline=gpu "
+                               "(the CPU restatement lives in oracle/ and is test infrastructure)")
+        self.first_randomization = True
+        self.dr_randomizations = {}
+        self.last_step = -1
+        self.last_rand_step = -1
+        self.viewer = None
+        self.enable_viewer_sync = True
+        self.sim_initialized = False
+        self.create_sim()
+        self.sim_initialized = True
+        self.allocate_buffers()
+        self.obs_dict = {}
+
+    def allocate_buffers(self):
+        """Same names / dtypes as vec_task.py:226-249; obs/rew/reset/progress/timeout are zero-copy views of
+        the simulator's own buffers (the fused kernel writes them in place)."""
+        from ... import abi
+        s = self.sim
+        self.obs_buf = s.tensor(abi.TENSOR_OBS)
+        self.states_buf = torch.zeros((self.num_envs, self.num_states), device=self.device, dtype=torch.float)
+        self.rew_buf = s.tensor(abi.TENSOR_REW)
+        self.reset_buf = s.tensor(abi.TENSOR_RESET)
+        self.timeout_buf = s.tensor(abi.TENSOR_TIMEOUT)
+        self.progress_buf = s.tensor(abi.TENSOR_PROGRESS)
+        self.randomize_buf = torch.zeros(self.num_envs, device=self.device, dtype=torch.long)
+        self.extras = {}
+
+    def get_state(self):
+        return torch.clamp(self.states_buf, -self.clip_obs, self.clip_obs).to(self.rl_device)
+
+    @abc.abstractmethod
+    def pre_physics_step(self, actions: torch.Tensor): ...
+
+    @abc.abstractmethod
+    def post_physics_step(self): ...
+
+    def step(self, actions: torch.Tensor):
+        """vec_task.py:303-349.  With no Python-side hooks active this is ONE kernel launch
+        (bez_sim_step: clamp, PD targets, physics, bookkeeping, reset, obs, reward)."""
+        if self.dr_randomizations.get('actions', None):
+            actions = self.dr_randomizations['actions']['noise_lambda'](actions)
+        actions = actions.to(self.device, torch.float32).contiguous()
+        self._fused_step(actions)
+        if self.dr_randomizations.get('observations', None):
+            self.obs_buf.copy_(self.dr_randomizations['observations']['noise_lambda'](self.obs_buf))
+        self.extras["time_outs"] = self.timeout_buf.to(self.rl_device)
+        self.obs_dict["obs"] = torch.clamp(self.obs_buf, -self.clip_obs, self.clip_obs).to(self.rl_device)
+        if self.num_states > 0:
+            self.obs_dict["states"] = self.get_state()
+        return self.obs_dict, self.rew_buf.to(self.rl_device), self.reset_buf.to(self.rl_device), self.extras
+
+    def _fused_step(self, actions):
+        """Default: the split path through the subclass hooks (vec_task.py:317-335)."""
+        action_tensor = torch.clamp(actions, -self.clip_actions, self.clip_actions)
+        self.pre_physics_step(action_tensor)
+        for _ in range(self.control_freq_inv):
+            self.render()
+            self.sim.simulate()
+        self.post_physics_step()
+
+    def zero_actions(self) -> torch.Tensor:
+        return torch.zeros([self.num_envs, self.num_actions], dtype=torch.float32, device=self.rl_device)
+
+    def reset(self):
+        """vec_task.py:361-377: one step with zero actions."""
+        self.step(self.zero_actions())
+        self.obs_dict["obs"] = torch.clamp(self.obs_buf, -self.clip_obs, self.clip_obs).to(self.rl_device)
+        if self.num_states > 0:
+            self.obs_dict["states"] = self.get_state()
+        return self.obs_dict
+
+    def render(self):
+        """Headless only (viewer is out of scope): no-op."""
+        return None
+
+    def get_number_of_agents(self):
+        return self.num_agents
+
+    # ---- domain randomisation (vec_task.py:505-725) -> per-env parameter arrays read by the kernel
+    def apply_randomizations(self, dr_params):
+        from ... import abi
+        rand_freq = dr_params.get("frequency", 1)
+        self.last_step += 1
+        do_nonenv = (self.last_step - self.last_rand_step) >= rand_freq or self.first_randomization
+        if do_nonenv:
+            self.last_rand_step = self.last_step
+        if self.first_randomization:
+            env_ids = torch.arange(self.num_envs, device=self.device)
+        else:
+            mask = (self.randomize_buf >= rand_freq) & (self.reset_buf > 0)
+            env_ids = mask.nonzero(as_tuple=False).squeeze(-1)
+            self.randomize_buf[mask] = 0
+
+        def sched(attr):  # vec_task.py:560-566 linear schedule
+            if attr.get("schedule") == "linear":
+                return min(self.last_step, attr["schedule_steps"]) / attr["schedule_steps"]
+            return 1.0
+
+        if do_nonenv:
+            for key in ("observations", "actions"):  # vec_task.py:544-618 (gaussian additive noise lambdas)
+                if key in dr_params:
+                    attr = dr_params[key]
+                    mu, var = attr["range"]
+                    s = sched(attr)
+                    if attr["operation"] == "additive":
+                        mu, var = mu * s, var * s
+                    else:
+                        mu, var = mu * s + 1.0 * (1 - s), var * s + 1.0 * (1 - s)
+                    std = float(np.sqrt(var)) if attr["distribution"] == "gaussian" else None
+                    op = (lambda a, b: a + b) if attr["operation"] == "additive" else (lambda a, b: a * b)
+                    if std is not None:
+                        fn = (lambda t, op=op, mu=mu, std=std: op(t, torch.randn_like(t) * std + mu))
+                    else:
+                        lo, hi = attr["range"]
+                        fn = (lambda t, op=op, lo=lo, hi=hi: op(t, torch.rand_like(t) * (hi - lo) + lo))
+                    self.dr_randomizations[key] = {"noise_lambda": fn}
+            if "sim_params" in dr_params and "gravity" in dr_params["sim_params"]:  # vec_task.py:620-632
+                attr = dr_params["sim_params"]["gravity"]
+                s = sched(attr)
+                g0 = torch.tensor(list(self.cfg["sim"]["gravity"]), device=self.device, dtype=torch.float32)
+                noise = torch.randn(3, device=self.device) * float(np.sqrt(attr["range"][1] * s)) + attr["range"][0] * s
+                self.sim.set_env_params(abi.PARAM_GRAVITY, (g0 + noise).repeat(self.num_envs, 1).contiguous())
+        if len(env_ids) and "actor_params" in dr_params and "bez" in dr_params["actor_params"]:
+            ap = dr_params["actor_params"]["bez"]
+
+            def uniform_scale(attr, width):
+                lo, hi = attr["range"]
+                s = sched(attr)
+                lo, hi = lo * s + 1.0 * (1 - s), hi * s + 1.0 * (1 - s)
+                return torch.rand(len(env_ids), width, device=self.device) * (hi - lo) + lo
+
+            def update(name, param, attr, width, base=1.0):
+                if not hasattr(self, name):
+                    setattr(self, name, torch.full((self.num_envs, width), base, device=self.device, dtype=torch.float32))
+                buf = getattr(self, name)
+                buf[env_ids] = base * uniform_scale(attr, width)
+                self.sim.set_env_params(param, buf.contiguous())
+
+            rsp = ap.get("rigid_shape_properties", {})
+            if "friction" in rsp:
+                update("_dr_friction", abi.PARAM_FRICTION, rsp["friction"], 1, base=float(self.cfg["env"]["plane"]["dynamicFriction"]))
+            dp = ap.get("dof_properties", {})
+            if "stiffness" in dp:
+                update("_dr_kp", abi.PARAM_KP_SCALE, dp["stiffness"], 18)
+            if "damping" in dp:
+                update("_dr_kd", abi.PARAM_KD_SCALE, dp["damping"], 18)
+            rbp = ap.get("rigid_body_properties", {})
+            if "mass" in rbp and (self.first_randomization or not rbp["mass"].get("setup_only", False)):
+                update("_dr_mass", abi.PARAM_MASS_SCALE, rbp["mass"], 19)
+        self.first_randomization = False

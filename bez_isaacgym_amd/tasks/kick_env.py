@@ -1,0 +1,192 @@
+"""KickEnv with the reference's surface (bez_isaacgym/tasks/kick_env.py) over the HIP simulator.
+
+What stays drop-in: ctor `(cfg, sim_device, graphics_device_id, headless)` (kick_env.py:46); attributes the
+reference's tests / controllers read -- actions, device, dt, dof_pos_limits_lower/upper, default_dof_pos,
+root_pos_bez, root_orient_bez, num_envs, reset_buf, root_states, dof_state, rigid_body ... (kick_env.py:126-238);
+hooks pre_physics_step (:410), post_physics_step (:426), reset_idx (:779), compute_observations (:749),
+compute_reward (:584).  What changed: every hook is a call into libbez_sim.so; step() is the fused kernel.
+"""
+import enum
+import json
+import os
+
+import numpy as np
+import torch
+
+from .. import abi
+from ..sim import BezSim
+from .base.vec_task import VecTask
+
+
+class Joints(enum.IntEnum):  # kick_env.py:23-41
+    HEAD_1 = 0
+    HEAD_2 = 1
+    LEFT_ARM_1 = 2
+    LEFT_ARM_2 = 3
+    LEFT_LEG_1 = 4
+    LEFT_LEG_2 = 5
+    LEFT_LEG_3 = 6
+    LEFT_LEG_4 = 7
+    LEFT_LEG_5 = 8
+    LEFT_LEG_6 = 9
+    RIGHT_ARM_1 = 10
+    RIGHT_ARM_2 = 11
+    RIGHT_LEG_1 = 12
+    RIGHT_LEG_2 = 13
+    RIGHT_LEG_3 = 14
+    RIGHT_LEG_4 = 15
+    RIGHT_LEG_5 = 16
+    RIGHT_LEG_6 = 17
+
+
+_MODEL = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "model", "bez_model.json")))
+
+
+class KickEnv(VecTask):
+
+    def __init__(self, cfg, sim_device, graphics_device_id, headless):
+        self.cfg = cfg
+        self.randomization_params = self.cfg["task"]["randomization_params"]
+        self.randomize = self.cfg["task"]["randomize"]
+        env = self.cfg["env"]
+        self.plane_static_friction = env["plane"]["staticFriction"]
+        self.plane_dynamic_friction = env["plane"]["dynamicFriction"]
+        self.plane_restitution = env["plane"]["restitution"]
+        self.bez_init_state = env["bezInitState"]["pos"] + env["bezInitState"]["rot"] + \
+            env["bezInitState"]["vLinear"] + env["bezInitState"]["vAngular"]
+        self.ball_init_state = env["ballInitState"]["pos"] + env["ballInitState"]["rot"] + \
+            env["ballInitState"]["vLinear"] + env["ballInitState"]["vAngular"]
+        goal = env["goalState"]["goal"]
+        self.cleats = env["asset"]["cleats"]
+        if self.cleats or not env["asset"]["stl"]:
+            raise NotImplementedError("only the default asset (stl: True, cleats: False -> soccerbot_stl.urdf) is compiled "
+                                      "into the kernels; the cleats/box variants are listed as 'next' in DESIGN.md")
+        self.debug_rewards = env["debug"]["rewards"]
+        self.named_default_joint_angles = env["readyJointAngles"]
+        self.max_episode_length_s = env["learn"]["episodeLength_s"]
+        self.Kp = env["control"]["stiffness"]
+        self.Kd = env["control"]["damping"]
+        self.orn_dim, self.imu_dim, self.feet_dim, self.dof_dim, self.rnn_dim, self.ball_dim = 2, 6, 8, 18, 1, 2
+        self.imu_max_ang_vel = 8.7266
+        self.imu_max_lin_acc = 2. * 9.81
+        self.MX_28_velocity = 2 * np.pi
+        self.cfg["env"]["numObservations"] = self.dof_dim * 2 + self.imu_dim + self.orn_dim + self.feet_dim + self.ball_dim  # 54
+        self.cfg["env"]["numActions"] = self.dof_dim
+        self.strict_reference_quirks = bool(self.cfg.get("strict_reference_quirks", True))
+
+        super().__init__(config=self.cfg, sim_device=sim_device, graphics_device_id=graphics_device_id, headless=headless)
+
+        self.dt = self.cfg["sim"]["dt"]
+        self.max_episode_length = int(self.max_episode_length_s / self.dt + 0.5)
+        dev = self.device
+        n = self.num_envs
+        self.goal = torch.tensor([goal], device=dev, dtype=torch.float32).repeat((n, 1))
+        self.bez_init_xy = torch.tensor(self.bez_init_state[0:2], device=dev, dtype=torch.float32)
+        self.ball_init = torch.tensor([self.ball_init_state[0:2]], device=dev, dtype=torch.float32).repeat((n, 1))
+        self.initial_root_states = torch.tensor([self.bez_init_state, self.ball_init_state], device=dev,
+                                                dtype=torch.float32).repeat((n, 1))
+        self.initial_root_states[:, 7:13] = 0
+        self.default_dof_pos = torch.tensor(_MODEL["dof_default"], device=dev, dtype=torch.float32).repeat((n, 1))
+        for i, name in enumerate(self.dof_names):
+            self.default_dof_pos[:, i] = float(self.named_default_joint_angles[name])
+        self.num_dofs = self.num_dof
+        self.actions = torch.zeros(n, self.num_actions, dtype=torch.float, device=dev)
+        self.gravity_vec = torch.tensor([0., 0., -1.], device=dev).repeat((n, 1))
+        self.up_vec = torch.tensor([0., 0., 1.], device=dev).repeat((n, 1))
+        self._stale = True
+        # (reset_idx(all envs), kick_env.py:238, already happened inside bez_sim_create)
+
+    # ---- sim construction (kick_env.py:240-408)
+    def create_sim(self):
+        self.up_axis_idx = 2
+        rank_offset = int(self.cfg.get("env_id_offset", 0))
+        seed = int(self.cfg.get("seed", 42))
+        sim_cfg = abi.config_from_task_cfg(self.cfg, seed=seed, env_id_offset=rank_offset,
+                                           strict_reference_quirks=self.strict_reference_quirks)
+        self.sim_cfg = sim_cfg
+        self.sim = BezSim(sim_cfg, self.device_id)
+        self.num_dof = 18
+        self.num_bodies = 21
+        self.num_joints = 20
+        self.dof_names = list(_MODEL["dof_names"])
+        self.bez_indices = torch.arange(0, self.num_envs * 2, 2, device=self.device, dtype=torch.long)
+        self.ball_indices = self.bez_indices + 1
+        self.dof_pos_limits_lower = torch.tensor(_MODEL["dof_lower"], device=self.device, dtype=torch.float32)
+        self.dof_pos_limits_upper = torch.tensor(_MODEL["dof_upper"], device=self.device, dtype=torch.float32)
+        self.dof_vel_limits_upper = torch.full((18, 1), self.MX_28_velocity, device=self.device)
+        self.dof_vel_limits_lower = -self.dof_vel_limits_upper
+        self.start_rotation = torch.tensor([0., 0., 0., 1.], device=self.device)
+        if self.randomize:
+            self.apply_randomizations(self.randomization_params)
+
+    # ---- Isaac-layout tensors and the reference's views of them (kick_env.py:143-196), refreshed lazily
+    def _refresh_all(self):
+        if self._stale:
+            for t in (abi.TENSOR_ROOT_STATE, abi.TENSOR_DOF_STATE, abi.TENSOR_RIGID_BODY_STATE, abi.TENSOR_NET_CONTACT_FORCE):
+                self.sim.refresh(t)
+            self._stale = False
+
+    @property
+    def root_states(self):
+        self._refresh_all(); return self.sim.tensor(abi.TENSOR_ROOT_STATE)
+
+    @property
+    def dof_state(self):
+        self._refresh_all(); return self.sim.tensor(abi.TENSOR_DOF_STATE)
+
+    @property
+    def rigid_body(self):
+        self._refresh_all(); return self.sim.tensor(abi.TENSOR_RIGID_BODY_STATE)
+
+    @property
+    def net_contact_forces(self):
+        self._refresh_all(); return self.sim.tensor(abi.TENSOR_NET_CONTACT_FORCE)
+
+    dof_pos_bez = property(lambda s: s.dof_state.view(s.num_envs, 18, 2)[..., 0])
+    dof_vel_bez = property(lambda s: s.dof_state.view(s.num_envs, 18, 2)[..., 1])
+    root_pos_bez = property(lambda s: s.root_states.view(s.num_envs, 2, 13)[..., 0, 0:3])
+    root_orient_bez = property(lambda s: s.rigid_body.view(s.num_envs, 22, 13)[..., 1, 3:7])
+    root_vel_bez = property(lambda s: s.rigid_body.view(s.num_envs, 22, 13)[..., 1, 7:10])
+    root_ang_bez = property(lambda s: s.rigid_body.view(s.num_envs, 22, 13)[..., 1, 10:13])
+    root_pos_ball = property(lambda s: s.root_states.view(s.num_envs, 2, 13)[..., 1, 0:3])
+    root_orient_ball = property(lambda s: s.root_states.view(s.num_envs, 2, 13)[..., 1, 3:7])
+    root_vel_ball = property(lambda s: s.root_states.view(s.num_envs, 2, 13)[..., 1, 7:10])
+    left_foot_contact_forces = property(lambda s: s.net_contact_forces.view(s.num_envs, 22, 3)[..., 12, 0:3])
+    right_foot_contact_forces = property(lambda s: s.net_contact_forces.view(s.num_envs, 22, 3)[..., 20, 0:3])
+    prev_lin_vel = property(lambda s: s.sim.refresh(abi.TENSOR_PREV_LIN_VEL))
+    feet = property(lambda s: s.sim.refresh(abi.TENSOR_FEET))
+
+    # ---- step
+    def _fused_step(self, actions):
+        # actions[:, 0:2] are zeroed inside the kernel (kick_env.py:414); keep the Python-visible copy in step
+        self.actions = torch.clamp(actions, -self.clip_actions, self.clip_actions)
+        self.actions[..., 0:2] = 0.0
+        if self.randomize:
+            self.randomize_buf += 1
+            if (self.reset_buf > 0).any():  # DR only happens at reset time (kick_env.py:781-782)
+                self.apply_randomizations(self.randomization_params)
+        self.sim.step(actions)
+        self._stale = True
+
+    def pre_physics_step(self, actions):
+        self.actions = actions.clone().to(self.device)
+        self.sim.pre_physics(actions.to(self.device, torch.float32).contiguous())
+        self.actions[..., 0:2] = 0.0
+
+    def post_physics_step(self):
+        self.sim.post_physics()
+        self.randomize_buf += 1
+        self._stale = True
+
+    def compute_observations(self):
+        self.sim.observe_reward()
+        self._stale = True
+
+    def compute_reward(self, actions=None):
+        pass  # produced together with the observations by the same kernel
+
+    def reset_idx(self, env_ids):
+        if self.randomize:
+            self.apply_randomizations(self.randomization_params)
+        self.sim.reset_indexed(env_ids.to(self.device, torch.int32).contiguous())
+        self._stale = True

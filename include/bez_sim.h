@@ -100,7 +100,8 @@ enum BezTensor {
 enum BezDtype { BEZ_DTYPE_F32 = 0, BEZ_DTYPE_I64 = 1 };
 
 /* gym.create_sim + create_env/create_actor loop + prepare_sim + allocate_buffers
- * (vec_task.py:174-193, kick_env.py:240-408).  All envs start with reset_buf = 1. */
+ * (vec_task.py:174-193, kick_env.py:240-408) followed by KickEnv.__init__'s reset_idx(all)
+ * (kick_env.py:238): every env starts from its first reset draw with reset_buf = 0. */
 int bez_sim_create(const BezSimConfig* cfg, int device_id, BezSim** out);
 int bez_sim_destroy(BezSim* sim);
 const char* bez_sim_last_error(const BezSim* sim); /* sim may be NULL: last create error */
@@ -161,6 +162,14 @@ enum BezEnvParam {
   BEZ_PARAM_COUNT = 5
 };
 int bez_sim_set_env_params(BezSim* sim, int param, const float* values_dev, void* stream);
+
+/* Test hooks (state injection for the parity tests; no reference counterpart). */
+int bez_sim_set_prev_lin_vel_tensor(BezSim* sim, const float* prev_dev, void* stream); /* (N,3) */
+int bez_sim_set_flags(BezSim* sim, uint32_t flags);
+/* compute_observations + compute_reward on the current state, without timeout/progress/reset bookkeeping */
+int bez_sim_observe_reward(BezSim* sim, void* stream);
+/* number of compute_observations passes already done: only pass 0 differences against prev = zeros (Q1) */
+int bez_sim_set_obs_calls(BezSim* sim, int64_t calls);
 
 /* Re-keys the reset-noise stream (utils/utils.py:45-70 set_seed). */
 int bez_sim_seed(BezSim* sim, uint64_t seed);

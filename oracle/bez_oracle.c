@@ -233,6 +233,7 @@ typedef struct {
   BezSimConfig cfg;
   int n;
   Env* env;
+  int64_t obs_calls; /* number of compute_observations passes so far (quirk Q1 bookkeeping) */
 } Oracle;
 
 /* kinematics of one env: link frames relative to O = root_pos, world axes */
@@ -645,7 +646,10 @@ static void feet_no_cleats(real f[3], real out[4]) {
   if (f[2] < 1) for (int i = 0; i < 4; ++i) out[i] = -1; /* kick_env.py:1036-1038 */
 }
 
-static void env_observe_reward(const BezSimConfig* c, Env* e) {
+/* use_prev: take the finite difference against the stored prev_lin_vel.  The reference does so only on
+ * the first compute_imu call of a process (prev = zeros, kick_env.py:183); afterwards prev aliases the
+ * live velocity tensor (kick_env.py:930,441) and the difference is identically zero (quirk Q1). */
+static void env_observe_reward(const BezSimConfig* c, Env* e, int use_prev) {
   /* IMU link (body 1) is rigidly at the torso origin with identity offset (soccerbot_stl.urdf:567-572),
    * so its pose/twist equal the root state. */
   const real* q = e->root_quat; /* xyzw */
@@ -656,7 +660,7 @@ static void env_observe_reward(const BezSimConfig* c, Env* e) {
   real dt = (real)c->dt;
   real gunit[3] = {0, 0, -1}; /* kick_env.py:217 */
   for (int i = 0; i < 3; ++i) {
-    real prev = (c->flags & BEZ_FLAG_IMU_PREV_ALIAS) ? vimu[i] : e->prev_lin_vel[i];
+    real prev = use_prev ? e->prev_lin_vel[i] : vimu[i];
     acc[i] = (vimu[i] - prev) / dt - gunit[i];
   }
   /* quaternion_to_matrix with (r,i,j,k) <- (x,y,z,w): quirk Q2 */
@@ -732,11 +736,13 @@ static void env_observe_reward(const BezSimConfig* c, Env* e) {
   e->reset = reset;
 }
 
-static void env_post_physics(const BezSimConfig* c, Env* e, int64_t genv) {
+static int oracle_use_prev(const Oracle* o) { return !(o->cfg.flags & BEZ_FLAG_IMU_PREV_ALIAS) || o->obs_calls == 0; }
+
+static void env_post_physics(const BezSimConfig* c, Env* e, int64_t genv, int use_prev) {
   e->timeout = (e->progress >= c->max_episode_length - 1) ? 1 : 0; /* vec_task.py:331-332 */
   e->progress += 1;                                                /* kick_env.py:429 */
   if (e->reset != 0) env_reset(c, e, genv);                        /* kick_env.py:433-435 */
-  env_observe_reward(c, e);                                        /* kick_env.py:437-438 */
+  env_observe_reward(c, e, use_prev);                              /* kick_env.py:437-438 */
 }
 
 static void env_simulate(const BezSimConfig* c, Env* e) {
@@ -872,28 +878,36 @@ void bez_oracle_simulate(void* h) {
 }
 void bez_oracle_post_physics(void* h) {
   Oracle* o = (Oracle*)h;
-  for (int i = 0; i < o->n; ++i) env_post_physics(&o->cfg, &o->env[i], o->cfg.env_id_offset + i);
+  int up = oracle_use_prev(o);
+  for (int i = 0; i < o->n; ++i) env_post_physics(&o->cfg, &o->env[i], o->cfg.env_id_offset + i, up);
+  o->obs_calls += 1;
 }
 /* obs + reward only (no progress increment / reset handling): golden-vector checks of the jit functions */
 void bez_oracle_observe_reward(void* h) {
   Oracle* o = (Oracle*)h;
-  for (int i = 0; i < o->n; ++i) env_observe_reward(&o->cfg, &o->env[i]);
+  int up = oracle_use_prev(o);
+  for (int i = 0; i < o->n; ++i) env_observe_reward(&o->cfg, &o->env[i], up);
+  o->obs_calls += 1;
 }
 void bez_oracle_step(void* h, const float* actions) {
   Oracle* o = (Oracle*)h;
+  int up = oracle_use_prev(o);
 #pragma omp parallel for schedule(static)
   for (int i = 0; i < o->n; ++i) {
     Env* e = &o->env[i];
     env_pre_physics(&o->cfg, e, actions + (size_t)i * ND);
     env_simulate(&o->cfg, e);
-    env_post_physics(&o->cfg, e, o->cfg.env_id_offset + i);
+    env_post_physics(&o->cfg, e, o->cfg.env_id_offset + i, up);
   }
+  o->obs_calls += 1;
 }
 void bez_oracle_reset_idx(void* h, const int32_t* ids, int n) {
   Oracle* o = (Oracle*)h;
   for (int k = 0; k < n; ++k) env_reset(&o->cfg, &o->env[ids[k]], o->cfg.env_id_offset + ids[k]);
 }
 void bez_oracle_seed(void* h, uint64_t seed) { ((Oracle*)h)->cfg.seed = seed; }
+void bez_oracle_set_flags(void* h, uint32_t flags) { ((Oracle*)h)->cfg.flags = flags; }
+void bez_oracle_set_obs_calls(void* h, int64_t n) { ((Oracle*)h)->obs_calls = n; }
 
 /* Known-answer hooks: bare dynamics of env 0 in double-precision interface.
  * mode 1: pure ABA with joint torques tau (no PD, friction, limits, armature, contact).

@@ -119,6 +119,12 @@ class Oracle:
         a = np.ascontiguousarray(ids, dtype=np.int32)
         self.lib.bez_oracle_reset_idx(self.h, _fp(a), C.c_int(len(a)))
 
+    def set_flags(self, flags):
+        self.lib.bez_oracle_set_flags(self.h, C.c_uint32(flags))
+
+    def set_obs_calls(self, n):
+        self.lib.bez_oracle_set_obs_calls(self.h, C.c_int64(n))
+
     def seed(self, s):
         self.lib.bez_oracle_seed(self.h, C.c_uint64(s))
 

@@ -1,0 +1,68 @@
+"""CPU: the C-ABI library loads without a GPU and exports every symbol include/bez_sim.h declares;
+the ctypes mirror of BezSimConfig matches the C struct; the product refuses to run without a GPU."""
+import ctypes as C
+import os
+import re
+
+import pytest
+import torch
+
+from bez_isaacgym_amd import abi
+from bez_isaacgym_amd.build import build, lib_path
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    build()
+    from bez_isaacgym_amd.sim import load_library
+    return load_library()
+
+
+def test_exports_match_header(lib):
+    hdr = open(os.path.join(ROOT, "include", "bez_sim.h")).read()
+    declared = set(re.findall(r"\b(bez_sim_[a-z_0-9]+)\s*\(", hdr))
+    assert len(declared) >= 20
+    from bez_isaacgym_amd.sim import EXPORTS
+    assert declared == set(EXPORTS)
+    for name in declared:
+        assert hasattr(lib, name), name
+
+
+def test_default_config_matches_python(lib):
+    c = abi.BezSimConfig()
+    assert lib.bez_sim_default_config(C.byref(c), 4096) == 0
+    assert bytes(c) == bytes(abi.default_config(4096))
+    assert c.max_episode_length == 900 and c.substeps == 2 and c.num_envs == 4096
+
+
+def test_create_argument_errors(lib):
+    h = C.c_void_p()
+    c = abi.default_config(8)
+    c.abi_version = 99
+    assert lib.bez_sim_create(C.byref(c), 0, C.byref(h)) < 0
+    assert b"abi_version" in lib.bez_sim_last_error(None)
+    c = abi.default_config(0)
+    assert lib.bez_sim_create(C.byref(c), 0, C.byref(h)) < 0
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU failure mode")
+def test_product_fails_loudly_without_gpu(lib):
+    from bez_isaacgym_amd.sim import BezSim, BezSimError
+    with pytest.raises(BezSimError):
+        BezSim(abi.default_config(8), 0)
+    h = C.c_void_p()
+    c = abi.default_config(8)
+    assert lib.bez_sim_create(C.byref(c), 0, C.byref(h)) < 0  # no device: error, not a CPU fallback
+    assert b"no HIP device" in lib.bez_sim_last_error(None) or b"hip" in lib.bez_sim_last_error(None).lower()
+
+
+def test_product_does_not_import_oracle():
+    """The shipped package must never reference oracle/ (the oracle is the checker, not a fallback)."""
+    pkg = os.path.join(ROOT, "bez_isaacgym_amd")
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                txt = open(os.path.join(dp, f)).read()
+                assert "bez_oracle" not in txt and "import oracle" not in txt and "from oracle" not in txt, os.path.join(dp, f)
