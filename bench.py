@@ -1,0 +1,153 @@
+#!/usr/bin/env python3
+"""bez_kick random-action rollout benchmark (BASELINE.json configs[1]): env-steps/s at num_envs=4096 per GPU.
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+One process per GPU; every rank owns its own 4096 envs (weak scaling; env ids are global so reset noise does not
+depend on N); the rollout has no data-path collective.  A "step" is one fused control step of all local envs
+(bez_sim_step: action clamp, PD targets, 2 physics substeps, bookkeeping, reset, obs, reward) on synthetic
+U(-1,1) actions that are resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+ALGO_BYTES_PER_ENV_STEP = 828  # SURVEY.md 8(d) / BASELINE.md 4: read 336 B + write 492 B per env-step
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+ACTION_RING = 64               # distinct pre-generated action batches cycled through
+
+
+def cpu_baseline(num_envs, seconds_target=12.0):
+    """The oracle (kind 'port': this build's CPU restatement; the reference's own CPU pipeline is the closed
+    PhysX binary and cannot run) on the host cores, bounded sample of the same workload."""
+    import numpy as np
+    from oracle.bez_oracle import Oracle, build
+    from bez_isaacgym_amd import abi
+    build()
+    cores = min(len(os.sched_getaffinity(0)), 16)  # a 1-GPU box's CPU share is 16 cores
+    os.environ["OMP_NUM_THREADS"] = str(cores)  # read by libgomp when the oracle library is first loaded
+    orc = Oracle(abi.default_config(num_envs))
+    rng = np.random.default_rng(0)
+    acts = rng.uniform(-1, 1, (8, num_envs, 18)).astype(np.float32)
+    orc.step(acts[0])
+    t0 = time.perf_counter()
+    orc.step(acts[1])
+    one = time.perf_counter() - t0
+    steps = int(max(3, min(2000, seconds_target / max(one, 1e-6))))
+    t0 = time.perf_counter()
+    for t in range(steps):
+        orc.step(acts[t % 8])
+    dt = time.perf_counter() - t0
+    return {"value": num_envs * steps / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
+            "sample": "%d envs x %d control steps, fp64 C oracle, OpenMP over envs (%.1f s)" % (num_envs, steps, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--num-envs", type=int, default=4096, help="envs per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--launch", choices=["python", "c"], default="python",
+                    help="python: one bez_sim_step call per step from Python; c: bez_sim_step_many (C loop)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from bez_isaacgym_amd import abi
+    from bez_isaacgym_amd.sim import BezSim
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    n = args.num_envs
+    sim = BezSim(abi.default_config(n, seed=42, env_id_offset=rank * n), local_rank)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(1000 + rank)
+    actions = (torch.rand(ACTION_RING, n * 18, device=dev, generator=gen) * 2 - 1).contiguous()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def run(k, t0=0):
+        if args.launch == "c":
+            done = 0
+            while done < k:  # the ring is contiguous: up to ACTION_RING steps per C call
+                start = (t0 + done) % ACTION_RING
+                m = min(k - done, ACTION_RING - start)
+                sim.step_many(actions[start:start + m].reshape(-1), m)
+                done += m
+        else:
+            for t in range(k):
+                sim.step(actions[(t0 + t) % ACTION_RING])
+
+    run(args.warmup)
+    barrier()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t_start = time.perf_counter()
+    ev0.record()  # same stream the kernels are launched on (torch's current stream is passed through the C ABI)
+    run(args.steps, args.warmup)
+    ev1.record()
+    barrier()
+    elapsed = time.perf_counter() - t_start
+    dev_ms = ev0.elapsed_time(ev1)
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    # sanity: the rollout really ran (resets happen with random actions; everything finite)
+    obs = sim.tensor(abi.TENSOR_OBS)
+    assert torch.isfinite(obs).all()
+
+    if rank == 0:
+        total_envs = n * world
+        kernel_ms = dev_ms / args.steps  # avg device time per fused-step launch over the timed region (HIP events)
+        achieved = ALGO_BYTES_PER_ENV_STEP * n / (kernel_ms * 1e-3) / 1e9
+        out = {
+            "metric": "env-steps/s at num_envs=4096 (random-action rollout, bez_kick)",
+            "value": total_envs * args.steps / elapsed,
+            "unit": "env-steps/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "bez_kick num_envs=%d per GPU, random-action rollout only (no PPO), dt=1/60 s x 2 substeps, "
+                                   "natural resets included" % n,
+                       "envs_per_gpu": n, "total_envs": total_envs, "launch": args.launch, "parallelism": "env-sharded x%d" % world},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "bez::step_kernel<true,true,true,false>", "kernel_ms": kernel_ms,
+                         "algorithmic_bytes_per_launch": ALGO_BYTES_PER_ENV_STEP * n,
+                         "note": "N=4096 is latency/occupancy-bound (64 waves on 256 CUs, working set L2-resident): see DESIGN.md"},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(n)
+        elif not args.no_cpu_baseline:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

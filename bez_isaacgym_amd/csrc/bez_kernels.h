@@ -600,8 +600,8 @@ BEZ_DEV void env_reset(const Params& P, EnvState& S, float* target, float* cf, u
   }
 #pragma unroll
   for (int j = 0; j < BEZ_ND; ++j) {
-    float off = 0.3f * u[j] + (-0.15f);
-    float vel = 0.2f * u[BEZ_ND + j] + (-0.1f);
+    float off = fmaf(0.3f, u[j], -0.15f);  // torch_rand_float: (upper-lower)*rand + lower
+    float vel = fmaf(0.2f, u[BEZ_ND + j], -0.1f);
     float q = (float)BEZ_DOF_DEFAULT[j] + off;
     q = fmaxf(fminf(q, (float)BEZ_DOF_UPPER[j]), (float)BEZ_DOF_LOWER[j]);
     S.q[j] = q; S.qd[j] = vel;

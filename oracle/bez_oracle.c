@@ -581,8 +581,8 @@ static void env_reset(const BezSimConfig* c, Env* e, int64_t genv) {
   for (int j = 0; j < ND; ++j) {
     float up = reset_uniform(c->seed, genv, e->episode, j);
     float uv = reset_uniform(c->seed, genv, e->episode, ND + j);
-    float off = 0.3f * up + (-0.15f);
-    float vel = 0.2f * uv + (-0.1f);
+    float off = fmaf(0.3f, up, -0.15f); /* torch_rand_float: (upper-lower)*rand + lower */
+    float vel = fmaf(0.2f, uv, -0.1f);
     real q = (real)((float)BEZ_DOF_DEFAULT[j] + off);
     real lo = (real)(float)BEZ_DOF_LOWER[j], hi = (real)(float)BEZ_DOF_UPPER[j];
     if (q > hi) q = hi;
