@@ -926,6 +926,13 @@ void bez_oracle_forward_dynamics(void* h, int env, int mode, const double* tau, 
   if (ball_acc6) for (int i = 0; i < 3; ++i) { ball_acc6[i] = d.ball_ang_acc.v[i]; ball_acc6[3 + i] = d.ball_lin_acc.v[i]; }
   if (contact_force) for (int b = 0; b < BEZ_NBE; ++b) for (int k = 0; k < 3; ++k) contact_force[b * 3 + k] = d.contact_force[b][k];
 }
+/* full-precision state injection for the known-answer tests: s = pos3 quat4 lin3 ang3 q18 qd18 (49 doubles) */
+void bez_oracle_set_env_state_f64(void* h, int env, const double* s) {
+  Env* e = &((Oracle*)h)->env[env];
+  for (int i = 0; i < 3; ++i) { e->root_pos[i] = (real)s[i]; e->root_lin[i] = (real)s[7 + i]; e->root_ang[i] = (real)s[10 + i]; }
+  for (int i = 0; i < 4; ++i) e->root_quat[i] = (real)s[3 + i];
+  for (int j = 0; j < ND; ++j) { e->q[j] = (real)s[13 + j]; e->qd[j] = (real)s[31 + j]; }
+}
 uint32_t bez_oracle_philox_word(uint64_t seed, int64_t genv, uint32_t episode, int k) {
   uint32_t c[4] = {(uint32_t)genv, (uint32_t)((uint64_t)genv >> 32), episode, (uint32_t)(k >> 2)};
   philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));

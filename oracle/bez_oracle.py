@@ -136,5 +136,10 @@ class Oracle:
                                              _fp(a0), _fp(qdd), _fp(ball), _fp(cf))
         return a0, qdd, ball, cf
 
+    def set_env_state_f64(self, env, pos, quat, lin, ang, q, qd):
+        s = np.ascontiguousarray(np.concatenate([pos, quat, lin, ang, q, qd]), dtype=np.float64)
+        assert s.size == 49
+        self.lib.bez_oracle_set_env_state_f64(self.h, C.c_int(env), _fp(s))
+
     def philox_word(self, seed, genv, episode, k):
         return int(self.lib.bez_oracle_philox_word(C.c_uint64(seed), C.c_int64(genv), C.c_uint32(episode), C.c_int(k)))

@@ -1,0 +1,193 @@
+"""CPU: known-answer and invariant tests of the oracle's physics (the reference pins none: SURVEY.md section 4).
+
+  * bare ABA vs an independent numpy RNEA in link-local coordinates (tests/rbd_numpy.py)
+  * conservation laws of the contact-free, drive-free model integrated with RK4
+  * Philox4x32-10 known answers (Random123 kat vectors)
+  * behaviour of the full model: standing, ball drop / rest / roll, PD step response, weight on the feet
+"""
+import numpy as np
+import pytest
+
+from bez_isaacgym_amd import abi
+from oracle.bez_oracle import Oracle
+from tests import rbd_numpy as R
+
+G = np.array([0.0, 0.0, float(np.float32(-9.81))])  # BezSimConfig.gravity is fp32
+
+
+def _rand_state(rng, scale_v=1.0):
+    quat = rng.normal(size=4); quat /= np.linalg.norm(quat)
+    v0 = np.concatenate([rng.normal(size=3) * 2.0, rng.normal(size=3)]) * scale_v
+    q = rng.uniform(-1.0, 1.0, 18)
+    qd = rng.normal(size=18) * 2.0 * scale_v
+    return quat, v0, q, qd
+
+
+def _inject(o, pos, quat, v0, q, qd):
+    """Full-precision state injection (v0 = [w; v]); the ball is parked far away."""
+    quat = np.asarray(quat, float) / np.linalg.norm(quat)
+    o.set_env_state_f64(0, pos, quat, v0[3:], v0[:3], q, qd)
+    return np.asarray(pos, float), quat, np.asarray(v0, float), np.asarray(q, float), np.asarray(qd, float)
+
+
+def test_aba_matches_independent_rnea(model):
+    """Forward dynamics (oracle, world-aligned ABA) plugged into inverse dynamics (numpy RNEA, link-local):
+    must return the applied joint torques and a zero base wrench."""
+    rng = np.random.default_rng(0)
+    o = Oracle(num_envs=1)
+    for trial in range(20):
+        quat, v0, q, qd = _rand_state(rng)
+        tau = rng.normal(size=18) * 0.5
+        pos, quat, v0, q, qd = _inject(o, [0.1, -0.2, 0.6], quat, v0, q, qd)
+        a0, qdd, _, _ = o.forward_dynamics(0, 1, tau)
+        f0, tau_back = R.rnea_floating(model, quat, v0, a0, q, qd, qdd, G)
+        np.testing.assert_allclose(tau_back, tau, atol=1e-7)  # 7000:1 mass ratios: fp64 round-off ~1e-8
+        np.testing.assert_allclose(f0, 0.0, atol=1e-7)
+
+
+def test_free_flight_conservation(model):
+    """No drives, no contact: RK4 on the oracle's accelerations conserves total energy and angular momentum about
+    the COM; linear momentum changes by exactly m g t."""
+    rng = np.random.default_rng(1)
+    o = Oracle(num_envs=1)
+    quat, v0, q, qd = _rand_state(rng, scale_v=0.5)
+    pos = np.array([0.0, 0.0, 2.0])
+
+    def deriv(s):
+        p, qu, v, qq, qqd = s[0:3], s[3:7], s[7:13], s[13:31], s[31:49]
+        p_, qu_, v_, qq_, qqd_ = _inject(o, p, qu / np.linalg.norm(qu), v, qq, qqd)
+        a0, qdd, _, _ = o.forward_dynamics(0, 1, np.zeros(18))
+        w, vl = v[:3], v[3:]
+        x, y, z, s_ = qu
+        dq = 0.5 * np.array([w[0] * s_ + w[1] * z - w[2] * y, -w[0] * z + w[1] * s_ + w[2] * x,
+                             w[0] * y - w[1] * x + w[2] * s_, -w[0] * x - w[1] * y - w[2] * z])
+        return np.concatenate([vl, dq, a0[:3], a0[3:] + np.cross(w, vl), qqd, qdd])
+
+    s = np.concatenate([pos, quat, v0, q, qd])
+    h, steps = 5e-4, 400
+
+    def mech(s):
+        return R.mechanics(model, s[0:3], s[3:7] / np.linalg.norm(s[3:7]), s[7:13], s[13:31], s[31:49], G)
+    m0 = mech(s)
+    for _ in range(steps):
+        k1 = deriv(s); k2 = deriv(s + 0.5 * h * k1); k3 = deriv(s + 0.5 * h * k2); k4 = deriv(s + h * k3)
+        s = s + h / 6 * (k1 + 2 * k2 + 2 * k3 + k4)
+    m1 = mech(s)
+    T = h * steps
+    E0, E1 = m0["KE"] + m0["PE"], m1["KE"] + m1["PE"]
+    assert abs(E1 - E0) < 1e-8 * max(1.0, abs(E0)), (E0, E1)
+    np.testing.assert_allclose(m1["P"], m0["P"] + m0["mass"] * G * T, atol=1e-9)
+    Lc0 = m0["L"] - np.cross(m0["com"], m0["P"]); Lc1 = m1["L"] - np.cross(m1["com"], m1["P"])
+    np.testing.assert_allclose(Lc1, Lc0, atol=1e-9)
+    assert abs(m0["mass"] - model["total_mass"]) < 1e-12
+
+
+def test_philox_known_answers():
+    """Random123 kat_vectors, philox4x32-10."""
+    o = Oracle(num_envs=1)
+    assert [o.philox_word(0, 0, 0, k) for k in range(4)] == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
+    ones = [o.philox_word(0xffffffffffffffff, -1, 0xffffffff, -4 + k) for k in range(4)]
+    assert ones == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
+
+
+def test_reset_distribution_and_sharding():
+    """kick_env.py:786-791: q = clamp(default + U(-.15,.15)), qd = U(-.1,.1); keyed by global env id."""
+    a = Oracle(abi.default_config(512, seed=9))
+    b = Oracle(abi.default_config(256, seed=9, env_id_offset=256))
+    da, db = a.dof_state.reshape(512, 18, 2), b.dof_state.reshape(256, 18, 2)
+    np.testing.assert_array_equal(da[256:], db)
+    dflt = np.array([0, 0, 0, 1.5, 0, 0, .564, -1.176, .613, 0, 0, 1.5, 0, 0, .564, -1.176, .613, 0], np.float32)
+    off = da[:, :, 0] - dflt
+    assert off.min() >= -0.1500001 and off.max() <= 0.1500001 and abs(off.mean()) < 0.01 and off.std() > 0.07
+    assert np.abs(da[:, :, 1]).max() <= 0.1000001 and da[:, :, 1].std() > 0.05
+    c = Oracle(abi.default_config(512, seed=10))
+    assert not np.array_equal(c.dof_state, a.dof_state)
+    ids = np.array([3, 5], np.int32)
+    before = a.dof_state.reshape(512, 18, 2).copy()
+    a.reset_idx(ids)
+    after = a.dof_state.reshape(512, 18, 2)
+    assert not np.array_equal(before[3], after[3]) and np.array_equal(before[4], after[4])  # new episode -> new draw
+
+
+def test_standing_full_episode():
+    """Scenario of the reference's zero-action smoke test (test/test_kick_env.py:96-112), with assertions: the
+    ready pose stands for the whole 900-step episode; the feet carry the weight; the horizon reset fires."""
+    o = Oracle(num_envs=4)
+    act = np.zeros((4, 18), np.float32)
+    for t in range(899):
+        o.step(act)
+        assert (o.reset_buf == 0).all(), t
+    rs = o.root_states.reshape(4, 2, 13)
+    assert np.all(np.abs(rs[:, 0, 2] - 0.3235) < 0.01) and np.all(np.linalg.norm(rs[:, 0, :2], axis=1) < 0.05)
+    assert np.all(np.abs(rs[:, 0, 7:13]) < 1e-3)
+    cf = o.contact_forces.reshape(4, 22, 3)
+    np.testing.assert_allclose(cf[:, 12, 2] + cf[:, 20, 2], 2.827994 * 9.81, rtol=5e-3)
+    assert np.all(np.abs(cf[:, [12, 20], :2]) < 0.5)
+    np.testing.assert_array_equal(o.obs[:, 44:52], np.ones((4, 8), np.float32))  # fx=fy=0 after the noise gate -> case 11
+    np.testing.assert_allclose(rs[:, 1, 2], 0.08, atol=5e-4)  # ball rests on the plane
+    o.step(act)
+    assert (o.reset_buf == 1).all() and (o.rew == 0).all() and (o.timeout_buf == 1).all()
+    o.step(act)
+    assert (o.progress_buf == 0).all() and (o.reset_buf == 0).all()
+
+
+def test_ball_drop_roll_and_kick_contact():
+    """Ball: free fall matches g t^2/2 before impact, no bounce (restitution 0), rolling without slipping after a
+    push, spin decays with the angular damping; a leg box hitting the ball accelerates it (equal and opposite)."""
+    o = Oracle(num_envs=1)
+    root = o.root_states.reshape(1, 2, 13).copy()
+    root[0, 1, 0:3] = [1.0, 0.5, 0.5]; root[0, 1, 7:13] = 0
+    o.set_root_states(root.reshape(-1, 13))
+    z = []
+    for t in range(12):
+        o.simulate(); z.append(o.root_states.reshape(1, 2, 13)[0, 1, 2])
+    tt = 0.01667 * np.arange(1, 13)
+    np.testing.assert_allclose(z, 0.5 - 0.5 * 9.81 * tt * (tt + 0.01667 / 2), atol=2e-4)  # semi-implicit Euler, 2 substeps
+    for t in range(60):
+        o.simulate()
+    r = o.root_states.reshape(1, 2, 13)[0, 1]
+    assert abs(r[2] - 0.08) < 5e-4 and abs(r[9]) < 1e-3
+    root = o.root_states.reshape(1, 2, 13).copy()
+    root[0, 1, 7] = 1.0  # push along x
+    o.set_root_states(root.reshape(-1, 13))
+    for t in range(60):
+        o.simulate()
+    r = o.root_states.reshape(1, 2, 13)[0, 1]
+    assert 0.3 < r[7] < 1.0 and abs(r[7] - r[11] * 0.08) < 0.02  # v = w R: rolling
+    # kick: put the ball just in front of the left foot and swing the hip forward
+    o2 = Oracle(num_envs=1)
+    for t in range(60):
+        o2.step(np.zeros((1, 18), np.float32))
+    rb = o2.rigid_body_states.reshape(1, 22, 13)
+    foot = rb[0, 12, 0:3]
+    root = o2.root_states.reshape(1, 2, 13).copy()
+    root[0, 1, 0:3] = [foot[0] + 0.045 + 0.08 + 0.005, foot[1], 0.08]
+    o2.set_root_states(root.reshape(-1, 13))
+    act = np.zeros((1, 18), np.float32); act[0, 6] = 1.0; act[0, 7] = 0.6  # left thigh forward, knee extend
+    vmax, hit = 0.0, False
+    for t in range(25):
+        o2.step(act)
+        cf = o2.contact_forces.reshape(1, 22, 3)[0]
+        leg = cf[[8, 9, 10, 11, 12]].sum(axis=0) - np.array([0, 0, cf[12, 2]])
+        if np.linalg.norm(cf[21, :2]) > 0.2:
+            hit = True
+        vmax = max(vmax, o2.root_states.reshape(1, 2, 13)[0, 1, 7])
+    assert hit and vmax > 0.2, (hit, vmax)
+
+
+def test_pd_step_response_and_limits():
+    """Arm joint follows a target step without overshoot beyond the limit, respects the 2*pi rad/s clamp, and a
+    target outside the limits is clamped to them (kick_env.py:417-418)."""
+    o = Oracle(num_envs=1)
+    act = np.zeros((1, 18), np.float32)
+    act[0, 3] = -3.9  # left forearm: default 1.5, lower limit 0 -> target clamps to 0
+    qs, vs = [], []
+    for t in range(60):
+        o.step(act)
+        d = o.dof_state.reshape(1, 18, 2)[0, 3]
+        qs.append(d[0]); vs.append(d[1])
+        if o.reset_buf[0]:
+            break
+    assert np.abs(vs).max() <= 2 * np.pi + 1e-6
+    assert o.targets[0, 3] == 0.0
+    assert min(qs) > -0.05 and qs[-1] < 0.2
