@@ -48,6 +48,48 @@ def cpu_baseline(num_envs, seconds_target=12.0):
             "sample": "%d envs x %d control steps, fp64 C oracle, OpenMP over envs (%.1f s)" % (num_envs, steps, dt)}
 
 
+def ppo_leg(args, rank, local_rank, world, n):
+    """bez_kick PPO training (BASELINE.json configs[2]: rl_games default MLP, horizon 32, minibatch 32768, 5 mini-epochs,
+    AMP): samples/s = horizon * envs * GPUs / epoch wall time (rollout + update), max over ranks."""
+    import torch
+    import torch.distributed as dist
+    from bez_isaacgym_amd.ppo.a2c_continuous import A2CAgent
+    from bez_isaacgym_amd.utils.config import load_config
+    from bez_isaacgym_amd.utils.rlgames_utils import RLGPUEnv, get_rlgames_env_creator
+    cfg = load_config(["task=bez_kick", "num_envs=%d" % n, "headless=True"])
+    task = cfg["task"]
+    task["seed"] = 42
+    dev = "cuda:%d" % local_rank
+    task["rl_device"] = dev
+    task["env_id_offset"] = rank * n
+    venv = RLGPUEnv("rlgpu", n, env_creator=get_rlgames_env_creator(task, "bez_kick", dev, dev, 0, True))
+    params = cfg["train"]["params"]
+    params["config"].update(save_frequency=0, save_best_after=10 ** 9)
+    params["config"]["minibatch_size"] = min(int(params["config"]["minibatch_size"]), n * int(params["config"]["horizon_length"]))
+    agent = A2CAgent(params, venv, dev, rank=rank, world=world)
+    agent.obs = agent.env_reset()
+    agent.train_epoch()  # warm-up (allocations, hipBLASLt heuristics)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    play = 0.0
+    for _ in range(args.ppo_epochs):
+        st = agent.train_epoch()
+        play += st["play_time"]
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt, play], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt, play = float(t[0]), float(t[1])
+    samples = agent.batch_size * world * args.ppo_epochs
+    return {"metric": "PPO samples/s (rollout + update)", "value": samples / dt, "unit": "samples/s", "epochs": args.ppo_epochs,
+            "samples_per_epoch": agent.batch_size * world, "epoch_ms": dt / args.ppo_epochs * 1e3,
+            "rollout_share": play / dt, "dtype": "fp16 autocast (AMP, as bez_kickPPO.yaml mixed_precision) + f32 sim",
+            "minibatch": agent.minibatch_size, "mini_epochs": agent.mini_epochs}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -55,6 +97,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--num-envs", type=int, default=4096, help="envs per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--ppo-epochs", type=int, default=3, help="extra leg after the timed rollout: PPO epochs timed for the "
+                    "'PPO samples/s' half of BASELINE.json's metric (0 = skip)")
     ap.add_argument("--launch", choices=["python", "c"], default="python",
                     help="python: one bez_sim_step call per step from Python; c: bez_sim_step_many (C loop)")
     args = ap.parse_args()
@@ -113,6 +157,10 @@ def main():
     obs = sim.tensor(abi.TENSOR_OBS)
     assert torch.isfinite(obs).all()
 
+    ppo = None
+    if args.ppo_epochs > 0:
+        ppo = ppo_leg(args, rank, local_rank, world, n)
+
     if rank == 0:
         total_envs = n * world
         kernel_ms = dev_ms / args.steps  # avg device time per fused-step launch over the timed region (HIP events)
@@ -139,6 +187,8 @@ def main():
                          "algorithmic_bytes_per_launch": ALGO_BYTES_PER_ENV_STEP * n,
                          "note": "N=4096 is latency/occupancy-bound (64 waves on 256 CUs, working set L2-resident): see DESIGN.md"},
         }
+        if ppo is not None:
+            out["ppo"] = ppo
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(n)
         elif not args.no_cpu_baseline:

@@ -1,0 +1,444 @@
+"""PPO (rl_games `a2c_continuous` semantics) for the bez_kick env, in PyTorch-ROCm.
+
+The reference trains through the un-vendored rl_games package (call sites bez_isaacgym/train.py:89-113; hyper-parameters
+bez_isaacgym/cfg/train/bez_kickPPO.yaml:1-79).  This module is this build's consumer loop with the same semantics
+(rl_games 1.1.x [ext]; its source is not under /root/reference, so the algorithm is restated from its published
+behaviour and anchored on the YAML keys and on the shipped checkpoint's tensor names/shapes):
+
+  network   actor_critic, separate: False -> shared MLP 54-400-200-100 (ELU), mu Linear(100,18) without activation,
+            fixed sigma = nn.Parameter(zeros(18)) used as log-std, value Linear(100,1)        bez_kickPPO.yaml:10-27
+  inputs    RunningMeanStd on observations (clamp +-5) and on values (normalize_value)         :51-52
+  rollout   horizon_length 32, reward * scale_value 0.01, value bootstrap on time-outs        :53-56,72
+  returns   GAE(gamma .99, tau .95)                                                           :58-59
+  update    5 mini-epochs x (N*32 / minibatch_size) minibatches, PPO clip .2, clipped value loss, critic_coef 2 (x0.5),
+            entropy_coef 0, bounds loss .001, advantage normalisation, grad-norm clip 1.0, AMP fp16 + GradScaler,
+            Adam, adaptive LR on KL (threshold .008, x/ 1.5, clamp [1e-6, 1e-2])               :57-79
+  multi-GPU one process per GPU; one fused all-reduce of the flat gradient (124 237 fp32) per optimiser step over
+            RCCL (torch.distributed backend "nccl"), KL and running-moment sums averaged the same way; parameters
+            broadcast from rank 0 at start (reference: Horovod, utils/rlgames_utils.py:71-81, config.yaml:40).
+Checkpoints keep rl_games' key layout (model / running_mean_std / reward_mean_std / optimizer / epoch / frame /
+last_mean_rewards) as evidenced by results/Bez_Kick/Normal/Bez_Kick_33.pth.
+"""
+import math
+import os
+import time
+
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+
+
+def _dist_on():
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
+class RunningMeanStd(nn.Module):
+    """rl_games RunningMeanStd: parallel-variance update of (mean, var, count); fp64 buffers like the checkpoint."""
+
+    def __init__(self, shape, epsilon=1e-5):
+        super().__init__()
+        self.epsilon = epsilon
+        self.register_buffer("running_mean", torch.zeros(shape, dtype=torch.float64))
+        self.register_buffer("running_var", torch.ones(shape, dtype=torch.float64))
+        self.register_buffer("count", torch.ones((), dtype=torch.float64))
+
+    @torch.no_grad()
+    def update(self, x):
+        x = x.reshape(-1, *self.running_mean.shape).double()
+        n = torch.tensor(float(x.shape[0]), dtype=torch.float64, device=x.device)
+        s1, s2 = x.sum(0), (x * x).sum(0)
+        if _dist_on():  # moments of the GLOBAL batch: every rank ends with identical statistics
+            flat = torch.cat([s1.reshape(-1), s2.reshape(-1), n.reshape(1)])
+            dist.all_reduce(flat)
+            k = s1.numel()
+            s1, s2, n = flat[:k].reshape(s1.shape), flat[k:2 * k].reshape(s2.shape), flat[2 * k]
+        b_mean = s1 / n
+        b_var = (s2 / n - b_mean * b_mean).clamp_min(0.0) * (n / (n - 1).clamp_min(1.0))  # unbiased, as torch.var
+        delta = b_mean - self.running_mean
+        tot = self.count + n
+        self.running_mean += delta * n / tot
+        m2 = self.running_var * self.count + b_var * n + delta * delta * self.count * n / tot
+        self.running_var.copy_(m2 / tot)
+        self.count.copy_(tot)
+
+    def forward(self, x, unnorm=False):
+        if self.training and not unnorm:
+            self.update(x)
+        mean, var = self.running_mean.float(), self.running_var.float()
+        if unnorm:
+            y = torch.clamp(x, min=-5.0, max=5.0)
+            return torch.sqrt(var + self.epsilon) * y + mean
+        y = (x - mean) / torch.sqrt(var + self.epsilon)
+        return torch.clamp(y, min=-5.0, max=5.0)
+
+
+class A2CNetwork(nn.Module):
+    """Parameter names match rl_games' a2c_network.* so state dicts interoperate."""
+
+    def __init__(self, obs_dim, act_dim, units=(400, 200, 100)):
+        super().__init__()
+        layers, d = [], obs_dim
+        for u in units:
+            layers += [nn.Linear(d, u), nn.ELU()]
+            d = u
+        self.actor_mlp = nn.Sequential(*layers)
+        self.value = nn.Linear(d, 1)
+        self.mu = nn.Linear(d, act_dim)
+        self.sigma = nn.Parameter(torch.zeros(act_dim))  # const_initializer val 0, fixed_sigma True
+
+    def forward(self, obs):
+        h = self.actor_mlp(obs)
+        return self.mu(h), self.sigma.unsqueeze(0).expand(obs.shape[0], -1), self.value(h)
+
+
+class ModelA2CContinuousLogStd(nn.Module):
+    def __init__(self, obs_dim, act_dim, units):
+        super().__init__()
+        self.a2c_network = A2CNetwork(obs_dim, act_dim, units)
+
+    @staticmethod
+    def neglogp(x, mean, std, logstd):
+        return 0.5 * (((x - mean) / std) ** 2).sum(-1) + 0.5 * math.log(2.0 * math.pi) * x.shape[-1] + logstd.sum(-1)
+
+    def forward(self, obs, prev_actions=None):
+        mu, logstd, value = self.a2c_network(obs)
+        sigma = torch.exp(logstd)
+        if prev_actions is not None:  # training pass
+            entropy = (0.5 + 0.5 * math.log(2 * math.pi) + logstd).sum(-1)
+            return dict(prev_neglogp=self.neglogp(prev_actions, mu, sigma, logstd), values=value, entropy=entropy,
+                        mus=mu, sigmas=sigma)
+        action = mu + sigma * torch.randn_like(mu)
+        return dict(neglogpacs=self.neglogp(action, mu, sigma, logstd), values=value, actions=action, mus=mu, sigmas=sigma)
+
+
+def policy_kl(p0_mu, p0_sigma, p1_mu, p1_sigma):
+    c1 = torch.log(p1_sigma / p0_sigma + 1e-5)
+    c2 = (p0_sigma ** 2 + (p1_mu - p0_mu) ** 2) / (2.0 * (p1_sigma ** 2 + 1e-5))
+    return (c1 + c2 - 0.5).sum(-1).mean()
+
+
+class AdaptiveScheduler:
+    def __init__(self, kl_threshold=0.008):
+        self.min_lr, self.max_lr, self.kl_threshold = 1e-6, 1e-2, kl_threshold
+
+    def update(self, lr, kl):
+        if kl > 2.0 * self.kl_threshold:
+            lr = max(lr / 1.5, self.min_lr)
+        if kl < 0.5 * self.kl_threshold:
+            lr = min(lr * 1.5, self.max_lr)
+        return lr
+
+
+def discount_values(gamma, tau, fdones, last_values, mb_fdones, mb_values, mb_rewards):
+    """GAE backward scan over the horizon (rl_games a2c_common.discount_values)."""
+    horizon = mb_rewards.shape[0]
+    advs = torch.zeros_like(mb_rewards)
+    lastgaelam = torch.zeros_like(last_values)
+    for t in reversed(range(horizon)):
+        if t == horizon - 1:
+            nextnonterminal, nextvalues = 1.0 - fdones, last_values
+        else:
+            nextnonterminal, nextvalues = 1.0 - mb_fdones[t + 1], mb_values[t + 1]
+        nextnonterminal = nextnonterminal.unsqueeze(1)
+        delta = mb_rewards[t] + gamma * nextvalues * nextnonterminal - mb_values[t]
+        lastgaelam = delta + gamma * tau * nextnonterminal * lastgaelam
+        advs[t] = lastgaelam
+    return advs
+
+
+def swap_and_flatten01(x):
+    s = x.shape
+    return x.transpose(0, 1).reshape(s[0] * s[1], *s[2:])
+
+
+class A2CAgent:
+    """Continuous-action PPO agent.  `vec_env` needs step(actions)->(obs_dict, rew, done, info), reset()->obs_dict."""
+
+    def __init__(self, params, vec_env, device, writer=None, rank=0, world=1):
+        c = params["config"]
+        self.cfg, self.params = c, params
+        self.vec_env, self.device = vec_env, torch.device(device)
+        self.rank, self.world = rank, world
+        self.num_actors = int(c["num_actors"])
+        self.horizon = int(c["horizon_length"])
+        self.gamma, self.tau = float(c["gamma"]), float(c["tau"])
+        self.e_clip = float(c["e_clip"])
+        self.critic_coef, self.entropy_coef = float(c["critic_coef"]), float(c["entropy_coef"])
+        self.bounds_loss_coef = float(c.get("bounds_loss_coef", 0.0) or 0.0)
+        self.grad_norm = float(c["grad_norm"])
+        self.truncate_grads = bool(c.get("truncate_grads", False))
+        self.clip_value = bool(c.get("clip_value", True))
+        self.normalize_input = bool(c.get("normalize_input", False))
+        self.normalize_value = bool(c.get("normalize_value", False))
+        self.normalize_advantage = bool(c.get("normalize_advantage", True))
+        self.value_bootstrap = bool(c.get("value_bootstrap", False))
+        self.mixed_precision = bool(c.get("mixed_precision", False)) and self.device.type == "cuda"
+        self.reward_scale = float(c.get("reward_shaper", {}).get("scale_value", 1.0))
+        self.mini_epochs = int(c["mini_epochs"])
+        self.batch_size = self.horizon * self.num_actors
+        self.minibatch_size = min(int(c["minibatch_size"]), self.batch_size)
+        assert self.batch_size % self.minibatch_size == 0, "batch must be a multiple of minibatch_size"
+        self.num_minibatches = self.batch_size // self.minibatch_size
+        self.max_epochs = int(c.get("max_epochs", 100000))
+        self.save_frequency = int(c.get("save_frequency", 0) or 0)
+        self.save_best_after = int(c.get("save_best_after", 100))
+        self.score_to_win = float(c.get("score_to_win", float("inf")))
+        self.last_lr = float(c["learning_rate"])
+        self.is_adaptive_lr = c.get("lr_schedule") == "adaptive"
+        self.scheduler = AdaptiveScheduler(float(c.get("kl_threshold", 0.008)))
+        self.name = c.get("full_experiment_name") or c.get("name", "bez_kick")
+        self.writer = writer
+        net = params["network"]
+        assert net["name"] == "actor_critic" and not net.get("separate", False)
+        units = tuple(net["mlp"]["units"])
+        assert str(net["mlp"]["activation"]).lower() == "elu"
+        obs_dim, act_dim = 54, 18
+        info = getattr(vec_env, "get_env_info", None)
+        if info is not None:
+            ei = vec_env.get_env_info()
+            obs_dim, act_dim = ei["observation_space"].shape[0], ei["action_space"].shape[0]
+        self.obs_dim, self.act_dim = obs_dim, act_dim
+        seed = params.get("seed", 42)
+        torch.manual_seed(int(seed if seed not in ("", None) else 42))
+        self.model = ModelA2CContinuousLogStd(obs_dim, act_dim, units).to(self.device)
+        self.running_mean_std = RunningMeanStd((obs_dim,)).to(self.device) if self.normalize_input else None
+        self.value_mean_std = RunningMeanStd((1,)).to(self.device) if self.normalize_value else None
+        self.optimizer = torch.optim.Adam(self.model.parameters(), lr=self.last_lr, eps=1e-8)
+        self.scaler = torch.amp.GradScaler("cuda", enabled=self.mixed_precision)
+        self.epoch_num, self.frame = 0, 0
+        self.games_to_track = 100
+        self.game_rewards, self.game_lengths = [], []
+        self.last_mean_rewards = -100500.0
+        self.current_rewards = torch.zeros(self.num_actors, device=self.device)
+        self.current_lengths = torch.zeros(self.num_actors, device=self.device)
+        self.dones = torch.ones(self.num_actors, dtype=torch.uint8, device=self.device)
+        self._flat_grad = None
+        if _dist_on():  # identical replicas (hvd.broadcast_parameters equivalent)
+            for p in self.model.parameters():
+                dist.broadcast(p.data, src=0)
+        self.obs = None
+
+    # ------------------------------------------------------------------ rollout
+    def _preproc_obs(self, obs):
+        return self.running_mean_std(obs) if self.normalize_input else obs
+
+    @torch.no_grad()
+    def get_action_values(self, obs):
+        self.model.eval()
+        if self.normalize_input:
+            self.running_mean_std.eval()
+        with torch.autocast("cuda", dtype=torch.float16, enabled=self.mixed_precision):
+            res = self.model(self._preproc_obs(obs))
+        res = {k: v.float() for k, v in res.items()}
+        if self.normalize_value:
+            self.value_mean_std.eval()
+            res["values"] = self.value_mean_std(res["values"], True)
+        return res
+
+    @torch.no_grad()
+    def get_values(self, obs):
+        return self.get_action_values(obs)["values"]
+
+    def env_reset(self):
+        return self.vec_env.reset()["obs"].to(self.device)
+
+    def play_steps(self):
+        H, N, dev = self.horizon, self.num_actors, self.device
+        mb_obs = torch.zeros(H, N, self.obs_dim, device=dev)
+        mb_act = torch.zeros(H, N, self.act_dim, device=dev)
+        mb_mu, mb_sigma = torch.zeros_like(mb_act), torch.zeros_like(mb_act)
+        mb_val, mb_rew = torch.zeros(H, N, 1, device=dev), torch.zeros(H, N, 1, device=dev)
+        mb_neglogp, mb_dones = torch.zeros(H, N, device=dev), torch.zeros(H, N, device=dev)
+        for n in range(H):
+            res = self.get_action_values(self.obs)
+            mb_obs[n], mb_dones[n] = self.obs, self.dones.float()
+            mb_act[n], mb_mu[n], mb_sigma[n] = res["actions"], res["mus"], res["sigmas"]
+            mb_val[n], mb_neglogp[n] = res["values"], res["neglogpacs"]
+            obs_dict, rew, dones, infos = self.vec_env.step(torch.clamp(res["actions"], -1.0, 1.0))
+            self.obs = obs_dict["obs"].to(dev)
+            rew = rew.to(dev).float().unsqueeze(1)
+            shaped = rew * self.reward_scale
+            if self.value_bootstrap and "time_outs" in infos:
+                shaped = shaped + self.gamma * res["values"] * infos["time_outs"].to(dev).unsqueeze(1).float()
+            mb_rew[n] = shaped
+            self.dones = dones.to(dev).to(torch.uint8)
+            self.current_rewards += rew.squeeze(1)
+            self.current_lengths += 1
+            done_idx = self.dones.nonzero(as_tuple=False).squeeze(-1)
+            if done_idx.numel():
+                self.game_rewards = (self.game_rewards + self.current_rewards[done_idx].tolist())[-self.games_to_track:]
+                self.game_lengths = (self.game_lengths + self.current_lengths[done_idx].tolist())[-self.games_to_track:]
+                not_done = 1.0 - self.dones.float()
+                self.current_rewards *= not_done
+                self.current_lengths *= not_done
+        last_values = self.get_values(self.obs)
+        advs = discount_values(self.gamma, self.tau, self.dones.float(), last_values, mb_dones, mb_val, mb_rew)
+        returns = advs + mb_val
+        batch = dict(obs=swap_and_flatten01(mb_obs), actions=swap_and_flatten01(mb_act), mus=swap_and_flatten01(mb_mu),
+                     sigmas=swap_and_flatten01(mb_sigma), values=swap_and_flatten01(mb_val),
+                     returns=swap_and_flatten01(returns), neglogpacs=swap_and_flatten01(mb_neglogp))
+        return batch
+
+    # ------------------------------------------------------------------ update
+    def prepare_dataset(self, batch):
+        values, returns = batch["values"], batch["returns"]
+        if self.normalize_value:
+            self.value_mean_std.train()
+            values = self.value_mean_std(values)
+            returns = self.value_mean_std(returns)
+            self.value_mean_std.eval()
+        adv = (returns - values).sum(dim=1)
+        if self.normalize_advantage:
+            if _dist_on():
+                st = torch.stack([adv.sum(), (adv * adv).sum(), torch.tensor(float(adv.numel()), device=adv.device)]).double()
+                dist.all_reduce(st)
+                mean = st[0] / st[2]
+                std = torch.sqrt(((st[1] / st[2] - mean * mean) * st[2] / (st[2] - 1)).clamp_min(0))
+                adv = (adv - mean.float()) / (std.float() + 1e-8)
+            else:
+                adv = (adv - adv.mean()) / (adv.std() + 1e-8)
+        self.dataset = dict(old_values=values, old_logp=batch["neglogpacs"], advantages=adv, returns=returns,
+                            actions=batch["actions"], obs=batch["obs"], mu=batch["mus"], sigma=batch["sigmas"])
+
+    def _allreduce_grads(self):
+        """ONE fused all-reduce of the flat fp32 gradient (124 237 elements = 497 KB) per optimiser step: the message
+        is latency-bound on xGMI, so bucketing per parameter would only multiply the latency."""
+        params = [p for p in self.model.parameters() if p.grad is not None]
+        n = sum(p.numel() for p in params)
+        if self._flat_grad is None or self._flat_grad.numel() != n:
+            self._flat_grad = torch.empty(n, device=self.device, dtype=torch.float32)
+        off = 0
+        for p in params:
+            self._flat_grad[off:off + p.numel()].copy_(p.grad.reshape(-1))
+            off += p.numel()
+        dist.all_reduce(self._flat_grad)
+        self._flat_grad.div_(dist.get_world_size())
+        off = 0
+        for p in params:
+            p.grad.copy_(self._flat_grad[off:off + p.numel()].view_as(p.grad))
+            off += p.numel()
+
+    def calc_gradients(self, mb):
+        self.model.train()
+        if self.normalize_input:
+            self.running_mean_std.train()
+        obs = self._preproc_obs(mb["obs"])
+        e = self.e_clip
+        with torch.autocast("cuda", dtype=torch.float16, enabled=self.mixed_precision):
+            res = self.model(obs, mb["actions"])
+            neglogp, values, entropy, mu, sigma = (res[k].float() for k in ("prev_neglogp", "values", "entropy", "mus", "sigmas"))
+            ratio = torch.exp(mb["old_logp"] - neglogp)
+            surr1 = mb["advantages"] * ratio
+            surr2 = mb["advantages"] * torch.clamp(ratio, 1.0 - e, 1.0 + e)
+            a_loss = torch.max(-surr1, -surr2)
+            if self.clip_value:
+                vclip = mb["old_values"] + (values - mb["old_values"]).clamp(-e, e)
+                c_loss = torch.max((values - mb["returns"]) ** 2, (vclip - mb["returns"]) ** 2)
+            else:
+                c_loss = (mb["returns"] - values) ** 2
+            if self.bounds_loss_coef > 0:
+                soft = 1.1
+                b_loss = (torch.clamp_min(mu - soft, 0.0) ** 2 + torch.clamp_max(mu + soft, 0.0) ** 2).sum(-1)
+            else:
+                b_loss = torch.zeros_like(a_loss)
+            a_l, c_l, ent, b_l = a_loss.mean(), c_loss.mean(), entropy.mean(), b_loss.mean()
+            loss = a_l + 0.5 * c_l * self.critic_coef - ent * self.entropy_coef + b_l * self.bounds_loss_coef
+        self.optimizer.zero_grad(set_to_none=True)
+        self.scaler.scale(loss).backward()
+        if self.truncate_grads or _dist_on():
+            self.scaler.unscale_(self.optimizer)
+        if _dist_on():
+            self._allreduce_grads()
+        if self.truncate_grads:
+            nn.utils.clip_grad_norm_(self.model.parameters(), self.grad_norm)
+        self.scaler.step(self.optimizer)
+        self.scaler.update()
+        with torch.no_grad():
+            kl = policy_kl(mu.detach(), sigma.detach(), mb["mu"], mb["sigma"])
+            if _dist_on():
+                dist.all_reduce(kl)
+                kl /= dist.get_world_size()
+        return a_l.detach(), c_l.detach(), ent.detach(), kl, b_l.detach()
+
+    def train_epoch(self):
+        t0 = time.perf_counter()
+        batch = self.play_steps()
+        if self.device.type == "cuda":
+            torch.cuda.synchronize()
+        t_play = time.perf_counter() - t0
+        self.prepare_dataset(batch)
+        kls, a_ls, c_ls = [], [], []
+        for _ in range(self.mini_epochs):
+            ep_kls = []
+            for i in range(self.num_minibatches):
+                sl = slice(i * self.minibatch_size, (i + 1) * self.minibatch_size)
+                mb = {k: v[sl] for k, v in self.dataset.items()}
+                a_l, c_l, ent, kl, b_l = self.calc_gradients(mb)
+                ep_kls.append(kl); a_ls.append(a_l); c_ls.append(c_l)
+            av_kl = torch.stack(ep_kls).mean().item()
+            if self.is_adaptive_lr:
+                self.last_lr = self.scheduler.update(self.last_lr, av_kl)
+                for g in self.optimizer.param_groups:
+                    g["lr"] = self.last_lr
+            kls.append(av_kl)
+        if self.device.type == "cuda":
+            torch.cuda.synchronize()
+        t_total = time.perf_counter() - t0
+        self.epoch_num += 1
+        self.frame += self.batch_size * self.world
+        return dict(play_time=t_play, update_time=t_total - t_play, total_time=t_total, kl=sum(kls) / len(kls),
+                    a_loss=torch.stack(a_ls).mean().item(), c_loss=torch.stack(c_ls).mean().item(), lr=self.last_lr)
+
+    def train(self, max_epochs=None, log=print):
+        self.obs = self.env_reset()
+        max_epochs = max_epochs or self.max_epochs
+        total_time = 0.0
+        while self.epoch_num < max_epochs:
+            st = self.train_epoch()
+            total_time += st["total_time"]
+            mean_rew = sum(self.game_rewards) / len(self.game_rewards) if self.game_rewards else float("nan")
+            if self.rank == 0:
+                fps = self.batch_size * self.world / st["total_time"]
+                log("epoch %d frames %d fps total %.0f (step %.0f) kl %.5f lr %.2e a_loss %.4f c_loss %.4f mean_reward %.3f" % (
+                    self.epoch_num, self.frame, fps, self.batch_size * self.world / st["play_time"], st["kl"], st["lr"],
+                    st["a_loss"], st["c_loss"], mean_rew))
+                if self.writer is not None:
+                    self.writer.add(dict(epoch=self.epoch_num, frame=self.frame, time=total_time, fps=fps, mean_reward=mean_rew, **st))
+                if self.save_frequency and self.epoch_num % self.save_frequency == 0:
+                    self.save(os.path.join("runs", str(self.name), "nn", "last_%s_ep_%d.pth" % (self.name, self.epoch_num)))
+                if self.game_rewards and mean_rew > self.last_mean_rewards and self.epoch_num >= self.save_best_after:
+                    self.last_mean_rewards = mean_rew
+                    self.save(os.path.join("runs", str(self.name), "nn", "%s.pth" % self.name))
+            if self.game_rewards and mean_rew > self.score_to_win:
+                break
+        return self.last_mean_rewards, self.epoch_num
+
+    # ------------------------------------------------------------------ checkpoints (rl_games key layout)
+    def get_full_state_weights(self):
+        state = {"model": self.model.state_dict(), "epoch": self.epoch_num, "frame": self.frame,
+                 "optimizer": self.optimizer.state_dict(), "last_mean_rewards": self.last_mean_rewards,
+                 "scaler": self.scaler.state_dict(), "env_state": None}
+        if self.normalize_input:
+            state["running_mean_std"] = self.running_mean_std.state_dict()
+        if self.normalize_value:
+            state["reward_mean_std"] = self.value_mean_std.state_dict()
+        return state
+
+    def set_full_state_weights(self, state):
+        self.model.load_state_dict(state["model"])
+        if self.normalize_input and "running_mean_std" in state:
+            self.running_mean_std.load_state_dict(state["running_mean_std"])
+        if self.normalize_value and "reward_mean_std" in state:
+            self.value_mean_std.load_state_dict(state["reward_mean_std"])
+        if "optimizer" in state:
+            self.optimizer.load_state_dict(state["optimizer"])
+        self.epoch_num = int(state.get("epoch", 0))
+        self.frame = int(state.get("frame", 0))
+        self.last_mean_rewards = float(state.get("last_mean_rewards", -100500.0))
+
+    def save(self, path):
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        torch.save(self.get_full_state_weights(), path)
+
+    def restore(self, path):
+        self.set_full_state_weights(torch.load(path, map_location=self.device, weights_only=False))

@@ -1,0 +1,64 @@
+"""Entry point with the reference's CLI contract (bez_isaacgym/train.py:60-116):
+
+    python -m bez_isaacgym_amd.train task=bez_kick num_envs=4096 sim_device=cuda:0 pipeline=gpu headless=True
+    python -m torch.distributed.run --nproc-per-node 8 -m bez_isaacgym_amd.train task=bez_kick multi_gpu=True headless=True
+
+Composes cfg/config.yaml + task + train groups (utils/config.py), seeds, builds the env through the rl_games-style
+factory, dumps runs/<name>/config.yaml (train.py:105-108) and runs the PPO loop (ppo/a2c_continuous.py).
+"""
+import os
+import sys
+
+import yaml
+
+
+def launch(argv=None):
+    import torch
+    import torch.distributed as dist
+    from .ppo.a2c_continuous import A2CAgent
+    from .utils.config import load_config, print_dict
+    from .utils.rlgames_utils import RLGPUAlgoObserver, RLGPUEnv, get_rlgames_env_creator
+    from .utils.utils import set_np_formatting, set_seed
+
+    cfg = load_config(list(sys.argv[1:] if argv is None else argv))
+    if cfg.get("checkpoint"):
+        cfg["checkpoint"] = os.path.abspath(cfg["checkpoint"])
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    multi_gpu = bool(cfg.get("multi_gpu", False)) and world > 1
+    if multi_gpu and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if rank == 0:
+        print_dict(cfg)
+    set_np_formatting()
+    cfg["seed"] = set_seed(cfg["seed"], torch_deterministic=cfg.get("torch_deterministic", False))
+    task_cfg = cfg["task"]
+    task_cfg["seed"] = cfg["seed"]
+    create_env = get_rlgames_env_creator(task_cfg, cfg["task_name"], cfg["sim_device"], cfg["rl_device"],
+                                         cfg["graphics_device_id"], cfg["headless"], multi_gpu=multi_gpu)
+    vec_env = RLGPUEnv("rlgpu", task_cfg["env"]["numEnvs"], env_creator=create_env)
+    params = cfg["train"]["params"]
+    name = params["config"]["name"]
+    run_dir = os.path.join("runs", str(name))
+    writer = None
+    if rank == 0:
+        os.makedirs(run_dir, exist_ok=True)
+        with open(os.path.join(run_dir, "config.yaml"), "w") as f:
+            yaml.safe_dump(cfg, f)
+        writer = RLGPUAlgoObserver(run_dir)
+    agent = A2CAgent(params, vec_env, vec_env.env.rl_device, writer=writer, rank=rank, world=world if multi_gpu else 1)
+    if params.get("load_checkpoint"):
+        agent.restore(params["load_path"])
+    if cfg.get("test"):
+        raise NotImplementedError("play/inference (reference play.py) is listed as 'next' in DESIGN.md")
+    result = agent.train()
+    if multi_gpu:
+        dist.barrier()
+        dist.destroy_process_group()
+    return result
+
+
+if __name__ == "__main__":
+    launch()

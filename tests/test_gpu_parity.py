@@ -205,3 +205,47 @@ def test_kickenv_surface():
     np.testing.assert_allclose(env.obs_buf[:, 0:18].cpu().numpy(), env.dof_pos_bez.cpu().numpy(), atol=0)
     env.reset_idx(torch.arange(0, 64, 2, device="cuda:0"))
     assert (env.progress_buf[0::2] == 0).all() and (env.progress_buf[1::2] == 2).all()
+
+
+def test_domain_randomization_parity():
+    """Config 5 path: per-env friction / gain / mass / gravity arrays (vec_task.py:505-725 -> bez_sim_set_env_params)
+    change the HIP step exactly as they change the oracle's."""
+    n = 128
+    o, g = _pair(n, seed=3)
+    rng = np.random.default_rng(8)
+    params = {abi.PARAM_FRICTION: rng.uniform(0.7, 1.3, (n, 1)), abi.PARAM_KP_SCALE: rng.uniform(0.5, 1.5, (n, 18)),
+              abi.PARAM_KD_SCALE: rng.uniform(0.5, 1.5, (n, 18)), abi.PARAM_MASS_SCALE: rng.uniform(0.5, 1.5, (n, 19)),
+              abi.PARAM_GRAVITY: np.tile([[0.0, 0.0, -9.81]], (n, 1)) + rng.normal(0, 0.3, (n, 3))}
+    for k, v in params.items():
+        o.set_env_params(k, v.astype(np.float32)); g.set_env_params(k, v.astype(np.float32))
+    base_o, base_g = _pair(n, seed=3)
+    for t in range(12):
+        g.set_root_states(o.root_states); g.set_dof_state(o.dof_state); g.set_contact_forces(o.contact_forces)
+        g.set_targets(o.targets); g.set_reset(o.reset_buf); g.set_progress(o.progress_buf)
+        act = rng.uniform(-1, 1, (n, 18)).astype(np.float32)
+        o.step(act); g.step(act); base_o.step(act)
+        _compare_state(o, g)
+        np.testing.assert_array_equal(g.reset_buf, o.reset_buf)
+    assert np.abs(o.dof_state - base_o.dof_state).max() > 1e-2  # the randomisation really changed the dynamics
+    g.set_env_params(abi.PARAM_MASS_SCALE, None)  # back to defaults is accepted
+    g.step(act)
+
+
+def test_ppo_epochs_on_gpu():
+    """The consumer loop end to end on the GPU: KickEnv (fused HIP step) -> rollout buffer -> GAE -> AMP PPO update."""
+    from bez_isaacgym_amd.utils.config import load_config
+    from bez_isaacgym_amd.utils.rlgames_utils import RLGPUEnv, get_rlgames_env_creator
+    from bez_isaacgym_amd.ppo.a2c_continuous import A2CAgent
+    cfg = load_config(["task=bez_kick", "num_envs=512", "headless=True"])
+    cfg["task"]["seed"] = 42
+    creator = get_rlgames_env_creator(cfg["task"], "bez_kick", "cuda:0", "cuda:0", 0, True)
+    venv = RLGPUEnv("rlgpu", 512, env_creator=creator)
+    params = cfg["train"]["params"]
+    params["config"].update(minibatch_size=4096, save_frequency=0, save_best_after=10 ** 9)
+    agent = A2CAgent(params, venv, "cuda:0")
+    assert agent.batch_size == 512 * 32 and agent.num_minibatches == 4
+    agent.obs = agent.env_reset()
+    stats = [agent.train_epoch() for _ in range(3)]
+    assert all(np.isfinite([s["kl"], s["a_loss"], s["c_loss"]]).all() for s in stats)
+    assert agent.frame == 3 * 512 * 32 and len(agent.game_rewards) > 0
+    assert all(torch.isfinite(p).all() for p in agent.model.parameters())

@@ -1,0 +1,127 @@
+"""CPU: the PPO consumer loop (rl_games a2c_continuous semantics) -- shapes, GAE against a literal restatement, learning
+on a toy env, checkpoint key layout, and the multi-process path on gloo (world_size 2)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from bez_isaacgym_amd.ppo.a2c_continuous import (A2CAgent, ModelA2CContinuousLogStd, RunningMeanStd, discount_values)
+from bez_isaacgym_amd.utils.config import load_config
+from tests.fake_env import FakeVecEnv
+
+
+def _params(num_actors, minibatch, horizon=8, epochs=3):
+    cfg = load_config(["task=bez_kick"], resolve=True)
+    p = cfg["train"]["params"]
+    p["config"].update(num_actors=num_actors, minibatch_size=minibatch, horizon_length=horizon, max_epochs=epochs,
+                       mixed_precision=False, save_frequency=0, save_best_after=10 ** 9)
+    return p
+
+
+def test_network_matches_reference_checkpoint_shapes():
+    """54-400-200-100 ELU trunk, mu 18, sigma 18, value 1: 124 237 parameters (Bez_Kick_33.pth / bez_kickPPO.yaml:25-27)."""
+    m = ModelA2CContinuousLogStd(54, 18, (400, 200, 100))
+    sd = m.state_dict()
+    assert sum(v.numel() for v in sd.values()) == 124237
+    expect = {"a2c_network.sigma": (18,), "a2c_network.actor_mlp.0.weight": (400, 54), "a2c_network.actor_mlp.2.weight": (200, 400),
+              "a2c_network.actor_mlp.4.weight": (100, 200), "a2c_network.value.weight": (1, 100), "a2c_network.mu.weight": (18, 100)}
+    for k, shp in expect.items():
+        assert tuple(sd[k].shape) == shp, k
+
+
+def test_gae_matches_literal_definition():
+    torch.manual_seed(0)
+    H, N = 7, 5
+    rew, val = torch.randn(H, N, 1), torch.randn(H, N, 1)
+    dones = (torch.rand(H, N) < 0.2).float()
+    last_v, last_d = torch.randn(N, 1), (torch.rand(N) < 0.2).float()
+    adv = discount_values(0.99, 0.95, last_d, last_v, dones, val, rew)
+    ref = torch.zeros(H, N)
+    for n in range(N):
+        gae = 0.0
+        for t in reversed(range(H)):
+            nd = last_d[n] if t == H - 1 else dones[t + 1, n]
+            nv = last_v[n, 0] if t == H - 1 else val[t + 1, n, 0]
+            delta = rew[t, n, 0] + 0.99 * nv * (1 - nd) - val[t, n, 0]
+            gae = delta + 0.99 * 0.95 * (1 - nd) * gae
+            ref[t, n] = gae
+    np.testing.assert_allclose(adv.squeeze(-1).numpy(), ref.numpy(), atol=1e-5)
+
+
+def test_running_mean_std_matches_numpy():
+    rms = RunningMeanStd((3,))
+    rng = np.random.default_rng(0)
+    chunks = [rng.normal(2.0, 3.0, (100, 3)), rng.normal(-1.0, 0.5, (50, 3))]
+    rms.train()
+    for c in chunks:
+        rms(torch.from_numpy(c).float())
+    allx = np.concatenate(chunks)
+    # rl_games starts from count=1 (a virtual sample at mean 0, var 1): reproduce
+    n = len(allx)
+    mean = allx.sum(0) / (n + 1)
+    np.testing.assert_allclose(rms.running_mean.numpy(), mean, rtol=1e-5)
+    assert abs(float(rms.count) - (n + 1)) < 1e-9
+
+
+def test_learns_toy_env_and_checkpoint_roundtrip(tmp_path):
+    env = FakeVecEnv(64, seed=1)
+    agent = A2CAgent(_params(64, 256, horizon=8), env, "cpu")
+    agent.obs = agent.env_reset()
+    first = [agent.train_epoch() for _ in range(3)]
+    r0 = float(np.mean(agent.game_rewards)) if agent.game_rewards else None
+    for _ in range(40):
+        agent.train_epoch()
+    r1 = float(np.mean(agent.game_rewards))
+    assert r0 is None or r1 > r0, (r0, r1)
+    state = agent.get_full_state_weights()
+    assert {"model", "running_mean_std", "reward_mean_std", "optimizer", "epoch", "frame", "last_mean_rewards"} <= set(state)
+    assert set(state["running_mean_std"]) == {"running_mean", "running_var", "count"} and state["running_mean_std"]["running_mean"].dtype == torch.float64
+    path = str(tmp_path / "ck.pth")
+    agent.save(path)
+    other = A2CAgent(_params(64, 256, horizon=8), FakeVecEnv(64, seed=1), "cpu")
+    other.restore(path)
+    for a, b in zip(agent.model.parameters(), other.model.parameters()):
+        assert torch.equal(a, b)
+    assert other.epoch_num == agent.epoch_num and other.frame == agent.frame
+
+
+def _dp_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    env = FakeVecEnv(32, seed=100 + rank)           # each rank owns its own envs (sharded, no data-path collective)
+    agent = A2CAgent(_params(32, 128, horizon=8), env, "cpu", rank=rank, world=world)
+    agent.obs = agent.env_reset()
+    for _ in range(3):
+        agent.train_epoch()
+    flat = torch.cat([p.detach().reshape(-1) for p in agent.model.parameters()])
+    out[rank] = (flat.clone(), agent.running_mean_std.running_mean.clone(), agent.last_lr, agent.frame)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_data_parallel_gloo_world2_replicas_stay_identical():
+    """One process per rank, gradient all-reduce per optimiser step: after training on DIFFERENT env shards both replicas
+    hold bit-identical parameters, identical input statistics and the same adaptive LR; frames count the whole job."""
+    mgr = mp.Manager()
+    out = mgr.dict()
+    port = 29500 + (os.getpid() % 2000)
+    mp.spawn(_dp_worker, args=(2, port, out), nprocs=2, join=True)
+    (p0, m0, lr0, f0), (p1, m1, lr1, f1) = out[0], out[1]
+    assert torch.equal(p0, p1)
+    assert torch.equal(m0, m1)
+    assert lr0 == lr1 and f0 == f1 == 3 * 8 * 32 * 2
+
+
+def test_cli_config_contract():
+    """train.py's CLI contract: task=bez_kick num_envs=... sim_device=... pipeline=... headless=... (README.md:46-63)."""
+    cfg = load_config(["task=bez_kick", "num_envs=64", "sim_device=cpu", "pipeline=cpu", "headless=True", "max_iterations=7"])
+    assert cfg["task_name"] == "bez_kick" and cfg["task"]["env"]["numEnvs"] == 64
+    assert cfg["task"]["sim"]["use_gpu_pipeline"] is False and cfg["task"]["sim"]["physx"]["use_gpu"] is False
+    assert cfg["train"]["params"]["config"]["max_epochs"] == 7 and cfg["train"]["params"]["config"]["num_actors"] == 64
+    assert cfg["train"]["params"]["config"]["minibatch_size"] == 32768 and cfg["train"]["params"]["config"]["horizon_length"] == 32
