@@ -1,0 +1,485 @@
+// bez_kernel_ws.h -- wave-specialised fused step kernel (the production hot path at num_envs = 4096).
+//
+// One workgroup = 4 waves = 64 environments.  Lane l of EVERY wave works on the same env (block*64 + l); the
+// wave index selects a ROLE, so the four SIMDs of a CU advance the four independent parts of one articulated
+// body at the same time instead of one wave walking all 19 links serially:
+//     role 0  left leg   (links 5..10)      passes 1-3, foot ground contact, ball<->leg-box contact
+//     role 1  right leg  (links 13..18)     same
+//     role 2  head + arms (links 1,2 / 3,4 / 11,12), their guard points
+//     role 3  torso, ball, 6x6 root solve, root/ball integration, then the whole post-physics
+//             (bookkeeping, reset, observations, reward)
+// Chains only meet at the torso: per substep the roles exchange 27 floats (articulated inertia + bias of a chain)
+// up and 6 floats (torso acceleration) down through LDS, lds[slot * 64 + lane] (bank = lane, conflict-free),
+// with five workgroup barriers.  Role dispatch is a scalar branch on readfirstlane(wave id), every role executes
+// the same number of barriers.  Because a wave only ever holds ONE chain, all per-link data of passes 1-3 stays
+// in VGPRs (no scratch, no LDS staging of the pass-3 operands).
+// Actions (N,18) and observations (N,54) are row-major in HBM: each workgroup's 64 rows are one contiguous block,
+// moved with coalesced accesses by all 256 threads and transposed through LDS.
+#pragma once
+#include "bez_kernels.h"
+
+namespace bez {
+
+constexpr int WS_BLOCK = 256;
+constexpr int WS_ENVS = 64;
+
+// LDS exchange slots (floats per env lane)
+enum : int {
+  X_ROOT = 0,    // pos3 quat4 lin3 ang3
+  X_BALL = 13,   // pos3 lin3 ang3
+  X_IA = 22,     // 3 roles x (Sym6 21 + bias 6)
+  X_A0 = 103,    // torso spatial acceleration
+  X_DEPTH = 109, // deepest ball/box penetration found by each leg
+  X_FL = 111,    // ball<->link force on the link (3) + contact point rel. ball centre (3)
+  X_FOOT = 117,  // net contact force on left / right foot
+  X_Q = 123, X_QD = 141, X_TGT = 159,
+  X_SLOTS = 177
+};
+constexpr int WS_OBS_STRIDE = 55;  // odd stride: conflict-free transposes
+constexpr int WS_ACT_STRIDE = 19;
+constexpr int WS_LDS_FLOATS = X_SLOTS * WS_ENVS + WS_ENVS * WS_OBS_STRIDE;
+
+#define XS(slot) lds[(slot) * WS_ENVS + lane]
+
+BEZ_DEV void ws_barrier() { __syncthreads(); }
+
+BEZ_DEV void xs_store_sv(float* lds, int lane, int slot, SV v) {
+  XS(slot + 0) = v.a.x; XS(slot + 1) = v.a.y; XS(slot + 2) = v.a.z; XS(slot + 3) = v.l.x; XS(slot + 4) = v.l.y; XS(slot + 5) = v.l.z;
+}
+BEZ_DEV SV xs_load_sv(const float* lds, int lane, int slot) {
+  return mksv(mk(XS(slot + 0), XS(slot + 1), XS(slot + 2)), mk(XS(slot + 3), XS(slot + 4), XS(slot + 5)));
+}
+BEZ_DEV void xs_store_v3(float* lds, int lane, int slot, V3 v) { XS(slot) = v.x; XS(slot + 1) = v.y; XS(slot + 2) = v.z; }
+BEZ_DEV V3 xs_load_v3(const float* lds, int lane, int slot) { return mk(XS(slot), XS(slot + 1), XS(slot + 2)); }
+BEZ_DEV void xs_store_sym6(float* lds, int lane, int slot, const Sym6& I, SV p) {
+  const float* f = (const float*)&I;
+#pragma unroll
+  for (int i = 0; i < 21; ++i) XS(slot + i) = f[i];
+  xs_store_sv(lds, lane, slot + 21, p);
+}
+BEZ_DEV void xs_add_sym6(const float* lds, int lane, int slot, Sym6& I, SV& p) {
+  float* f = (float*)&I;
+#pragma unroll
+  for (int i = 0; i < 21; ++i) f[i] += XS(slot + i);
+  p = p + xs_load_sv(lds, lane, slot + 21);
+}
+
+// shared (read-only within a substep) root / ball state as the chain roles see it
+struct RootView { M3 E0; SV V0; float root_z; V3 bc, ball_lin, ball_ang; float ball_z; };
+BEZ_DEV RootView load_root_view(const float* lds, int lane) {
+  RootView R;
+  V3 pos = xs_load_v3(lds, lane, X_ROOT);
+  R.E0 = quat_to_mat(XS(X_ROOT + 3), XS(X_ROOT + 4), XS(X_ROOT + 5), XS(X_ROOT + 6));
+  R.V0 = mksv(xs_load_v3(lds, lane, X_ROOT + 10), xs_load_v3(lds, lane, X_ROOT + 7));
+  R.root_z = pos.z;
+  V3 bp = xs_load_v3(lds, lane, X_BALL);
+  R.bc = bp - pos; R.ball_z = bp.z;
+  R.ball_lin = xs_load_v3(lds, lane, X_BALL + 3); R.ball_ang = xs_load_v3(lds, lane, X_BALL + 6);
+  return R;
+}
+
+// per-joint data a chain keeps in registers between pass 2 and pass 3
+struct P3 { SV UD; float uD; SV S, cb; };
+// contact rows of a body: F = F0 - (B^T a_ang + C a_lin) for the body's spatial acceleration a
+struct BodyContact { M3 B; Sym3 C; V3 F0; };
+BEZ_DEV BodyContact body_contact_of(const Sym6& Kc, SV pc) { BodyContact b; b.B = Kc.B; b.C = Kc.C; b.F0 = -pc.l; return b; }
+BEZ_DEV V3 body_contact_force(const BodyContact& b, SV a) { return b.F0 - (mulT(b.B, a.a) + mul(b.C, a.l)); }
+
+template <int L>
+BEZ_DEV void ws_ground_points(const Params& P, float mu, float root_z, const M3& E, V3 r, SV V, Sym6& Kc, SV& pc) {
+#pragma unroll
+  for (int i = 0; i < BEZ_NPT; ++i) {
+    if (BEZ_PT_LINK[i] == L) {
+      V3 pl = mk((float)BEZ_PT_POS[i][0], (float)BEZ_PT_POS[i][1], (float)BEZ_PT_POS[i][2]);
+      V3 x = r + mul(E, pl);
+      (void)ground_contact(P, mu, x, root_z + x.z, V, Kc, pc);
+    }
+  }
+}
+
+// Per-role DR scalars
+struct ChainDyn { float mu; V3 g; };
+
+// ---- passes 1+2 of one serial chain.  Outputs the chain's articulated inertia/bias as seen by the torso (added to
+// IAo/pAo), the pass-3 operands p3[LEN], the contact rows of the chain-end link, and (legs) the ball/box candidate.
+template <int FIRST, int LEN, bool LEG>
+BEZ_DEV void ws_chain_pass1(const Params& P, const ChainDyn& D, const float* ms, const RootView& R, const float* q, const float* qd,
+                            LinkInertia* LI, SV* pAl, SV* Sl, SV* cbl, Sym6& Kc, SV& pc, BallSel& sel) {
+  M3 E = R.E0;
+  V3 r = mk(0, 0, 0);
+  SV V = R.V0;
+  static_for<LEN>([&](auto I) {
+    constexpr int i = decltype(I)::value;
+    constexpr int L = FIRST + i;
+    link_kinematics<L>(q[i], qd[i], E, r, V, Sl[i], cbl[i]);
+    link_inertia<L>(ms[i], D.g, E, r, V, LI[i], pAl[i]);
+    if constexpr (LEG && link_has_box(L)) test_box<link_box(L)>(E, r, R.bc, sel);
+  });
+  Kc = sym6zero(); pc = svzero();
+  ws_ground_points<FIRST + LEN - 1>(P, D.mu, R.root_z, E, r, V, Kc, pc);
+}
+
+template <int FIRST, int LEN, bool LEG>
+BEZ_DEV void ws_chain_pass2(const Params& P, const ChainDyn& D, const float* kps, const float* kds, const RootView& R, const BallBody& ball,
+                            const float* q, const float* qd, const float* target, const LinkInertia* LI, const SV* pAl, const SV* Sl,
+                            const SV* cbl, const Sym6& Kc, SV pc, bool mine, BallSel& sel, P3* p3, Sym6& IAo, SV& pAo) {
+  Sym6 IA = Kc;
+  SV pA = pc;
+  static_for<LEN>([&](auto I) {
+    constexpr int i = LEN - 1 - decltype(I)::value;
+    constexpr int L = FIRST + i;
+    add_link_inertia(IA, LI[i]);
+    pA = pA + pAl[i];
+    if constexpr (LEG && link_has_box(L)) {
+      if (mine && sel.link == L) {
+        // velocity of the selected link: V0 + sum of the joint velocities down to it
+        SV V = R.V0;
+        static_for<i + 1>([&](auto J) { constexpr int j = decltype(J)::value; V = V + Sl[j] * qd[j]; });
+        ball_link_contact(P, D.mu, R.ball_ang, R.ball_lin, ball, R.bc, V, sel);
+        if (sel.link == L) {  // still active after the approach-velocity test
+          add_point_stiffness(IA, sel.x, sel.A);
+          pA = pA - wrench_at(sel.x, sel.f0p);
+        }
+      }
+    }
+    SV U; float Dinv, u;
+    joint_terms<L>(P, kps[i], kds[i], q[i], qd[i], target[i], IA, pA, Sl[i], cbl[i], U, Dinv, u);
+    p3[i].UD = U * Dinv; p3[i].uD = u * Dinv; p3[i].S = Sl[i]; p3[i].cb = cbl[i];
+    add_outer(IA, U, -Dinv);
+    pA = pA + mul(IA, cbl[i]) + U * p3[i].uD;
+  });
+  add_to(IAo, IA);
+  pAo = pAo + pA;
+}
+
+// pass 3: joint accelerations, semi-implicit Euler with the velocity clamp; returns the chain-end acceleration
+template <int FIRST, int LEN, bool LEG>
+BEZ_DEV SV ws_chain_pass3(const Params& P, SV a0, const P3* p3, float* q, float* qd, bool mine, const BallSel& sel, V3& fl, V3& f_end_ball,
+                          float* cf_base, int n, bool keep, bool active) {
+  SV a = a0;
+  static_for<LEN>([&](auto I) {
+    constexpr int i = decltype(I)::value;
+    constexpr int L = FIRST + i;
+    SV ap = a + p3[i].cb;
+    float qdd = p3[i].uD - dot(p3[i].UD, ap);
+    a = ap + p3[i].S * qdd;
+    float v = fmaf(P.h, qdd, qd[i]);
+    v = fminf(fmaxf(v, -P.vel_limit), P.vel_limit);
+    qd[i] = v;
+    q[i] = fmaf(P.h, v, q[i]);
+    if constexpr (LEG && link_has_box(L)) {
+      V3 f = mk(0, 0, 0);
+      if (mine && sel.link == L) { fl = sel.f0p - mul(sel.A, point_of(a, sel.x)); f = fl; }
+      if (keep) {
+        if constexpr (i == LEN - 1) f_end_ball = f;
+        else if (active) {
+          constexpr int body = BEZ_LINK_BODY[L];
+          cf_base[(size_t)(body * 3 + 0) * n] = f.x; cf_base[(size_t)(body * 3 + 1) * n] = f.y; cf_base[(size_t)(body * 3 + 2) * n] = f.z;
+        }
+      }
+    }
+  });
+  return a;
+}
+
+// ------------------------------------------------------------------------------------------------ roles
+template <int FIRST, bool PRE, bool POST, bool DR>
+BEZ_DEV void ws_leg_role(const Params& P, float* lds, int lane, int e, bool active, int side) {
+  constexpr int LEN = 6;
+  const int n = P.n;
+  float* st = P.state;
+  float q[LEN], qd[LEN], target[LEN], kps[LEN], kds[LEN], ms[LEN];
+  ChainDyn D; D.mu = P.mu; D.g = mk(P.g[0], P.g[1], P.g[2]);
+#pragma unroll
+  for (int i = 0; i < LEN; ++i) {
+    constexpr int d0 = FIRST - 1;
+    q[i] = st[(size_t)(F_Q + d0 + i) * n + e]; qd[i] = st[(size_t)(F_QD + d0 + i) * n + e];
+    kps[i] = 1.f; kds[i] = 1.f; ms[i] = 1.f;
+    if (DR) {
+      if (P.dr_kp) kps[i] = P.dr_kp[(size_t)e * BEZ_ND + d0 + i];
+      if (P.dr_kd) kds[i] = P.dr_kd[(size_t)e * BEZ_ND + d0 + i];
+      if (P.dr_mass) ms[i] = P.dr_mass[(size_t)e * BEZ_NL + FIRST + i];
+    }
+  }
+  if (DR) {
+    if (P.dr_friction) D.mu = P.dr_friction[e];
+    if (P.dr_gravity) D.g = mk(P.dr_gravity[(size_t)e * 3], P.dr_gravity[(size_t)e * 3 + 1], P.dr_gravity[(size_t)e * 3 + 2]);
+  }
+  ws_barrier();  // B0: actions staged, root/ball published
+  if (PRE) {
+    const float* act = lds + X_SLOTS * WS_ENVS + lane * WS_ACT_STRIDE;
+#pragma unroll
+    for (int i = 0; i < LEN; ++i) {
+      constexpr int d0 = FIRST - 1;
+      float a = fminf(fmaxf(act[d0 + i], -P.clip), P.clip);
+      float t = a + (float)BEZ_DOF_DEFAULT[d0 + i];
+      target[i] = fmaxf(fminf(t, (float)BEZ_DOF_UPPER[d0 + i]), (float)BEZ_DOF_LOWER[d0 + i]);
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < LEN; ++i) target[i] = st[(size_t)(F_TARGET + FIRST - 1 + i) * n + e];
+  }
+  float* cf_base = st + (size_t)F_CF * n + e;
+  for (int s = 0; s < P.substeps; ++s) {
+    const bool keep = (s == P.substeps - 1);
+    RootView R = load_root_view(lds, lane);
+    LinkInertia LI[LEN]; SV pAl[LEN], Sl[LEN], cbl[LEN];
+    Sym6 Kc; SV pc;
+    BallSel sel;
+    sel.link = -1; sel.depth = 0.f; sel.n = sel.P = sel.f0p = sel.x = sel.xb = mk(0, 0, 0); sel.A = sym3zero();
+    ws_chain_pass1<FIRST, LEN, true>(P, D, ms, R, q, qd, LI, pAl, Sl, cbl, Kc, pc, sel);
+    XS(X_DEPTH + side) = sel.depth;
+    ws_barrier();  // B1
+    float other = XS(X_DEPTH + (1 - side));
+    bool mine = sel.link >= 0 && (sel.depth > other || (sel.depth == other && side == 0));
+    BallBody ball = ball_setup(P, D.mu, D.g, R.ball_z, R.ball_ang, R.ball_lin);
+    P3 p3[LEN];
+    Sym6 IA = sym6zero(); SV pA = svzero();
+    ws_chain_pass2<FIRST, LEN, true>(P, D, kps, kds, R, ball, q, qd, target, LI, pAl, Sl, cbl, Kc, pc, mine, sel, p3, IA, pA);
+    xs_store_sym6(lds, lane, X_IA + side * 27, IA, pA);
+    BodyContact bcn = body_contact_of(Kc, pc);
+    ws_barrier();  // B2
+    ws_barrier();  // B3: torso acceleration published
+    SV a0 = xs_load_sv(lds, lane, X_A0);
+    V3 fl = mk(0, 0, 0), fend = mk(0, 0, 0);
+    SV aend = ws_chain_pass3<FIRST, LEN, true>(P, a0, p3, q, qd, mine, sel, fl, fend, cf_base, n, keep, active);
+    if (mine && sel.link >= 0) { xs_store_v3(lds, lane, X_FL, fl); xs_store_v3(lds, lane, X_FL + 3, sel.xb); }
+    if (keep) xs_store_v3(lds, lane, X_FOOT + side * 3, fend + body_contact_force(bcn, aend));
+    ws_barrier();  // B4
+    ws_barrier();  // B5: new root/ball state published
+  }
+#pragma unroll
+  for (int i = 0; i < LEN; ++i) { XS(X_Q + FIRST - 1 + i) = q[i]; XS(X_QD + FIRST - 1 + i) = qd[i]; XS(X_TGT + FIRST - 1 + i) = target[i]; }
+  ws_barrier();  // B6
+}
+
+template <bool PRE, bool POST, bool DR>
+BEZ_DEV void ws_upper_role(const Params& P, float* lds, int lane, int e, bool active) {
+  // joints (dof index): head 0,1 (links 1,2); left arm 2,3 (links 3,4); right arm 10,11 (links 11,12)
+  const int n = P.n;
+  float* st = P.state;
+  constexpr int DOF[6] = {0, 1, 2, 3, 10, 11};
+  float q[6], qd[6], target[6], kps[6], kds[6], ms[6];
+  ChainDyn D; D.mu = P.mu; D.g = mk(P.g[0], P.g[1], P.g[2]);
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    q[i] = st[(size_t)(F_Q + DOF[i]) * n + e]; qd[i] = st[(size_t)(F_QD + DOF[i]) * n + e];
+    kps[i] = 1.f; kds[i] = 1.f; ms[i] = 1.f;
+    if (DR) {
+      if (P.dr_kp) kps[i] = P.dr_kp[(size_t)e * BEZ_ND + DOF[i]];
+      if (P.dr_kd) kds[i] = P.dr_kd[(size_t)e * BEZ_ND + DOF[i]];
+      if (P.dr_mass) ms[i] = P.dr_mass[(size_t)e * BEZ_NL + DOF[i] + 1];
+    }
+  }
+  if (DR) {
+    if (P.dr_friction) D.mu = P.dr_friction[e];
+    if (P.dr_gravity) D.g = mk(P.dr_gravity[(size_t)e * 3], P.dr_gravity[(size_t)e * 3 + 1], P.dr_gravity[(size_t)e * 3 + 2]);
+  }
+  ws_barrier();  // B0
+  if (PRE) {
+    const float* act = lds + X_SLOTS * WS_ENVS + lane * WS_ACT_STRIDE;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      float a = fminf(fmaxf(act[DOF[i]], -P.clip), P.clip);
+      if (DOF[i] < 2) a = 0.f;  // head frozen (kick_env.py:414)
+      float t = a + (float)BEZ_DOF_DEFAULT[DOF[i]];
+      target[i] = fmaxf(fminf(t, (float)BEZ_DOF_UPPER[DOF[i]]), (float)BEZ_DOF_LOWER[DOF[i]]);
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 6; ++i) target[i] = st[(size_t)(F_TARGET + DOF[i]) * n + e];
+  }
+  float* cf_base = st + (size_t)F_CF * n + e;
+  BallSel nosel; nosel.link = -1; nosel.depth = 0.f; nosel.n = nosel.P = nosel.f0p = nosel.x = nosel.xb = mk(0, 0, 0); nosel.A = sym3zero();
+  BallBody noball; noball.ground = false;
+  for (int s = 0; s < P.substeps; ++s) {
+    const bool keep = (s == P.substeps - 1);
+    RootView R = load_root_view(lds, lane);
+    P3 p3[6];
+    BodyContact bcn[3];
+    Sym6 IA = sym6zero(); SV pA = svzero();
+    {  // three 2-link chains, one after the other
+      LinkInertia LI[2]; SV pAl[2], Sl[2], cbl[2]; Sym6 Kc; SV pc;
+      ws_chain_pass1<1, 2, false>(P, D, ms + 0, R, q + 0, qd + 0, LI, pAl, Sl, cbl, Kc, pc, nosel);
+      ws_chain_pass2<1, 2, false>(P, D, kps + 0, kds + 0, R, noball, q + 0, qd + 0, target + 0, LI, pAl, Sl, cbl, Kc, pc, false, nosel, p3 + 0, IA, pA);
+      bcn[0] = body_contact_of(Kc, pc);
+      ws_chain_pass1<3, 2, false>(P, D, ms + 2, R, q + 2, qd + 2, LI, pAl, Sl, cbl, Kc, pc, nosel);
+      ws_chain_pass2<3, 2, false>(P, D, kps + 2, kds + 2, R, noball, q + 2, qd + 2, target + 2, LI, pAl, Sl, cbl, Kc, pc, false, nosel, p3 + 2, IA, pA);
+      bcn[1] = body_contact_of(Kc, pc);
+      ws_chain_pass1<11, 2, false>(P, D, ms + 4, R, q + 4, qd + 4, LI, pAl, Sl, cbl, Kc, pc, nosel);
+      ws_chain_pass2<11, 2, false>(P, D, kps + 4, kds + 4, R, noball, q + 4, qd + 4, target + 4, LI, pAl, Sl, cbl, Kc, pc, false, nosel, p3 + 4, IA, pA);
+      bcn[2] = body_contact_of(Kc, pc);
+    }
+    ws_barrier();  // B1
+    xs_store_sym6(lds, lane, X_IA + 2 * 27, IA, pA);
+    ws_barrier();  // B2
+    ws_barrier();  // B3
+    SV a0 = xs_load_sv(lds, lane, X_A0);
+    V3 fl = mk(0, 0, 0), fend = mk(0, 0, 0);
+    SV ae0 = ws_chain_pass3<1, 2, false>(P, a0, p3 + 0, q + 0, qd + 0, false, nosel, fl, fend, cf_base, n, keep, active);
+    SV ae1 = ws_chain_pass3<3, 2, false>(P, a0, p3 + 2, q + 2, qd + 2, false, nosel, fl, fend, cf_base, n, keep, active);
+    SV ae2 = ws_chain_pass3<11, 2, false>(P, a0, p3 + 4, q + 4, qd + 4, false, nosel, fl, fend, cf_base, n, keep, active);
+    if (keep && active) {
+      V3 f0 = body_contact_force(bcn[0], ae0), f1 = body_contact_force(bcn[1], ae1), f2 = body_contact_force(bcn[2], ae2);
+      constexpr int b0 = BEZ_LINK_BODY[2], b1 = BEZ_LINK_BODY[4], b2 = BEZ_LINK_BODY[12];
+      cf_base[(size_t)(b0 * 3 + 0) * n] = f0.x; cf_base[(size_t)(b0 * 3 + 1) * n] = f0.y; cf_base[(size_t)(b0 * 3 + 2) * n] = f0.z;
+      cf_base[(size_t)(b1 * 3 + 0) * n] = f1.x; cf_base[(size_t)(b1 * 3 + 1) * n] = f1.y; cf_base[(size_t)(b1 * 3 + 2) * n] = f1.z;
+      cf_base[(size_t)(b2 * 3 + 0) * n] = f2.x; cf_base[(size_t)(b2 * 3 + 1) * n] = f2.y; cf_base[(size_t)(b2 * 3 + 2) * n] = f2.z;
+    }
+    ws_barrier();  // B4
+    ws_barrier();  // B5
+  }
+#pragma unroll
+  for (int i = 0; i < 6; ++i) { XS(X_Q + DOF[i]) = q[i]; XS(X_QD + DOF[i]) = qd[i]; XS(X_TGT + DOF[i]) = target[i]; }
+  ws_barrier();  // B6
+}
+
+template <bool PRE, bool POST, bool DR>
+BEZ_DEV void ws_root_role(const Params& P, float* lds, int lane, int e, bool active) {
+  const int n = P.n;
+  float* st = P.state;
+  auto ld = [&](int f) { return st[(size_t)f * n + e]; };
+  V3 root_pos = mk(ld(F_ROOT_POS), ld(F_ROOT_POS + 1), ld(F_ROOT_POS + 2));
+  float rq[4] = {ld(F_ROOT_QUAT), ld(F_ROOT_QUAT + 1), ld(F_ROOT_QUAT + 2), ld(F_ROOT_QUAT + 3)};
+  V3 root_lin = mk(ld(F_ROOT_LIN), ld(F_ROOT_LIN + 1), ld(F_ROOT_LIN + 2));
+  V3 root_ang = mk(ld(F_ROOT_ANG), ld(F_ROOT_ANG + 1), ld(F_ROOT_ANG + 2));
+  V3 ball_pos = mk(ld(F_BALL_POS), ld(F_BALL_POS + 1), ld(F_BALL_POS + 2));
+  float bq[4] = {ld(F_BALL_QUAT), ld(F_BALL_QUAT + 1), ld(F_BALL_QUAT + 2), ld(F_BALL_QUAT + 3)};
+  V3 ball_lin = mk(ld(F_BALL_LIN), ld(F_BALL_LIN + 1), ld(F_BALL_LIN + 2));
+  V3 ball_ang = mk(ld(F_BALL_ANG), ld(F_BALL_ANG + 1), ld(F_BALL_ANG + 2));
+  ChainDyn D; D.mu = P.mu; D.g = mk(P.g[0], P.g[1], P.g[2]);
+  float ms0 = 1.f;
+  if (DR) {
+    if (P.dr_friction) D.mu = P.dr_friction[e];
+    if (P.dr_gravity) D.g = mk(P.dr_gravity[(size_t)e * 3], P.dr_gravity[(size_t)e * 3 + 1], P.dr_gravity[(size_t)e * 3 + 2]);
+    if (P.dr_mass) ms0 = P.dr_mass[(size_t)e * BEZ_NL];
+  }
+  auto publish = [&]() {
+    xs_store_v3(lds, lane, X_ROOT, root_pos);
+    XS(X_ROOT + 3) = rq[0]; XS(X_ROOT + 4) = rq[1]; XS(X_ROOT + 5) = rq[2]; XS(X_ROOT + 6) = rq[3];
+    xs_store_v3(lds, lane, X_ROOT + 7, root_lin); xs_store_v3(lds, lane, X_ROOT + 10, root_ang);
+    xs_store_v3(lds, lane, X_BALL, ball_pos); xs_store_v3(lds, lane, X_BALL + 3, ball_lin); xs_store_v3(lds, lane, X_BALL + 6, ball_ang);
+  };
+  publish();
+  ws_barrier();  // B0
+  float* cf_base = st + (size_t)F_CF * n + e;
+  for (int s = 0; s < P.substeps; ++s) {
+    const bool keep = (s == P.substeps - 1);
+    const M3 E0 = quat_to_mat(rq[0], rq[1], rq[2], rq[3]);
+    const SV V0 = mksv(root_ang, root_lin);
+    xs_store_v3(lds, lane, X_FL, mk(0, 0, 0)); xs_store_v3(lds, lane, X_FL + 3, mk(0, 0, 0));
+    Sym6 IA0 = sym6zero(); SV pA0;
+    LinkInertia I0;
+    link_inertia<0>(ms0, D.g, E0, mk(0, 0, 0), V0, I0, pA0);
+    Sym6 Kc = sym6zero(); SV pc = svzero();
+    ws_ground_points<0>(P, D.mu, root_pos.z, E0, mk(0, 0, 0), V0, Kc, pc);
+    BodyContact bc0 = body_contact_of(Kc, pc);
+    add_link_inertia(IA0, I0);
+    add_to(IA0, Kc); pA0 = pA0 + pc;
+    BallBody ball = ball_setup(P, D.mu, D.g, ball_pos.z, ball_ang, ball_lin);
+    ws_barrier();  // B1
+    ws_barrier();  // B2: chain contributions published
+    xs_add_sym6(lds, lane, X_IA + 0 * 27, IA0, pA0);
+    xs_add_sym6(lds, lane, X_IA + 1 * 27, IA0, pA0);
+    xs_add_sym6(lds, lane, X_IA + 2 * 27, IA0, pA0);
+    SV a0 = solve_spd6(IA0, svzero() - pA0);
+    xs_store_sv(lds, lane, X_A0, a0);
+    ws_barrier();  // B3
+    if (keep && active) { V3 f = body_contact_force(bc0, a0); cf_base[0] = f.x; cf_base[(size_t)1 * n] = f.y; cf_base[(size_t)2 * n] = f.z; }
+    V3 vdot = a0.l + cross(root_ang, root_lin);
+    root_ang = fma3(a0.a, P.h, root_ang);
+    root_lin = fma3(vdot, P.h, root_lin);
+    root_pos = fma3(root_lin, P.h, root_pos);
+    quat_integrate(rq, root_ang, P.h);
+    ws_barrier();  // B4: ball<->link force published
+    V3 fl = xs_load_v3(lds, lane, X_FL), xb = xs_load_v3(lds, lane, X_FL + 3);
+    SV ab = ball_minv(ball, svzero() - ball.pb - wrench_at(xb, fl));
+    if (keep && active) {
+      V3 fb = -fl;
+      if (ball.ground) fb = fb + hit_force(P, ball.ghit, ab);
+      constexpr int bb = BEZ_NBE - 1;
+      cf_base[(size_t)(bb * 3 + 0) * n] = fb.x; cf_base[(size_t)(bb * 3 + 1) * n] = fb.y; cf_base[(size_t)(bb * 3 + 2) * n] = fb.z;
+    }
+    float damp = fmaxf(1.0f - P.h * P.ball_damp, 0.f);
+    ball_lin = fma3(ab.l, P.h, ball_lin);
+    ball_ang = fma3(ab.a, P.h, ball_ang) * damp;
+    ball_pos = fma3(ball_lin, P.h, ball_pos);
+    quat_integrate(bq, ball_ang, P.h);
+    publish();
+    ws_barrier();  // B5
+  }
+  ws_barrier();  // B6: joint state / targets / foot forces of the other roles are in LDS
+  EnvState S;
+  S.root_pos = root_pos; S.root_lin = root_lin; S.root_ang = root_ang; S.ball_pos = ball_pos; S.ball_lin = ball_lin; S.ball_ang = ball_ang;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { S.rq[i] = rq[i]; S.bq[i] = bq[i]; }
+  float target[BEZ_ND];
+#pragma unroll
+  for (int j = 0; j < BEZ_ND; ++j) { S.q[j] = XS(X_Q + j); S.qd[j] = XS(X_QD + j); target[j] = XS(X_TGT + j); }
+  CfOut co;
+  co.base = cf_base; co.n = n;
+  co.lf = xs_load_v3(lds, lane, X_FOOT); co.rf = xs_load_v3(lds, lane, X_FOOT + 3);
+  float* obs_row = lds + X_SLOTS * WS_ENVS + lane * WS_OBS_STRIDE;
+  if (POST) {
+    int64_t progress = P.progress[e], reset = P.reset[e];
+    uint32_t episode = P.episode[e];
+    int64_t timeout = (progress >= (int64_t)(P.max_len - 1)) ? 1 : 0;  // vec_task.py:331-332
+    progress += 1;                                                    // kick_env.py:429
+    if (reset != 0) {                                                 // kick_env.py:433-435
+      if (active) { env_reset(P, S, target, co, episode, P.env_off + e); P.episode[e] = episode; }
+      progress = 0; reset = 0;
+    }
+    float prev[3], feet[8], obs[BEZ_NUM_OBS], rew;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) prev[i] = st[(size_t)(F_PREV + i) * n + e];
+    env_observe_reward(P, S, co, prev, feet, obs, rew, reset, progress);
+#pragma unroll
+    for (int i = 0; i < BEZ_NUM_OBS; ++i) obs_row[i] = obs[i];
+    if (active) {
+#pragma unroll
+      for (int i = 0; i < 3; ++i) st[(size_t)(F_PREV + i) * n + e] = prev[i];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) st[(size_t)(F_FEET + i) * n + e] = feet[i];
+      P.rew[e] = rew; P.reset[e] = reset; P.progress[e] = progress; P.timeout[e] = timeout;
+    }
+  }
+  if (active) {
+    store_state(st, n, e, S);
+    cf_store(co, BEZ_LFOOT_BODY, co.lf);
+    cf_store(co, BEZ_RFOOT_BODY, co.rf);
+#pragma unroll
+    for (int j = 0; j < BEZ_ND; ++j) st[(size_t)(F_TARGET + j) * n + e] = target[j];
+  }
+}
+
+// ---- the kernel.  grid = ceil(N / 64) workgroups of 256 threads.
+template <bool PRE, bool POST, bool DR>
+__global__ __launch_bounds__(WS_BLOCK) void step_kernel_ws(Params P) {
+  __shared__ float lds[WS_LDS_FLOATS];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int role = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int env0 = blockIdx.x * WS_ENVS;
+  const int nloc = min(WS_ENVS, P.n - env0);
+  const bool active = lane < nloc;
+  const int e = env0 + (active ? lane : 0);  // inactive lanes shadow env0 (loads only; every store is guarded)
+  if (PRE) {
+    // coalesced stage of this workgroup's contiguous (nloc,18) action block, transposed to [lane][19]
+    float* act = lds + X_SLOTS * WS_ENVS;
+    const float* src = P.actions + (size_t)env0 * BEZ_ND;
+    for (int i = tid; i < nloc * BEZ_ND; i += WS_BLOCK) act[(i / BEZ_ND) * WS_ACT_STRIDE + (i % BEZ_ND)] = src[i];
+  }
+  if (role == 0) ws_leg_role<5, PRE, POST, DR>(P, lds, lane, e, active, 0);
+  else if (role == 1) ws_leg_role<13, PRE, POST, DR>(P, lds, lane, e, active, 1);
+  else if (role == 2) ws_upper_role<PRE, POST, DR>(P, lds, lane, e, active);
+  else ws_root_role<PRE, POST, DR>(P, lds, lane, e, active);
+  if (POST) {
+    ws_barrier();  // observation rows staged in LDS by role 3
+    const float* rows = lds + X_SLOTS * WS_ENVS;
+    float* dst = P.obs + (size_t)env0 * BEZ_NUM_OBS;
+    for (int i = tid; i < nloc * BEZ_NUM_OBS; i += WS_BLOCK) dst[i] = rows[(i / BEZ_NUM_OBS) * WS_OBS_STRIDE + (i % BEZ_NUM_OBS)];
+  }
+}
+
+#undef XS
+}  // namespace bez

@@ -142,8 +142,8 @@ BEZ_DEV Hit ground_contact(const Params& P, float mu, V3 x, float z, SV V, Sym6&
     float fn0 = fmaf(P.kn, d, -kd * vp.z);
     if (fn0 > 0.f) {
       float kn = P.h * kd;
-      float vt = sqrtf(fmaf(vp.x, vp.x, vp.y * vp.y));
-      float ct = fminf(mu * fn0 / fmaxf(vt, P.veps), P.ct);
+      float vt = fsqrt(fmaf(vp.x, vp.x, vp.y * vp.y));
+      float ct = fminf(mu * fn0 * frcp(fmaxf(vt, P.veps)), P.ct);
       float kt = P.h * ct;
       Sym3 K = sym3zero();
       K.xx = kt; K.yy = kt; K.zz = kn;
@@ -171,6 +171,13 @@ BEZ_DEV Hit lds_load_hit(const float* lds, int lane, int idx) {
   return h;
 }
 
+// ---- net contact force output (Isaac NET_CONTACT_FORCE rows).  Only the two foot rows are consumed by the
+// observation (kick_env.py:193-196), so only those stay in registers; every other row goes straight to HBM.
+struct CfOut { float* base; int n; V3 lf, rf; };  // base = &state[F_CF * n + env]
+BEZ_DEV void cf_store(const CfOut& c, int body, V3 f) {
+  c.base[(size_t)(body * 3 + 0) * c.n] = f.x; c.base[(size_t)(body * 3 + 1) * c.n] = f.y; c.base[(size_t)(body * 3 + 2) * c.n] = f.z;
+}
+
 // ---- ball <-> leg-box contact bookkeeping (deepest penetration only)
 struct BallSel {
   int link;      // -1 none
@@ -195,10 +202,11 @@ BEZ_DEV void test_box(const M3& E, V3 r, V3 bc, BallSel& sel) {
   V3 nl; float depth;
   if (!inside) {
     V3 dlt = ql - cp;
-    float dist = sqrtf(dot(dlt, dlt));
+    float d2 = dot(dlt, dlt);
+    float dist = fsqrt(d2);
     depth = R - dist;
     if (!(depth > 0.f)) return;
-    nl = dlt * (1.0f / dist);
+    nl = dlt * frsq(d2);
   } else {
     float dx = he.x - fabsf(ql.x), dy = he.y - fabsf(ql.y), dz = he.z - fabsf(ql.z);
     int ax = 0; float md = dx;
@@ -233,36 +241,36 @@ BEZ_DEV SV ball_minv(const BallBody& B, SV f) {
   a.a.x = fmaf(B.b11, f.a.x, B.b12 * f.l.y); a.l.y = fmaf(B.b12, f.a.x, B.b22 * f.l.y);
   return a;
 }
-BEZ_DEV BallBody ball_setup(const Params& P, const EnvDyn& D, const EnvState& S) {
+BEZ_DEV BallBody ball_setup(const Params& P, float mu, V3 g, float ball_z, V3 ball_ang, V3 ball_lin) {
   const float R = (float)BEZ_BALL_RADIUS, mb = (float)BEZ_BALL_MASS, Ib = (float)BEZ_BALL_INERTIA;
   BallBody B;
-  B.pb = mksv(mk(0, 0, 0), D.g * (-mb));
+  B.pb = mksv(mk(0, 0, 0), g * (-mb));
   Sym6 dummy = sym6zero();
-  SV Vb = mksv(S.ball_ang, S.ball_lin);
-  B.ghit = ground_contact(P, D.mu, mk(0, 0, -R), S.ball_pos.z - R, Vb, dummy, B.pb);
+  SV Vb = mksv(ball_ang, ball_lin);
+  B.ghit = ground_contact(P, mu, mk(0, 0, -R), ball_z - R, Vb, dummy, B.pb);
   B.ground = B.ghit.kn > 0.f;
   float kt = P.h * B.ghit.ct, kn = B.ghit.kn;
   // det = (Ib + kt R^2)(m + kt) - kt^2 R^2 = Ib m + Ib kt + m kt R^2  (expanded: no cancellation)
   float p = fmaf(kt, R * R, Ib), s = mb + kt, o = kt * R;
-  float idet = 1.0f / fmaf(Ib, mb, fmaf(Ib, kt, mb * kt * R * R));
+  float idet = frcp(fmaf(Ib, mb, fmaf(Ib, kt, mb * kt * R * R)));
   B.a11 = s * idet; B.a22 = p * idet; B.a12 = o * idet;    // inverse of [[p,-o],[-o,s]] = 1/det [[s,o],[o,p]]
   B.b11 = s * idet; B.b22 = p * idet; B.b12 = -o * idet;   // inverse of [[p, o],[ o,s]] = 1/det [[s,-o],[-o,p]]
-  B.i_wz = 1.0f / Ib; B.i_vz = 1.0f / (mb + kn);
+  B.i_wz = 1.0f / Ib; B.i_vz = frcp(mb + kn);
   return B;
 }
 
 // Evaluate the ball<->link contact when the selected link is reached in pass 1 (needs the link velocity).
-BEZ_DEV void ball_link_contact(const Params& P, const EnvDyn& D, const EnvState& S, const BallBody& B, V3 bc, SV Vl, BallSel& sel) {
+BEZ_DEV void ball_link_contact(const Params& P, float mu, V3 ball_ang, V3 ball_lin, const BallBody& B, V3 bc, SV Vl, BallSel& sel) {
   V3 x = sel.P, xb = sel.P - bc, n = sel.n;
-  SV Vb = mksv(S.ball_ang, S.ball_lin);
+  SV Vb = mksv(ball_ang, ball_lin);
   V3 u = point_of(Vl, x) - point_of(Vb, xb);
   float un = dot(u, n);
   float kd = fmaf(P.h, P.kn, P.cn);
   float fmag = fmaf(P.kn, sel.depth, kd * un);
   if (!(fmag > 0.f)) { sel.link = -1; return; }
   V3 ut = u - n * un;
-  float vt = sqrtf(dot(ut, ut));
-  float ct = fminf(D.mu * fmag / fmaxf(vt, P.veps), P.ct);
+  float vt = fsqrt(dot(ut, ut));
+  float ct = fminf(mu * fmag * frcp(fmaxf(vt, P.veps)), P.ct);
   float kn = P.h * kd, kt = P.h * ct;
   V3 f0 = -(n * fmag + ut * ct);
   Sym3 K;  // kn nn^T + kt (1 - nn^T)
@@ -299,7 +307,7 @@ BEZ_DEV void link_kinematics(float q, float qd, M3& E, V3& r, SV& V, SV& S, SV& 
   if (ty != 0.f) r = fma3(col(E, 1), ty, r);
   if (tz != 0.f) r = fma3(col(E, 2), tz, r);
   float s, c;
-  sincosf(sg * q, &s, &c);
+  fsincos(sg * q, &s, &c);
   E = rotate_about(E, ax, s, c);
   S = mksv(a, cross(r, a));
   SV vj = S * qd;
@@ -315,15 +323,14 @@ BEZ_DEV void link_frame_only(float q, M3& E, V3& r) {
   if (ty != 0.f) r = fma3(col(E, 1), ty, r);
   if (tz != 0.f) r = fma3(col(E, 2), tz, r);
   float s, c;
-  sincosf(sg * q, &s, &c);
+  fsincos(sg * q, &s, &c);
   E = rotate_about(E, ax, s, c);
 }
 
 // rigid-body inertia of link L about O in compact form + its bias force (velocity product - gravity)
 struct LinkInertia { float m; V3 h; Sym3 Ibar; };
 template <int L>
-BEZ_DEV void link_inertia(const EnvDyn& D, const M3& E, V3 r, SV V, LinkInertia& I, SV& pA) {
-  const float ms = D.mass_scale[L];
+BEZ_DEV void link_inertia(float ms, V3 g, const M3& E, V3 r, SV V, LinkInertia& I, SV& pA) {
   const float m = (float)BEZ_LINK_MASS[L] * ms;
   const V3 cl = mk((float)BEZ_LINK_COM[L][0], (float)BEZ_LINK_COM[L][1], (float)BEZ_LINK_COM[L][2]);
   Sym3 Il;
@@ -338,7 +345,7 @@ BEZ_DEV void link_inertia(const EnvDyn& D, const M3& E, V3 r, SV V, LinkInertia&
   // momentum  I V = [Ibar w + h x v ; m v - h x w]
   V3 ha = mul(I.Ibar, V.a) + cross(I.h, V.l);
   V3 hl = V.l * m - cross(I.h, V.a);
-  pA = crf(V, mksv(ha, hl)) - mksv(cross(I.h, D.g), D.g * m);
+  pA = crf(V, mksv(ha, hl)) - mksv(cross(I.h, g), g * m);
 }
 BEZ_DEV void add_link_inertia(Sym6& IA, const LinkInertia& I) {
   add_to(IA.A, I.Ibar);
@@ -349,14 +356,14 @@ BEZ_DEV void add_link_inertia(Sym6& IA, const LinkInertia& I) {
 
 // ground points of link L (compile-time filtered), using the link's frame and velocity
 template <int L>
-BEZ_DEV void link_ground_points(const Params& P, const EnvDyn& D, float root_z, const M3& E, V3 r, SV V, Sym6& IA, SV& pA,
+BEZ_DEV void link_ground_points(const Params& P, float mu, float root_z, const M3& E, V3 r, SV V, Sym6& IA, SV& pA,
                                 float* lds, int lane, bool keep) {
 #pragma unroll
   for (int i = 0; i < BEZ_NPT; ++i) {
     if (BEZ_PT_LINK[i] == L) {
       V3 pl = mk((float)BEZ_PT_POS[i][0], (float)BEZ_PT_POS[i][1], (float)BEZ_PT_POS[i][2]);
       V3 x = r + mul(E, pl);
-      Hit hit = ground_contact(P, D.mu, x, root_z + x.z, V, IA, pA);
+      Hit hit = ground_contact(P, mu, x, root_z + x.z, V, IA, pA);
       if (keep) lds_store_hit(lds, lane, i, hit);
     }
   }
@@ -376,15 +383,15 @@ BEZ_DEV V3 link_ground_forces(const Params& P, SV acc, const float* lds, int lan
 
 // joint drive / friction / limit terms and the ABA joint-space quantities for DOF d = L-1
 template <int L>
-BEZ_DEV void joint_terms(const Params& P, const EnvDyn& D, float q, float qd, float target, const Sym6& IA, SV pA, SV S, SV cb,
+BEZ_DEV void joint_terms(const Params& P, float kp_scale, float kd_scale, float q, float qd, float target, const Sym6& IA, SV pA, SV S, SV cb,
                          SV& U, float& Dinv, float& u) {
   constexpr int d = L - 1;
   U = mul(IA, S);
   float J = dot(S, U) + P.armature;
-  float kp = P.kp * D.kp_scale[d], kdm = P.kd * D.kd_scale[d];
+  float kp = P.kp * kp_scale, kdm = P.kd * kd_scale;
   float tau_pd0 = fmaf(kp, target - q - P.h * qd, -kdm * qd);
   float k_pd = fmaf(P.h * P.h, kp, P.h * kdm);
-  float cf = P.jfric / fmaxf(fabsf(qd), P.jf_veps);
+  float cf = P.jfric * frcp(fmaxf(fabsf(qd), P.jf_veps));
   float k_f = P.h * cf, tau_f0 = -cf * qd;
   float k_l = 0.f, tau_l0 = 0.f;
   constexpr float lo = (float)BEZ_DOF_LOWER[d], hi = (float)BEZ_DOF_UPPER[d];
@@ -392,13 +399,13 @@ BEZ_DEV void joint_terms(const Params& P, const EnvDyn& D, float q, float qd, fl
   else if (q > hi) { tau_l0 = fmaf(P.lim_k, hi - q - P.h * qd, -P.lim_d * qd); k_l = fmaf(P.h * P.h, P.lim_k, P.h * P.lim_d); }
   float sp = dot(S, pA);
   float bias = sp + dot(U, cb);
-  float qdd_est = (tau_pd0 + tau_f0 + tau_l0 - bias) / (J + k_pd + k_f + k_l);
+  float qdd_est = (tau_pd0 + tau_f0 + tau_l0 - bias) * frcp(J + k_pd + k_f + k_l);
   float tau_drive = fmaf(-k_pd, qdd_est, tau_pd0);
   float tau, Dj;
   if (tau_drive > P.effort) { tau = P.effort + tau_f0 + tau_l0; Dj = J + k_f + k_l; }
   else if (tau_drive < -P.effort) { tau = -P.effort + tau_f0 + tau_l0; Dj = J + k_f + k_l; }
   else { tau = tau_pd0 + tau_f0 + tau_l0; Dj = J + k_pd + k_f + k_l; }
-  Dinv = 1.0f / Dj;
+  Dinv = frcp(Dj);
   u = tau - sp;
 }
 
@@ -423,15 +430,15 @@ BEZ_DEV void chain_up(const Params& P, const EnvDyn& D, const EnvState& S, const
     constexpr int i = decltype(I)::value;
     constexpr int L = FIRST + i;
     link_kinematics<L>(S.q[L - 1], S.qd[L - 1], E, r, V, Sl[i], cbl[i]);
-    link_inertia<L>(D, E, r, V, LI[i], pAl[i]);
+    link_inertia<L>(D.mass_scale[L], D.g, E, r, V, LI[i], pAl[i]);
     if constexpr (link_has_box(L)) {
-      if (sel.link == L) ball_link_contact(P, D, S, ball, bc, V, sel);
+      if (sel.link == L) ball_link_contact(P, D.mu, S.ball_ang, S.ball_lin, ball, bc, V, sel);
     }
   });
   // tip: ground points of the chain-end link (E, r, V are still the tip's)
   Sym6 IA = sym6zero();
   SV pA = svzero();
-  link_ground_points<FIRST + LEN - 1>(P, D, S.root_pos.z, E, r, V, IA, pA, lds, lane, keep);
+  link_ground_points<FIRST + LEN - 1>(P, D.mu, S.root_pos.z, E, r, V, IA, pA, lds, lane, keep);
   // pass 2: tip -> root
   static_for<LEN>([&](auto I) {
     constexpr int i = LEN - 1 - decltype(I)::value;
@@ -445,7 +452,7 @@ BEZ_DEV void chain_up(const Params& P, const EnvDyn& D, const EnvState& S, const
       }
     }
     SV U; float Dinv, u;
-    joint_terms<L>(P, D, S.q[L - 1], S.qd[L - 1], target[L - 1], IA, pA, Sl[i], cbl[i], U, Dinv, u);
+    joint_terms<L>(P, D.kp_scale[L - 1], D.kd_scale[L - 1], S.q[L - 1], S.qd[L - 1], target[L - 1], IA, pA, Sl[i], cbl[i], U, Dinv, u);
     SV UD = U * Dinv;
     float uD = u * Dinv;
     float* p3 = lds + (size_t)(LDS_P3 + (L - 1) * P3_STRIDE) * BLOCK + lane;
@@ -464,8 +471,10 @@ BEZ_DEV void chain_up(const Params& P, const EnvDyn& D, const EnvState& S, const
 // ---- pass 3 of one chain: joint accelerations from the torso acceleration; integrates the joints in
 // place (semi-implicit Euler + velocity clamp) and resolves contact forces on the way.
 template <int FIRST, int LEN>
-BEZ_DEV void chain_down(const Params& P, EnvState& S, SV a0, BallSel& sel, V3& ball_link_force, float* cf, const float* lds, int lane, bool keep) {
+BEZ_DEV void chain_down(const Params& P, EnvState& S, SV a0, BallSel& sel, V3& ball_link_force, CfOut& co, const float* lds, int lane, bool keep) {
   SV a = a0;
+  constexpr int Lend = FIRST + LEN - 1;
+  V3 fend = mk(0, 0, 0);  // ball force on the chain-end link (a foot), if it is the selected box
   static_for<LEN>([&](auto I) {
     constexpr int i = decltype(I)::value;
     constexpr int L = FIRST + i;
@@ -482,20 +491,22 @@ BEZ_DEV void chain_down(const Params& P, EnvState& S, SV a0, BallSel& sel, V3& b
     S.qd[L - 1] = v;
     S.q[L - 1] = fmaf(P.h, v, S.q[L - 1]);
     if constexpr (link_has_box(L)) {
+      V3 f = mk(0, 0, 0);
       if (sel.link == L) {
         ball_link_force = sel.f0p - mul(sel.A, point_of(a, sel.x));
-        if (keep) {
-          constexpr int body = BEZ_LINK_BODY[L];
-          cf[body * 3 + 0] += ball_link_force.x; cf[body * 3 + 1] += ball_link_force.y; cf[body * 3 + 2] += ball_link_force.z;
-        }
+        f = ball_link_force;
+      }
+      if (keep) {
+        if constexpr (L == Lend) fend = f;
+        else cf_store(co, BEZ_LINK_BODY[L], f);
       }
     }
   });
   if (keep) {
-    constexpr int Lend = FIRST + LEN - 1;
-    constexpr int body = BEZ_LINK_BODY[Lend];
-    V3 f = link_ground_forces<Lend>(P, a, lds, lane);
-    cf[body * 3 + 0] += f.x; cf[body * 3 + 1] += f.y; cf[body * 3 + 2] += f.z;
+    V3 f = fend + link_ground_forces<Lend>(P, a, lds, lane);
+    if constexpr (Lend == BEZ_LFOOT_LINK) co.lf = f;
+    else if constexpr (Lend == BEZ_RFOOT_LINK) co.rf = f;
+    else cf_store(co, BEZ_LINK_BODY[Lend], f);
   }
 }
 
@@ -507,13 +518,13 @@ BEZ_DEV void quat_integrate(float q[4], V3 w, float h) {
   float dw = -fmaf(w.x, x, fmaf(w.y, y, w.z * z));
   float hh = 0.5f * h;
   x = fmaf(hh, dx, x); y = fmaf(hh, dy, y); z = fmaf(hh, dz, z); s = fmaf(hh, dw, s);
-  float n = 1.0f / sqrtf(fmaf(x, x, fmaf(y, y, fmaf(z, z, s * s))));
+  float n = frsq(fmaf(x, x, fmaf(y, y, fmaf(z, z, s * s))));
   q[0] = x * n; q[1] = y * n; q[2] = z * n; q[3] = s * n;
 }
 
-// ---- one substep of the articulated-body dynamics for this lane's env.  `cf` (22x3, registers/scratch)
-// receives the net contact force per body when `keep` (last substep only).
-BEZ_DEV void substep(const Params& P, const EnvDyn& D, EnvState& S, const float* target, float* cf, float* lds, int lane, bool keep) {
+// ---- one substep of the articulated-body dynamics for this lane's env.  When `keep` (last substep only) the
+// net contact force per body is produced: foot rows in `co`, all other rows stored to HBM.
+BEZ_DEV void substep(const Params& P, const EnvDyn& D, EnvState& S, const float* target, CfOut& co, float* lds, int lane, bool keep) {
   const M3 E0 = quat_to_mat(S.rq[0], S.rq[1], S.rq[2], S.rq[3]);
   const SV V0 = mksv(S.root_ang, S.root_lin);
   const V3 bc = S.ball_pos - S.root_pos;  // ball centre rel. O
@@ -535,15 +546,15 @@ BEZ_DEV void substep(const Params& P, const EnvDyn& D, EnvState& S, const float*
     });
   }
   // (b) ball free body with its ground contact
-  BallBody ball = ball_setup(P, D, S);
+  BallBody ball = ball_setup(P, D.mu, D.g, S.ball_pos.z, S.ball_ang, S.ball_lin);
   // (c) torso: own inertia + guard points, then the five chains
   Sym6 IA0 = sym6zero();
   SV pA0;
   {
     LinkInertia I0;
-    link_inertia<0>(D, E0, mk(0, 0, 0), V0, I0, pA0);
+    link_inertia<0>(D.mass_scale[0], D.g, E0, mk(0, 0, 0), V0, I0, pA0);
     add_link_inertia(IA0, I0);
-    link_ground_points<0>(P, D, S.root_pos.z, E0, mk(0, 0, 0), V0, IA0, pA0, lds, lane, keep);
+    link_ground_points<0>(P, D.mu, S.root_pos.z, E0, mk(0, 0, 0), V0, IA0, pA0, lds, lane, keep);
   }
   chain_up<1, 2>(P, D, S, target, E0, V0, ball, bc, sel, IA0, pA0, lds, lane, keep);    // neck, head
   chain_up<3, 2>(P, D, S, target, E0, V0, ball, bc, sel, IA0, pA0, lds, lane, keep);    // left arm
@@ -553,24 +564,19 @@ BEZ_DEV void substep(const Params& P, const EnvDyn& D, EnvState& S, const float*
   // (d) root: I0^A a0 = -p0^A
   SV a0 = solve_spd6(IA0, svzero() - pA0);
   // (e) pass 3 + joint integration + contact forces
-  if (keep) {
-#pragma unroll
-    for (int i = 0; i < BEZ_NBE * 3; ++i) cf[i] = 0.f;
-    V3 f = link_ground_forces<0>(P, a0, lds, lane);
-    cf[0] = f.x; cf[1] = f.y; cf[2] = f.z;
-  }
+  if (keep) cf_store(co, 0, link_ground_forces<0>(P, a0, lds, lane));
   V3 fl = mk(0, 0, 0);
-  chain_down<1, 2>(P, S, a0, sel, fl, cf, lds, lane, keep);
-  chain_down<3, 2>(P, S, a0, sel, fl, cf, lds, lane, keep);
-  chain_down<5, 6>(P, S, a0, sel, fl, cf, lds, lane, keep);
-  chain_down<11, 2>(P, S, a0, sel, fl, cf, lds, lane, keep);
-  chain_down<13, 6>(P, S, a0, sel, fl, cf, lds, lane, keep);
+  chain_down<1, 2>(P, S, a0, sel, fl, co, lds, lane, keep);
+  chain_down<3, 2>(P, S, a0, sel, fl, co, lds, lane, keep);
+  chain_down<5, 6>(P, S, a0, sel, fl, co, lds, lane, keep);
+  chain_down<11, 2>(P, S, a0, sel, fl, co, lds, lane, keep);
+  chain_down<13, 6>(P, S, a0, sel, fl, co, lds, lane, keep);
   // (f) ball: Mb ab = -pb - Jb^T fl
   SV ab = ball_minv(ball, svzero() - ball.pb - wrench_at(sel.xb, fl));
   if (keep) {
-    float* cb = cf + (BEZ_NBE - 1) * 3;
-    cb[0] -= fl.x; cb[1] -= fl.y; cb[2] -= fl.z;
-    if (ball.ground) { V3 f = hit_force(P, ball.ghit, ab); cb[0] += f.x; cb[1] += f.y; cb[2] += f.z; }
+    V3 fb = -fl;
+    if (ball.ground) fb = fb + hit_force(P, ball.ghit, ab);
+    cf_store(co, BEZ_NBE - 1, fb);
   }
   // (g) integrate root (spatial -> classical acceleration of the torso origin) and ball
   V3 vdot = a0.l + cross(S.root_ang, S.root_lin);
@@ -588,7 +594,7 @@ BEZ_DEV void substep(const Params& P, const EnvDyn& D, EnvState& S, const float*
 // ---- env logic ---------------------------------------------------------------------------------------
 
 // kick_env.py:779-850 for this lane's env
-BEZ_DEV void env_reset(const Params& P, EnvState& S, float* target, float* cf, uint32_t& episode, int64_t genv) {
+BEZ_DEV void env_reset(const Params& P, EnvState& S, float* target, CfOut& co, uint32_t& episode, int64_t genv) {
   uint32_t k0 = (uint32_t)P.seed, k1 = (uint32_t)(P.seed >> 32);
   float u[36];
 #pragma unroll
@@ -613,8 +619,8 @@ BEZ_DEV void env_reset(const Params& P, EnvState& S, float* target, float* cf, u
 #pragma unroll
   for (int i = 0; i < 4; ++i) { S.rq[i] = P.bez_init[3 + i]; S.bq[i] = P.ball_init[3 + i]; }
   S.root_lin = S.root_ang = S.ball_lin = S.ball_ang = mk(0, 0, 0);
-#pragma unroll
-  for (int i = 0; i < BEZ_NBE * 3; ++i) cf[i] = 0.f;
+  for (int b = 0; b < BEZ_NBE; ++b) cf_store(co, b, mk(0, 0, 0));
+  co.lf = co.rf = mk(0, 0, 0);
 }
 
 // vec_task.py:317 + kick_env.py:413-418
@@ -651,7 +657,7 @@ BEZ_DEV void feet_no_cleats(float* f, float* out) {
 }
 
 // compute_observations + compute_reward (kick_env.py:749-777, 724-747) for this lane's env.
-BEZ_DEV void env_observe_reward(const Params& P, const EnvState& S, float* cf, float* prev, float* feet, float* obs,
+BEZ_DEV void env_observe_reward(const Params& P, const EnvState& S, CfOut& co, float* prev, float* feet, float* obs,
                                 float& rew, int64_t& reset, int64_t progress) {
   // IMU link = torso origin frame (soccerbot_stl.urdf:567-572)
   V3 v = S.root_lin, w = S.root_ang;
@@ -683,8 +689,10 @@ BEZ_DEV void env_observe_reward(const Params& P, const EnvState& S, float* cf, f
   float cosv = hc * ux + hs * uy;
   float sinv = fabsf(ux * hs - uy * hc);
   // feet (kick_env.py:538-576)
-  feet_no_cleats(cf + BEZ_LFOOT_BODY * 3, feet);
-  feet_no_cleats(cf + BEZ_RFOOT_BODY * 3, feet + 4);
+  float fl[3] = {co.lf.x, co.lf.y, co.lf.z}, fr[3] = {co.rf.x, co.rf.y, co.rf.z};
+  feet_no_cleats(fl, feet);
+  feet_no_cleats(fr, feet + 4);
+  co.lf = mk(fl[0], fl[1], fl[2]); co.rf = mk(fr[0], fr[1], fr[2]);
   // observation row (kick_env.py:1409-1415)
 #pragma unroll
   for (int j = 0; j < BEZ_ND; ++j) { obs[j] = S.q[j]; obs[BEZ_ND + j] = S.qd[j]; }
@@ -752,7 +760,9 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(Params P) {
 #pragma unroll
     for (int j = 0; j < BEZ_ND; ++j) target[j] = st[(size_t)(F_TARGET + j) * n + e];
   }
-  float cf[BEZ_NBE * 3];
+  CfOut co;
+  co.base = st + (size_t)F_CF * n + e; co.n = n;
+  co.lf = co.rf = mk(0, 0, 0);
   if (SIM) {
     EnvDyn D;
     D.mu = P.mu; D.g = mk(P.g[0], P.g[1], P.g[2]);
@@ -776,10 +786,10 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(Params P) {
         for (int l = 0; l < BEZ_NL; ++l) D.mass_scale[l] = P.dr_mass[(size_t)e * BEZ_NL + l];
       }
     }
-    for (int s = 0; s < P.substeps; ++s) substep(P, D, S, target, cf, lds, lane, s == P.substeps - 1);
+    for (int s = 0; s < P.substeps; ++s) substep(P, D, S, target, co, lds, lane, s == P.substeps - 1);
   } else if (POST) {
-#pragma unroll
-    for (int i = 0; i < BEZ_NBE * 3; ++i) cf[i] = st[(size_t)(F_CF + i) * n + e];
+    co.lf = mk(co.base[(size_t)(BEZ_LFOOT_BODY * 3 + 0) * n], co.base[(size_t)(BEZ_LFOOT_BODY * 3 + 1) * n], co.base[(size_t)(BEZ_LFOOT_BODY * 3 + 2) * n]);
+    co.rf = mk(co.base[(size_t)(BEZ_RFOOT_BODY * 3 + 0) * n], co.base[(size_t)(BEZ_RFOOT_BODY * 3 + 1) * n], co.base[(size_t)(BEZ_RFOOT_BODY * 3 + 2) * n]);
   }
   if (POST) {
     int64_t progress = P.progress[e], reset = P.reset[e];
@@ -788,7 +798,7 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(Params P) {
       P.timeout[e] = (progress >= (int64_t)(P.max_len - 1)) ? 1 : 0;  // vec_task.py:331-332
       progress += 1;                                                  // kick_env.py:429
       if (reset != 0) {                                               // kick_env.py:433-435
-        env_reset(P, S, target, cf, episode, P.env_off + e);
+        env_reset(P, S, target, co, episode, P.env_off + e);
         progress = 0; reset = 0;
         P.episode[e] = episode;
       }
@@ -796,7 +806,7 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(Params P) {
     float prev[3], feet[8], obs[BEZ_NUM_OBS], rew;
 #pragma unroll
     for (int i = 0; i < 3; ++i) prev[i] = st[(size_t)(F_PREV + i) * n + e];
-    env_observe_reward(P, S, cf, prev, feet, obs, rew, reset, progress);
+    env_observe_reward(P, S, co, prev, feet, obs, rew, reset, progress);
 #pragma unroll
     for (int i = 0; i < 3; ++i) st[(size_t)(F_PREV + i) * n + e] = prev[i];
 #pragma unroll
@@ -807,8 +817,8 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(Params P) {
   }
   if (SIM || POST) {
     store_state(st, n, e, S);
-#pragma unroll
-    for (int i = 0; i < BEZ_NBE * 3; ++i) st[(size_t)(F_CF + i) * n + e] = cf[i];
+    cf_store(co, BEZ_LFOOT_BODY, co.lf);
+    cf_store(co, BEZ_RFOOT_BODY, co.rf);
 #pragma unroll
     for (int j = 0; j < BEZ_ND; ++j) st[(size_t)(F_TARGET + j) * n + e] = target[j];
   }

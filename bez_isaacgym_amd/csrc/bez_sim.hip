@@ -8,6 +8,9 @@
 #include <new>
 #include <string>
 
+#include <cstdlib>
+
+#include "bez_kernel_ws.h"
 #include "bez_kernels.h"
 
 using namespace bez;
@@ -101,13 +104,14 @@ __global__ void reset_kernel(Params P, const int32_t* ids, int count) {
   int e = ids ? ids[t] : t;
   if (e < 0 || e >= P.n) return;
   EnvState S;
-  float target[BEZ_ND], cf[BEZ_NBE * 3];
+  float target[BEZ_ND];
+  CfOut co;
+  co.base = P.state + (size_t)F_CF * P.n + e; co.n = P.n;
   uint32_t episode = P.episode[e];
-  env_reset(P, S, target, cf, episode, P.env_off + e);
+  env_reset(P, S, target, co, episode, P.env_off + e);  // also zeroes the env's contact-force rows
   P.episode[e] = episode;
   store_state(P.state, P.n, e, S);
   for (int j = 0; j < BEZ_ND; ++j) P.state[(size_t)(F_TARGET + j) * P.n + e] = target[j];
-  for (int i = 0; i < BEZ_NBE * 3; ++i) P.state[(size_t)(F_CF + i) * P.n + e] = 0.f;
   P.progress[e] = 0;  // kick_env.py:849-850
   P.reset[e] = 0;
 }
@@ -227,11 +231,30 @@ __global__ void set_target_indexed_kernel(float* __restrict__ st, const float* _
   st[(size_t)(F_TARGET + j) * n + e] = src[(size_t)e * BEZ_ND + j];
 }
 
+// Kernel choice for launches that include the physics: the wave-specialised kernel (bez_kernel_ws.h) is the
+// production path; BEZ_SIM_KERNEL=lane selects the one-env-per-lane reference kernel (bez_kernels.h) for A/B runs.
+bool use_ws_kernel() {
+  static const bool ws = [] { const char* v = std::getenv("BEZ_SIM_KERNEL"); return !(v && std::string(v) == "lane"); }();
+  return ws;
+}
+
 template <bool PRE, bool SIM, bool POST>
 int launch_step(BezSim* s, const float* actions, hipStream_t stream) {
   Params P = make_params(s, actions);
+  const bool dr = has_dr(s);
+  if constexpr (SIM && PRE == POST) {
+    if (use_ws_kernel()) {
+      dim3 grid((s->n + WS_ENVS - 1) / WS_ENVS), block(WS_BLOCK);
+      if (dr) hipLaunchKernelGGL((step_kernel_ws<PRE, POST, true>), grid, block, 0, stream, P);
+      else hipLaunchKernelGGL((step_kernel_ws<PRE, POST, false>), grid, block, 0, stream, P);
+      hipError_t e = hipGetLastError();
+      if (e != hipSuccess) return fail(s, -2, "step_kernel_ws launch", e);
+      if (POST) s->obs_calls += 1;
+      return 0;
+    }
+  }
   dim3 grid(grid_for(s->n)), block(BLOCK);
-  if (has_dr(s)) hipLaunchKernelGGL((step_kernel<PRE, SIM, POST, true>), grid, block, 0, stream, P);
+  if (dr) hipLaunchKernelGGL((step_kernel<PRE, SIM, POST, true>), grid, block, 0, stream, P);
   else hipLaunchKernelGGL((step_kernel<PRE, SIM, POST, false>), grid, block, 0, stream, P);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(s, -2, "step kernel launch", e);

@@ -9,6 +9,16 @@
 
 #define BEZ_DEV __device__ __forceinline__
 
+// single-instruction approximations (v_rcp_f32 / v_sqrt_f32 / v_rsq_f32: 1 ulp; v_sin_f32 / v_cos_f32 take revolutions)
+BEZ_DEV float frcp(float x) { return __builtin_amdgcn_rcpf(x); }
+BEZ_DEV float fsqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+BEZ_DEV float frsq(float x) { return __builtin_amdgcn_rsqf(x); }
+BEZ_DEV void fsincos(float x, float* s, float* c) {
+  float r = x * 0.15915494309189535f;
+  *s = __builtin_amdgcn_sinf(r);
+  *c = __builtin_amdgcn_cosf(r);
+}
+
 struct V3 { float x, y, z; };
 struct Sym3 { float xx, yy, zz, xy, xz, yz; };
 struct M3 { float m00, m01, m02, m10, m11, m12, m20, m21, m22; };  // row-major general 3x3
@@ -142,7 +152,7 @@ BEZ_DEV Sym3 rotate_inertia(const M3& E, const Sym3& Il) {
 BEZ_DEV M3 inverse(const M3& a) {
   float c00 = fmaf(a.m11, a.m22, -a.m12 * a.m21), c01 = fmaf(a.m12, a.m20, -a.m10 * a.m22), c02 = fmaf(a.m10, a.m21, -a.m11 * a.m20);
   float det = fmaf(a.m00, c00, fmaf(a.m01, c01, a.m02 * c02));
-  float id = 1.0f / det;
+  float id = frcp(det);
   M3 r;
   r.m00 = c00 * id; r.m01 = fmaf(a.m02, a.m21, -a.m01 * a.m22) * id; r.m02 = fmaf(a.m01, a.m12, -a.m02 * a.m11) * id;
   r.m10 = c01 * id; r.m11 = fmaf(a.m00, a.m22, -a.m02 * a.m20) * id; r.m12 = fmaf(a.m02, a.m10, -a.m00 * a.m12) * id;
@@ -174,7 +184,7 @@ BEZ_DEV SV solve_spd6(const Sym6& I, SV b) {
 #pragma unroll
     for (int k = 0; k < j; ++k) dj = fmaf(-L[j][k] * L[j][k], d[k], dj);
     d[j] = dj;
-    float inv = 1.0f / dj;
+    float inv = frcp(dj);
 #pragma unroll
     for (int i = j + 1; i < 6; ++i) {
       float s = L[i][j];
@@ -189,7 +199,7 @@ BEZ_DEV SV solve_spd6(const Sym6& I, SV b) {
     for (int k = 0; k < i; ++k) x[i] = fmaf(-L[i][k], x[k], x[i]);
   }
 #pragma unroll
-  for (int i = 0; i < 6; ++i) x[i] = x[i] / d[i];
+  for (int i = 0; i < 6; ++i) x[i] = x[i] * frcp(d[i]);
 #pragma unroll
   for (int i = 5; i >= 0; --i) {
 #pragma unroll
