@@ -21,7 +21,7 @@
 namespace bez {
 
 constexpr int WS_BLOCK = 256;
-constexpr int WS_ENVS = 64;
+constexpr int WS_ENVS = 64;  // lanes per wave; a workgroup may use only the first NE (64, 32 or 16) of them
 
 // LDS exchange slots (floats per env lane)
 enum : int {
@@ -32,16 +32,27 @@ enum : int {
   X_DEPTH = 109, // deepest ball/box penetration found by each leg
   X_FL = 111,    // ball<->link force on the link (3) + contact point rel. ball centre (3)
   X_FOOT = 117,  // net contact force on left / right foot
-  X_Q = 123, X_QD = 141, X_TGT = 159,
-  X_SLOTS = 177
+  X_PSUM = 123,  // per chain role: sum of (default - q)^2 over its joints
+  X_SLOTS = 126
 };
-constexpr int WS_OBS_STRIDE = 55;  // odd stride: conflict-free transposes
+constexpr int WS_OBS_STRIDE = 54;  // rows unpadded: the staged block IS the contiguous HBM image (float4 copy-out)
 constexpr int WS_ACT_STRIDE = 19;
-constexpr int WS_LDS_FLOATS = X_SLOTS * WS_ENVS + WS_ENVS * WS_OBS_STRIDE;
+constexpr int WS_LDS_FLOATS = X_SLOTS * WS_ENVS + WS_ENVS * WS_OBS_STRIDE;  // sized for NE = 64
 
 #define XS(slot) lds[(slot) * WS_ENVS + lane]
 
 BEZ_DEV void ws_barrier() { __syncthreads(); }
+
+// In-kernel stamps (diagnostic build only; the shipped kernel contains none): clock at phase boundaries of
+// workgroup 0, written to a buffer nothing else reads.
+#ifdef BEZ_WS_STAMPS
+#define WS_STAMP(role, k)                                                                         \
+  do {                                                                                            \
+    if (P.stamps && blockIdx.x == 0 && lane == 0) P.stamps[(role) * 32 + (k)] = __builtin_amdgcn_s_memtime(); \
+  } while (0)
+#else
+#define WS_STAMP(role, k) do { } while (0)
+#endif
 
 BEZ_DEV void xs_store_sv(float* lds, int lane, int slot, SV v) {
   XS(slot + 0) = v.a.x; XS(slot + 1) = v.a.y; XS(slot + 2) = v.a.z; XS(slot + 3) = v.l.x; XS(slot + 4) = v.l.y; XS(slot + 5) = v.l.z;
@@ -131,15 +142,9 @@ BEZ_DEV void ws_chain_pass2(const Params& P, const ChainDyn& D, const float* kps
     add_link_inertia(IA, LI[i]);
     pA = pA + pAl[i];
     if constexpr (LEG && link_has_box(L)) {
-      if (mine && sel.link == L) {
-        // velocity of the selected link: V0 + sum of the joint velocities down to it
-        SV V = R.V0;
-        static_for<i + 1>([&](auto J) { constexpr int j = decltype(J)::value; V = V + Sl[j] * qd[j]; });
-        ball_link_contact(P, D.mu, R.ball_ang, R.ball_lin, ball, R.bc, V, sel);
-        if (sel.link == L) {  // still active after the approach-velocity test
-          add_point_stiffness(IA, sel.x, sel.A);
-          pA = pA - wrench_at(sel.x, sel.f0p);
-        }
+      if (mine && sel.link == L) {  // contact operands were prepared once by ws_ball_contact_prepare
+        add_point_stiffness(IA, sel.x, sel.A);
+        pA = pA - wrench_at(sel.x, sel.f0p);
       }
     }
     SV U; float Dinv, u;
@@ -150,6 +155,23 @@ BEZ_DEV void ws_chain_pass2(const Params& P, const ChainDyn& D, const float* kps
   });
   add_to(IAo, IA);
   pAo = pAo + pA;
+}
+
+// Ball<->link contact operands for the (per-lane, runtime) selected link, evaluated ONCE per wave instead of once per
+// candidate link: the link's velocity is V0 + sum_{j <= idx} S_j qd_j.  Clears sel.link when the contact is not active.
+template <int FIRST, int LEN>
+BEZ_DEV void ws_ball_contact_prepare(const Params& P, const ChainDyn& D, const RootView& R, const BallBody& ball, const SV* Sl,
+                                     const float* qd, bool mine, BallSel& sel) {
+  if (mine) {
+    SV V = R.V0;
+    const int idx = sel.link - FIRST;
+    static_for<LEN>([&](auto J) {
+      constexpr int j = decltype(J)::value;
+      const float w = (j <= idx) ? qd[j] : 0.f;
+      V = V + Sl[j] * w;
+    });
+    ball_link_contact(P, D.mu, R.ball_ang, R.ball_lin, ball, R.bc, V, sel);
+  }
 }
 
 // pass 3: joint accelerations, semi-implicit Euler with the velocity clamp; returns the chain-end acceleration
@@ -182,6 +204,65 @@ BEZ_DEV SV ws_chain_pass3(const Params& P, SV a0, const P3* p3, float* q, float*
   return a;
 }
 
+// ---- joint-side post-physics of a chain role (runs in parallel in the three chain waves): the reset draw for ITS joints
+// (kick_env.py:786-791,839-842), the observation slots q / qd (kick_env.py:1409-1410), its share of |default - q|^2, and
+// the stores of its joints' state.
+BEZ_DEV constexpr int role_dof(int role, int i) { return role == 0 ? 4 + i : (role == 1 ? 12 + i : (i < 4 ? i : 6 + i)); }
+BEZ_DEV constexpr bool role_needs_block(int role, int b) {
+  for (int i = 0; i < 6; ++i) if ((role_dof(role, i) >> 2) == b || ((BEZ_ND + role_dof(role, i)) >> 2) == b) return true;
+  return false;
+}
+template <int ROLE, bool POST>
+BEZ_DEV void ws_chain_epilogue(const Params& P, float* lds, int lane, int e, bool active, bool do_reset, uint32_t episode,
+                               float* q, float* qd, float* target) {
+  const int n = P.n;
+  if (POST) {
+    if (do_reset) {
+      const int64_t genv = P.env_off + e;
+      const uint32_t k0 = (uint32_t)P.seed, k1 = (uint32_t)(P.seed >> 32);
+      static_for<9>([&](auto B) {
+        constexpr int b = decltype(B)::value;
+        if constexpr (role_needs_block(ROLE, b)) {
+          uint32_t c[4] = {(uint32_t)genv, (uint32_t)((uint64_t)genv >> 32), episode, (uint32_t)b};
+          philox4x32_10(c, k0, k1);
+          static_for<6>([&](auto I) {
+            constexpr int i = decltype(I)::value;
+            constexpr int d = role_dof(ROLE, i);
+            if constexpr ((d >> 2) == b) {
+              float u = (float)(c[d & 3] >> 8) * (1.0f / 16777216.0f);
+              float qq = (float)BEZ_DOF_DEFAULT[d] + fmaf(0.3f, u, -0.15f);
+              q[i] = fmaxf(fminf(qq, (float)BEZ_DOF_UPPER[d]), (float)BEZ_DOF_LOWER[d]);
+            }
+            if constexpr (((BEZ_ND + d) >> 2) == b) {
+              float u = (float)(c[(BEZ_ND + d) & 3] >> 8) * (1.0f / 16777216.0f);
+              qd[i] = fmaf(0.2f, u, -0.1f);
+            }
+          });
+        }
+      });
+      static_for<6>([&](auto I) { constexpr int i = decltype(I)::value; target[i] = (float)BEZ_DOF_DEFAULT[role_dof(ROLE, i)]; });
+    }
+    float* obs_row = lds + X_SLOTS * WS_ENVS + lane * WS_OBS_STRIDE;
+    float psum = 0.f;
+    static_for<6>([&](auto I) {
+      constexpr int i = decltype(I)::value;
+      constexpr int d = role_dof(ROLE, i);
+      obs_row[d] = q[i]; obs_row[BEZ_ND + d] = qd[i];
+      float dd = (float)BEZ_DOF_DEFAULT[d] - q[i];
+      psum = fmaf(dd, dd, psum);
+    });
+    XS(X_PSUM + ROLE) = psum;
+  }
+  if (active) {
+    float* st = P.state;
+    static_for<6>([&](auto I) {
+      constexpr int i = decltype(I)::value;
+      constexpr int d = role_dof(ROLE, i);
+      st[(size_t)(F_Q + d) * n + e] = q[i]; st[(size_t)(F_QD + d) * n + e] = qd[i]; st[(size_t)(F_TARGET + d) * n + e] = target[i];
+    });
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ roles
 template <int FIRST, bool PRE, bool POST, bool DR>
 BEZ_DEV void ws_leg_role(const Params& P, float* lds, int lane, int e, bool active, int side) {
@@ -205,7 +286,11 @@ BEZ_DEV void ws_leg_role(const Params& P, float* lds, int lane, int e, bool acti
     if (P.dr_friction) D.mu = P.dr_friction[e];
     if (P.dr_gravity) D.g = mk(P.dr_gravity[(size_t)e * 3], P.dr_gravity[(size_t)e * 3 + 1], P.dr_gravity[(size_t)e * 3 + 2]);
   }
+  const bool do_reset = POST && P.reset[e] != 0;  // reset_buf of the previous step (kick_env.py:433-435)
+  const uint32_t episode = POST ? P.episode[e] : 0u;
+  WS_STAMP(side, 0);
   ws_barrier();  // B0: actions staged, root/ball published
+  WS_STAMP(side, 1);
   if (PRE) {
     const float* act = lds + X_SLOTS * WS_ENVS + lane * WS_ACT_STRIDE;
 #pragma unroll
@@ -229,27 +314,37 @@ BEZ_DEV void ws_leg_role(const Params& P, float* lds, int lane, int e, bool acti
     sel.link = -1; sel.depth = 0.f; sel.n = sel.P = sel.f0p = sel.x = sel.xb = mk(0, 0, 0); sel.A = sym3zero();
     ws_chain_pass1<FIRST, LEN, true>(P, D, ms, R, q, qd, LI, pAl, Sl, cbl, Kc, pc, sel);
     XS(X_DEPTH + side) = sel.depth;
+    WS_STAMP(side, 2 + 8 * s);
     ws_barrier();  // B1
+    WS_STAMP(side, 3 + 8 * s);
     float other = XS(X_DEPTH + (1 - side));
     bool mine = sel.link >= 0 && (sel.depth > other || (sel.depth == other && side == 0));
-    BallBody ball = ball_setup(P, D.mu, D.g, R.ball_z, R.ball_ang, R.ball_lin);
+    BallBody ball;
+    if (mine) ball = ball_setup(P, D.mu, D.g, R.ball_z, R.ball_ang, R.ball_lin);
+    ws_ball_contact_prepare<FIRST, LEN>(P, D, R, ball, Sl, qd, mine, sel);
+    mine = mine && sel.link >= 0;
     P3 p3[LEN];
     Sym6 IA = sym6zero(); SV pA = svzero();
     ws_chain_pass2<FIRST, LEN, true>(P, D, kps, kds, R, ball, q, qd, target, LI, pAl, Sl, cbl, Kc, pc, mine, sel, p3, IA, pA);
     xs_store_sym6(lds, lane, X_IA + side * 27, IA, pA);
     BodyContact bcn = body_contact_of(Kc, pc);
+    WS_STAMP(side, 4 + 8 * s);
     ws_barrier();  // B2
+    WS_STAMP(side, 5 + 8 * s);
     ws_barrier();  // B3: torso acceleration published
+    WS_STAMP(side, 6 + 8 * s);
     SV a0 = xs_load_sv(lds, lane, X_A0);
     V3 fl = mk(0, 0, 0), fend = mk(0, 0, 0);
     SV aend = ws_chain_pass3<FIRST, LEN, true>(P, a0, p3, q, qd, mine, sel, fl, fend, cf_base, n, keep, active);
     if (mine && sel.link >= 0) { xs_store_v3(lds, lane, X_FL, fl); xs_store_v3(lds, lane, X_FL + 3, sel.xb); }
     if (keep) xs_store_v3(lds, lane, X_FOOT + side * 3, fend + body_contact_force(bcn, aend));
+    WS_STAMP(side, 7 + 8 * s);
     ws_barrier();  // B4
+    WS_STAMP(side, 8 + 8 * s);
     ws_barrier();  // B5: new root/ball state published
+    WS_STAMP(side, 9 + 8 * s);
   }
-#pragma unroll
-  for (int i = 0; i < LEN; ++i) { XS(X_Q + FIRST - 1 + i) = q[i]; XS(X_QD + FIRST - 1 + i) = qd[i]; XS(X_TGT + FIRST - 1 + i) = target[i]; }
+  ws_chain_epilogue<(FIRST == 5 ? 0 : 1), POST>(P, lds, lane, e, active, do_reset, episode, q, qd, target);
   ws_barrier();  // B6
 }
 
@@ -275,6 +370,8 @@ BEZ_DEV void ws_upper_role(const Params& P, float* lds, int lane, int e, bool ac
     if (P.dr_friction) D.mu = P.dr_friction[e];
     if (P.dr_gravity) D.g = mk(P.dr_gravity[(size_t)e * 3], P.dr_gravity[(size_t)e * 3 + 1], P.dr_gravity[(size_t)e * 3 + 2]);
   }
+  const bool do_reset = POST && P.reset[e] != 0;
+  const uint32_t episode = POST ? P.episode[e] : 0u;
   ws_barrier();  // B0
   if (PRE) {
     const float* act = lds + X_SLOTS * WS_ENVS + lane * WS_ACT_STRIDE;
@@ -298,6 +395,7 @@ BEZ_DEV void ws_upper_role(const Params& P, float* lds, int lane, int e, bool ac
     P3 p3[6];
     BodyContact bcn[3];
     Sym6 IA = sym6zero(); SV pA = svzero();
+    ws_barrier();  // B1 (only the legs exchange data here: take it first so the chains below overlap the legs' passes)
     {  // three 2-link chains, one after the other
       LinkInertia LI[2]; SV pAl[2], Sl[2], cbl[2]; Sym6 Kc; SV pc;
       ws_chain_pass1<1, 2, false>(P, D, ms + 0, R, q + 0, qd + 0, LI, pAl, Sl, cbl, Kc, pc, nosel);
@@ -310,7 +408,6 @@ BEZ_DEV void ws_upper_role(const Params& P, float* lds, int lane, int e, bool ac
       ws_chain_pass2<11, 2, false>(P, D, kps + 4, kds + 4, R, noball, q + 4, qd + 4, target + 4, LI, pAl, Sl, cbl, Kc, pc, false, nosel, p3 + 4, IA, pA);
       bcn[2] = body_contact_of(Kc, pc);
     }
-    ws_barrier();  // B1
     xs_store_sym6(lds, lane, X_IA + 2 * 27, IA, pA);
     ws_barrier();  // B2
     ws_barrier();  // B3
@@ -329,8 +426,7 @@ BEZ_DEV void ws_upper_role(const Params& P, float* lds, int lane, int e, bool ac
     ws_barrier();  // B4
     ws_barrier();  // B5
   }
-#pragma unroll
-  for (int i = 0; i < 6; ++i) { XS(X_Q + DOF[i]) = q[i]; XS(X_QD + DOF[i]) = qd[i]; XS(X_TGT + DOF[i]) = target[i]; }
+  ws_chain_epilogue<2, POST>(P, lds, lane, e, active, do_reset, episode, q, qd, target);
   ws_barrier();  // B6
 }
 
@@ -347,6 +443,14 @@ BEZ_DEV void ws_root_role(const Params& P, float* lds, int lane, int e, bool act
   float bq[4] = {ld(F_BALL_QUAT), ld(F_BALL_QUAT + 1), ld(F_BALL_QUAT + 2), ld(F_BALL_QUAT + 3)};
   V3 ball_lin = mk(ld(F_BALL_LIN), ld(F_BALL_LIN + 1), ld(F_BALL_LIN + 2));
   V3 ball_ang = mk(ld(F_BALL_ANG), ld(F_BALL_ANG + 1), ld(F_BALL_ANG + 2));
+  // bookkeeping inputs of the post-physics, fetched now so that their latency hides behind the physics
+  int64_t progress = 0, reset = 0;
+  float prev[3] = {0.f, 0.f, 0.f};
+  if (POST) {
+    progress = P.progress[e]; reset = P.reset[e];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) prev[i] = ld(F_PREV + i);
+  }
   ChainDyn D; D.mu = P.mu; D.g = mk(P.g[0], P.g[1], P.g[2]);
   float ms0 = 1.f;
   if (DR) {
@@ -361,7 +465,9 @@ BEZ_DEV void ws_root_role(const Params& P, float* lds, int lane, int e, bool act
     xs_store_v3(lds, lane, X_BALL, ball_pos); xs_store_v3(lds, lane, X_BALL + 3, ball_lin); xs_store_v3(lds, lane, X_BALL + 6, ball_ang);
   };
   publish();
+  WS_STAMP(3, 0);
   ws_barrier();  // B0
+  WS_STAMP(3, 1);
   float* cf_base = st + (size_t)F_CF * n + e;
   for (int s = 0; s < P.substeps; ++s) {
     const bool keep = (s == P.substeps - 1);
@@ -377,21 +483,28 @@ BEZ_DEV void ws_root_role(const Params& P, float* lds, int lane, int e, bool act
     add_link_inertia(IA0, I0);
     add_to(IA0, Kc); pA0 = pA0 + pc;
     BallBody ball = ball_setup(P, D.mu, D.g, ball_pos.z, ball_ang, ball_lin);
+    WS_STAMP(3, 2 + 8 * s);
     ws_barrier();  // B1
+    WS_STAMP(3, 3 + 8 * s);
     ws_barrier();  // B2: chain contributions published
+    WS_STAMP(3, 5 + 8 * s);
     xs_add_sym6(lds, lane, X_IA + 0 * 27, IA0, pA0);
     xs_add_sym6(lds, lane, X_IA + 1 * 27, IA0, pA0);
     xs_add_sym6(lds, lane, X_IA + 2 * 27, IA0, pA0);
     SV a0 = solve_spd6(IA0, svzero() - pA0);
     xs_store_sv(lds, lane, X_A0, a0);
+    WS_STAMP(3, 4 + 8 * s);
     ws_barrier();  // B3
+    WS_STAMP(3, 6 + 8 * s);
     if (keep && active) { V3 f = body_contact_force(bc0, a0); cf_base[0] = f.x; cf_base[(size_t)1 * n] = f.y; cf_base[(size_t)2 * n] = f.z; }
     V3 vdot = a0.l + cross(root_ang, root_lin);
     root_ang = fma3(a0.a, P.h, root_ang);
     root_lin = fma3(vdot, P.h, root_lin);
     root_pos = fma3(root_lin, P.h, root_pos);
     quat_integrate(rq, root_ang, P.h);
+    WS_STAMP(3, 7 + 8 * s);
     ws_barrier();  // B4: ball<->link force published
+    WS_STAMP(3, 8 + 8 * s);
     V3 fl = xs_load_v3(lds, lane, X_FL), xb = xs_load_v3(lds, lane, X_FL + 3);
     SV ab = ball_minv(ball, svzero() - ball.pb - wrench_at(xb, fl));
     if (keep && active) {
@@ -407,34 +520,36 @@ BEZ_DEV void ws_root_role(const Params& P, float* lds, int lane, int e, bool act
     quat_integrate(bq, ball_ang, P.h);
     publish();
     ws_barrier();  // B5
+    WS_STAMP(3, 9 + 8 * s);
   }
-  ws_barrier();  // B6: joint state / targets / foot forces of the other roles are in LDS
-  EnvState S;
-  S.root_pos = root_pos; S.root_lin = root_lin; S.root_ang = root_ang; S.ball_pos = ball_pos; S.ball_lin = ball_lin; S.ball_ang = ball_ang;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) { S.rq[i] = rq[i]; S.bq[i] = bq[i]; }
-  float target[BEZ_ND];
-#pragma unroll
-  for (int j = 0; j < BEZ_ND; ++j) { S.q[j] = XS(X_Q + j); S.qd[j] = XS(X_QD + j); target[j] = XS(X_TGT + j); }
+  ws_barrier();  // B6: joint obs slots / pose-error sums / foot forces of the chain roles are in LDS
+  WS_STAMP(3, 20);
   CfOut co;
   co.base = cf_base; co.n = n;
   co.lf = xs_load_v3(lds, lane, X_FOOT); co.rf = xs_load_v3(lds, lane, X_FOOT + 3);
-  float* obs_row = lds + X_SLOTS * WS_ENVS + lane * WS_OBS_STRIDE;
   if (POST) {
-    int64_t progress = P.progress[e], reset = P.reset[e];
-    uint32_t episode = P.episode[e];
     int64_t timeout = (progress >= (int64_t)(P.max_len - 1)) ? 1 : 0;  // vec_task.py:331-332
     progress += 1;                                                    // kick_env.py:429
-    if (reset != 0) {                                                 // kick_env.py:433-435
-      if (active) { env_reset(P, S, target, co, episode, P.env_off + e); P.episode[e] = episode; }
+    if (reset != 0) {                                                 // kick_env.py:433-435, 831-850 (root / ball part)
+      root_pos = mk(P.bez_init[0], P.bez_init[1], P.bez_init[2]);
+      ball_pos = mk(P.ball_init[0], P.ball_init[1], P.ball_init[2]);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { rq[i] = P.bez_init[3 + i]; bq[i] = P.ball_init[3 + i]; }
+      root_lin = root_ang = ball_lin = ball_ang = mk(0, 0, 0);
+      co.lf = co.rf = mk(0, 0, 0);
+      if (active) {
+        for (int b = 0; b < BEZ_NBE; ++b) cf_store(co, b, mk(0, 0, 0));
+        P.episode[e] = P.episode[e] + 1;
+      }
       progress = 0; reset = 0;
     }
-    float prev[3], feet[8], obs[BEZ_NUM_OBS], rew;
+    float pn = (XS(X_PSUM + 2) + XS(X_PSUM + 0)) + XS(X_PSUM + 1);
+    float feet[8], rew;
+    float* obs_row = lds + X_SLOTS * WS_ENVS + lane * WS_OBS_STRIDE;
+    float tail[18];
+    env_observe_core(P, root_pos, rq, root_lin, root_ang, ball_pos, ball_lin, co, prev, feet, tail, pn, rew, reset, progress);
 #pragma unroll
-    for (int i = 0; i < 3; ++i) prev[i] = st[(size_t)(F_PREV + i) * n + e];
-    env_observe_reward(P, S, co, prev, feet, obs, rew, reset, progress);
-#pragma unroll
-    for (int i = 0; i < BEZ_NUM_OBS; ++i) obs_row[i] = obs[i];
+    for (int i = 0; i < 18; ++i) obs_row[36 + i] = tail[i];
     if (active) {
 #pragma unroll
       for (int i = 0; i < 3; ++i) st[(size_t)(F_PREV + i) * n + e] = prev[i];
@@ -443,42 +558,58 @@ BEZ_DEV void ws_root_role(const Params& P, float* lds, int lane, int e, bool act
       P.rew[e] = rew; P.reset[e] = reset; P.progress[e] = progress; P.timeout[e] = timeout;
     }
   }
+  WS_STAMP(3, 21);
   if (active) {
-    store_state(st, n, e, S);
+    auto sv = [&](int f, float v) { st[(size_t)f * n + e] = v; };
+    sv(F_ROOT_POS, root_pos.x); sv(F_ROOT_POS + 1, root_pos.y); sv(F_ROOT_POS + 2, root_pos.z);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { sv(F_ROOT_QUAT + i, rq[i]); sv(F_BALL_QUAT + i, bq[i]); }
+    sv(F_ROOT_LIN, root_lin.x); sv(F_ROOT_LIN + 1, root_lin.y); sv(F_ROOT_LIN + 2, root_lin.z);
+    sv(F_ROOT_ANG, root_ang.x); sv(F_ROOT_ANG + 1, root_ang.y); sv(F_ROOT_ANG + 2, root_ang.z);
+    sv(F_BALL_POS, ball_pos.x); sv(F_BALL_POS + 1, ball_pos.y); sv(F_BALL_POS + 2, ball_pos.z);
+    sv(F_BALL_LIN, ball_lin.x); sv(F_BALL_LIN + 1, ball_lin.y); sv(F_BALL_LIN + 2, ball_lin.z);
+    sv(F_BALL_ANG, ball_ang.x); sv(F_BALL_ANG + 1, ball_ang.y); sv(F_BALL_ANG + 2, ball_ang.z);
     cf_store(co, BEZ_LFOOT_BODY, co.lf);
     cf_store(co, BEZ_RFOOT_BODY, co.rf);
-#pragma unroll
-    for (int j = 0; j < BEZ_ND; ++j) st[(size_t)(F_TARGET + j) * n + e] = target[j];
   }
 }
 
 // ---- the kernel.  grid = ceil(N / 64) workgroups of 256 threads.
-template <bool PRE, bool POST, bool DR>
+template <bool PRE, bool POST, bool DR, int NE>
 __global__ __launch_bounds__(WS_BLOCK) void step_kernel_ws(Params P) {
-  __shared__ float lds[WS_LDS_FLOATS];
+  __shared__ __attribute__((aligned(16))) float lds[WS_LDS_FLOATS];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int role = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int env0 = blockIdx.x * WS_ENVS;
-  const int nloc = min(WS_ENVS, P.n - env0);
+  const int env0 = blockIdx.x * NE;
+  const int nloc = min(NE, P.n - env0);
   const bool active = lane < nloc;
   const int e = env0 + (active ? lane : 0);  // inactive lanes shadow env0 (loads only; every store is guarded)
+  WS_STAMP(role, 22);
   if (PRE) {
     // coalesced stage of this workgroup's contiguous (nloc,18) action block, transposed to [lane][19]
     float* act = lds + X_SLOTS * WS_ENVS;
     const float* src = P.actions + (size_t)env0 * BEZ_ND;
     for (int i = tid; i < nloc * BEZ_ND; i += WS_BLOCK) act[(i / BEZ_ND) * WS_ACT_STRIDE + (i % BEZ_ND)] = src[i];
   }
-  if (role == 0) ws_leg_role<5, PRE, POST, DR>(P, lds, lane, e, active, 0);
-  else if (role == 1) ws_leg_role<13, PRE, POST, DR>(P, lds, lane, e, active, 1);
-  else if (role == 2) ws_upper_role<PRE, POST, DR>(P, lds, lane, e, active);
-  else ws_root_role<PRE, POST, DR>(P, lds, lane, e, active);
+  // Lanes >= NE of every wave are masked off for the whole role body (lane 0 is always active, so every wave
+  // still reaches every barrier: s_barrier is a scalar instruction).
+  if (lane < NE) {
+    if (role == 0) ws_leg_role<5, PRE, POST, DR>(P, lds, lane, e, active, 0);
+    else if (role == 1) ws_leg_role<13, PRE, POST, DR>(P, lds, lane, e, active, 1);
+    else if (role == 2) ws_upper_role<PRE, POST, DR>(P, lds, lane, e, active);
+    else ws_root_role<PRE, POST, DR>(P, lds, lane, e, active);
+  }
   if (POST) {
     ws_barrier();  // observation rows staged in LDS by role 3
-    const float* rows = lds + X_SLOTS * WS_ENVS;
-    float* dst = P.obs + (size_t)env0 * BEZ_NUM_OBS;
-    for (int i = tid; i < nloc * BEZ_NUM_OBS; i += WS_BLOCK) dst[i] = rows[(i / BEZ_NUM_OBS) * WS_OBS_STRIDE + (i % BEZ_NUM_OBS)];
+    // the staged rows are the contiguous (nloc,54) image of this workgroup's slice of obs_buf: 16-byte copy-out
+    const float4* rows = reinterpret_cast<const float4*>(lds + X_SLOTS * WS_ENVS);
+    float4* dst = reinterpret_cast<float4*>(P.obs + (size_t)env0 * BEZ_NUM_OBS);
+    const int nvec = (nloc * BEZ_NUM_OBS) >> 2;  // NE is a multiple of 16, so full workgroups copy whole float4s
+    for (int i = tid; i < nvec; i += WS_BLOCK) dst[i] = rows[i];
+    for (int i = (nvec << 2) + tid; i < nloc * BEZ_NUM_OBS; i += WS_BLOCK) P.obs[(size_t)env0 * BEZ_NUM_OBS + i] = lds[X_SLOTS * WS_ENVS + i];
   }
+  WS_STAMP(role, 23);
 }
 
 #undef XS

@@ -41,6 +41,7 @@ constexpr int LDS_SLOTS = LDS_HIT + BEZ_NPT * HIT_STRIDE;
 struct Params {
   int n, substeps, max_len, use_prev, obs_only;
   float dt, h;
+  float ang_init;  // atan2 of the unit vector ball_init -> goal (kick_env.py:1238-1243): constant of the config
   float g[3];
   float kp, kd, armature, effort, vel_limit, jfric, mu, clip;
   float bez_init[7], ball_init[7], goal[2];
@@ -61,6 +62,7 @@ struct Params {
   const float* dr_kd;        // (N,18)   or null
   const float* dr_mass;      // (N,19)   or null
   const float* dr_gravity;   // (N,3)    or null
+  unsigned long long* stamps; // diagnostic builds only (-DBEZ_WS_STAMPS): s_memtime per role / phase of workgroup 0
 };
 
 // ---- compile-time model access
@@ -656,83 +658,84 @@ BEZ_DEV void feet_no_cleats(float* f, float* out) {
   out[0] = o0; out[1] = o1; out[2] = o2; out[3] = o3;
 }
 
-// compute_observations + compute_reward (kick_env.py:749-777, 724-747) for this lane's env.
-BEZ_DEV void env_observe_reward(const Params& P, const EnvState& S, CfOut& co, float* prev, float* feet, float* obs,
-                                float& rew, int64_t& reset, int64_t progress) {
+// compute_observations + compute_reward (kick_env.py:749-777, 724-747) for this lane's env, everything except the
+// joint slots obs[0:36]: writes tail[18] = imu(6) off_orn(2) feet(8) ball_init(2).  `pn` = sum_j (default_j - q_j)^2.
+BEZ_DEV void env_observe_core(const Params& P, V3 root_pos, const float* rq, V3 v, V3 w, V3 ball_pos, V3 ball_lin, CfOut& co,
+                              float* prev, float* feet, float* tail, float pn, float& rew, int64_t& reset, int64_t progress) {
   // IMU link = torso origin frame (soccerbot_stl.urdf:567-572)
-  V3 v = S.root_lin, w = S.root_ang;
   // compute_imu (kick_env.py:918-930), quaternion_to_matrix fed xyzw as (r,i,j,k) (quirk Q2)
   float pvx = P.use_prev ? prev[0] : v.x, pvy = P.use_prev ? prev[1] : v.y, pvz = P.use_prev ? prev[2] : v.z;
   float ax = (v.x - pvx) / P.dt - 0.f, ay = (v.y - pvy) / P.dt - 0.f, az = (v.z - pvz) / P.dt - (-1.f);
-  float r = S.rq[0], i_ = S.rq[1], j_ = S.rq[2], k_ = S.rq[3];
+  float r = rq[0], i_ = rq[1], j_ = rq[2], k_ = rq[3];
   float two_s = 2.0f / (r * r + i_ * i_ + j_ * j_ + k_ * k_);
   float m00 = 1.f - two_s * (j_ * j_ + k_ * k_), m01 = two_s * (i_ * j_ - k_ * r), m02 = two_s * (i_ * k_ + j_ * r);
   float m10 = two_s * (i_ * j_ + k_ * r), m11 = 1.f - two_s * (i_ * i_ + k_ * k_), m12 = two_s * (j_ * k_ - i_ * r);
   float m20 = two_s * (i_ * k_ - j_ * r), m21 = two_s * (j_ * k_ + i_ * r), m22 = 1.f - two_s * (i_ * i_ + j_ * j_);
   const float LIN = (float)(2. * 9.81), ANG = 8.7266f;
-  float imu[6];
-  imu[0] = fminf(fmaxf(m00 * ax + m01 * ay + m02 * az, -LIN), LIN);
-  imu[1] = fminf(fmaxf(m10 * ax + m11 * ay + m12 * az, -LIN), LIN);
-  imu[2] = fminf(fmaxf(m20 * ax + m21 * ay + m22 * az, -LIN), LIN);
-  imu[3] = fminf(fmaxf(w.x, -ANG), ANG); imu[4] = fminf(fmaxf(w.y, -ANG), ANG); imu[5] = fminf(fmaxf(w.z, -ANG), ANG);
+  tail[0] = fminf(fmaxf(m00 * ax + m01 * ay + m02 * az, -LIN), LIN);
+  tail[1] = fminf(fmaxf(m10 * ax + m11 * ay + m12 * az, -LIN), LIN);
+  tail[2] = fminf(fmaxf(m20 * ax + m21 * ay + m22 * az, -LIN), LIN);
+  tail[3] = fminf(fmaxf(w.x, -ANG), ANG); tail[4] = fminf(fmaxf(w.y, -ANG), ANG); tail[5] = fminf(fmaxf(w.z, -ANG), ANG);
   prev[0] = v.x; prev[1] = v.y; prev[2] = v.z;
   // compute_off_orn (kick_env.py:941-960)
-  float gx = P.goal[0] - S.root_pos.x, gy = P.goal[1] - S.root_pos.y;
+  float gx = P.goal[0] - root_pos.x, gy = P.goal[1] - root_pos.y;
   float gn = sqrtf(gx * gx + gy * gy);
   float ux = gx / gn, uy = gy / gn;
-  float qx = S.rq[0], qy = S.rq[1], qz = S.rq[2], qw = S.rq[3];
-  float yaw = atan2f(2.0f * (qw * qz + qx * qy), qw * qw + qx * qx - qy * qy - qz * qz);
-  const float TWO_PI = 6.283185307179586f;
-  yaw = yaw - TWO_PI * floorf(yaw / TWO_PI);  // python-style % (2 pi)
-  float hs, hc;
-  sincosf(yaw, &hs, &hc);
+  float qx = rq[0], qy = rq[1], qz = rq[2], qw = rq[3];
+  // heading (cos yaw, sin yaw) with yaw = atan2(sy, cy) (get_euler_xyz [ext]): the unit vector (cy, sy)/|.| itself --
+  // the % 2pi wrap and the atan2/sincos round trip of the reference only cost rounding (checked by the golden tests)
+  float sy = 2.0f * (qw * qz + qx * qy), cy = qw * qw + qx * qx - qy * qy - qz * qz;
+  float hn = 1.0f / sqrtf(sy * sy + cy * cy);
+  float hs = sy * hn, hc = cy * hn;
   float cosv = hc * ux + hs * uy;
   float sinv = fabsf(ux * hs - uy * hc);
+  tail[6] = sinv; tail[7] = -cosv;
   // feet (kick_env.py:538-576)
   float fl[3] = {co.lf.x, co.lf.y, co.lf.z}, fr[3] = {co.rf.x, co.rf.y, co.rf.z};
   feet_no_cleats(fl, feet);
   feet_no_cleats(fr, feet + 4);
   co.lf = mk(fl[0], fl[1], fl[2]); co.rf = mk(fr[0], fr[1], fr[2]);
-  // observation row (kick_env.py:1409-1415)
 #pragma unroll
-  for (int j = 0; j < BEZ_ND; ++j) { obs[j] = S.q[j]; obs[BEZ_ND + j] = S.qd[j]; }
-#pragma unroll
-  for (int i = 0; i < 6; ++i) obs[36 + i] = imu[i];
-  obs[42] = sinv; obs[43] = -cosv;
-#pragma unroll
-  for (int i = 0; i < 8; ++i) obs[44 + i] = feet[i];
-  obs[52] = P.ball_init[0]; obs[53] = P.ball_init[1];
+  for (int i = 0; i < 8; ++i) tail[8 + i] = feet[i];
+  tail[16] = P.ball_init[0]; tail[17] = P.ball_init[1];  // constant ball_init (quirk Q5, kick_env.py:776)
   // compute_bez_reward (kick_env.py:1224-1391)
-  float bx = S.ball_pos.x, by = S.ball_pos.y;
-  float dbx = bx - S.root_pos.x, dby = by - S.root_pos.y;
+  float bx = ball_pos.x, by = ball_pos.y;
+  float dbx = bx - root_pos.x, dby = by - root_pos.y;
   float dbn = sqrtf(dbx * dbx + dby * dby);
   float vel_fwd = (dbx / dbn) * v.x + (dby / dbn) * v.y;
   float dgx = P.goal[0] - bx, dgy = P.goal[1] - by;
   float dgn = sqrtf(dgx * dgx + dgy * dgy);
   float b2gx = dgx / dgn, b2gy = dgy / dgn;
-  float ball_fwd = b2gx * S.ball_lin.x + b2gy * S.ball_lin.y;
-  float igx = P.goal[0] - P.ball_init[0], igy = P.goal[1] - P.ball_init[1];
-  float ign = sqrtf(igx * igx + igy * igy);
-  float goal_angle_diff = fabsf(atan2f(igy / ign, igx / ign) - atan2f(b2gy, b2gx));
+  float ball_fwd = b2gx * ball_lin.x + b2gy * ball_lin.y;
+  float goal_angle_diff = fabsf(P.ang_init - atan2f(b2gy, b2gx));
   float vel_reward = sqrtf(dot(v, v) + dot(w, w));
-  float pn = 0.f;
-#pragma unroll
-  for (int j = 0; j < BEZ_ND; ++j) { float d = (float)BEZ_DOF_DEFAULT[j] - S.q[j]; pn = fmaf(d, d, pn); }
   float pos_reward = sqrtf(pn);
-  float height = fabsf(0.325f - S.root_pos.z);
+  float height = fabsf(0.325f - root_pos.z);
   float kx = bx - P.ball_init[0], ky = by - P.ball_init[1];
   float kicked = sqrtf(kx * kx + ky * ky);
   float height_vel_pos = height + (vel_reward * 0.05f + pos_reward * 0.05f);
   float r_after = ball_fwd * 0.1f - height_vel_pos;
   float r_before = ball_fwd * 0.1f + (vel_fwd * 0.05f - height);
   float reward = kicked > 0.3f ? r_after : r_before;
-  if (S.root_pos.z < 0.275f) { reset = 1; reward = -1.f; }
-  float tx = S.root_pos.x - P.bez_init[0], ty = S.root_pos.y - P.bez_init[1];
+  if (root_pos.z < 0.275f) { reset = 1; reward = -1.f; }
+  float tx = root_pos.x - P.bez_init[0], ty = root_pos.y - P.bez_init[1];
   if (sqrtf(tx * tx + ty * ty) > 0.5f) { reset = 1; reward = -1.f; }
   if (goal_angle_diff > 1.5708f) { reset = 1; reward = -1.f; }
   if (dgn < 0.05f) { reset = 1; reward = 100.0f - 100.0f * ((float)progress / (float)P.max_len); }
   if (progress >= (int64_t)P.max_len) { reset = 1; reward = 0.f; }
   rew = reward;
+}
+
+BEZ_DEV void env_observe_reward(const Params& P, const EnvState& S, CfOut& co, float* prev, float* feet, float* obs,
+                                float& rew, int64_t& reset, int64_t progress) {
+  float pn = 0.f;
+#pragma unroll
+  for (int j = 0; j < BEZ_ND; ++j) {
+    obs[j] = S.q[j]; obs[BEZ_ND + j] = S.qd[j];  // kick_env.py:1409-1410
+    float d = (float)BEZ_DOF_DEFAULT[j] - S.q[j];
+    pn = fmaf(d, d, pn);
+  }
+  env_observe_core(P, S.root_pos, S.rq, S.root_lin, S.root_ang, S.ball_pos, S.ball_lin, co, prev, feet, obs + 36, pn, rew, reset, progress);
 }
 
 // ---- the fused kernel: PRE (targets) / SIM (substeps) / POST (bookkeeping, reset, obs, reward)

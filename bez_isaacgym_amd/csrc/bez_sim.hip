@@ -50,6 +50,7 @@ struct BezSim {
   float* feet_aos = nullptr;     // (N,8)
   float* dr[BEZ_PARAM_COUNT] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  unsigned long long* stamps = nullptr;  // diagnostic builds only
 };
 
 namespace {
@@ -74,6 +75,11 @@ Params make_params(const BezSim* s, const float* actions) {
   P.n = s->n; P.substeps = c.substeps; P.max_len = c.max_episode_length;
   P.use_prev = (!(c.flags & BEZ_FLAG_IMU_PREV_ALIAS) || s->obs_calls == 0) ? 1 : 0;
   P.dt = c.dt; P.h = c.dt / (float)c.substeps;
+  {
+    float igx = c.goal[0] - c.ball_init[0], igy = c.goal[1] - c.ball_init[1];
+    float ign = std::sqrt(igx * igx + igy * igy);
+    P.ang_init = std::atan2(igy / ign, igx / ign);
+  }
   for (int i = 0; i < 3; ++i) P.g[i] = c.gravity[i];
   P.kp = c.kp; P.kd = c.kd; P.armature = c.armature; P.effort = c.effort; P.vel_limit = c.vel_limit;
   P.jfric = c.joint_friction; P.mu = c.plane_friction; P.clip = c.clip_actions;
@@ -86,6 +92,7 @@ Params make_params(const BezSim* s, const float* actions) {
   P.timeout = s->timeout; P.episode = s->episode; P.actions = actions;
   P.dr_friction = s->dr[BEZ_PARAM_FRICTION]; P.dr_kp = s->dr[BEZ_PARAM_KP_SCALE]; P.dr_kd = s->dr[BEZ_PARAM_KD_SCALE];
   P.dr_mass = s->dr[BEZ_PARAM_MASS_SCALE]; P.dr_gravity = s->dr[BEZ_PARAM_GRAVITY];
+  P.stamps = s->stamps;
   return P;
 }
 bool has_dr(const BezSim* s) {
@@ -244,9 +251,12 @@ int launch_step(BezSim* s, const float* actions, hipStream_t stream) {
   const bool dr = has_dr(s);
   if constexpr (SIM && PRE == POST) {
     if (use_ws_kernel()) {
-      dim3 grid((s->n + WS_ENVS - 1) / WS_ENVS), block(WS_BLOCK);
-      if (dr) hipLaunchKernelGGL((step_kernel_ws<PRE, POST, true>), grid, block, 0, stream, P);
-      else hipLaunchKernelGGL((step_kernel_ws<PRE, POST, false>), grid, block, 0, stream, P);
+      static const int ne = [] { const char* v = std::getenv("BEZ_WS_ENVS"); int k = v ? std::atoi(v) : 64; return (k == 16 || k == 32) ? k : 64; }();
+      dim3 grid((s->n + ne - 1) / ne), block(WS_BLOCK);
+      if (dr) hipLaunchKernelGGL((step_kernel_ws<PRE, POST, true, 64>), dim3((s->n + 63) / 64), block, 0, stream, P);
+      else if (ne == 64) hipLaunchKernelGGL((step_kernel_ws<PRE, POST, false, 64>), grid, block, 0, stream, P);
+      else if (ne == 32) hipLaunchKernelGGL((step_kernel_ws<PRE, POST, false, 32>), grid, block, 0, stream, P);
+      else hipLaunchKernelGGL((step_kernel_ws<PRE, POST, false, 16>), grid, block, 0, stream, P);
       hipError_t e = hipGetLastError();
       if (e != hipSuccess) return fail(s, -2, "step_kernel_ws launch", e);
       if (POST) s->obs_calls += 1;
@@ -502,6 +512,19 @@ int bez_sim_set_env_params(BezSim* s, int param, const float* values_dev, void* 
   HIP_TRY(s, hipMemcpyAsync(s->dr[param], values_dev, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
   return 0;
 }
+
+#ifdef BEZ_WS_STAMPS
+/* diagnostic build only: run one fused step and return the 4 x 32 s_memtime stamps of workgroup 0 */
+int bez_sim_debug_stamps(BezSim* s, const float* actions_dev, unsigned long long* out_host) {
+  if (!s->stamps) { HIP_TRY(s, hipMalloc((void**)&s->stamps, 128 * sizeof(unsigned long long))); }
+  HIP_TRY(s, hipMemset(s->stamps, 0, 128 * sizeof(unsigned long long)));
+  int rc = bez_sim_step(s, actions_dev, nullptr);
+  if (rc) return rc;
+  HIP_TRY(s, hipDeviceSynchronize());
+  HIP_TRY(s, hipMemcpy(out_host, s->stamps, 128 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  return 0;
+}
+#endif
 
 int bez_sim_seed(BezSim* s, uint64_t seed) { if (!s) return -1; s->cfg.seed = seed; return 0; }
 
