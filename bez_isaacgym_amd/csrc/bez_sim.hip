@@ -245,6 +245,18 @@ bool use_ws_kernel() {
   return ws;
 }
 
+// PMC calibration: dword-per-lane coalesced read of `n` floats (the access shape of the step kernels' state loads)
+__global__ void calib_read_kernel(const float* __restrict__ in, float* __restrict__ out, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  float acc = 0.f;
+  for (; i < n; i += (size_t)gridDim.x * blockDim.x) acc += in[i];
+  if (acc == 12345.678f) out[0] = acc;  // keeps the loads alive, never true for the calibration data
+}
+__global__ void calib_write_kernel(float* __restrict__ out, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = 1.0f;
+}
+
 template <bool PRE, bool SIM, bool POST>
 int launch_step(BezSim* s, const float* actions, hipStream_t stream) {
   Params P = make_params(s, actions);
@@ -525,6 +537,15 @@ int bez_sim_debug_stamps(BezSim* s, const float* actions_dev, unsigned long long
   return 0;
 }
 #endif
+
+/* Measurement utility (tools/pmc_calibrate.py): known-size dword-per-lane read / write kernels to calibrate the
+ * FETCH_SIZE / WRITE_SIZE counters for this library's access shape (MI355X_MICROARCH.md: only 16 B/lane is calibrated). */
+int bez_sim_calibrate(void* buf_dev, uint64_t n_floats, int32_t write, void* stream) {
+  if (!buf_dev || n_floats == 0) return -1;
+  if (write) hipLaunchKernelGGL(calib_write_kernel, dim3(2048), dim3(256), 0, (hipStream_t)stream, (float*)buf_dev, (size_t)n_floats);
+  else hipLaunchKernelGGL(calib_read_kernel, dim3(2048), dim3(256), 0, (hipStream_t)stream, (const float*)buf_dev, (float*)buf_dev, (size_t)n_floats);
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}
 
 int bez_sim_seed(BezSim* s, uint64_t seed) { if (!s) return -1; s->cfg.seed = seed; return 0; }
 

@@ -51,6 +51,7 @@ def load_library():
         "bez_sim_reset_indexed": (C.c_int, [vp, vp, i32, vp]),
         "bez_sim_set_env_params": (C.c_int, [vp, C.c_int, fp, vp]),
         "bez_sim_seed": (C.c_int, [vp, u64]),
+        "bez_sim_calibrate": (C.c_int, [vp, u64, i32, vp]),
         "bez_sim_time_steps": (C.c_int, [vp, fp, i32, vp, C.POINTER(C.c_float)]),
     }
     for name, (res, args) in sigs.items():
@@ -65,7 +66,8 @@ EXPORTS = ["bez_sim_default_config", "bez_sim_create", "bez_sim_destroy", "bez_s
            "bez_sim_set_dof_position_target_tensor", "bez_sim_set_dof_position_target_tensor_indexed",
            "bez_sim_set_net_contact_force_tensor", "bez_sim_set_prev_lin_vel_tensor", "bez_sim_set_flags",
            "bez_sim_set_obs_calls", "bez_sim_pre_physics", "bez_sim_simulate", "bez_sim_post_physics", "bez_sim_observe_reward", "bez_sim_step",
-           "bez_sim_step_many", "bez_sim_reset_indexed", "bez_sim_set_env_params", "bez_sim_seed", "bez_sim_time_steps"]
+           "bez_sim_step_many", "bez_sim_reset_indexed", "bez_sim_set_env_params", "bez_sim_seed", "bez_sim_time_steps",
+           "bez_sim_calibrate"]
 
 
 class _DevView:

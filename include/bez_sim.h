@@ -174,6 +174,10 @@ int bez_sim_set_obs_calls(BezSim* sim, int64_t calls);
 /* Re-keys the reset-noise stream (utils/utils.py:45-70 set_seed). */
 int bez_sim_seed(BezSim* sim, uint64_t seed);
 
+/* Measurement utility: launches a known-size dword-per-lane read (write=0) or write (write=1) of n_floats floats of
+ * buf_dev, to calibrate rocprofv3's FETCH_SIZE / WRITE_SIZE for this library's access shape. */
+int bez_sim_calibrate(void* buf_dev, uint64_t n_floats, int32_t write, void* stream);
+
 /* Average device time [ms] of the fused step kernel over `n_steps` launches on `stream`,
  * measured with HIP events recorded on that same stream (bench.py roofline leg). */
 int bez_sim_time_steps(BezSim* sim, const float* actions_dev, int32_t n_steps, void* stream, float* avg_ms);
