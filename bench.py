@@ -23,6 +23,20 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 ACTION_RING = 64               # distinct pre-generated action batches cycled through
 
 
+def pmc_traffic(num_envs):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary (separate FETCH_SIZE /
+    WRITE_SIZE passes with the gfx950 correction; profiles/r01_pmc_traffic.json).  bench.py cannot run under the
+    profiler itself, so this is the profiled figure for the same kernel and size, or None when it does not apply."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    try:
+        d = json.load(open(path))
+        if int(d["num_envs"]) == int(num_envs):
+            return float(d["hbm_bytes_per_launch"]["total"])
+    except Exception:
+        pass
+    return None
+
+
 def cpu_baseline(num_envs, seconds_target=12.0):
     """The oracle (kind 'port': this build's CPU restatement; the reference's own CPU pipeline is the closed
     PhysX binary and cannot run) on the host cores, bounded sample of the same workload."""
@@ -182,10 +196,11 @@ def main():
                                    "natural resets included" % n,
                        "envs_per_gpu": n, "total_envs": total_envs, "launch": args.launch, "parallelism": "env-sharded x%d" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "bez::step_kernel<true,true,true,false>", "kernel_ms": kernel_ms,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(n),
+                         "kernel": "bez::step_kernel_ws<PRE,POST> (fused control step)", "kernel_ms": kernel_ms,
                          "algorithmic_bytes_per_launch": ALGO_BYTES_PER_ENV_STEP * n,
-                         "note": "N=4096 is latency/occupancy-bound (64 waves on 256 CUs, working set L2-resident): see DESIGN.md"},
+                         "traffic_unit": "bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_pmc_traffic.json)",
+                         "note": "N=4096 is latency-bound (64 workgroups x 4 role waves on 256 CUs, serial ABA chains): see DESIGN.md"},
         }
         if ppo is not None:
             out["ppo"] = ppo
