@@ -45,7 +45,7 @@ class RunningMeanStd(nn.Module):
     @torch.no_grad()
     def update(self, x):
         x = x.reshape(-1, *self.running_mean.shape).double()
-        n = torch.tensor(float(x.shape[0]), dtype=torch.float64, device=x.device)
+        n = torch.full((), float(x.shape[0]), dtype=torch.float64, device=x.device)  # fill kernel: graph-capturable
         s1, s2 = x.sum(0), (x * x).sum(0)
         if _dist_on():  # moments of the GLOBAL batch: every rank ends with identical statistics
             flat = torch.cat([s1.reshape(-1), s2.reshape(-1), n.reshape(1)])
@@ -118,6 +118,8 @@ def policy_kl(p0_mu, p0_sigma, p1_mu, p1_sigma):
 
 
 class AdaptiveScheduler:
+    """rl_games AdaptiveScheduler; `update_` is the same rule on a device-resident lr tensor (no host sync)."""
+
     def __init__(self, kl_threshold=0.008):
         self.min_lr, self.max_lr, self.kl_threshold = 1e-6, 1e-2, kl_threshold
 
@@ -127,6 +129,14 @@ class AdaptiveScheduler:
         if kl < 0.5 * self.kl_threshold:
             lr = min(lr * 1.5, self.max_lr)
         return lr
+
+    @torch.no_grad()
+    def update_(self, lr_t, kl_t):
+        cur = lr_t.value if hasattr(lr_t, "value") else lr_t
+        down = torch.clamp(cur / 1.5, min=self.min_lr)
+        lr1 = torch.where(kl_t > 2.0 * self.kl_threshold, down, cur)
+        up = torch.clamp(lr1 * 1.5, max=self.max_lr)
+        lr_t.copy_(torch.where(kl_t < 0.5 * self.kl_threshold, up, lr1))
 
 
 def discount_values(gamma, tau, fdones, last_values, mb_fdones, mb_values, mb_rewards):
@@ -149,6 +159,21 @@ def discount_values(gamma, tau, fdones, last_values, mb_fdones, mb_values, mb_re
 def swap_and_flatten01(x):
     s = x.shape
     return x.transpose(0, 1).reshape(s[0] * s[1], *s[2:])
+
+
+class _CpuLr:
+    """CPU fallback of the device-resident lr tensor (tests): same interface, writes through to the param groups."""
+
+    def __init__(self, optimizer, lr):
+        self.optimizer, self.value = optimizer, torch.tensor(float(lr))
+
+    def copy_(self, t):
+        self.value = t.detach().clone().reshape(())
+        for g in self.optimizer.param_groups:
+            g["lr"] = float(self.value)
+
+    def item(self):
+        return float(self.value)
 
 
 class A2CAgent:
@@ -203,15 +228,27 @@ class A2CAgent:
         self.model = ModelA2CContinuousLogStd(obs_dim, act_dim, units).to(self.device)
         self.running_mean_std = RunningMeanStd((obs_dim,)).to(self.device) if self.normalize_input else None
         self.value_mean_std = RunningMeanStd((1,)).to(self.device) if self.normalize_value else None
-        self.optimizer = torch.optim.Adam(self.model.parameters(), lr=self.last_lr, eps=1e-8)
+        on_gpu = self.device.type == "cuda"
+        # lr lives on the device so that the adaptive-KL rule needs no host sync and the update can be graph-captured
+        self.lr_t = torch.tensor(self.last_lr, device=self.device, dtype=torch.float32)
+        self.optimizer = torch.optim.Adam(self.model.parameters(), lr=self.lr_t if on_gpu else self.last_lr, eps=1e-8,
+                                          capturable=on_gpu)
+        if not on_gpu:
+            self.lr_t = _CpuLr(self.optimizer, self.last_lr)
         self.scaler = torch.amp.GradScaler("cuda", enabled=self.mixed_precision)
+        g = c.get("hip_graphs", "auto")
+        self.use_graphs = bool(on_gpu and world == 1 and (g is True or g == "auto"))
+        self.graph_warmup_epochs = 2
+        self._g_rollout = self._g_update = self._pool = None
+        self.mb = None
+        self._ep_hist = []
         self.epoch_num, self.frame = 0, 0
         self.games_to_track = 100
         self.game_rewards, self.game_lengths = [], []
         self.last_mean_rewards = -100500.0
         self.current_rewards = torch.zeros(self.num_actors, device=self.device)
         self.current_lengths = torch.zeros(self.num_actors, device=self.device)
-        self.dones = torch.ones(self.num_actors, dtype=torch.uint8, device=self.device)
+        self.dones = torch.ones(self.num_actors, dtype=torch.float32, device=self.device)
         self._flat_grad = None
         if _dist_on():  # identical replicas (hvd.broadcast_parameters equivalent)
             for p in self.model.parameters():
@@ -240,48 +277,58 @@ class A2CAgent:
         return self.get_action_values(obs)["values"]
 
     def env_reset(self):
-        return self.vec_env.reset()["obs"].to(self.device)
+        obs = self.vec_env.reset()["obs"].to(self.device)
+        if self.obs is None or self.obs.shape != obs.shape:
+            self.obs = obs.clone()
+        else:
+            self.obs.copy_(obs)
+        return self.obs
 
-    def play_steps(self):
+    def _alloc_static(self):
+        """Rollout / dataset storage allocated ONCE: fixed addresses are what lets the rollout and the minibatch update be
+        captured as HIP graphs and replayed without a host round trip per op."""
         H, N, dev = self.horizon, self.num_actors, self.device
-        mb_obs = torch.zeros(H, N, self.obs_dim, device=dev)
-        mb_act = torch.zeros(H, N, self.act_dim, device=dev)
-        mb_mu, mb_sigma = torch.zeros_like(mb_act), torch.zeros_like(mb_act)
-        mb_val, mb_rew = torch.zeros(H, N, 1, device=dev), torch.zeros(H, N, 1, device=dev)
-        mb_neglogp, mb_dones = torch.zeros(H, N, device=dev), torch.zeros(H, N, device=dev)
-        for n in range(H):
+        z = lambda *s: torch.zeros(*s, device=dev)
+        self.mb = dict(obs=z(H, N, self.obs_dim), act=z(H, N, self.act_dim), mu=z(H, N, self.act_dim), sigma=z(H, N, self.act_dim),
+                       val=z(H, N, 1), rew=z(H, N, 1), neglogp=z(H, N), dones=z(H, N))
+        B = self.batch_size
+        self.dataset = dict(old_values=z(B, 1), old_logp=z(B), advantages=z(B), returns=z(B, 1), actions=z(B, self.act_dim),
+                            obs=z(B, self.obs_dim), mu=z(B, self.act_dim), sigma=z(B, self.act_dim))
+        # episode statistics accumulated on the device (no .nonzero()/.tolist() inside the rollout)
+        self.ep_stats = torch.zeros(3, device=dev, dtype=torch.float64)  # [finished episodes, sum of returns, sum of lengths]
+        self.kl_acc = torch.zeros(self.mini_epochs, device=dev)
+        self.loss_acc = torch.zeros(2, device=dev)
+
+    @torch.no_grad()
+    def _rollout_impl(self):
+        """horizon_length env steps + GAE + dataset preparation; device ops only (capturable)."""
+        mb, dev = self.mb, self.device
+        for n in range(self.horizon):
             res = self.get_action_values(self.obs)
-            mb_obs[n], mb_dones[n] = self.obs, self.dones.float()
-            mb_act[n], mb_mu[n], mb_sigma[n] = res["actions"], res["mus"], res["sigmas"]
-            mb_val[n], mb_neglogp[n] = res["values"], res["neglogpacs"]
+            mb["obs"][n].copy_(self.obs); mb["dones"][n].copy_(self.dones)
+            mb["act"][n].copy_(res["actions"]); mb["mu"][n].copy_(res["mus"]); mb["sigma"][n].copy_(res["sigmas"])
+            mb["val"][n].copy_(res["values"]); mb["neglogp"][n].copy_(res["neglogpacs"])
             obs_dict, rew, dones, infos = self.vec_env.step(torch.clamp(res["actions"], -1.0, 1.0))
-            self.obs = obs_dict["obs"].to(dev)
+            self.obs.copy_(obs_dict["obs"])
             rew = rew.to(dev).float().unsqueeze(1)
             shaped = rew * self.reward_scale
             if self.value_bootstrap and "time_outs" in infos:
                 shaped = shaped + self.gamma * res["values"] * infos["time_outs"].to(dev).unsqueeze(1).float()
-            mb_rew[n] = shaped
-            self.dones = dones.to(dev).to(torch.uint8)
+            mb["rew"][n].copy_(shaped)
+            self.dones.copy_(dones.to(dev).float())
             self.current_rewards += rew.squeeze(1)
             self.current_lengths += 1
-            done_idx = self.dones.nonzero(as_tuple=False).squeeze(-1)
-            if done_idx.numel():
-                self.game_rewards = (self.game_rewards + self.current_rewards[done_idx].tolist())[-self.games_to_track:]
-                self.game_lengths = (self.game_lengths + self.current_lengths[done_idx].tolist())[-self.games_to_track:]
-                not_done = 1.0 - self.dones.float()
-                self.current_rewards *= not_done
-                self.current_lengths *= not_done
+            self.ep_stats[0] += self.dones.sum()
+            self.ep_stats[1] += (self.current_rewards * self.dones).sum()
+            self.ep_stats[2] += (self.current_lengths * self.dones).sum()
+            not_done = 1.0 - self.dones
+            self.current_rewards *= not_done
+            self.current_lengths *= not_done
         last_values = self.get_values(self.obs)
-        advs = discount_values(self.gamma, self.tau, self.dones.float(), last_values, mb_dones, mb_val, mb_rew)
-        returns = advs + mb_val
-        batch = dict(obs=swap_and_flatten01(mb_obs), actions=swap_and_flatten01(mb_act), mus=swap_and_flatten01(mb_mu),
-                     sigmas=swap_and_flatten01(mb_sigma), values=swap_and_flatten01(mb_val),
-                     returns=swap_and_flatten01(returns), neglogpacs=swap_and_flatten01(mb_neglogp))
-        return batch
-
-    # ------------------------------------------------------------------ update
-    def prepare_dataset(self, batch):
-        values, returns = batch["values"], batch["returns"]
+        advs = discount_values(self.gamma, self.tau, self.dones, last_values, mb["dones"], mb["val"], mb["rew"])
+        returns = advs + mb["val"]
+        # ---- prepare_dataset (rl_games a2c_continuous.prepare_dataset)
+        values, returns = swap_and_flatten01(mb["val"]), swap_and_flatten01(returns)
         if self.normalize_value:
             self.value_mean_std.train()
             values = self.value_mean_std(values)
@@ -290,16 +337,40 @@ class A2CAgent:
         adv = (returns - values).sum(dim=1)
         if self.normalize_advantage:
             if _dist_on():
-                st = torch.stack([adv.sum(), (adv * adv).sum(), torch.tensor(float(adv.numel()), device=adv.device)]).double()
+                st = torch.stack([adv.sum(), (adv * adv).sum(), torch.full((), float(adv.numel()), device=adv.device)]).double()
                 dist.all_reduce(st)
                 mean = st[0] / st[2]
                 std = torch.sqrt(((st[1] / st[2] - mean * mean) * st[2] / (st[2] - 1)).clamp_min(0))
                 adv = (adv - mean.float()) / (std.float() + 1e-8)
             else:
                 adv = (adv - adv.mean()) / (adv.std() + 1e-8)
-        self.dataset = dict(old_values=values, old_logp=batch["neglogpacs"], advantages=adv, returns=returns,
-                            actions=batch["actions"], obs=batch["obs"], mu=batch["mus"], sigma=batch["sigmas"])
+        ds = self.dataset
+        ds["old_values"].copy_(values); ds["returns"].copy_(returns); ds["advantages"].copy_(adv)
+        ds["old_logp"].copy_(swap_and_flatten01(mb["neglogp"])); ds["actions"].copy_(swap_and_flatten01(mb["act"]))
+        ds["obs"].copy_(swap_and_flatten01(mb["obs"])); ds["mu"].copy_(swap_and_flatten01(mb["mu"]))
+        ds["sigma"].copy_(swap_and_flatten01(mb["sigma"]))
 
+    def play_steps(self):
+        """Rollout + dataset.  With HIP graphs enabled the first call after warm-up captures, later calls replay."""
+        if self.mb is None:
+            self._alloc_static()
+        if not self.use_graphs or self.epoch_num < self.graph_warmup_epochs:
+            self._rollout_impl()
+        elif self._g_rollout is None:
+            torch.cuda.synchronize()
+            self._g_rollout = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self._g_rollout, pool=self._graph_pool()):
+                self._rollout_impl()
+        else:
+            self._g_rollout.replay()
+        return self.dataset
+
+    def _graph_pool(self):
+        if self._pool is None:
+            self._pool = torch.cuda.graph_pool_handle()
+        return self._pool
+
+    # ------------------------------------------------------------------ update
     def _allreduce_grads(self):
         """ONE fused all-reduce of the flat fp32 gradient (124 237 elements = 497 KB) per optimiser step: the message
         is latency-bound on xGMI, so bucketing per parameter would only multiply the latency."""
@@ -318,7 +389,8 @@ class A2CAgent:
             p.grad.copy_(self._flat_grad[off:off + p.numel()].view_as(p.grad))
             off += p.numel()
 
-    def calc_gradients(self, mb):
+    def calc_gradients(self, mb, kl_out, loss_out):
+        """One optimiser step on minibatch `mb`; device ops only.  KL is written to kl_out (0-dim view), losses added to loss_out."""
         self.model.train()
         if self.normalize_input:
             self.running_mean_std.train()
@@ -358,36 +430,62 @@ class A2CAgent:
             if _dist_on():
                 dist.all_reduce(kl)
                 kl /= dist.get_world_size()
-        return a_l.detach(), c_l.detach(), ent.detach(), kl, b_l.detach()
+            kl_out.add_(kl / self.num_minibatches)
+            loss_out[0] += a_l.detach(); loss_out[1] += c_l.detach()
+
+    def _minibatch(self, i):
+        sl = slice(i * self.minibatch_size, (i + 1) * self.minibatch_size)
+        return {k: v[sl] for k, v in self.dataset.items()}
+
+    def _update_impl(self):
+        """mini_epochs x num_minibatches optimiser steps + the adaptive LR rule, all on the device."""
+        self.kl_acc.zero_(); self.loss_acc.zero_()
+        for ep in range(self.mini_epochs):
+            for i in range(self.num_minibatches):
+                self.calc_gradients(self._minibatch(i), self.kl_acc[ep], self.loss_acc)
+            if self.is_adaptive_lr:
+                self.scheduler.update_(self.lr_t, self.kl_acc[ep])
+
+    def run_update(self):
+        if not self.use_graphs or self.epoch_num < self.graph_warmup_epochs:
+            self._update_impl()
+        elif self._g_update is None:
+            torch.cuda.synchronize()
+            self._g_update = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self._g_update, pool=self._graph_pool()):
+                self._update_impl()
+        else:
+            self._g_update.replay()
+
+    def _drain_episode_stats(self):
+        """One device->host read per epoch: finished-episode count / return / length sums of this epoch's rollout."""
+        cnt, rsum, lsum = self.ep_stats.tolist()
+        self.ep_stats.zero_()
+        if cnt > 0:
+            self._ep_hist.append((cnt, rsum, lsum))
+            while len(self._ep_hist) > 1 and sum(c for c, _, _ in self._ep_hist[1:]) >= self.games_to_track:
+                self._ep_hist.pop(0)
+        tot = sum(c for c, _, _ in self._ep_hist)
+        if tot > 0:  # mean over (at least) the last games_to_track finished episodes
+            self.game_rewards = [sum(r for _, r, _ in self._ep_hist) / tot]
+            self.game_lengths = [sum(l for _, _, l in self._ep_hist) / tot]
 
     def train_epoch(self):
         t0 = time.perf_counter()
-        batch = self.play_steps()
+        self.play_steps()
         if self.device.type == "cuda":
             torch.cuda.synchronize()
         t_play = time.perf_counter() - t0
-        self.prepare_dataset(batch)
-        kls, a_ls, c_ls = [], [], []
-        for _ in range(self.mini_epochs):
-            ep_kls = []
-            for i in range(self.num_minibatches):
-                sl = slice(i * self.minibatch_size, (i + 1) * self.minibatch_size)
-                mb = {k: v[sl] for k, v in self.dataset.items()}
-                a_l, c_l, ent, kl, b_l = self.calc_gradients(mb)
-                ep_kls.append(kl); a_ls.append(a_l); c_ls.append(c_l)
-            av_kl = torch.stack(ep_kls).mean().item()
-            if self.is_adaptive_lr:
-                self.last_lr = self.scheduler.update(self.last_lr, av_kl)
-                for g in self.optimizer.param_groups:
-                    g["lr"] = self.last_lr
-            kls.append(av_kl)
-        if self.device.type == "cuda":
-            torch.cuda.synchronize()
+        self.run_update()
+        self.last_lr = float(self.lr_t.item())  # the epoch's only other host sync
+        kls = self.kl_acc.tolist()
+        a_l, c_l = (self.loss_acc / (self.mini_epochs * self.num_minibatches)).tolist()
+        self._drain_episode_stats()
         t_total = time.perf_counter() - t0
         self.epoch_num += 1
         self.frame += self.batch_size * self.world
         return dict(play_time=t_play, update_time=t_total - t_play, total_time=t_total, kl=sum(kls) / len(kls),
-                    a_loss=torch.stack(a_ls).mean().item(), c_loss=torch.stack(c_ls).mean().item(), lr=self.last_lr)
+                    a_loss=a_l, c_loss=c_l, lr=self.last_lr)
 
     def train(self, max_epochs=None, log=print):
         self.obs = self.env_reset()
