@@ -82,7 +82,8 @@ def ppo_leg(args, rank, local_rank, world, n):
     params["config"]["minibatch_size"] = min(int(params["config"]["minibatch_size"]), n * int(params["config"]["horizon_length"]))
     agent = A2CAgent(params, venv, dev, rank=rank, world=world)
     agent.obs = agent.env_reset()
-    agent.train_epoch()  # warm-up (allocations, hipBLASLt heuristics)
+    for _ in range(4):  # warm-up: allocations, hipBLASLt heuristics, 2 eager epochs, then HIP-graph capture of rollout + update
+        agent.train_epoch()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()

@@ -231,8 +231,9 @@ class A2CAgent:
         on_gpu = self.device.type == "cuda"
         # lr lives on the device so that the adaptive-KL rule needs no host sync and the update can be graph-captured
         self.lr_t = torch.tensor(self.last_lr, device=self.device, dtype=torch.float32)
+        # fused + capturable Adam: takes GradScaler's found_inf / scale as tensors (no .item()), so scaler.step() is graph-safe
         self.optimizer = torch.optim.Adam(self.model.parameters(), lr=self.lr_t if on_gpu else self.last_lr, eps=1e-8,
-                                          capturable=on_gpu)
+                                          capturable=on_gpu, fused=on_gpu)
         if not on_gpu:
             self.lr_t = _CpuLr(self.optimizer, self.last_lr)
         self.scaler = torch.amp.GradScaler("cuda", enabled=self.mixed_precision)
