@@ -147,9 +147,7 @@ BEZ_DEV Hit ground_contact(const Params& P, float mu, V3 x, float z, SV V, Sym6&
       float vt = fsqrt(fmaf(vp.x, vp.x, vp.y * vp.y));
       float ct = fminf(mu * fn0 * frcp(fmaxf(vt, P.veps)), P.ct);
       float kt = P.h * ct;
-      Sym3 K = sym3zero();
-      K.xx = kt; K.yy = kt; K.zz = kn;
-      add_point_stiffness(IA, x, K);
+      add_point_stiffness_diag(IA, x, kt, kn);
       hit.x = x; hit.fn0 = fn0; hit.kn = kn; hit.ct = ct; hit.ftx0 = -ct * vp.x; hit.fty0 = -ct * vp.y;
       pA = pA - wrench_at(x, mk(hit.ftx0, hit.fty0, fn0));
     }

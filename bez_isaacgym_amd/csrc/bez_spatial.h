@@ -107,6 +107,20 @@ BEZ_DEV void add_point_stiffness(Sym6& I, V3 x, const Sym3& K) {
   I.A.zz += fmaf(-x.y, M.m20, x.x * M.m21);
 }
 
+// Same for K = diag(kt, kt, kn) (ground contact: tangential / normal point stiffness): the zero terms are dropped.
+//   M = [x]x K = [[0, -z kt, y kn], [z kt, 0, -x kn], [-y kt, x kt, 0]],  A += M [x]x^T,  B += M,  C += K
+BEZ_DEV void add_point_stiffness_diag(Sym6& I, V3 x, float kt, float kn) {
+  const float xt = x.x * kt, yt = x.y * kt, zt = x.z * kt, xn = x.x * kn, yn = x.y * kn;
+  I.B.m01 -= zt; I.B.m02 += yn; I.B.m10 += zt; I.B.m12 -= xn; I.B.m20 -= yt; I.B.m21 += xt;
+  I.C.xx += kt; I.C.yy += kt; I.C.zz += kn;
+  I.A.xx += fmaf(x.z, zt, x.y * yn);
+  I.A.yy += fmaf(x.z, zt, x.x * xn);
+  I.A.zz += fmaf(x.y, yt, x.x * xt);
+  I.A.xy -= x.x * yn;
+  I.A.xz -= x.x * zt;
+  I.A.yz -= x.y * zt;
+}
+
 // rotation matrix (body->world) of an xyzw unit quaternion
 BEZ_DEV M3 quat_to_mat(float x, float y, float z, float w) {
   M3 R;
