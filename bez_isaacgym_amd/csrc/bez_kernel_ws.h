@@ -10,7 +10,7 @@
 //             (bookkeeping, reset, observations, reward)
 // Chains only meet at the torso: per substep the roles exchange 27 floats (articulated inertia + bias of a chain)
 // up and 6 floats (torso acceleration) down through LDS, lds[slot * 64 + lane] (bank = lane, conflict-free),
-// with five workgroup barriers.  Role dispatch is a scalar branch on readfirstlane(wave id), every role executes
+// with six workgroup barriers.  Role dispatch is a scalar branch on readfirstlane(wave id), every role executes
 // the same number of barriers.  Because a wave only ever holds ONE chain, all per-link data of passes 1-3 stays
 // in VGPRs (no scratch, no LDS staging of the pass-3 operands).
 // Actions (N,18) and observations (N,54) are row-major in HBM: each workgroup's 64 rows are one contiguous block,
@@ -29,11 +29,13 @@ enum : int {
   X_BALL = 13,   // pos3 lin3 ang3
   X_IA = 22,     // 3 roles x (Sym6 21 + bias 6)
   X_A0 = 103,    // torso spatial acceleration
-  X_DEPTH = 109, // deepest ball/box penetration found by each leg
+  X_DEPTH = 109, // (unused since the root role selects; kept so slot numbers stay stable)
   X_FL = 111,    // ball<->link force on the link (3) + contact point rel. ball centre (3)
   X_FOOT = 117,  // net contact force on left / right foot
   X_PSUM = 123,  // per chain role: sum of (default - q)^2 over its joints
-  X_SLOTS = 126
+  X_CAND = 126,  // per leg: depth, link, n(3), P(3), V(6) of its deepest ball/box candidate = 14 floats x 2
+  X_FOLD = 154,  // winner side, link, A(6), f0p(3), x(3), xb(3) = 17 floats (written by the root role)
+  X_SLOTS = 171
 };
 constexpr int WS_OBS_STRIDE = 54;  // rows unpadded: the staged block IS the contiguous HBM image (float4 copy-out)
 constexpr int WS_ACT_STRIDE = 19;
@@ -115,7 +117,7 @@ struct ChainDyn { float mu; V3 g; };
 // IAo/pAo), the pass-3 operands p3[LEN], the contact rows of the chain-end link, and (legs) the ball/box candidate.
 template <int FIRST, int LEN, bool LEG>
 BEZ_DEV void ws_chain_pass1(const Params& P, const ChainDyn& D, const float* ms, const RootView& R, const float* q, const float* qd,
-                            LinkInertia* LI, SV* pAl, SV* Sl, SV* cbl, Sym6& Kc, SV& pc, BallSel& sel) {
+                            LinkInertia* LI, SV* pAl, SV* Sl, SV* cbl, M3& Eend, V3& rend, SV& Vend, BallSel& sel, SV& Vsel) {
   M3 E = R.E0;
   V3 r = mk(0, 0, 0);
   SV V = R.V0;
@@ -124,10 +126,12 @@ BEZ_DEV void ws_chain_pass1(const Params& P, const ChainDyn& D, const float* ms,
     constexpr int L = FIRST + i;
     link_kinematics<L>(q[i], qd[i], E, r, V, Sl[i], cbl[i]);
     link_inertia<L>(ms[i], D.g, E, r, V, LI[i], pAl[i]);
-    if constexpr (LEG && link_has_box(L)) test_box<link_box(L)>(E, r, R.bc, sel);
+    if constexpr (LEG && link_has_box(L)) {
+      test_box<link_box(L)>(E, r, R.bc, sel);
+      if (sel.link == L) Vsel = V;  // this box just became the deepest candidate: keep its link velocity
+    }
   });
-  Kc = sym6zero(); pc = svzero();
-  ws_ground_points<FIRST + LEN - 1>(P, D.mu, R.root_z, E, r, V, Kc, pc);
+  Eend = E; rend = r; Vend = V;  // chain-end frame / velocity for the ground points
 }
 
 template <int FIRST, int LEN, bool LEG>
@@ -142,7 +146,7 @@ BEZ_DEV void ws_chain_pass2(const Params& P, const ChainDyn& D, const float* kps
     add_link_inertia(IA, LI[i]);
     pA = pA + pAl[i];
     if constexpr (LEG && link_has_box(L)) {
-      if (mine && sel.link == L) {  // contact operands were prepared once by ws_ball_contact_prepare
+      if (mine && sel.link == L) {  // contact operands were prepared once, by the root role (X_FOLD)
         add_point_stiffness(IA, sel.x, sel.A);
         pA = pA - wrench_at(sel.x, sel.f0p);
       }
@@ -155,23 +159,6 @@ BEZ_DEV void ws_chain_pass2(const Params& P, const ChainDyn& D, const float* kps
   });
   add_to(IAo, IA);
   pAo = pAo + pA;
-}
-
-// Ball<->link contact operands for the (per-lane, runtime) selected link, evaluated ONCE per wave instead of once per
-// candidate link: the link's velocity is V0 + sum_{j <= idx} S_j qd_j.  Clears sel.link when the contact is not active.
-template <int FIRST, int LEN>
-BEZ_DEV void ws_ball_contact_prepare(const Params& P, const ChainDyn& D, const RootView& R, const BallBody& ball, const SV* Sl,
-                                     const float* qd, bool mine, BallSel& sel) {
-  if (mine) {
-    SV V = R.V0;
-    const int idx = sel.link - FIRST;
-    static_for<LEN>([&](auto J) {
-      constexpr int j = decltype(J)::value;
-      const float w = (j <= idx) ? qd[j] : 0.f;
-      V = V + Sl[j] * w;
-    });
-    ball_link_contact(P, D.mu, R.ball_ang, R.ball_lin, ball, R.bc, V, sel);
-  }
 }
 
 // pass 3: joint accelerations, semi-implicit Euler with the velocity clamp; returns the chain-end acceleration
@@ -309,20 +296,32 @@ BEZ_DEV void ws_leg_role(const Params& P, float* lds, int lane, int e, bool acti
     const bool keep = (s == P.substeps - 1);
     RootView R = load_root_view(lds, lane);
     LinkInertia LI[LEN]; SV pAl[LEN], Sl[LEN], cbl[LEN];
-    Sym6 Kc; SV pc;
     BallSel sel;
     sel.link = -1; sel.depth = 0.f; sel.n = sel.P = sel.f0p = sel.x = sel.xb = mk(0, 0, 0); sel.A = sym3zero();
-    ws_chain_pass1<FIRST, LEN, true>(P, D, ms, R, q, qd, LI, pAl, Sl, cbl, Kc, pc, sel);
-    XS(X_DEPTH + side) = sel.depth;
+    M3 Eend; V3 rend; SV Vend, Vsel = svzero();
+    ws_chain_pass1<FIRST, LEN, true>(P, D, ms, R, q, qd, LI, pAl, Sl, cbl, Eend, rend, Vend, sel, Vsel);
+    {  // publish this leg's deepest ball/box candidate; the root role picks the winner and prepares the contact
+      const int c0 = X_CAND + side * 14;
+      XS(c0) = sel.depth; XS(c0 + 1) = (float)sel.link;
+      xs_store_v3(lds, lane, c0 + 2, sel.n); xs_store_v3(lds, lane, c0 + 5, sel.P); xs_store_sv(lds, lane, c0 + 8, Vsel);
+    }
     WS_STAMP(side, 2 + 8 * s);
     ws_barrier();  // B1
     WS_STAMP(side, 3 + 8 * s);
-    float other = XS(X_DEPTH + (1 - side));
-    bool mine = sel.link >= 0 && (sel.depth > other || (sel.depth == other && side == 0));
-    BallBody ball;
-    if (mine) ball = ball_setup(P, D.mu, D.g, R.ball_z, R.ball_ang, R.ball_lin);
-    ws_ball_contact_prepare<FIRST, LEN>(P, D, R, ball, Sl, qd, mine, sel);
-    mine = mine && sel.link >= 0;
+    // foot ground contact while the root role evaluates the ball<->link contact operands
+    Sym6 Kc = sym6zero(); SV pc = svzero();
+    ws_ground_points<FIRST + LEN - 1>(P, D.mu, R.root_z, Eend, rend, Vend, Kc, pc);
+    ws_barrier();  // B1b: fold operands published
+    bool mine = (XS(X_FOLD) == (float)side) && (XS(X_FOLD + 1) >= 0.f);
+    BallBody ball; ball.ground = false;
+    if (mine) {
+      sel.link = (int)XS(X_FOLD + 1);
+      sel.A.xx = XS(X_FOLD + 2); sel.A.yy = XS(X_FOLD + 3); sel.A.zz = XS(X_FOLD + 4);
+      sel.A.xy = XS(X_FOLD + 5); sel.A.xz = XS(X_FOLD + 6); sel.A.yz = XS(X_FOLD + 7);
+      sel.f0p = xs_load_v3(lds, lane, X_FOLD + 8); sel.x = xs_load_v3(lds, lane, X_FOLD + 11); sel.xb = xs_load_v3(lds, lane, X_FOLD + 14);
+    } else {
+      sel.link = -1;
+    }
     P3 p3[LEN];
     Sym6 IA = sym6zero(); SV pA = svzero();
     ws_chain_pass2<FIRST, LEN, true>(P, D, kps, kds, R, ball, q, qd, target, LI, pAl, Sl, cbl, Kc, pc, mine, sel, p3, IA, pA);
@@ -395,16 +394,20 @@ BEZ_DEV void ws_upper_role(const Params& P, float* lds, int lane, int e, bool ac
     P3 p3[6];
     BodyContact bcn[3];
     Sym6 IA = sym6zero(); SV pA = svzero();
-    ws_barrier();  // B1 (only the legs exchange data here: take it first so the chains below overlap the legs' passes)
+    ws_barrier();  // B1  (only the legs / root exchange data at B1 and B1b: take both first so the chains below overlap them)
+    ws_barrier();  // B1b
     {  // three 2-link chains, one after the other
-      LinkInertia LI[2]; SV pAl[2], Sl[2], cbl[2]; Sym6 Kc; SV pc;
-      ws_chain_pass1<1, 2, false>(P, D, ms + 0, R, q + 0, qd + 0, LI, pAl, Sl, cbl, Kc, pc, nosel);
+      LinkInertia LI[2]; SV pAl[2], Sl[2], cbl[2]; Sym6 Kc; SV pc; M3 Ee; V3 re; SV Ve, Vs = svzero();
+      ws_chain_pass1<1, 2, false>(P, D, ms + 0, R, q + 0, qd + 0, LI, pAl, Sl, cbl, Ee, re, Ve, nosel, Vs);
+      Kc = sym6zero(); pc = svzero(); ws_ground_points<2>(P, D.mu, R.root_z, Ee, re, Ve, Kc, pc);
       ws_chain_pass2<1, 2, false>(P, D, kps + 0, kds + 0, R, noball, q + 0, qd + 0, target + 0, LI, pAl, Sl, cbl, Kc, pc, false, nosel, p3 + 0, IA, pA);
       bcn[0] = body_contact_of(Kc, pc);
-      ws_chain_pass1<3, 2, false>(P, D, ms + 2, R, q + 2, qd + 2, LI, pAl, Sl, cbl, Kc, pc, nosel);
+      ws_chain_pass1<3, 2, false>(P, D, ms + 2, R, q + 2, qd + 2, LI, pAl, Sl, cbl, Ee, re, Ve, nosel, Vs);
+      Kc = sym6zero(); pc = svzero(); ws_ground_points<4>(P, D.mu, R.root_z, Ee, re, Ve, Kc, pc);
       ws_chain_pass2<3, 2, false>(P, D, kps + 2, kds + 2, R, noball, q + 2, qd + 2, target + 2, LI, pAl, Sl, cbl, Kc, pc, false, nosel, p3 + 2, IA, pA);
       bcn[1] = body_contact_of(Kc, pc);
-      ws_chain_pass1<11, 2, false>(P, D, ms + 4, R, q + 4, qd + 4, LI, pAl, Sl, cbl, Kc, pc, nosel);
+      ws_chain_pass1<11, 2, false>(P, D, ms + 4, R, q + 4, qd + 4, LI, pAl, Sl, cbl, Ee, re, Ve, nosel, Vs);
+      Kc = sym6zero(); pc = svzero(); ws_ground_points<12>(P, D.mu, R.root_z, Ee, re, Ve, Kc, pc);
       ws_chain_pass2<11, 2, false>(P, D, kps + 4, kds + 4, R, noball, q + 4, qd + 4, target + 4, LI, pAl, Sl, cbl, Kc, pc, false, nosel, p3 + 4, IA, pA);
       bcn[2] = body_contact_of(Kc, pc);
     }
@@ -484,8 +487,26 @@ BEZ_DEV void ws_root_role(const Params& P, float* lds, int lane, int e, bool act
     add_to(IA0, Kc); pA0 = pA0 + pc;
     BallBody ball = ball_setup(P, D.mu, D.g, ball_pos.z, ball_ang, ball_lin);
     WS_STAMP(3, 2 + 8 * s);
-    ws_barrier();  // B1
+    ws_barrier();  // B1: both legs' ball/box candidates are in LDS
     WS_STAMP(3, 3 + 8 * s);
+    {  // deepest candidate wins (left on ties, as the box order of the oracle); evaluate the contact once, here
+      const float dl = XS(X_CAND), dr = XS(X_CAND + 14);
+      const int side_w = (dr > dl) ? 1 : 0;
+      const int c0 = X_CAND + side_w * 14;
+      BallSel sel;
+      sel.depth = XS(c0); sel.link = (int)XS(c0 + 1);
+      sel.n = xs_load_v3(lds, lane, c0 + 2); sel.P = xs_load_v3(lds, lane, c0 + 5);
+      sel.A = sym3zero(); sel.f0p = sel.x = sel.xb = mk(0, 0, 0);
+      if (sel.link >= 0) {
+        SV Vl = xs_load_sv(lds, lane, c0 + 8);
+        ball_link_contact(P, D.mu, ball_ang, ball_lin, ball, ball_pos - root_pos, Vl, sel);
+      }
+      XS(X_FOLD) = (float)side_w; XS(X_FOLD + 1) = (float)sel.link;
+      XS(X_FOLD + 2) = sel.A.xx; XS(X_FOLD + 3) = sel.A.yy; XS(X_FOLD + 4) = sel.A.zz;
+      XS(X_FOLD + 5) = sel.A.xy; XS(X_FOLD + 6) = sel.A.xz; XS(X_FOLD + 7) = sel.A.yz;
+      xs_store_v3(lds, lane, X_FOLD + 8, sel.f0p); xs_store_v3(lds, lane, X_FOLD + 11, sel.x); xs_store_v3(lds, lane, X_FOLD + 14, sel.xb);
+    }
+    ws_barrier();  // B1b
     ws_barrier();  // B2: chain contributions published
     WS_STAMP(3, 5 + 8 * s);
     xs_add_sym6(lds, lane, X_IA + 0 * 27, IA0, pA0);
