@@ -7,7 +7,7 @@ reference).  Loading / calling the library is in `bez_isaacgym_amd.sim`.
 import ctypes as C
 import math
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 NUM_OBS = 54
 NUM_ACTIONS = 18
 NUM_DOFS = 18
@@ -16,13 +16,18 @@ NUM_ACTORS = 2
 NUM_LINKS = 19
 
 FLAG_IMU_PREV_ALIAS = 1
+FLAG_CF_WITH_FRICTION = 2
+FLAG_CF_LAST_SUBSTEP = 4
+FLAG_NO_SELF_COLLISION = 8
 
 (TENSOR_ROOT_STATE, TENSOR_DOF_STATE, TENSOR_RIGID_BODY_STATE, TENSOR_NET_CONTACT_FORCE, TENSOR_OBS,
  TENSOR_REW, TENSOR_RESET, TENSOR_PROGRESS, TENSOR_TIMEOUT, TENSOR_DOF_TARGET, TENSOR_PREV_LIN_VEL,
  TENSOR_FEET, TENSOR_COUNT) = range(13)
 DTYPE_F32, DTYPE_I64 = 0, 1
-PARAM_FRICTION, PARAM_KP_SCALE, PARAM_KD_SCALE, PARAM_MASS_SCALE, PARAM_GRAVITY, PARAM_COUNT = range(6)
-PARAM_WIDTH = {PARAM_FRICTION: 1, PARAM_KP_SCALE: 18, PARAM_KD_SCALE: 18, PARAM_MASS_SCALE: 19, PARAM_GRAVITY: 3}
+(PARAM_FRICTION, PARAM_KP_SCALE, PARAM_KD_SCALE, PARAM_MASS_SCALE, PARAM_GRAVITY, PARAM_DOF_LOWER, PARAM_DOF_UPPER,
+ PARAM_COUNT) = range(8)
+PARAM_WIDTH = {PARAM_FRICTION: 1, PARAM_KP_SCALE: 18, PARAM_KD_SCALE: 18, PARAM_MASS_SCALE: 19, PARAM_GRAVITY: 3,
+               PARAM_DOF_LOWER: 18, PARAM_DOF_UPPER: 18}
 
 
 class BezSimConfig(C.Structure):
@@ -52,6 +57,9 @@ class BezSimConfig(C.Structure):
         ("limit_d", C.c_float),
         ("jfric_veps", C.c_float),
         ("ball_ang_damping", C.c_float),
+        ("self_kn", C.c_float),
+        ("self_cn", C.c_float),
+        ("tune", C.c_float * 8),
         ("flags", C.c_uint32),
         ("seed", C.c_uint64),
         ("env_id_offset", C.c_int64),
@@ -67,7 +75,8 @@ class BezSimConfig(C.Structure):
 
 # Contact / limit model constants of this build (no reference counterpart; DESIGN.md "Physics model")
 CONTACT_DEFAULTS = dict(contact_kn=2.0e4, contact_cn=20.0, contact_ct=1.0e3, contact_veps=0.01,
-                        limit_k=200.0, limit_d=2.0, jfric_veps=0.1, ball_ang_damping=0.5)
+                        limit_k=200.0, limit_d=2.0, jfric_veps=0.1, ball_ang_damping=0.5,
+                        self_kn=3000.0, self_cn=5.0)
 
 
 def default_config(num_envs=4096, seed=42, env_id_offset=0):

@@ -5,9 +5,29 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc", "bez_sim.hip")
-DEPS = [SRC] + [os.path.join(HERE, "csrc", f) for f in ("bez_kernels.h", "bez_spatial.h", "bez_model_gen.h")] + \
-       [os.path.join(HERE, "..", "include", "bez_sim.h")]
 OUT = os.path.join(HERE, "lib", "libbez_sim.so")
+STAMP = OUT + ".buildinfo"  # hash of every source + the compiler flags the .so was built from
+
+
+def _deps():
+    import glob
+    return sorted(glob.glob(os.path.join(HERE, "csrc", "*.h")) + glob.glob(os.path.join(HERE, "csrc", "*.hip")) +
+                  [os.path.join(HERE, "..", "include", "bez_sim.h")])
+
+
+def _flags():
+    return ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fno-slp-vectorize"] + \
+        os.environ.get("BEZ_HIPCC_FLAGS", "").split()
+
+
+def source_hash():
+    import hashlib
+    h = hashlib.sha256(" ".join(_flags()).encode())
+    for d in _deps():
+        h.update(os.path.basename(d).encode())
+        with open(d, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
 
 
 def lib_path():
@@ -15,10 +35,10 @@ def lib_path():
 
 
 def needs_build():
-    if not os.path.exists(OUT):
+    if not os.path.exists(OUT) or not os.path.exists(STAMP):
         return True
-    t = os.path.getmtime(OUT)
-    return any(os.path.getmtime(d) > t for d in DEPS)
+    with open(STAMP) as f:
+        return f.read().strip() != source_hash()
 
 
 def build(force=False, verbose=False):
@@ -28,11 +48,14 @@ def build(force=False, verbose=False):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     # -fno-slp-vectorize: hipcc's SLP pass packs adjacent scalar f32 ops into v_pk_* and pays for it in v_mov shuffles
     # (23.1k -> 16.4k VALU instructions in the fused kernel, 33.2 -> 29.1 us per step on MI355X)
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fno-slp-vectorize"] + \
-        os.environ.get("BEZ_HIPCC_FLAGS", "").split() + ["-o", OUT, SRC]
+    cmd = [hipcc] + _flags() + ["-o", OUT, SRC]
     if verbose:
         print(" ".join(cmd))
+    if os.path.exists(STAMP):
+        os.remove(STAMP)
     subprocess.run(cmd, check=True)
+    with open(STAMP, "w") as f:
+        f.write(source_hash() + "\n")
     return OUT
 
 

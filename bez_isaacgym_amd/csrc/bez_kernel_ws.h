@@ -5,41 +5,45 @@
 // body at the same time instead of one wave walking all 19 links serially:
 //     role 0  left leg   (links 5..10)      passes 1-3, foot ground contact, ball<->leg-box contact
 //     role 1  right leg  (links 13..18)     same
-//     role 2  head + arms (links 1,2 / 3,4 / 11,12), their guard points
-//     role 3  torso, ball, 6x6 root solve, root/ball integration, then the whole post-physics
-//             (bookkeeping, reset, observations, reward)
+//     role 2  leg<->leg self-collision (capsule pairs, while the legs run pass 1), then head + arms
+//             (links 1,2 / 3,4 / 11,12) and their guard points
+//     role 3  torso, ball, ball<->box winner (legs / torso box), 6x6 root solve, root/ball integration, then the
+//             whole post-physics (bookkeeping, reset, observations, reward)
 // Chains only meet at the torso: per substep the roles exchange 27 floats (articulated inertia + bias of a chain)
 // up and 6 floats (torso acceleration) down through LDS, lds[slot * 64 + lane] (bank = lane, conflict-free),
 // with six workgroup barriers.  Role dispatch is a scalar branch on readfirstlane(wave id), every role executes
 // the same number of barriers.  Because a wave only ever holds ONE chain, all per-link data of passes 1-3 stays
 // in VGPRs (no scratch, no LDS staging of the pass-3 operands).
 // Actions (N,18) and observations (N,54) are row-major in HBM: each workgroup's 64 rows are one contiguous block,
-// moved with coalesced accesses by all 256 threads and transposed through LDS.
+// moved with coalesced accesses by all 256 threads and transposed through LDS.  The 22 net-contact-force rows are
+// accumulated (mean over the substeps) in LDS by the role that owns the body and written out once, coalesced.
 #pragma once
 #include "bez_kernels.h"
 
 namespace bez {
 
 constexpr int WS_BLOCK = 256;
-constexpr int WS_ENVS = 64;  // lanes per wave; a workgroup may use only the first NE (64, 32 or 16) of them
+constexpr int WS_ENVS = 64;  // envs per workgroup = lanes per wave
 
 // LDS exchange slots (floats per env lane)
 enum : int {
-  X_ROOT = 0,    // pos3 quat4 lin3 ang3
-  X_BALL = 13,   // pos3 lin3 ang3
-  X_IA = 22,     // 3 roles x (Sym6 21 + bias 6)
-  X_A0 = 103,    // torso spatial acceleration
-  X_DEPTH = 109, // (unused since the root role selects; kept so slot numbers stay stable)
-  X_FL = 111,    // ball<->link force on the link (3) + contact point rel. ball centre (3)
-  X_FOOT = 117,  // net contact force on left / right foot
-  X_PSUM = 123,  // per chain role: sum of (default - q)^2 over its joints
-  X_CAND = 126,  // per leg: depth, link, n(3), P(3), V(6) of its deepest ball/box candidate = 14 floats x 2
-  X_FOLD = 154,  // winner side, link, A(6), f0p(3), x(3), xb(3) = 17 floats (written by the root role)
-  X_SLOTS = 171
+  X_ROOT = 0,      // pos3 quat4 lin3 ang3
+  X_BALL = 13,     // pos3 lin3 ang3
+  X_IA = 22,       // 3 roles x (Sym6 21 + bias 6)
+  X_A0 = 103,      // torso spatial acceleration
+  X_FL = 109,      // ball<->link force on the link (3) + contact point rel. ball centre (3)
+  X_PSUM = 115,    // per chain role: sum of (default - q)^2 over its joints
+  X_CAND = 118,    // per leg: depth, link, n(3), P(3), V(6) of its deepest ball/box candidate = 14 floats x 2
+  X_FOLD = 146,    // winner side, link, A(6), f0p(3), x(3), xb(3) = 17 floats (written by the root role)
+  X_LEGQ = 163,    // per leg: q(6) qd(6) at the start of the substep (read by the self-collision role)
+  X_SELFW = 187,   // per leg box link (left 5, right 5): bias wrench of the leg<->leg contacts (6)
+  X_SELFCF = 247,  // per leg box link: reported contact force of the leg<->leg contacts (3)
+  X_CF = 277,      // net contact force rows of the 22 bodies (mean over substeps)
+  X_SLOTS = 343
 };
 constexpr int WS_OBS_STRIDE = 54;  // rows unpadded: the staged block IS the contiguous HBM image (float4 copy-out)
 constexpr int WS_ACT_STRIDE = 19;
-constexpr int WS_LDS_FLOATS = X_SLOTS * WS_ENVS + WS_ENVS * WS_OBS_STRIDE;  // sized for NE = 64
+constexpr int WS_LDS_FLOATS = X_SLOTS * WS_ENVS + WS_ENVS * WS_OBS_STRIDE;
 
 #define XS(slot) lds[(slot) * WS_ENVS + lane]
 
@@ -76,6 +80,14 @@ BEZ_DEV void xs_add_sym6(const float* lds, int lane, int slot, Sym6& I, SV& p) {
   for (int i = 0; i < 21; ++i) f[i] += XS(slot + i);
   p = p + xs_load_sv(lds, lane, slot + 21);
 }
+// net-contact-force row of `body`: the first contributing substep stores w * f, later ones add (cf_accum of bez_kernels.h, in LDS)
+BEZ_DEV void ws_cf_acc(float* lds, int lane, int body, V3 f, float w, bool first) {
+  const int s = X_CF + body * 3;
+  if (first) { XS(s) = f.x * w; XS(s + 1) = f.y * w; XS(s + 2) = f.z * w; }
+  else { XS(s) = fmaf(f.x, w, XS(s)); XS(s + 1) = fmaf(f.y, w, XS(s + 1)); XS(s + 2) = fmaf(f.z, w, XS(s + 2)); }
+}
+// leg box link L (6..10 / 14..18) -> 0..9
+BEZ_DEV constexpr int self_index(int L) { return L < 11 ? L - 6 : 5 + (L - 14); }
 
 // shared (read-only within a substep) root / ball state as the chain roles see it
 struct RootView { M3 E0; SV V0; float root_z; V3 bc, ball_lin, ball_ang; float ball_z; };
@@ -135,7 +147,7 @@ BEZ_DEV void ws_chain_pass1(const Params& P, const ChainDyn& D, const float* ms,
 }
 
 template <int FIRST, int LEN, bool LEG>
-BEZ_DEV void ws_chain_pass2(const Params& P, const ChainDyn& D, const float* kps, const float* kds, const RootView& R, const BallBody& ball,
+BEZ_DEV void ws_chain_pass2(const Params& P, const ChainDyn& D, const float* kps, const float* kds, const float* lo, const float* hi,
                             const float* q, const float* qd, const float* target, const LinkInertia* LI, const SV* pAl, const SV* Sl,
                             const SV* cbl, const Sym6& Kc, SV pc, bool mine, BallSel& sel, P3* p3, Sym6& IAo, SV& pAo) {
   Sym6 IA = Kc;
@@ -152,7 +164,7 @@ BEZ_DEV void ws_chain_pass2(const Params& P, const ChainDyn& D, const float* kps
       }
     }
     SV U; float Dinv, u;
-    joint_terms<L>(P, kps[i], kds[i], q[i], qd[i], target[i], IA, pA, Sl[i], cbl[i], U, Dinv, u);
+    joint_terms<L>(P, kps[i], kds[i], lo[i], hi[i], q[i], qd[i], target[i], IA, pA, Sl[i], cbl[i], U, Dinv, u);
     p3[i].UD = U * Dinv; p3[i].uD = u * Dinv; p3[i].S = Sl[i]; p3[i].cb = cbl[i];
     add_outer(IA, U, -Dinv);
     pA = pA + mul(IA, cbl[i]) + U * p3[i].uD;
@@ -163,8 +175,8 @@ BEZ_DEV void ws_chain_pass2(const Params& P, const ChainDyn& D, const float* kps
 
 // pass 3: joint accelerations, semi-implicit Euler with the velocity clamp; returns the chain-end acceleration
 template <int FIRST, int LEN, bool LEG>
-BEZ_DEV SV ws_chain_pass3(const Params& P, SV a0, const P3* p3, float* q, float* qd, bool mine, const BallSel& sel, V3& fl, V3& f_end_ball,
-                          float* cf_base, int n, bool keep, bool active) {
+BEZ_DEV SV ws_chain_pass3(const Params& P, SV a0, const P3* p3, float* q, float* qd, bool mine, const BallSel& sel, V3& fl, V3& f_end,
+                          float* lds, int lane, bool keep, bool first) {
   SV a = a0;
   static_for<LEN>([&](auto I) {
     constexpr int i = decltype(I)::value;
@@ -177,14 +189,11 @@ BEZ_DEV SV ws_chain_pass3(const Params& P, SV a0, const P3* p3, float* q, float*
     qd[i] = v;
     q[i] = fmaf(P.h, v, q[i]);
     if constexpr (LEG && link_has_box(L)) {
-      V3 f = mk(0, 0, 0);
-      if (mine && sel.link == L) { fl = sel.f0p - mul(sel.A, point_of(a, sel.x)); f = fl; }
+      V3 f = xs_load_v3(lds, lane, X_SELFCF + self_index(L) * 3);  // leg<->leg contacts of this link
+      if (mine && sel.link == L) { fl = sel.f0p - mul(sel.A, point_of(a, sel.x)); f = f + cf_along(P, fl, sel.n); }
       if (keep) {
-        if constexpr (i == LEN - 1) f_end_ball = f;
-        else if (active) {
-          constexpr int body = BEZ_LINK_BODY[L];
-          cf_base[(size_t)(body * 3 + 0) * n] = f.x; cf_base[(size_t)(body * 3 + 1) * n] = f.y; cf_base[(size_t)(body * 3 + 2) * n] = f.z;
-        }
+        if constexpr (i == LEN - 1) f_end = f;
+        else ws_cf_acc(lds, lane, BEZ_LINK_BODY[L], f, P.cf_w, first);
       }
     }
   });
@@ -250,24 +259,84 @@ BEZ_DEV void ws_chain_epilogue(const Params& P, float* lds, int lane, int e, boo
   }
 }
 
+// ---- leg<->leg self-collision, evaluated by the upper role while the leg roles run pass 1.  Forward kinematics of both
+// legs from the joint state they published (X_LEGQ); right-leg capsules stay in registers while the left leg is walked;
+// the wrenches / reported forces are accumulated per link in LDS (X_SELFW / X_SELFCF) for the leg roles.
+BEZ_DEV void ws_self_collision(const Params& P, float mu, float* lds, int lane, const RootView& R) {
+#pragma unroll
+  for (int k = 0; k < 90; ++k) XS(X_SELFW + k) = 0.f;  // X_SELFW (60) and X_SELFCF (30) are adjacent
+  if (P.flags & BEZ_FLAG_NO_SELF_COLLISION) return;
+  constexpr int NH = BEZ_NCAP / 2;  // capsules per leg: left 0..NH-1, right NH..2NH-1
+  V3 rc0[NH], rc1[NH]; SV rV[NH];
+  {
+    M3 E = R.E0; V3 r = mk(0, 0, 0); SV V = R.V0, Sj, cbj;
+    static_for<6>([&](auto I) {
+      constexpr int i = decltype(I)::value;
+      constexpr int L = 13 + i;
+      link_kinematics<L>(XS(X_LEGQ + 12 + i), XS(X_LEGQ + 18 + i), E, r, V, Sj, cbj);
+      static_for<NH>([&](auto C) {
+        constexpr int c = NH + decltype(C)::value;
+        if constexpr (BEZ_CAP_LINK[c] == L) {
+          rc0[c - NH] = r + mul(E, mk((float)BEZ_CAP_P0[c][0], (float)BEZ_CAP_P0[c][1], (float)BEZ_CAP_P0[c][2]));
+          rc1[c - NH] = r + mul(E, mk((float)BEZ_CAP_P1[c][0], (float)BEZ_CAP_P1[c][1], (float)BEZ_CAP_P1[c][2]));
+          rV[c - NH] = V;
+        }
+      });
+    });
+  }
+  M3 E = R.E0; V3 r = mk(0, 0, 0); SV V = R.V0, Sj, cbj;
+  static_for<6>([&](auto I) {
+    constexpr int i = decltype(I)::value;
+    constexpr int L = 5 + i;
+    link_kinematics<L>(XS(X_LEGQ + i), XS(X_LEGQ + 6 + i), E, r, V, Sj, cbj);
+    static_for<NH>([&](auto C) {
+      constexpr int ia = decltype(C)::value;
+      if constexpr (BEZ_CAP_LINK[ia] == L) {
+        const V3 a0 = r + mul(E, mk((float)BEZ_CAP_P0[ia][0], (float)BEZ_CAP_P0[ia][1], (float)BEZ_CAP_P0[ia][2]));
+        const V3 a1 = r + mul(E, mk((float)BEZ_CAP_P1[ia][0], (float)BEZ_CAP_P1[ia][1], (float)BEZ_CAP_P1[ia][2]));
+        static_for<BEZ_NCPAIR>([&](auto Q) {
+          constexpr int pr = decltype(Q)::value;
+          if constexpr (BEZ_CPAIR[pr][0] == ia) {
+            constexpr int ib = BEZ_CPAIR[pr][1];
+            constexpr int sa = self_index(L), sb = self_index(BEZ_CAP_LINK[ib]);
+            V3 x, f, fn;
+            if (self_pair(P, mu, (float)BEZ_CAP_R[ia], (float)BEZ_CAP_R[ib], a0, a1, rc0[ib - NH], rc1[ib - NH], V, rV[ib - NH], x, f, fn)) {
+              const SV w = wrench_at(x, f);
+              const float wf[6] = {w.a.x, w.a.y, w.a.z, w.l.x, w.l.y, w.l.z};
+#pragma unroll
+              for (int k = 0; k < 6; ++k) { XS(X_SELFW + sa * 6 + k) -= wf[k]; XS(X_SELFW + sb * 6 + k) += wf[k]; }
+              const V3 fr = (P.flags & BEZ_FLAG_CF_WITH_FRICTION) ? f : fn;
+              XS(X_SELFCF + sa * 3) += fr.x; XS(X_SELFCF + sa * 3 + 1) += fr.y; XS(X_SELFCF + sa * 3 + 2) += fr.z;
+              XS(X_SELFCF + sb * 3) -= fr.x; XS(X_SELFCF + sb * 3 + 1) -= fr.y; XS(X_SELFCF + sb * 3 + 2) -= fr.z;
+            }
+          }
+        });
+      }
+    });
+  });
+}
+
 // ------------------------------------------------------------------------------------------------ roles
 template <int FIRST, bool PRE, bool POST, bool DR>
 BEZ_DEV void ws_leg_role(const Params& P, float* lds, int lane, int e, bool active, int side) {
   constexpr int LEN = 6;
   const int n = P.n;
   float* st = P.state;
-  float q[LEN], qd[LEN], target[LEN], kps[LEN], kds[LEN], ms[LEN];
+  float q[LEN], qd[LEN], target[LEN], kps[LEN], kds[LEN], ms[LEN], lo[LEN], hi[LEN];
   ChainDyn D; D.mu = P.mu; D.g = mk(P.g[0], P.g[1], P.g[2]);
 #pragma unroll
   for (int i = 0; i < LEN; ++i) {
     constexpr int d0 = FIRST - 1;
     q[i] = st[(size_t)(F_Q + d0 + i) * n + e]; qd[i] = st[(size_t)(F_QD + d0 + i) * n + e];
-    kps[i] = 1.f; kds[i] = 1.f; ms[i] = 1.f;
+    kps[i] = 1.f; kds[i] = 1.f; ms[i] = 1.f; lo[i] = (float)BEZ_DOF_LOWER[d0 + i]; hi[i] = (float)BEZ_DOF_UPPER[d0 + i];
     if (DR) {
       if (P.dr_kp) kps[i] = P.dr_kp[(size_t)e * BEZ_ND + d0 + i];
       if (P.dr_kd) kds[i] = P.dr_kd[(size_t)e * BEZ_ND + d0 + i];
       if (P.dr_mass) ms[i] = P.dr_mass[(size_t)e * BEZ_NL + FIRST + i];
+      if (P.dr_lower) lo[i] = P.dr_lower[(size_t)e * BEZ_ND + d0 + i];
+      if (P.dr_upper) hi[i] = P.dr_upper[(size_t)e * BEZ_ND + d0 + i];
     }
+    XS(X_LEGQ + side * 12 + i) = q[i]; XS(X_LEGQ + side * 12 + 6 + i) = qd[i];
   }
   if (DR) {
     if (P.dr_friction) D.mu = P.dr_friction[e];
@@ -275,8 +344,9 @@ BEZ_DEV void ws_leg_role(const Params& P, float* lds, int lane, int e, bool acti
   }
   const bool do_reset = POST && P.reset[e] != 0;  // reset_buf of the previous step (kick_env.py:433-435)
   const uint32_t episode = POST ? P.episode[e] : 0u;
+  const bool last_only = (P.flags & BEZ_FLAG_CF_LAST_SUBSTEP) != 0;
   WS_STAMP(side, 0);
-  ws_barrier();  // B0: actions staged, root/ball published
+  ws_barrier();  // B0: actions staged, root/ball and the leg joint state published
   WS_STAMP(side, 1);
   if (PRE) {
     const float* act = lds + X_SLOTS * WS_ENVS + lane * WS_ACT_STRIDE;
@@ -291,9 +361,9 @@ BEZ_DEV void ws_leg_role(const Params& P, float* lds, int lane, int e, bool acti
 #pragma unroll
     for (int i = 0; i < LEN; ++i) target[i] = st[(size_t)(F_TARGET + FIRST - 1 + i) * n + e];
   }
-  float* cf_base = st + (size_t)F_CF * n + e;
   for (int s = 0; s < P.substeps; ++s) {
-    const bool keep = (s == P.substeps - 1);
+    const bool keep = last_only ? (s == P.substeps - 1) : true;
+    const bool first = last_only ? true : (s == 0);
     RootView R = load_root_view(lds, lane);
     LinkInertia LI[LEN]; SV pAl[LEN], Sl[LEN], cbl[LEN];
     BallSel sel;
@@ -306,14 +376,15 @@ BEZ_DEV void ws_leg_role(const Params& P, float* lds, int lane, int e, bool acti
       xs_store_v3(lds, lane, c0 + 2, sel.n); xs_store_v3(lds, lane, c0 + 5, sel.P); xs_store_sv(lds, lane, c0 + 8, Vsel);
     }
     WS_STAMP(side, 2 + 8 * s);
-    ws_barrier();  // B1
+    ws_barrier();  // B1: candidates and the leg<->leg contact wrenches are in LDS
     WS_STAMP(side, 3 + 8 * s);
     // foot ground contact while the root role evaluates the ball<->link contact operands
     Sym6 Kc = sym6zero(); SV pc = svzero();
     ws_ground_points<FIRST + LEN - 1>(P, D.mu, R.root_z, Eend, rend, Vend, Kc, pc);
+#pragma unroll
+    for (int i = 1; i < LEN; ++i) pAl[i] = pAl[i] + xs_load_sv(lds, lane, X_SELFW + (side * 5 + i - 1) * 6);
     ws_barrier();  // B1b: fold operands published
-    bool mine = (XS(X_FOLD) == (float)side) && (XS(X_FOLD + 1) >= 0.f);
-    BallBody ball; ball.ground = false;
+    bool mine = (XS(X_FOLD) == (float)side) && (XS(X_FOLD + 1) >= 1.f);
     if (mine) {
       sel.link = (int)XS(X_FOLD + 1);
       sel.A.xx = XS(X_FOLD + 2); sel.A.yy = XS(X_FOLD + 3); sel.A.zz = XS(X_FOLD + 4);
@@ -324,7 +395,7 @@ BEZ_DEV void ws_leg_role(const Params& P, float* lds, int lane, int e, bool acti
     }
     P3 p3[LEN];
     Sym6 IA = sym6zero(); SV pA = svzero();
-    ws_chain_pass2<FIRST, LEN, true>(P, D, kps, kds, R, ball, q, qd, target, LI, pAl, Sl, cbl, Kc, pc, mine, sel, p3, IA, pA);
+    ws_chain_pass2<FIRST, LEN, true>(P, D, kps, kds, lo, hi, q, qd, target, LI, pAl, Sl, cbl, Kc, pc, mine, sel, p3, IA, pA);
     xs_store_sym6(lds, lane, X_IA + side * 27, IA, pA);
     BodyContact bcn = body_contact_of(Kc, pc);
     WS_STAMP(side, 4 + 8 * s);
@@ -334,9 +405,11 @@ BEZ_DEV void ws_leg_role(const Params& P, float* lds, int lane, int e, bool acti
     WS_STAMP(side, 6 + 8 * s);
     SV a0 = xs_load_sv(lds, lane, X_A0);
     V3 fl = mk(0, 0, 0), fend = mk(0, 0, 0);
-    SV aend = ws_chain_pass3<FIRST, LEN, true>(P, a0, p3, q, qd, mine, sel, fl, fend, cf_base, n, keep, active);
+    SV aend = ws_chain_pass3<FIRST, LEN, true>(P, a0, p3, q, qd, mine, sel, fl, fend, lds, lane, keep, first);
     if (mine && sel.link >= 0) { xs_store_v3(lds, lane, X_FL, fl); xs_store_v3(lds, lane, X_FL + 3, sel.xb); }
-    if (keep) xs_store_v3(lds, lane, X_FOOT + side * 3, fend + body_contact_force(bcn, aend));
+    if (keep) ws_cf_acc(lds, lane, BEZ_LINK_BODY[FIRST + LEN - 1], fend + cf_ground(P, body_contact_force(bcn, aend)), P.cf_w, first);
+#pragma unroll
+    for (int i = 0; i < LEN; ++i) { XS(X_LEGQ + side * 12 + i) = q[i]; XS(X_LEGQ + side * 12 + 6 + i) = qd[i]; }
     WS_STAMP(side, 7 + 8 * s);
     ws_barrier();  // B4
     WS_STAMP(side, 8 + 8 * s);
@@ -353,16 +426,18 @@ BEZ_DEV void ws_upper_role(const Params& P, float* lds, int lane, int e, bool ac
   const int n = P.n;
   float* st = P.state;
   constexpr int DOF[6] = {0, 1, 2, 3, 10, 11};
-  float q[6], qd[6], target[6], kps[6], kds[6], ms[6];
+  float q[6], qd[6], target[6], kps[6], kds[6], ms[6], lo[6], hi[6];
   ChainDyn D; D.mu = P.mu; D.g = mk(P.g[0], P.g[1], P.g[2]);
 #pragma unroll
   for (int i = 0; i < 6; ++i) {
     q[i] = st[(size_t)(F_Q + DOF[i]) * n + e]; qd[i] = st[(size_t)(F_QD + DOF[i]) * n + e];
-    kps[i] = 1.f; kds[i] = 1.f; ms[i] = 1.f;
+    kps[i] = 1.f; kds[i] = 1.f; ms[i] = 1.f; lo[i] = (float)BEZ_DOF_LOWER[DOF[i]]; hi[i] = (float)BEZ_DOF_UPPER[DOF[i]];
     if (DR) {
       if (P.dr_kp) kps[i] = P.dr_kp[(size_t)e * BEZ_ND + DOF[i]];
       if (P.dr_kd) kds[i] = P.dr_kd[(size_t)e * BEZ_ND + DOF[i]];
       if (P.dr_mass) ms[i] = P.dr_mass[(size_t)e * BEZ_NL + DOF[i] + 1];
+      if (P.dr_lower) lo[i] = P.dr_lower[(size_t)e * BEZ_ND + DOF[i]];
+      if (P.dr_upper) hi[i] = P.dr_upper[(size_t)e * BEZ_ND + DOF[i]];
     }
   }
   if (DR) {
@@ -371,6 +446,7 @@ BEZ_DEV void ws_upper_role(const Params& P, float* lds, int lane, int e, bool ac
   }
   const bool do_reset = POST && P.reset[e] != 0;
   const uint32_t episode = POST ? P.episode[e] : 0u;
+  const bool last_only = (P.flags & BEZ_FLAG_CF_LAST_SUBSTEP) != 0;
   ws_barrier();  // B0
   if (PRE) {
     const float* act = lds + X_SLOTS * WS_ENVS + lane * WS_ACT_STRIDE;
@@ -385,30 +461,30 @@ BEZ_DEV void ws_upper_role(const Params& P, float* lds, int lane, int e, bool ac
 #pragma unroll
     for (int i = 0; i < 6; ++i) target[i] = st[(size_t)(F_TARGET + DOF[i]) * n + e];
   }
-  float* cf_base = st + (size_t)F_CF * n + e;
   BallSel nosel; nosel.link = -1; nosel.depth = 0.f; nosel.n = nosel.P = nosel.f0p = nosel.x = nosel.xb = mk(0, 0, 0); nosel.A = sym3zero();
-  BallBody noball; noball.ground = false;
   for (int s = 0; s < P.substeps; ++s) {
-    const bool keep = (s == P.substeps - 1);
+    const bool keep = last_only ? (s == P.substeps - 1) : true;
+    const bool first = last_only ? true : (s == 0);
     RootView R = load_root_view(lds, lane);
+    ws_self_collision(P, D.mu, lds, lane, R);  // overlaps the legs' pass 1
     P3 p3[6];
     BodyContact bcn[3];
     Sym6 IA = sym6zero(); SV pA = svzero();
-    ws_barrier();  // B1  (only the legs / root exchange data at B1 and B1b: take both first so the chains below overlap them)
-    ws_barrier();  // B1b
+    ws_barrier();  // B1
+    ws_barrier();  // B1b  (only the legs / root exchange data here: the chains below overlap the legs' pass 2)
     {  // three 2-link chains, one after the other
       LinkInertia LI[2]; SV pAl[2], Sl[2], cbl[2]; Sym6 Kc; SV pc; M3 Ee; V3 re; SV Ve, Vs = svzero();
       ws_chain_pass1<1, 2, false>(P, D, ms + 0, R, q + 0, qd + 0, LI, pAl, Sl, cbl, Ee, re, Ve, nosel, Vs);
       Kc = sym6zero(); pc = svzero(); ws_ground_points<2>(P, D.mu, R.root_z, Ee, re, Ve, Kc, pc);
-      ws_chain_pass2<1, 2, false>(P, D, kps + 0, kds + 0, R, noball, q + 0, qd + 0, target + 0, LI, pAl, Sl, cbl, Kc, pc, false, nosel, p3 + 0, IA, pA);
+      ws_chain_pass2<1, 2, false>(P, D, kps + 0, kds + 0, lo + 0, hi + 0, q + 0, qd + 0, target + 0, LI, pAl, Sl, cbl, Kc, pc, false, nosel, p3 + 0, IA, pA);
       bcn[0] = body_contact_of(Kc, pc);
       ws_chain_pass1<3, 2, false>(P, D, ms + 2, R, q + 2, qd + 2, LI, pAl, Sl, cbl, Ee, re, Ve, nosel, Vs);
       Kc = sym6zero(); pc = svzero(); ws_ground_points<4>(P, D.mu, R.root_z, Ee, re, Ve, Kc, pc);
-      ws_chain_pass2<3, 2, false>(P, D, kps + 2, kds + 2, R, noball, q + 2, qd + 2, target + 2, LI, pAl, Sl, cbl, Kc, pc, false, nosel, p3 + 2, IA, pA);
+      ws_chain_pass2<3, 2, false>(P, D, kps + 2, kds + 2, lo + 2, hi + 2, q + 2, qd + 2, target + 2, LI, pAl, Sl, cbl, Kc, pc, false, nosel, p3 + 2, IA, pA);
       bcn[1] = body_contact_of(Kc, pc);
       ws_chain_pass1<11, 2, false>(P, D, ms + 4, R, q + 4, qd + 4, LI, pAl, Sl, cbl, Ee, re, Ve, nosel, Vs);
       Kc = sym6zero(); pc = svzero(); ws_ground_points<12>(P, D.mu, R.root_z, Ee, re, Ve, Kc, pc);
-      ws_chain_pass2<11, 2, false>(P, D, kps + 4, kds + 4, R, noball, q + 4, qd + 4, target + 4, LI, pAl, Sl, cbl, Kc, pc, false, nosel, p3 + 4, IA, pA);
+      ws_chain_pass2<11, 2, false>(P, D, kps + 4, kds + 4, lo + 4, hi + 4, q + 4, qd + 4, target + 4, LI, pAl, Sl, cbl, Kc, pc, false, nosel, p3 + 4, IA, pA);
       bcn[2] = body_contact_of(Kc, pc);
     }
     xs_store_sym6(lds, lane, X_IA + 2 * 27, IA, pA);
@@ -416,15 +492,13 @@ BEZ_DEV void ws_upper_role(const Params& P, float* lds, int lane, int e, bool ac
     ws_barrier();  // B3
     SV a0 = xs_load_sv(lds, lane, X_A0);
     V3 fl = mk(0, 0, 0), fend = mk(0, 0, 0);
-    SV ae0 = ws_chain_pass3<1, 2, false>(P, a0, p3 + 0, q + 0, qd + 0, false, nosel, fl, fend, cf_base, n, keep, active);
-    SV ae1 = ws_chain_pass3<3, 2, false>(P, a0, p3 + 2, q + 2, qd + 2, false, nosel, fl, fend, cf_base, n, keep, active);
-    SV ae2 = ws_chain_pass3<11, 2, false>(P, a0, p3 + 4, q + 4, qd + 4, false, nosel, fl, fend, cf_base, n, keep, active);
-    if (keep && active) {
-      V3 f0 = body_contact_force(bcn[0], ae0), f1 = body_contact_force(bcn[1], ae1), f2 = body_contact_force(bcn[2], ae2);
-      constexpr int b0 = BEZ_LINK_BODY[2], b1 = BEZ_LINK_BODY[4], b2 = BEZ_LINK_BODY[12];
-      cf_base[(size_t)(b0 * 3 + 0) * n] = f0.x; cf_base[(size_t)(b0 * 3 + 1) * n] = f0.y; cf_base[(size_t)(b0 * 3 + 2) * n] = f0.z;
-      cf_base[(size_t)(b1 * 3 + 0) * n] = f1.x; cf_base[(size_t)(b1 * 3 + 1) * n] = f1.y; cf_base[(size_t)(b1 * 3 + 2) * n] = f1.z;
-      cf_base[(size_t)(b2 * 3 + 0) * n] = f2.x; cf_base[(size_t)(b2 * 3 + 1) * n] = f2.y; cf_base[(size_t)(b2 * 3 + 2) * n] = f2.z;
+    SV ae0 = ws_chain_pass3<1, 2, false>(P, a0, p3 + 0, q + 0, qd + 0, false, nosel, fl, fend, lds, lane, keep, first);
+    SV ae1 = ws_chain_pass3<3, 2, false>(P, a0, p3 + 2, q + 2, qd + 2, false, nosel, fl, fend, lds, lane, keep, first);
+    SV ae2 = ws_chain_pass3<11, 2, false>(P, a0, p3 + 4, q + 4, qd + 4, false, nosel, fl, fend, lds, lane, keep, first);
+    if (keep) {
+      ws_cf_acc(lds, lane, BEZ_LINK_BODY[2], cf_ground(P, body_contact_force(bcn[0], ae0)), P.cf_w, first);
+      ws_cf_acc(lds, lane, BEZ_LINK_BODY[4], cf_ground(P, body_contact_force(bcn[1], ae1)), P.cf_w, first);
+      ws_cf_acc(lds, lane, BEZ_LINK_BODY[12], cf_ground(P, body_contact_force(bcn[2], ae2)), P.cf_w, first);
     }
     ws_barrier();  // B4
     ws_barrier();  // B5
@@ -461,6 +535,7 @@ BEZ_DEV void ws_root_role(const Params& P, float* lds, int lane, int e, bool act
     if (P.dr_gravity) D.g = mk(P.dr_gravity[(size_t)e * 3], P.dr_gravity[(size_t)e * 3 + 1], P.dr_gravity[(size_t)e * 3 + 2]);
     if (P.dr_mass) ms0 = P.dr_mass[(size_t)e * BEZ_NL];
   }
+  const bool last_only = (P.flags & BEZ_FLAG_CF_LAST_SUBSTEP) != 0;
   auto publish = [&]() {
     xs_store_v3(lds, lane, X_ROOT, root_pos);
     XS(X_ROOT + 3) = rq[0]; XS(X_ROOT + 4) = rq[1]; XS(X_ROOT + 5) = rq[2]; XS(X_ROOT + 6) = rq[3];
@@ -471,11 +546,12 @@ BEZ_DEV void ws_root_role(const Params& P, float* lds, int lane, int e, bool act
   WS_STAMP(3, 0);
   ws_barrier();  // B0
   WS_STAMP(3, 1);
-  float* cf_base = st + (size_t)F_CF * n + e;
   for (int s = 0; s < P.substeps; ++s) {
-    const bool keep = (s == P.substeps - 1);
+    const bool keep = last_only ? (s == P.substeps - 1) : true;
+    const bool first = last_only ? true : (s == 0);
     const M3 E0 = quat_to_mat(rq[0], rq[1], rq[2], rq[3]);
     const SV V0 = mksv(root_ang, root_lin);
+    const V3 bc = ball_pos - root_pos;
     xs_store_v3(lds, lane, X_FL, mk(0, 0, 0)); xs_store_v3(lds, lane, X_FL + 3, mk(0, 0, 0));
     Sym6 IA0 = sym6zero(); SV pA0;
     LinkInertia I0;
@@ -489,23 +565,27 @@ BEZ_DEV void ws_root_role(const Params& P, float* lds, int lane, int e, bool act
     WS_STAMP(3, 2 + 8 * s);
     ws_barrier();  // B1: both legs' ball/box candidates are in LDS
     WS_STAMP(3, 3 + 8 * s);
-    {  // deepest candidate wins (left on ties, as the box order of the oracle); evaluate the contact once, here
+    // deepest candidate wins: left leg, right leg, torso box -- in that order on ties, as the box order of the oracle;
+    // the contact is evaluated once, here
+    BallSel sel;
+    {
       const float dl = XS(X_CAND), dr = XS(X_CAND + 14);
       const int side_w = (dr > dl) ? 1 : 0;
       const int c0 = X_CAND + side_w * 14;
-      BallSel sel;
       sel.depth = XS(c0); sel.link = (int)XS(c0 + 1);
       sel.n = xs_load_v3(lds, lane, c0 + 2); sel.P = xs_load_v3(lds, lane, c0 + 5);
       sel.A = sym3zero(); sel.f0p = sel.x = sel.xb = mk(0, 0, 0);
-      if (sel.link >= 0) {
-        SV Vl = xs_load_sv(lds, lane, c0 + 8);
-        ball_link_contact(P, D.mu, ball_ang, ball_lin, ball, ball_pos - root_pos, Vl, sel);
-      }
-      XS(X_FOLD) = (float)side_w; XS(X_FOLD + 1) = (float)sel.link;
+      SV Vl = xs_load_sv(lds, lane, c0 + 8);
+      test_box<link_box(0)>(E0, mk(0, 0, 0), bc, sel);
+      if (sel.link == 0) Vl = V0;
+      if (sel.link >= 0) ball_link_contact(P, D.mu, ball_ang, ball_lin, ball, bc, Vl, sel);
+      XS(X_FOLD) = (float)side_w; XS(X_FOLD + 1) = (float)sel.link;  // link 0 / -1: neither leg folds anything
       XS(X_FOLD + 2) = sel.A.xx; XS(X_FOLD + 3) = sel.A.yy; XS(X_FOLD + 4) = sel.A.zz;
       XS(X_FOLD + 5) = sel.A.xy; XS(X_FOLD + 6) = sel.A.xz; XS(X_FOLD + 7) = sel.A.yz;
       xs_store_v3(lds, lane, X_FOLD + 8, sel.f0p); xs_store_v3(lds, lane, X_FOLD + 11, sel.x); xs_store_v3(lds, lane, X_FOLD + 14, sel.xb);
     }
+    const bool torso_hit = (sel.link == 0);
+    if (torso_hit) { add_point_stiffness(IA0, sel.x, sel.A); pA0 = pA0 - wrench_at(sel.x, sel.f0p); }
     ws_barrier();  // B1b
     ws_barrier();  // B2: chain contributions published
     WS_STAMP(3, 5 + 8 * s);
@@ -517,7 +597,9 @@ BEZ_DEV void ws_root_role(const Params& P, float* lds, int lane, int e, bool act
     WS_STAMP(3, 4 + 8 * s);
     ws_barrier();  // B3
     WS_STAMP(3, 6 + 8 * s);
-    if (keep && active) { V3 f = body_contact_force(bc0, a0); cf_base[0] = f.x; cf_base[(size_t)1 * n] = f.y; cf_base[(size_t)2 * n] = f.z; }
+    V3 fl_t = mk(0, 0, 0);
+    if (torso_hit) fl_t = sel.f0p - mul(sel.A, point_of(a0, sel.x));
+    if (keep) ws_cf_acc(lds, lane, 0, cf_along(P, fl_t, sel.n) + cf_ground(P, body_contact_force(bc0, a0)), P.cf_w, first);
     V3 vdot = a0.l + cross(root_ang, root_lin);
     root_ang = fma3(a0.a, P.h, root_ang);
     root_lin = fma3(vdot, P.h, root_lin);
@@ -527,12 +609,12 @@ BEZ_DEV void ws_root_role(const Params& P, float* lds, int lane, int e, bool act
     ws_barrier();  // B4: ball<->link force published
     WS_STAMP(3, 8 + 8 * s);
     V3 fl = xs_load_v3(lds, lane, X_FL), xb = xs_load_v3(lds, lane, X_FL + 3);
+    if (torso_hit) { fl = fl_t; xb = sel.xb; }
     SV ab = ball_minv(ball, svzero() - ball.pb - wrench_at(xb, fl));
-    if (keep && active) {
-      V3 fb = -fl;
-      if (ball.ground) fb = fb + hit_force(P, ball.ghit, ab);
-      constexpr int bb = BEZ_NBE - 1;
-      cf_base[(size_t)(bb * 3 + 0) * n] = fb.x; cf_base[(size_t)(bb * 3 + 1) * n] = fb.y; cf_base[(size_t)(bb * 3 + 2) * n] = fb.z;
+    if (keep) {
+      V3 fb = -cf_along(P, fl, sel.n);
+      if (ball.ground) fb = fb + cf_ground(P, hit_force(P, ball.ghit, ab));
+      ws_cf_acc(lds, lane, BEZ_NBE - 1, fb, P.cf_w, first);
     }
     float damp = fmaxf(1.0f - P.h * P.ball_damp, 0.f);
     ball_lin = fma3(ab.l, P.h, ball_lin);
@@ -543,12 +625,12 @@ BEZ_DEV void ws_root_role(const Params& P, float* lds, int lane, int e, bool act
     ws_barrier();  // B5
     WS_STAMP(3, 9 + 8 * s);
   }
-  ws_barrier();  // B6: joint obs slots / pose-error sums / foot forces of the chain roles are in LDS
+  ws_barrier();  // B6: joint obs slots / pose-error sums / contact-force rows of the chain roles are in LDS
   WS_STAMP(3, 20);
-  CfOut co;
-  co.base = cf_base; co.n = n;
-  co.lf = xs_load_v3(lds, lane, X_FOOT); co.rf = xs_load_v3(lds, lane, X_FOOT + 3);
   if (POST) {
+    CfOut co;
+    co.base = nullptr; co.n = n;
+    co.lf = xs_load_v3(lds, lane, X_CF + BEZ_LFOOT_BODY * 3); co.rf = xs_load_v3(lds, lane, X_CF + BEZ_RFOOT_BODY * 3);
     int64_t timeout = (progress >= (int64_t)(P.max_len - 1)) ? 1 : 0;  // vec_task.py:331-332
     progress += 1;                                                    // kick_env.py:429
     if (reset != 0) {                                                 // kick_env.py:433-435, 831-850 (root / ball part)
@@ -558,10 +640,9 @@ BEZ_DEV void ws_root_role(const Params& P, float* lds, int lane, int e, bool act
       for (int i = 0; i < 4; ++i) { rq[i] = P.bez_init[3 + i]; bq[i] = P.ball_init[3 + i]; }
       root_lin = root_ang = ball_lin = ball_ang = mk(0, 0, 0);
       co.lf = co.rf = mk(0, 0, 0);
-      if (active) {
-        for (int b = 0; b < BEZ_NBE; ++b) cf_store(co, b, mk(0, 0, 0));
-        P.episode[e] = P.episode[e] + 1;
-      }
+#pragma unroll
+      for (int k = 0; k < BEZ_NBE * 3; ++k) XS(X_CF + k) = 0.f;
+      if (active) P.episode[e] = P.episode[e] + 1;
       progress = 0; reset = 0;
     }
     float pn = (XS(X_PSUM + 2) + XS(X_PSUM + 0)) + XS(X_PSUM + 1);
@@ -571,6 +652,8 @@ BEZ_DEV void ws_root_role(const Params& P, float* lds, int lane, int e, bool act
     env_observe_core(P, root_pos, rq, root_lin, root_ang, ball_pos, ball_lin, co, prev, feet, tail, pn, rew, reset, progress);
 #pragma unroll
     for (int i = 0; i < 18; ++i) obs_row[36 + i] = tail[i];
+    // the feet logic filters the two foot rows in place (kick_env.py:987-990)
+    xs_store_v3(lds, lane, X_CF + BEZ_LFOOT_BODY * 3, co.lf); xs_store_v3(lds, lane, X_CF + BEZ_RFOOT_BODY * 3, co.rf);
     if (active) {
 #pragma unroll
       for (int i = 0; i < 3; ++i) st[(size_t)(F_PREV + i) * n + e] = prev[i];
@@ -590,22 +673,20 @@ BEZ_DEV void ws_root_role(const Params& P, float* lds, int lane, int e, bool act
     sv(F_BALL_POS, ball_pos.x); sv(F_BALL_POS + 1, ball_pos.y); sv(F_BALL_POS + 2, ball_pos.z);
     sv(F_BALL_LIN, ball_lin.x); sv(F_BALL_LIN + 1, ball_lin.y); sv(F_BALL_LIN + 2, ball_lin.z);
     sv(F_BALL_ANG, ball_ang.x); sv(F_BALL_ANG + 1, ball_ang.y); sv(F_BALL_ANG + 2, ball_ang.z);
-    cf_store(co, BEZ_LFOOT_BODY, co.lf);
-    cf_store(co, BEZ_RFOOT_BODY, co.rf);
   }
 }
 
 // ---- the kernel.  grid = ceil(N / 64) workgroups of 256 threads.
-template <bool PRE, bool POST, bool DR, int NE>
+template <bool PRE, bool POST, bool DR>
 __global__ __launch_bounds__(WS_BLOCK) void step_kernel_ws(Params P) {
   __shared__ __attribute__((aligned(16))) float lds[WS_LDS_FLOATS];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int role = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int env0 = blockIdx.x * NE;
-  const int nloc = min(NE, P.n - env0);
+  const int env0 = blockIdx.x * WS_ENVS;
+  const int nloc = min(WS_ENVS, P.n - env0);
   const bool active = lane < nloc;
-  const int e = env0 + (active ? lane : 0);  // inactive lanes shadow env0 (loads only; every store is guarded)
+  const int e = env0 + (active ? lane : 0);  // inactive lanes shadow env0 (loads only; every global store is guarded)
   WS_STAMP(role, 22);
   if (PRE) {
     // coalesced stage of this workgroup's contiguous (nloc,18) action block, transposed to [lane][19]
@@ -613,20 +694,26 @@ __global__ __launch_bounds__(WS_BLOCK) void step_kernel_ws(Params P) {
     const float* src = P.actions + (size_t)env0 * BEZ_ND;
     for (int i = tid; i < nloc * BEZ_ND; i += WS_BLOCK) act[(i / BEZ_ND) * WS_ACT_STRIDE + (i % BEZ_ND)] = src[i];
   }
-  // Lanes >= NE of every wave are masked off for the whole role body (lane 0 is always active, so every wave
-  // still reaches every barrier: s_barrier is a scalar instruction).
-  if (lane < NE) {
-    if (role == 0) ws_leg_role<5, PRE, POST, DR>(P, lds, lane, e, active, 0);
-    else if (role == 1) ws_leg_role<13, PRE, POST, DR>(P, lds, lane, e, active, 1);
-    else if (role == 2) ws_upper_role<PRE, POST, DR>(P, lds, lane, e, active);
-    else ws_root_role<PRE, POST, DR>(P, lds, lane, e, active);
+  // contact-force rows start from zero: bodies nothing touches are never accumulated into
+  for (int i = tid; i < BEZ_NBE * 3 * WS_ENVS; i += WS_BLOCK) lds[X_CF * WS_ENVS + i] = 0.f;
+  if (role == 0) ws_leg_role<5, PRE, POST, DR>(P, lds, lane, e, active, 0);
+  else if (role == 1) ws_leg_role<13, PRE, POST, DR>(P, lds, lane, e, active, 1);
+  else if (role == 2) ws_upper_role<PRE, POST, DR>(P, lds, lane, e, active);
+  else ws_root_role<PRE, POST, DR>(P, lds, lane, e, active);
+  ws_barrier();  // contact-force rows (and, with POST, the observation rows staged by role 3) are complete in LDS
+  {
+    // net contact force: 66 SoA rows of 64 consecutive envs each -> coalesced
+    float* dst = P.state + (size_t)F_CF * P.n + env0;
+    for (int i = tid; i < BEZ_NBE * 3 * WS_ENVS; i += WS_BLOCK) {
+      const int k = i >> 6, l = i & 63;
+      if (l < nloc) dst[(size_t)k * P.n + l] = lds[(X_CF + k) * WS_ENVS + l];
+    }
   }
   if (POST) {
-    ws_barrier();  // observation rows staged in LDS by role 3
     // the staged rows are the contiguous (nloc,54) image of this workgroup's slice of obs_buf: 16-byte copy-out
     const float4* rows = reinterpret_cast<const float4*>(lds + X_SLOTS * WS_ENVS);
     float4* dst = reinterpret_cast<float4*>(P.obs + (size_t)env0 * BEZ_NUM_OBS);
-    const int nvec = (nloc * BEZ_NUM_OBS) >> 2;  // NE is a multiple of 16, so full workgroups copy whole float4s
+    const int nvec = (nloc * BEZ_NUM_OBS) >> 2;
     for (int i = tid; i < nvec; i += WS_BLOCK) dst[i] = rows[i];
     for (int i = (nvec << 2) + tid; i < nloc * BEZ_NUM_OBS; i += WS_BLOCK) P.obs[(size_t)env0 * BEZ_NUM_OBS + i] = lds[X_SLOTS * WS_ENVS + i];
   }

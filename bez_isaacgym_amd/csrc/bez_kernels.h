@@ -46,6 +46,8 @@ struct Params {
   float kp, kd, armature, effort, vel_limit, jfric, mu, clip;
   float bez_init[7], ball_init[7], goal[2];
   float kn, cn, ct, veps, lim_k, lim_d, jf_veps, ball_damp;
+  float self_kn, self_cn;
+  float cf_w;  // weight of one substep in the net-contact-force mean (1/substeps, or 1 with BEZ_FLAG_CF_LAST_SUBSTEP)
   uint32_t flags;
   uint64_t seed;
   int64_t env_off;
@@ -62,6 +64,8 @@ struct Params {
   const float* dr_kd;        // (N,18)   or null
   const float* dr_mass;      // (N,19)   or null
   const float* dr_gravity;   // (N,3)    or null
+  const float* dr_lower;     // (N,18)   or null: physical joint limits (targets keep the model's, kick_env.py:393-400)
+  const float* dr_upper;     // (N,18)   or null
   unsigned long long* stamps; // diagnostic builds only (-DBEZ_WS_STAMPS): s_memtime per role / phase of workgroup 0
 };
 
@@ -127,7 +131,7 @@ BEZ_DEV void store_state(float* __restrict__ s, int n, int e, const EnvState& S)
 struct EnvDyn {
   float mu;
   V3 g;
-  float kp_scale[BEZ_ND], kd_scale[BEZ_ND], mass_scale[BEZ_NL];
+  float kp_scale[BEZ_ND], kd_scale[BEZ_ND], mass_scale[BEZ_NL], lo[BEZ_ND], hi[BEZ_ND];
 };
 
 // ---- contact: implicit spring-damper at a point against the ground plane z = 0.
@@ -177,6 +181,17 @@ struct CfOut { float* base; int n; V3 lf, rf; };  // base = &state[F_CF * n + en
 BEZ_DEV void cf_store(const CfOut& c, int body, V3 f) {
   c.base[(size_t)(body * 3 + 0) * c.n] = f.x; c.base[(size_t)(body * 3 + 1) * c.n] = f.y; c.base[(size_t)(body * 3 + 2) * c.n] = f.z;
 }
+// The tensor holds the MEAN force over the substeps of the control step (physx.contact_collection 2 = CC_ALL_SUBSTEPS,
+// bez_kick.yaml:147): the first contributing substep stores w * f, later ones add.
+BEZ_DEV void cf_accum(const CfOut& c, int body, V3 f, float w, bool first) {
+  float* p = c.base + (size_t)(body * 3) * c.n;
+  if (first) { p[0] = f.x * w; p[(size_t)c.n] = f.y * w; p[(size_t)2 * c.n] = f.z * w; }
+  else { p[0] = fmaf(f.x, w, p[0]); p[(size_t)c.n] = fmaf(f.y, w, p[(size_t)c.n]); p[(size_t)2 * c.n] = fmaf(f.z, w, p[(size_t)2 * c.n]); }
+}
+// Isaac Gym's net contact force sums the NORMAL contact impulses only [ext] (checkpoint obs statistics);
+// BEZ_FLAG_CF_WITH_FRICTION keeps the friction part.  Ground normal = +z.
+BEZ_DEV V3 cf_ground(const Params& P, V3 f) { return (P.flags & BEZ_FLAG_CF_WITH_FRICTION) ? f : mk(0.f, 0.f, f.z); }
+BEZ_DEV V3 cf_along(const Params& P, V3 f, V3 n) { return (P.flags & BEZ_FLAG_CF_WITH_FRICTION) ? f : n * dot(f, n); }
 
 // ---- ball <-> leg-box contact bookkeeping (deepest penetration only)
 struct BallSel {
@@ -296,6 +311,55 @@ BEZ_DEV void ball_link_contact(const Params& P, float mu, V3 ball_ang, V3 ball_l
   sel.x = x; sel.xb = xb;
 }
 
+// ---- leg <-> leg self-collision (kick_env.py:365-366: collision_filter 0).  Each leg box is a capsule (BEZ_CAP_*);
+// a penetrating left x right pair is ONE explicit spring-damper + regularised Coulomb point contact with equal and
+// opposite forces on the two links (a contact inside the tree closes a loop the ABA recursion cannot fold in).
+BEZ_DEV float clamp01(float s) { return fminf(fmaxf(s, 0.f), 1.f); }
+BEZ_DEV void segment_closest(V3 p1, V3 q1, V3 p2, V3 q2, V3& c1, V3& c2) {
+  V3 d1 = q1 - p1, d2 = q2 - p2, r = p1 - p2;
+  float a = dot(d1, d1), e = dot(d2, d2), f = dot(d2, r), c = dot(d1, r), b = dot(d1, d2);
+  float den = fmaf(a, e, -b * b);
+  float s = den > 1e-12f ? clamp01(fmaf(b, f, -c * e) / den) : 0.f;
+  float t = fmaf(b, s, f) / e;
+  if (t < 0.f) { t = 0.f; s = clamp01(-c / a); }
+  else if (t > 1.f) { t = 1.f; s = clamp01((b - c) / a); }
+  c1 = fma3(d1, s, p1);
+  c2 = fma3(d2, t, p2);
+}
+// capsule pair (world endpoints rel. O, link velocities about O) -> force f on link a at x; fn = its normal part
+BEZ_DEV bool self_pair(const Params& P, float mu, float ra, float rb, V3 a0, V3 a1, V3 b0, V3 b1, SV Va, SV Vb, V3& x, V3& f, V3& fn) {
+  V3 ca, cb;
+  segment_closest(a0, a1, b0, b1, ca, cb);
+  V3 dl = ca - cb;
+  float d2 = dot(dl, dl), rs = ra + rb;
+  if (!(d2 < rs * rs) || !(d2 > 1e-12f)) return false;
+  float dist = sqrtf(d2), depth = rs - dist;
+  V3 n = dl * (1.0f / dist);
+  x = fma3(n, rb - 0.5f * depth, cb);
+  V3 u = point_of(Va, x) - point_of(Vb, x);
+  float un = dot(u, n);
+  float fmag = fmaf(P.self_kn, depth, -P.self_cn * un);
+  if (!(fmag > 0.f)) return false;
+  V3 ut = u - n * un;
+  float vt = sqrtf(dot(ut, ut));
+  float ct = fminf(mu * fmag / fmaxf(vt, P.veps), P.self_cn);
+  fn = n * fmag;
+  f = fn - ut * ct;
+  return true;
+}
+// world endpoints of the capsules carried by link L
+template <int L>
+BEZ_DEV void link_capsules(const M3& E, V3 r, SV V, V3* c0, V3* c1, SV* cV) {
+#pragma unroll
+  for (int c = 0; c < BEZ_NCAP; ++c) {
+    if (BEZ_CAP_LINK[c] == L) {
+      c0[c] = r + mul(E, mk((float)BEZ_CAP_P0[c][0], (float)BEZ_CAP_P0[c][1], (float)BEZ_CAP_P0[c][2]));
+      c1[c] = r + mul(E, mk((float)BEZ_CAP_P1[c][0], (float)BEZ_CAP_P1[c][1], (float)BEZ_CAP_P1[c][2]));
+      cV[c] = V;
+    }
+  }
+}
+
 // ---- one kinematic step down the tree: child frame / joint axis / velocity from the parent's
 template <int L>
 BEZ_DEV void link_kinematics(float q, float qd, M3& E, V3& r, SV& V, SV& S, SV& cb) {
@@ -383,9 +447,8 @@ BEZ_DEV V3 link_ground_forces(const Params& P, SV acc, const float* lds, int lan
 
 // joint drive / friction / limit terms and the ABA joint-space quantities for DOF d = L-1
 template <int L>
-BEZ_DEV void joint_terms(const Params& P, float kp_scale, float kd_scale, float q, float qd, float target, const Sym6& IA, SV pA, SV S, SV cb,
-                         SV& U, float& Dinv, float& u) {
-  constexpr int d = L - 1;
+BEZ_DEV void joint_terms(const Params& P, float kp_scale, float kd_scale, float lo, float hi, float q, float qd, float target, const Sym6& IA, SV pA,
+                         SV S, SV cb, SV& U, float& Dinv, float& u) {
   U = mul(IA, S);
   float J = dot(S, U) + P.armature;
   float kp = P.kp * kp_scale, kdm = P.kd * kd_scale;
@@ -394,7 +457,6 @@ BEZ_DEV void joint_terms(const Params& P, float kp_scale, float kd_scale, float 
   float cf = P.jfric * frcp(fmaxf(fabsf(qd), P.jf_veps));
   float k_f = P.h * cf, tau_f0 = -cf * qd;
   float k_l = 0.f, tau_l0 = 0.f;
-  constexpr float lo = (float)BEZ_DOF_LOWER[d], hi = (float)BEZ_DOF_UPPER[d];
   if (q < lo) { tau_l0 = fmaf(P.lim_k, lo - q - P.h * qd, -P.lim_d * qd); k_l = fmaf(P.h * P.h, P.lim_k, P.h * P.lim_d); }
   else if (q > hi) { tau_l0 = fmaf(P.lim_k, hi - q - P.h * qd, -P.lim_d * qd); k_l = fmaf(P.h * P.h, P.lim_k, P.h * P.lim_d); }
   float sp = dot(S, pA);
@@ -419,7 +481,7 @@ BEZ_DEV void static_for(F&& f) { static_for_impl(std::make_integer_sequence<int,
 // articulated inertia / bias into the torso's (IA0, pA0) and stages pass-3 data in LDS.
 template <int FIRST, int LEN>
 BEZ_DEV void chain_up(const Params& P, const EnvDyn& D, const EnvState& S, const float* target, const M3& E0, SV V0,
-                      const BallBody& ball, V3 bc, BallSel& sel, Sym6& IA0, SV& pA0, float* lds, int lane, bool keep) {
+                      const BallBody& ball, V3 bc, BallSel& sel, const SV* selfw, Sym6& IA0, SV& pA0, float* lds, int lane, bool keep) {
   LinkInertia LI[LEN];
   SV pAl[LEN], Sl[LEN], cbl[LEN];
   M3 E = E0;
@@ -432,6 +494,7 @@ BEZ_DEV void chain_up(const Params& P, const EnvDyn& D, const EnvState& S, const
     link_kinematics<L>(S.q[L - 1], S.qd[L - 1], E, r, V, Sl[i], cbl[i]);
     link_inertia<L>(D.mass_scale[L], D.g, E, r, V, LI[i], pAl[i]);
     if constexpr (link_has_box(L)) {
+      pAl[i] = pAl[i] + selfw[L];  // explicit leg<->leg contact wrenches of this link
       if (sel.link == L) ball_link_contact(P, D.mu, S.ball_ang, S.ball_lin, ball, bc, V, sel);
     }
   });
@@ -452,7 +515,8 @@ BEZ_DEV void chain_up(const Params& P, const EnvDyn& D, const EnvState& S, const
       }
     }
     SV U; float Dinv, u;
-    joint_terms<L>(P, D.kp_scale[L - 1], D.kd_scale[L - 1], S.q[L - 1], S.qd[L - 1], target[L - 1], IA, pA, Sl[i], cbl[i], U, Dinv, u);
+    joint_terms<L>(P, D.kp_scale[L - 1], D.kd_scale[L - 1], D.lo[L - 1], D.hi[L - 1], S.q[L - 1], S.qd[L - 1], target[L - 1], IA, pA, Sl[i], cbl[i], U,
+                   Dinv, u);
     SV UD = U * Dinv;
     float uD = u * Dinv;
     float* p3 = lds + (size_t)(LDS_P3 + (L - 1) * P3_STRIDE) * BLOCK + lane;
@@ -471,7 +535,8 @@ BEZ_DEV void chain_up(const Params& P, const EnvDyn& D, const EnvState& S, const
 // ---- pass 3 of one chain: joint accelerations from the torso acceleration; integrates the joints in
 // place (semi-implicit Euler + velocity clamp) and resolves contact forces on the way.
 template <int FIRST, int LEN>
-BEZ_DEV void chain_down(const Params& P, EnvState& S, SV a0, BallSel& sel, V3& ball_link_force, CfOut& co, const float* lds, int lane, bool keep) {
+BEZ_DEV void chain_down(const Params& P, EnvState& S, SV a0, BallSel& sel, const V3* selfcf, V3& ball_link_force, CfOut& co, const float* lds,
+                        int lane, bool keep, bool first) {
   SV a = a0;
   constexpr int Lend = FIRST + LEN - 1;
   V3 fend = mk(0, 0, 0);  // ball force on the chain-end link (a foot), if it is the selected box
@@ -491,22 +556,22 @@ BEZ_DEV void chain_down(const Params& P, EnvState& S, SV a0, BallSel& sel, V3& b
     S.qd[L - 1] = v;
     S.q[L - 1] = fmaf(P.h, v, S.q[L - 1]);
     if constexpr (link_has_box(L)) {
-      V3 f = mk(0, 0, 0);
+      V3 f = selfcf[L];
       if (sel.link == L) {
         ball_link_force = sel.f0p - mul(sel.A, point_of(a, sel.x));
-        f = ball_link_force;
+        f = f + cf_along(P, ball_link_force, sel.n);
       }
       if (keep) {
         if constexpr (L == Lend) fend = f;
-        else cf_store(co, BEZ_LINK_BODY[L], f);
+        else cf_accum(co, BEZ_LINK_BODY[L], f, P.cf_w, first);
       }
     }
   });
   if (keep) {
-    V3 f = fend + link_ground_forces<Lend>(P, a, lds, lane);
-    if constexpr (Lend == BEZ_LFOOT_LINK) co.lf = f;
-    else if constexpr (Lend == BEZ_RFOOT_LINK) co.rf = f;
-    else cf_store(co, BEZ_LINK_BODY[Lend], f);
+    V3 f = fend + cf_ground(P, link_ground_forces<Lend>(P, a, lds, lane));
+    if constexpr (Lend == BEZ_LFOOT_LINK) co.lf = first ? f * P.cf_w : fma3(f, P.cf_w, co.lf);
+    else if constexpr (Lend == BEZ_RFOOT_LINK) co.rf = first ? f * P.cf_w : fma3(f, P.cf_w, co.rf);
+    else cf_accum(co, BEZ_LINK_BODY[Lend], f, P.cf_w, first);
   }
 }
 
@@ -522,32 +587,51 @@ BEZ_DEV void quat_integrate(float q[4], V3 w, float h) {
   q[0] = x * n; q[1] = y * n; q[2] = z * n; q[3] = s * n;
 }
 
-// ---- one substep of the articulated-body dynamics for this lane's env.  When `keep` (last substep only) the
-// net contact force per body is produced: foot rows in `co`, all other rows stored to HBM.
-BEZ_DEV void substep(const Params& P, const EnvDyn& D, EnvState& S, const float* target, CfOut& co, float* lds, int lane, bool keep) {
+// ---- one substep of the articulated-body dynamics for this lane's env.  When `keep` the net contact force per body of
+// this substep is accumulated (`first`: it starts the mean): foot rows in `co`, all other rows in HBM.
+BEZ_DEV void substep(const Params& P, const EnvDyn& D, EnvState& S, const float* target, CfOut& co, float* lds, int lane, bool keep, bool first) {
   const M3 E0 = quat_to_mat(S.rq[0], S.rq[1], S.rq[2], S.rq[3]);
   const SV V0 = mksv(S.root_ang, S.root_lin);
   const V3 bc = S.ball_pos - S.root_pos;  // ball centre rel. O
-  // (a) which leg box, if any, does the ball penetrate deepest?  Frames only.
+  // (a) leg frames: which box, if any, does the ball penetrate deepest (legs first, torso box last; strict >), and the
+  //     leg capsules for the self-collision
   BallSel sel;
   sel.link = -1; sel.depth = 0.f; sel.n = sel.P = sel.f0p = sel.x = sel.xb = mk(0, 0, 0); sel.A = sym3zero();
+  V3 cap0[BEZ_NCAP], cap1[BEZ_NCAP]; SV capV[BEZ_NCAP];
   {
-    M3 E = E0; V3 r = mk(0, 0, 0);
+    M3 E = E0; V3 r = mk(0, 0, 0); SV V = V0, Sj, cbj;
     static_for<6>([&](auto I) {
       constexpr int L = 5 + decltype(I)::value;
-      link_frame_only<L>(S.q[L - 1], E, r);
-      if constexpr (link_has_box(L)) test_box<link_box(L)>(E, r, bc, sel);
+      link_kinematics<L>(S.q[L - 1], S.qd[L - 1], E, r, V, Sj, cbj);
+      if constexpr (link_has_box(L)) { test_box<link_box(L)>(E, r, bc, sel); link_capsules<L>(E, r, V, cap0, cap1, capV); }
     });
-    E = E0; r = mk(0, 0, 0);
+    E = E0; r = mk(0, 0, 0); V = V0;
     static_for<6>([&](auto I) {
       constexpr int L = 13 + decltype(I)::value;
-      link_frame_only<L>(S.q[L - 1], E, r);
-      if constexpr (link_has_box(L)) test_box<link_box(L)>(E, r, bc, sel);
+      link_kinematics<L>(S.q[L - 1], S.qd[L - 1], E, r, V, Sj, cbj);
+      if constexpr (link_has_box(L)) { test_box<link_box(L)>(E, r, bc, sel); link_capsules<L>(E, r, V, cap0, cap1, capV); }
+    });
+    test_box<link_box(0)>(E0, mk(0, 0, 0), bc, sel);
+  }
+  SV selfw[BEZ_NL]; V3 selfcf[BEZ_NL];
+#pragma unroll
+  for (int l = 0; l < BEZ_NL; ++l) { selfw[l] = svzero(); selfcf[l] = mk(0, 0, 0); }
+  if (!(P.flags & BEZ_FLAG_NO_SELF_COLLISION)) {
+    static_for<BEZ_NCPAIR>([&](auto I) {
+      constexpr int ia = BEZ_CPAIR[decltype(I)::value][0], ib = BEZ_CPAIR[decltype(I)::value][1];
+      constexpr int la = BEZ_CAP_LINK[ia], lb = BEZ_CAP_LINK[ib];
+      V3 x, f, fn;
+      if (self_pair(P, D.mu, (float)BEZ_CAP_R[ia], (float)BEZ_CAP_R[ib], cap0[ia], cap1[ia], cap0[ib], cap1[ib], capV[ia], capV[ib], x, f, fn)) {
+        SV w = wrench_at(x, f);
+        selfw[la] = selfw[la] - w; selfw[lb] = selfw[lb] + w;
+        V3 fr = (P.flags & BEZ_FLAG_CF_WITH_FRICTION) ? f : fn;
+        selfcf[la] = selfcf[la] + fr; selfcf[lb] = selfcf[lb] - fr;
+      }
     });
   }
   // (b) ball free body with its ground contact
   BallBody ball = ball_setup(P, D.mu, D.g, S.ball_pos.z, S.ball_ang, S.ball_lin);
-  // (c) torso: own inertia + guard points, then the five chains
+  // (c) torso: own inertia + guard points (+ the ball when the torso box is the deepest), then the five chains
   Sym6 IA0 = sym6zero();
   SV pA0;
   {
@@ -555,28 +639,36 @@ BEZ_DEV void substep(const Params& P, const EnvDyn& D, EnvState& S, const float*
     link_inertia<0>(D.mass_scale[0], D.g, E0, mk(0, 0, 0), V0, I0, pA0);
     add_link_inertia(IA0, I0);
     link_ground_points<0>(P, D.mu, S.root_pos.z, E0, mk(0, 0, 0), V0, IA0, pA0, lds, lane, keep);
+    if (sel.link == 0) {
+      ball_link_contact(P, D.mu, S.ball_ang, S.ball_lin, ball, bc, V0, sel);
+      if (sel.link == 0) { add_point_stiffness(IA0, sel.x, sel.A); pA0 = pA0 - wrench_at(sel.x, sel.f0p); }
+    }
   }
-  chain_up<1, 2>(P, D, S, target, E0, V0, ball, bc, sel, IA0, pA0, lds, lane, keep);    // neck, head
-  chain_up<3, 2>(P, D, S, target, E0, V0, ball, bc, sel, IA0, pA0, lds, lane, keep);    // left arm
-  chain_up<5, 6>(P, D, S, target, E0, V0, ball, bc, sel, IA0, pA0, lds, lane, keep);    // left leg
-  chain_up<11, 2>(P, D, S, target, E0, V0, ball, bc, sel, IA0, pA0, lds, lane, keep);   // right arm
-  chain_up<13, 6>(P, D, S, target, E0, V0, ball, bc, sel, IA0, pA0, lds, lane, keep);   // right leg
+  chain_up<1, 2>(P, D, S, target, E0, V0, ball, bc, sel, selfw, IA0, pA0, lds, lane, keep);    // neck, head
+  chain_up<3, 2>(P, D, S, target, E0, V0, ball, bc, sel, selfw, IA0, pA0, lds, lane, keep);    // left arm
+  chain_up<5, 6>(P, D, S, target, E0, V0, ball, bc, sel, selfw, IA0, pA0, lds, lane, keep);    // left leg
+  chain_up<11, 2>(P, D, S, target, E0, V0, ball, bc, sel, selfw, IA0, pA0, lds, lane, keep);   // right arm
+  chain_up<13, 6>(P, D, S, target, E0, V0, ball, bc, sel, selfw, IA0, pA0, lds, lane, keep);   // right leg
   // (d) root: I0^A a0 = -p0^A
   SV a0 = solve_spd6(IA0, svzero() - pA0);
   // (e) pass 3 + joint integration + contact forces
-  if (keep) cf_store(co, 0, link_ground_forces<0>(P, a0, lds, lane));
   V3 fl = mk(0, 0, 0);
-  chain_down<1, 2>(P, S, a0, sel, fl, co, lds, lane, keep);
-  chain_down<3, 2>(P, S, a0, sel, fl, co, lds, lane, keep);
-  chain_down<5, 6>(P, S, a0, sel, fl, co, lds, lane, keep);
-  chain_down<11, 2>(P, S, a0, sel, fl, co, lds, lane, keep);
-  chain_down<13, 6>(P, S, a0, sel, fl, co, lds, lane, keep);
+  {
+    V3 f0 = mk(0, 0, 0);
+    if (sel.link == 0) { fl = sel.f0p - mul(sel.A, point_of(a0, sel.x)); f0 = cf_along(P, fl, sel.n); }
+    if (keep) cf_accum(co, 0, f0 + cf_ground(P, link_ground_forces<0>(P, a0, lds, lane)), P.cf_w, first);
+  }
+  chain_down<1, 2>(P, S, a0, sel, selfcf, fl, co, lds, lane, keep, first);
+  chain_down<3, 2>(P, S, a0, sel, selfcf, fl, co, lds, lane, keep, first);
+  chain_down<5, 6>(P, S, a0, sel, selfcf, fl, co, lds, lane, keep, first);
+  chain_down<11, 2>(P, S, a0, sel, selfcf, fl, co, lds, lane, keep, first);
+  chain_down<13, 6>(P, S, a0, sel, selfcf, fl, co, lds, lane, keep, first);
   // (f) ball: Mb ab = -pb - Jb^T fl
   SV ab = ball_minv(ball, svzero() - ball.pb - wrench_at(sel.xb, fl));
   if (keep) {
-    V3 fb = -fl;
-    if (ball.ground) fb = fb + hit_force(P, ball.ghit, ab);
-    cf_store(co, BEZ_NBE - 1, fb);
+    V3 fb = -cf_along(P, fl, sel.n);
+    if (ball.ground) fb = fb + cf_ground(P, hit_force(P, ball.ghit, ab));
+    cf_accum(co, BEZ_NBE - 1, fb, P.cf_w, first);
   }
   // (g) integrate root (spatial -> classical acceleration of the torso origin) and ball
   V3 vdot = a0.l + cross(S.root_ang, S.root_lin);
@@ -771,7 +863,17 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(Params P) {
     for (int j = 0; j < BEZ_ND; ++j) { D.kp_scale[j] = 1.f; D.kd_scale[j] = 1.f; }
 #pragma unroll
     for (int l = 0; l < BEZ_NL; ++l) D.mass_scale[l] = 1.f;
+#pragma unroll
+    for (int j = 0; j < BEZ_ND; ++j) { D.lo[j] = (float)BEZ_DOF_LOWER[j]; D.hi[j] = (float)BEZ_DOF_UPPER[j]; }
     if (DR) {
+      if (P.dr_lower) {
+#pragma unroll
+        for (int j = 0; j < BEZ_ND; ++j) D.lo[j] = P.dr_lower[(size_t)e * BEZ_ND + j];
+      }
+      if (P.dr_upper) {
+#pragma unroll
+        for (int j = 0; j < BEZ_ND; ++j) D.hi[j] = P.dr_upper[(size_t)e * BEZ_ND + j];
+      }
       if (P.dr_friction) D.mu = P.dr_friction[e];
       if (P.dr_gravity) D.g = mk(P.dr_gravity[(size_t)e * 3], P.dr_gravity[(size_t)e * 3 + 1], P.dr_gravity[(size_t)e * 3 + 2]);
       if (P.dr_kp) {
@@ -787,7 +889,11 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(Params P) {
         for (int l = 0; l < BEZ_NL; ++l) D.mass_scale[l] = P.dr_mass[(size_t)e * BEZ_NL + l];
       }
     }
-    for (int s = 0; s < P.substeps; ++s) substep(P, D, S, target, co, lds, lane, s == P.substeps - 1);
+    const bool last_only = (P.flags & BEZ_FLAG_CF_LAST_SUBSTEP) != 0;
+    for (int s = 0; s < P.substeps; ++s) {
+      const bool last = (s == P.substeps - 1);
+      substep(P, D, S, target, co, lds, lane, last_only ? last : true, last_only ? true : (s == 0));
+    }
   } else if (POST) {
     co.lf = mk(co.base[(size_t)(BEZ_LFOOT_BODY * 3 + 0) * n], co.base[(size_t)(BEZ_LFOOT_BODY * 3 + 1) * n], co.base[(size_t)(BEZ_LFOOT_BODY * 3 + 2) * n]);
     co.rf = mk(co.base[(size_t)(BEZ_RFOOT_BODY * 3 + 0) * n], co.base[(size_t)(BEZ_RFOOT_BODY * 3 + 1) * n], co.base[(size_t)(BEZ_RFOOT_BODY * 3 + 2) * n]);

@@ -48,7 +48,7 @@ struct BezSim {
   float* targets_aos = nullptr;  // (N,18)
   float* prev_aos = nullptr;     // (N,3)
   float* feet_aos = nullptr;     // (N,8)
-  float* dr[BEZ_PARAM_COUNT] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  float* dr[BEZ_PARAM_COUNT] = {};
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   unsigned long long* stamps = nullptr;  // diagnostic builds only
 };
@@ -87,11 +87,14 @@ Params make_params(const BezSim* s, const float* actions) {
   P.goal[0] = c.goal[0]; P.goal[1] = c.goal[1];
   P.kn = c.contact_kn; P.cn = c.contact_cn; P.ct = c.contact_ct; P.veps = c.contact_veps;
   P.lim_k = c.limit_k; P.lim_d = c.limit_d; P.jf_veps = c.jfric_veps; P.ball_damp = c.ball_ang_damping;
+  P.self_kn = c.self_kn; P.self_cn = c.self_cn;
+  P.cf_w = (c.flags & BEZ_FLAG_CF_LAST_SUBSTEP) ? 1.0f : 1.0f / (float)c.substeps;
   P.flags = c.flags; P.seed = c.seed; P.env_off = c.env_id_offset;
   P.state = s->state; P.obs = s->obs; P.rew = s->rew; P.reset = s->reset; P.progress = s->progress;
   P.timeout = s->timeout; P.episode = s->episode; P.actions = actions;
   P.dr_friction = s->dr[BEZ_PARAM_FRICTION]; P.dr_kp = s->dr[BEZ_PARAM_KP_SCALE]; P.dr_kd = s->dr[BEZ_PARAM_KD_SCALE];
   P.dr_mass = s->dr[BEZ_PARAM_MASS_SCALE]; P.dr_gravity = s->dr[BEZ_PARAM_GRAVITY];
+  P.dr_lower = s->dr[BEZ_PARAM_DOF_LOWER]; P.dr_upper = s->dr[BEZ_PARAM_DOF_UPPER];
   P.stamps = s->stamps;
   return P;
 }
@@ -263,12 +266,9 @@ int launch_step(BezSim* s, const float* actions, hipStream_t stream) {
   const bool dr = has_dr(s);
   if constexpr (SIM && PRE == POST) {
     if (use_ws_kernel()) {
-      static const int ne = [] { const char* v = std::getenv("BEZ_WS_ENVS"); int k = v ? std::atoi(v) : 64; return (k == 16 || k == 32) ? k : 64; }();
-      dim3 grid((s->n + ne - 1) / ne), block(WS_BLOCK);
-      if (dr) hipLaunchKernelGGL((step_kernel_ws<PRE, POST, true, 64>), dim3((s->n + 63) / 64), block, 0, stream, P);
-      else if (ne == 64) hipLaunchKernelGGL((step_kernel_ws<PRE, POST, false, 64>), grid, block, 0, stream, P);
-      else if (ne == 32) hipLaunchKernelGGL((step_kernel_ws<PRE, POST, false, 32>), grid, block, 0, stream, P);
-      else hipLaunchKernelGGL((step_kernel_ws<PRE, POST, false, 16>), grid, block, 0, stream, P);
+      dim3 grid((s->n + WS_ENVS - 1) / WS_ENVS), block(WS_BLOCK);
+      if (dr) hipLaunchKernelGGL((step_kernel_ws<PRE, POST, true>), grid, block, 0, stream, P);
+      else hipLaunchKernelGGL((step_kernel_ws<PRE, POST, false>), grid, block, 0, stream, P);
       hipError_t e = hipGetLastError();
       if (e != hipSuccess) return fail(s, -2, "step_kernel_ws launch", e);
       if (POST) s->obs_calls += 1;
@@ -306,6 +306,7 @@ int bez_sim_default_config(BezSimConfig* c, int32_t num_envs) {
   c->goal[0] = (float)BEZ_DEFAULT_GOAL[0]; c->goal[1] = (float)BEZ_DEFAULT_GOAL[1];
   c->contact_kn = 2.0e4f; c->contact_cn = 20.0f; c->contact_ct = 1.0e3f; c->contact_veps = 0.01f;
   c->limit_k = 200.0f; c->limit_d = 2.0f; c->jfric_veps = 0.1f; c->ball_ang_damping = 0.5f;
+  c->self_kn = 3000.0f; c->self_cn = 5.0f;
   c->flags = BEZ_FLAG_IMU_PREV_ALIAS;
   c->seed = 42;
   c->env_id_offset = 0;
@@ -514,7 +515,7 @@ int bez_sim_reset_indexed(BezSim* s, const int32_t* env_ids_dev, int32_t count, 
 
 int bez_sim_set_env_params(BezSim* s, int param, const float* values_dev, void* stream) {
   if (!s || param < 0 || param >= BEZ_PARAM_COUNT) return fail(s, -1, "bez_sim_set_env_params: bad argument");
-  static const int width[BEZ_PARAM_COUNT] = {1, BEZ_ND, BEZ_ND, BEZ_NL, 3};
+  static const int width[BEZ_PARAM_COUNT] = {1, BEZ_ND, BEZ_ND, BEZ_NL, 3, BEZ_ND, BEZ_ND};
   if (!values_dev) {
     if (s->dr[param]) { HIP_TRY(s, hipStreamSynchronize((hipStream_t)stream)); (void)hipFree(s->dr[param]); s->dr[param] = nullptr; }
     return 0;

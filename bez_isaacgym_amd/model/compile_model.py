@@ -182,11 +182,13 @@ def build():
         lower.append(lo); upper.append(hi)
         default.append(float(env["readyJointAngles"][d["joint_name"]]))
 
-    # leg collision boxes used for ball contact (foot, ankle, calve, thigh, hip_front per leg)
+    # collision boxes used for ball contact: foot, ankle, calve, thigh, hip_front per leg (+ the torso box, appended below)
     boxes = []
     for li, d in enumerate(dyn):
         if d["box"] is not None and min(d["box"]["half"]) > 1e-3:
             boxes.append({"link": li, "center": d["box"]["center"], "half": d["box"]["half"]})
+    # ball <-> torso: the torso collision mesh is approximated by its bounding box (same vertex data as the guard points below)
+    boxes.append({"link": 0, "center": [0.012, 0.0, -0.033], "half": [0.052, 0.0725, 0.095]})
     # ground contact points: foot box bottom corners + guard points on the torso and on the other
     # chain-end links (head, forearms).  Mid-chain links carry no ground points: an episode ends at
     # torso z < 0.275 (kick_env.py:1331) long before a knee could reach the floor.
@@ -213,6 +215,41 @@ def build():
     for side, sgn in (("left", 1.0), ("right", -1.0)):
         add("/%s_forearm" % side, [-0.0055 - 0.005, sgn * (0.005 + 0.0245), -0.131], "guard")
 
+    # leg <-> leg self-collision shapes (the reference enables self-collision: kick_env.py:365-366, collision_filter 0):
+    # every leg box becomes a capsule along its longest axis with the larger cross-section half-extent as radius;
+    # the 3 mm foot plate becomes two thin capsules along its long edges.  Pairs: left x right, the hip boxes only
+    # against the other hip box / thigh (they cannot reach further down).
+    capsules = []
+    for b in boxes:
+        if b["link"] == 0:
+            continue
+        h, c = b["half"], b["center"]
+        ax = int(np.argmax(h))
+        o1, o2 = [i for i in range(3) if i != ax]
+        side = "L" if dyn[b["link"]]["name"].startswith("/left") else "R"
+        short = dyn[b["link"]]["name"].split("_", 1)[1]
+        if min(h) < 3e-3:
+            mid = o1 if h[o1] > h[o2] else o2
+            r = 0.01
+            for sgn in (+1.0, -1.0):
+                p0, p1 = list(c), list(c)
+                p0[mid] += sgn * (h[mid] - r); p1[mid] += sgn * (h[mid] - r)
+                p0[ax] -= h[ax] - r; p1[ax] += h[ax] - r
+                capsules.append({"link": b["link"], "p0": p0, "p1": p1, "r": r, "side": side, "part": short})
+        else:
+            r = max(h[o1], h[o2])
+            hl = max(h[ax] - r, 0.0)
+            p0, p1 = list(c), list(c)
+            p0[ax] -= hl; p1[ax] += hl
+            capsules.append({"link": b["link"], "p0": p0, "p1": p1, "r": r, "side": side, "part": short})
+    cap_pairs = []
+    for i, a in enumerate(capsules):
+        for j, b in enumerate(capsules):
+            if a["side"] == "L" and b["side"] == "R":
+                if "hip_front" in (a["part"], b["part"]) and not ({a["part"], b["part"]} <= {"hip_front", "thigh"}):
+                    continue
+                cap_pairs.append([i, j])
+
     ball = ball_links["base_link"]
     model = {
         "num_bodies": 21, "num_links": 19, "num_dofs": 18,
@@ -225,6 +262,7 @@ def build():
         } for d in dyn],
         "dof_lower": lower, "dof_upper": upper, "dof_default": default,
         "boxes": boxes, "ground_points": points,
+        "capsules": [{k: c[k] for k in ("link", "p0", "p1", "r")} for c in capsules], "capsule_pairs": cap_pairs,
         "ball": {"mass": ball["mass"], "inertia": ball["inertia"][0], "radius": ball["sphere"]},
         "cfg": {
             "dt": float(cfg["sim"]["dt"]), "substeps": int(cfg["sim"]["substeps"]),
@@ -294,6 +332,13 @@ def emit_header(m):
     o.append("/* ground contact points (link-local), only on the torso and on chain-end links; the first 8 are the foot-box bottom corners (4 left, 4 right) */")
     o.append("BEZ_TBL int BEZ_PT_LINK[BEZ_NPT] = {%s};" % ", ".join(str(p["link"]) for p in m["ground_points"]))
     o.append("BEZ_TBL double BEZ_PT_POS[BEZ_NPT][3] = {%s};" % ", ".join(arr(p["p"]) for p in m["ground_points"]))
+    o.append("/* leg self-collision capsules (link-local segment p0-p1, radius) and the left x right pair list */")
+    o.append("#define BEZ_NCAP %d\n#define BEZ_NCPAIR %d" % (len(m["capsules"]), len(m["capsule_pairs"])))
+    o.append("BEZ_TBL int BEZ_CAP_LINK[BEZ_NCAP] = {%s};" % ", ".join(str(c["link"]) for c in m["capsules"]))
+    o.append("BEZ_TBL double BEZ_CAP_P0[BEZ_NCAP][3] = {%s};" % ", ".join(arr(c["p0"]) for c in m["capsules"]))
+    o.append("BEZ_TBL double BEZ_CAP_P1[BEZ_NCAP][3] = {%s};" % ", ".join(arr(c["p1"]) for c in m["capsules"]))
+    o.append("BEZ_TBL double BEZ_CAP_R[BEZ_NCAP] = %s;" % arr(c["r"] for c in m["capsules"]))
+    o.append("BEZ_TBL int BEZ_CPAIR[BEZ_NCPAIR][2] = {%s};" % ", ".join("{%d, %d}" % tuple(p) for p in m["capsule_pairs"]))
     o.append("#define BEZ_BALL_MASS %s\n#define BEZ_BALL_INERTIA %s\n#define BEZ_BALL_RADIUS %s" % (
         fmt(m["ball"]["mass"]), fmt(m["ball"]["inertia"]), fmt(m["ball"]["radius"])))
     c = m["cfg"]

@@ -105,9 +105,25 @@ def _materialise(node, zf, prefix):
             pers, offset, size, stride = node.args[0], node.args[1], node.args[2], node.args[3]
             _tag, styp, key, _dev, numel = pers.pid
             dt = np.dtype(_STORAGE_DTYPE[styp.name])
-            raw = np.frombuffer(zf.read("%s/data/%s" % (prefix, key)), dtype=dt, count=numel)
+            buf = zf.read("%s/data/%s" % (prefix, key))
+            # every number below comes from the untrusted pickle: validate before building a strided view
+            ints = [offset, numel] + list(size) + list(stride)
+            if not all(isinstance(v, int) and not isinstance(v, bool) for v in ints):
+                raise ValueError("checkpoint tensor record holds non-integer geometry")
+            if numel < 0 or numel * dt.itemsize > len(buf) or offset < 0 or len(size) != len(stride):
+                raise ValueError("checkpoint tensor record is out of bounds of its storage")
+            if any(v < 0 for v in size) or any(v < 0 for v in stride):
+                raise ValueError("checkpoint tensor record has a negative size or stride")
+            raw = np.frombuffer(buf, dtype=dt, count=numel)
             if len(size) == 0:
+                if offset >= numel:
+                    raise ValueError("checkpoint scalar offset is out of bounds of its storage")
                 return raw[offset].copy()
+            if any(v == 0 for v in size):
+                return np.zeros(tuple(size), dtype=dt)
+            last = offset + sum((sz - 1) * st for sz, st in zip(size, stride))
+            if last >= numel:
+                raise ValueError("checkpoint tensor view reaches past the end of its storage")
             view = np.lib.stride_tricks.as_strided(raw[offset:], shape=tuple(size), strides=tuple(s * dt.itemsize for s in stride))
             return np.array(view)  # own the memory
         if node.fn == "numpy.core.multiarray scalar":  # (dtype record, latin1-encoded raw bytes): decode plain numbers only

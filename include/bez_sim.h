@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define BEZ_SIM_ABI_VERSION 1
+#define BEZ_SIM_ABI_VERSION 2
 
 #define BEZ_NUM_OBS 54
 #define BEZ_NUM_ACTIONS 18
@@ -43,6 +43,12 @@ extern "C" {
 /* flags */
 #define BEZ_FLAG_IMU_PREV_ALIAS 1u /* quirk Q1 (kick_env.py:930,441): prev_lin_vel aliases the live \
                                       velocity, so the finite difference is identically 0 */
+
+#define BEZ_FLAG_CF_LAST_SUBSTEP 4u   /* NET_CONTACT_FORCE = last substep only; default: mean over the substeps of the \
+                                        control step (physx.contact_collection 2 = CC_ALL_SUBSTEPS, bez_kick.yaml:147) */
+#define BEZ_FLAG_NO_SELF_COLLISION 8u /* disable leg<->leg contact (the reference enables self-collision) */
+#define BEZ_FLAG_CF_WITH_FRICTION 2u /* NET_CONTACT_FORCE rows include friction; default off: Isaac Gym reports the \
+                                        normal contact impulses only [ext] (checkpoint obs statistics) */
 
 typedef struct BezSimConfig {
   int32_t abi_version; /* must be BEZ_SIM_ABI_VERSION */
@@ -71,6 +77,9 @@ typedef struct BezSimConfig {
   float limit_d;       /* joint-limit damper                  [N*m*s/rad] */
   float jfric_veps;    /* joint-friction regularisation speed [rad/s] */
   float ball_ang_damping; /* Isaac asset default angular_damping 0.5 [ext] for the ball actor */
+  float self_kn;       /* leg<->leg self-collision (kick_env.py:365-366, filter 0): spring [N/m]   */
+  float self_cn;       /*                                                     damper [N*s/m] */
+  float tune[8];       /* calibration knobs of the physics model; 0 = default behaviour */
   uint32_t flags;      /* BEZ_FLAG_* */
   uint64_t seed;       /* reset-noise stream key (config.yaml:11 seed: 42) */
   int64_t env_id_offset; /* global id of local env 0; reset noise is keyed by GLOBAL env id so
@@ -159,7 +168,9 @@ enum BezEnvParam {
   BEZ_PARAM_KD_SCALE = 2,   /* (N,18) damping scaling                       bez_kick.yaml:194-199 */
   BEZ_PARAM_MASS_SCALE = 3, /* (N,19) link mass scaling (setup only)        bez_kick.yaml:170-177 */
   BEZ_PARAM_GRAVITY = 4,    /* (N,3)  gravity vector                        bez_kick.yaml:162-167 */
-  BEZ_PARAM_COUNT = 5
+  BEZ_PARAM_DOF_LOWER = 5,  /* (N,18) physical lower joint limits           bez_kick.yaml:206-212 */
+  BEZ_PARAM_DOF_UPPER = 6,  /* (N,18) physical upper joint limits           bez_kick.yaml:213-219 */
+  BEZ_PARAM_COUNT = 7
 };
 int bez_sim_set_env_params(BezSim* sim, int param, const float* values_dev, void* stream);
 

@@ -226,7 +226,7 @@ typedef struct {
   int64_t reset, progress, timeout;
   uint32_t episode;
   /* DR */
-  real friction, kp_scale[ND], kd_scale[ND], mass_scale[NL], gravity[3];
+  real friction, kp_scale[ND], kd_scale[ND], mass_scale[NL], gravity[3], lim_lo[ND], lim_hi[ND];
 } Env;
 
 typedef struct {
@@ -295,6 +295,61 @@ static int ground_contact(const BezSimConfig* c, real mu, real h, V3 x, real z, 
   return 1;
 }
 
+
+/* ---- leg <-> leg self-collision (kick_env.py:365-366: create_actor(..., collision_filter 0) enables it).
+ * Each leg box is a capsule (bez_model_gen.h: BEZ_CAP_*); every left x right pair of BEZ_CPAIR is tested by the
+ * closest points of the two segments.  A penetrating pair is one EXPLICIT spring-damper + regularised Coulomb point
+ * contact with equal and opposite forces on the two links (momentum is conserved exactly).  Explicit because a
+ * contact between two links of the same tree closes a kinematic loop that the ABA recursion cannot fold in. */
+static void segment_closest(V3 p1, V3 q1, V3 p2, V3 q2, V3* c1, V3* c2) {
+  V3 d1 = v3sub(q1, p1), d2 = v3sub(q2, p2), r = v3sub(p1, p2);
+  real a = v3dot(d1, d1), e = v3dot(d2, d2), f = v3dot(d2, r);
+  real c = v3dot(d1, r), b = v3dot(d1, d2);
+  real den = a * e - b * b; /* >= 0; segments here never degenerate to points (a, e > 0) */
+  real s = den > (real)1e-12 ? (b * f - c * e) / den : 0;
+  if (s < 0) s = 0;
+  if (s > 1) s = 1;
+  real t = (b * s + f) / e;
+  if (t < 0) { t = 0; s = -c / a; if (s < 0) s = 0; if (s > 1) s = 1; }
+  else if (t > 1) { t = 1; s = (b - c) / a; if (s < 0) s = 0; if (s > 1) s = 1; }
+  *c1 = v3add(p1, v3scale(d1, s));
+  *c2 = v3add(p2, v3scale(d2, t));
+}
+static void self_collision(const BezSimConfig* c, real mu, const Kin* k, const SV* V, SV* pA, real cf[][3], int with_fric) {
+  for (int pr = 0; pr < BEZ_NCPAIR; ++pr) {
+    const int ia = BEZ_CPAIR[pr][0], ib = BEZ_CPAIR[pr][1];
+    const int la = BEZ_CAP_LINK[ia], lb = BEZ_CAP_LINK[ib];
+    V3 a0 = v3add(k->r[la], m3mulv(&k->E[la], v3((real)BEZ_CAP_P0[ia][0], (real)BEZ_CAP_P0[ia][1], (real)BEZ_CAP_P0[ia][2])));
+    V3 a1 = v3add(k->r[la], m3mulv(&k->E[la], v3((real)BEZ_CAP_P1[ia][0], (real)BEZ_CAP_P1[ia][1], (real)BEZ_CAP_P1[ia][2])));
+    V3 b0 = v3add(k->r[lb], m3mulv(&k->E[lb], v3((real)BEZ_CAP_P0[ib][0], (real)BEZ_CAP_P0[ib][1], (real)BEZ_CAP_P0[ib][2])));
+    V3 b1 = v3add(k->r[lb], m3mulv(&k->E[lb], v3((real)BEZ_CAP_P1[ib][0], (real)BEZ_CAP_P1[ib][1], (real)BEZ_CAP_P1[ib][2])));
+    V3 ca, cb;
+    segment_closest(a0, a1, b0, b1, &ca, &cb);
+    V3 dl = v3sub(ca, cb);
+    real d2 = v3dot(dl, dl);
+    real rs = (real)BEZ_CAP_R[ia] + (real)BEZ_CAP_R[ib];
+    if (!(d2 < rs * rs) || !(d2 > (real)1e-12)) continue;
+    real dist = sqrt(d2), depth = rs - dist;
+    V3 n = v3scale(dl, 1 / dist);                                         /* from capsule b towards capsule a */
+    V3 x = v3add(cb, v3scale(n, (real)BEZ_CAP_R[ib] - (real)0.5 * depth)); /* mid-point of the overlap, rel. O */
+    V3 va = v3add(sv_lin(V[la]), v3cross(sv_ang(V[la]), x)), vb = v3add(sv_lin(V[lb]), v3cross(sv_ang(V[lb]), x));
+    V3 u = v3sub(va, vb);
+    real un = v3dot(u, n);
+    real fmag = (real)c->self_kn * depth - (real)c->self_cn * un;
+    if (!(fmag > 0)) continue;
+    V3 ut = v3sub(u, v3scale(n, un));
+    real vt = sqrt(v3dot(ut, ut));
+    real ct = mu * fmag / fmax(vt, (real)c->contact_veps);
+    if (ct > (real)c->self_cn) ct = (real)c->self_cn; /* explicit: the stick viscosity is capped like the normal damper */
+    V3 fn = v3scale(n, fmag);
+    V3 f = v3add(fn, v3scale(ut, -ct));                                   /* force on link la; -f on link lb */
+    pA[la] = sv_add(pA[la], sv_scale(wrench_at(x, f), -1));
+    pA[lb] = sv_add(pA[lb], wrench_at(x, f));
+    V3 fr = with_fric ? f : fn;
+    for (int i = 0; i < 3; ++i) { cf[BEZ_LINK_BODY[la]][i] += fr.v[i]; cf[BEZ_LINK_BODY[lb]][i] -= fr.v[i]; }
+  }
+}
+
 /* One evaluation of the build's dynamics model for one env at substep size h.
  * `mode` 0 = full model; 1 = bare ABA (no PD / friction / limits / contact / armature: used by the
  * known-answer tests, with tau_in as the applied joint torques). */
@@ -342,7 +397,7 @@ static void dynamics(const BezSimConfig* c, const Env* e, real h, int mode, cons
   M6 Mb; memset(&Mb, 0, sizeof(Mb));
   SV pb; memset(&pb, 0, sizeof(pb));
   GroundHit bhit; int ball_ground = 0;
-  int bl_link = -1; V3 bl_x = v3(0, 0, 0), bl_xb = v3(0, 0, 0); M3 bl_A; V3 bl_f0p = v3(0, 0, 0);
+  int bl_link = -1; V3 bl_x = v3(0, 0, 0), bl_xb = v3(0, 0, 0), bl_n = v3(0, 0, 0); M3 bl_A; V3 bl_f0p = v3(0, 0, 0);
   memset(&bl_A, 0, sizeof(bl_A));
   if (mode == 0) {
     for (int i = 0; i < BEZ_NPT; ++i) {
@@ -351,6 +406,9 @@ static void dynamics(const BezSimConfig* c, const Env* e, real h, int mode, cons
       V3 x = v3add(k.r[l], m3mulv(&k.E[l], pl));
       real z = e->root_pos[2] + x.v[2];
       if (ground_contact(c, mu, h, x, z, V[l], &IA[l], &pA[l], &hits[nhit])) { hits[nhit].link = l; ++nhit; }
+    }
+    if (!(c->flags & BEZ_FLAG_NO_SELF_COLLISION)) {
+      self_collision(c, mu, &k, V, pA, out->contact_force, (c->flags & BEZ_FLAG_CF_WITH_FRICTION) != 0);
     }
     /* ball */
     real R = (real)BEZ_BALL_RADIUS, mb = (real)BEZ_BALL_MASS, Ib = (real)BEZ_BALL_INERTIA;
@@ -434,7 +492,7 @@ static void dynamics(const BezSimConfig* c, const Env* e, real h, int mode, cons
         for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j)
           for (int a = 0; a < 6; ++a) for (int b2 = 0; b2 < 6; ++b2) IA[l].m[a][b2] += Jc[i].v[a] * bl_A.m[i][j] * Jc[j].v[b2];
         pA[l] = sv_add(pA[l], sv_scale(wrench_at(x, bl_f0p), -1));
-        bl_x = x; bl_xb = xb;
+        bl_x = x; bl_xb = xb; bl_n = bn;
       } else {
         bl_link = -1;
       }
@@ -456,7 +514,7 @@ static void dynamics(const BezSimConfig* c, const Env* e, real h, int mode, cons
       real cf = (real)c->joint_friction / fmax(fabs(e->qd[d]), (real)c->jfric_veps);
       real k_f = h * cf, tau_f0 = -cf * e->qd[d];
       real k_l = 0, tau_l0 = 0;
-      real lo = (real)BEZ_DOF_LOWER[d], hi = (real)BEZ_DOF_UPPER[d];
+      real lo = e->lim_lo[d], hi = e->lim_hi[d]; /* DR may jitter the PHYSICAL limits (bez_kick.yaml:206-219); targets keep the originals */
       if (e->q[d] < lo) { tau_l0 = (real)c->limit_k * (lo - e->q[d] - h * e->qd[d]) - (real)c->limit_d * e->qd[d]; k_l = h * h * (real)c->limit_k + h * (real)c->limit_d; }
       else if (e->q[d] > hi) { tau_l0 = (real)c->limit_k * (hi - e->q[d] - h * e->qd[d]) - (real)c->limit_d * e->qd[d]; k_l = h * h * (real)c->limit_k + h * (real)c->limit_d; }
       /* effort-limit predictor: joint acceleration with the parent held (a_parent = 0) */
@@ -497,13 +555,19 @@ static void dynamics(const BezSimConfig* c, const Env* e, real h, int mode, cons
   /* contact forces actually applied (implicit part resolved with the link accelerations) */
   out->ball_lin_acc = v3(0, 0, 0); out->ball_ang_acc = v3(0, 0, 0);
   if (mode == 0) {
+    /* Isaac Gym's net contact force tensor sums the solver's NORMAL contact impulses only [ext]; the
+     * checkpoint's obs statistics show it (feet flags 1..3 are +1 17-45 % of the time, which needs fx = fy = 0
+     * under load, kick_env.py:993-1038).  BEZ_FLAG_CF_WITH_FRICTION adds the friction part. */
+    const int with_fric = (c->flags & BEZ_FLAG_CF_WITH_FRICTION) != 0;
     for (int i = 0; i < nhit; ++i) {
       const GroundHit* hh = &hits[i];
       SV a = acc[hh->link];
       V3 ap = v3add(sv_lin(a), v3cross(sv_ang(a), hh->x));
       int body = BEZ_LINK_BODY[hh->link];
-      out->contact_force[body][0] += hh->ftx0 - h * hh->ct * ap.v[0];
-      out->contact_force[body][1] += hh->fty0 - h * hh->ct * ap.v[1];
+      if (with_fric) {
+        out->contact_force[body][0] += hh->ftx0 - h * hh->ct * ap.v[0];
+        out->contact_force[body][1] += hh->fty0 - h * hh->ct * ap.v[1];
+      }
       out->contact_force[body][2] += hh->fn0 - hh->kn * ap.v[2];
     }
     V3 fl = v3(0, 0, 0); /* force on the link from the ball */
@@ -512,7 +576,8 @@ static void dynamics(const BezSimConfig* c, const Env* e, real h, int mode, cons
       V3 ap = v3add(sv_lin(a), v3cross(sv_ang(a), bl_x));
       fl = v3sub(bl_f0p, m3mulv(&bl_A, ap));
       int body = BEZ_LINK_BODY[bl_link];
-      for (int i = 0; i < 3; ++i) { out->contact_force[body][i] += fl.v[i]; out->contact_force[BEZ_NBE - 1][i] -= fl.v[i]; }
+      V3 fr = with_fric ? fl : v3scale(bl_n, v3dot(fl, bl_n));
+      for (int i = 0; i < 3; ++i) { out->contact_force[body][i] += fr.v[i]; out->contact_force[BEZ_NBE - 1][i] -= fr.v[i]; }
     }
     /* ball: Mb ab = -pb - Jb^T fl */
     SV rhs = sv_add(sv_scale(pb, -1), sv_scale(wrench_at(bl_xb, fl), -1));
@@ -521,8 +586,10 @@ static void dynamics(const BezSimConfig* c, const Env* e, real h, int mode, cons
     out->ball_ang_acc = sv_ang(rhs); out->ball_lin_acc = sv_lin(rhs);
     if (ball_ground) {
       V3 ap = v3add(out->ball_lin_acc, v3cross(out->ball_ang_acc, bhit.x));
-      out->contact_force[BEZ_NBE - 1][0] += bhit.ftx0 - h * bhit.ct * ap.v[0];
-      out->contact_force[BEZ_NBE - 1][1] += bhit.fty0 - h * bhit.ct * ap.v[1];
+      if (with_fric) {
+        out->contact_force[BEZ_NBE - 1][0] += bhit.ftx0 - h * bhit.ct * ap.v[0];
+        out->contact_force[BEZ_NBE - 1][1] += bhit.fty0 - h * bhit.ct * ap.v[1];
+      }
       out->contact_force[BEZ_NBE - 1][2] += bhit.fn0 - bhit.kn * ap.v[2];
     }
   }
@@ -541,7 +608,7 @@ static void quat_integrate(real q[4], const real w[3], real h) {
   q[0] = x * n; q[1] = y * n; q[2] = z * n; q[3] = s * n;
 }
 
-static void substep(const BezSimConfig* c, Env* e, real h) {
+static void substep(const BezSimConfig* c, Env* e, real h, int first, real wgt) {
   Dyn d;
   dynamics(c, e, h, 0, NULL, &d);
   /* joints: semi-implicit Euler + velocity clamp (kick_env.py:327 velocity limit) */
@@ -572,7 +639,8 @@ static void substep(const BezSimConfig* c, Env* e, real h) {
     e->ball_pos[i] += h * e->ball_lin[i];
   }
   quat_integrate(e->ball_quat, e->ball_ang, h);
-  memcpy(e->contact_force, d.contact_force, sizeof(d.contact_force));
+  /* physx.contact_collection 2 = CC_ALL_SUBSTEPS (bez_kick.yaml:147): the tensor holds the mean force over the control step [ext] */
+  for (int b = 0; b < BEZ_NBE; ++b) for (int i = 0; i < 3; ++i) e->contact_force[b][i] = first ? d.contact_force[b][i] * wgt : e->contact_force[b][i] + d.contact_force[b][i] * wgt;
 }
 
 /* ------------------------------------------------------------------ env logic (reference restatement) */
@@ -747,7 +815,11 @@ static void env_post_physics(const BezSimConfig* c, Env* e, int64_t genv, int us
 
 static void env_simulate(const BezSimConfig* c, Env* e) {
   real h = (real)c->dt / (real)c->substeps;
-  for (int s = 0; s < c->substeps; ++s) substep(c, e, h);
+  const int last_only = (c->flags & BEZ_FLAG_CF_LAST_SUBSTEP) != 0;
+  for (int s = 0; s < c->substeps; ++s) {
+    if (last_only) substep(c, e, h, 1, 1);
+    else substep(c, e, h, s == 0, (real)1 / (real)c->substeps);
+  }
 }
 
 /* ------------------------------------------------------------------ exported API (ctypes) */
@@ -760,7 +832,7 @@ void* bez_oracle_create(const BezSimConfig* cfg) {
     Env* e = &o->env[i];
     e->reset = 1; /* vec_task.py:241 */
     e->friction = cfg->plane_friction;
-    for (int j = 0; j < ND; ++j) { e->kp_scale[j] = 1; e->kd_scale[j] = 1; }
+    for (int j = 0; j < ND; ++j) { e->kp_scale[j] = 1; e->kd_scale[j] = 1; e->lim_lo[j] = (real)(float)BEZ_DOF_LOWER[j]; e->lim_hi[j] = (real)(float)BEZ_DOF_UPPER[j]; }
     for (int l = 0; l < NL; ++l) e->mass_scale[l] = 1;
     for (int k = 0; k < 3; ++k) e->gravity[k] = cfg->gravity[k];
     for (int k = 0; k < 8; ++k) e->feet[k] = -1; /* kick_env.py:185 */
@@ -836,6 +908,8 @@ void bez_oracle_set_env_params(void* h, int param, const float* v) {
       case BEZ_PARAM_KD_SCALE: for (int j = 0; j < ND; ++j) e->kd_scale[j] = v ? v[(size_t)i * ND + j] : 1; break;
       case BEZ_PARAM_MASS_SCALE: for (int l = 0; l < NL; ++l) e->mass_scale[l] = v ? v[(size_t)i * NL + l] : 1; break;
       case BEZ_PARAM_GRAVITY: for (int k = 0; k < 3; ++k) e->gravity[k] = v ? v[(size_t)i * 3 + k] : o->cfg.gravity[k]; break;
+      case BEZ_PARAM_DOF_LOWER: for (int j = 0; j < ND; ++j) e->lim_lo[j] = v ? v[(size_t)i * ND + j] : (real)(float)BEZ_DOF_LOWER[j]; break;
+      case BEZ_PARAM_DOF_UPPER: for (int j = 0; j < ND; ++j) e->lim_hi[j] = v ? v[(size_t)i * ND + j] : (real)(float)BEZ_DOF_UPPER[j]; break;
       default: break;
     }
   }

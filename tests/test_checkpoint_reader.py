@@ -56,3 +56,35 @@ def test_reference_checkpoint_layout_and_interop():
     # the reference's own observation statistics show the quirks this build reproduces:
     assert abs(float(rms.running_mean[38]) - 1.0) < 0.05      # imu z-acc == R(q)(0,0,1): prev_lin_vel aliasing (Q1)
     assert float(rms.running_var[52]) < 1e-6 and float(rms.running_var[53]) < 1e-6  # constant ball_init tail (Q5)
+
+
+def _tamper(path, out, fn):
+    """Rewrite the tensor geometry inside data.pkl of a torch.save archive (the zip payloads stay as they are)."""
+    import pickletools
+    import zipfile
+    with zipfile.ZipFile(path) as zf:
+        names = zf.namelist()
+        blobs = {n: zf.read(n) for n in names}
+    pkl = [n for n in names if n.endswith("/data.pkl")][0]
+    blobs[pkl] = fn(blobs[pkl])
+    with zipfile.ZipFile(out, "w") as zf:
+        for n in names:
+            zf.writestr(n, blobs[n])
+
+
+def test_refuses_out_of_bounds_tensor_geometry(tmp_path):
+    """offset / size / stride come from the untrusted pickle: a view that leaves its storage must be refused, not read."""
+    src = str(tmp_path / "ok.pth")
+    torch.save({"w": torch.arange(6.0)}, src)
+    assert read_rlgames_checkpoint(src)["w"].shape == (6,)
+    # BININT1 6 (the size tuple's only entry) -> 200: reaches far past the 6-element storage
+    big = str(tmp_path / "big.pth")
+    _tamper(src, big, lambda b: b.replace(b"K\x06\x85", b"K\xc8\x85", 1))
+    with pytest.raises(ValueError):
+        read_rlgames_checkpoint(big)
+    # stride 1 -> BININT -1
+    neg = str(tmp_path / "neg.pth")
+    _tamper(src, neg, lambda b: b.replace(b"K\x06\x85q\x05K\x01\x85", b"K\x06\x85q\x05J\xff\xff\xff\xff\x85", 1)
+            if b"K\x06\x85q\x05K\x01\x85" in b else b.replace(b"K\x01\x85", b"J\xff\xff\xff\xff\x85", 1))
+    with pytest.raises(ValueError):
+        read_rlgames_checkpoint(neg)
