@@ -238,8 +238,11 @@ class A2CAgent:
             self.lr_t = _CpuLr(self.optimizer, self.last_lr)
         self.scaler = torch.amp.GradScaler("cuda", enabled=self.mixed_precision)
         g = c.get("hip_graphs", "auto")
-        self.use_graphs = bool(on_gpu and world == 1 and (g is True or g == "auto"))
+        # an env whose step() syncs with the host or allocates (domain randomisation: vec_task.py:505-725) cannot be captured
+        env_graph_safe = bool(getattr(getattr(vec_env, "env", vec_env), "graph_safe", True))
+        self.use_graphs = bool(on_gpu and world == 1 and env_graph_safe and (g is True or g == "auto"))
         self.graph_warmup_epochs = 2
+        self._eager_epochs = 0  # epochs run eagerly IN THIS PROCESS (a restored epoch_num says nothing about warm-up)
         self._g_rollout = self._g_update = self._pool = None
         self.mb = None
         self._ep_hist = []
@@ -355,7 +358,7 @@ class A2CAgent:
         """Rollout + dataset.  With HIP graphs enabled the first call after warm-up captures, later calls replay."""
         if self.mb is None:
             self._alloc_static()
-        if not self.use_graphs or self.epoch_num < self.graph_warmup_epochs:
+        if not self.use_graphs or self._eager_epochs < self.graph_warmup_epochs:
             self._rollout_impl()
         elif self._g_rollout is None:
             torch.cuda.synchronize()
@@ -418,11 +421,12 @@ class A2CAgent:
             loss = a_l + 0.5 * c_l * self.critic_coef - ent * self.entropy_coef + b_l * self.bounds_loss_coef
         self.optimizer.zero_grad(set_to_none=True)
         self.scaler.scale(loss).backward()
-        if self.truncate_grads or _dist_on():
-            self.scaler.unscale_(self.optimizer)
         if _dist_on():
+            # all-reduce the STILL-SCALED gradients (as DDP does): an fp16 overflow on any rank reaches every rank, so
+            # unscale_ below records the same found_inf everywhere and all replicas skip (or take) the step together.
             self._allreduce_grads()
         if self.truncate_grads:
+            self.scaler.unscale_(self.optimizer)
             nn.utils.clip_grad_norm_(self.model.parameters(), self.grad_norm)
         self.scaler.step(self.optimizer)
         self.scaler.update()
@@ -448,7 +452,7 @@ class A2CAgent:
                 self.scheduler.update_(self.lr_t, self.kl_acc[ep])
 
     def run_update(self):
-        if not self.use_graphs or self.epoch_num < self.graph_warmup_epochs:
+        if not self.use_graphs or self._eager_epochs < self.graph_warmup_epochs:
             self._update_impl()
         elif self._g_update is None:
             torch.cuda.synchronize()
@@ -483,6 +487,7 @@ class A2CAgent:
         a_l, c_l = (self.loss_acc / (self.mini_epochs * self.num_minibatches)).tolist()
         self._drain_episode_stats()
         t_total = time.perf_counter() - t0
+        self._eager_epochs += 1
         self.epoch_num += 1
         self.frame += self.batch_size * self.world
         return dict(play_time=t_play, update_time=t_total - t_play, total_time=t_total, kl=sum(kls) / len(kls),
@@ -531,6 +536,17 @@ class A2CAgent:
             self.value_mean_std.load_state_dict(state["reward_mean_std"])
         if "optimizer" in state:
             self.optimizer.load_state_dict(state["optimizer"])
+            # load_state_dict replaces param_groups[..]['lr'] by a copy: re-point every group at the live device tensor the
+            # adaptive-KL rule updates, and carry the checkpoint's learning rate over into it
+            lr = self.optimizer.param_groups[0]["lr"]
+            lr = float(lr.item() if torch.is_tensor(lr) else lr)
+            if isinstance(self.lr_t, _CpuLr):
+                self.lr_t.copy_(torch.tensor(lr))
+            else:
+                self.lr_t.fill_(lr)
+                for g in self.optimizer.param_groups:
+                    g["lr"] = self.lr_t
+            self.last_lr = lr
         self.epoch_num = int(state.get("epoch", 0))
         self.frame = int(state.get("frame", 0))
         self.last_mean_rewards = float(state.get("last_mean_rewards", -100500.0))
@@ -540,4 +556,18 @@ class A2CAgent:
         torch.save(self.get_full_state_weights(), path)
 
     def restore(self, path):
-        self.set_full_state_weights(torch.load(path, map_location=self.device, weights_only=False))
+        """Load a checkpoint WITHOUT ever unpickling arbitrary objects: this build's own files pass torch's weights_only
+        loader; anything else (e.g. the reference's rl_games .pth, whose pickle references numpy scalars) is read by
+        utils/rlg_checkpoint.py, which only disassembles the pickle -- model and normaliser statistics are restored,
+        optimiser state is not."""
+        try:
+            state = torch.load(path, map_location=self.device, weights_only=True)
+        except Exception:
+            from ..utils.rlg_checkpoint import load_into_agent_modules, read_rlgames_checkpoint
+            ck = read_rlgames_checkpoint(path)
+            load_into_agent_modules(ck, self.model, self.running_mean_std, self.value_mean_std)
+            self.epoch_num = int(ck.get("epoch", 0) or 0)
+            self.frame = int(ck.get("frame", 0) or 0)
+            self.last_mean_rewards = float(ck.get("last_mean_rewards", -100500.0) or -100500.0)
+            return
+        self.set_full_state_weights(state)

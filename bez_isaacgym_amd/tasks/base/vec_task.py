@@ -150,10 +150,18 @@ class VecTask(Env):
         if self.dr_randomizations.get('observations', None):
             self.obs_buf.copy_(self.dr_randomizations['observations']['noise_lambda'](self.obs_buf))
         self.extras["time_outs"] = self.timeout_buf.to(self.rl_device)
-        self.obs_dict["obs"] = torch.clamp(self.obs_buf, -self.clip_obs, self.clip_obs).to(self.rl_device)
+        self.obs_dict["obs"] = self._clipped_obs()
         if self.num_states > 0:
             self.obs_dict["states"] = self.get_state()
         return self.obs_dict, self.rew_buf.to(self.rl_device), self.reset_buf.to(self.rl_device), self.extras
+
+    def _clipped_obs(self):
+        """vec_task.py:347: clamp(obs_buf, +-clipObservations).to(rl_device).  With the default clipObservations = inf the clamp
+        is the identity: the simulator's own buffer is returned (zero-copy, valid until the next step()) instead of a
+        full-tensor copy per control step."""
+        if np.isinf(self.clip_obs):
+            return self.obs_buf.to(self.rl_device)
+        return torch.clamp(self.obs_buf, -self.clip_obs, self.clip_obs).to(self.rl_device)
 
     def _fused_step(self, actions):
         """Default: the split path through the subclass hooks (vec_task.py:317-335)."""
@@ -170,7 +178,7 @@ class VecTask(Env):
     def reset(self):
         """vec_task.py:361-377: one step with zero actions."""
         self.step(self.zero_actions())
-        self.obs_dict["obs"] = torch.clamp(self.obs_buf, -self.clip_obs, self.clip_obs).to(self.rl_device)
+        self.obs_dict["obs"] = self._clipped_obs()
         if self.num_states > 0:
             self.obs_dict["states"] = self.get_state()
         return self.obs_dict
@@ -212,7 +220,7 @@ class VecTask(Env):
                         mu, var = mu * s, var * s
                     else:
                         mu, var = mu * s + 1.0 * (1 - s), var * s + 1.0 * (1 - s)
-                    std = float(np.sqrt(var)) if attr["distribution"] == "gaussian" else None
+                    std = float(var) if attr["distribution"] == "gaussian" else None  # vec_task.py:589: randn * params['var']
                     op = (lambda a, b: a + b) if attr["operation"] == "additive" else (lambda a, b: a * b)
                     if std is not None:
                         fn = (lambda t, op=op, mu=mu, std=std: op(t, torch.randn_like(t) * std + mu))
@@ -224,7 +232,8 @@ class VecTask(Env):
                 attr = dr_params["sim_params"]["gravity"]
                 s = sched(attr)
                 g0 = torch.tensor(list(self.cfg["sim"]["gravity"]), device=self.device, dtype=torch.float32)
-                noise = torch.randn(3, device=self.device) * float(np.sqrt(attr["range"][1] * s)) + attr["range"][0] * s
+                # gymutil.apply_random_samples [ext]: np.random.normal(mu, var) -- the second number of `range` is used as the std
+                noise = torch.randn(3, device=self.device) * float(attr["range"][1] * s) + attr["range"][0] * s
                 self.sim.set_env_params(abi.PARAM_GRAVITY, (g0 + noise).repeat(self.num_envs, 1).contiguous())
         if len(env_ids) and "actor_params" in dr_params and "bez" in dr_params["actor_params"]:
             ap = dr_params["actor_params"]["bez"]
@@ -233,7 +242,11 @@ class VecTask(Env):
                 lo, hi = attr["range"]
                 s = sched(attr)
                 lo, hi = lo * s + 1.0 * (1 - s), hi * s + 1.0 * (1 - s)
-                return torch.rand(len(env_ids), width, device=self.device) * (hi - lo) + lo
+                u = torch.rand(len(env_ids), width, device=self.device)
+                nb = int(attr.get("num_buckets", 0) or 0)
+                if nb > 1:  # bez_kick.yaml:180 num_buckets 500: PhysX material limit -> samples snap to nb evenly spaced values [ext]
+                    u = torch.round(u * (nb - 1)) / (nb - 1)
+                return u * (hi - lo) + lo
 
             def update(name, param, attr, width, base=1.0):
                 if not hasattr(self, name):
@@ -250,6 +263,18 @@ class VecTask(Env):
                 update("_dr_kp", abi.PARAM_KP_SCALE, dp["stiffness"], 18)
             if "damping" in dp:
                 update("_dr_kd", abi.PARAM_KD_SCALE, dp["damping"], 18)
+            for key, param, name in (("lower", abi.PARAM_DOF_LOWER, "_dr_lower"), ("upper", abi.PARAM_DOF_UPPER, "_dr_upper")):
+                if key in dp:  # bez_kick.yaml:206-219: additive gaussian jitter of the PHYSICAL joint limits; the target clamp keeps
+                    attr = dp[key]  # the limits read once at creation (kick_env.py:393-400)
+                    base = self.dof_pos_limits_lower if key == "lower" else self.dof_pos_limits_upper
+                    if not hasattr(self, name):
+                        setattr(self, name, base.repeat(self.num_envs, 1).contiguous())
+                    s = sched(attr)
+                    buf = getattr(self, name)
+                    buf[env_ids] = base + torch.randn(len(env_ids), 18, device=self.device) * float(attr["range"][1] * s) + attr["range"][0] * s
+                    self.sim.set_env_params(param, buf.contiguous())
+            # rigid_shape_properties.restitution (bez_kick.yaml:187-192) SCALES the asset's restitution, which is 0 (plane
+            # restitution 0, bez_kick.yaml:16; asset default 0 [ext]): 0 * U(0, 0.7) = 0 -- nothing to randomise.
             rbp = ap.get("rigid_body_properties", {})
             if "mass" in rbp and (self.first_randomization or not rbp["mass"].get("setup_only", False)):
                 update("_dr_mass", abi.PARAM_MASS_SCALE, rbp["mass"], 19)

@@ -157,10 +157,28 @@ class KickEnv(VecTask):
     feet = property(lambda s: s.sim.refresh(abi.TENSOR_FEET))
 
     # ---- step
+    @property
+    def actions(self):
+        """The reference keeps `self.actions` = clamped actions with the head zeroed (vec_task.py:317, kick_env.py:411-414).
+        The kernel does that clamp itself; the Python-visible copy is materialised only when somebody reads it."""
+        if self._raw_actions is not None:
+            a = torch.clamp(self._raw_actions, -self.clip_actions, self.clip_actions)
+            a[..., 0:2] = 0.0
+            self._actions, self._raw_actions = a, None
+        return self._actions
+
+    @actions.setter
+    def actions(self, value):
+        self._actions, self._raw_actions = value, None
+
+    @property
+    def graph_safe(self):
+        """False when step() may sync with the host / allocate (domain randomisation resamples at reset time): the PPO
+        loop must not capture such a step into a HIP graph."""
+        return not self.randomize
+
     def _fused_step(self, actions):
-        # actions[:, 0:2] are zeroed inside the kernel (kick_env.py:414); keep the Python-visible copy in step
-        self.actions = torch.clamp(actions, -self.clip_actions, self.clip_actions)
-        self.actions[..., 0:2] = 0.0
+        self._raw_actions = actions  # borrowed until the next step (see `actions`)
         if self.randomize:
             self.randomize_buf += 1
             if (self.reset_buf > 0).any():  # DR only happens at reset time (kick_env.py:781-782)

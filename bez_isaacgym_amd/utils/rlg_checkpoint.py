@@ -14,7 +14,7 @@ import numpy as np
 
 _ALLOWED_GLOBALS = {"collections OrderedDict", "torch._utils _rebuild_tensor_v2", "torch FloatStorage", "torch DoubleStorage",
                     "torch HalfStorage", "torch LongStorage", "torch IntStorage", "numpy dtype", "numpy.core.multiarray scalar",
-                    "_codecs encode"}
+                    "numpy._core.multiarray scalar", "_codecs encode"}
 _STORAGE_DTYPE = {"torch FloatStorage": "<f4", "torch DoubleStorage": "<f8", "torch HalfStorage": "<f2",
                   "torch LongStorage": "<i8", "torch IntStorage": "<i4"}
 
@@ -126,7 +126,7 @@ def _materialise(node, zf, prefix):
                 raise ValueError("checkpoint tensor view reaches past the end of its storage")
             view = np.lib.stride_tricks.as_strided(raw[offset:], shape=tuple(size), strides=tuple(s * dt.itemsize for s in stride))
             return np.array(view)  # own the memory
-        if node.fn == "numpy.core.multiarray scalar":  # (dtype record, latin1-encoded raw bytes): decode plain numbers only
+        if node.fn in ("numpy.core.multiarray scalar", "numpy._core.multiarray scalar"):  # (dtype record, latin1-encoded raw bytes): decode plain numbers only
             dtc, enc = node.args
             code = dtc.args[0] if isinstance(dtc, _Call) else None
             raw = enc.args[0].encode("latin1") if isinstance(enc, _Call) and isinstance(enc.args[0], str) else None

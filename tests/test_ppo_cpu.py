@@ -118,6 +118,70 @@ def test_data_parallel_gloo_world2_replicas_stay_identical():
     assert lr0 == lr1 and f0 == f1 == 3 * 8 * 32 * 2
 
 
+def test_restore_foreign_checkpoint_never_unpickles(tmp_path):
+    """rl_games writes numpy scalars into its checkpoints (the reference's Bez_Kick_33.pth does): torch's weights_only loader
+    refuses them.  restore() must then read the file with the no-unpickle reader, not fall back to a full unpickle."""
+    src = A2CAgent(_params(16, 64, horizon=4), FakeVecEnv(16, seed=3), "cpu")
+    state = src.get_full_state_weights()
+    state["last_mean_rewards"] = np.float32(12.5)   # numpy.core.multiarray.scalar in the pickle, as rl_games does
+    del state["optimizer"], state["scaler"]
+    path = str(tmp_path / "foreign.pth")
+    torch.save(state, path)
+    with pytest.raises(Exception):
+        torch.load(path, weights_only=True)
+    dst = A2CAgent(_params(16, 64, horizon=4), FakeVecEnv(16, seed=4), "cpu")
+    for p in dst.model.parameters():
+        p.data.add_(1.0)
+    dst.restore(path)
+    for a, b in zip(src.model.parameters(), dst.model.parameters()):
+        assert torch.equal(a, b)
+    assert abs(dst.last_mean_rewards - 12.5) < 1e-6
+
+
+def _amp_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    agent = A2CAgent(_params(32, 128, horizon=8), FakeVecEnv(32, seed=200 + rank), "cpu", rank=rank, world=world)
+    agent.scaler = torch.amp.GradScaler("cpu", enabled=True, init_scale=1024.0, growth_interval=10 ** 6)  # AMP bookkeeping on CPU
+    agent.obs = agent.env_reset()
+    before = torch.cat([p.detach().reshape(-1) for p in agent.model.parameters()]).clone()
+    if rank == 1:  # an fp16-style overflow on ONE rank only, on the first optimiser step
+        fired = []
+        p0 = next(agent.model.parameters())
+        def poison(g):
+            if not fired:
+                fired.append(1)
+                return torch.full_like(g, float("inf"))
+            return g
+        p0.register_hook(poison)
+    agent.play_steps()
+    agent.calc_gradients(agent._minibatch(0), torch.zeros(()), torch.zeros(2))
+    after1 = torch.cat([p.detach().reshape(-1) for p in agent.model.parameters()]).clone()
+    scale1 = float(agent.scaler.get_scale())
+    agent.calc_gradients(agent._minibatch(1), torch.zeros(()), torch.zeros(2))
+    after2 = torch.cat([p.detach().reshape(-1) for p in agent.model.parameters()]).clone()
+    out[rank] = (before, after1, after2, scale1)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_amp_overflow_on_one_rank_skips_the_step_everywhere():
+    """Mixed precision + data parallel: the scaled gradients are all-reduced BEFORE unscale_, so an overflow on one rank
+    makes every rank skip that optimiser step and back off its loss scale together; the replicas stay bit-identical and finite."""
+    mgr = mp.Manager()
+    out = mgr.dict()
+    port = 31500 + (os.getpid() % 2000)
+    mp.spawn(_amp_worker, args=(2, port, out), nprocs=2, join=True)
+    (b0, a0, c0, s0), (b1, a1, c1, s1) = out[0], out[1]
+    assert torch.equal(b0, b1)
+    assert torch.equal(a0, b0) and torch.equal(a1, b1)      # step 1 skipped on BOTH ranks
+    assert s0 == s1 == 512.0                                # both backed off 1024 -> 512
+    assert torch.equal(c0, c1) and not torch.equal(c0, a0)  # step 2 taken, identically
+    assert torch.isfinite(c0).all()
+
+
 def test_cli_config_contract():
     """train.py's CLI contract: task=bez_kick num_envs=... sim_device=... pipeline=... headless=... (README.md:46-63)."""
     cfg = load_config(["task=bez_kick", "num_envs=64", "sim_device=cpu", "pipeline=cpu", "headless=True", "max_iterations=7"])
