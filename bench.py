@@ -24,17 +24,21 @@ ACTION_RING = 64               # distinct pre-generated action batches cycled th
 
 
 def pmc_traffic(num_envs):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary (separate FETCH_SIZE /
-    WRITE_SIZE passes with the gfx950 correction; profiles/r01_pmc_traffic.json).  bench.py cannot run under the
-    profiler itself, so this is the profiled figure for the same kernel and size, or None when it does not apply."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    try:
-        d = json.load(open(path))
-        if int(d["num_envs"]) == int(num_envs):
-            return float(d["hbm_bytes_per_launch"]["total"])
-    except Exception:
-        pass
-    return None
+    """HBM bytes per launch of the dominant kernel from a committed rocprofv3 PMC summary (separate FETCH_SIZE / WRITE_SIZE
+    passes, corrected as MI355X_MICROARCH.md prescribes; tools/collect_profiles.sh + tools/summarize_profiles.py).  bench.py
+    cannot run under the profiler itself, so this is the profiled figure -- but ONLY of a profile whose recorded source hash
+    is the hash of the library that is running now and whose size matches; otherwise None (never a stale number)."""
+    import glob
+    from bez_isaacgym_amd.build import source_hash
+    cur = source_hash()
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")), reverse=True):
+        try:
+            d = json.load(open(path))
+            if d.get("source_hash") == cur and int(d["num_envs"]) == int(num_envs):
+                return float(d["hbm_bytes_per_launch"]["total"]), os.path.basename(path)
+        except Exception:
+            continue
+    return None, None
 
 
 def cpu_baseline(num_envs, seconds_target=12.0):
@@ -179,6 +183,7 @@ def main():
     if rank == 0:
         total_envs = n * world
         kernel_ms = dev_ms / args.steps  # avg device time per fused-step launch over the timed region (HIP events)
+        traffic, traffic_src = pmc_traffic(n)
         achieved = ALGO_BYTES_PER_ENV_STEP * n / (kernel_ms * 1e-3) / 1e9
         out = {
             "metric": "env-steps/s at num_envs=4096 (random-action rollout, bez_kick)",
@@ -197,10 +202,11 @@ def main():
                                    "natural resets included" % n,
                        "envs_per_gpu": n, "total_envs": total_envs, "launch": args.launch, "parallelism": "env-sharded x%d" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(n),
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "bez::step_kernel_ws<PRE,POST> (fused control step)", "kernel_ms": kernel_ms,
                          "algorithmic_bytes_per_launch": ALGO_BYTES_PER_ENV_STEP * n,
-                         "traffic_unit": "bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_pmc_traffic.json)",
+                         "traffic_unit": "bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE; source: profiles/%s)" % traffic_src
+                                         if traffic is not None else "no committed PMC profile matches this build's source hash",
                          "note": "N=4096 is latency-bound (64 workgroups x 4 role waves on 256 CUs, serial ABA chains): see DESIGN.md"},
         }
         if ppo is not None:

@@ -36,10 +36,9 @@ enum : int {
   X_CAND = 118,    // per leg: depth, link, n(3), P(3), V(6) of its deepest ball/box candidate = 14 floats x 2
   X_FOLD = 146,    // winner side, link, A(6), f0p(3), x(3), xb(3) = 17 floats (written by the root role)
   X_LEGQ = 163,    // per leg: q(6) qd(6) at the start of the substep (read by the self-collision role)
-  X_SELFW = 187,   // per leg box link (left 5, right 5): bias wrench of the leg<->leg contacts (6)
-  X_SELFCF = 247,  // per leg box link: reported contact force of the leg<->leg contacts (3)
-  X_CF = 277,      // net contact force rows of the 22 bodies (mean over substeps)
-  X_SLOTS = 343
+  X_SELF = 187,    // 2 helper parts x [per leg box link (left 5, right 5): bias wrench (6) + reported force (3)] = 2 x 90
+  X_CF = 367,      // net contact force rows of the 22 bodies (mean over substeps)
+  X_SLOTS = 433
 };
 constexpr int WS_OBS_STRIDE = 54;  // rows unpadded: the staged block IS the contiguous HBM image (float4 copy-out)
 constexpr int WS_ACT_STRIDE = 19;
@@ -86,6 +85,9 @@ BEZ_DEV void ws_cf_acc(float* lds, int lane, int body, V3 f, float w, bool first
   if (first) { XS(s) = f.x * w; XS(s + 1) = f.y * w; XS(s + 2) = f.z * w; }
   else { XS(s) = fmaf(f.x, w, XS(s)); XS(s + 1) = fmaf(f.y, w, XS(s + 1)); XS(s + 2) = fmaf(f.z, w, XS(s + 2)); }
 }
+// the two helper parts' leg<->leg contact results of leg box link k (see ws_self_collision)
+BEZ_DEV SV xs_self_wrench(const float* lds, int lane, int k) { return xs_load_sv(lds, lane, X_SELF + k * 9) + xs_load_sv(lds, lane, X_SELF + 90 + k * 9); }
+BEZ_DEV V3 xs_self_force(const float* lds, int lane, int k) { return xs_load_v3(lds, lane, X_SELF + k * 9 + 6) + xs_load_v3(lds, lane, X_SELF + 90 + k * 9 + 6); }
 // leg box link L (6..10 / 14..18) -> 0..9
 BEZ_DEV constexpr int self_index(int L) { return L < 11 ? L - 6 : 5 + (L - 14); }
 
@@ -104,7 +106,7 @@ BEZ_DEV RootView load_root_view(const float* lds, int lane) {
 }
 
 // per-joint data a chain keeps in registers between pass 2 and pass 3
-struct P3 { SV UD; float uD; SV S, cb; };
+struct P3 { SV UD; float uD, Dinv; SV S, cb; };
 // contact rows of a body: F = F0 - (B^T a_ang + C a_lin) for the body's spatial acceleration a
 struct BodyContact { M3 B; Sym3 C; V3 F0; };
 BEZ_DEV BodyContact body_contact_of(const Sym6& Kc, SV pc) { BodyContact b; b.B = Kc.B; b.C = Kc.C; b.F0 = -pc.l; return b; }
@@ -165,12 +167,28 @@ BEZ_DEV void ws_chain_pass2(const Params& P, const ChainDyn& D, const float* kps
     }
     SV U; float Dinv, u;
     joint_terms<L>(P, kps[i], kds[i], lo[i], hi[i], q[i], qd[i], target[i], IA, pA, Sl[i], cbl[i], U, Dinv, u);
-    p3[i].UD = U * Dinv; p3[i].uD = u * Dinv; p3[i].S = Sl[i]; p3[i].cb = cbl[i];
+    p3[i].UD = U * Dinv; p3[i].uD = u * Dinv; p3[i].Dinv = Dinv; p3[i].S = Sl[i]; p3[i].cb = cbl[i];
     add_outer(IA, U, -Dinv);
     pA = pA + mul(IA, cbl[i]) + U * p3[i].uD;
   });
   add_to(IAo, IA);
   pAo = pAo + pA;
+}
+
+// The explicit leg<->leg contact wrenches enter AFTER pass 2 (the helper waves compute them while the legs run passes 1-2):
+// an extra bias force dp on link i changes u_i by -S_i . dp and travels up the chain as (1 - U_i S_i^T / D_i) dp, an exact
+// linear correction of pass 2's bias recursion (the drive-saturation predictor does not see these forces: same rule in the oracle).
+template <int LEN>
+BEZ_DEV void ws_chain_self_correction(const float* lds, int lane, int side, P3* p3, SV& pAo) {
+  SV acc = svzero();
+  static_for<LEN>([&](auto I) {
+    constexpr int i = LEN - 1 - decltype(I)::value;
+    if constexpr (i >= 1) acc = acc + xs_self_wrench(lds, lane, side * 5 + i - 1);
+    const float sd = -dot(p3[i].S, acc);
+    p3[i].uD = fmaf(sd, p3[i].Dinv, p3[i].uD);
+    acc = acc + p3[i].UD * sd;
+  });
+  pAo = pAo + acc;
 }
 
 // pass 3: joint accelerations, semi-implicit Euler with the velocity clamp; returns the chain-end acceleration
@@ -189,7 +207,7 @@ BEZ_DEV SV ws_chain_pass3(const Params& P, SV a0, const P3* p3, float* q, float*
     qd[i] = v;
     q[i] = fmaf(P.h, v, q[i]);
     if constexpr (LEG && link_has_box(L)) {
-      V3 f = xs_load_v3(lds, lane, X_SELFCF + self_index(L) * 3);  // leg<->leg contacts of this link
+      V3 f = xs_self_force(lds, lane, self_index(L));  // leg<->leg contacts of this link
       if (mine && sel.link == L) { fl = sel.f0p - mul(sel.A, point_of(a, sel.x)); f = f + cf_along(P, fl, sel.n); }
       if (keep) {
         if constexpr (i == LEN - 1) f_end = f;
@@ -259,61 +277,72 @@ BEZ_DEV void ws_chain_epilogue(const Params& P, float* lds, int lane, int e, boo
   }
 }
 
-// ---- leg<->leg self-collision, evaluated by the upper role while the leg roles run pass 1.  Forward kinematics of both
-// legs from the joint state they published (X_LEGQ); right-leg capsules stay in registers while the left leg is walked;
-// the wrenches / reported forces are accumulated per link in LDS (X_SELFW / X_SELFCF) for the leg roles.
-BEZ_DEV void ws_self_collision(const Params& P, float mu, float* lds, int lane, const RootView& R) {
-#pragma unroll
-  for (int k = 0; k < 90; ++k) XS(X_SELFW + k) = 0.f;  // X_SELFW (60) and X_SELFCF (30) are adjacent
-  if (P.flags & BEZ_FLAG_NO_SELF_COLLISION) return;
-  constexpr int NH = BEZ_NCAP / 2;  // capsules per leg: left 0..NH-1, right NH..2NH-1
-  V3 rc0[NH], rc1[NH]; SV rV[NH];
-  {
-    M3 E = R.E0; V3 r = mk(0, 0, 0); SV V = R.V0, Sj, cbj;
-    static_for<6>([&](auto I) {
+// ---- leg<->leg self-collision, evaluated by the two waves that would otherwise idle while the leg roles run pass 1:
+// PART 0 (upper role, in the window of the legs' pass 1) owns the hip/thigh x hip/thigh pairs and only walks both legs down to
+// the thigh; PART 1 (root role, in the window of the legs' pass 2) owns every other pair of BEZ_CPAIR.  Forward kinematics of both legs comes from the joint state
+// the leg roles published (X_LEGQ); per-link wrenches / reported forces are summed in registers and written once to this
+// part's LDS block (X_SELF + PART * 90: link k -> wrench 6 floats at k*9, force 3 floats at k*9+6); the legs add both blocks.
+BEZ_DEV constexpr bool self_part_owns(int part, int ia, int ib) { return (part == 0) == (ia <= 1 && ib <= BEZ_NCAP / 2 + 1); }
+struct SelfCaps { V3 c0[BEZ_NCAP], c1[BEZ_NCAP]; SV V[BEZ_NCAP]; };  // world end points / link velocity per capsule (left 0..5, right 6..11)
+// stage 1: forward kinematics of both legs (as deep as this part's pairs need) -> capsules
+template <int PART>
+BEZ_DEV void ws_self_fk(const float* lds, int lane, const M3& E0, SV V0, SelfCaps& K) {
+  constexpr int NFK = PART == 0 ? 3 : 6;  // links to walk per leg (hip_side, hip_front, thigh | all)
+  static_for<2>([&](auto SIDE) {
+    constexpr int side = decltype(SIDE)::value;
+    M3 E = E0; V3 r = mk(0, 0, 0); SV V = V0, Sj, cbj;
+    static_for<NFK>([&](auto I) {
       constexpr int i = decltype(I)::value;
-      constexpr int L = 13 + i;
-      link_kinematics<L>(XS(X_LEGQ + 12 + i), XS(X_LEGQ + 18 + i), E, r, V, Sj, cbj);
-      static_for<NH>([&](auto C) {
-        constexpr int c = NH + decltype(C)::value;
+      constexpr int L = (side == 0 ? 5 : 13) + i;
+      link_kinematics<L>(XS(X_LEGQ + side * 12 + i), XS(X_LEGQ + side * 12 + 6 + i), E, r, V, Sj, cbj);
+      static_for<BEZ_NCAP>([&](auto C) {
+        constexpr int c = decltype(C)::value;
         if constexpr (BEZ_CAP_LINK[c] == L) {
-          rc0[c - NH] = r + mul(E, mk((float)BEZ_CAP_P0[c][0], (float)BEZ_CAP_P0[c][1], (float)BEZ_CAP_P0[c][2]));
-          rc1[c - NH] = r + mul(E, mk((float)BEZ_CAP_P1[c][0], (float)BEZ_CAP_P1[c][1], (float)BEZ_CAP_P1[c][2]));
-          rV[c - NH] = V;
+          K.c0[c] = r + mul(E, mk((float)BEZ_CAP_P0[c][0], (float)BEZ_CAP_P0[c][1], (float)BEZ_CAP_P0[c][2]));
+          K.c1[c] = r + mul(E, mk((float)BEZ_CAP_P1[c][0], (float)BEZ_CAP_P1[c][1], (float)BEZ_CAP_P1[c][2]));
+          K.V[c] = V;
         }
       });
     });
-  }
-  M3 E = R.E0; V3 r = mk(0, 0, 0); SV V = R.V0, Sj, cbj;
-  static_for<6>([&](auto I) {
-    constexpr int i = decltype(I)::value;
-    constexpr int L = 5 + i;
-    link_kinematics<L>(XS(X_LEGQ + i), XS(X_LEGQ + 6 + i), E, r, V, Sj, cbj);
-    static_for<NH>([&](auto C) {
-      constexpr int ia = decltype(C)::value;
-      if constexpr (BEZ_CAP_LINK[ia] == L) {
-        const V3 a0 = r + mul(E, mk((float)BEZ_CAP_P0[ia][0], (float)BEZ_CAP_P0[ia][1], (float)BEZ_CAP_P0[ia][2]));
-        const V3 a1 = r + mul(E, mk((float)BEZ_CAP_P1[ia][0], (float)BEZ_CAP_P1[ia][1], (float)BEZ_CAP_P1[ia][2]));
-        static_for<BEZ_NCPAIR>([&](auto Q) {
-          constexpr int pr = decltype(Q)::value;
-          if constexpr (BEZ_CPAIR[pr][0] == ia) {
-            constexpr int ib = BEZ_CPAIR[pr][1];
-            constexpr int sa = self_index(L), sb = self_index(BEZ_CAP_LINK[ib]);
-            V3 x, f, fn;
-            if (self_pair(P, mu, (float)BEZ_CAP_R[ia], (float)BEZ_CAP_R[ib], a0, a1, rc0[ib - NH], rc1[ib - NH], V, rV[ib - NH], x, f, fn)) {
-              const SV w = wrench_at(x, f);
-              const float wf[6] = {w.a.x, w.a.y, w.a.z, w.l.x, w.l.y, w.l.z};
+  });
+}
+// Keeps stage 1 where it is written: without this the compiler sinks the kinematics past the barriers to their first use,
+// i.e. out of the idle window they are meant to fill.
+BEZ_DEV void pin(float& x) { asm volatile("" : "+v"(x)); }
+BEZ_DEV void pin(V3& v) { pin(v.x); pin(v.y); pin(v.z); }
+template <int PART>
+BEZ_DEV void ws_self_pin(SelfCaps& K) {
+  static_for<BEZ_NCAP>([&](auto C) {
+    constexpr int c = decltype(C)::value;
+    constexpr int depth = BEZ_CAP_LINK[c] < 11 ? BEZ_CAP_LINK[c] - 5 : BEZ_CAP_LINK[c] - 13;
+    if constexpr (PART == 1 || depth < 3) { pin(K.c0[c]); pin(K.c1[c]); pin(K.V[c].a); pin(K.V[c].l); }
+  });
+}
+// stage 2: this part's capsule pairs -> per-link wrench / reported force, one LDS block per part
+template <int PART>
+BEZ_DEV void ws_self_pairs(const Params& P, float mu, float* lds, int lane, const SelfCaps& K) {
+  constexpr int base = X_SELF + PART * 90;
+  SV w[10]; V3 cf[10];
 #pragma unroll
-              for (int k = 0; k < 6; ++k) { XS(X_SELFW + sa * 6 + k) -= wf[k]; XS(X_SELFW + sb * 6 + k) += wf[k]; }
-              const V3 fr = (P.flags & BEZ_FLAG_CF_WITH_FRICTION) ? f : fn;
-              XS(X_SELFCF + sa * 3) += fr.x; XS(X_SELFCF + sa * 3 + 1) += fr.y; XS(X_SELFCF + sa * 3 + 2) += fr.z;
-              XS(X_SELFCF + sb * 3) -= fr.x; XS(X_SELFCF + sb * 3 + 1) -= fr.y; XS(X_SELFCF + sb * 3 + 2) -= fr.z;
-            }
-          }
-        });
+  for (int k = 0; k < 10; ++k) { w[k] = svzero(); cf[k] = mk(0, 0, 0); }
+  if (!(P.flags & BEZ_FLAG_NO_SELF_COLLISION)) {
+    static_for<BEZ_NCPAIR>([&](auto Q) {
+      constexpr int pr = decltype(Q)::value;
+      constexpr int ia = BEZ_CPAIR[pr][0], ib = BEZ_CPAIR[pr][1];
+      if constexpr (self_part_owns(PART, ia, ib)) {
+        constexpr int sa = self_index(BEZ_CAP_LINK[ia]), sb = self_index(BEZ_CAP_LINK[ib]);
+        V3 x, f, fn;
+        if (self_pair(P, mu, (float)BEZ_CAP_R[ia], (float)BEZ_CAP_R[ib], K.c0[ia], K.c1[ia], K.c0[ib], K.c1[ib], K.V[ia], K.V[ib], x, f, fn)) {
+          const SV wr = wrench_at(x, f);
+          w[sa] = w[sa] - wr; w[sb] = w[sb] + wr;
+          const V3 fr = (P.flags & BEZ_FLAG_CF_WITH_FRICTION) ? f : fn;
+          cf[sa] = cf[sa] + fr; cf[sb] = cf[sb] - fr;
+        }
       }
     });
-  });
+  }
+#pragma unroll
+  for (int k = 0; k < 10; ++k) { xs_store_sv(lds, lane, base + k * 9, w[k]); xs_store_v3(lds, lane, base + k * 9 + 6, cf[k]); }
 }
 
 // ------------------------------------------------------------------------------------------------ roles
@@ -381,8 +410,6 @@ BEZ_DEV void ws_leg_role(const Params& P, float* lds, int lane, int e, bool acti
     // foot ground contact while the root role evaluates the ball<->link contact operands
     Sym6 Kc = sym6zero(); SV pc = svzero();
     ws_ground_points<FIRST + LEN - 1>(P, D.mu, R.root_z, Eend, rend, Vend, Kc, pc);
-#pragma unroll
-    for (int i = 1; i < LEN; ++i) pAl[i] = pAl[i] + xs_load_sv(lds, lane, X_SELFW + (side * 5 + i - 1) * 6);
     ws_barrier();  // B1b: fold operands published
     bool mine = (XS(X_FOLD) == (float)side) && (XS(X_FOLD + 1) >= 1.f);
     if (mine) {
@@ -396,6 +423,9 @@ BEZ_DEV void ws_leg_role(const Params& P, float* lds, int lane, int e, bool acti
     P3 p3[LEN];
     Sym6 IA = sym6zero(); SV pA = svzero();
     ws_chain_pass2<FIRST, LEN, true>(P, D, kps, kds, lo, hi, q, qd, target, LI, pAl, Sl, cbl, Kc, pc, mine, sel, p3, IA, pA);
+    WS_STAMP(side, 24 + s);
+    ws_barrier();  // B1c: both helper parts' leg<->leg contact wrenches are in LDS
+    ws_chain_self_correction<LEN>(lds, lane, side, p3, pA);
     xs_store_sym6(lds, lane, X_IA + side * 27, IA, pA);
     BodyContact bcn = body_contact_of(Kc, pc);
     WS_STAMP(side, 4 + 8 * s);
@@ -466,11 +496,17 @@ BEZ_DEV void ws_upper_role(const Params& P, float* lds, int lane, int e, bool ac
     const bool keep = last_only ? (s == P.substeps - 1) : true;
     const bool first = last_only ? true : (s == 0);
     RootView R = load_root_view(lds, lane);
-    ws_self_collision(P, D.mu, lds, lane, R);  // overlaps the legs' pass 1
+    {  // leg<->leg self-collision, part 0: overlaps the legs' pass 1
+      SelfCaps K;
+      ws_self_fk<0>(lds, lane, R.E0, R.V0, K);
+      ws_self_pairs<0>(P, D.mu, lds, lane, K);
+    }
     P3 p3[6];
     BodyContact bcn[3];
     Sym6 IA = sym6zero(); SV pA = svzero();
+    WS_STAMP(2, 2 + 8 * s);
     ws_barrier();  // B1
+    WS_STAMP(2, 3 + 8 * s);
     ws_barrier();  // B1b  (only the legs / root exchange data here: the chains below overlap the legs' pass 2)
     {  // three 2-link chains, one after the other
       LinkInertia LI[2]; SV pAl[2], Sl[2], cbl[2]; Sym6 Kc; SV pc; M3 Ee; V3 re; SV Ve, Vs = svzero();
@@ -488,8 +524,12 @@ BEZ_DEV void ws_upper_role(const Params& P, float* lds, int lane, int e, bool ac
       bcn[2] = body_contact_of(Kc, pc);
     }
     xs_store_sym6(lds, lane, X_IA + 2 * 27, IA, pA);
+    WS_STAMP(2, 4 + 8 * s);
+    ws_barrier();  // B1c
     ws_barrier();  // B2
+    WS_STAMP(2, 5 + 8 * s);
     ws_barrier();  // B3
+    WS_STAMP(2, 6 + 8 * s);
     SV a0 = xs_load_sv(lds, lane, X_A0);
     V3 fl = mk(0, 0, 0), fend = mk(0, 0, 0);
     SV ae0 = ws_chain_pass3<1, 2, false>(P, a0, p3 + 0, q + 0, qd + 0, false, nosel, fl, fend, lds, lane, keep, first);
@@ -562,6 +602,9 @@ BEZ_DEV void ws_root_role(const Params& P, float* lds, int lane, int e, bool act
     add_link_inertia(IA0, I0);
     add_to(IA0, Kc); pA0 = pA0 + pc;
     BallBody ball = ball_setup(P, D.mu, D.g, ball_pos.z, ball_ang, ball_lin);
+    SelfCaps K;  // this wave's share of the leg<->leg self-collision: kinematics now (the legs run pass 1), pairs after B1b
+    ws_self_fk<1>(lds, lane, E0, V0, K);
+    ws_self_pin<1>(K);
     WS_STAMP(3, 2 + 8 * s);
     ws_barrier();  // B1: both legs' ball/box candidates are in LDS
     WS_STAMP(3, 3 + 8 * s);
@@ -587,6 +630,9 @@ BEZ_DEV void ws_root_role(const Params& P, float* lds, int lane, int e, bool act
     const bool torso_hit = (sel.link == 0);
     if (torso_hit) { add_point_stiffness(IA0, sel.x, sel.A); pA0 = pA0 - wrench_at(sel.x, sel.f0p); }
     ws_barrier();  // B1b
+    ws_self_pairs<1>(P, D.mu, lds, lane, K);  // in the window of the legs' pass 2
+    WS_STAMP(3, 24 + s);
+    ws_barrier();  // B1c
     ws_barrier();  // B2: chain contributions published
     WS_STAMP(3, 5 + 8 * s);
     xs_add_sym6(lds, lane, X_IA + 0 * 27, IA0, pA0);

@@ -315,16 +315,19 @@ BEZ_DEV void ball_link_contact(const Params& P, float mu, V3 ball_ang, V3 ball_l
 // a penetrating left x right pair is ONE explicit spring-damper + regularised Coulomb point contact with equal and
 // opposite forces on the two links (a contact inside the tree closes a loop the ABA recursion cannot fold in).
 BEZ_DEV float clamp01(float s) { return fminf(fmaxf(s, 0.f), 1.f); }
+// closest points of two (non-degenerate) segments, branch-free: the unconstrained s, the t it implies, and -- when that t
+// had to be clamped to its segment -- the s that is closest to the clamped end point
 BEZ_DEV void segment_closest(V3 p1, V3 q1, V3 p2, V3 q2, V3& c1, V3& c2) {
   V3 d1 = q1 - p1, d2 = q2 - p2, r = p1 - p2;
   float a = dot(d1, d1), e = dot(d2, d2), f = dot(d2, r), c = dot(d1, r), b = dot(d1, d2);
   float den = fmaf(a, e, -b * b);
-  float s = den > 1e-12f ? clamp01(fmaf(b, f, -c * e) / den) : 0.f;
-  float t = fmaf(b, s, f) / e;
-  if (t < 0.f) { t = 0.f; s = clamp01(-c / a); }
-  else if (t > 1.f) { t = 1.f; s = clamp01((b - c) / a); }
+  float s = den > 1e-12f ? clamp01(fmaf(b, f, -c * e) * frcp(den)) : 0.f;
+  float t = fmaf(b, s, f) * frcp(e);
+  float tc = clamp01(t);
+  float s2 = clamp01(fmaf(b, tc, -c) * frcp(a));
+  s = (t != tc) ? s2 : s;
   c1 = fma3(d1, s, p1);
-  c2 = fma3(d2, t, p2);
+  c2 = fma3(d2, tc, p2);
 }
 // capsule pair (world endpoints rel. O, link velocities about O) -> force f on link a at x; fn = its normal part
 BEZ_DEV bool self_pair(const Params& P, float mu, float ra, float rb, V3 a0, V3 a1, V3 b0, V3 b1, SV Va, SV Vb, V3& x, V3& f, V3& fn) {
@@ -333,16 +336,16 @@ BEZ_DEV bool self_pair(const Params& P, float mu, float ra, float rb, V3 a0, V3 
   V3 dl = ca - cb;
   float d2 = dot(dl, dl), rs = ra + rb;
   if (!(d2 < rs * rs) || !(d2 > 1e-12f)) return false;
-  float dist = sqrtf(d2), depth = rs - dist;
-  V3 n = dl * (1.0f / dist);
+  float idist = frsq(d2), depth = rs - d2 * idist;
+  V3 n = dl * idist;
   x = fma3(n, rb - 0.5f * depth, cb);
   V3 u = point_of(Va, x) - point_of(Vb, x);
   float un = dot(u, n);
   float fmag = fmaf(P.self_kn, depth, -P.self_cn * un);
   if (!(fmag > 0.f)) return false;
   V3 ut = u - n * un;
-  float vt = sqrtf(dot(ut, ut));
-  float ct = fminf(mu * fmag / fmaxf(vt, P.veps), P.self_cn);
+  float vt = fsqrt(dot(ut, ut));
+  float ct = fminf(mu * fmag * frcp(fmaxf(vt, P.veps)), P.self_cn);
   fn = n * fmag;
   f = fn - ut * ct;
   return true;
@@ -494,13 +497,13 @@ BEZ_DEV void chain_up(const Params& P, const EnvDyn& D, const EnvState& S, const
     link_kinematics<L>(S.q[L - 1], S.qd[L - 1], E, r, V, Sl[i], cbl[i]);
     link_inertia<L>(D.mass_scale[L], D.g, E, r, V, LI[i], pAl[i]);
     if constexpr (link_has_box(L)) {
-      pAl[i] = pAl[i] + selfw[L];  // explicit leg<->leg contact wrenches of this link
       if (sel.link == L) ball_link_contact(P, D.mu, S.ball_ang, S.ball_lin, ball, bc, V, sel);
     }
   });
   // tip: ground points of the chain-end link (E, r, V are still the tip's)
   Sym6 IA = sym6zero();
   SV pA = svzero();
+  SV pS = svzero();  // explicit leg<->leg contact wrenches, propagated next to pA (the drive-saturation predictor does not see them)
   link_ground_points<FIRST + LEN - 1>(P, D.mu, S.root_pos.z, E, r, V, IA, pA, lds, lane, keep);
   // pass 2: tip -> root
   static_for<LEN>([&](auto I) {
@@ -508,6 +511,7 @@ BEZ_DEV void chain_up(const Params& P, const EnvDyn& D, const EnvState& S, const
     constexpr int L = FIRST + i;
     add_link_inertia(IA, LI[i]);
     pA = pA + pAl[i];
+    if constexpr (link_has_box(L)) pS = pS + selfw[L];
     if constexpr (link_has_box(L)) {
       if (sel.link == L) {
         add_point_stiffness(IA, sel.x, sel.A);
@@ -518,7 +522,8 @@ BEZ_DEV void chain_up(const Params& P, const EnvDyn& D, const EnvState& S, const
     joint_terms<L>(P, D.kp_scale[L - 1], D.kd_scale[L - 1], D.lo[L - 1], D.hi[L - 1], S.q[L - 1], S.qd[L - 1], target[L - 1], IA, pA, Sl[i], cbl[i], U,
                    Dinv, u);
     SV UD = U * Dinv;
-    float uD = u * Dinv;
+    const float duD = -dot(Sl[i], pS) * Dinv;
+    float uD = fmaf(u, Dinv, duD);
     float* p3 = lds + (size_t)(LDS_P3 + (L - 1) * P3_STRIDE) * BLOCK + lane;
     p3[0 * BLOCK] = UD.a.x; p3[1 * BLOCK] = UD.a.y; p3[2 * BLOCK] = UD.a.z; p3[3 * BLOCK] = UD.l.x; p3[4 * BLOCK] = UD.l.y; p3[5 * BLOCK] = UD.l.z;
     p3[6 * BLOCK] = uD;
@@ -526,10 +531,11 @@ BEZ_DEV void chain_up(const Params& P, const EnvDyn& D, const EnvState& S, const
     p3[13 * BLOCK] = cbl[i].a.x; p3[14 * BLOCK] = cbl[i].a.y; p3[15 * BLOCK] = cbl[i].a.z; p3[16 * BLOCK] = cbl[i].l.x; p3[17 * BLOCK] = cbl[i].l.y; p3[18 * BLOCK] = cbl[i].l.z;
     // Ia = IA - U U^T / D ;  pa = pA + Ia c + U u / D
     add_outer(IA, U, -Dinv);
-    pA = pA + mul(IA, cbl[i]) + U * uD;
+    pA = pA + mul(IA, cbl[i]) + U * (u * Dinv);
+    pS = pS + U * duD;
   });
   add_to(IA0, IA);
-  pA0 = pA0 + pA;
+  pA0 = pA0 + pA + pS;
 }
 
 // ---- pass 3 of one chain: joint accelerations from the torso acceleration; integrates the joints in

@@ -315,7 +315,7 @@ static void segment_closest(V3 p1, V3 q1, V3 p2, V3 q2, V3* c1, V3* c2) {
   *c1 = v3add(p1, v3scale(d1, s));
   *c2 = v3add(p2, v3scale(d2, t));
 }
-static void self_collision(const BezSimConfig* c, real mu, const Kin* k, const SV* V, SV* pA, real cf[][3], int with_fric) {
+static void self_collision(const BezSimConfig* c, real mu, const Kin* k, const SV* V, SV* pS, real cf[][3], int with_fric) {
   for (int pr = 0; pr < BEZ_NCPAIR; ++pr) {
     const int ia = BEZ_CPAIR[pr][0], ib = BEZ_CPAIR[pr][1];
     const int la = BEZ_CAP_LINK[ia], lb = BEZ_CAP_LINK[ib];
@@ -343,8 +343,8 @@ static void self_collision(const BezSimConfig* c, real mu, const Kin* k, const S
     if (ct > (real)c->self_cn) ct = (real)c->self_cn; /* explicit: the stick viscosity is capped like the normal damper */
     V3 fn = v3scale(n, fmag);
     V3 f = v3add(fn, v3scale(ut, -ct));                                   /* force on link la; -f on link lb */
-    pA[la] = sv_add(pA[la], sv_scale(wrench_at(x, f), -1));
-    pA[lb] = sv_add(pA[lb], wrench_at(x, f));
+    pS[la] = sv_add(pS[la], sv_scale(wrench_at(x, f), -1));
+    pS[lb] = sv_add(pS[lb], wrench_at(x, f));
     V3 fr = with_fric ? f : fn;
     for (int i = 0; i < 3; ++i) { cf[BEZ_LINK_BODY[la]][i] += fr.v[i]; cf[BEZ_LINK_BODY[lb]][i] -= fr.v[i]; }
   }
@@ -358,7 +358,9 @@ static void dynamics(const BezSimConfig* c, const Env* e, real h, int mode, cons
   forward_kinematics(e, &k);
   V3 g = v3(e->gravity[0], e->gravity[1], e->gravity[2]);
   SV V[NL], S[NL], cb[NL], pA[NL];
+  SV pS[NL]; /* explicit leg<->leg contact wrenches, propagated next to pA: the drive-saturation predictor below does not see them */
   M6 IA[NL];
+  memset(pS, 0, sizeof(pS));
   memset(out->contact_force, 0, sizeof(out->contact_force));
 
   /* pass 1: velocities, bias accelerations, rigid-body inertias and bias forces */
@@ -408,7 +410,7 @@ static void dynamics(const BezSimConfig* c, const Env* e, real h, int mode, cons
       if (ground_contact(c, mu, h, x, z, V[l], &IA[l], &pA[l], &hits[nhit])) { hits[nhit].link = l; ++nhit; }
     }
     if (!(c->flags & BEZ_FLAG_NO_SELF_COLLISION)) {
-      self_collision(c, mu, &k, V, pA, out->contact_force, (c->flags & BEZ_FLAG_CF_WITH_FRICTION) != 0);
+      self_collision(c, mu, &k, V, pS, out->contact_force, (c->flags & BEZ_FLAG_CF_WITH_FRICTION) != 0);
     }
     /* ball */
     real R = (real)BEZ_BALL_RADIUS, mb = (real)BEZ_BALL_MASS, Ib = (real)BEZ_BALL_INERTIA;
@@ -530,16 +532,18 @@ static void dynamics(const BezSimConfig* c, const Env* e, real h, int mode, cons
       D = J;
     }
     Dinv[l] = 1 / D;
-    u[l] = tau - sv_dot(S[l], pA[l]);
+    real u_main = tau - sv_dot(S[l], pA[l]), du = -sv_dot(S[l], pS[l]);
+    u[l] = u_main + du;
     M6 Ia = IA[l];
     for (int i = 0; i < 6; ++i) for (int j = 0; j < 6; ++j) Ia.m[i][j] -= U[l].v[i] * U[l].v[j] * Dinv[l];
-    SV pa = sv_add(pA[l], sv_add(m6mulv(&Ia, cb[l]), sv_scale(U[l], u[l] * Dinv[l])));
+    SV pa = sv_add(pA[l], sv_add(m6mulv(&Ia, cb[l]), sv_scale(U[l], u_main * Dinv[l])));
     for (int i = 0; i < 6; ++i) for (int j = 0; j < 6; ++j) IA[p].m[i][j] += Ia.m[i][j];
     pA[p] = sv_add(pA[p], pa);
+    pS[p] = sv_add(pS[p], sv_add(pS[l], sv_scale(U[l], du * Dinv[l])));
   }
   /* root */
   M6 I0 = IA[0];
-  SV a0 = sv_scale(pA[0], -1);
+  SV a0 = sv_scale(sv_add(pA[0], pS[0]), -1);
   chol6_solve(&I0, &a0, 1);
   out->a0 = a0;
   /* pass 3 */

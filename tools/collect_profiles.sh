@@ -1,0 +1,19 @@
+#!/bin/bash
+# Runs on the GPU box (gpurun): bench line, rocprofv3 kernel stats, and the HBM / SQ counters in their own passes.
+# usage: bash tools/collect_profiles.sh r02      (raw output under gpurun_out/<tag>_*; summarise with tools/summarize_profiles.py)
+set -e
+TAG=${1:-r02}
+export TMPDIR=/tmp
+O=gpurun_out
+B="python3 bench.py --steps 1000 --warmup 100 --no-cpu-baseline --ppo-epochs 0"
+S="python3 bench.py --steps 200 --warmup 20 --no-cpu-baseline --ppo-epochs 0"
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_stats -- $B > $O/${TAG}_stats.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/${TAG}_pmc_fetch -- $S > $O/${TAG}_pmc_fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/${TAG}_pmc_write -- $S > $O/${TAG}_pmc_write.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS --output-format csv -d $O/${TAG}_pmc_sq1 -- $S > $O/${TAG}_pmc_sq1.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU --output-format csv -d $O/${TAG}_pmc_sq2 -- $S > $O/${TAG}_pmc_sq2.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/${TAG}_cal_fetch -- python3 tools/pmc_calibrate.py > $O/${TAG}_cal_fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/${TAG}_cal_write -- python3 tools/pmc_calibrate.py > $O/${TAG}_cal_write.log 2>&1
+# keep only the CSVs the summary needs (the merge back is capped at 64 MiB)
+find $O -name "*agent_info.csv" -delete
+echo collected

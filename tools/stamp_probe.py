@@ -27,8 +27,8 @@ a = allrows[-1]
 t0 = a[:, 22].min()
 names = {22: "kernel entry", 0: "loads done", 1: "after B0", 2: "s0 pass1 done", 3: "s0 after B1", 4: "s0 pass2/solve done", 5: "s0 after B2", 6: "s0 after B3",
          7: "s0 pass3 done", 8: "s0 after B4", 9: "s0 after B5", 10: "s1 pass1 done", 11: "s1 after B1", 12: "s1 pass2/solve done", 13: "s1 after B2",
-         14: "s1 after B3", 15: "s1 pass3 done", 16: "s1 after B4", 17: "s1 after B5", 20: "after B6", 21: "post done", 23: "kernel end"}
-order = [22, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 20, 21, 23]
+         14: "s1 after B3", 15: "s1 pass3 done", 16: "s1 after B4", 17: "s1 after B5", 20: "after B6", 21: "post done", 23: "kernel end", 24: "s0 before B1c", 25: "s1 before B1c"}
+order = [22, 0, 1, 2, 3, 24, 4, 5, 6, 7, 8, 9, 10, 11, 25, 12, 13, 14, 15, 16, 17, 20, 21, 23]
 print("%-22s %10s %10s %10s %10s   (cycles since first wave entry; s_memtime ticks)" % ("phase", "L-leg", "R-leg", "upper", "root"))
 for k in order:
     row = [(a[r, k] - t0) if a[r, k] else -1 for r in range(4)]
