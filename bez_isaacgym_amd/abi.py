@@ -7,7 +7,7 @@ reference).  Loading / calling the library is in `bez_isaacgym_amd.sim`.
 import ctypes as C
 import math
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 NUM_OBS = 54
 NUM_ACTIONS = 18
 NUM_DOFS = 18
@@ -19,10 +19,13 @@ FLAG_IMU_PREV_ALIAS = 1
 FLAG_CF_WITH_FRICTION = 2
 FLAG_CF_LAST_SUBSTEP = 4
 FLAG_NO_SELF_COLLISION = 8
+FLAG_CLEATS = 16
+TASK_KICK, TASK_WALK, TASK_ORIENT = 0, 1, 2
+TASK_IDS = {"bez_kick": TASK_KICK, "bez_walk": TASK_WALK, "bez_orient": TASK_ORIENT}
 
 (TENSOR_ROOT_STATE, TENSOR_DOF_STATE, TENSOR_RIGID_BODY_STATE, TENSOR_NET_CONTACT_FORCE, TENSOR_OBS,
  TENSOR_REW, TENSOR_RESET, TENSOR_PROGRESS, TENSOR_TIMEOUT, TENSOR_DOF_TARGET, TENSOR_PREV_LIN_VEL,
- TENSOR_FEET, TENSOR_COUNT) = range(13)
+ TENSOR_FEET, TENSOR_GOAL, TENSOR_COUNT) = range(14)
 DTYPE_F32, DTYPE_I64 = 0, 1
 (PARAM_FRICTION, PARAM_KP_SCALE, PARAM_KD_SCALE, PARAM_MASS_SCALE, PARAM_GRAVITY, PARAM_DOF_LOWER, PARAM_DOF_UPPER,
  PARAM_COUNT) = range(8)
@@ -60,6 +63,8 @@ class BezSimConfig(C.Structure):
         ("self_kn", C.c_float),
         ("self_cn", C.c_float),
         ("tune", C.c_float * 8),
+        ("task", C.c_int32),
+        ("goal_angle", C.c_float),
         ("flags", C.c_uint32),
         ("seed", C.c_uint64),
         ("env_id_offset", C.c_int64),
@@ -106,10 +111,12 @@ def default_config(num_envs=4096, seed=42, env_id_offset=0):
     return c
 
 
-def config_from_task_cfg(cfg, seed=42, env_id_offset=0, strict_reference_quirks=True):
-    """Build a BezSimConfig from the task config dict (the structure of cfg/task/bez_kick.yaml)."""
+def config_from_task_cfg(cfg, seed=42, env_id_offset=0, strict_reference_quirks=True, task="bez_kick"):
+    """Build a BezSimConfig from the task config dict (the structure of cfg/task/bez_{kick,walk,orient}.yaml)."""
     env, sim = cfg["env"], cfg["sim"]
     c = default_config(int(env["numEnvs"]), seed=seed, env_id_offset=env_id_offset)
+    c.task = TASK_IDS[task]
+    c.goal_angle = float(env["goalState"].get("goal_angle", 0.0))
     c.substeps = int(sim.get("substeps", 2))
     c.dt = float(sim["dt"])
     c.max_episode_length = int(float(env["learn"]["episodeLength_s"]) / float(sim["dt"]) + 0.5)
@@ -120,10 +127,13 @@ def config_from_task_cfg(cfg, seed=42, env_id_offset=0, strict_reference_quirks=
     c.plane_friction = float(env["plane"]["dynamicFriction"])
     c.clip_actions = float(env.get("clipActions", float("inf")))
     c.bez_init[:] = [float(x) for x in env["bezInitState"]["pos"] + env["bezInitState"]["rot"]]
-    c.ball_init[:] = [float(x) for x in env["ballInitState"]["pos"] + env["ballInitState"]["rot"]]
+    if "ballInitState" in env:  # bez_walk / bez_orient have no ball actor
+        c.ball_init[:] = [float(x) for x in env["ballInitState"]["pos"] + env["ballInitState"]["rot"]]
     c.goal[:] = [float(x) for x in env["goalState"]["goal"]]
     for k in CONTACT_DEFAULTS:
         if k in sim.get("bez", {}):
             setattr(c, k, float(sim["bez"][k]))
     c.flags = FLAG_IMU_PREV_ALIAS if strict_reference_quirks else 0
+    if env.get("asset", {}).get("cleats", False):
+        c.flags |= FLAG_CLEATS
     return c

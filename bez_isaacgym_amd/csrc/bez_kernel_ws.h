@@ -37,10 +37,11 @@ enum : int {
   X_FOLD = 146,    // winner side, link, A(6), f0p(3), x(3), xb(3) = 17 floats (written by the root role)
   X_LEGQ = 163,    // per leg: q(6) qd(6) at the start of the substep (read by the self-collision role)
   X_SELF = 187,    // 2 helper parts x [per leg box link (left 5, right 5): bias wrench (6) + reported force (3)] = 2 x 90
-  X_CF = 367,      // net contact force rows of the 22 bodies (mean over substeps)
-  X_SLOTS = 433
+  X_CF = 367,      // net contact force rows, up to BEZ_NBE_MAX = 30 bodies (mean over substeps)
+  X_HIT = 457,     // cleats asset only: per leg 4 ground-point records x 8 floats (x3 fn0 kn ct ftx0 fty0)
+  X_SLOTS = 521
 };
-constexpr int WS_OBS_STRIDE = 54;  // rows unpadded: the staged block IS the contiguous HBM image (float4 copy-out)
+constexpr int WS_OBS_STRIDE = 54;  // staging sized for the widest row; rows are unpadded (stride = P.nobs): the staged block IS the contiguous HBM image
 constexpr int WS_ACT_STRIDE = 19;
 constexpr int WS_LDS_FLOATS = X_SLOTS * WS_ENVS + WS_ENVS * WS_OBS_STRIDE;
 
@@ -112,14 +113,36 @@ struct BodyContact { M3 B; Sym3 C; V3 F0; };
 BEZ_DEV BodyContact body_contact_of(const Sym6& Kc, SV pc) { BodyContact b; b.B = Kc.B; b.C = Kc.C; b.F0 = -pc.l; return b; }
 BEZ_DEV V3 body_contact_force(const BodyContact& b, SV a) { return b.F0 - (mulT(b.B, a.a) + mul(b.C, a.l)); }
 
-template <int L>
-BEZ_DEV void ws_ground_points(const Params& P, float mu, float root_z, const M3& E, V3 r, SV V, Sym6& Kc, SV& pc) {
+// `hits` != null (cleats asset, foot links): the per-point records are kept in LDS, every cleat reports its own contact row
+template <int L, bool CL>
+BEZ_DEV void ws_ground_points(const Params& P, float mu, float root_z, const M3& E, V3 r, SV V, Sym6& Kc, SV& pc, float* lds = nullptr, int lane = 0, int hit0 = 0) {
+  int k = 0;
 #pragma unroll
   for (int i = 0; i < BEZ_NPT; ++i) {
     if (BEZ_PT_LINK[i] == L) {
-      V3 pl = mk((float)BEZ_PT_POS[i][0], (float)BEZ_PT_POS[i][1], (float)BEZ_PT_POS[i][2]);
+      V3 pl = mk((float)pt_pos<CL>(i, 0), (float)pt_pos<CL>(i, 1), (float)pt_pos<CL>(i, 2));
       V3 x = r + mul(E, pl);
-      (void)ground_contact(P, mu, x, root_z + x.z, V, Kc, pc);
+      Hit h = ground_contact(P, mu, x, root_z + x.z, V, Kc, pc);
+      if (CL && lds) {
+        const int s0 = hit0 + k * 8;
+        XS(s0) = h.x.x; XS(s0 + 1) = h.x.y; XS(s0 + 2) = h.x.z; XS(s0 + 3) = h.fn0; XS(s0 + 4) = h.kn; XS(s0 + 5) = h.ct; XS(s0 + 6) = h.ftx0; XS(s0 + 7) = h.fty0;
+      }
+      ++k;
+    }
+  }
+}
+// the cleat rows of one foot from the records above and the foot's acceleration
+template <int L>
+BEZ_DEV void ws_cleat_forces(const Params& P, float* lds, int lane, int hit0, SV a, bool first) {
+  int k = 0;
+#pragma unroll
+  for (int i = 0; i < BEZ_NPT; ++i) {
+    if (BEZ_PT_LINK[i] == L) {
+      const int s0 = hit0 + k * 8;
+      Hit h; h.x = mk(XS(s0), XS(s0 + 1), XS(s0 + 2)); h.fn0 = XS(s0 + 3); h.kn = XS(s0 + 4); h.ct = XS(s0 + 5); h.ftx0 = XS(s0 + 6); h.fty0 = XS(s0 + 7);
+      V3 f = h.kn > 0.f ? cf_ground(P, hit_force(P, h, a)) : mk(0, 0, 0);
+      ws_cf_acc(lds, lane, BEZ_PT_BODY_CL[i], f, P.cf_w, first);
+      ++k;
     }
   }
 }
@@ -129,7 +152,7 @@ struct ChainDyn { float mu; V3 g; };
 
 // ---- passes 1+2 of one serial chain.  Outputs the chain's articulated inertia/bias as seen by the torso (added to
 // IAo/pAo), the pass-3 operands p3[LEN], the contact rows of the chain-end link, and (legs) the ball/box candidate.
-template <int FIRST, int LEN, bool LEG>
+template <int FIRST, int LEN, bool LEG, bool CL>
 BEZ_DEV void ws_chain_pass1(const Params& P, const ChainDyn& D, const float* ms, const RootView& R, const float* q, const float* qd,
                             LinkInertia* LI, SV* pAl, SV* Sl, SV* cbl, M3& Eend, V3& rend, SV& Vend, BallSel& sel, SV& Vsel) {
   M3 E = R.E0;
@@ -139,7 +162,7 @@ BEZ_DEV void ws_chain_pass1(const Params& P, const ChainDyn& D, const float* ms,
     constexpr int i = decltype(I)::value;
     constexpr int L = FIRST + i;
     link_kinematics<L>(q[i], qd[i], E, r, V, Sl[i], cbl[i]);
-    link_inertia<L>(ms[i], D.g, E, r, V, LI[i], pAl[i]);
+    link_inertia<L, CL>(ms[i], D.g, E, r, V, LI[i], pAl[i]);
     if constexpr (LEG && link_has_box(L)) {
       test_box<link_box(L)>(E, r, R.bc, sel);
       if (sel.link == L) Vsel = V;  // this box just became the deepest candidate: keep its link velocity
@@ -192,7 +215,7 @@ BEZ_DEV void ws_chain_self_correction(const float* lds, int lane, int side, P3* 
 }
 
 // pass 3: joint accelerations, semi-implicit Euler with the velocity clamp; returns the chain-end acceleration
-template <int FIRST, int LEN, bool LEG>
+template <int FIRST, int LEN, bool LEG, bool CL>
 BEZ_DEV SV ws_chain_pass3(const Params& P, SV a0, const P3* p3, float* q, float* qd, bool mine, const BallSel& sel, V3& fl, V3& f_end,
                           float* lds, int lane, bool keep, bool first) {
   SV a = a0;
@@ -211,7 +234,7 @@ BEZ_DEV SV ws_chain_pass3(const Params& P, SV a0, const P3* p3, float* q, float*
       if (mine && sel.link == L) { fl = sel.f0p - mul(sel.A, point_of(a, sel.x)); f = f + cf_along(P, fl, sel.n); }
       if (keep) {
         if constexpr (i == LEN - 1) f_end = f;
-        else ws_cf_acc(lds, lane, BEZ_LINK_BODY[L], f, P.cf_w, first);
+        else ws_cf_acc(lds, lane, link_body<CL>(L), f, P.cf_w, first);
       }
     }
   });
@@ -256,7 +279,7 @@ BEZ_DEV void ws_chain_epilogue(const Params& P, float* lds, int lane, int e, boo
       });
       static_for<6>([&](auto I) { constexpr int i = decltype(I)::value; target[i] = (float)BEZ_DOF_DEFAULT[role_dof(ROLE, i)]; });
     }
-    float* obs_row = lds + X_SLOTS * WS_ENVS + lane * WS_OBS_STRIDE;
+    float* obs_row = lds + X_SLOTS * WS_ENVS + lane * P.nobs;
     float psum = 0.f;
     static_for<6>([&](auto I) {
       constexpr int i = decltype(I)::value;
@@ -346,7 +369,7 @@ BEZ_DEV void ws_self_pairs(const Params& P, float mu, float* lds, int lane, cons
 }
 
 // ------------------------------------------------------------------------------------------------ roles
-template <int FIRST, bool PRE, bool POST, bool DR>
+template <int FIRST, bool PRE, bool POST, bool DR, bool CL>
 BEZ_DEV void ws_leg_role(const Params& P, float* lds, int lane, int e, bool active, int side) {
   constexpr int LEN = 6;
   const int n = P.n;
@@ -398,7 +421,7 @@ BEZ_DEV void ws_leg_role(const Params& P, float* lds, int lane, int e, bool acti
     BallSel sel;
     sel.link = -1; sel.depth = 0.f; sel.n = sel.P = sel.f0p = sel.x = sel.xb = mk(0, 0, 0); sel.A = sym3zero();
     M3 Eend; V3 rend; SV Vend, Vsel = svzero();
-    ws_chain_pass1<FIRST, LEN, true>(P, D, ms, R, q, qd, LI, pAl, Sl, cbl, Eend, rend, Vend, sel, Vsel);
+    ws_chain_pass1<FIRST, LEN, true, CL>(P, D, ms, R, q, qd, LI, pAl, Sl, cbl, Eend, rend, Vend, sel, Vsel);
     {  // publish this leg's deepest ball/box candidate; the root role picks the winner and prepares the contact
       const int c0 = X_CAND + side * 14;
       XS(c0) = sel.depth; XS(c0 + 1) = (float)sel.link;
@@ -409,7 +432,7 @@ BEZ_DEV void ws_leg_role(const Params& P, float* lds, int lane, int e, bool acti
     WS_STAMP(side, 3 + 8 * s);
     // foot ground contact while the root role evaluates the ball<->link contact operands
     Sym6 Kc = sym6zero(); SV pc = svzero();
-    ws_ground_points<FIRST + LEN - 1>(P, D.mu, R.root_z, Eend, rend, Vend, Kc, pc);
+    ws_ground_points<FIRST + LEN - 1, CL>(P, D.mu, R.root_z, Eend, rend, Vend, Kc, pc, lds, lane, X_HIT + side * 32);
     ws_barrier();  // B1b: fold operands published
     bool mine = (XS(X_FOLD) == (float)side) && (XS(X_FOLD + 1) >= 1.f);
     if (mine) {
@@ -435,9 +458,16 @@ BEZ_DEV void ws_leg_role(const Params& P, float* lds, int lane, int e, bool acti
     WS_STAMP(side, 6 + 8 * s);
     SV a0 = xs_load_sv(lds, lane, X_A0);
     V3 fl = mk(0, 0, 0), fend = mk(0, 0, 0);
-    SV aend = ws_chain_pass3<FIRST, LEN, true>(P, a0, p3, q, qd, mine, sel, fl, fend, lds, lane, keep, first);
+    SV aend = ws_chain_pass3<FIRST, LEN, true, CL>(P, a0, p3, q, qd, mine, sel, fl, fend, lds, lane, keep, first);
     if (mine && sel.link >= 0) { xs_store_v3(lds, lane, X_FL, fl); xs_store_v3(lds, lane, X_FL + 3, sel.xb); }
-    if (keep) ws_cf_acc(lds, lane, BEZ_LINK_BODY[FIRST + LEN - 1], fend + cf_ground(P, body_contact_force(bcn, aend)), P.cf_w, first);
+    if (keep) {
+      if constexpr (CL) {  // the foot plate only feels the ball / the other leg; the ground acts on the four cleats
+        ws_cf_acc(lds, lane, link_body<CL>(FIRST + LEN - 1), fend, P.cf_w, first);
+        ws_cleat_forces<FIRST + LEN - 1>(P, lds, lane, X_HIT + side * 32, aend, first);
+      } else {
+        ws_cf_acc(lds, lane, link_body<CL>(FIRST + LEN - 1), fend + cf_ground(P, body_contact_force(bcn, aend)), P.cf_w, first);
+      }
+    }
 #pragma unroll
     for (int i = 0; i < LEN; ++i) { XS(X_LEGQ + side * 12 + i) = q[i]; XS(X_LEGQ + side * 12 + 6 + i) = qd[i]; }
     WS_STAMP(side, 7 + 8 * s);
@@ -450,7 +480,7 @@ BEZ_DEV void ws_leg_role(const Params& P, float* lds, int lane, int e, bool acti
   ws_barrier();  // B6
 }
 
-template <bool PRE, bool POST, bool DR>
+template <bool PRE, bool POST, bool DR, bool CL>
 BEZ_DEV void ws_upper_role(const Params& P, float* lds, int lane, int e, bool active) {
   // joints (dof index): head 0,1 (links 1,2); left arm 2,3 (links 3,4); right arm 10,11 (links 11,12)
   const int n = P.n;
@@ -510,16 +540,16 @@ BEZ_DEV void ws_upper_role(const Params& P, float* lds, int lane, int e, bool ac
     ws_barrier();  // B1b  (only the legs / root exchange data here: the chains below overlap the legs' pass 2)
     {  // three 2-link chains, one after the other
       LinkInertia LI[2]; SV pAl[2], Sl[2], cbl[2]; Sym6 Kc; SV pc; M3 Ee; V3 re; SV Ve, Vs = svzero();
-      ws_chain_pass1<1, 2, false>(P, D, ms + 0, R, q + 0, qd + 0, LI, pAl, Sl, cbl, Ee, re, Ve, nosel, Vs);
-      Kc = sym6zero(); pc = svzero(); ws_ground_points<2>(P, D.mu, R.root_z, Ee, re, Ve, Kc, pc);
+      ws_chain_pass1<1, 2, false, CL>(P, D, ms + 0, R, q + 0, qd + 0, LI, pAl, Sl, cbl, Ee, re, Ve, nosel, Vs);
+      Kc = sym6zero(); pc = svzero(); ws_ground_points<2, CL>(P, D.mu, R.root_z, Ee, re, Ve, Kc, pc);
       ws_chain_pass2<1, 2, false>(P, D, kps + 0, kds + 0, lo + 0, hi + 0, q + 0, qd + 0, target + 0, LI, pAl, Sl, cbl, Kc, pc, false, nosel, p3 + 0, IA, pA);
       bcn[0] = body_contact_of(Kc, pc);
-      ws_chain_pass1<3, 2, false>(P, D, ms + 2, R, q + 2, qd + 2, LI, pAl, Sl, cbl, Ee, re, Ve, nosel, Vs);
-      Kc = sym6zero(); pc = svzero(); ws_ground_points<4>(P, D.mu, R.root_z, Ee, re, Ve, Kc, pc);
+      ws_chain_pass1<3, 2, false, CL>(P, D, ms + 2, R, q + 2, qd + 2, LI, pAl, Sl, cbl, Ee, re, Ve, nosel, Vs);
+      Kc = sym6zero(); pc = svzero(); ws_ground_points<4, CL>(P, D.mu, R.root_z, Ee, re, Ve, Kc, pc);
       ws_chain_pass2<3, 2, false>(P, D, kps + 2, kds + 2, lo + 2, hi + 2, q + 2, qd + 2, target + 2, LI, pAl, Sl, cbl, Kc, pc, false, nosel, p3 + 2, IA, pA);
       bcn[1] = body_contact_of(Kc, pc);
-      ws_chain_pass1<11, 2, false>(P, D, ms + 4, R, q + 4, qd + 4, LI, pAl, Sl, cbl, Ee, re, Ve, nosel, Vs);
-      Kc = sym6zero(); pc = svzero(); ws_ground_points<12>(P, D.mu, R.root_z, Ee, re, Ve, Kc, pc);
+      ws_chain_pass1<11, 2, false, CL>(P, D, ms + 4, R, q + 4, qd + 4, LI, pAl, Sl, cbl, Ee, re, Ve, nosel, Vs);
+      Kc = sym6zero(); pc = svzero(); ws_ground_points<12, CL>(P, D.mu, R.root_z, Ee, re, Ve, Kc, pc);
       ws_chain_pass2<11, 2, false>(P, D, kps + 4, kds + 4, lo + 4, hi + 4, q + 4, qd + 4, target + 4, LI, pAl, Sl, cbl, Kc, pc, false, nosel, p3 + 4, IA, pA);
       bcn[2] = body_contact_of(Kc, pc);
     }
@@ -532,13 +562,13 @@ BEZ_DEV void ws_upper_role(const Params& P, float* lds, int lane, int e, bool ac
     WS_STAMP(2, 6 + 8 * s);
     SV a0 = xs_load_sv(lds, lane, X_A0);
     V3 fl = mk(0, 0, 0), fend = mk(0, 0, 0);
-    SV ae0 = ws_chain_pass3<1, 2, false>(P, a0, p3 + 0, q + 0, qd + 0, false, nosel, fl, fend, lds, lane, keep, first);
-    SV ae1 = ws_chain_pass3<3, 2, false>(P, a0, p3 + 2, q + 2, qd + 2, false, nosel, fl, fend, lds, lane, keep, first);
-    SV ae2 = ws_chain_pass3<11, 2, false>(P, a0, p3 + 4, q + 4, qd + 4, false, nosel, fl, fend, lds, lane, keep, first);
+    SV ae0 = ws_chain_pass3<1, 2, false, CL>(P, a0, p3 + 0, q + 0, qd + 0, false, nosel, fl, fend, lds, lane, keep, first);
+    SV ae1 = ws_chain_pass3<3, 2, false, CL>(P, a0, p3 + 2, q + 2, qd + 2, false, nosel, fl, fend, lds, lane, keep, first);
+    SV ae2 = ws_chain_pass3<11, 2, false, CL>(P, a0, p3 + 4, q + 4, qd + 4, false, nosel, fl, fend, lds, lane, keep, first);
     if (keep) {
-      ws_cf_acc(lds, lane, BEZ_LINK_BODY[2], cf_ground(P, body_contact_force(bcn[0], ae0)), P.cf_w, first);
-      ws_cf_acc(lds, lane, BEZ_LINK_BODY[4], cf_ground(P, body_contact_force(bcn[1], ae1)), P.cf_w, first);
-      ws_cf_acc(lds, lane, BEZ_LINK_BODY[12], cf_ground(P, body_contact_force(bcn[2], ae2)), P.cf_w, first);
+      ws_cf_acc(lds, lane, link_body<CL>(2), cf_ground(P, body_contact_force(bcn[0], ae0)), P.cf_w, first);
+      ws_cf_acc(lds, lane, link_body<CL>(4), cf_ground(P, body_contact_force(bcn[1], ae1)), P.cf_w, first);
+      ws_cf_acc(lds, lane, link_body<CL>(12), cf_ground(P, body_contact_force(bcn[2], ae2)), P.cf_w, first);
     }
     ws_barrier();  // B4
     ws_barrier();  // B5
@@ -547,7 +577,7 @@ BEZ_DEV void ws_upper_role(const Params& P, float* lds, int lane, int e, bool ac
   ws_barrier();  // B6
 }
 
-template <bool PRE, bool POST, bool DR>
+template <bool PRE, bool POST, bool DR, bool CL>
 BEZ_DEV void ws_root_role(const Params& P, float* lds, int lane, int e, bool active) {
   const int n = P.n;
   float* st = P.state;
@@ -595,9 +625,9 @@ BEZ_DEV void ws_root_role(const Params& P, float* lds, int lane, int e, bool act
     xs_store_v3(lds, lane, X_FL, mk(0, 0, 0)); xs_store_v3(lds, lane, X_FL + 3, mk(0, 0, 0));
     Sym6 IA0 = sym6zero(); SV pA0;
     LinkInertia I0;
-    link_inertia<0>(ms0, D.g, E0, mk(0, 0, 0), V0, I0, pA0);
+    link_inertia<0, CL>(ms0, D.g, E0, mk(0, 0, 0), V0, I0, pA0);
     Sym6 Kc = sym6zero(); SV pc = svzero();
-    ws_ground_points<0>(P, D.mu, root_pos.z, E0, mk(0, 0, 0), V0, Kc, pc);
+    ws_ground_points<0, CL>(P, D.mu, root_pos.z, E0, mk(0, 0, 0), V0, Kc, pc);
     BodyContact bc0 = body_contact_of(Kc, pc);
     add_link_inertia(IA0, I0);
     add_to(IA0, Kc); pA0 = pA0 + pc;
@@ -660,7 +690,7 @@ BEZ_DEV void ws_root_role(const Params& P, float* lds, int lane, int e, bool act
     if (keep) {
       V3 fb = -cf_along(P, fl, sel.n);
       if (ball.ground) fb = fb + cf_ground(P, hit_force(P, ball.ghit, ab));
-      ws_cf_acc(lds, lane, BEZ_NBE - 1, fb, P.cf_w, first);
+      ws_cf_acc(lds, lane, nb_of<CL>(), fb, P.cf_w, first);
     }
     float damp = fmaxf(1.0f - P.h * P.ball_damp, 0.f);
     ball_lin = fma3(ab.l, P.h, ball_lin);
@@ -676,7 +706,9 @@ BEZ_DEV void ws_root_role(const Params& P, float* lds, int lane, int e, bool act
   if (POST) {
     CfOut co;
     co.base = nullptr; co.n = n;
-    co.lf = xs_load_v3(lds, lane, X_CF + BEZ_LFOOT_BODY * 3); co.rf = xs_load_v3(lds, lane, X_CF + BEZ_RFOOT_BODY * 3);
+    co.lf = xs_load_v3(lds, lane, X_CF + lfoot_body<CL>() * 3); co.rf = xs_load_v3(lds, lane, X_CF + rfoot_body<CL>() * 3);
+    float goal_x = P.goal[0], goal_y = P.goal[1];
+    if (P.task != BEZ_TASK_KICK) { goal_x = ld(F_GOAL); goal_y = ld(F_GOAL + 1); }
     int64_t timeout = (progress >= (int64_t)(P.max_len - 1)) ? 1 : 0;  // vec_task.py:331-332
     progress += 1;                                                    // kick_env.py:429
     if (reset != 0) {                                                 // kick_env.py:433-435, 831-850 (root / ball part)
@@ -687,19 +719,30 @@ BEZ_DEV void ws_root_role(const Params& P, float* lds, int lane, int e, bool act
       root_lin = root_ang = ball_lin = ball_ang = mk(0, 0, 0);
       co.lf = co.rf = mk(0, 0, 0);
 #pragma unroll
-      for (int k = 0; k < BEZ_NBE * 3; ++k) XS(X_CF + k) = 0.f;
+      for (int k = 0; k < (nb_of<CL>() + 1) * 3; ++k) XS(X_CF + k) = 0.f;
       if (active) P.episode[e] = P.episode[e] + 1;
+      if (P.task != BEZ_TASK_KICK) {  // walk_env.py:570-575: every env reset by this call receives the same fresh goal
+        goal_x = P.goal_draw[0]; goal_y = P.goal_draw[1];
+        if (active) { st[(size_t)F_GOAL * n + e] = goal_x; st[(size_t)(F_GOAL + 1) * n + e] = goal_y; }
+      }
       progress = 0; reset = 0;
     }
     float pn = (XS(X_PSUM + 2) + XS(X_PSUM + 0)) + XS(X_PSUM + 1);
     float feet[8], rew;
-    float* obs_row = lds + X_SLOTS * WS_ENVS + lane * WS_OBS_STRIDE;
+    float* obs_row = lds + X_SLOTS * WS_ENVS + lane * P.nobs;
     float tail[18];
-    env_observe_core(P, root_pos, rq, root_lin, root_ang, ball_pos, ball_lin, co, prev, feet, tail, pn, rew, reset, progress);
+    float cleats[24];
+    if (CL) {
 #pragma unroll
-    for (int i = 0; i < 18; ++i) obs_row[36 + i] = tail[i];
-    // the feet logic filters the two foot rows in place (kick_env.py:987-990)
-    xs_store_v3(lds, lane, X_CF + BEZ_LFOOT_BODY * 3, co.lf); xs_store_v3(lds, lane, X_CF + BEZ_RFOOT_BODY * 3, co.rf);
+      for (int k = 0; k < 12; ++k) { cleats[k] = XS(X_CF + BEZ_LCLEAT_BODY_CL * 3 + k); cleats[12 + k] = XS(X_CF + BEZ_RCLEAT_BODY_CL * 3 + k); }
+    }
+    env_observe_core(P, root_pos, rq, root_lin, root_ang, ball_pos, ball_lin, co, prev, feet, tail, pn, rew, reset, progress, goal_x, goal_y,
+                     CL ? cleats : nullptr);
+#pragma unroll
+    for (int i = 0; i < 18; ++i) if (36 + i < P.nobs) obs_row[36 + i] = tail[i];
+    if (!CL) {  // the no-cleats feet logic filters the two foot rows in place (kick_env.py:987-990)
+      xs_store_v3(lds, lane, X_CF + BEZ_LFOOT_BODY * 3, co.lf); xs_store_v3(lds, lane, X_CF + BEZ_RFOOT_BODY * 3, co.rf);
+    }
     if (active) {
 #pragma unroll
       for (int i = 0; i < 3; ++i) st[(size_t)(F_PREV + i) * n + e] = prev[i];
@@ -723,7 +766,7 @@ BEZ_DEV void ws_root_role(const Params& P, float* lds, int lane, int e, bool act
 }
 
 // ---- the kernel.  grid = ceil(N / 64) workgroups of 256 threads.
-template <bool PRE, bool POST, bool DR>
+template <bool PRE, bool POST, bool DR, bool CL>
 __global__ __launch_bounds__(WS_BLOCK) void step_kernel_ws(Params P) {
   __shared__ __attribute__((aligned(16))) float lds[WS_LDS_FLOATS];
   const int tid = threadIdx.x;
@@ -741,16 +784,17 @@ __global__ __launch_bounds__(WS_BLOCK) void step_kernel_ws(Params P) {
     for (int i = tid; i < nloc * BEZ_ND; i += WS_BLOCK) act[(i / BEZ_ND) * WS_ACT_STRIDE + (i % BEZ_ND)] = src[i];
   }
   // contact-force rows start from zero: bodies nothing touches are never accumulated into
-  for (int i = tid; i < BEZ_NBE * 3 * WS_ENVS; i += WS_BLOCK) lds[X_CF * WS_ENVS + i] = 0.f;
-  if (role == 0) ws_leg_role<5, PRE, POST, DR>(P, lds, lane, e, active, 0);
-  else if (role == 1) ws_leg_role<13, PRE, POST, DR>(P, lds, lane, e, active, 1);
-  else if (role == 2) ws_upper_role<PRE, POST, DR>(P, lds, lane, e, active);
-  else ws_root_role<PRE, POST, DR>(P, lds, lane, e, active);
+  constexpr int NROW = (nb_of<CL>() + 1) * 3;  // contact-force rows of this asset (robot bodies + ball)
+  for (int i = tid; i < NROW * WS_ENVS; i += WS_BLOCK) lds[X_CF * WS_ENVS + i] = 0.f;
+  if (role == 0) ws_leg_role<5, PRE, POST, DR, CL>(P, lds, lane, e, active, 0);
+  else if (role == 1) ws_leg_role<13, PRE, POST, DR, CL>(P, lds, lane, e, active, 1);
+  else if (role == 2) ws_upper_role<PRE, POST, DR, CL>(P, lds, lane, e, active);
+  else ws_root_role<PRE, POST, DR, CL>(P, lds, lane, e, active);
   ws_barrier();  // contact-force rows (and, with POST, the observation rows staged by role 3) are complete in LDS
   {
     // net contact force: 66 SoA rows of 64 consecutive envs each -> coalesced
     float* dst = P.state + (size_t)F_CF * P.n + env0;
-    for (int i = tid; i < BEZ_NBE * 3 * WS_ENVS; i += WS_BLOCK) {
+    for (int i = tid; i < NROW * WS_ENVS; i += WS_BLOCK) {
       const int k = i >> 6, l = i & 63;
       if (l < nloc) dst[(size_t)k * P.n + l] = lds[(X_CF + k) * WS_ENVS + l];
     }
@@ -758,10 +802,10 @@ __global__ __launch_bounds__(WS_BLOCK) void step_kernel_ws(Params P) {
   if (POST) {
     // the staged rows are the contiguous (nloc,54) image of this workgroup's slice of obs_buf: 16-byte copy-out
     const float4* rows = reinterpret_cast<const float4*>(lds + X_SLOTS * WS_ENVS);
-    float4* dst = reinterpret_cast<float4*>(P.obs + (size_t)env0 * BEZ_NUM_OBS);
-    const int nvec = (nloc * BEZ_NUM_OBS) >> 2;
+    float4* dst = reinterpret_cast<float4*>(P.obs + (size_t)env0 * P.nobs);  // 64 * nobs * 4 B per workgroup: 16-B aligned for 54 and 52
+    const int nvec = (nloc * P.nobs) >> 2;
     for (int i = tid; i < nvec; i += WS_BLOCK) dst[i] = rows[i];
-    for (int i = (nvec << 2) + tid; i < nloc * BEZ_NUM_OBS; i += WS_BLOCK) P.obs[(size_t)env0 * BEZ_NUM_OBS + i] = lds[X_SLOTS * WS_ENVS + i];
+    for (int i = (nvec << 2) + tid; i < nloc * P.nobs; i += WS_BLOCK) P.obs[(size_t)env0 * P.nobs + i] = lds[X_SLOTS * WS_ENVS + i];
   }
   WS_STAMP(role, 23);
 }

@@ -28,7 +28,8 @@ constexpr int BLOCK = 64;  // one wave per workgroup
 enum : int {
   F_ROOT_POS = 0, F_ROOT_QUAT = 3, F_ROOT_LIN = 7, F_ROOT_ANG = 10, F_Q = 13, F_QD = 31,
   F_BALL_POS = 49, F_BALL_QUAT = 52, F_BALL_LIN = 56, F_BALL_ANG = 59, F_TARGET = 62, F_PREV = 80,
-  F_CF = 83 /* 22 bodies x 3 */, F_FEET = 149, F_COUNT = 157
+  F_CF = 83 /* up to BEZ_NBE_MAX = 30 bodies x 3 (22 used without cleats) */, F_FEET = F_CF + BEZ_NBE_MAX * 3, F_GOAL = F_FEET + 8 /* bez_walk: per-env goal xy */,
+  F_COUNT = F_GOAL + 2
 };
 
 // ---- LDS slots per lane
@@ -48,6 +49,9 @@ struct Params {
   float kn, cn, ct, veps, lim_k, lim_d, jf_veps, ball_damp;
   float self_kn, self_cn;
   float cf_w;  // weight of one substep in the net-contact-force mean (1/substeps, or 1 with BEZ_FLAG_CF_LAST_SUBSTEP)
+  int task, nobs;       // BEZ_TASK_*; observation width (54 kick, 52 walk / orient)
+  float goal_angle;     // bez_orient
+  float goal_draw[2];   // bez_walk / bez_orient: the ONE goal every env reset by this launch receives (walk_env.py:570-575)
   uint32_t flags;
   uint64_t seed;
   int64_t env_off;
@@ -68,6 +72,17 @@ struct Params {
   const float* dr_upper;     // (N,18)   or null
   unsigned long long* stamps; // diagnostic builds only (-DBEZ_WS_STAMPS): s_memtime per role / phase of workgroup 0
 };
+
+// ---- model variant: CL = the cleats asset (BEZ_FLAG_CLEATS): same tree, heavier feet, 8 cleat bodies, per-cleat ground points
+template <bool CL> BEZ_DEV constexpr int nb_of() { return CL ? BEZ_NB_CL : BEZ_NB; }   // robot bodies; the ball's row follows
+template <bool CL> BEZ_DEV constexpr int link_body(int l) { return CL ? BEZ_LINK_BODY_CL[l] : BEZ_LINK_BODY[l]; }
+template <bool CL> BEZ_DEV constexpr double link_mass(int l) { return CL ? BEZ_LINK_MASS_CL[l] : BEZ_LINK_MASS[l]; }
+template <bool CL> BEZ_DEV constexpr double link_com(int l, int k) { return CL ? BEZ_LINK_COM_CL[l][k] : BEZ_LINK_COM[l][k]; }
+template <bool CL> BEZ_DEV constexpr double link_inertia_c(int l, int k) { return CL ? BEZ_LINK_INERTIA_CL[l][k] : BEZ_LINK_INERTIA[l][k]; }
+template <bool CL> BEZ_DEV constexpr double pt_pos(int i, int k) { return CL ? BEZ_PT_POS_CL[i][k] : BEZ_PT_POS[i][k]; }
+template <bool CL> BEZ_DEV constexpr int pt_body(int i) { return CL ? BEZ_PT_BODY_CL[i] : BEZ_PT_BODY[i]; }
+template <bool CL> BEZ_DEV constexpr int lfoot_body() { return CL ? BEZ_LFOOT_BODY_CL : BEZ_LFOOT_BODY; }
+template <bool CL> BEZ_DEV constexpr int rfoot_body() { return CL ? BEZ_RFOOT_BODY_CL : BEZ_RFOOT_BODY; }
 
 // ---- compile-time model access
 BEZ_DEV constexpr int axis_index(int l) { return (BEZ_LINK_AXIS[l] < 0 ? -BEZ_LINK_AXIS[l] : BEZ_LINK_AXIS[l]) - 1; }
@@ -396,13 +411,13 @@ BEZ_DEV void link_frame_only(float q, M3& E, V3& r) {
 
 // rigid-body inertia of link L about O in compact form + its bias force (velocity product - gravity)
 struct LinkInertia { float m; V3 h; Sym3 Ibar; };
-template <int L>
+template <int L, bool CL = false>
 BEZ_DEV void link_inertia(float ms, V3 g, const M3& E, V3 r, SV V, LinkInertia& I, SV& pA) {
-  const float m = (float)BEZ_LINK_MASS[L] * ms;
-  const V3 cl = mk((float)BEZ_LINK_COM[L][0], (float)BEZ_LINK_COM[L][1], (float)BEZ_LINK_COM[L][2]);
+  const float m = (float)link_mass<CL>(L) * ms;
+  const V3 cl = mk((float)link_com<CL>(L, 0), (float)link_com<CL>(L, 1), (float)link_com<CL>(L, 2));
   Sym3 Il;
-  Il.xx = (float)BEZ_LINK_INERTIA[L][0] * ms; Il.yy = (float)BEZ_LINK_INERTIA[L][1] * ms; Il.zz = (float)BEZ_LINK_INERTIA[L][2] * ms;
-  Il.xy = (float)BEZ_LINK_INERTIA[L][3] * ms; Il.xz = (float)BEZ_LINK_INERTIA[L][4] * ms; Il.yz = (float)BEZ_LINK_INERTIA[L][5] * ms;
+  Il.xx = (float)link_inertia_c<CL>(L, 0) * ms; Il.yy = (float)link_inertia_c<CL>(L, 1) * ms; Il.zz = (float)link_inertia_c<CL>(L, 2) * ms;
+  Il.xy = (float)link_inertia_c<CL>(L, 3) * ms; Il.xz = (float)link_inertia_c<CL>(L, 4) * ms; Il.yz = (float)link_inertia_c<CL>(L, 5) * ms;
   V3 c = r + mul(E, cl);
   Sym3 Iw = rotate_inertia(E, Il);
   float cc = dot(c, c);
@@ -422,13 +437,13 @@ BEZ_DEV void add_link_inertia(Sym6& IA, const LinkInertia& I) {
 }
 
 // ground points of link L (compile-time filtered), using the link's frame and velocity
-template <int L>
+template <int L, bool CL = false>
 BEZ_DEV void link_ground_points(const Params& P, float mu, float root_z, const M3& E, V3 r, SV V, Sym6& IA, SV& pA,
                                 float* lds, int lane, bool keep) {
 #pragma unroll
   for (int i = 0; i < BEZ_NPT; ++i) {
     if (BEZ_PT_LINK[i] == L) {
-      V3 pl = mk((float)BEZ_PT_POS[i][0], (float)BEZ_PT_POS[i][1], (float)BEZ_PT_POS[i][2]);
+      V3 pl = mk((float)pt_pos<CL>(i, 0), (float)pt_pos<CL>(i, 1), (float)pt_pos<CL>(i, 2));
       V3 x = r + mul(E, pl);
       Hit hit = ground_contact(P, mu, x, root_z + x.z, V, IA, pA);
       if (keep) lds_store_hit(lds, lane, i, hit);
@@ -446,6 +461,18 @@ BEZ_DEV V3 link_ground_forces(const Params& P, SV acc, const float* lds, int lan
     }
   }
   return f;
+}
+// cleats: every ground point of the foot link reports into its own cleat body's row
+template <int L>
+BEZ_DEV void link_ground_forces_cleats(const Params& P, SV acc, const float* lds, int lane, const CfOut& co, bool first) {
+#pragma unroll
+  for (int i = 0; i < BEZ_NPT; ++i) {
+    if (BEZ_PT_LINK[i] == L) {
+      Hit hit = lds_load_hit(lds, lane, i);
+      V3 f = hit.kn > 0.f ? cf_ground(P, hit_force(P, hit, acc)) : mk(0, 0, 0);
+      cf_accum(co, BEZ_PT_BODY_CL[i], f, P.cf_w, first);
+    }
+  }
 }
 
 // joint drive / friction / limit terms and the ABA joint-space quantities for DOF d = L-1
@@ -482,7 +509,7 @@ BEZ_DEV void static_for(F&& f) { static_for_impl(std::make_integer_sequence<int,
 
 // ---- passes 1+2 of one serial chain FIRST..FIRST+LEN-1 hanging off the torso.  Accumulates the chain's
 // articulated inertia / bias into the torso's (IA0, pA0) and stages pass-3 data in LDS.
-template <int FIRST, int LEN>
+template <int FIRST, int LEN, bool CL>
 BEZ_DEV void chain_up(const Params& P, const EnvDyn& D, const EnvState& S, const float* target, const M3& E0, SV V0,
                       const BallBody& ball, V3 bc, BallSel& sel, const SV* selfw, Sym6& IA0, SV& pA0, float* lds, int lane, bool keep) {
   LinkInertia LI[LEN];
@@ -495,7 +522,7 @@ BEZ_DEV void chain_up(const Params& P, const EnvDyn& D, const EnvState& S, const
     constexpr int i = decltype(I)::value;
     constexpr int L = FIRST + i;
     link_kinematics<L>(S.q[L - 1], S.qd[L - 1], E, r, V, Sl[i], cbl[i]);
-    link_inertia<L>(D.mass_scale[L], D.g, E, r, V, LI[i], pAl[i]);
+    link_inertia<L, CL>(D.mass_scale[L], D.g, E, r, V, LI[i], pAl[i]);
     if constexpr (link_has_box(L)) {
       if (sel.link == L) ball_link_contact(P, D.mu, S.ball_ang, S.ball_lin, ball, bc, V, sel);
     }
@@ -504,7 +531,7 @@ BEZ_DEV void chain_up(const Params& P, const EnvDyn& D, const EnvState& S, const
   Sym6 IA = sym6zero();
   SV pA = svzero();
   SV pS = svzero();  // explicit leg<->leg contact wrenches, propagated next to pA (the drive-saturation predictor does not see them)
-  link_ground_points<FIRST + LEN - 1>(P, D.mu, S.root_pos.z, E, r, V, IA, pA, lds, lane, keep);
+  link_ground_points<FIRST + LEN - 1, CL>(P, D.mu, S.root_pos.z, E, r, V, IA, pA, lds, lane, keep);
   // pass 2: tip -> root
   static_for<LEN>([&](auto I) {
     constexpr int i = LEN - 1 - decltype(I)::value;
@@ -540,7 +567,7 @@ BEZ_DEV void chain_up(const Params& P, const EnvDyn& D, const EnvState& S, const
 
 // ---- pass 3 of one chain: joint accelerations from the torso acceleration; integrates the joints in
 // place (semi-implicit Euler + velocity clamp) and resolves contact forces on the way.
-template <int FIRST, int LEN>
+template <int FIRST, int LEN, bool CL>
 BEZ_DEV void chain_down(const Params& P, EnvState& S, SV a0, BallSel& sel, const V3* selfcf, V3& ball_link_force, CfOut& co, const float* lds,
                         int lane, bool keep, bool first) {
   SV a = a0;
@@ -569,15 +596,21 @@ BEZ_DEV void chain_down(const Params& P, EnvState& S, SV a0, BallSel& sel, const
       }
       if (keep) {
         if constexpr (L == Lend) fend = f;
-        else cf_accum(co, BEZ_LINK_BODY[L], f, P.cf_w, first);
+        else cf_accum(co, link_body<CL>(L), f, P.cf_w, first);
       }
     }
   });
   if (keep) {
-    V3 f = fend + cf_ground(P, link_ground_forces<Lend>(P, a, lds, lane));
-    if constexpr (Lend == BEZ_LFOOT_LINK) co.lf = first ? f * P.cf_w : fma3(f, P.cf_w, co.lf);
-    else if constexpr (Lend == BEZ_RFOOT_LINK) co.rf = first ? f * P.cf_w : fma3(f, P.cf_w, co.rf);
-    else cf_accum(co, BEZ_LINK_BODY[Lend], f, P.cf_w, first);
+    constexpr bool foot = (Lend == BEZ_LFOOT_LINK || Lend == BEZ_RFOOT_LINK);
+    if constexpr (CL && foot) {  // the foot plate itself only feels the ball / the other leg; the ground acts on the cleats
+      cf_accum(co, link_body<CL>(Lend), fend, P.cf_w, first);
+      link_ground_forces_cleats<Lend>(P, a, lds, lane, co, first);
+    } else {
+      V3 f = fend + cf_ground(P, link_ground_forces<Lend>(P, a, lds, lane));
+      if constexpr (Lend == BEZ_LFOOT_LINK) co.lf = first ? f * P.cf_w : fma3(f, P.cf_w, co.lf);
+      else if constexpr (Lend == BEZ_RFOOT_LINK) co.rf = first ? f * P.cf_w : fma3(f, P.cf_w, co.rf);
+      else cf_accum(co, link_body<CL>(Lend), f, P.cf_w, first);
+    }
   }
 }
 
@@ -595,6 +628,7 @@ BEZ_DEV void quat_integrate(float q[4], V3 w, float h) {
 
 // ---- one substep of the articulated-body dynamics for this lane's env.  When `keep` the net contact force per body of
 // this substep is accumulated (`first`: it starts the mean): foot rows in `co`, all other rows in HBM.
+template <bool CL>
 BEZ_DEV void substep(const Params& P, const EnvDyn& D, EnvState& S, const float* target, CfOut& co, float* lds, int lane, bool keep, bool first) {
   const M3 E0 = quat_to_mat(S.rq[0], S.rq[1], S.rq[2], S.rq[3]);
   const SV V0 = mksv(S.root_ang, S.root_lin);
@@ -642,19 +676,19 @@ BEZ_DEV void substep(const Params& P, const EnvDyn& D, EnvState& S, const float*
   SV pA0;
   {
     LinkInertia I0;
-    link_inertia<0>(D.mass_scale[0], D.g, E0, mk(0, 0, 0), V0, I0, pA0);
+    link_inertia<0, CL>(D.mass_scale[0], D.g, E0, mk(0, 0, 0), V0, I0, pA0);
     add_link_inertia(IA0, I0);
-    link_ground_points<0>(P, D.mu, S.root_pos.z, E0, mk(0, 0, 0), V0, IA0, pA0, lds, lane, keep);
+    link_ground_points<0, CL>(P, D.mu, S.root_pos.z, E0, mk(0, 0, 0), V0, IA0, pA0, lds, lane, keep);
     if (sel.link == 0) {
       ball_link_contact(P, D.mu, S.ball_ang, S.ball_lin, ball, bc, V0, sel);
       if (sel.link == 0) { add_point_stiffness(IA0, sel.x, sel.A); pA0 = pA0 - wrench_at(sel.x, sel.f0p); }
     }
   }
-  chain_up<1, 2>(P, D, S, target, E0, V0, ball, bc, sel, selfw, IA0, pA0, lds, lane, keep);    // neck, head
-  chain_up<3, 2>(P, D, S, target, E0, V0, ball, bc, sel, selfw, IA0, pA0, lds, lane, keep);    // left arm
-  chain_up<5, 6>(P, D, S, target, E0, V0, ball, bc, sel, selfw, IA0, pA0, lds, lane, keep);    // left leg
-  chain_up<11, 2>(P, D, S, target, E0, V0, ball, bc, sel, selfw, IA0, pA0, lds, lane, keep);   // right arm
-  chain_up<13, 6>(P, D, S, target, E0, V0, ball, bc, sel, selfw, IA0, pA0, lds, lane, keep);   // right leg
+  chain_up<1, 2, CL>(P, D, S, target, E0, V0, ball, bc, sel, selfw, IA0, pA0, lds, lane, keep);    // neck, head
+  chain_up<3, 2, CL>(P, D, S, target, E0, V0, ball, bc, sel, selfw, IA0, pA0, lds, lane, keep);    // left arm
+  chain_up<5, 6, CL>(P, D, S, target, E0, V0, ball, bc, sel, selfw, IA0, pA0, lds, lane, keep);    // left leg
+  chain_up<11, 2, CL>(P, D, S, target, E0, V0, ball, bc, sel, selfw, IA0, pA0, lds, lane, keep);   // right arm
+  chain_up<13, 6, CL>(P, D, S, target, E0, V0, ball, bc, sel, selfw, IA0, pA0, lds, lane, keep);   // right leg
   // (d) root: I0^A a0 = -p0^A
   SV a0 = solve_spd6(IA0, svzero() - pA0);
   // (e) pass 3 + joint integration + contact forces
@@ -664,17 +698,17 @@ BEZ_DEV void substep(const Params& P, const EnvDyn& D, EnvState& S, const float*
     if (sel.link == 0) { fl = sel.f0p - mul(sel.A, point_of(a0, sel.x)); f0 = cf_along(P, fl, sel.n); }
     if (keep) cf_accum(co, 0, f0 + cf_ground(P, link_ground_forces<0>(P, a0, lds, lane)), P.cf_w, first);
   }
-  chain_down<1, 2>(P, S, a0, sel, selfcf, fl, co, lds, lane, keep, first);
-  chain_down<3, 2>(P, S, a0, sel, selfcf, fl, co, lds, lane, keep, first);
-  chain_down<5, 6>(P, S, a0, sel, selfcf, fl, co, lds, lane, keep, first);
-  chain_down<11, 2>(P, S, a0, sel, selfcf, fl, co, lds, lane, keep, first);
-  chain_down<13, 6>(P, S, a0, sel, selfcf, fl, co, lds, lane, keep, first);
+  chain_down<1, 2, CL>(P, S, a0, sel, selfcf, fl, co, lds, lane, keep, first);
+  chain_down<3, 2, CL>(P, S, a0, sel, selfcf, fl, co, lds, lane, keep, first);
+  chain_down<5, 6, CL>(P, S, a0, sel, selfcf, fl, co, lds, lane, keep, first);
+  chain_down<11, 2, CL>(P, S, a0, sel, selfcf, fl, co, lds, lane, keep, first);
+  chain_down<13, 6, CL>(P, S, a0, sel, selfcf, fl, co, lds, lane, keep, first);
   // (f) ball: Mb ab = -pb - Jb^T fl
   SV ab = ball_minv(ball, svzero() - ball.pb - wrench_at(sel.xb, fl));
   if (keep) {
     V3 fb = -cf_along(P, fl, sel.n);
     if (ball.ground) fb = fb + cf_ground(P, hit_force(P, ball.ghit, ab));
-    cf_accum(co, BEZ_NBE - 1, fb, P.cf_w, first);
+    cf_accum(co, nb_of<CL>(), fb, P.cf_w, first);
   }
   // (g) integrate root (spatial -> classical acceleration of the torso origin) and ball
   V3 vdot = a0.l + cross(S.root_ang, S.root_lin);
@@ -717,7 +751,7 @@ BEZ_DEV void env_reset(const Params& P, EnvState& S, float* target, CfOut& co, u
 #pragma unroll
   for (int i = 0; i < 4; ++i) { S.rq[i] = P.bez_init[3 + i]; S.bq[i] = P.ball_init[3 + i]; }
   S.root_lin = S.root_ang = S.ball_lin = S.ball_ang = mk(0, 0, 0);
-  for (int b = 0; b < BEZ_NBE; ++b) cf_store(co, b, mk(0, 0, 0));
+  for (int b = 0; b < BEZ_NBE_MAX; ++b) cf_store(co, b, mk(0, 0, 0));
   co.lf = co.rf = mk(0, 0, 0);
 }
 
@@ -756,8 +790,11 @@ BEZ_DEV void feet_no_cleats(float* f, float* out) {
 
 // compute_observations + compute_reward (kick_env.py:749-777, 724-747) for this lane's env, everything except the
 // joint slots obs[0:36]: writes tail[18] = imu(6) off_orn(2) feet(8) ball_init(2).  `pn` = sum_j (default_j - q_j)^2.
+// `goal` = this env's goal xy (bez_kick: the configured point; bez_walk: redrawn at reset).  `cleats` = the 8 cleat rows of the
+// net contact force (24 floats) with the cleats asset, else null.
 BEZ_DEV void env_observe_core(const Params& P, V3 root_pos, const float* rq, V3 v, V3 w, V3 ball_pos, V3 ball_lin, CfOut& co,
-                              float* prev, float* feet, float* tail, float pn, float& rew, int64_t& reset, int64_t progress) {
+                              float* prev, float* feet, float* tail, float pn, float& rew, int64_t& reset, int64_t progress,
+                              float goal_x, float goal_y, const float* cleats) {
   // IMU link = torso origin frame (soccerbot_stl.urdf:567-572)
   // compute_imu (kick_env.py:918-930), quaternion_to_matrix fed xyzw as (r,i,j,k) (quirk Q2)
   float pvx = P.use_prev ? prev[0] : v.x, pvy = P.use_prev ? prev[1] : v.y, pvz = P.use_prev ? prev[2] : v.z;
@@ -774,7 +811,7 @@ BEZ_DEV void env_observe_core(const Params& P, V3 root_pos, const float* rq, V3 
   tail[3] = fminf(fmaxf(w.x, -ANG), ANG); tail[4] = fminf(fmaxf(w.y, -ANG), ANG); tail[5] = fminf(fmaxf(w.z, -ANG), ANG);
   prev[0] = v.x; prev[1] = v.y; prev[2] = v.z;
   // compute_off_orn (kick_env.py:941-960)
-  float gx = P.goal[0] - root_pos.x, gy = P.goal[1] - root_pos.y;
+  float gx = goal_x - root_pos.x, gy = goal_y - root_pos.y;
   float gn = sqrtf(gx * gx + gy * gy);
   float ux = gx / gn, uy = gy / gn;
   float qx = rq[0], qy = rq[1], qz = rq[2], qw = rq[3];
@@ -786,14 +823,56 @@ BEZ_DEV void env_observe_core(const Params& P, V3 root_pos, const float* rq, V3 
   float cosv = hc * ux + hs * uy;
   float sinv = fabsf(ux * hs - uy * hc);
   tail[6] = sinv; tail[7] = -cosv;
-  // feet (kick_env.py:538-576)
-  float fl[3] = {co.lf.x, co.lf.y, co.lf.z}, fr[3] = {co.rf.x, co.rf.y, co.rf.z};
-  feet_no_cleats(fl, feet);
-  feet_no_cleats(fr, feet + 4);
-  co.lf = mk(fl[0], fl[1], fl[2]); co.rf = mk(fr[0], fr[1], fr[2]);
+  // orient_env.py:719-735 compute_off_angle: (cos, sin) of goal_angle - normalize_angle(yaw)
+  const float ang_goal = P.goal_angle - atan2f(hs, hc);
+  if (P.task == BEZ_TASK_ORIENT) { tail[6] = cosf(ang_goal); tail[7] = sinf(ang_goal); }
+  // feet (kick_env.py:538-576; with cleats kick_env.py:467-495,1044-1069: |force on the cleat| > 1 N)
+  if (cleats) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const float* f = cleats + 3 * k;
+      feet[k] = sqrtf(f[0] * f[0] + f[1] * f[1] + f[2] * f[2]) > 1.0f ? 1.f : -1.f;
+    }
+  } else {
+    float fl[3] = {co.lf.x, co.lf.y, co.lf.z}, fr[3] = {co.rf.x, co.rf.y, co.rf.z};
+    feet_no_cleats(fl, feet);
+    feet_no_cleats(fr, feet + 4);
+    co.lf = mk(fl[0], fl[1], fl[2]); co.rf = mk(fr[0], fr[1], fr[2]);
+  }
 #pragma unroll
   for (int i = 0; i < 8; ++i) tail[8 + i] = feet[i];
-  tail[16] = P.ball_init[0]; tail[17] = P.ball_init[1];  // constant ball_init (quirk Q5, kick_env.py:776)
+  tail[16] = P.ball_init[0]; tail[17] = P.ball_init[1];  // constant ball_init (quirk Q5, kick_env.py:776); bez_kick only
+  if (P.task != BEZ_TASK_KICK) {
+    // compute_bez_reward of walk_env.py:826-1031 / orient_env.py:843-1018
+    const float vel_lin = sqrtf(dot(v, v)), vel_ang = sqrtf(dot(w, w)), vel_reward = sqrtf(dot(v, v) + dot(w, w)), pos_reward = sqrtf(pn);
+    const float up_proj = 1.f - 2.f * (qx * qx + qy * qy);  // get_basis_vector(q, (0,0,1)).z
+    const float dh = fabsf(1.f - up_proj);
+    const float height_vel_pos = -((vel_reward * 0.05f + pos_reward * 0.05f) + dh);
+    float reward, near;
+    if (P.task == BEZ_TASK_WALK) {
+      const float vfwd = ux * v.x + uy * v.y;
+      const float vel_height = vfwd * 10.f - (dh + 5.f * (pos_reward * 0.05f));
+      near = gn;
+      reward = gn < 0.05f ? height_vel_pos : vel_height;
+    } else {
+      const float vel_height = fabsf(ang_goal) * -0.5f - (dh + 0.05f * (pos_reward * 0.05f));
+      near = ang_goal;  // signed, as the reference compares it (orient_env.py:935)
+      reward = ang_goal < 0.05f ? height_vel_pos : vel_height;
+    }
+    if (up_proj < 0.7f) { reset = 1; reward = -100.f; }
+    const int state = (near < 0.05f) + (pos_reward < 0.15f) + (vel_ang < 0.1f) + (vel_lin < 0.1f);
+    if (state == 4) { reset = 1; reward = 1000.0f - 1000.0f * ((float)progress / (float)P.max_len); }
+    if (P.task == BEZ_TASK_WALK) {
+      const float gnn = sqrtf(goal_x * goal_x + goal_y * goal_y);
+      if (fabsf(atan2f(goal_y / gnn, goal_x / gnn) - atan2f(uy, ux)) > 1.5708f) { reset = 1; reward = -100.f; }
+    } else {
+      const float tx = root_pos.x - P.bez_init[0], ty = root_pos.y - P.bez_init[1];
+      if (sqrtf(tx * tx + ty * ty) > 0.3f) { reset = 1; reward = -5.f; }
+    }
+    if (progress >= (int64_t)P.max_len) { reset = 1; reward = 0.f; }
+    rew = reward;
+    return;
+  }
   // compute_bez_reward (kick_env.py:1224-1391)
   float bx = ball_pos.x, by = ball_pos.y;
   float dbx = bx - root_pos.x, dby = by - root_pos.y;
@@ -823,7 +902,7 @@ BEZ_DEV void env_observe_core(const Params& P, V3 root_pos, const float* rq, V3 
 }
 
 BEZ_DEV void env_observe_reward(const Params& P, const EnvState& S, CfOut& co, float* prev, float* feet, float* obs,
-                                float& rew, int64_t& reset, int64_t progress) {
+                                float& rew, int64_t& reset, int64_t progress, float goal_x, float goal_y, const float* cleats) {
   float pn = 0.f;
 #pragma unroll
   for (int j = 0; j < BEZ_ND; ++j) {
@@ -831,11 +910,11 @@ BEZ_DEV void env_observe_reward(const Params& P, const EnvState& S, CfOut& co, f
     float d = (float)BEZ_DOF_DEFAULT[j] - S.q[j];
     pn = fmaf(d, d, pn);
   }
-  env_observe_core(P, S.root_pos, S.rq, S.root_lin, S.root_ang, S.ball_pos, S.ball_lin, co, prev, feet, obs + 36, pn, rew, reset, progress);
+  env_observe_core(P, S.root_pos, S.rq, S.root_lin, S.root_ang, S.ball_pos, S.ball_lin, co, prev, feet, obs + 36, pn, rew, reset, progress, goal_x, goal_y, cleats);
 }
 
 // ---- the fused kernel: PRE (targets) / SIM (substeps) / POST (bookkeeping, reset, obs, reward)
-template <bool PRE, bool SIM, bool POST, bool DR>
+template <bool PRE, bool SIM, bool POST, bool DR, bool CL>
 __global__ __launch_bounds__(BLOCK) void step_kernel(Params P) {
   __shared__ float lds[SIM ? LDS_SLOTS * BLOCK : 1];
   const int lane = threadIdx.x;
@@ -898,9 +977,9 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(Params P) {
     const bool last_only = (P.flags & BEZ_FLAG_CF_LAST_SUBSTEP) != 0;
     for (int s = 0; s < P.substeps; ++s) {
       const bool last = (s == P.substeps - 1);
-      substep(P, D, S, target, co, lds, lane, last_only ? last : true, last_only ? true : (s == 0));
+      substep<CL>(P, D, S, target, co, lds, lane, last_only ? last : true, last_only ? true : (s == 0));
     }
-  } else if (POST) {
+  } else if (POST && !CL) {
     co.lf = mk(co.base[(size_t)(BEZ_LFOOT_BODY * 3 + 0) * n], co.base[(size_t)(BEZ_LFOOT_BODY * 3 + 1) * n], co.base[(size_t)(BEZ_LFOOT_BODY * 3 + 2) * n]);
     co.rf = mk(co.base[(size_t)(BEZ_RFOOT_BODY * 3 + 0) * n], co.base[(size_t)(BEZ_RFOOT_BODY * 3 + 1) * n], co.base[(size_t)(BEZ_RFOOT_BODY * 3 + 2) * n]);
   }
@@ -914,24 +993,36 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(Params P) {
         env_reset(P, S, target, co, episode, P.env_off + e);
         progress = 0; reset = 0;
         P.episode[e] = episode;
+        if (P.task != BEZ_TASK_KICK) { st[(size_t)F_GOAL * n + e] = P.goal_draw[0]; st[(size_t)(F_GOAL + 1) * n + e] = P.goal_draw[1]; }  // walk_env.py:570-575
       }
     }
     float prev[3], feet[8], obs[BEZ_NUM_OBS], rew;
 #pragma unroll
     for (int i = 0; i < 3; ++i) prev[i] = st[(size_t)(F_PREV + i) * n + e];
-    env_observe_reward(P, S, co, prev, feet, obs, rew, reset, progress);
+    const float goal_x = P.task == BEZ_TASK_KICK ? P.goal[0] : st[(size_t)F_GOAL * n + e], goal_y = P.task == BEZ_TASK_KICK ? P.goal[1] : st[(size_t)(F_GOAL + 1) * n + e];
+    float cleats[24];
+    if (CL) {  // the 8 cleat rows as the substeps left them in HBM (or as the caller injected them)
+#pragma unroll
+      for (int k = 0; k < 12; ++k) {
+        cleats[k] = co.base[(size_t)(BEZ_LCLEAT_BODY_CL * 3 + k) * n];
+        cleats[12 + k] = co.base[(size_t)(BEZ_RCLEAT_BODY_CL * 3 + k) * n];
+      }
+    }
+    env_observe_reward(P, S, co, prev, feet, obs, rew, reset, progress, goal_x, goal_y, CL ? cleats : nullptr);
 #pragma unroll
     for (int i = 0; i < 3; ++i) st[(size_t)(F_PREV + i) * n + e] = prev[i];
 #pragma unroll
     for (int i = 0; i < 8; ++i) st[(size_t)(F_FEET + i) * n + e] = feet[i];
 #pragma unroll
-    for (int i = 0; i < BEZ_NUM_OBS; ++i) P.obs[(size_t)e * BEZ_NUM_OBS + i] = obs[i];
+    for (int i = 0; i < BEZ_NUM_OBS; ++i) if (i < P.nobs) P.obs[(size_t)e * P.nobs + i] = obs[i];
     P.rew[e] = rew; P.reset[e] = reset; P.progress[e] = progress;
   }
   if (SIM || POST) {
     store_state(st, n, e, S);
-    cf_store(co, BEZ_LFOOT_BODY, co.lf);
-    cf_store(co, BEZ_RFOOT_BODY, co.rf);
+    if (!CL) {  // with cleats the foot rows live in HBM throughout (no in-place filter: kick_env.py:467-495)
+      cf_store(co, BEZ_LFOOT_BODY, co.lf);
+      cf_store(co, BEZ_RFOOT_BODY, co.rf);
+    }
 #pragma unroll
     for (int j = 0; j < BEZ_ND; ++j) st[(size_t)(F_TARGET + j) * n + e] = target[j];
   }

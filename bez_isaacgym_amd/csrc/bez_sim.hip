@@ -31,6 +31,9 @@ struct BezSim {
   int device = 0;
   int n = 0;
   int64_t obs_calls = 0;  // compute_observations passes so far (quirk Q1: only the first sees prev = zeros)
+  uint64_t post_calls = 0, reset_calls = 0;  // keys of the shared goal draw (bez_walk / bez_orient)
+  bool cleats = false, has_ball = true;
+  int nb = BEZ_NB, nbe = BEZ_NBE, nobs = BEZ_NUM_OBS, nact = 2;  // robot bodies, exported body rows, obs width, actors per env
   std::string err;
   // sim-owned device memory
   float* state = nullptr;       // SoA [F_COUNT][N]
@@ -48,6 +51,7 @@ struct BezSim {
   float* targets_aos = nullptr;  // (N,18)
   float* prev_aos = nullptr;     // (N,3)
   float* feet_aos = nullptr;     // (N,8)
+  float* goal_aos = nullptr;     // (N,2)
   float* dr[BEZ_PARAM_COUNT] = {};
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   unsigned long long* stamps = nullptr;  // diagnostic builds only
@@ -67,6 +71,23 @@ int fail(BezSim* s, int code, const char* what, hipError_t e = hipSuccess) {
     hipError_t _e = (call);                                           \
     if (_e != hipSuccess) return fail((s), -2, #call, _e);            \
   } while (0)
+
+// host copy of the reset-noise Philox (bez_kernels.h) for the per-call goal draw
+void philox_host(uint32_t c[4], uint32_t k0, uint32_t k1) {
+  for (int r = 0; r < 10; ++r) {
+    uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
+    uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0, n1 = (uint32_t)p1, n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1, n3 = (uint32_t)p0;
+    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+}
+// bez_walk / bez_orient: reset_idx draws goal xy ~ U(-2,2)^2 and gives THE FIRST SAMPLE to every env it resets
+// (walk_env.py:570-575): one draw per reset call, keyed by (seed, call counter, kind 0 = post_physics_step / 1 = explicit reset_idx)
+void goal_draw(uint64_t seed, uint64_t counter, uint32_t kind, float out[2]) {
+  uint32_t c[4] = {(uint32_t)counter, (uint32_t)(counter >> 32), 0x474f414cu, kind};
+  philox_host(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+  for (int k = 0; k < 2; ++k) out[k] = std::fmaf(4.0f, (float)(c[k] >> 8) * (1.0f / 16777216.0f), -2.0f);
+}
 
 Params make_params(const BezSim* s, const float* actions) {
   const BezSimConfig& c = s->cfg;
@@ -89,6 +110,8 @@ Params make_params(const BezSim* s, const float* actions) {
   P.lim_k = c.limit_k; P.lim_d = c.limit_d; P.jf_veps = c.jfric_veps; P.ball_damp = c.ball_ang_damping;
   P.self_kn = c.self_kn; P.self_cn = c.self_cn;
   P.cf_w = (c.flags & BEZ_FLAG_CF_LAST_SUBSTEP) ? 1.0f : 1.0f / (float)c.substeps;
+  P.task = c.task; P.nobs = s->nobs; P.goal_angle = c.goal_angle;
+  P.goal_draw[0] = c.goal[0]; P.goal_draw[1] = c.goal[1];
   P.flags = c.flags; P.seed = c.seed; P.env_off = c.env_id_offset;
   P.state = s->state; P.obs = s->obs; P.rew = s->rew; P.reset = s->reset; P.progress = s->progress;
   P.timeout = s->timeout; P.episode = s->episode; P.actions = actions;
@@ -122,21 +145,24 @@ __global__ void reset_kernel(Params P, const int32_t* ids, int count) {
   P.episode[e] = episode;
   store_state(P.state, P.n, e, S);
   for (int j = 0; j < BEZ_ND; ++j) P.state[(size_t)(F_TARGET + j) * P.n + e] = target[j];
+  if (P.task != BEZ_TASK_KICK) { P.state[(size_t)F_GOAL * P.n + e] = P.goal_draw[0]; P.state[(size_t)(F_GOAL + 1) * P.n + e] = P.goal_draw[1]; }
   P.progress[e] = 0;  // kick_env.py:849-850
   P.reset[e] = 0;
 }
 
-__global__ void init_misc_kernel(float* state, int n) {
+__global__ void init_misc_kernel(float* state, int n, float gx, float gy) {
   int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= n) return;
+  state[(size_t)F_GOAL * n + e] = gx; state[(size_t)(F_GOAL + 1) * n + e] = gy;  // walk_env.py:143 self.goal
   for (int i = 0; i < 3; ++i) state[(size_t)(F_PREV + i) * n + e] = 0.f;  // kick_env.py:183
   for (int i = 0; i < 8; ++i) state[(size_t)(F_FEET + i) * n + e] = -1.f; // kick_env.py:185
 }
 
-__global__ void refresh_root_kernel(const float* __restrict__ st, float* __restrict__ out, int n) {
+__global__ void refresh_root_kernel(const float* __restrict__ st, float* __restrict__ out, int n, int nact) {
   int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= n * 26) return;
-  int e = t / 26, k = t % 26;
+  const int w = 13 * nact;  // robot row (+ ball row)
+  if (t >= n * w) return;
+  int e = t / w, k = t % w;
   int f = (k < 13) ? (F_ROOT_POS + k) : (F_BALL_POS + (k - 13));
   out[t] = st[(size_t)f * n + e];
 }
@@ -178,7 +204,8 @@ BEZ_DEV void mat_to_quat(const M3& R, float q[4]) {
 }
 
 // gym.refresh_rigid_body_state_tensor: forward kinematics of all 21 robot bodies + the ball row
-__global__ void refresh_rigid_body_kernel(const float* __restrict__ st, float* __restrict__ out, int n) {
+template <bool CL>
+__global__ void refresh_rigid_body_kernel(const float* __restrict__ st, float* __restrict__ out, int n, int has_ball) {
   int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= n) return;
   EnvState S;
@@ -194,50 +221,54 @@ __global__ void refresh_rigid_body_kernel(const float* __restrict__ st, float* _
     SV Sj, cb;
     link_kinematics<L>(S.q[L - 1], S.qd[L - 1], E[L], r[L], V[L], Sj, cb);
   });
-  static_for<BEZ_NB>([&](auto I) {
+  constexpr int NB = nb_of<CL>();
+  const int nbe = NB + (has_ball ? 1 : 0);
+  static_for<NB>([&](auto I) {
     constexpr int b = decltype(I)::value;
-    constexpr int l = BEZ_BODY_LINK[b];
-    V3 off = mk((float)BEZ_BODY_OFFSET[b][0], (float)BEZ_BODY_OFFSET[b][1], (float)BEZ_BODY_OFFSET[b][2]);
+    constexpr int l = CL ? BEZ_BODY_LINK_CL[b] : BEZ_BODY_LINK[b];
+    V3 off = CL ? mk((float)BEZ_BODY_OFFSET_CL[b][0], (float)BEZ_BODY_OFFSET_CL[b][1], (float)BEZ_BODY_OFFSET_CL[b][2])
+                : mk((float)BEZ_BODY_OFFSET[b < BEZ_NB ? b : 0][0], (float)BEZ_BODY_OFFSET[b < BEZ_NB ? b : 0][1], (float)BEZ_BODY_OFFSET[b < BEZ_NB ? b : 0][2]);
     V3 x = r[l] + mul(E[l], off);
     V3 vel = point_of(V[l], x);
     float q[4];
     mat_to_quat(E[l], q);
-    float* o = out + ((size_t)e * BEZ_NBE + b) * 13;
+    float* o = out + ((size_t)e * nbe + b) * 13;
     o[0] = S.root_pos.x + x.x; o[1] = S.root_pos.y + x.y; o[2] = S.root_pos.z + x.z;
     o[3] = q[0]; o[4] = q[1]; o[5] = q[2]; o[6] = q[3];
     o[7] = vel.x; o[8] = vel.y; o[9] = vel.z; o[10] = V[l].a.x; o[11] = V[l].a.y; o[12] = V[l].a.z;
   });
-  float* o = out + ((size_t)e * BEZ_NBE + BEZ_NB) * 13;
+  if (!has_ball) return;
+  float* o = out + ((size_t)e * nbe + NB) * 13;
   o[0] = S.ball_pos.x; o[1] = S.ball_pos.y; o[2] = S.ball_pos.z;
   o[3] = S.bq[0]; o[4] = S.bq[1]; o[5] = S.bq[2]; o[6] = S.bq[3];
   o[7] = S.ball_lin.x; o[8] = S.ball_lin.y; o[9] = S.ball_lin.z; o[10] = S.ball_ang.x; o[11] = S.ball_ang.y; o[12] = S.ball_ang.z;
 }
 
 // gym.set_actor_root_state_tensor_indexed
-__global__ void set_root_indexed_kernel(float* __restrict__ st, const float* __restrict__ src, const int32_t* __restrict__ ids, int count, int n) {
+__global__ void set_root_indexed_kernel(float* __restrict__ st, const float* __restrict__ src, const int32_t* __restrict__ ids, int count, int n, int nact) {
   int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= count * 13) return;
   int a = ids[t / 13], k = t % 13;
-  if (a < 0 || a >= n * 2) return;
-  int e = a >> 1;
-  int f = (a & 1) ? (F_BALL_POS + k) : (F_ROOT_POS + k);
+  if (a < 0 || a >= n * nact) return;
+  int e = a / nact;
+  int f = (a % nact) ? (F_BALL_POS + k) : (F_ROOT_POS + k);
   st[(size_t)f * n + e] = src[(size_t)a * 13 + k];
 }
 // gym.set_dof_state_tensor_indexed (actor ids of robot actors: env*2)
-__global__ void set_dof_indexed_kernel(float* __restrict__ st, const float* __restrict__ src, const int32_t* __restrict__ ids, int count, int n) {
+__global__ void set_dof_indexed_kernel(float* __restrict__ st, const float* __restrict__ src, const int32_t* __restrict__ ids, int count, int n, int nact) {
   int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= count * BEZ_ND * 2) return;
   int a = ids[t / (BEZ_ND * 2)], k = t % (BEZ_ND * 2);
-  if (a < 0 || a >= n * 2 || (a & 1)) return;
-  int e = a >> 1, j = k >> 1;
+  if (a < 0 || a >= n * nact || (a % nact)) return;
+  int e = a / nact, j = k >> 1;
   st[(size_t)((k & 1) ? (F_QD + j) : (F_Q + j)) * n + e] = src[((size_t)e * BEZ_ND + j) * 2 + (k & 1)];
 }
-__global__ void set_target_indexed_kernel(float* __restrict__ st, const float* __restrict__ src, const int32_t* __restrict__ ids, int count, int n) {
+__global__ void set_target_indexed_kernel(float* __restrict__ st, const float* __restrict__ src, const int32_t* __restrict__ ids, int count, int n, int nact) {
   int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= count * BEZ_ND) return;
   int a = ids[t / BEZ_ND], j = t % BEZ_ND;
-  if (a < 0 || a >= n * 2 || (a & 1)) return;
-  int e = a >> 1;
+  if (a < 0 || a >= n * nact || (a % nact)) return;
+  int e = a / nact;
   st[(size_t)(F_TARGET + j) * n + e] = src[(size_t)e * BEZ_ND + j];
 }
 
@@ -260,15 +291,20 @@ __global__ void calib_write_kernel(float* __restrict__ out, size_t n) {
   for (; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = 1.0f;
 }
 
+// Kernel instantiations: the default asset keeps its DR-free specialisation (the benchmark path); the cleats asset is always
+// compiled with the per-env parameter loads (null pointers = defaults), which halves the number of variants to build.
 template <bool PRE, bool SIM, bool POST>
-int launch_step(BezSim* s, const float* actions, hipStream_t stream) {
+int launch_step(BezSim* s, const float* actions, hipStream_t stream, bool obs_only = false) {
   Params P = make_params(s, actions);
+  P.obs_only = obs_only ? 1 : 0;
+  if (POST && !obs_only) goal_draw(s->cfg.seed, s->post_calls++, 0, P.goal_draw);  // the reset inside this post_physics_step
   const bool dr = has_dr(s);
   if constexpr (SIM && PRE == POST) {
     if (use_ws_kernel()) {
       dim3 grid((s->n + WS_ENVS - 1) / WS_ENVS), block(WS_BLOCK);
-      if (dr) hipLaunchKernelGGL((step_kernel_ws<PRE, POST, true>), grid, block, 0, stream, P);
-      else hipLaunchKernelGGL((step_kernel_ws<PRE, POST, false>), grid, block, 0, stream, P);
+      if (s->cleats) hipLaunchKernelGGL((step_kernel_ws<PRE, POST, true, true>), grid, block, 0, stream, P);
+      else if (dr) hipLaunchKernelGGL((step_kernel_ws<PRE, POST, true, false>), grid, block, 0, stream, P);
+      else hipLaunchKernelGGL((step_kernel_ws<PRE, POST, false, false>), grid, block, 0, stream, P);
       hipError_t e = hipGetLastError();
       if (e != hipSuccess) return fail(s, -2, "step_kernel_ws launch", e);
       if (POST) s->obs_calls += 1;
@@ -276,8 +312,9 @@ int launch_step(BezSim* s, const float* actions, hipStream_t stream) {
     }
   }
   dim3 grid(grid_for(s->n)), block(BLOCK);
-  if (dr) hipLaunchKernelGGL((step_kernel<PRE, SIM, POST, true>), grid, block, 0, stream, P);
-  else hipLaunchKernelGGL((step_kernel<PRE, SIM, POST, false>), grid, block, 0, stream, P);
+  if (s->cleats) hipLaunchKernelGGL((step_kernel<PRE, SIM, POST, true, true>), grid, block, 0, stream, P);
+  else if (dr) hipLaunchKernelGGL((step_kernel<PRE, SIM, POST, true, false>), grid, block, 0, stream, P);
+  else hipLaunchKernelGGL((step_kernel<PRE, SIM, POST, false, false>), grid, block, 0, stream, P);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(s, -2, "step kernel launch", e);
   if (POST) s->obs_calls += 1;
@@ -319,7 +356,7 @@ int bez_sim_destroy(BezSim* s) {
   if (!s) return 0;
   (void)hipSetDevice(s->device);
   void* bufs[] = {s->state, s->obs, s->rew, s->reset, s->progress, s->timeout, s->episode, s->root_states, s->dof_state,
-                  s->rigid_body, s->contact, s->targets_aos, s->prev_aos, s->feet_aos};
+                  s->rigid_body, s->contact, s->targets_aos, s->prev_aos, s->feet_aos, s->goal_aos};
   for (void* b : bufs) if (b) (void)hipFree(b);
   for (int i = 0; i < BEZ_PARAM_COUNT; ++i) if (s->dr[i]) (void)hipFree(s->dr[i]);
   if (s->ev0) (void)hipEventDestroy(s->ev0);
@@ -343,15 +380,23 @@ int bez_sim_create(const BezSimConfig* cfg, int device_id, BezSim** out) {
   BezSim* s = new (std::nothrow) BezSim();
   if (!s) return fail(nullptr, -4, "out of host memory");
   s->cfg = *cfg; s->device = device_id; s->n = cfg->num_envs;
+  if (cfg->task < BEZ_TASK_KICK || cfg->task > BEZ_TASK_ORIENT) { delete s; return fail(nullptr, -1, "bez_sim_create: unknown task"); }
+  s->cleats = (cfg->flags & BEZ_FLAG_CLEATS) != 0;
+  s->has_ball = cfg->task == BEZ_TASK_KICK;                    // walk_env.py / orient_env.py create no ball actor
+  s->nb = s->cleats ? BEZ_NB_CL : BEZ_NB;
+  s->nbe = s->nb + (s->has_ball ? 1 : 0);
+  s->nact = s->has_ball ? 2 : 1;
+  s->nobs = s->has_ball ? BEZ_NUM_OBS : BEZ_NUM_OBS_WALK;      // walk_env.py:104
+  if (!s->has_ball) { s->cfg.ball_init[0] = 1000.0f; s->cfg.ball_init[1] = 0.0f; s->cfg.ball_init[2] = (float)BEZ_BALL_RADIUS; }  // parked out of reach
   const size_t n = (size_t)s->n;
   struct { void** p; size_t bytes; } allocs[] = {
       {(void**)&s->state, n * F_COUNT * sizeof(float)}, {(void**)&s->obs, n * BEZ_NUM_OBS * sizeof(float)},
       {(void**)&s->rew, n * sizeof(float)}, {(void**)&s->reset, n * sizeof(int64_t)}, {(void**)&s->progress, n * sizeof(int64_t)},
       {(void**)&s->timeout, n * sizeof(int64_t)}, {(void**)&s->episode, n * sizeof(uint32_t)},
       {(void**)&s->root_states, n * 26 * sizeof(float)}, {(void**)&s->dof_state, n * BEZ_ND * 2 * sizeof(float)},
-      {(void**)&s->rigid_body, n * BEZ_NBE * 13 * sizeof(float)}, {(void**)&s->contact, n * BEZ_NBE * 3 * sizeof(float)},
+      {(void**)&s->rigid_body, n * BEZ_NBE_MAX * 13 * sizeof(float)}, {(void**)&s->contact, n * BEZ_NBE_MAX * 3 * sizeof(float)},
       {(void**)&s->targets_aos, n * BEZ_ND * sizeof(float)}, {(void**)&s->prev_aos, n * 3 * sizeof(float)},
-      {(void**)&s->feet_aos, n * 8 * sizeof(float)}};
+      {(void**)&s->feet_aos, n * 8 * sizeof(float)}, {(void**)&s->goal_aos, n * 2 * sizeof(float)}};
   for (auto& a : allocs) {
     e = hipMalloc(a.p, a.bytes);
     if (e == hipSuccess) e = hipMemset(*a.p, 0, a.bytes);
@@ -361,7 +406,8 @@ int bez_sim_create(const BezSimConfig* cfg, int device_id, BezSim** out) {
   (void)hipEventCreate(&s->ev1);
   // state after KickEnv.__init__: allocate_buffers (vec_task.py:226-249) then reset_idx(all) (kick_env.py:238)
   Params P = make_params(s, nullptr);
-  hipLaunchKernelGGL(init_misc_kernel, dim3((s->n + TB - 1) / TB), dim3(TB), 0, 0, s->state, s->n);
+  goal_draw(s->cfg.seed, s->reset_calls++, 1, P.goal_draw);  // the reset_idx(all) that ends Kick/Walk/OrientEnv.__init__
+  hipLaunchKernelGGL(init_misc_kernel, dim3((s->n + TB - 1) / TB), dim3(TB), 0, 0, s->state, s->n, s->cfg.goal[0], s->cfg.goal[1]);
   hipLaunchKernelGGL(reset_kernel, dim3((s->n + TB - 1) / TB), dim3(TB), 0, 0, P, (const int32_t*)nullptr, s->n);
   e = hipDeviceSynchronize();
   if (e != hipSuccess) { int rc = fail(nullptr, -2, "init kernels", e); bez_sim_destroy(s); return rc; }
@@ -374,11 +420,11 @@ int bez_sim_get_tensor(BezSim* s, int which, void** dev_ptr, int64_t shape[3], i
   const int64_t n = s->n;
   *dtype = BEZ_DTYPE_F32;
   switch (which) {
-    case BEZ_TENSOR_ROOT_STATE: *dev_ptr = s->root_states; shape[0] = n * 2; shape[1] = 13; *ndim = 2; break;
+    case BEZ_TENSOR_ROOT_STATE: *dev_ptr = s->root_states; shape[0] = n * s->nact; shape[1] = 13; *ndim = 2; break;
     case BEZ_TENSOR_DOF_STATE: *dev_ptr = s->dof_state; shape[0] = n * BEZ_ND; shape[1] = 2; *ndim = 2; break;
-    case BEZ_TENSOR_RIGID_BODY_STATE: *dev_ptr = s->rigid_body; shape[0] = n * BEZ_NBE; shape[1] = 13; *ndim = 2; break;
-    case BEZ_TENSOR_NET_CONTACT_FORCE: *dev_ptr = s->contact; shape[0] = n * BEZ_NBE; shape[1] = 3; *ndim = 2; break;
-    case BEZ_TENSOR_OBS: *dev_ptr = s->obs; shape[0] = n; shape[1] = BEZ_NUM_OBS; *ndim = 2; break;
+    case BEZ_TENSOR_RIGID_BODY_STATE: *dev_ptr = s->rigid_body; shape[0] = n * s->nbe; shape[1] = 13; *ndim = 2; break;
+    case BEZ_TENSOR_NET_CONTACT_FORCE: *dev_ptr = s->contact; shape[0] = n * s->nbe; shape[1] = 3; *ndim = 2; break;
+    case BEZ_TENSOR_OBS: *dev_ptr = s->obs; shape[0] = n; shape[1] = s->nobs; *ndim = 2; break;
     case BEZ_TENSOR_REW: *dev_ptr = s->rew; shape[0] = n; *ndim = 1; break;
     case BEZ_TENSOR_RESET: *dev_ptr = s->reset; shape[0] = n; *ndim = 1; *dtype = BEZ_DTYPE_I64; break;
     case BEZ_TENSOR_PROGRESS: *dev_ptr = s->progress; shape[0] = n; *ndim = 1; *dtype = BEZ_DTYPE_I64; break;
@@ -386,6 +432,7 @@ int bez_sim_get_tensor(BezSim* s, int which, void** dev_ptr, int64_t shape[3], i
     case BEZ_TENSOR_DOF_TARGET: *dev_ptr = s->targets_aos; shape[0] = n; shape[1] = BEZ_ND; *ndim = 2; break;
     case BEZ_TENSOR_PREV_LIN_VEL: *dev_ptr = s->prev_aos; shape[0] = n; shape[1] = 3; *ndim = 2; break;
     case BEZ_TENSOR_FEET: *dev_ptr = s->feet_aos; shape[0] = n; shape[1] = 8; *ndim = 2; break;
+    case BEZ_TENSOR_GOAL: *dev_ptr = s->goal_aos; shape[0] = n; shape[1] = 2; *ndim = 2; break;
     default: return fail(s, -1, "bez_sim_get_tensor: unknown tensor id");
   }
   return 0;
@@ -397,13 +444,17 @@ int bez_sim_refresh_tensor(BezSim* s, int which, void* stream_) {
   const int n = s->n;
   auto blocks = [](size_t total) { return dim3((unsigned)((total + TB - 1) / TB)); };
   switch (which) {
-    case BEZ_TENSOR_ROOT_STATE: hipLaunchKernelGGL(refresh_root_kernel, blocks((size_t)n * 26), dim3(TB), 0, stream, s->state, s->root_states, n); break;
+    case BEZ_TENSOR_ROOT_STATE: hipLaunchKernelGGL(refresh_root_kernel, blocks((size_t)n * 13 * s->nact), dim3(TB), 0, stream, s->state, s->root_states, n, s->nact); break;
     case BEZ_TENSOR_DOF_STATE: hipLaunchKernelGGL(refresh_dof_kernel, blocks((size_t)n * BEZ_ND * 2), dim3(TB), 0, stream, s->state, s->dof_state, n); break;
-    case BEZ_TENSOR_RIGID_BODY_STATE: hipLaunchKernelGGL(refresh_rigid_body_kernel, dim3((n + 63) / 64), dim3(64), 0, stream, s->state, s->rigid_body, n); break;
-    case BEZ_TENSOR_NET_CONTACT_FORCE: hipLaunchKernelGGL(refresh_rows_kernel, blocks((size_t)n * BEZ_NBE * 3), dim3(TB), 0, stream, s->state, s->contact, n, (int)F_CF, BEZ_NBE * 3); break;
+    case BEZ_TENSOR_RIGID_BODY_STATE:
+      if (s->cleats) hipLaunchKernelGGL(refresh_rigid_body_kernel<true>, dim3((n + 63) / 64), dim3(64), 0, stream, s->state, s->rigid_body, n, (int)s->has_ball);
+      else hipLaunchKernelGGL(refresh_rigid_body_kernel<false>, dim3((n + 63) / 64), dim3(64), 0, stream, s->state, s->rigid_body, n, (int)s->has_ball);
+      break;
+    case BEZ_TENSOR_NET_CONTACT_FORCE: hipLaunchKernelGGL(refresh_rows_kernel, blocks((size_t)n * s->nbe * 3), dim3(TB), 0, stream, s->state, s->contact, n, (int)F_CF, s->nbe * 3); break;
     case BEZ_TENSOR_DOF_TARGET: hipLaunchKernelGGL(refresh_rows_kernel, blocks((size_t)n * BEZ_ND), dim3(TB), 0, stream, s->state, s->targets_aos, n, (int)F_TARGET, BEZ_ND); break;
     case BEZ_TENSOR_PREV_LIN_VEL: hipLaunchKernelGGL(refresh_rows_kernel, blocks((size_t)n * 3), dim3(TB), 0, stream, s->state, s->prev_aos, n, (int)F_PREV, 3); break;
     case BEZ_TENSOR_FEET: hipLaunchKernelGGL(refresh_rows_kernel, blocks((size_t)n * 8), dim3(TB), 0, stream, s->state, s->feet_aos, n, (int)F_FEET, 8); break;
+    case BEZ_TENSOR_GOAL: hipLaunchKernelGGL(refresh_rows_kernel, blocks((size_t)n * 2), dim3(TB), 0, stream, s->state, s->goal_aos, n, (int)F_GOAL, 2); break;
     case BEZ_TENSOR_OBS: case BEZ_TENSOR_REW: case BEZ_TENSOR_RESET: case BEZ_TENSOR_PROGRESS: case BEZ_TENSOR_TIMEOUT: break;  // always live
     default: return fail(s, -1, "bez_sim_refresh_tensor: unknown tensor id");
   }
@@ -415,14 +466,14 @@ int bez_sim_refresh_tensor(BezSim* s, int which, void* stream_) {
 int bez_sim_set_actor_root_state_tensor_indexed(BezSim* s, const float* root_states_dev, const int32_t* ids, int32_t count, void* stream) {
   if (!s || !root_states_dev || (!ids && count > 0) || count < 0) return fail(s, -1, "set_actor_root_state_tensor_indexed: bad argument");
   if (count == 0) return 0;
-  hipLaunchKernelGGL(set_root_indexed_kernel, dim3(((size_t)count * 13 + TB - 1) / TB), dim3(TB), 0, (hipStream_t)stream, s->state, root_states_dev, ids, count, s->n);
+  hipLaunchKernelGGL(set_root_indexed_kernel, dim3(((size_t)count * 13 + TB - 1) / TB), dim3(TB), 0, (hipStream_t)stream, s->state, root_states_dev, ids, count, s->n, s->nact);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : fail(s, -2, "set_root_indexed launch", e);
 }
 int bez_sim_set_dof_state_tensor_indexed(BezSim* s, const float* dof_state_dev, const int32_t* ids, int32_t count, void* stream) {
   if (!s || !dof_state_dev || (!ids && count > 0) || count < 0) return fail(s, -1, "set_dof_state_tensor_indexed: bad argument");
   if (count == 0) return 0;
-  hipLaunchKernelGGL(set_dof_indexed_kernel, dim3(((size_t)count * BEZ_ND * 2 + TB - 1) / TB), dim3(TB), 0, (hipStream_t)stream, s->state, dof_state_dev, ids, count, s->n);
+  hipLaunchKernelGGL(set_dof_indexed_kernel, dim3(((size_t)count * BEZ_ND * 2 + TB - 1) / TB), dim3(TB), 0, (hipStream_t)stream, s->state, dof_state_dev, ids, count, s->n, s->nact);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : fail(s, -2, "set_dof_indexed launch", e);
 }
@@ -435,13 +486,13 @@ int bez_sim_set_dof_position_target_tensor(BezSim* s, const float* targets_dev, 
 int bez_sim_set_dof_position_target_tensor_indexed(BezSim* s, const float* targets_dev, const int32_t* ids, int32_t count, void* stream) {
   if (!s || !targets_dev || (!ids && count > 0) || count < 0) return fail(s, -1, "set_dof_position_target_tensor_indexed: bad argument");
   if (count == 0) return 0;
-  hipLaunchKernelGGL(set_target_indexed_kernel, dim3(((size_t)count * BEZ_ND + TB - 1) / TB), dim3(TB), 0, (hipStream_t)stream, s->state, targets_dev, ids, count, s->n);
+  hipLaunchKernelGGL(set_target_indexed_kernel, dim3(((size_t)count * BEZ_ND + TB - 1) / TB), dim3(TB), 0, (hipStream_t)stream, s->state, targets_dev, ids, count, s->n, s->nact);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : fail(s, -2, "set_target_indexed launch", e);
 }
 int bez_sim_set_net_contact_force_tensor(BezSim* s, const float* forces_dev, void* stream) {
   if (!s || !forces_dev) return fail(s, -1, "set_net_contact_force_tensor: bad argument");
-  hipLaunchKernelGGL(scatter_rows_kernel, dim3(((size_t)s->n * BEZ_NBE * 3 + TB - 1) / TB), dim3(TB), 0, (hipStream_t)stream, s->state, forces_dev, s->n, (int)F_CF, BEZ_NBE * 3);
+  hipLaunchKernelGGL(scatter_rows_kernel, dim3(((size_t)s->n * s->nbe * 3 + TB - 1) / TB), dim3(TB), 0, (hipStream_t)stream, s->state, forces_dev, s->n, (int)F_CF, s->nbe * 3);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : fail(s, -2, "set_contact launch", e);
 }
@@ -470,13 +521,14 @@ int bez_sim_post_physics(BezSim* s, void* stream) {
 /* test hook: compute_observations + compute_reward only (no timeout/progress/reset bookkeeping) */
 int bez_sim_observe_reward(BezSim* s, void* stream) {
   if (!s) return -1;
-  Params P = make_params(s, nullptr);
-  P.obs_only = 1;
-  hipLaunchKernelGGL((step_kernel<false, false, true, false>), dim3(grid_for(s->n)), dim3(BLOCK), 0, (hipStream_t)stream, P);
+  return launch_step<false, false, true>(s, nullptr, (hipStream_t)stream, /*obs_only=*/true);
+}
+/* (N,2) per-env goal of bez_walk (test hook; walk_env.py:143,570-575) */
+int bez_sim_set_goal_tensor(BezSim* s, const float* goal_dev, void* stream) {
+  if (!s || !goal_dev) return fail(s, -1, "set_goal_tensor: bad argument");
+  hipLaunchKernelGGL(scatter_rows_kernel, dim3(((size_t)s->n * 2 + TB - 1) / TB), dim3(TB), 0, (hipStream_t)stream, s->state, goal_dev, s->n, (int)F_GOAL, 2);
   hipError_t e = hipGetLastError();
-  if (e != hipSuccess) return fail(s, -2, "observe kernel launch", e);
-  s->obs_calls += 1;
-  return 0;
+  return e == hipSuccess ? 0 : fail(s, -2, "set_goal launch", e);
 }
 int bez_sim_step(BezSim* s, const float* actions_dev, void* stream) {
   if (!s || !actions_dev) return fail(s, -1, "bez_sim_step: bad argument");
@@ -508,6 +560,7 @@ int bez_sim_reset_indexed(BezSim* s, const int32_t* env_ids_dev, int32_t count, 
   if (!s || (!env_ids_dev && count > 0) || count < 0) return fail(s, -1, "bez_sim_reset_indexed: bad argument");
   if (count == 0) return 0;
   Params P = make_params(s, nullptr);
+  goal_draw(s->cfg.seed, s->reset_calls++, 1, P.goal_draw);
   hipLaunchKernelGGL(reset_kernel, dim3((count + TB - 1) / TB), dim3(TB), 0, (hipStream_t)stream, P, env_ids_dev, count);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : fail(s, -2, "reset launch", e);

@@ -108,8 +108,8 @@ def merge_inertia(m1, c1, I1, m2, c2, I2):
     return m, c, shift(m1, c1, I1) + shift(m2, c2, I2)
 
 
-def build():
-    links, joints = parse_urdf(URDF_BEZ)
+def build(urdf=None, cleats=False):
+    links, joints = parse_urdf(urdf or URDF_BEZ)
     ball_links, _ = parse_urdf(URDF_BALL)
     cfg = yaml.safe_load(open(YAML_TASK))
     env = cfg["env"]
@@ -129,9 +129,13 @@ def build():
         for j in sorted(children.get(name, []), key=lambda jj: jj["name"]):
             dfs(j["child"], idx, j)
     dfs("/torso", -1, None)
-    assert len(bodies) == 21
     names = [b["name"] for b in bodies]
-    assert names[1] == "/imu_link" and names[12] == "/left_foot" and names[20] == "/right_foot", names
+    if cleats:  # kick_env.py:187-191: contact rows 13:17 are the left cleats, 25:29 the right ones
+        assert len(bodies) == 29 and names[12] == "/left_foot" and names[24] == "/right_foot", names
+        assert names[13:17] == ["/left_foot_cleat_%d" % i for i in (4, 5, 6, 7)] and names[25:29] == ["/right_foot_cleat_%d" % i for i in range(4)]
+    else:
+        assert len(bodies) == 21
+        assert names[1] == "/imu_link" and names[12] == "/left_foot" and names[20] == "/right_foot", names
 
     # dynamic links: root + revolute children; fixed children merged into parent link
     link_of_body = [None] * len(bodies)
@@ -185,7 +189,7 @@ def build():
     # collision boxes used for ball contact: foot, ankle, calve, thigh, hip_front per leg (+ the torso box, appended below)
     boxes = []
     for li, d in enumerate(dyn):
-        if d["box"] is not None and min(d["box"]["half"]) > 1e-3:
+        if d["box"] is not None and min(d["box"]["half"]) > 1e-3 and "cleat" not in d["name"]:
             boxes.append({"link": li, "center": d["box"]["center"], "half": d["box"]["half"]})
     # ball <-> torso: the torso collision mesh is approximated by its bounding box (same vertex data as the guard points below)
     boxes.append({"link": 0, "center": [0.012, 0.0, -0.033], "half": [0.052, 0.0725, 0.095]})
@@ -199,11 +203,20 @@ def build():
         li = [i for i, d in enumerate(dyn) if d["name"] == link_name][0]
         points.append({"link": li, "p": [float(x) for x in p], "kind": kind})
     for side in ("left", "right"):
-        fb = links["/%s_foot" % side]["box"]
-        c, h = fb["center"], fb["half"]
-        for sx in (+1, -1):
-            for sy in (+1, -1):
-                add("/%s_foot" % side, [c[0] + sx * h[0], c[1] + sy * h[1], c[2] - h[2]], "foot")
+        if cleats:
+            # the four cleats of a foot (1 cm x 1 cm x 2 mm boxes, 2 mm proud of the foot plate) carry the ground contact:
+            # one point at the bottom centre of each, reported in the cleat body's own contact row
+            for bi, b in enumerate(bodies):
+                if b["name"].startswith("/%s_foot_cleat" % side):
+                    cb = links[b["name"]]["box"]
+                    add("/%s_foot" % side, [cb["center"][0], cb["center"][1], cb["center"][2] - cb["half"][2]], "cleat")
+                    points[-1]["body"] = bi
+        else:
+            fb = links["/%s_foot" % side]["box"]
+            c, h = fb["center"], fb["half"]
+            for sx in (+1, -1):
+                for sy in (+1, -1):
+                    add("/%s_foot" % side, [c[0] + sx * h[0], c[1] + sy * h[1], c[2] - h[2]], "foot")
     for sx in (-0.040, 0.064):
         for sy in (-0.0725, 0.0725):
             for sz in (-0.128, 0.062):
@@ -251,8 +264,10 @@ def build():
                 cap_pairs.append([i, j])
 
     ball = ball_links["base_link"]
+    for pt in points:
+        pt.setdefault("body", dyn[pt["link"]]["body"])
     model = {
-        "num_bodies": 21, "num_links": 19, "num_dofs": 18,
+        "num_bodies": len(bodies), "num_links": 19, "num_dofs": 18,
         "body_names": names, "dof_names": dof_names,
         "body_link": link_of_body, "body_offset": body_off,
         "links": [{
@@ -290,7 +305,7 @@ def arr(vals):
     return "{" + ", ".join(fmt(v) for v in vals) + "}"
 
 
-def emit_header(m):
+def emit_header(m, mc=None):
     L = m["links"]
     o = []
     o.append("/* GENERATED by bez_isaacgym_amd/model/compile_model.py -- do not edit.\n"
@@ -332,6 +347,25 @@ def emit_header(m):
     o.append("/* ground contact points (link-local), only on the torso and on chain-end links; the first 8 are the foot-box bottom corners (4 left, 4 right) */")
     o.append("BEZ_TBL int BEZ_PT_LINK[BEZ_NPT] = {%s};" % ", ".join(str(p["link"]) for p in m["ground_points"]))
     o.append("BEZ_TBL double BEZ_PT_POS[BEZ_NPT][3] = {%s};" % ", ".join(arr(p["p"]) for p in m["ground_points"]))
+    o.append("/* body whose NET_CONTACT_FORCE row reports the point */")
+    o.append("BEZ_TBL int BEZ_PT_BODY[BEZ_NPT] = {%s};" % ", ".join(str(p["body"]) for p in m["ground_points"]))
+    if mc is not None:
+        LC = mc["links"]
+        assert len(mc["ground_points"]) == len(m["ground_points"]) and [p["link"] for p in mc["ground_points"]] == [p["link"] for p in m["ground_points"]]
+        assert [l["parent"] for l in LC] == [l["parent"] for l in L] and [l["xyz"] for l in LC] == [l["xyz"] for l in L]
+        o.append("/* ---- cleats variant (asset.cleats: True -> soccerbot_stl_sensor.urdf, kick_env.py:267-276): 8 cleat bodies fixed to the\n"
+                 " * feet (29 robot bodies; contact rows 13:17 / 25:29, kick_env.py:187-191); same tree, the cleats' mass is merged into\n"
+                 " * the feet, and the foot ground points are the cleats' bottom centres. */")
+        o.append("#define BEZ_NB_CL %d\n#define BEZ_NBE_CL %d\n#define BEZ_NBE_MAX %d" % (mc["num_bodies"], mc["num_bodies"] + 1, mc["num_bodies"] + 1))
+        o.append("#define BEZ_LFOOT_BODY_CL 12\n#define BEZ_RFOOT_BODY_CL 24\n#define BEZ_LCLEAT_BODY_CL 13\n#define BEZ_RCLEAT_BODY_CL 25")
+        o.append("BEZ_TBL int BEZ_LINK_BODY_CL[BEZ_NL] = {%s};" % ", ".join(str(l["body"]) for l in LC))
+        o.append("BEZ_TBL double BEZ_LINK_MASS_CL[BEZ_NL] = %s;" % arr(l["mass"] for l in LC))
+        o.append("BEZ_TBL double BEZ_LINK_COM_CL[BEZ_NL][3] = {%s};" % ", ".join(arr(l["com"]) for l in LC))
+        o.append("BEZ_TBL double BEZ_LINK_INERTIA_CL[BEZ_NL][6] = {%s};" % ", ".join(arr(l["inertia"]) for l in LC))
+        o.append("BEZ_TBL int BEZ_BODY_LINK_CL[BEZ_NB_CL] = {%s};" % ", ".join(str(x) for x in mc["body_link"]))
+        o.append("BEZ_TBL double BEZ_BODY_OFFSET_CL[BEZ_NB_CL][3] = {%s};" % ", ".join(arr(x) for x in mc["body_offset"]))
+        o.append("BEZ_TBL double BEZ_PT_POS_CL[BEZ_NPT][3] = {%s};" % ", ".join(arr(p["p"]) for p in mc["ground_points"]))
+        o.append("BEZ_TBL int BEZ_PT_BODY_CL[BEZ_NPT] = {%s};" % ", ".join(str(p["body"]) for p in mc["ground_points"]))
     o.append("/* leg self-collision capsules (link-local segment p0-p1, radius) and the left x right pair list */")
     o.append("#define BEZ_NCAP %d\n#define BEZ_NCPAIR %d" % (len(m["capsules"]), len(m["capsule_pairs"])))
     o.append("BEZ_TBL int BEZ_CAP_LINK[BEZ_NCAP] = {%s};" % ", ".join(str(c["link"]) for c in m["capsules"]))
@@ -357,10 +391,12 @@ def emit_header(m):
 
 def main():
     m = build()
+    mc = build(os.path.join(REF, "resources/assets/bez/model/soccerbot_stl_sensor.urdf"), cleats=True)
+    m["cleats"] = {k: mc[k] for k in ("num_bodies", "body_names", "body_link", "body_offset", "links", "ground_points", "total_mass")}
     with open(OUT_JSON, "w") as f:
         json.dump(m, f, indent=1)
     with open(OUT_H, "w") as f:
-        f.write(emit_header(m))
+        f.write(emit_header(m, mc))
     print("links:")
     for i, l in enumerate(m["links"]):
         print(i, l["name"], "parent", l["parent"], "axis", l["axis"], "xyz", l["xyz"], "m=%.6f" % l["mass"])

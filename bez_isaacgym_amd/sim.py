@@ -40,6 +40,7 @@ def load_library():
         "bez_sim_set_dof_position_target_tensor_indexed": (C.c_int, [vp, fp, vp, i32, vp]),
         "bez_sim_set_net_contact_force_tensor": (C.c_int, [vp, fp, vp]),
         "bez_sim_set_prev_lin_vel_tensor": (C.c_int, [vp, fp, vp]),
+        "bez_sim_set_goal_tensor": (C.c_int, [vp, fp, vp]),
         "bez_sim_set_flags": (C.c_int, [vp, u32]),
         "bez_sim_set_obs_calls": (C.c_int, [vp, i64]),
         "bez_sim_pre_physics": (C.c_int, [vp, fp, vp]),
@@ -64,7 +65,7 @@ def load_library():
 EXPORTS = ["bez_sim_default_config", "bez_sim_create", "bez_sim_destroy", "bez_sim_last_error", "bez_sim_get_tensor",
            "bez_sim_refresh_tensor", "bez_sim_set_actor_root_state_tensor_indexed", "bez_sim_set_dof_state_tensor_indexed",
            "bez_sim_set_dof_position_target_tensor", "bez_sim_set_dof_position_target_tensor_indexed",
-           "bez_sim_set_net_contact_force_tensor", "bez_sim_set_prev_lin_vel_tensor", "bez_sim_set_flags",
+           "bez_sim_set_net_contact_force_tensor", "bez_sim_set_prev_lin_vel_tensor", "bez_sim_set_goal_tensor", "bez_sim_set_flags",
            "bez_sim_set_obs_calls", "bez_sim_pre_physics", "bez_sim_simulate", "bez_sim_post_physics", "bez_sim_observe_reward", "bez_sim_step",
            "bez_sim_step_many", "bez_sim_reset_indexed", "bez_sim_set_env_params", "bez_sim_seed", "bez_sim_time_steps",
            "bez_sim_calibrate"]
@@ -91,6 +92,10 @@ class BezSim:
         self.device_id = int(device_id)
         self.device = torch.device("cuda", self.device_id)
         self.num_envs = int(cfg.num_envs)
+        self.has_ball = int(cfg.task) == abi.TASK_KICK
+        self.num_actors = 2 if self.has_ball else 1
+        self.num_bodies = (29 if int(cfg.flags) & abi.FLAG_CLEATS else 21) + (1 if self.has_ball else 0)
+        self.num_obs = 54 if self.has_ball else 52
         h = C.c_void_p()
         rc = self.lib.bez_sim_create(C.byref(cfg), self.device_id, C.byref(h))
         if rc != 0:
@@ -145,7 +150,7 @@ class BezSim:
     # ---- gym.set_* equivalents
     def set_actor_root_state_tensor_indexed(self, root_states, actor_ids):
         self._check(self.lib.bez_sim_set_actor_root_state_tensor_indexed(
-            self.h, self._ptr(root_states, torch.float32, self.num_envs * 26), self._ptr(actor_ids, torch.int32),
+            self.h, self._ptr(root_states, torch.float32, self.num_envs * 13 * self.num_actors), self._ptr(actor_ids, torch.int32),
             actor_ids.numel(), self._stream()))
 
     def set_dof_state_tensor_indexed(self, dof_state, actor_ids):
@@ -164,10 +169,13 @@ class BezSim:
 
     def set_net_contact_force_tensor(self, forces):
         self._check(self.lib.bez_sim_set_net_contact_force_tensor(
-            self.h, self._ptr(forces, torch.float32, self.num_envs * 66), self._stream()))
+            self.h, self._ptr(forces, torch.float32, self.num_envs * self.num_bodies * 3), self._stream()))
 
     def set_prev_lin_vel_tensor(self, prev):
         self._check(self.lib.bez_sim_set_prev_lin_vel_tensor(self.h, self._ptr(prev, torch.float32, self.num_envs * 3), self._stream()))
+
+    def set_goal_tensor(self, goal):
+        self._check(self.lib.bez_sim_set_goal_tensor(self.h, self._ptr(goal, torch.float32, self.num_envs * 2), self._stream()))
 
     def set_flags(self, flags):
         self._check(self.lib.bez_sim_set_flags(self.h, int(flags)))

@@ -43,6 +43,10 @@ _MODEL = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)),
 
 
 class KickEnv(VecTask):
+    """bez_kick.  WalkEnv / OrientEnv (tasks/walk_env.py, tasks/orient_env.py) derive from it: same robot, same tensor API,
+    no ball actor, 52 observations, their own reward / reset logic inside the kernel (BezSimConfig.task)."""
+    TASK = "bez_kick"
+    HAS_BALL = True
 
     def __init__(self, cfg, sim_device, graphics_device_id, headless):
         self.cfg = cfg
@@ -54,19 +58,21 @@ class KickEnv(VecTask):
         self.plane_restitution = env["plane"]["restitution"]
         self.bez_init_state = env["bezInitState"]["pos"] + env["bezInitState"]["rot"] + \
             env["bezInitState"]["vLinear"] + env["bezInitState"]["vAngular"]
-        self.ball_init_state = env["ballInitState"]["pos"] + env["ballInitState"]["rot"] + \
-            env["ballInitState"]["vLinear"] + env["ballInitState"]["vAngular"]
+        if self.HAS_BALL:
+            self.ball_init_state = env["ballInitState"]["pos"] + env["ballInitState"]["rot"] + \
+                env["ballInitState"]["vLinear"] + env["ballInitState"]["vAngular"]
         goal = env["goalState"]["goal"]
-        self.cleats = env["asset"]["cleats"]
-        if self.cleats or not env["asset"]["stl"]:
-            raise NotImplementedError("only the default asset (stl: True, cleats: False -> soccerbot_stl.urdf) is compiled "
-                                      "into the kernels; the cleats/box variants are listed as 'next' in DESIGN.md")
+        self.cleats = bool(env["asset"]["cleats"])  # True -> soccerbot_stl_sensor.urdf: 29 bodies, per-cleat contact rows
+        if not env["asset"]["stl"]:
+            raise NotImplementedError("asset.stl: False selects the soccerbot_box*.urdf collision variants, which are not "
+                                      "compiled into the kernels (the stl assets with and without cleats are)")
         self.debug_rewards = env["debug"]["rewards"]
         self.named_default_joint_angles = env["readyJointAngles"]
         self.max_episode_length_s = env["learn"]["episodeLength_s"]
         self.Kp = env["control"]["stiffness"]
         self.Kd = env["control"]["damping"]
-        self.orn_dim, self.imu_dim, self.feet_dim, self.dof_dim, self.rnn_dim, self.ball_dim = 2, 6, 8, 18, 1, 2
+        self.orn_dim, self.imu_dim, self.feet_dim, self.dof_dim, self.rnn_dim = 2, 6, 8, 18, 1
+        self.ball_dim = 2 if self.HAS_BALL else 0
         self.imu_max_ang_vel = 8.7266
         self.imu_max_lin_acc = 2. * 9.81
         self.MX_28_velocity = 2 * np.pi
@@ -80,11 +86,13 @@ class KickEnv(VecTask):
         self.max_episode_length = int(self.max_episode_length_s / self.dt + 0.5)
         dev = self.device
         n = self.num_envs
-        self.goal = torch.tensor([goal], device=dev, dtype=torch.float32).repeat((n, 1))
+        self._goal_cfg = torch.tensor([goal], device=dev, dtype=torch.float32).repeat((n, 1))
         self.bez_init_xy = torch.tensor(self.bez_init_state[0:2], device=dev, dtype=torch.float32)
-        self.ball_init = torch.tensor([self.ball_init_state[0:2]], device=dev, dtype=torch.float32).repeat((n, 1))
-        self.initial_root_states = torch.tensor([self.bez_init_state, self.ball_init_state], device=dev,
-                                                dtype=torch.float32).repeat((n, 1))
+        actors = [self.bez_init_state]
+        if self.HAS_BALL:
+            self.ball_init = torch.tensor([self.ball_init_state[0:2]], device=dev, dtype=torch.float32).repeat((n, 1))
+            actors.append(self.ball_init_state)
+        self.initial_root_states = torch.tensor(actors, device=dev, dtype=torch.float32).repeat((n, 1))
         self.initial_root_states[:, 7:13] = 0
         self.default_dof_pos = torch.tensor(_MODEL["dof_default"], device=dev, dtype=torch.float32).repeat((n, 1))
         for i, name in enumerate(self.dof_names):
@@ -102,15 +110,17 @@ class KickEnv(VecTask):
         rank_offset = int(self.cfg.get("env_id_offset", 0))
         seed = int(self.cfg.get("seed", 42))
         sim_cfg = abi.config_from_task_cfg(self.cfg, seed=seed, env_id_offset=rank_offset,
-                                           strict_reference_quirks=self.strict_reference_quirks)
+                                           strict_reference_quirks=self.strict_reference_quirks, task=self.TASK)
         self.sim_cfg = sim_cfg
         self.sim = BezSim(sim_cfg, self.device_id)
         self.num_dof = 18
-        self.num_bodies = 21
-        self.num_joints = 20
+        self.num_bodies = 29 if self.cleats else 21
+        self.num_joints = self.num_bodies - 1
         self.dof_names = list(_MODEL["dof_names"])
-        self.bez_indices = torch.arange(0, self.num_envs * 2, 2, device=self.device, dtype=torch.long)
-        self.ball_indices = self.bez_indices + 1
+        na = self.sim.num_actors
+        self.bez_indices = torch.arange(0, self.num_envs * na, na, device=self.device, dtype=torch.long)
+        if self.HAS_BALL:
+            self.ball_indices = self.bez_indices + 1
         self.dof_pos_limits_lower = torch.tensor(_MODEL["dof_lower"], device=self.device, dtype=torch.float32)
         self.dof_pos_limits_upper = torch.tensor(_MODEL["dof_upper"], device=self.device, dtype=torch.float32)
         self.dof_vel_limits_upper = torch.full((18, 1), self.MX_28_velocity, device=self.device)
@@ -144,15 +154,23 @@ class KickEnv(VecTask):
 
     dof_pos_bez = property(lambda s: s.dof_state.view(s.num_envs, 18, 2)[..., 0])
     dof_vel_bez = property(lambda s: s.dof_state.view(s.num_envs, 18, 2)[..., 1])
-    root_pos_bez = property(lambda s: s.root_states.view(s.num_envs, 2, 13)[..., 0, 0:3])
-    root_orient_bez = property(lambda s: s.rigid_body.view(s.num_envs, 22, 13)[..., 1, 3:7])
-    root_vel_bez = property(lambda s: s.rigid_body.view(s.num_envs, 22, 13)[..., 1, 7:10])
-    root_ang_bez = property(lambda s: s.rigid_body.view(s.num_envs, 22, 13)[..., 1, 10:13])
-    root_pos_ball = property(lambda s: s.root_states.view(s.num_envs, 2, 13)[..., 1, 0:3])
-    root_orient_ball = property(lambda s: s.root_states.view(s.num_envs, 2, 13)[..., 1, 3:7])
-    root_vel_ball = property(lambda s: s.root_states.view(s.num_envs, 2, 13)[..., 1, 7:10])
-    left_foot_contact_forces = property(lambda s: s.net_contact_forces.view(s.num_envs, 22, 3)[..., 12, 0:3])
-    right_foot_contact_forces = property(lambda s: s.net_contact_forces.view(s.num_envs, 22, 3)[..., 20, 0:3])
+    root_pos_bez = property(lambda s: s.root_states.view(s.num_envs, -1, 13)[..., 0, 0:3])
+    root_orient_bez = property(lambda s: s.rigid_body.view(s.num_envs, -1, 13)[..., 1, 3:7])
+    root_vel_bez = property(lambda s: s.rigid_body.view(s.num_envs, -1, 13)[..., 1, 7:10])
+    root_ang_bez = property(lambda s: s.rigid_body.view(s.num_envs, -1, 13)[..., 1, 10:13])
+    root_pos_ball = property(lambda s: s.root_states.view(s.num_envs, -1, 13)[..., 1, 0:3])
+    root_orient_ball = property(lambda s: s.root_states.view(s.num_envs, -1, 13)[..., 1, 3:7])
+    root_vel_ball = property(lambda s: s.root_states.view(s.num_envs, -1, 13)[..., 1, 7:10])
+    # kick_env.py:187-196: per-cleat rows with the cleats asset, the two foot rows otherwise
+    left_contact_forces = property(lambda s: s.net_contact_forces.view(s.num_envs, -1, 3)[..., 13:17, 0:3])
+    right_contact_forces = property(lambda s: s.net_contact_forces.view(s.num_envs, -1, 3)[..., 25:29, 0:3])
+    left_foot_contact_forces = property(lambda s: s.net_contact_forces.view(s.num_envs, -1, 3)[..., 12, 0:3])
+    right_foot_contact_forces = property(lambda s: s.net_contact_forces.view(s.num_envs, -1, 3)[..., 24 if s.cleats else 20, 0:3])
+
+    @property
+    def goal(self):
+        """(N,2) goal: constant for bez_kick; bez_walk / bez_orient redraw it inside reset_idx (walk_env.py:570-575)."""
+        return self._goal_cfg if self.HAS_BALL else self.sim.refresh(abi.TENSOR_GOAL)
     prev_lin_vel = property(lambda s: s.sim.refresh(abi.TENSOR_PREV_LIN_VEL))
     feet = property(lambda s: s.sim.refresh(abi.TENSOR_FEET))
 

@@ -15,11 +15,13 @@
  *   - every function returns 0 on success, <0 on error (message: bez_sim_last_error()).
  *   - the sim owns all state buffers for its lifetime; bez_sim_get_tensor() exposes them
  *     zero-copy (gymtorch.wrap_tensor equivalent, kick_env.py:155-157).
- *   - Isaac-layout tensors (row-major AoS, fp32, per env: 2 actors, 22 bodies, 18 DOFs):
- *       ROOT_STATE        (N*2, 13)  pos3 quat_xyzw4 linvel3 angvel3     kick_env.py:143
+ *   - Isaac-layout tensors (row-major AoS, fp32, per env: A actors, B bodies, 18 DOFs):
+ *       ROOT_STATE        (N*A, 13)  pos3 quat_xyzw4 linvel3 angvel3     kick_env.py:143
  *       DOF_STATE         (N*18, 2)  pos vel                             kick_env.py:144
- *       RIGID_BODY_STATE  (N*22, 13)                                     kick_env.py:145
- *       NET_CONTACT_FORCE (N*22, 3)                                      kick_env.py:146
+ *       RIGID_BODY_STATE  (N*B, 13)                                      kick_env.py:145
+ *       NET_CONTACT_FORCE (N*B, 3)                                       kick_env.py:146
+ *     bez_kick: A = 2 (robot, ball), B = 22 (21 robot bodies + ball); with the cleats asset (BEZ_FLAG_CLEATS) B = 30;
+ *     bez_walk / bez_orient have no ball actor: A = 1, B = 21 (29 with cleats); OBS is (N,54) for bez_kick, (N,52) otherwise.
  *     They are *materialised on demand* by bez_sim_refresh_tensor (gym.refresh_*_tensor);
  *     the simulator's own state is SoA ([field][env], one env per lane).
  */
@@ -32,9 +34,10 @@
 extern "C" {
 #endif
 
-#define BEZ_SIM_ABI_VERSION 2
+#define BEZ_SIM_ABI_VERSION 3
 
-#define BEZ_NUM_OBS 54
+#define BEZ_NUM_OBS 54       /* bez_kick; bez_walk / bez_orient: 52 (no ball tail)  walk_env.py:104 */
+#define BEZ_NUM_OBS_WALK 52
 #define BEZ_NUM_ACTIONS 18
 #define BEZ_NUM_DOFS 18
 #define BEZ_NUM_BODIES 22 /* 21 robot + ball */
@@ -49,6 +52,15 @@ extern "C" {
 #define BEZ_FLAG_NO_SELF_COLLISION 8u /* disable leg<->leg contact (the reference enables self-collision) */
 #define BEZ_FLAG_CF_WITH_FRICTION 2u /* NET_CONTACT_FORCE rows include friction; default off: Isaac Gym reports the \
                                         normal contact impulses only [ext] (checkpoint obs statistics) */
+
+#define BEZ_FLAG_CLEATS 16u /* asset.cleats: True -> soccerbot_stl_sensor.urdf: 29 robot bodies, per-cleat contact rows \
+                               13:17 / 25:29 and compute_feet_sensors_cleats (kick_env.py:187-191,267-276,1044-1069) */
+
+/* Tasks sharing the robot, the physics and the tensor API; they differ in the post-physics logic (observation tail,
+ * reward, reset conditions, goal sampling) and in the ball actor (bez_kick only). */
+#define BEZ_TASK_KICK 0   /* tasks/kick_env.py    54 obs, ball + goal point                              */
+#define BEZ_TASK_WALK 1   /* tasks/walk_env.py    52 obs, no ball, goal xy ~ U(-2,2)^2 redrawn at reset  */
+#define BEZ_TASK_ORIENT 2 /* tasks/orient_env.py  52 obs, no ball, goal heading                          */
 
 typedef struct BezSimConfig {
   int32_t abi_version; /* must be BEZ_SIM_ABI_VERSION */
@@ -80,6 +92,8 @@ typedef struct BezSimConfig {
   float self_kn;       /* leg<->leg self-collision (kick_env.py:365-366, filter 0): spring [N/m]   */
   float self_cn;       /*                                                     damper [N*s/m] */
   float tune[8];       /* calibration knobs of the physics model; 0 = default behaviour */
+  int32_t task;        /* BEZ_TASK_*: which env logic POST runs (tasks/__init__.py:10-16)                */
+  float goal_angle;    /* bez_orient: env.goalState.goal_angle                       orient_env.py:61 */
   uint32_t flags;      /* BEZ_FLAG_* */
   uint64_t seed;       /* reset-noise stream key (config.yaml:11 seed: 42) */
   int64_t env_id_offset; /* global id of local env 0; reset noise is keyed by GLOBAL env id so
@@ -104,7 +118,8 @@ enum BezTensor {
   BEZ_TENSOR_DOF_TARGET = 9,        /* f32 (N,18)     PD position targets */
   BEZ_TENSOR_PREV_LIN_VEL = 10,     /* f32 (N,3)      prev_lin_vel  kick_env.py:183 */
   BEZ_TENSOR_FEET = 11,             /* f32 (N,8)      self.feet     kick_env.py:185 */
-  BEZ_TENSOR_COUNT = 12
+  BEZ_TENSOR_GOAL = 12,             /* f32 (N,2)      self.goal     walk_env.py:143 (bez_walk / bez_orient: redrawn at reset) */
+  BEZ_TENSOR_COUNT = 13
 };
 enum BezDtype { BEZ_DTYPE_F32 = 0, BEZ_DTYPE_I64 = 1 };
 
@@ -179,6 +194,8 @@ int bez_sim_set_prev_lin_vel_tensor(BezSim* sim, const float* prev_dev, void* st
 int bez_sim_set_flags(BezSim* sim, uint32_t flags);
 /* compute_observations + compute_reward on the current state, without timeout/progress/reset bookkeeping */
 int bez_sim_observe_reward(BezSim* sim, void* stream);
+/* writes the per-env goal (N,2) of bez_walk / bez_orient */
+int bez_sim_set_goal_tensor(BezSim* sim, const float* goal_dev, void* stream);
 /* number of compute_observations passes already done: only pass 0 differences against prev = zeros (Q1) */
 int bez_sim_set_obs_calls(BezSim* sim, int64_t calls);
 

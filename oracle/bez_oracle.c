@@ -43,6 +43,22 @@ typedef BEZ_REAL real;
 
 #define NL BEZ_NL
 #define ND BEZ_ND
+#define NBMAX BEZ_NBE_MAX
+
+/* model variant: default asset or the cleats asset (BEZ_FLAG_CLEATS) */
+static int m_cl(const BezSimConfig* c) { return (c->flags & BEZ_FLAG_CLEATS) != 0; }
+static int m_nb(const BezSimConfig* c) { return m_cl(c) ? BEZ_NB_CL : BEZ_NB; }              /* robot bodies; the ball row follows */
+static int m_has_ball(const BezSimConfig* c) { return c->task == BEZ_TASK_KICK; }
+static int m_nbe(const BezSimConfig* c) { return m_nb(c) + (m_has_ball(c) ? 1 : 0); }        /* rows of the exported tensors */
+static int m_nobs(const BezSimConfig* c) { return c->task == BEZ_TASK_KICK ? BEZ_NUM_OBS : BEZ_NUM_OBS_WALK; }
+static int m_link_body(const BezSimConfig* c, int l) { return m_cl(c) ? BEZ_LINK_BODY_CL[l] : BEZ_LINK_BODY[l]; }
+static real m_mass(const BezSimConfig* c, int l) { return (real)(m_cl(c) ? BEZ_LINK_MASS_CL[l] : BEZ_LINK_MASS[l]); }
+static const double* m_com(const BezSimConfig* c, int l) { return m_cl(c) ? BEZ_LINK_COM_CL[l] : BEZ_LINK_COM[l]; }
+static const double* m_inertia(const BezSimConfig* c, int l) { return m_cl(c) ? BEZ_LINK_INERTIA_CL[l] : BEZ_LINK_INERTIA[l]; }
+static const double* m_pt_pos(const BezSimConfig* c, int i) { return m_cl(c) ? BEZ_PT_POS_CL[i] : BEZ_PT_POS[i]; }
+static int m_pt_body(const BezSimConfig* c, int i) { return m_cl(c) ? BEZ_PT_BODY_CL[i] : BEZ_PT_BODY[i]; }
+static int m_body_link(const BezSimConfig* c, int b) { return m_cl(c) ? BEZ_BODY_LINK_CL[b] : BEZ_BODY_LINK[b]; }
+static const double* m_body_offset(const BezSimConfig* c, int b) { return m_cl(c) ? BEZ_BODY_OFFSET_CL[b] : BEZ_BODY_OFFSET[b]; }
 
 /* ------------------------------------------------------------------ small linear algebra */
 typedef struct { real v[3]; } V3;
@@ -212,6 +228,15 @@ static float reset_uniform(uint64_t seed, int64_t genv, uint32_t episode, int k)
   return (float)(c[k & 3] >> 8) * (1.0f / 16777216.0f);
 }
 
+/* bez_walk / bez_orient draw a goal in reset_idx and give THE FIRST SAMPLE to every env reset by that call
+ * (`self.goal[env_ids, 0] = goal_x[0]`, walk_env.py:570-575): one draw per reset call, keyed by (seed, call counter, kind)
+ * -- kind 0 = the reset inside post_physics_step of that step, 1 = an explicit reset_idx call. */
+static void goal_draw(uint64_t seed, uint64_t counter, uint32_t kind, float out[2]) {
+  uint32_t c[4] = {(uint32_t)counter, (uint32_t)(counter >> 32), 0x474f414cu, kind};
+  philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+  for (int k = 0; k < 2; ++k) out[k] = fmaf(4.0f, (float)(c[k] >> 8) * (1.0f / 16777216.0f), -2.0f); /* torch_rand_float(-2, 2) */
+}
+
 /* ------------------------------------------------------------------ per-env state */
 typedef struct {
   real root_pos[3], root_quat[4], root_lin[3], root_ang[3];
@@ -219,7 +244,8 @@ typedef struct {
   real ball_pos[3], ball_quat[4], ball_lin[3], ball_ang[3];
   real target[ND];
   real prev_lin_vel[3];
-  real contact_force[BEZ_NBE][3]; /* per body, world, last substep */
+  real contact_force[NBMAX][3]; /* per body (robot bodies, then the ball), world */
+  real goal[2];                 /* bez_walk: per-env goal, redrawn at reset (walk_env.py:570-575) */
   real feet[8];
   real obs[BEZ_NUM_OBS];
   real rew;
@@ -234,6 +260,7 @@ typedef struct {
   int n;
   Env* env;
   int64_t obs_calls; /* number of compute_observations passes so far (quirk Q1 bookkeeping) */
+  uint64_t post_calls, reset_calls; /* keys of the shared goal draw (bez_walk / bez_orient) */
 } Oracle;
 
 /* kinematics of one env: link frames relative to O = root_pos, world axes */
@@ -263,10 +290,10 @@ typedef struct {
   SV a0;         /* root spatial acceleration about O */
   real qdd[ND];
   V3 ball_lin_acc, ball_ang_acc; /* classical */
-  real contact_force[BEZ_NBE][3];
+  real contact_force[NBMAX][3];
 } Dyn;
 
-typedef struct { int link; V3 x; real fn0, kn, ct, ftx0, fty0; } GroundHit;
+typedef struct { int link, body; V3 x; real fn0, kn, ct, ftx0, fty0; } GroundHit;
 
 /* Adds the implicit ground contact of a point at x (rel. O) on a body with velocity V (about O) whose
  * world height is z.  Returns 1 if active and fills hit.  IA/pA are the body's inertia and bias. */
@@ -346,7 +373,7 @@ static void self_collision(const BezSimConfig* c, real mu, const Kin* k, const S
     pS[la] = sv_add(pS[la], sv_scale(wrench_at(x, f), -1));
     pS[lb] = sv_add(pS[lb], wrench_at(x, f));
     V3 fr = with_fric ? f : fn;
-    for (int i = 0; i < 3; ++i) { cf[BEZ_LINK_BODY[la]][i] += fr.v[i]; cf[BEZ_LINK_BODY[lb]][i] -= fr.v[i]; }
+    for (int i = 0; i < 3; ++i) { cf[m_link_body(c, la)][i] += fr.v[i]; cf[m_link_body(c, lb)][i] -= fr.v[i]; }
   }
 }
 
@@ -356,6 +383,7 @@ static void self_collision(const BezSimConfig* c, real mu, const Kin* k, const S
 static void dynamics(const BezSimConfig* c, const Env* e, real h, int mode, const real* tau_in, Dyn* out) {
   Kin k;
   forward_kinematics(e, &k);
+  const int nb = m_nb(c); /* row of the ball */
   V3 g = v3(e->gravity[0], e->gravity[1], e->gravity[2]);
   SV V[NL], S[NL], cb[NL], pA[NL];
   SV pS[NL]; /* explicit leg<->leg contact wrenches, propagated next to pA: the drive-saturation predictor below does not see them */
@@ -375,10 +403,10 @@ static void dynamics(const BezSimConfig* c, const Env* e, real h, int mode, cons
       V[l] = sv_add(V[p], vj);
       cb[l] = crm(V[l], vj);
     }
-    real m = (real)BEZ_LINK_MASS[l] * e->mass_scale[l];
-    V3 cl = v3((real)BEZ_LINK_COM[l][0], (real)BEZ_LINK_COM[l][1], (real)BEZ_LINK_COM[l][2]);
+    real m = m_mass(c, l) * e->mass_scale[l];
+    V3 cl = v3((real)m_com(c, l)[0], (real)m_com(c, l)[1], (real)m_com(c, l)[2]);
     V3 cw = v3add(k.r[l], m3mulv(&k.E[l], cl));
-    const double* il = BEZ_LINK_INERTIA[l];
+    const double* il = m_inertia(c, l);
     M3 Il = {{{(real)il[0], (real)il[3], (real)il[4]}, {(real)il[3], (real)il[1], (real)il[5]}, {(real)il[4], (real)il[5], (real)il[2]}}};
     for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) Il.m[i][j] *= e->mass_scale[l];
     M3 ET = m3T(&k.E[l]);
@@ -404,10 +432,10 @@ static void dynamics(const BezSimConfig* c, const Env* e, real h, int mode, cons
   if (mode == 0) {
     for (int i = 0; i < BEZ_NPT; ++i) {
       int l = BEZ_PT_LINK[i];
-      V3 pl = v3((real)BEZ_PT_POS[i][0], (real)BEZ_PT_POS[i][1], (real)BEZ_PT_POS[i][2]);
+      V3 pl = v3((real)m_pt_pos(c, i)[0], (real)m_pt_pos(c, i)[1], (real)m_pt_pos(c, i)[2]);
       V3 x = v3add(k.r[l], m3mulv(&k.E[l], pl));
       real z = e->root_pos[2] + x.v[2];
-      if (ground_contact(c, mu, h, x, z, V[l], &IA[l], &pA[l], &hits[nhit])) { hits[nhit].link = l; ++nhit; }
+      if (ground_contact(c, mu, h, x, z, V[l], &IA[l], &pA[l], &hits[nhit])) { hits[nhit].link = l; hits[nhit].body = m_pt_body(c, i); ++nhit; }
     }
     if (!(c->flags & BEZ_FLAG_NO_SELF_COLLISION)) {
       self_collision(c, mu, &k, V, pS, out->contact_force, (c->flags & BEZ_FLAG_CF_WITH_FRICTION) != 0);
@@ -567,7 +595,7 @@ static void dynamics(const BezSimConfig* c, const Env* e, real h, int mode, cons
       const GroundHit* hh = &hits[i];
       SV a = acc[hh->link];
       V3 ap = v3add(sv_lin(a), v3cross(sv_ang(a), hh->x));
-      int body = BEZ_LINK_BODY[hh->link];
+      int body = hh->body;
       if (with_fric) {
         out->contact_force[body][0] += hh->ftx0 - h * hh->ct * ap.v[0];
         out->contact_force[body][1] += hh->fty0 - h * hh->ct * ap.v[1];
@@ -579,9 +607,9 @@ static void dynamics(const BezSimConfig* c, const Env* e, real h, int mode, cons
       SV a = acc[bl_link];
       V3 ap = v3add(sv_lin(a), v3cross(sv_ang(a), bl_x));
       fl = v3sub(bl_f0p, m3mulv(&bl_A, ap));
-      int body = BEZ_LINK_BODY[bl_link];
+      int body = m_link_body(c, bl_link);
       V3 fr = with_fric ? fl : v3scale(bl_n, v3dot(fl, bl_n));
-      for (int i = 0; i < 3; ++i) { out->contact_force[body][i] += fr.v[i]; out->contact_force[BEZ_NBE - 1][i] -= fr.v[i]; }
+      for (int i = 0; i < 3; ++i) { out->contact_force[body][i] += fr.v[i]; out->contact_force[nb][i] -= fr.v[i]; }
     }
     /* ball: Mb ab = -pb - Jb^T fl */
     SV rhs = sv_add(sv_scale(pb, -1), sv_scale(wrench_at(bl_xb, fl), -1));
@@ -591,10 +619,10 @@ static void dynamics(const BezSimConfig* c, const Env* e, real h, int mode, cons
     if (ball_ground) {
       V3 ap = v3add(out->ball_lin_acc, v3cross(out->ball_ang_acc, bhit.x));
       if (with_fric) {
-        out->contact_force[BEZ_NBE - 1][0] += bhit.ftx0 - h * bhit.ct * ap.v[0];
-        out->contact_force[BEZ_NBE - 1][1] += bhit.fty0 - h * bhit.ct * ap.v[1];
+        out->contact_force[nb][0] += bhit.ftx0 - h * bhit.ct * ap.v[0];
+        out->contact_force[nb][1] += bhit.fty0 - h * bhit.ct * ap.v[1];
       }
-      out->contact_force[BEZ_NBE - 1][2] += bhit.fn0 - bhit.kn * ap.v[2];
+      out->contact_force[nb][2] += bhit.fn0 - bhit.kn * ap.v[2];
     }
   }
 }
@@ -644,11 +672,12 @@ static void substep(const BezSimConfig* c, Env* e, real h, int first, real wgt) 
   }
   quat_integrate(e->ball_quat, e->ball_ang, h);
   /* physx.contact_collection 2 = CC_ALL_SUBSTEPS (bez_kick.yaml:147): the tensor holds the mean force over the control step [ext] */
-  for (int b = 0; b < BEZ_NBE; ++b) for (int i = 0; i < 3; ++i) e->contact_force[b][i] = first ? d.contact_force[b][i] * wgt : e->contact_force[b][i] + d.contact_force[b][i] * wgt;
+  for (int b = 0; b < NBMAX; ++b) for (int i = 0; i < 3; ++i) e->contact_force[b][i] = first ? d.contact_force[b][i] * wgt : e->contact_force[b][i] + d.contact_force[b][i] * wgt;
 }
 
 /* ------------------------------------------------------------------ env logic (reference restatement) */
-static void env_reset(const BezSimConfig* c, Env* e, int64_t genv) {
+static void env_reset(const BezSimConfig* c, Env* e, int64_t genv, const float* goal) {
+  if (c->task != BEZ_TASK_KICK) { e->goal[0] = goal[0]; e->goal[1] = goal[1]; }
   /* kick_env.py:786-791: q = clamp(default + U(-.15,.15), lo, hi); qd = U(-.1,.1) */
   for (int j = 0; j < ND; ++j) {
     float up = reset_uniform(c->seed, genv, e->episode, j);
@@ -721,6 +750,16 @@ static void feet_no_cleats(real f[3], real out[4]) {
 /* use_prev: take the finite difference against the stored prev_lin_vel.  The reference does so only on
  * the first compute_imu call of a process (prev = zeros, kick_env.py:183); afterwards prev aliases the
  * live velocity tensor (kick_env.py:930,441) and the difference is identically zero (quirk Q1). */
+/* compute_feet_sensors_cleats (kick_env.py:1044-1069): +1 where the cleat's contact force norm exceeds 1 N */
+static void feet_cleats(const Env* e, real out[8]) {
+  for (int k = 0; k < 8; ++k) {
+    const real* f = e->contact_force[(k < 4 ? BEZ_LCLEAT_BODY_CL : BEZ_RCLEAT_BODY_CL - 4) + k];
+    out[k] = sqrt(f[0] * f[0] + f[1] * f[1] + f[2] * f[2]) > 1 ? 1 : -1;
+  }
+}
+
+static real wrap_pi(real a) { return atan2(sin(a), cos(a)); } /* isaacgym.torch_utils.normalize_angle [ext] */
+
 static void env_observe_reward(const BezSimConfig* c, Env* e, int use_prev) {
   /* IMU link (body 1) is rigidly at the torso origin with identity offset (soccerbot_stl.urdf:567-572),
    * so its pose/twist equal the root state. */
@@ -751,24 +790,68 @@ static void env_observe_reward(const BezSimConfig* c, Env* e, int use_prev) {
   }
   for (int i = 0; i < 3; ++i) e->prev_lin_vel[i] = vimu[i]; /* kick_env.py:441,930 */
   /* compute_off_orn, kick_env.py:941-960 */
-  real gx = (real)c->goal[0] - e->root_pos[0], gy = (real)c->goal[1] - e->root_pos[1];
+  const real goal_x = c->task == BEZ_TASK_KICK ? (real)c->goal[0] : e->goal[0], goal_y = c->task == BEZ_TASK_KICK ? (real)c->goal[1] : e->goal[1];
+  real gx = goal_x - e->root_pos[0], gy = goal_y - e->root_pos[1];
   real gn = sqrt(gx * gx + gy * gy);
   real ux = gx / gn, uy = gy / gn;
   real yaw = euler_yaw(q);
   real hx = cos(yaw), hy = sin(yaw);
   real cosv = hx * ux + hy * uy;
   real sinv = fabs(ux * hy - uy * hx); /* || cross(u3, h3) || : unsigned (quirk Q4) */
-  /* feet, kick_env.py:538-576 */
-  real lf[4], rf[4];
-  feet_no_cleats(e->contact_force[BEZ_LFOOT_BODY], lf);
-  feet_no_cleats(e->contact_force[BEZ_RFOOT_BODY], rf);
-  for (int i = 0; i < 4; ++i) { e->feet[i] = lf[i]; e->feet[4 + i] = rf[i]; }
+  real o42 = sinv, o43 = -cosv;
+  const real ang_goal = (real)c->goal_angle - wrap_pi(yaw); /* orient_env.py:719-735 compute_off_angle */
+  if (c->task == BEZ_TASK_ORIENT) { o42 = cos(ang_goal); o43 = sin(ang_goal); }
+  /* feet, kick_env.py:538-576 (cleats: kick_env.py:467-495) */
+  if (m_cl(c)) {
+    feet_cleats(e, e->feet);
+  } else {
+    real lf[4], rf[4];
+    feet_no_cleats(e->contact_force[BEZ_LFOOT_BODY], lf);
+    feet_no_cleats(e->contact_force[BEZ_RFOOT_BODY], rf);
+    for (int i = 0; i < 4; ++i) { e->feet[i] = lf[i]; e->feet[4 + i] = rf[i]; }
+  }
   /* compute_bez_observations, kick_env.py:1409-1415 (tail = constant ball_init, quirk Q5) */
   for (int j = 0; j < ND; ++j) { e->obs[j] = e->q[j]; e->obs[ND + j] = e->qd[j]; }
   for (int i = 0; i < 6; ++i) e->obs[36 + i] = imu[i];
-  e->obs[42] = sinv; e->obs[43] = -cosv;
+  e->obs[42] = o42; e->obs[43] = o43;
   for (int i = 0; i < 8; ++i) e->obs[44 + i] = e->feet[i];
-  e->obs[52] = c->ball_init[0]; e->obs[53] = c->ball_init[1];
+  e->obs[52] = c->ball_init[0]; e->obs[53] = c->ball_init[1]; /* bez_kick only; bez_walk / bez_orient stop at 52 (walk_env.py:1033-1050) */
+  if (c->task != BEZ_TASK_KICK) {
+    /* compute_bez_reward of walk_env.py:826-1031 / orient_env.py:843-1018 */
+    real vn2 = 0, wn2 = 0, pn2 = 0;
+    for (int i = 0; i < 3; ++i) { vn2 += vimu[i] * vimu[i]; wn2 += wimu[i] * wimu[i]; }
+    for (int j = 0; j < ND; ++j) { real d = (real)(float)BEZ_DOF_DEFAULT[j] - e->q[j]; pn2 += d * d; }
+    real vel_reward = sqrt(vn2 + wn2), vel_lin = sqrt(vn2), vel_ang = sqrt(wn2), pos_reward = sqrt(pn2);
+    real up_proj = 1 - 2 * (q[0] * q[0] + q[1] * q[1]); /* get_basis_vector(q, (0,0,1)).z = quat_rotate [ext] */
+    real dh = fabs(1 - up_proj);
+    real height_vel_pos = -((vel_reward * (real)0.05 + pos_reward * (real)0.05) + dh);
+    real reward, near;
+    if (c->task == BEZ_TASK_WALK) {
+      real vfwd = ux * vimu[0] + uy * vimu[1];
+      real vel_height = vfwd * 10 - (dh + 5 * (pos_reward * (real)0.05));
+      near = gn;
+      reward = gn < (real)0.05 ? height_vel_pos : vel_height;
+    } else {
+      real vel_height = fabs(ang_goal) * (real)-0.5 - (dh + (real)0.05 * (pos_reward * (real)0.05));
+      near = ang_goal; /* signed, as the reference compares it (orient_env.py:935) */
+      reward = ang_goal < (real)0.05 ? height_vel_pos : vel_height;
+    }
+    int64_t reset = e->reset;
+    if (up_proj < (real)0.7) { reset = 1; reward = -100; }
+    int state = (near < (real)0.05) + (pos_reward < (real)0.15) + (vel_ang < (real)0.1) + (vel_lin < (real)0.1);
+    if (state == 4) { reset = 1; reward = (real)1000.0 - (real)1000.0 * ((real)e->progress / (real)c->max_episode_length); }
+    if (c->task == BEZ_TASK_WALK) { /* walk_env.py:966-990: heading to the goal turned by more than 90 deg since the start (0,0) */
+      real a_init = atan2(goal_y / sqrt(goal_x * goal_x + goal_y * goal_y), goal_x / sqrt(goal_x * goal_x + goal_y * goal_y));
+      if (fabs(a_init - atan2(uy, ux)) > (real)1.5708) { reset = 1; reward = -100; }
+    } else { /* orient_env.py:1000-1009: wandered more than 0.3 m from the start */
+      real tx = e->root_pos[0] - (real)c->bez_init[0], ty = e->root_pos[1] - (real)c->bez_init[1];
+      if (sqrt(tx * tx + ty * ty) > (real)0.3) { reset = 1; reward = -5; }
+    }
+    if (e->progress >= c->max_episode_length) { reset = 1; reward = 0; }
+    e->rew = reward;
+    e->reset = reset;
+    return;
+  }
 
   /* compute_bez_reward, kick_env.py:1224-1391 */
   real bx = e->ball_pos[0], by = e->ball_pos[1];
@@ -810,10 +893,10 @@ static void env_observe_reward(const BezSimConfig* c, Env* e, int use_prev) {
 
 static int oracle_use_prev(const Oracle* o) { return !(o->cfg.flags & BEZ_FLAG_IMU_PREV_ALIAS) || o->obs_calls == 0; }
 
-static void env_post_physics(const BezSimConfig* c, Env* e, int64_t genv, int use_prev) {
+static void env_post_physics(const BezSimConfig* c, Env* e, int64_t genv, int use_prev, const float* goal) {
   e->timeout = (e->progress >= c->max_episode_length - 1) ? 1 : 0; /* vec_task.py:331-332 */
   e->progress += 1;                                                /* kick_env.py:429 */
-  if (e->reset != 0) env_reset(c, e, genv);                        /* kick_env.py:433-435 */
+  if (e->reset != 0) env_reset(c, e, genv, goal);                  /* kick_env.py:433-435 */
   env_observe_reward(c, e, use_prev);                              /* kick_env.py:437-438 */
 }
 
@@ -830,8 +913,14 @@ static void env_simulate(const BezSimConfig* c, Env* e) {
 void* bez_oracle_create(const BezSimConfig* cfg) {
   Oracle* o = (Oracle*)calloc(1, sizeof(Oracle));
   o->cfg = *cfg;
+  if (!m_has_ball(cfg)) { /* walk_env.py / orient_env.py create no ball actor: the free body is parked out of reach */
+    o->cfg.ball_init[0] = 1000.0f; o->cfg.ball_init[1] = 0.0f; o->cfg.ball_init[2] = (float)BEZ_BALL_RADIUS;
+  }
   o->n = cfg->num_envs;
   o->env = (Env*)calloc((size_t)o->n, sizeof(Env));
+  float goal0[2];
+  goal_draw(cfg->seed, 0, 1, goal0); /* KickEnv/WalkEnv.__init__ ends with reset_idx(all): explicit reset call number 0 */
+  o->reset_calls = 1;
   for (int i = 0; i < o->n; ++i) {
     Env* e = &o->env[i];
     e->reset = 1; /* vec_task.py:241 */
@@ -843,7 +932,8 @@ void* bez_oracle_create(const BezSimConfig* cfg) {
     e->root_quat[3] = 1; e->ball_quat[3] = 1;
     /* vec_task.py:193 allocate_buffers sets reset_buf = 1, then KickEnv.__init__ ends with
      * reset_idx(all) (kick_env.py:238) which clears it: the first step() does NOT re-reset. */
-    env_reset(&o->cfg, e, cfg->env_id_offset + i);
+    e->goal[0] = cfg->goal[0]; e->goal[1] = cfg->goal[1];
+    env_reset(&o->cfg, e, cfg->env_id_offset + i, goal0);
   }
   return o;
 }
@@ -852,11 +942,13 @@ int bez_oracle_real_size(void) { return (int)sizeof(real); }
 
 void bez_oracle_get_root_states(void* h, float* out) {
   Oracle* o = (Oracle*)h;
+  const int na = m_has_ball(&o->cfg) ? 2 : 1; /* actors per env */
   for (int i = 0; i < o->n; ++i) {
     const Env* e = &o->env[i];
-    float* r = out + (size_t)i * 26;
+    float* r = out + (size_t)i * 13 * na;
     for (int k = 0; k < 3; ++k) { r[k] = (float)e->root_pos[k]; r[7 + k] = (float)e->root_lin[k]; r[10 + k] = (float)e->root_ang[k]; }
     for (int k = 0; k < 4; ++k) r[3 + k] = (float)e->root_quat[k];
+    if (na == 1) continue;
     r += 13;
     for (int k = 0; k < 3; ++k) { r[k] = (float)e->ball_pos[k]; r[7 + k] = (float)e->ball_lin[k]; r[10 + k] = (float)e->ball_ang[k]; }
     for (int k = 0; k < 4; ++k) r[3 + k] = (float)e->ball_quat[k];
@@ -864,11 +956,13 @@ void bez_oracle_get_root_states(void* h, float* out) {
 }
 void bez_oracle_set_root_states(void* h, const float* in) {
   Oracle* o = (Oracle*)h;
+  const int na = m_has_ball(&o->cfg) ? 2 : 1;
   for (int i = 0; i < o->n; ++i) {
     Env* e = &o->env[i];
-    const float* r = in + (size_t)i * 26;
+    const float* r = in + (size_t)i * 13 * na;
     for (int k = 0; k < 3; ++k) { e->root_pos[k] = r[k]; e->root_lin[k] = r[7 + k]; e->root_ang[k] = r[10 + k]; }
     for (int k = 0; k < 4; ++k) e->root_quat[k] = r[3 + k];
+    if (na == 1) continue;
     r += 13;
     for (int k = 0; k < 3; ++k) { e->ball_pos[k] = r[k]; e->ball_lin[k] = r[7 + k]; e->ball_ang[k] = r[10 + k]; }
     for (int k = 0; k < 4; ++k) e->ball_quat[k] = r[3 + k];
@@ -886,15 +980,22 @@ void bez_oracle_get_targets(void* h, float* out) { Oracle* o = (Oracle*)h; for (
 void bez_oracle_set_targets(void* h, const float* in) { Oracle* o = (Oracle*)h; for (int i = 0; i < o->n; ++i) for (int j = 0; j < ND; ++j) o->env[i].target[j] = in[(size_t)i * ND + j]; }
 void bez_oracle_get_contact_forces(void* h, float* out) {
   Oracle* o = (Oracle*)h;
-  for (int i = 0; i < o->n; ++i) for (int b = 0; b < BEZ_NBE; ++b) for (int k = 0; k < 3; ++k) out[((size_t)i * BEZ_NBE + b) * 3 + k] = (float)o->env[i].contact_force[b][k];
+  const int nbe = m_nbe(&o->cfg);
+  for (int i = 0; i < o->n; ++i) for (int b = 0; b < nbe; ++b) for (int k = 0; k < 3; ++k) out[((size_t)i * nbe + b) * 3 + k] = (float)o->env[i].contact_force[b][k];
 }
 void bez_oracle_set_contact_forces(void* h, const float* in) {
   Oracle* o = (Oracle*)h;
-  for (int i = 0; i < o->n; ++i) for (int b = 0; b < BEZ_NBE; ++b) for (int k = 0; k < 3; ++k) o->env[i].contact_force[b][k] = in[((size_t)i * BEZ_NBE + b) * 3 + k];
+  const int nbe = m_nbe(&o->cfg);
+  for (int i = 0; i < o->n; ++i) for (int b = 0; b < nbe; ++b) for (int k = 0; k < 3; ++k) o->env[i].contact_force[b][k] = in[((size_t)i * nbe + b) * 3 + k];
 }
+void bez_oracle_get_goal(void* h, float* out) { Oracle* o = (Oracle*)h; for (int i = 0; i < o->n; ++i) for (int k = 0; k < 2; ++k) out[(size_t)i * 2 + k] = (float)o->env[i].goal[k]; }
+void bez_oracle_set_goal(void* h, const float* in) { Oracle* o = (Oracle*)h; for (int i = 0; i < o->n; ++i) for (int k = 0; k < 2; ++k) o->env[i].goal[k] = in[(size_t)i * 2 + k]; }
+int bez_oracle_num_bodies(void* h) { return m_nbe(&((Oracle*)h)->cfg); }
+int bez_oracle_num_obs(void* h) { return m_nobs(&((Oracle*)h)->cfg); }
+int bez_oracle_num_actors(void* h) { return m_has_ball(&((Oracle*)h)->cfg) ? 2 : 1; }
 void bez_oracle_get_prev_lin_vel(void* h, float* out) { Oracle* o = (Oracle*)h; for (int i = 0; i < o->n; ++i) for (int k = 0; k < 3; ++k) out[(size_t)i * 3 + k] = (float)o->env[i].prev_lin_vel[k]; }
 void bez_oracle_set_prev_lin_vel(void* h, const float* in) { Oracle* o = (Oracle*)h; for (int i = 0; i < o->n; ++i) for (int k = 0; k < 3; ++k) o->env[i].prev_lin_vel[k] = in[(size_t)i * 3 + k]; }
-void bez_oracle_get_obs(void* h, float* out) { Oracle* o = (Oracle*)h; for (int i = 0; i < o->n; ++i) for (int k = 0; k < BEZ_NUM_OBS; ++k) out[(size_t)i * BEZ_NUM_OBS + k] = (float)o->env[i].obs[k]; }
+void bez_oracle_get_obs(void* h, float* out) { Oracle* o = (Oracle*)h; const int no = m_nobs(&o->cfg); for (int i = 0; i < o->n; ++i) for (int k = 0; k < no; ++k) out[(size_t)i * no + k] = (float)o->env[i].obs[k]; }
 void bez_oracle_get_feet(void* h, float* out) { Oracle* o = (Oracle*)h; for (int i = 0; i < o->n; ++i) for (int k = 0; k < 8; ++k) out[(size_t)i * 8 + k] = (float)o->env[i].feet[k]; }
 void bez_oracle_get_rew(void* h, float* out) { Oracle* o = (Oracle*)h; for (int i = 0; i < o->n; ++i) out[i] = (float)o->env[i].rew; }
 void bez_oracle_get_reset(void* h, int64_t* out) { Oracle* o = (Oracle*)h; for (int i = 0; i < o->n; ++i) out[i] = o->env[i].reset; }
@@ -928,18 +1029,20 @@ void bez_oracle_get_rigid_body_states(void* h, float* out) {
     SV V[NL];
     V[0] = sv(v3(e->root_ang[0], e->root_ang[1], e->root_ang[2]), v3(e->root_lin[0], e->root_lin[1], e->root_lin[2]));
     for (int l = 1; l < NL; ++l) V[l] = sv_add(V[BEZ_LINK_PARENT[l]], sv_scale(sv(k.a[l], v3cross(k.r[l], k.a[l])), e->qd[l - 1]));
-    for (int b = 0; b < BEZ_NB; ++b) {
-      int l = BEZ_BODY_LINK[b];
-      V3 off = v3((real)BEZ_BODY_OFFSET[b][0], (real)BEZ_BODY_OFFSET[b][1], (real)BEZ_BODY_OFFSET[b][2]);
+    const int nb = m_nb(&o->cfg), nbe = m_nbe(&o->cfg);
+    for (int b = 0; b < nb; ++b) {
+      int l = m_body_link(&o->cfg, b);
+      V3 off = v3((real)m_body_offset(&o->cfg, b)[0], (real)m_body_offset(&o->cfg, b)[1], (real)m_body_offset(&o->cfg, b)[2]);
       V3 x = v3add(k.r[l], m3mulv(&k.E[l], off));
       V3 vel = v3add(sv_lin(V[l]), v3cross(sv_ang(V[l]), x));
       real qq[4];
       mat_to_quat(&k.E[l], qq);
-      float* r = out + ((size_t)i * BEZ_NBE + b) * 13;
+      float* r = out + ((size_t)i * nbe + b) * 13;
       for (int a = 0; a < 3; ++a) { r[a] = (float)(e->root_pos[a] + x.v[a]); r[7 + a] = (float)vel.v[a]; r[10 + a] = (float)V[l].v[a]; }
       for (int a = 0; a < 4; ++a) r[3 + a] = (float)qq[a];
     }
-    float* r = out + ((size_t)i * BEZ_NBE + BEZ_NB) * 13;
+    if (nbe == nb) continue;
+    float* r = out + ((size_t)i * nbe + nb) * 13;
     for (int a = 0; a < 3; ++a) { r[a] = (float)e->ball_pos[a]; r[7 + a] = (float)e->ball_lin[a]; r[10 + a] = (float)e->ball_ang[a]; }
     for (int a = 0; a < 4; ++a) r[3 + a] = (float)e->ball_quat[a];
   }
@@ -957,7 +1060,9 @@ void bez_oracle_simulate(void* h) {
 void bez_oracle_post_physics(void* h) {
   Oracle* o = (Oracle*)h;
   int up = oracle_use_prev(o);
-  for (int i = 0; i < o->n; ++i) env_post_physics(&o->cfg, &o->env[i], o->cfg.env_id_offset + i, up);
+  float goal[2];
+  goal_draw(o->cfg.seed, o->post_calls++, 0, goal);
+  for (int i = 0; i < o->n; ++i) env_post_physics(&o->cfg, &o->env[i], o->cfg.env_id_offset + i, up, goal);
   o->obs_calls += 1;
 }
 /* obs + reward only (no progress increment / reset handling): golden-vector checks of the jit functions */
@@ -970,18 +1075,22 @@ void bez_oracle_observe_reward(void* h) {
 void bez_oracle_step(void* h, const float* actions) {
   Oracle* o = (Oracle*)h;
   int up = oracle_use_prev(o);
+  float goal[2];
+  goal_draw(o->cfg.seed, o->post_calls++, 0, goal);
 #pragma omp parallel for schedule(static)
   for (int i = 0; i < o->n; ++i) {
     Env* e = &o->env[i];
     env_pre_physics(&o->cfg, e, actions + (size_t)i * ND);
     env_simulate(&o->cfg, e);
-    env_post_physics(&o->cfg, e, o->cfg.env_id_offset + i, up);
+    env_post_physics(&o->cfg, e, o->cfg.env_id_offset + i, up, goal);
   }
   o->obs_calls += 1;
 }
 void bez_oracle_reset_idx(void* h, const int32_t* ids, int n) {
   Oracle* o = (Oracle*)h;
-  for (int k = 0; k < n; ++k) env_reset(&o->cfg, &o->env[ids[k]], o->cfg.env_id_offset + ids[k]);
+  float goal[2];
+  goal_draw(o->cfg.seed, o->reset_calls++, 1, goal);
+  for (int k = 0; k < n; ++k) env_reset(&o->cfg, &o->env[ids[k]], o->cfg.env_id_offset + ids[k], goal);
 }
 void bez_oracle_seed(void* h, uint64_t seed) { ((Oracle*)h)->cfg.seed = seed; }
 void bez_oracle_set_flags(void* h, uint32_t flags) { ((Oracle*)h)->cfg.flags = flags; }
@@ -1002,7 +1111,7 @@ void bez_oracle_forward_dynamics(void* h, int env, int mode, const double* tau, 
   for (int i = 0; i < 6; ++i) a0[i] = d.a0.v[i];
   for (int j = 0; j < ND; ++j) qdd[j] = d.qdd[j];
   if (ball_acc6) for (int i = 0; i < 3; ++i) { ball_acc6[i] = d.ball_ang_acc.v[i]; ball_acc6[3 + i] = d.ball_lin_acc.v[i]; }
-  if (contact_force) for (int b = 0; b < BEZ_NBE; ++b) for (int k = 0; k < 3; ++k) contact_force[b * 3 + k] = d.contact_force[b][k];
+  if (contact_force) for (int b = 0; b < BEZ_NBE; ++b) for (int k = 0; k < 3; ++k) contact_force[b * 3 + k] = d.contact_force[b][k]; /* default-asset layout (known-answer tests) */
 }
 /* full-precision state injection for the known-answer tests: s = pos3 quat4 lin3 ang3 q18 qd18 (49 doubles) */
 void bez_oracle_set_env_state_f64(void* h, int env, const double* s) {

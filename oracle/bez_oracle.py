@@ -50,6 +50,9 @@ class Oracle:
         self.cfg = cfg if cfg is not None else default_config(num_envs)
         self.n = int(self.cfg.num_envs)
         self.h = C.c_void_p(self.lib.bez_oracle_create(C.byref(self.cfg)))
+        self.nbe = int(self.lib.bez_oracle_num_bodies(self.h))    # rows per env of the body tensors (22; cleats 30; walk/orient: no ball row)
+        self.nobs = int(self.lib.bez_oracle_num_obs(self.h))      # 54 (kick) / 52 (walk, orient)
+        self.nact = int(self.lib.bez_oracle_num_actors(self.h))   # 2 (robot + ball) / 1
 
     def __del__(self):
         try:
@@ -69,13 +72,14 @@ class Oracle:
         a = np.ascontiguousarray(arr, dtype=dtype)
         getattr(self.lib, "bez_oracle_set_" + name)(self.h, _fp(a))
 
-    root_states = property(lambda s: s._get("root_states", (s.n * 2, 13)))
+    root_states = property(lambda s: s._get("root_states", (s.n * s.nact, 13)))
+    goal = property(lambda s: s._get("goal", (s.n, 2)))
     dof_state = property(lambda s: s._get("dof_state", (s.n * NUM_DOFS, 2)))
-    rigid_body_states = property(lambda s: s._get("rigid_body_states", (s.n * NUM_BODIES, 13)))
-    contact_forces = property(lambda s: s._get("contact_forces", (s.n * NUM_BODIES, 3)))
+    rigid_body_states = property(lambda s: s._get("rigid_body_states", (s.n * s.nbe, 13)))
+    contact_forces = property(lambda s: s._get("contact_forces", (s.n * s.nbe, 3)))
     targets = property(lambda s: s._get("targets", (s.n, NUM_DOFS)))
     prev_lin_vel = property(lambda s: s._get("prev_lin_vel", (s.n, 3)))
-    obs = property(lambda s: s._get("obs", (s.n, NUM_OBS)))
+    obs = property(lambda s: s._get("obs", (s.n, s.nobs)))
     feet = property(lambda s: s._get("feet", (s.n, 8)))
     rew = property(lambda s: s._get("rew", (s.n,)))
     reset_buf = property(lambda s: s._get("reset", (s.n,), np.int64))
@@ -86,6 +90,7 @@ class Oracle:
     def set_dof_state(self, a): self._set("dof_state", a)
     def set_contact_forces(self, a): self._set("contact_forces", a)
     def set_targets(self, a): self._set("targets", a)
+    def set_goal(self, a): self._set("goal", a)
     def set_prev_lin_vel(self, a): self._set("prev_lin_vel", a)
     def set_reset(self, a): self._set("reset", a, np.int64)
     def set_progress(self, a): self._set("progress", a, np.int64)

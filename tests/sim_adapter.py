@@ -13,8 +13,9 @@ class SimAdapter:
         self.sim = BezSim(self.cfg, 0)
         self.n = self.sim.num_envs
         self.dev = self.sim.device
-        self._robot_ids = torch.arange(0, self.n * 2, 2, dtype=torch.int32, device=self.dev)
-        self._all_ids = torch.arange(0, self.n * 2, dtype=torch.int32, device=self.dev)
+        self.nact, self.nbe, self.nobs = self.sim.num_actors, self.sim.num_bodies, self.sim.num_obs
+        self._robot_ids = torch.arange(0, self.n * self.nact, self.nact, dtype=torch.int32, device=self.dev)
+        self._all_ids = torch.arange(0, self.n * self.nact, dtype=torch.int32, device=self.dev)
 
     def _t(self, a, dtype=torch.float32):
         return torch.as_tensor(np.ascontiguousarray(a), dtype=dtype).to(self.dev).contiguous()
@@ -29,6 +30,7 @@ class SimAdapter:
     rigid_body_states = property(lambda s: s._get(abi.TENSOR_RIGID_BODY_STATE))
     contact_forces = property(lambda s: s._get(abi.TENSOR_NET_CONTACT_FORCE))
     targets = property(lambda s: s._get(abi.TENSOR_DOF_TARGET))
+    goal = property(lambda s: s._get(abi.TENSOR_GOAL))
     prev_lin_vel = property(lambda s: s._get(abi.TENSOR_PREV_LIN_VEL))
     obs = property(lambda s: s._get(abi.TENSOR_OBS))
     feet = property(lambda s: s._get(abi.TENSOR_FEET))
@@ -41,6 +43,7 @@ class SimAdapter:
     def set_dof_state(self, a): self.sim.set_dof_state_tensor_indexed(self._t(a).reshape(-1), self._robot_ids)
     def set_contact_forces(self, a): self.sim.set_net_contact_force_tensor(self._t(a).reshape(-1))
     def set_targets(self, a): self.sim.set_dof_position_target_tensor(self._t(a).reshape(-1))
+    def set_goal(self, a): self.sim.set_goal_tensor(self._t(a).reshape(-1))
     def set_prev_lin_vel(self, a): self.sim.set_prev_lin_vel_tensor(self._t(a).reshape(-1))
     def set_reset(self, a): self.sim.tensor(abi.TENSOR_RESET).copy_(self._t(a, torch.int64))
     def set_progress(self, a): self.sim.tensor(abi.TENSOR_PROGRESS).copy_(self._t(a, torch.int64))

@@ -1,0 +1,199 @@
+"""The cleats asset and the bez_walk / bez_orient tasks (8(f3)): golden vectors from the reference's own
+TorchScript functions (tests/golden/make_golden_tasks.py -> tasks_golden.npz) against the oracle (CPU) and the HIP path
+(GPU, through the C ABI), plus HIP-vs-oracle parity of the whole step for every variant."""
+import os
+
+import numpy as np
+import pytest
+
+from bez_isaacgym_amd import abi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+N = 64
+VARIANTS = [("bez_kick", True), ("bez_walk", False), ("bez_walk", True), ("bez_orient", False), ("bez_orient", True)]
+
+
+@pytest.fixture(scope="module")
+def TG():
+    return np.load(os.path.join(ROOT, "tests", "golden", "tasks_golden.npz"))
+
+
+def make_cfg(n, task="bez_kick", cleats=False, seed=42, **kw):
+    c = abi.default_config(n, seed=seed, **kw)
+    c.task = abi.TASK_IDS[task]
+    if task != "bez_kick":
+        c.max_episode_length = 600      # bez_walk.yaml / bez_orient.yaml: episodeLength_s 10
+        c.goal[:] = [2.0, 0.0]
+        c.goal_angle = 1.5708
+    if cleats:
+        c.flags |= abi.FLAG_CLEATS
+    return c
+
+
+def oracle(n, **kw):
+    from oracle.bez_oracle import Oracle
+    return Oracle(make_cfg(n, **kw))
+
+
+def hip(n, **kw):
+    from tests.sim_adapter import SimAdapter
+    return SimAdapter(make_cfg(n, **kw))
+
+
+def check_cleats_feet(b, G):
+    """compute_feet_sensors_cleats (kick_env.py:1044-1069) on the per-cleat contact rows 13:17 / 25:29 (kick_env.py:187-191)."""
+    assert b.nbe == 30
+    b.set_flags(int(b.cfg.flags)); b.set_obs_calls(1)
+    cf = np.zeros((N, 30, 3), np.float32)
+    cf[:, 13:17] = G["cleats_left"]; cf[:, 25:29] = G["cleats_right"]
+    cf[:, 12] = [3.0, 3.0, 30.0]; cf[:, 24] = [0.0, 0.0, 30.0]   # the foot rows themselves do not matter with cleats
+    b.set_contact_forces(cf.reshape(-1, 3))
+    b.observe_reward()
+    np.testing.assert_array_equal(b.obs[:, 44:52], G["cleats_out"])
+    np.testing.assert_array_equal(b.feet, G["cleats_out"])
+    np.testing.assert_array_equal(b.contact_forces.reshape(N, 30, 3), cf)   # no in-place filter in the cleats variant
+
+
+def check_task(b, G, task, tag):
+    """compute_bez_reward + observation layout of walk_env.py:826-1050 / orient_env.py:719-735,843-1018."""
+    g = lambda k: G["%s_%s_%s" % (task, tag, k)]
+    assert b.nobs == 52 and b.nact == 1
+    b.set_obs_calls(1)
+    root = np.zeros((N, 13), np.float32)
+    root[:, 0:3] = g("root"); root[:, 3:7] = g("q"); root[:, 7:10] = g("v"); root[:, 10:13] = g("w")
+    b.set_root_states(root)
+    dof = np.zeros((N, 18, 2), np.float32); dof[:, :, 0] = g("dof"); dof[:, :, 1] = g("dofv")
+    b.set_dof_state(dof.reshape(-1, 2))
+    b.set_goal(g("goal")); b.set_reset(g("reset")); b.set_progress(g("progress"))
+    b.observe_reward()
+    np.testing.assert_allclose(b.rew, g("rew"), atol=3e-4, rtol=2e-5)   # rewards reach 1000 (win) and 10 * v: relative bar
+    np.testing.assert_array_equal(b.reset_buf, g("rst"))
+    obs = b.obs
+    assert obs.shape == (N, 52)
+    np.testing.assert_array_equal(obs[:, 0:18], g("dof"))
+    np.testing.assert_array_equal(obs[:, 18:36], g("dofv"))
+    np.testing.assert_allclose(obs[:, 42:44], g("off"), atol=1e-5)
+
+
+# ------------------------------------------------------------------ CPU: oracle vs the reference's goldens
+def test_oracle_cleats_feet(TG): check_cleats_feet(oracle(N, cleats=True), TG)
+
+
+@pytest.mark.parametrize("task", ["walk", "orient"])
+@pytest.mark.parametrize("tag", ["normal", "edge"])
+def test_oracle_task_golden(TG, task, tag): check_task(oracle(N, task="bez_" + task), TG, task, tag)
+
+
+def test_oracle_variants_stand_and_report():
+    """Every variant: shapes follow the actor / body counts, the robot stands on zero actions, the weight shows up in the
+    foot rows (default asset) or in the eight cleat rows (cleats asset), the ball row exists only for bez_kick."""
+    for task, cleats in VARIANTS + [("bez_kick", False)]:
+        o = oracle(16, task=task, cleats=cleats)
+        assert o.nact == (2 if task == "bez_kick" else 1) and o.nobs == (54 if task == "bez_kick" else 52)
+        assert o.nbe == (29 if cleats else 21) + (1 if task == "bez_kick" else 0)
+        for t in range(60):
+            o.step(np.zeros((16, 18), np.float32))
+        assert (o.reset_buf == 0).all() or task == "bez_orient"   # bez_orient: heading error 1.57 never "wins", nobody falls
+        cf = o.contact_forces.reshape(16, o.nbe, 3)
+        rows = list(range(13, 17)) + list(range(25, 29)) if cleats else [12, 20]
+        weight = (2.867994 if cleats else 2.827994) * 9.81
+        load = cf[:, rows, 2].sum(1)   # a few reset draws are still settling after one second
+        assert abs(np.median(load) - weight) < 0.01 * weight and (np.abs(load - weight) < 0.3 * weight).all(), load
+        assert o.obs.shape == (16, o.nobs) and o.rigid_body_states.shape == (16 * o.nbe, 13)
+
+
+def test_oracle_walk_goal_is_shared_per_reset_call_and_shard_invariant():
+    """walk_env.py:570-575 gives goal_x[0] / goal_y[0] to EVERY env reset by one reset_idx call: all envs reset in the same
+    step share a goal; the draw is keyed by (seed, call counter), not by how the envs are sharded."""
+    a, b = oracle(32, task="bez_walk", seed=9), oracle(16, task="bez_walk", seed=9, env_id_offset=16)
+    assert np.ptp(a.goal, axis=0).max() == 0 and (np.abs(a.goal) <= 2).all()   # __init__'s reset_idx(all): one goal
+    np.testing.assert_array_equal(a.goal[16:], b.goal)
+    rst = np.zeros(32, np.int64); rst[[3, 20]] = 1
+    a.set_reset(rst); b.set_reset(rst[16:])
+    act = np.zeros((32, 18), np.float32)
+    a.step(act); b.step(act[16:])
+    ga = a.goal
+    assert (ga[3] == ga[20]).all() and not (ga[3] == ga[0]).all()
+    np.testing.assert_array_equal(ga[16:], b.goal)
+
+
+# ------------------------------------------------------------------ GPU: HIP path through the C ABI
+@pytest.mark.gpu
+def test_hip_cleats_feet(TG): check_cleats_feet(hip(N, cleats=True), TG)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("task", ["walk", "orient"])
+@pytest.mark.parametrize("tag", ["normal", "edge"])
+def test_hip_task_golden(TG, task, tag): check_task(hip(N, task="bez_" + task), TG, task, tag)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("task,cleats", VARIANTS)
+def test_hip_variant_step_parity(task, cleats):
+    """The whole fused step of every variant against the oracle, resynchronised each step (same bars as bez_kick)."""
+    n = 128
+    o, g = oracle(n, task=task, cleats=cleats, seed=7), hip(n, task=task, cleats=cleats, seed=7)
+    np.testing.assert_array_equal(o.dof_state, g.dof_state)
+    if task != "bez_kick":
+        np.testing.assert_array_equal(o.goal, g.goal)
+    rng = np.random.default_rng(3)
+    for t in range(25):
+        g.set_root_states(o.root_states); g.set_dof_state(o.dof_state); g.set_contact_forces(o.contact_forces)
+        g.set_targets(o.targets); g.set_reset(o.reset_buf); g.set_progress(o.progress_buf)
+        act = rng.uniform(-1, 1, (n, 18)).astype(np.float32)
+        o.step(act); g.step(act)
+        np.testing.assert_array_equal(g.reset_buf, o.reset_buf)
+        np.testing.assert_array_equal(g.progress_buf, o.progress_buf)
+        do, dg = o.dof_state.reshape(n, 18, 2), g.dof_state.reshape(n, 18, 2)
+        np.testing.assert_allclose(dg[..., 0], do[..., 0], atol=2e-4)
+        np.testing.assert_allclose(dg[..., 1], do[..., 1], atol=2e-2)
+        ro, rg = o.root_states.reshape(n, o.nact, 13), g.root_states.reshape(n, o.nact, 13)
+        np.testing.assert_allclose(rg[..., 0:7], ro[..., 0:7], atol=2e-4)
+        np.testing.assert_allclose(rg[..., 7:13], ro[..., 7:13], atol=2e-2)
+        np.testing.assert_allclose(g.contact_forces, o.contact_forces, rtol=0.02, atol=0.05)
+        np.testing.assert_allclose(g.obs[:, :44], o.obs[:, :44], atol=2e-2)
+        np.testing.assert_allclose(g.rew, o.rew, atol=0.2 if task == "bez_walk" else 2e-3, rtol=1e-3)  # bez_walk: 10 * forward speed
+        if task != "bez_kick":
+            np.testing.assert_array_equal(g.goal, o.goal)
+        if cleats:   # feet flags away from the 1 N threshold
+            fo = np.linalg.norm(o.contact_forces.reshape(n, o.nbe, 3)[:, list(range(13, 17)) + list(range(25, 29))], axis=2)
+            safe = (np.abs(fo - 1.0) > 0.1).all(axis=1)
+            np.testing.assert_array_equal(g.obs[safe, 44:52], o.obs[safe, 44:52])
+    rb_o, rb_g = o.rigid_body_states, g.rigid_body_states
+    assert rb_o.shape == rb_g.shape == (n * o.nbe, 13)
+    g.set_root_states(o.root_states); g.set_dof_state(o.dof_state)
+    np.testing.assert_allclose(g.rigid_body_states[:, 0:3], o.rigid_body_states[:, 0:3], atol=2e-4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("task,cleats", [("bez_walk", False), ("bez_orient", False), ("bez_kick", True)])
+def test_hip_task_env_surface_and_ppo(task, cleats):
+    """Walk/Orient/Kick(cleats) env classes: registry, shapes, a few PPO epochs through the reference's CLI contract."""
+    import torch
+    from bez_isaacgym_amd.ppo.a2c_continuous import A2CAgent
+    from bez_isaacgym_amd.tasks import isaacgym_task_map
+    from bez_isaacgym_amd.utils.config import load_config
+    from bez_isaacgym_amd.utils.rlgames_utils import RLGPUEnv, get_rlgames_env_creator
+    cfg = load_config(["task=%s" % task, "num_envs=256", "headless=True"])
+    cfg["task"]["seed"] = 42
+    cfg["task"]["env"]["asset"]["cleats"] = cleats
+    venv = RLGPUEnv("rlgpu", 256, env_creator=get_rlgames_env_creator(cfg["task"], task, "cuda:0", "cuda:0", 0, True))
+    env = venv.env
+    assert type(env) is isaacgym_task_map[task]
+    nobs = 54 if task == "bez_kick" else 52
+    assert env.num_obs == nobs and env.observation_space.shape == (nobs,) and env.max_episode_length == (900 if task == "bez_kick" else 600)
+    assert env.num_bodies == (29 if cleats else 21)
+    obs = env.reset()["obs"]
+    assert obs.shape == (256, nobs)
+    assert env.rigid_body.shape == (256 * ((29 if cleats else 21) + (1 if task == "bez_kick" else 0)), 13)
+    assert env.goal.shape == (256, 2)
+    if cleats:
+        assert env.left_contact_forces.shape == (256, 4, 3) and env.right_contact_forces.shape == (256, 4, 3)
+    params = cfg["train"]["params"]
+    params["config"].update(minibatch_size=2048, save_frequency=0, save_best_after=10 ** 9)
+    agent = A2CAgent(params, venv, "cuda:0")
+    agent.obs = agent.env_reset()
+    stats = [agent.train_epoch() for _ in range(4)]
+    assert all(np.isfinite([s["kl"], s["a_loss"], s["c_loss"]]).all() for s in stats)
+    assert all(torch.isfinite(p).all() for p in agent.model.parameters())
