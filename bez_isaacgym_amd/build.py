@@ -16,8 +16,12 @@ def _deps():
 
 
 def _flags():
-    return ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fno-slp-vectorize"] + \
-        os.environ.get("BEZ_HIPCC_FLAGS", "").split()
+    return ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-slp-vectorize"] + os.environ.get("BEZ_HIPCC_FLAGS", "").split()
+
+
+def _sources():
+    import glob
+    return sorted(glob.glob(os.path.join(HERE, "csrc", "*.hip")))
 
 
 def source_hash():
@@ -48,11 +52,25 @@ def build(force=False, verbose=False):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     # -fno-slp-vectorize: hipcc's SLP pass packs adjacent scalar f32 ops into v_pk_* and pays for it in v_mov shuffles
     # (23.1k -> 16.4k VALU instructions in the fused kernel, 33.2 -> 29.1 us per step on MI355X)
-    cmd = [hipcc] + _flags() + ["-o", OUT, SRC]
-    if verbose:
-        print(" ".join(cmd))
     if os.path.exists(STAMP):
         os.remove(STAMP)
+    # one translation unit per .hip file, compiled side by side, then linked into the one shared library
+    objdir = os.path.join(HERE, "lib", "obj")
+    os.makedirs(objdir, exist_ok=True)
+    procs, objs = [], []
+    for src in _sources():
+        obj = os.path.join(objdir, os.path.basename(src)[:-4] + ".o")
+        cmd = [hipcc] + _flags() + ["-c", "-o", obj, src]
+        if verbose:
+            print(" ".join(cmd))
+        procs.append((cmd, subprocess.Popen(cmd)))
+        objs.append(obj)
+    for cmd, p in procs:
+        if p.wait() != 0:
+            raise subprocess.CalledProcessError(p.returncode, cmd)
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs
+    if verbose:
+        print(" ".join(cmd))
     subprocess.run(cmd, check=True)
     with open(STAMP, "w") as f:
         f.write(source_hash() + "\n")

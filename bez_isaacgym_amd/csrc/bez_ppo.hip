@@ -1,0 +1,262 @@
+// bez_ppo.hip -- the elementwise / reduction glue of the PPO consumer loop as single gfx950 kernels (C ABI: include/bez_sim.h,
+// "bez_ppo_*").  The MLP forward / backward stays in PyTorch-ROCm (hipBLASLt GEMMs); what is fused here is everything around it
+// that torch would run as ~250 four-microsecond kernels per minibatch step: the observation normaliser (moments, running
+// update, normalise + clamp), the whole PPO loss with its analytic gradient, action sampling and the rollout bookkeeping.
+// Semantics restate rl_games' a2c_continuous (bez_isaacgym_amd/ppo/a2c_continuous.py is the readable reference, and the
+// tests compare these kernels with it term by term).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/bez_sim.h"
+
+namespace {
+
+constexpr int PPO_TB = 256;
+constexpr float LOG_2PI = 1.8378770664093453f;
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// ---- RunningMeanStd (rl_games): per-column sum / sum of squares of x (B,D) in fp64 -> out[0:D], out[D:2D]; out[2D] = B
+__global__ __launch_bounds__(PPO_TB) void rms_moments_kernel(const float* __restrict__ x, int64_t B, int D, double* __restrict__ out) {
+  // 256 threads = 4 row lanes x 64 column lanes (D <= 64)
+  const int col = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  __shared__ double sh[2][4][64];
+  double s1 = 0.0, s2 = 0.0;
+  if (col < D) {
+    for (int64_t r = (int64_t)blockIdx.x * 4 + rl; r < B; r += (int64_t)gridDim.x * 4) {
+      const double v = (double)x[r * D + col];
+      s1 += v; s2 += v * v;
+    }
+  }
+  sh[0][rl][col] = s1; sh[1][rl][col] = s2;
+  __syncthreads();
+  if (rl == 0 && col < D) {
+    s1 = sh[0][0][col] + sh[0][1][col] + sh[0][2][col] + sh[0][3][col];
+    s2 = sh[1][0][col] + sh[1][1][col] + sh[1][2][col] + sh[1][3][col];
+    atomicAdd(&out[col], s1);
+    atomicAdd(&out[D + col], s2);
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) out[2 * D] = (double)B;
+}
+
+// parallel-variance update of (mean, var, count) from the (possibly all-reduced) moments: a2c_continuous.py RunningMeanStd.update
+__global__ void rms_apply_kernel(const double* __restrict__ mom, int D, double* __restrict__ mean, double* __restrict__ var, double* __restrict__ count) {
+  const int c = threadIdx.x;
+  const double n = mom[2 * D], cnt = count[0], tot = cnt + n;
+  if (c < D) {
+    const double b_mean = mom[c] / n;
+    double b_var = mom[D + c] / n - b_mean * b_mean;
+    if (b_var < 0.0) b_var = 0.0;
+    b_var *= n / (n - 1.0 > 1.0 ? n - 1.0 : 1.0);  // unbiased, as torch.var
+    const double delta = b_mean - mean[c];
+    const double m2 = var[c] * cnt + b_var * n + delta * delta * cnt * n / tot;
+    mean[c] += delta * n / tot;
+    var[c] = m2 / tot;
+  }
+  __syncthreads();
+  if (c == 0) count[0] = tot;
+}
+
+// y = clamp((x - mean) / sqrt(var + eps), -5, 5), written as fp32 or fp16 (the autocast input of the first Linear)
+template <typename OUT>
+__global__ __launch_bounds__(PPO_TB) void rms_normalize_kernel(const float* __restrict__ x, int64_t total, int D, const double* __restrict__ mean,
+                                                               const double* __restrict__ var, float eps, OUT* __restrict__ y) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int c = (int)(i % D);
+  const float m = (float)mean[c], v = (float)var[c];
+  float t = (x[i] - m) / sqrtf(v + eps);
+  t = fminf(fmaxf(t, -5.0f), 5.0f);
+  y[i] = (OUT)t;
+}
+
+// ---- action sampling (rollout): a = mu + exp(logstd) * noise; neglogp(a); env action = clamp(a, -1, 1)
+__global__ __launch_bounds__(PPO_TB) void ppo_sample_kernel(const float* __restrict__ mu, const float* __restrict__ logstd, const float* __restrict__ noise,
+                                                            int64_t N, int A, float* __restrict__ act, float* __restrict__ act_env,
+                                                            float* __restrict__ neglogp, float* __restrict__ sigma_out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  float acc = 0.f, ls = 0.f;
+  for (int j = 0; j < A; ++j) {
+    const float l = logstd[j], s = expf(l), z = noise[i * A + j];
+    const float a = fmaf(s, z, mu[i * A + j]);
+    act[i * A + j] = a;
+    act_env[i * A + j] = fminf(fmaxf(a, -1.0f), 1.0f);
+    sigma_out[i * A + j] = s;
+    const float zz = (a - mu[i * A + j]) / s;  // as the reference computes it from the stored action
+    acc = fmaf(zz, zz, acc); ls += l;
+  }
+  neglogp[i] = 0.5f * acc + 0.5f * LOG_2PI * (float)A + ls;
+}
+
+// ---- rollout bookkeeping of one env step (a2c_continuous.py _rollout_impl): shaped reward with the time-out bootstrap, done
+// flags as floats, running episode return / length and the finished-episode statistics
+__global__ __launch_bounds__(PPO_TB) void ppo_rollout_post_kernel(const float* __restrict__ rew, const int64_t* __restrict__ dones, const int64_t* __restrict__ timeouts,
+                                                                  const float* __restrict__ values, int64_t N, float reward_scale, float gamma, int bootstrap,
+                                                                  float* __restrict__ shaped, float* __restrict__ dones_f, float* __restrict__ cur_rew,
+                                                                  float* __restrict__ cur_len, double* __restrict__ ep_stats) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  double c = 0.0, r = 0.0, l = 0.0;
+  if (i < N) {
+    const float rw = rew[i];
+    float s = rw * reward_scale;
+    if (bootstrap) s += gamma * values[i] * (float)timeouts[i];
+    shaped[i] = s;
+    const float d = (float)dones[i];
+    dones_f[i] = d;
+    const float cr = cur_rew[i] + rw, cl = cur_len[i] + 1.0f;
+    c = d; r = cr * d; l = cl * d;
+    cur_rew[i] = cr * (1.0f - d); cur_len[i] = cl * (1.0f - d);
+  }
+  c = wave_sum(c); r = wave_sum(r); l = wave_sum(l);
+  if ((threadIdx.x & 63) == 0 && c != 0.0) { atomicAdd(&ep_stats[0], c); atomicAdd(&ep_stats[1], r); atomicAdd(&ep_stats[2], l); }
+}
+
+// ---- the PPO loss of one minibatch and its gradient with respect to the network outputs, in one pass.
+//   loss = mean(a_loss) + 0.5 * critic_coef * mean(c_loss) - entropy_coef * mean(entropy) + bounds_coef * mean(b_loss)
+// stats (atomically accumulated, caller zeroes): [sum a_loss, sum c_loss, sum b_loss, sum kl, sum entropy]
+// grad_mu / grad_value are d(loss)/d(mu), d(loss)/d(value) times *scale (GradScaler's loss scale, a device scalar; null = 1);
+// grad_logstd (A) is accumulated atomically (caller zeroes).
+__global__ __launch_bounds__(PPO_TB) void ppo_loss_kernel(const float* __restrict__ mu, const float* __restrict__ logstd, const float* __restrict__ value,
+                                                          const float* __restrict__ act, const float* __restrict__ old_logp, const float* __restrict__ adv,
+                                                          const float* __restrict__ old_value, const float* __restrict__ ret, const float* __restrict__ old_mu,
+                                                          const float* __restrict__ old_sigma, int64_t B, int A, float e_clip, float critic_coef,
+                                                          float entropy_coef, float bounds_coef, int clip_value, const float* __restrict__ scale,
+                                                          float* __restrict__ grad_mu, float* __restrict__ grad_value, float* __restrict__ grad_logstd,
+                                                          float* __restrict__ stats) {
+  constexpr int AMAX = 32;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool on = i < B;
+  const float S = scale ? scale[0] : 1.0f, invB = 1.0f / (float)B;
+  float a_l = 0.f, c_l = 0.f, b_l = 0.f, kl = 0.f, ent = 0.f;
+  float gls[AMAX];
+#pragma unroll
+  for (int j = 0; j < AMAX; ++j) gls[j] = 0.f;
+  if (on) {
+    float z[AMAX], sg[AMAX];
+    float acc = 0.f, ls = 0.f;
+    for (int j = 0; j < A; ++j) {
+      const float l = logstd[j], s = expf(l), m = mu[i * A + j];
+      sg[j] = s;
+      z[j] = (act[i * A + j] - m) / s;
+      acc = fmaf(z[j], z[j], acc); ls += l;
+      ent += 0.5f + 0.5f * LOG_2PI + l;
+      // policy_kl(current, old)
+      const float s1 = old_sigma[i * A + j], dm = old_mu[i * A + j] - m;
+      kl += logf(s1 / s + 1e-5f) + (s * s + dm * dm) / (2.0f * (s1 * s1 + 1e-5f)) - 0.5f;
+    }
+    const float neglogp = 0.5f * acc + 0.5f * LOG_2PI * (float)A + ls;
+    const float ratio = expf(old_logp[i] - neglogp), ad = adv[i];
+    const float rc = fminf(fmaxf(ratio, 1.0f - e_clip), 1.0f + e_clip);
+    const float l1 = -ad * ratio, l2 = -ad * rc;
+    a_l = fmaxf(l1, l2);
+    // d a_loss / d ratio (torch.max splits ties evenly: with an unclipped ratio both branches carry -adv)
+    const bool unclipped = (ratio >= 1.0f - e_clip) && (ratio <= 1.0f + e_clip);
+    float g_ratio;
+    if (l1 > l2) g_ratio = -ad;
+    else if (l1 < l2) g_ratio = unclipped ? -ad : 0.f;
+    else g_ratio = 0.5f * (-ad) + 0.5f * (unclipped ? -ad : 0.f);
+    const float g_nlp = -ratio * g_ratio;  // d a_loss / d neglogp
+    // value loss
+    const float v = value[i], ov = old_value[i], rt = ret[i];
+    float g_v;
+    if (clip_value) {
+      const float dv = v - ov, dvc = fminf(fmaxf(dv, -e_clip), e_clip), vc = ov + dvc;
+      const float q1 = (v - rt) * (v - rt), q2 = (vc - rt) * (vc - rt);
+      c_l = fmaxf(q1, q2);
+      const bool vin = (dv >= -e_clip) && (dv <= e_clip);
+      const float g1 = 2.0f * (v - rt), g2 = vin ? 2.0f * (vc - rt) : 0.f;
+      g_v = q1 > q2 ? g1 : (q1 < q2 ? g2 : 0.5f * (g1 + g2));
+    } else {
+      c_l = (rt - v) * (rt - v);
+      g_v = 2.0f * (v - rt);
+    }
+    grad_value[i] = 0.5f * critic_coef * g_v * invB * S;
+    for (int j = 0; j < A; ++j) {
+      const float m = mu[i * A + j];
+      const float hi = fmaxf(m - 1.1f, 0.f), lo = fminf(m + 1.1f, 0.f);
+      b_l += hi * hi + lo * lo;
+      const float g_b = bounds_coef > 0.f ? bounds_coef * 2.0f * (hi + lo) : 0.f;
+      // d neglogp / d mu_j = -z_j / sigma_j ; d neglogp / d logstd_j = 1 - z_j^2
+      grad_mu[i * A + j] = (g_nlp * (-z[j] / sg[j]) + g_b) * invB * S;
+      gls[j] = (g_nlp * (1.0f - z[j] * z[j]) - entropy_coef) * invB * S;
+    }
+    if (!(bounds_coef > 0.f)) b_l = 0.f;
+  }
+  for (int j = 0; j < A; ++j) {
+    const float g = wave_sum(gls[j]);
+    if ((threadIdx.x & 63) == 0) atomicAdd(&grad_logstd[j], g);
+  }
+  a_l = wave_sum(a_l); c_l = wave_sum(c_l); b_l = wave_sum(b_l); kl = wave_sum(kl); ent = wave_sum(ent);
+  if ((threadIdx.x & 63) == 0) {
+    atomicAdd(&stats[0], a_l); atomicAdd(&stats[1], c_l); atomicAdd(&stats[2], b_l); atomicAdd(&stats[3], kl); atomicAdd(&stats[4], ent);
+  }
+}
+
+int launch_ok() { return hipGetLastError() == hipSuccess ? 0 : -2; }
+unsigned nblk(int64_t n) { return (unsigned)((n + PPO_TB - 1) / PPO_TB); }
+
+}  // namespace
+
+extern "C" {
+
+int bez_ppo_rms_moments(const float* x_dev, int64_t rows, int32_t cols, double* moments_dev, void* stream) {
+  if (!x_dev || !moments_dev || rows <= 0 || cols <= 0 || cols > 64) return -1;
+  (void)hipMemsetAsync(moments_dev, 0, (size_t)(2 * cols + 1) * sizeof(double), (hipStream_t)stream);
+  unsigned g = (unsigned)((rows + 127) / 128);
+  if (g > 1024) g = 1024;
+  hipLaunchKernelGGL(rms_moments_kernel, dim3(g), dim3(PPO_TB), 0, (hipStream_t)stream, x_dev, rows, (int)cols, moments_dev);
+  return launch_ok();
+}
+int bez_ppo_rms_apply(const double* moments_dev, int32_t cols, double* mean_dev, double* var_dev, double* count_dev, void* stream) {
+  if (!moments_dev || !mean_dev || !var_dev || !count_dev || cols <= 0 || cols > 64) return -1;
+  hipLaunchKernelGGL(rms_apply_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, moments_dev, (int)cols, mean_dev, var_dev, count_dev);
+  return launch_ok();
+}
+int bez_ppo_rms_normalize(const float* x_dev, int64_t rows, int32_t cols, const double* mean_dev, const double* var_dev, float eps, void* y_dev,
+                          int32_t out_f16, void* stream) {
+  if (!x_dev || !mean_dev || !var_dev || !y_dev || rows <= 0 || cols <= 0) return -1;
+  const int64_t total = rows * cols;
+  if (out_f16) hipLaunchKernelGGL(rms_normalize_kernel<_Float16>, dim3(nblk(total)), dim3(PPO_TB), 0, (hipStream_t)stream, x_dev, total, (int)cols, mean_dev, var_dev, eps, (_Float16*)y_dev);
+  else hipLaunchKernelGGL(rms_normalize_kernel<float>, dim3(nblk(total)), dim3(PPO_TB), 0, (hipStream_t)stream, x_dev, total, (int)cols, mean_dev, var_dev, eps, (float*)y_dev);
+  return launch_ok();
+}
+int bez_ppo_sample(const float* mu_dev, const float* logstd_dev, const float* noise_dev, int64_t n, int32_t num_actions, float* actions_dev,
+                   float* env_actions_dev, float* neglogp_dev, float* sigma_dev, void* stream) {
+  if (!mu_dev || !logstd_dev || !noise_dev || !actions_dev || !env_actions_dev || !neglogp_dev || !sigma_dev || n <= 0 || num_actions <= 0) return -1;
+  hipLaunchKernelGGL(ppo_sample_kernel, dim3(nblk(n)), dim3(PPO_TB), 0, (hipStream_t)stream, mu_dev, logstd_dev, noise_dev, n, (int)num_actions, actions_dev,
+                     env_actions_dev, neglogp_dev, sigma_dev);
+  return launch_ok();
+}
+int bez_ppo_rollout_post(const float* rew_dev, const int64_t* dones_dev, const int64_t* timeouts_dev, const float* values_dev, int64_t n, float reward_scale,
+                         float gamma, int32_t value_bootstrap, float* shaped_dev, float* dones_f_dev, float* cur_rew_dev, float* cur_len_dev,
+                         double* ep_stats_dev, void* stream) {
+  if (!rew_dev || !dones_dev || !timeouts_dev || !values_dev || !shaped_dev || !dones_f_dev || !cur_rew_dev || !cur_len_dev || !ep_stats_dev || n <= 0) return -1;
+  hipLaunchKernelGGL(ppo_rollout_post_kernel, dim3(nblk(n)), dim3(PPO_TB), 0, (hipStream_t)stream, rew_dev, dones_dev, timeouts_dev, values_dev, n, reward_scale,
+                     gamma, (int)value_bootstrap, shaped_dev, dones_f_dev, cur_rew_dev, cur_len_dev, ep_stats_dev);
+  return launch_ok();
+}
+int bez_ppo_loss(const float* mu_dev, const float* logstd_dev, const float* value_dev, const float* actions_dev, const float* old_logp_dev,
+                 const float* adv_dev, const float* old_value_dev, const float* returns_dev, const float* old_mu_dev, const float* old_sigma_dev,
+                 int64_t batch, int32_t num_actions, float e_clip, float critic_coef, float entropy_coef, float bounds_coef, int32_t clip_value,
+                 const float* loss_scale_dev, float* grad_mu_dev, float* grad_value_dev, float* grad_logstd_dev, float* stats_dev, void* stream) {
+  if (!mu_dev || !logstd_dev || !value_dev || !actions_dev || !old_logp_dev || !adv_dev || !old_value_dev || !returns_dev || !old_mu_dev ||
+      !old_sigma_dev || !grad_mu_dev || !grad_value_dev || !grad_logstd_dev || !stats_dev || batch <= 0 || num_actions <= 0 || num_actions > 32) return -1;
+  (void)hipMemsetAsync(grad_logstd_dev, 0, (size_t)num_actions * sizeof(float), (hipStream_t)stream);
+  (void)hipMemsetAsync(stats_dev, 0, 5 * sizeof(float), (hipStream_t)stream);
+  hipLaunchKernelGGL(ppo_loss_kernel, dim3(nblk(batch)), dim3(PPO_TB), 0, (hipStream_t)stream, mu_dev, logstd_dev, value_dev, actions_dev, old_logp_dev, adv_dev,
+                     old_value_dev, returns_dev, old_mu_dev, old_sigma_dev, batch, (int)num_actions, e_clip, critic_coef, entropy_coef, bounds_coef,
+                     (int)clip_value, loss_scale_dev, grad_mu_dev, grad_value_dev, grad_logstd_dev, stats_dev);
+  return launch_ok();
+}
+
+}  // extern "C"

@@ -10,8 +10,8 @@
 
 #include <cstdlib>
 
-#include "bez_kernel_ws.h"
 #include "bez_kernels.h"
+#include "bez_launch.h"
 
 using namespace bez;
 
@@ -298,23 +298,17 @@ int launch_step(BezSim* s, const float* actions, hipStream_t stream, bool obs_on
   Params P = make_params(s, actions);
   P.obs_only = obs_only ? 1 : 0;
   if (POST && !obs_only) goal_draw(s->cfg.seed, s->post_calls++, 0, P.goal_draw);  // the reset inside this post_physics_step
-  const bool dr = has_dr(s);
+  const bool dr = has_dr(s) || s->cleats;
   if constexpr (SIM && PRE == POST) {
     if (use_ws_kernel()) {
-      dim3 grid((s->n + WS_ENVS - 1) / WS_ENVS), block(WS_BLOCK);
-      if (s->cleats) hipLaunchKernelGGL((step_kernel_ws<PRE, POST, true, true>), grid, block, 0, stream, P);
-      else if (dr) hipLaunchKernelGGL((step_kernel_ws<PRE, POST, true, false>), grid, block, 0, stream, P);
-      else hipLaunchKernelGGL((step_kernel_ws<PRE, POST, false, false>), grid, block, 0, stream, P);
+      bez::launch_step_ws(P, PRE, dr, s->cleats, stream);
       hipError_t e = hipGetLastError();
       if (e != hipSuccess) return fail(s, -2, "step_kernel_ws launch", e);
       if (POST) s->obs_calls += 1;
       return 0;
     }
   }
-  dim3 grid(grid_for(s->n)), block(BLOCK);
-  if (s->cleats) hipLaunchKernelGGL((step_kernel<PRE, SIM, POST, true, true>), grid, block, 0, stream, P);
-  else if (dr) hipLaunchKernelGGL((step_kernel<PRE, SIM, POST, true, false>), grid, block, 0, stream, P);
-  else hipLaunchKernelGGL((step_kernel<PRE, SIM, POST, false, false>), grid, block, 0, stream, P);
+  bez::launch_step_lane(P, PRE, SIM, POST, dr, s->cleats, stream);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(s, -2, "step kernel launch", e);
   if (POST) s->obs_calls += 1;

@@ -254,6 +254,14 @@ class A2CAgent:
         self.current_lengths = torch.zeros(self.num_actors, device=self.device)
         self.dones = torch.ones(self.num_actors, dtype=torch.float32, device=self.device)
         self._flat_grad = None
+        # HIP glue kernels (csrc/bez_ppo.hip) for everything around the MLP: on by default on a GPU, `fused_ops: False` keeps
+        # the plain torch formulation (the one the CPU path runs and the kernels are tested against)
+        self.fused = bool(on_gpu and c.get("fused_ops", True))
+        if self.fused:
+            from . import fused as F
+            self._F = F
+            red = (lambda t: dist.all_reduce(t)) if _dist_on() else None
+            self._f_obs_rms = F.FusedRunningMeanStd(self.running_mean_std, red) if self.normalize_input else None
         if _dist_on():  # identical replicas (hvd.broadcast_parameters equivalent)
             for p in self.model.parameters():
                 dist.broadcast(p.data, src=0)
@@ -302,12 +310,40 @@ class A2CAgent:
         self.ep_stats = torch.zeros(3, device=dev, dtype=torch.float64)  # [finished episodes, sum of returns, sum of lengths]
         self.kl_acc = torch.zeros(self.mini_epochs, device=dev)
         self.loss_acc = torch.zeros(2, device=dev)
+        if self.fused:
+            hd = torch.float16 if self.mixed_precision else torch.float32
+            A, D, MB = self.act_dim, self.obs_dim, self.minibatch_size
+            self._fx = dict(obs_n=torch.zeros(N, D, device=dev, dtype=hd), env_act=z(N, A), noise=z(N, A),
+                            mb_obs_n=torch.zeros(MB, D, device=dev, dtype=hd), gmu=z(MB, A), gval=z(MB, 1), glog=z(A), stats=z(5))
+
+    @torch.no_grad()
+    def _rollout_steps_fused(self):
+        """The horizon loop with the HIP glue kernels: normalise (1 launch), MLP forward (torch), sample + neglogp + clamp
+        (1 launch), env step (1 launch), reward shaping + episode statistics (1 launch)."""
+        mb, F, fx = self.mb, self._F, self._fx
+        net = self.model.a2c_network
+        self.model.eval()
+        for n in range(self.horizon):
+            x = self._f_obs_rms.normalize(self.obs, fx["obs_n"]) if self.normalize_input else self.obs
+            with torch.autocast("cuda", dtype=torch.float16, enabled=self.mixed_precision):
+                mu, _logstd, value = net(x)
+            mu32, v32 = mu.float().contiguous(), value.float()
+            if self.normalize_value:
+                self.value_mean_std.eval()
+                v32 = self.value_mean_std(v32, True)
+            mb["obs"][n].copy_(self.obs); mb["dones"][n].copy_(self.dones); mb["mu"][n].copy_(mu32); mb["val"][n].copy_(v32)
+            fx["noise"].normal_()
+            F.sample(mu32, net.sigma.detach(), fx["noise"], mb["act"][n], fx["env_act"], mb["neglogp"][n], mb["sigma"][n])
+            obs_dict, rew, dones, infos = self.vec_env.step(fx["env_act"])
+            F.rollout_post(rew, dones, infos["time_outs"], mb["val"][n], self.reward_scale, self.gamma, self.value_bootstrap and "time_outs" in infos,
+                           mb["rew"][n], self.dones, self.current_rewards, self.current_lengths, self.ep_stats)
+            self.obs.copy_(obs_dict["obs"])
 
     @torch.no_grad()
     def _rollout_impl(self):
         """horizon_length env steps + GAE + dataset preparation; device ops only (capturable)."""
         mb, dev = self.mb, self.device
-        for n in range(self.horizon):
+        for n in range(0 if self.fused else self.horizon):
             res = self.get_action_values(self.obs)
             mb["obs"][n].copy_(self.obs); mb["dones"][n].copy_(self.dones)
             mb["act"][n].copy_(res["actions"]); mb["mu"][n].copy_(res["mus"]); mb["sigma"][n].copy_(res["sigmas"])
@@ -328,6 +364,8 @@ class A2CAgent:
             not_done = 1.0 - self.dones
             self.current_rewards *= not_done
             self.current_lengths *= not_done
+        if self.fused:
+            self._rollout_steps_fused()
         last_values = self.get_values(self.obs)
         advs = discount_values(self.gamma, self.tau, self.dones, last_values, mb["dones"], mb["val"], mb["rew"])
         returns = advs + mb["val"]
@@ -393,8 +431,50 @@ class A2CAgent:
             p.grad.copy_(self._flat_grad[off:off + p.numel()].view_as(p.grad))
             off += p.numel()
 
+    def _calc_gradients_fused(self, mb, kl_out, loss_out):
+        """calc_gradients with the HIP glue kernels: observation moments + running update + normalise (3 launches), MLP
+        forward (torch), the whole loss and its gradient w.r.t. mu / value / log-std (1 launch), MLP backward (torch), then
+        the same all-reduce / unscale / clip / Adam / scaler tail."""
+        F, fx, net = self._F, self._fx, self.model.a2c_network
+        self.model.train()
+        obs = mb["obs"]
+        if self.normalize_input:
+            self._f_obs_rms.update(obs)
+            obs = self._f_obs_rms.normalize(obs, fx["mb_obs_n"])
+        with torch.autocast("cuda", dtype=torch.float16, enabled=self.mixed_precision):
+            mu, _logstd, value = net(obs)
+        mu32, v32 = mu.float().contiguous(), value.float().contiguous()
+        scale = None
+        if self.scaler.is_enabled():
+            if self.scaler._scale is None:
+                self.scaler._lazy_init_scale_growth_tracker(self.device)
+            scale = self.scaler._scale
+        F.loss(mu32.detach(), net.sigma.detach(), v32.detach(), mb, self.e_clip, self.critic_coef, self.entropy_coef, self.bounds_loss_coef,
+               self.clip_value, scale, fx["gmu"], fx["gval"], fx["glog"], fx["stats"])
+        self.optimizer.zero_grad(set_to_none=True)
+        torch.autograd.backward([mu32, v32], [fx["gmu"], fx["gval"]])
+        net.sigma.grad = fx["glog"]  # rewritten by the next loss launch, after the optimiser has consumed it
+        if _dist_on():
+            self._allreduce_grads()
+        if self.truncate_grads:
+            self.scaler.unscale_(self.optimizer)
+            nn.utils.clip_grad_norm_(self.model.parameters(), self.grad_norm)
+        self.scaler.step(self.optimizer)
+        self.scaler.update()
+        with torch.no_grad():
+            inv_b = 1.0 / float(mu32.shape[0])
+            kl = fx["stats"][3] * inv_b
+            if _dist_on():
+                kl = kl.clone()
+                dist.all_reduce(kl)
+                kl /= dist.get_world_size()
+            kl_out.add_(kl / self.num_minibatches)
+            loss_out[0] += fx["stats"][0] * inv_b; loss_out[1] += fx["stats"][1] * inv_b
+
     def calc_gradients(self, mb, kl_out, loss_out):
         """One optimiser step on minibatch `mb`; device ops only.  KL is written to kl_out (0-dim view), losses added to loss_out."""
+        if self.fused:
+            return self._calc_gradients_fused(mb, kl_out, loss_out)
         self.model.train()
         if self.normalize_input:
             self.running_mean_std.train()

@@ -1,0 +1,94 @@
+"""ctypes bindings of the PPO glue kernels (include/bez_sim.h "bez_ppo_*", csrc/bez_ppo.hip) and the torch-side plumbing
+around them: device pointers, the current HIP stream, and one autograd bridge (the fused loss returns d loss / d mu,
+d loss / d value and d loss / d log-std; the MLP's own backward stays PyTorch's).  HIP only -- the CPU path of the agent
+keeps the plain torch formulation these kernels are tested against."""
+import ctypes as C
+
+import torch
+
+from ..sim import load_library
+
+_vp, _i32, _i64, _f = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+_SIGS = {
+    "bez_ppo_rms_moments": [_vp, _i64, _i32, _vp, _vp],
+    "bez_ppo_rms_apply": [_vp, _i32, _vp, _vp, _vp, _vp],
+    "bez_ppo_rms_normalize": [_vp, _i64, _i32, _vp, _vp, _f, _vp, _i32, _vp],
+    "bez_ppo_sample": [_vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp],
+    "bez_ppo_rollout_post": [_vp, _vp, _vp, _vp, _i64, _f, _f, _i32, _vp, _vp, _vp, _vp, _vp, _vp],
+    "bez_ppo_loss": [_vp] * 10 + [_i64, _i32, _f, _f, _f, _f, _i32] + [_vp] * 6,
+}
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        l = load_library()
+        for name, args in _SIGS.items():
+            fn = getattr(l, name)
+            fn.restype, fn.argtypes = C.c_int, args
+        _lib = l
+    return _lib
+
+
+def _p(t, dtype=torch.float32):
+    assert t.is_cuda and t.dtype == dtype and t.is_contiguous(), (t.dtype, t.is_contiguous())
+    return C.c_void_p(t.data_ptr())
+
+
+def _stream(t):
+    return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def _chk(rc, what):
+    if rc != 0:
+        raise RuntimeError("%s failed (%d)" % (what, rc))
+
+
+class FusedRunningMeanStd:
+    """The three kernels behind RunningMeanStd.forward (train: moments -> [all-reduce] -> apply -> normalise)."""
+
+    def __init__(self, rms, reduce_fn=None):
+        self.rms = rms
+        d = rms.running_mean.numel()
+        self.d = d
+        self.mom = torch.zeros(2 * d + 1, dtype=torch.float64, device=rms.running_mean.device)
+        self.reduce_fn = reduce_fn  # e.g. dist.all_reduce for data-parallel training
+
+    def update(self, x):
+        rows = x.numel() // self.d
+        _chk(lib().bez_ppo_rms_moments(_p(x), rows, self.d, _p(self.mom, torch.float64), _stream(x)), "bez_ppo_rms_moments")
+        if self.reduce_fn is not None:
+            self.reduce_fn(self.mom)
+        r = self.rms
+        _chk(lib().bez_ppo_rms_apply(_p(self.mom, torch.float64), self.d, _p(r.running_mean, torch.float64), _p(r.running_var, torch.float64),
+                                     _p(r.count.view(1), torch.float64), _stream(x)), "bez_ppo_rms_apply")
+
+    def normalize(self, x, out):
+        rows = x.numel() // self.d
+        r = self.rms
+        _chk(lib().bez_ppo_rms_normalize(_p(x), rows, self.d, _p(r.running_mean, torch.float64), _p(r.running_var, torch.float64),
+                                         float(r.epsilon), C.c_void_p(out.data_ptr()), 1 if out.dtype == torch.float16 else 0, _stream(x)),
+             "bez_ppo_rms_normalize")
+        return out
+
+
+def sample(mu, logstd, noise, actions, env_actions, neglogp, sigma):
+    n, a = mu.shape
+    _chk(lib().bez_ppo_sample(_p(mu), _p(logstd), _p(noise), n, a, _p(actions), _p(env_actions), _p(neglogp), _p(sigma), _stream(mu)), "bez_ppo_sample")
+
+
+def rollout_post(rew, dones, timeouts, values, reward_scale, gamma, bootstrap, shaped, dones_f, cur_rew, cur_len, ep_stats):
+    n = rew.numel()
+    _chk(lib().bez_ppo_rollout_post(_p(rew), _p(dones, torch.int64), _p(timeouts, torch.int64), _p(values), n, float(reward_scale), float(gamma),
+                                    1 if bootstrap else 0, _p(shaped), _p(dones_f), _p(cur_rew), _p(cur_len), _p(ep_stats, torch.float64), _stream(rew)),
+         "bez_ppo_rollout_post")
+
+
+def loss(mu, logstd, value, mb, e_clip, critic_coef, entropy_coef, bounds_coef, clip_value, scale, gmu, gval, glog, stats):
+    """stats[5] <- sums of a_loss, c_loss, b_loss, kl, entropy; gmu / gval / glog <- gradient of the mean loss (x loss scale)."""
+    b, a = mu.shape
+    _chk(lib().bez_ppo_loss(_p(mu), _p(logstd), _p(value), _p(mb["actions"]), _p(mb["old_logp"]), _p(mb["advantages"]), _p(mb["old_values"]),
+                            _p(mb["returns"]), _p(mb["mu"]), _p(mb["sigma"]), b, a, float(e_clip), float(critic_coef), float(entropy_coef),
+                            float(bounds_coef), 1 if clip_value else 0, None if scale is None else _p(scale), _p(gmu), _p(gval), _p(glog), _p(stats),
+                            _stream(mu)), "bez_ppo_loss")

@@ -12,6 +12,40 @@ import sys
 import yaml
 
 
+def play(cfg, vec_env, params, games=None, max_steps=None, log=print):
+    """test=True: the reference's play loop (play.py:125-236, utils/players.py:46-72) -- restore a checkpoint into the
+    deterministic continuous player and run whole episodes in all envs; returns (mean reward, mean steps, games)."""
+    import torch
+    from .utils.player import PpoPlayerContinuous
+    env = vec_env.env
+    path = params.get("load_path")
+    if not path:
+        raise ValueError("test=True needs checkpoint=<file> (an rl_games / this build's .pth, or the numeric .npz fixture)")
+    obs_dim, act_dim = env.observation_space.shape[0], env.action_space.shape[0]
+    player = PpoPlayerContinuous(path, env.rl_device, obs_dim, act_dim, tuple(params["network"]["mlp"]["units"]))
+    pc = params["config"].get("player", {}) or {}
+    n_games = int(games or pc.get("games_num", 2000))                    # rl_games BasePlayer defaults [ext]
+    max_steps = int(max_steps or pc.get("max_steps", 27000 // 4))
+    obs = env.reset()["obs"]
+    n = env.num_envs
+    cr, steps = torch.zeros(n, device=env.rl_device), torch.zeros(n, device=env.rl_device)
+    sum_r = sum_s = 0.0
+    played = 0
+    for _ in range(max_steps):
+        obs_d, r, done, _info = env.step(player.get_action(obs))
+        obs = obs_d["obs"]
+        cr += r; steps += 1
+        idx = done.nonzero(as_tuple=False).squeeze(-1)
+        if idx.numel():
+            sum_r += float(cr[idx].sum()); sum_s += float(steps[idx].sum()); played += int(idx.numel())
+            cr[idx] = 0; steps[idx] = 0
+            if played >= n_games:
+                break
+    mean_r, mean_s = sum_r / max(played, 1), sum_s / max(played, 1)
+    log("av reward: %.3f av steps: %.1f games: %d" % (mean_r, mean_s, played))  # play.py:227-231 wording
+    return mean_r, mean_s, played
+
+
 def launch(argv=None):
     import torch
     import torch.distributed as dist
@@ -49,10 +83,14 @@ def launch(argv=None):
             yaml.safe_dump(cfg, f)
         writer = RLGPUAlgoObserver(run_dir)
     agent = A2CAgent(params, vec_env, vec_env.env.rl_device, writer=writer, rank=rank, world=world if multi_gpu else 1)
-    if params.get("load_checkpoint"):
+    if params.get("load_checkpoint") and not cfg.get("test"):
         agent.restore(params["load_path"])
     if cfg.get("test"):
-        raise NotImplementedError("play/inference (reference play.py) is listed as 'next' in DESIGN.md")
+        result = play(cfg, vec_env, params)
+        if multi_gpu:
+            dist.barrier()
+            dist.destroy_process_group()
+        return result
     result = agent.train()
     if multi_gpu:
         dist.barrier()

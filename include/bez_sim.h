@@ -210,6 +210,35 @@ int bez_sim_calibrate(void* buf_dev, uint64_t n_floats, int32_t write, void* str
  * measured with HIP events recorded on that same stream (bench.py roofline leg). */
 int bez_sim_time_steps(BezSim* sim, const float* actions_dev, int32_t n_steps, void* stream, float* avg_ms);
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * PPO glue kernels (bez_ppo.hip).  The reference trains through rl_games' a2c_continuous (call sites train.py:89-113,
+ * hyper-parameters cfg/train/bez_kickPPO.yaml); its MLP stays in PyTorch-ROCm, these entry points replace the ~250 tiny
+ * elementwise / reduction launches per minibatch step around it.  All pointers are device memory, fp32 unless noted. */
+
+/* RunningMeanStd (normalize_input / normalize_value, bez_kickPPO.yaml:51-52): moments[0:D] = column sums, [D:2D] = sums of
+ * squares, [2D] = rows, in fp64 (the caller may all-reduce them across ranks before applying). */
+int bez_ppo_rms_moments(const float* x_dev, int64_t rows, int32_t cols, double* moments_dev, void* stream);
+int bez_ppo_rms_apply(const double* moments_dev, int32_t cols, double* mean_dev, double* var_dev, double* count_dev, void* stream);
+/* y = clamp((x - mean) / sqrt(var + eps), -5, 5); y_dev is fp32 or (out_f16 != 0) fp16 */
+int bez_ppo_rms_normalize(const float* x_dev, int64_t rows, int32_t cols, const double* mean_dev, const double* var_dev, float eps,
+                          void* y_dev, int32_t out_f16, void* stream);
+/* rollout: actions = mu + exp(logstd) * noise, neglogp(actions), env_actions = clamp(actions, -1, 1), sigma broadcast */
+int bez_ppo_sample(const float* mu_dev, const float* logstd_dev, const float* noise_dev, int64_t n, int32_t num_actions,
+                   float* actions_dev, float* env_actions_dev, float* neglogp_dev, float* sigma_dev, void* stream);
+/* rollout bookkeeping of one env step: shaped = rew * reward_scale (+ gamma * value * time_out, value_bootstrap),
+ * dones as float, running episode return / length, ep_stats[3] += (finished, sum of returns, sum of lengths) in fp64 */
+int bez_ppo_rollout_post(const float* rew_dev, const int64_t* dones_dev, const int64_t* timeouts_dev, const float* values_dev, int64_t n,
+                         float reward_scale, float gamma, int32_t value_bootstrap, float* shaped_dev, float* dones_f_dev,
+                         float* cur_rew_dev, float* cur_len_dev, double* ep_stats_dev, void* stream);
+/* PPO minibatch loss (clipped surrogate, clipped value loss, entropy, bounds loss) AND its gradient w.r.t. the network
+ * outputs mu (B,A), value (B) and the log-std parameter (A), multiplied by *loss_scale_dev (GradScaler; NULL = 1).
+ * stats_dev[5] = sums of a_loss, c_loss, b_loss, KL(current || old), entropy over the minibatch. */
+int bez_ppo_loss(const float* mu_dev, const float* logstd_dev, const float* value_dev, const float* actions_dev, const float* old_logp_dev,
+                 const float* adv_dev, const float* old_value_dev, const float* returns_dev, const float* old_mu_dev,
+                 const float* old_sigma_dev, int64_t batch, int32_t num_actions, float e_clip, float critic_coef, float entropy_coef,
+                 float bounds_coef, int32_t clip_value, const float* loss_scale_dev, float* grad_mu_dev, float* grad_value_dev,
+                 float* grad_logstd_dev, float* stats_dev, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

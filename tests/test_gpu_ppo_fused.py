@@ -1,0 +1,143 @@
+"""GPU: the PPO glue kernels (csrc/bez_ppo.hip, C ABI bez_ppo_*) against the plain torch formulation of the same
+rl_games a2c_continuous arithmetic (bez_isaacgym_amd/ppo/a2c_continuous.py) -- term by term, then a whole optimiser step."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def test_running_mean_std_kernels():
+    from bez_isaacgym_amd.ppo.a2c_continuous import RunningMeanStd
+    from bez_isaacgym_amd.ppo.fused import FusedRunningMeanStd
+    torch.manual_seed(0)
+    ref, fus = RunningMeanStd((54,)).to(DEV), RunningMeanStd((54,)).to(DEV)
+    f = FusedRunningMeanStd(fus)
+    ref.train()
+    for b in (32768, 4096, 100):
+        x = (torch.randn(b, 54, device=DEV) * torch.linspace(0.1, 5, 54, device=DEV) + 2.0).contiguous()
+        ref(x)
+        f.update(x)
+        np.testing.assert_allclose(fus.running_mean.cpu(), ref.running_mean.cpu(), rtol=1e-12, atol=1e-12)
+        np.testing.assert_allclose(fus.running_var.cpu(), ref.running_var.cpu(), rtol=1e-10)
+        assert float(fus.count) == float(ref.count)
+    ref.eval()
+    y = ref(x)
+    np.testing.assert_allclose(f.normalize(x, torch.empty_like(x)).cpu(), y.cpu(), atol=2e-6)
+    y16 = f.normalize(x, torch.empty(x.shape, device=DEV, dtype=torch.float16))
+    np.testing.assert_allclose(y16.float().cpu(), y.cpu(), atol=3e-3)
+    assert float(y.abs().max()) <= 5.0
+
+
+def test_sample_and_rollout_bookkeeping_kernels():
+    from bez_isaacgym_amd.ppo import fused as F
+    from bez_isaacgym_amd.ppo.a2c_continuous import ModelA2CContinuousLogStd
+    torch.manual_seed(1)
+    n, a = 4096, 18
+    mu, logstd, noise = torch.randn(n, a, device=DEV), torch.randn(a, device=DEV) * 0.5 - 1, torch.randn(n, a, device=DEV)
+    act, env_act, nlp, sig = (torch.empty(n, a, device=DEV), torch.empty(n, a, device=DEV), torch.empty(n, device=DEV), torch.empty(n, a, device=DEV))
+    F.sample(mu, logstd, noise, act, env_act, nlp, sig)
+    ref_act = mu + torch.exp(logstd) * noise
+    np.testing.assert_allclose(act.cpu(), ref_act.cpu(), atol=1e-6)
+    np.testing.assert_allclose(env_act.cpu(), ref_act.clamp(-1, 1).cpu(), atol=1e-6)
+    ref_nlp = ModelA2CContinuousLogStd.neglogp(act, mu, torch.exp(logstd), logstd)
+    np.testing.assert_allclose(nlp.cpu(), ref_nlp.cpu(), rtol=1e-5, atol=1e-4)
+    np.testing.assert_allclose(sig.cpu(), torch.exp(logstd).expand(n, a).cpu(), rtol=1e-6)
+    # one env step of bookkeeping
+    rew = torch.randn(n, device=DEV); dones = (torch.rand(n, device=DEV) < 0.1).long(); tmo = (torch.rand(n, device=DEV) < 0.05).long()
+    val = torch.randn(n, 1, device=DEV)
+    cur_r, cur_l = torch.randn(n, device=DEV), torch.randint(0, 50, (n,), device=DEV).float()
+    r0, l0 = cur_r.clone(), cur_l.clone()
+    shaped, dones_f, stats = torch.empty(n, 1, device=DEV), torch.empty(n, device=DEV), torch.zeros(3, device=DEV, dtype=torch.float64)
+    F.rollout_post(rew, dones, tmo, val, 0.01, 0.99, True, shaped, dones_f, cur_r, cur_l, stats)
+    np.testing.assert_allclose(shaped.cpu(), (rew.unsqueeze(1) * 0.01 + 0.99 * val * tmo.unsqueeze(1).float()).cpu(), atol=1e-6)
+    d = dones.float()
+    np.testing.assert_array_equal(dones_f.cpu(), d.cpu())
+    np.testing.assert_allclose(cur_r.cpu(), ((r0 + rew) * (1 - d)).cpu(), atol=1e-6)
+    np.testing.assert_allclose(cur_l.cpu(), ((l0 + 1) * (1 - d)).cpu(), atol=0)
+    np.testing.assert_allclose(stats.cpu(), torch.stack([d.sum(), ((r0 + rew) * d).sum(), ((l0 + 1) * d).sum()]).double().cpu(), rtol=1e-5)
+
+
+def _torch_loss(mu, logstd, value, mb, e, critic_coef, entropy_coef, bounds_coef, clip_value):
+    from bez_isaacgym_amd.ppo.a2c_continuous import ModelA2CContinuousLogStd, policy_kl
+    sigma = torch.exp(logstd).unsqueeze(0).expand_as(mu)
+    neglogp = ModelA2CContinuousLogStd.neglogp(mb["actions"], mu, sigma, logstd.unsqueeze(0).expand_as(mu))
+    entropy = (0.5 + 0.5 * math.log(2 * math.pi) + logstd.unsqueeze(0).expand_as(mu)).sum(-1)
+    ratio = torch.exp(mb["old_logp"] - neglogp)
+    a_loss = torch.max(-mb["advantages"] * ratio, -mb["advantages"] * torch.clamp(ratio, 1 - e, 1 + e))
+    if clip_value:
+        vclip = mb["old_values"] + (value - mb["old_values"]).clamp(-e, e)
+        c_loss = torch.max((value - mb["returns"]) ** 2, (vclip - mb["returns"]) ** 2)
+    else:
+        c_loss = (mb["returns"] - value) ** 2
+    b_loss = (torch.clamp_min(mu - 1.1, 0.0) ** 2 + torch.clamp_max(mu + 1.1, 0.0) ** 2).sum(-1)
+    loss = a_loss.mean() + 0.5 * c_loss.mean() * critic_coef - entropy.mean() * entropy_coef + b_loss.mean() * bounds_coef
+    kl = policy_kl(mu.detach(), sigma.detach(), mb["mu"], mb["sigma"])
+    return loss, a_loss.mean(), c_loss.mean(), b_loss.mean(), kl, entropy.mean()
+
+
+@pytest.mark.parametrize("clip_value,entropy_coef", [(True, 0.0), (False, 0.01)])
+def test_loss_kernel_value_and_gradient(clip_value, entropy_coef):
+    from bez_isaacgym_amd.ppo import fused as F
+    torch.manual_seed(2)
+    b, a = 32768, 18
+    mu = (torch.randn(b, a, device=DEV) * 0.8).requires_grad_()
+    logstd = (torch.randn(a, device=DEV) * 0.3 - 1.0).requires_grad_()
+    value = torch.randn(b, 1, device=DEV).requires_grad_()
+    old_sigma = torch.exp(logstd.detach() + 0.05 * torch.randn(a, device=DEV)).expand(b, a).contiguous()
+    old_mu = (mu.detach() + 0.05 * torch.randn(b, a, device=DEV)).contiguous()
+    actions = (old_mu + old_sigma * torch.randn(b, a, device=DEV)).contiguous()
+    from bez_isaacgym_amd.ppo.a2c_continuous import ModelA2CContinuousLogStd
+    old_logp = ModelA2CContinuousLogStd.neglogp(actions, old_mu, old_sigma, torch.log(old_sigma)) + 0.3 * torch.randn(b, device=DEV)
+    mb = dict(actions=actions, old_logp=old_logp.contiguous(), advantages=torch.randn(b, device=DEV), old_values=torch.randn(b, 1, device=DEV),
+              returns=torch.randn(b, 1, device=DEV), mu=old_mu, sigma=old_sigma)
+    e, cc, bc = 0.2, 2.0, 0.001
+    loss, a_l, c_l, b_l, kl, ent = _torch_loss(mu, logstd, value, mb, e, cc, entropy_coef, bc, clip_value)
+    S = 1024.0
+    (loss * S).backward()
+    gmu, gval, glog, stats = torch.empty(b, a, device=DEV), torch.empty(b, 1, device=DEV), torch.empty(a, device=DEV), torch.empty(5, device=DEV)
+    F.loss(mu.detach(), logstd.detach(), value.detach(), mb, e, cc, entropy_coef, bc, clip_value, torch.tensor([S], device=DEV), gmu, gval, glog, stats)
+    st = (stats / b).cpu().numpy()
+    np.testing.assert_allclose(st[:5], [float(a_l), float(c_l), float(b_l), float(kl), float(ent)], rtol=2e-4, atol=2e-6)
+    scale = float(mu.grad.abs().max())
+    np.testing.assert_allclose(gmu.cpu(), mu.grad.cpu(), atol=2e-5 * scale, rtol=1e-4)
+    np.testing.assert_allclose(gval.cpu(), value.grad.cpu(), atol=2e-5 * float(value.grad.abs().max()), rtol=1e-4)
+    np.testing.assert_allclose(glog.cpu(), logstd.grad.cpu(), rtol=2e-3, atol=2e-4 * float(logstd.grad.abs().max()))
+
+
+def test_fused_and_plain_optimiser_step_agree():
+    """Two agents with identical weights and an identical rollout dataset: one optimiser step through the fused kernels and
+    one through the plain torch formulation leave the same parameters (AMP on, as bez_kickPPO.yaml)."""
+    from tests.test_gpu_round2 import _agent
+    plain = _agent(512, 4096, fused_ops=False, hip_graphs=False)
+    fused = _agent(512, 4096, fused_ops=True, hip_graphs=False)
+    assert fused.fused and not plain.fused
+    fused.model.load_state_dict(plain.model.state_dict())
+    plain.obs = plain.env_reset()
+    plain.play_steps()                      # one rollout + dataset on the plain agent ...
+    fused._alloc_static()
+    for k in plain.dataset:                 # ... shared with the fused one
+        fused.dataset[k].copy_(plain.dataset[k])
+    for rms_a, rms_b in ((plain.running_mean_std, fused.running_mean_std), (plain.value_mean_std, fused.value_mean_std)):
+        rms_b.load_state_dict(rms_a.state_dict())
+    kl_a, kl_b = torch.zeros((), device=DEV), torch.zeros((), device=DEV)
+    la, lb = torch.zeros(2, device=DEV), torch.zeros(2, device=DEV)
+    plain.calc_gradients(plain._minibatch(0), kl_a, la)
+    fused.calc_gradients(fused._minibatch(0), kl_b, lb)
+    assert abs(float(kl_a) - float(kl_b)) < 1e-5 + 1e-3 * abs(float(kl_a))
+    np.testing.assert_allclose(lb.cpu(), la.cpu(), rtol=2e-3, atol=1e-5)
+    np.testing.assert_allclose(fused.running_mean_std.running_mean.cpu(), plain.running_mean_std.running_mean.cpu(), rtol=1e-10, atol=1e-12)
+    for (name, pa), pb in zip(plain.model.named_parameters(), fused.model.parameters()):
+        # the first Adam step moves every weight by ~lr * sign(grad) = 3e-4: a gradient that is ~0 may round to either sign, so
+        # all weights agree to 2 * lr and 99.9 % of them to a tenth of a step
+        d = (pb.detach() - pa.detach()).abs().cpu().numpy()
+        assert d.max() < 6.5e-4 and (d < 3e-5).mean() > 0.999, (name, d.max(), (d < 3e-5).mean())
+    # and the fused rollout + whole epochs run (eager, then captured)
+    fused2 = _agent(512, 4096, fused_ops=True)
+    fused2.obs = fused2.env_reset()
+    stats = [fused2.train_epoch() for _ in range(4)]
+    assert fused2._g_rollout is not None and all(np.isfinite([s["kl"], s["a_loss"], s["c_loss"]]).all() for s in stats)
+    assert len(fused2.game_rewards) > 0

@@ -248,3 +248,12 @@ def test_reference_policy_in_hip_sim():
     z = np.asarray(r["obs_z"])
     assert np.abs(z[0:36]).max() < 3.0               # joint-space statistics stay within 3 sigma of the checkpoint's
     assert abs(z[52]) < 1e-3 and abs(z[53]) < 1e-3   # constant ball_init tail (Q5)
+
+
+def test_play_mode_runs_the_reference_checkpoint_fixture():
+    """train.py test=True checkpoint=... (reference play.py / README): whole episodes with the deterministic player."""
+    from bez_isaacgym_amd.train import launch
+    mean_r, mean_s, played = launch(["task=bez_kick", "num_envs=512", "headless=True", "test=True",
+                                     "checkpoint=" + os.path.join(ROOT, "tests", "golden", "bez_kick_33_policy.npz"),
+                                     "train.params.config.player={games_num: 600, max_steps: 400}"])
+    assert played >= 600 and 20 < mean_s < 900 and np.isfinite(mean_r)

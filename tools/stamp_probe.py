@@ -9,8 +9,9 @@ import torch
 from bez_isaacgym_amd import abi
 so = os.path.join(ROOT, "gpurun_out", "libbez_sim_stamps.so")
 os.makedirs(os.path.dirname(so), exist_ok=True)
-subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fno-slp-vectorize", "-DBEZ_WS_STAMPS", "-o", so,
-                os.path.join(ROOT, "bez_isaacgym_amd", "csrc", "bez_sim.hip")], check=True)
+import glob
+subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fno-slp-vectorize", "-DBEZ_WS_STAMPS", "-o", so] +
+               sorted(glob.glob(os.path.join(ROOT, "bez_isaacgym_amd", "csrc", "*.hip"))), check=True)
 lib = C.CDLL(so)
 cfg = abi.default_config(4096)
 h = C.c_void_p()
