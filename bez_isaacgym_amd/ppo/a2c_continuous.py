@@ -72,6 +72,32 @@ class RunningMeanStd(nn.Module):
         return torch.clamp(y, min=-5.0, max=5.0)
 
 
+class _HalfLinearFn(torch.autograd.Function):
+    """y = x @ W^T + b on explicit fp16 operands (the AMP arithmetic of nn.Linear under autocast), with the weight gradient
+    computed split-K: for the PPO minibatch (32768 rows) dW = dY^T X has a tiny output (e.g. 400 x 54) and a huge reduction
+    dimension, for which the GEMM library launches a handful of workgroups on 256 CUs (108 us measured per call); as a batched
+    GEMM over `splits` row chunks plus one fp32 sum it fills the chip.  Gradients are returned in fp32 for the fp32 master
+    parameters, exactly what autocast's cast nodes would hand back."""
+
+    @staticmethod
+    def forward(ctx, x, w32, b32, w16, b16, splits):
+        ctx.save_for_backward(x, w16)
+        ctx.splits = splits
+        return torch.addmm(b16, x, w16.t())
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w16 = ctx.saved_tensors
+        gy = gy.contiguous()
+        gx = gy @ w16 if ctx.needs_input_grad[0] else None
+        k, s = x.shape[0], ctx.splits
+        if s > 1 and k % s == 0 and k // s >= 64:
+            gw = torch.bmm(gy.view(s, k // s, -1).transpose(1, 2), x.view(s, k // s, -1)).float().sum(0)
+        else:
+            gw = (gy.t() @ x).float()
+        return gx, gw, gy.float().sum(0), None, None, None
+
+
 class A2CNetwork(nn.Module):
     """Parameter names match rl_games' a2c_network.* so state dicts interoperate."""
 
@@ -86,7 +112,28 @@ class A2CNetwork(nn.Module):
         self.mu = nn.Linear(d, act_dim)
         self.sigma = nn.Parameter(torch.zeros(act_dim))  # const_initializer val 0, fixed_sigma True
 
+    # ---- explicit-fp16 fast path (GPU, mixed precision): fp16 copies of the fp32 master weights refreshed once per optimiser
+    # step by one multi-tensor copy instead of autocast's per-use casts; split-K weight gradients (_HalfLinearFn)
+    def enable_half_path(self, splits=64):
+        self._lin = [m for m in self.actor_mlp if isinstance(m, nn.Linear)] + [self.mu, self.value]
+        self._p32 = [p for m in self._lin for p in (m.weight, m.bias)]
+        self._p16 = [p.detach().half() for p in self._p32]
+        self._splits = int(splits)
+
+    def refresh_half(self):
+        torch._foreach_copy_(self._p16, [p.detach() for p in self._p32])
+
+    def _half_linear(self, i, x):
+        m = self._lin[i]
+        return _HalfLinearFn.apply(x, m.weight, m.bias, self._p16[2 * i], self._p16[2 * i + 1], self._splits)
+
     def forward(self, obs):
+        if obs.dtype == torch.float16 and getattr(self, "_p16", None) is not None:
+            h = obs
+            n_hidden = len(self._lin) - 2
+            for i in range(n_hidden):
+                h = torch.nn.functional.elu(self._half_linear(i, h))
+            return self._half_linear(n_hidden, h), self.sigma.unsqueeze(0).expand(obs.shape[0], -1), self._half_linear(n_hidden + 1, h)
         h = self.actor_mlp(obs)
         return self.mu(h), self.sigma.unsqueeze(0).expand(obs.shape[0], -1), self.value(h)
 
@@ -262,6 +309,9 @@ class A2CAgent:
             self._F = F
             red = (lambda t: dist.all_reduce(t)) if _dist_on() else None
             self._f_obs_rms = F.FusedRunningMeanStd(self.running_mean_std, red) if self.normalize_input else None
+            self.half_path = bool(self.mixed_precision and self.normalize_input and c.get("half_path", True))
+            if self.half_path:
+                self.model.a2c_network.enable_half_path(int(c.get("wgrad_splits", 64)))
         if _dist_on():  # identical replicas (hvd.broadcast_parameters equivalent)
             for p in self.model.parameters():
                 dist.broadcast(p.data, src=0)
@@ -323,9 +373,11 @@ class A2CAgent:
         mb, F, fx = self.mb, self._F, self._fx
         net = self.model.a2c_network
         self.model.eval()
+        if self.half_path:
+            net.refresh_half()
         for n in range(self.horizon):
             x = self._f_obs_rms.normalize(self.obs, fx["obs_n"]) if self.normalize_input else self.obs
-            with torch.autocast("cuda", dtype=torch.float16, enabled=self.mixed_precision):
+            with torch.autocast("cuda", dtype=torch.float16, enabled=self.mixed_precision and not self.half_path):
                 mu, _logstd, value = net(x)
             mu32, v32 = mu.float().contiguous(), value.float()
             if self.normalize_value:
@@ -441,7 +493,9 @@ class A2CAgent:
         if self.normalize_input:
             self._f_obs_rms.update(obs)
             obs = self._f_obs_rms.normalize(obs, fx["mb_obs_n"])
-        with torch.autocast("cuda", dtype=torch.float16, enabled=self.mixed_precision):
+        if self.half_path:
+            net.refresh_half()
+        with torch.autocast("cuda", dtype=torch.float16, enabled=self.mixed_precision and not self.half_path):
             mu, _logstd, value = net(obs)
         mu32, v32 = mu.float().contiguous(), value.float().contiguous()
         scale = None
