@@ -251,11 +251,11 @@ int bez_ppo_loss(const float* mu_dev, const float* logstd_dev, const float* valu
                  const float* loss_scale_dev, float* grad_mu_dev, float* grad_value_dev, float* grad_logstd_dev, float* stats_dev, void* stream) {
   if (!mu_dev || !logstd_dev || !value_dev || !actions_dev || !old_logp_dev || !adv_dev || !old_value_dev || !returns_dev || !old_mu_dev ||
       !old_sigma_dev || !grad_mu_dev || !grad_value_dev || !grad_logstd_dev || !stats_dev || batch <= 0 || num_actions <= 0 || num_actions > 32) return -1;
-  (void)hipMemsetAsync(grad_logstd_dev, 0, (size_t)num_actions * sizeof(float), (hipStream_t)stream);
+  if (!(clip_value & 2)) (void)hipMemsetAsync(grad_logstd_dev, 0, (size_t)num_actions * sizeof(float), (hipStream_t)stream);  // bit 1: accumulate
   (void)hipMemsetAsync(stats_dev, 0, 5 * sizeof(float), (hipStream_t)stream);
   hipLaunchKernelGGL(ppo_loss_kernel, dim3(nblk(batch)), dim3(PPO_TB), 0, (hipStream_t)stream, mu_dev, logstd_dev, value_dev, actions_dev, old_logp_dev, adv_dev,
                      old_value_dev, returns_dev, old_mu_dev, old_sigma_dev, batch, (int)num_actions, e_clip, critic_coef, entropy_coef, bounds_coef,
-                     (int)clip_value, loss_scale_dev, grad_mu_dev, grad_value_dev, grad_logstd_dev, stats_dev);
+                     (int)(clip_value & 1), loss_scale_dev, grad_mu_dev, grad_value_dev, grad_logstd_dev, stats_dev);
   return launch_ok();
 }
 

@@ -29,7 +29,8 @@ import torch.nn as nn
 
 
 def _dist_on():
-    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    # BEZ_PPO_FORCE_DIST=1 (tests): treat a 1-rank process group as data parallel, so the real RCCL calls run on a 1-GPU box
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or os.environ.get("BEZ_PPO_FORCE_DIST") == "1")
 
 
 class RunningMeanStd(nn.Module):
@@ -287,7 +288,9 @@ class A2CAgent:
         g = c.get("hip_graphs", "auto")
         # an env whose step() syncs with the host or allocates (domain randomisation: vec_task.py:505-725) cannot be captured
         env_graph_safe = bool(getattr(getattr(vec_env, "env", vec_env), "graph_safe", True))
-        self.use_graphs = bool(on_gpu and world == 1 and env_graph_safe and (g is True or g == "auto"))
+        # world > 1: graphs are captured in SEGMENTS that contain no collective (the RCCL calls run eagerly between replays),
+        # which needs the fused path's static flat gradient buffer -> decided below, once `self.fused` is known
+        self.use_graphs = bool(on_gpu and env_graph_safe and (g is True or g == "auto"))
         self.graph_warmup_epochs = 2
         self._eager_epochs = 0  # epochs run eagerly IN THIS PROCESS (a restored epoch_num says nothing about warm-up)
         self._g_rollout = self._g_update = self._pool = None
@@ -312,6 +315,10 @@ class A2CAgent:
             self.half_path = bool(self.mixed_precision and self.normalize_input and c.get("half_path", True))
             if self.half_path:
                 self.model.a2c_network.enable_half_path(int(c.get("wgrad_splits", 64)))
+            self._bind_flat_grads()
+        if world > 1 and not self.fused:
+            self.use_graphs = False  # the plain torch path has collectives in the middle of autograd-heavy code: eager only
+        self._seg = None  # segmented graphs of the data-parallel update
         if _dist_on():  # identical replicas (hvd.broadcast_parameters equivalent)
             for p in self.model.parameters():
                 dist.broadcast(p.data, src=0)
@@ -392,7 +399,7 @@ class A2CAgent:
             self.obs.copy_(obs_dict["obs"])
 
     @torch.no_grad()
-    def _rollout_impl(self):
+    def _rollout_impl(self, steps_done=False):
         """horizon_length env steps + GAE + dataset preparation; device ops only (capturable)."""
         mb, dev = self.mb, self.device
         for n in range(0 if self.fused else self.horizon):
@@ -416,7 +423,7 @@ class A2CAgent:
             not_done = 1.0 - self.dones
             self.current_rewards *= not_done
             self.current_lengths *= not_done
-        if self.fused:
+        if self.fused and not steps_done:
             self._rollout_steps_fused()
         last_values = self.get_values(self.obs)
         advs = discount_values(self.gamma, self.tau, self.dones, last_values, mb["dones"], mb["val"], mb["rew"])
@@ -448,7 +455,16 @@ class A2CAgent:
         """Rollout + dataset.  With HIP graphs enabled the first call after warm-up captures, later calls replay."""
         if self.mb is None:
             self._alloc_static()
-        if not self.use_graphs or self._eager_epochs < self.graph_warmup_epochs:
+        if self.use_graphs and self.world > 1 and self._eager_epochs >= self.graph_warmup_epochs:
+            # data parallel: the horizon loop has no collective and is replayed; GAE + dataset (two all-reduces) stay eager
+            if self._g_rollout is None:
+                torch.cuda.synchronize()
+                self._g_rollout = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self._g_rollout, pool=self._graph_pool()):
+                    self._rollout_steps_fused()
+            self._g_rollout.replay()  # (capture only records: the freshly captured graph is replayed like any later one)
+            self._rollout_impl(steps_done=True)
+        elif not self.use_graphs or self._eager_epochs < self.graph_warmup_epochs:
             self._rollout_impl()
         elif self._g_rollout is None:
             torch.cuda.synchronize()
@@ -465,6 +481,19 @@ class A2CAgent:
         return self._pool
 
     # ------------------------------------------------------------------ update
+    def _bind_flat_grads(self):
+        """Every parameter's .grad becomes a fixed view of ONE static fp32 buffer (124 237 + 1 floats; the extra slot carries
+        the minibatch KL): autograd accumulates in place, the data-parallel all-reduce runs on the buffer itself (no flatten /
+        unflatten copies), and graphs captured separately (forward+backward | optimiser) see the same addresses."""
+        params = list(self.model.parameters())
+        n = sum(p.numel() for p in params)
+        self._flat = torch.zeros(n + 1, device=self.device, dtype=torch.float32)
+        off = 0
+        for p in params:
+            p.grad = self._flat[off:off + p.numel()].view_as(p)
+            off += p.numel()
+        self._flat_kl = self._flat[n:n + 1]
+
     def _allreduce_grads(self):
         """ONE fused all-reduce of the flat fp32 gradient (124 237 elements = 497 KB) per optimiser step: the message
         is latency-bound on xGMI, so bucketing per parameter would only multiply the latency."""
@@ -483,15 +512,17 @@ class A2CAgent:
             p.grad.copy_(self._flat_grad[off:off + p.numel()].view_as(p.grad))
             off += p.numel()
 
-    def _calc_gradients_fused(self, mb, kl_out, loss_out):
-        """calc_gradients with the HIP glue kernels: observation moments + running update + normalise (3 launches), MLP
-        forward (torch), the whole loss and its gradient w.r.t. mu / value / log-std (1 launch), MLP backward (torch), then
-        the same all-reduce / unscale / clip / Adam / scaler tail."""
+    # ---- the fused optimiser step in three collective-free phases (A | all-reduce moments | B | all-reduce grads+KL | C)
+    def _phase_a(self, mb):
+        if self.normalize_input:
+            self._f_obs_rms.moments(mb["obs"])
+
+    def _phase_b(self, mb):
         F, fx, net = self._F, self._fx, self.model.a2c_network
         self.model.train()
         obs = mb["obs"]
         if self.normalize_input:
-            self._f_obs_rms.update(obs)
+            self._f_obs_rms.apply()
             obs = self._f_obs_rms.normalize(obs, fx["mb_obs_n"])
         if self.half_path:
             net.refresh_half()
@@ -503,27 +534,38 @@ class A2CAgent:
             if self.scaler._scale is None:
                 self.scaler._lazy_init_scale_growth_tracker(self.device)
             scale = self.scaler._scale
+        self._flat.zero_()
         F.loss(mu32.detach(), net.sigma.detach(), v32.detach(), mb, self.e_clip, self.critic_coef, self.entropy_coef, self.bounds_loss_coef,
-               self.clip_value, scale, fx["gmu"], fx["gval"], fx["glog"], fx["stats"])
-        self.optimizer.zero_grad(set_to_none=True)
+               self.clip_value, scale, fx["gmu"], fx["gval"], net.sigma.grad, fx["stats"], zero_glog=False)
         torch.autograd.backward([mu32, v32], [fx["gmu"], fx["gval"]])
-        net.sigma.grad = fx["glog"]  # rewritten by the next loss launch, after the optimiser has consumed it
+        self._flat_kl.copy_(fx["stats"][3:4] / float(mu32.shape[0]))
+
+    def _phase_c(self, kl_out, loss_out):
         if _dist_on():
-            self._allreduce_grads()
+            self._flat.div_(dist.get_world_size())  # mean of the (still scaled) gradients and of the KL
         if self.truncate_grads:
             self.scaler.unscale_(self.optimizer)
             nn.utils.clip_grad_norm_(self.model.parameters(), self.grad_norm)
         self.scaler.step(self.optimizer)
         self.scaler.update()
         with torch.no_grad():
-            inv_b = 1.0 / float(mu32.shape[0])
-            kl = fx["stats"][3] * inv_b
-            if _dist_on():
-                kl = kl.clone()
-                dist.all_reduce(kl)
-                kl /= dist.get_world_size()
-            kl_out.add_(kl / self.num_minibatches)
-            loss_out[0] += fx["stats"][0] * inv_b; loss_out[1] += fx["stats"][1] * inv_b
+            inv_b = 1.0 / float(self.minibatch_size)
+            kl_out.add_(self._flat_kl[0] / self.num_minibatches)
+            loss_out[0] += self._fx["stats"][0] * inv_b; loss_out[1] += self._fx["stats"][1] * inv_b
+
+    def _calc_gradients_fused(self, mb, kl_out, loss_out):
+        """calc_gradients with the HIP glue kernels: observation moments + running update + normalise (3 launches), MLP
+        forward (torch), the whole loss and its gradient w.r.t. mu / value / log-std (1 launch), MLP backward (torch, into the
+        static flat gradient), then the all-reduce / unscale / clip / Adam / scaler tail."""
+        self._phase_a(mb)
+        if _dist_on() and self.normalize_input:
+            dist.all_reduce(self._f_obs_rms.mom)
+        self._phase_b(mb)
+        if _dist_on():
+            # ONE all-reduce of the flat STILL-SCALED gradient + KL (124 238 fp32 = 497 KB, latency-bound on xGMI): an fp16
+            # overflow on any rank reaches every rank, so unscale_ records the same found_inf everywhere (as DDP does)
+            dist.all_reduce(self._flat)
+        self._phase_c(kl_out, loss_out)
 
     def calc_gradients(self, mb, kl_out, loss_out):
         """One optimiser step on minibatch `mb`; device ops only.  KL is written to kl_out (0-dim view), losses added to loss_out."""
@@ -585,7 +627,42 @@ class A2CAgent:
             if self.is_adaptive_lr:
                 self.scheduler.update_(self.lr_t, self.kl_acc[ep])
 
+    def _update_segmented(self):
+        """Data-parallel update with HIP graphs: per minibatch a moments graph and a forward/backward graph, one shared
+        optimiser graph; the two RCCL all-reduces of a step run eagerly between the replays (no collective is ever captured).
+        The first call captures the segments (capture records, it does not execute) and then replays them like every later call."""
+        if self._seg is None:
+            torch.cuda.synchronize()
+            seg = dict(a=[], b=[], c=torch.cuda.CUDAGraph(), kl=torch.zeros((), device=self.device))
+            for i in range(self.num_minibatches):
+                mb = self._minibatch(i)
+                for key, fn in (("a", self._phase_a), ("b", self._phase_b)):
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, pool=self._graph_pool()):
+                        fn(mb)
+                    seg[key].append(g)
+            with torch.cuda.graph(seg["c"], pool=self._graph_pool()):
+                self._phase_c(seg["kl"], self.loss_acc)
+            self._seg = seg
+        seg = self._seg
+        self.kl_acc.zero_(); self.loss_acc.zero_()
+        for ep in range(self.mini_epochs):
+            seg["kl"].zero_()
+            for i in range(self.num_minibatches):
+                seg["a"][i].replay()
+                if self.normalize_input and _dist_on():
+                    dist.all_reduce(self._f_obs_rms.mom)
+                seg["b"][i].replay()
+                if _dist_on():
+                    dist.all_reduce(self._flat)
+                seg["c"].replay()
+            self.kl_acc[ep].copy_(seg["kl"])
+            if self.is_adaptive_lr:
+                self.scheduler.update_(self.lr_t, self.kl_acc[ep])
+
     def run_update(self):
+        if self.use_graphs and self.world > 1 and self._eager_epochs >= self.graph_warmup_epochs:
+            return self._update_segmented()
         if not self.use_graphs or self._eager_epochs < self.graph_warmup_epochs:
             self._update_impl()
         elif self._g_update is None:

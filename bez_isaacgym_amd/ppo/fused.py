@@ -55,14 +55,20 @@ class FusedRunningMeanStd:
         self.mom = torch.zeros(2 * d + 1, dtype=torch.float64, device=rms.running_mean.device)
         self.reduce_fn = reduce_fn  # e.g. dist.all_reduce for data-parallel training
 
-    def update(self, x):
+    def moments(self, x):
         rows = x.numel() // self.d
         _chk(lib().bez_ppo_rms_moments(_p(x), rows, self.d, _p(self.mom, torch.float64), _stream(x)), "bez_ppo_rms_moments")
-        if self.reduce_fn is not None:
-            self.reduce_fn(self.mom)
+
+    def apply(self):
         r = self.rms
         _chk(lib().bez_ppo_rms_apply(_p(self.mom, torch.float64), self.d, _p(r.running_mean, torch.float64), _p(r.running_var, torch.float64),
-                                     _p(r.count.view(1), torch.float64), _stream(x)), "bez_ppo_rms_apply")
+                                     _p(r.count.view(1), torch.float64), _stream(self.mom)), "bez_ppo_rms_apply")
+
+    def update(self, x):
+        self.moments(x)
+        if self.reduce_fn is not None:
+            self.reduce_fn(self.mom)
+        self.apply()
 
     def normalize(self, x, out):
         rows = x.numel() // self.d
@@ -85,10 +91,11 @@ def rollout_post(rew, dones, timeouts, values, reward_scale, gamma, bootstrap, s
          "bez_ppo_rollout_post")
 
 
-def loss(mu, logstd, value, mb, e_clip, critic_coef, entropy_coef, bounds_coef, clip_value, scale, gmu, gval, glog, stats):
-    """stats[5] <- sums of a_loss, c_loss, b_loss, kl, entropy; gmu / gval / glog <- gradient of the mean loss (x loss scale)."""
+def loss(mu, logstd, value, mb, e_clip, critic_coef, entropy_coef, bounds_coef, clip_value, scale, gmu, gval, glog, stats, zero_glog=True):
+    """stats[5] <- sums of a_loss, c_loss, b_loss, kl, entropy; gmu / gval <- gradient of the mean loss (x loss scale);
+    glog is ACCUMULATED into (zero_glog: cleared first)."""
     b, a = mu.shape
     _chk(lib().bez_ppo_loss(_p(mu), _p(logstd), _p(value), _p(mb["actions"]), _p(mb["old_logp"]), _p(mb["advantages"]), _p(mb["old_values"]),
                             _p(mb["returns"]), _p(mb["mu"]), _p(mb["sigma"]), b, a, float(e_clip), float(critic_coef), float(entropy_coef),
-                            float(bounds_coef), 1 if clip_value else 0, None if scale is None else _p(scale), _p(gmu), _p(gval), _p(glog), _p(stats),
-                            _stream(mu)), "bez_ppo_loss")
+                            float(bounds_coef), (1 if clip_value else 0) | (0 if zero_glog else 2), None if scale is None else _p(scale), _p(gmu),
+                            _p(gval), _p(glog), _p(stats), _stream(mu)), "bez_ppo_loss")

@@ -46,7 +46,8 @@ def play(cfg, vec_env, params, games=None, max_steps=None, log=print):
     return mean_r, mean_s, played
 
 
-def launch(argv=None):
+def launch(argv=None, vec_env_factory=None):
+    """`vec_env_factory(task_cfg, rank)` replaces the HIP env (tests drive the whole CLI / multi-GPU wiring on CPU with it)."""
     import torch
     import torch.distributed as dist
     from .ppo.a2c_continuous import A2CAgent
@@ -62,8 +63,11 @@ def launch(argv=None):
     if multi_gpu and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if torch.cuda.is_available():
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))  # RCCL over xGMI
+        else:
+            dist.init_process_group("gloo")
     if rank == 0:
         print_dict(cfg)
     set_np_formatting()
@@ -72,7 +76,13 @@ def launch(argv=None):
     task_cfg["seed"] = cfg["seed"]
     create_env = get_rlgames_env_creator(task_cfg, cfg["task_name"], cfg["sim_device"], cfg["rl_device"],
                                          cfg["graphics_device_id"], cfg["headless"], multi_gpu=multi_gpu)
-    vec_env = RLGPUEnv("rlgpu", task_cfg["env"]["numEnvs"], env_creator=create_env)
+    if vec_env_factory is not None:
+        if multi_gpu:  # what create_rlgpu_env records for a rank (rlgames_utils.py:71-81 + global env ids)
+            task_cfg["rank"] = rank
+            task_cfg["env_id_offset"] = rank * int(task_cfg["env"]["numEnvs"])
+        vec_env = vec_env_factory(task_cfg, rank)
+    else:
+        vec_env = RLGPUEnv("rlgpu", task_cfg["env"]["numEnvs"], env_creator=create_env)
     params = cfg["train"]["params"]
     name = params["config"]["name"]
     run_dir = os.path.join("runs", str(name))
@@ -82,7 +92,8 @@ def launch(argv=None):
         with open(os.path.join(run_dir, "config.yaml"), "w") as f:
             yaml.safe_dump(cfg, f)
         writer = RLGPUAlgoObserver(run_dir)
-    agent = A2CAgent(params, vec_env, vec_env.env.rl_device, writer=writer, rank=rank, world=world if multi_gpu else 1)
+    rl_device = vec_env.env.rl_device if hasattr(vec_env, "env") else "cpu"
+    agent = A2CAgent(params, vec_env, rl_device, writer=writer, rank=rank, world=world if multi_gpu else 1)
     if params.get("load_checkpoint") and not cfg.get("test"):
         agent.restore(params["load_path"])
     if cfg.get("test"):

@@ -232,7 +232,8 @@ int bez_ppo_rollout_post(const float* rew_dev, const int64_t* dones_dev, const i
                          float* cur_rew_dev, float* cur_len_dev, double* ep_stats_dev, void* stream);
 /* PPO minibatch loss (clipped surrogate, clipped value loss, entropy, bounds loss) AND its gradient w.r.t. the network
  * outputs mu (B,A), value (B) and the log-std parameter (A), multiplied by *loss_scale_dev (GradScaler; NULL = 1).
- * stats_dev[5] = sums of a_loss, c_loss, b_loss, KL(current || old), entropy over the minibatch. */
+ * stats_dev[5] = sums of a_loss, c_loss, b_loss, KL(current || old), entropy over the minibatch.
+ * clip_value: bit 0 = clipped value loss; bit 1 = ACCUMULATE into grad_logstd_dev instead of clearing it first. */
 int bez_ppo_loss(const float* mu_dev, const float* logstd_dev, const float* value_dev, const float* actions_dev, const float* old_logp_dev,
                  const float* adv_dev, const float* old_value_dev, const float* returns_dev, const float* old_mu_dev,
                  const float* old_sigma_dev, int64_t batch, int32_t num_actions, float e_clip, float critic_coef, float entropy_coef,

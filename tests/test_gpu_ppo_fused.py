@@ -141,3 +141,64 @@ def test_fused_and_plain_optimiser_step_agree():
     stats = [fused2.train_epoch() for _ in range(4)]
     assert fused2._g_rollout is not None and all(np.isfinite([s["kl"], s["a_loss"], s["c_loss"]]).all() for s in stats)
     assert len(fused2.game_rewards) > 0
+
+
+def test_segmented_graphs_equal_the_monolithic_update():
+    """World > 1 replays collective-free graph SEGMENTS with the RCCL calls in between.  Forced on one GPU (world = 2 pretended,
+    no process group): from identical weights and an identical dataset the segmented update must leave the same parameters
+    as the monolithic captured update."""
+    from tests.test_gpu_round2 import _agent
+    mono, segm = _agent(512, 4096), _agent(512, 4096)
+    for ag in (mono, segm):
+        ag.obs = ag.env_reset()
+        for _ in range(2):
+            ag.train_epoch()            # eager warm-up epochs (each agent draws its own exploration noise)
+    import copy
+    # deep copy: Optimizer.load_state_dict keeps same-device tensors BY REFERENCE, the two agents must not share Adam moments
+    segm.set_full_state_weights(copy.deepcopy(mono.get_full_state_weights()))   # weights, normalisers, Adam moments, lr
+    segm.scaler.load_state_dict(mono.scaler.state_dict())
+    for a, b in zip(mono.model.parameters(), segm.model.parameters()):
+        assert torch.equal(a, b)
+    segm.world = 2                       # -> play_steps / run_update take the data-parallel (segmented) route
+    for ag in (mono, segm):
+        ag.play_steps()
+    for k in mono.dataset:
+        segm.dataset[k].copy_(mono.dataset[k])
+    mono.run_update()                    # capture only (records, does not execute)
+    mono.run_update()                    # replay: one real update
+    segm.run_update()                    # captures the segments, then replays them: one real update
+    torch.cuda.synchronize()
+    assert segm._seg is not None and len(segm._seg["b"]) == segm.num_minibatches and mono._g_update is not None
+    np.testing.assert_allclose(segm.kl_acc.cpu(), mono.kl_acc.cpu(), rtol=2e-3, atol=1e-6)
+    for (name, pa), pb in zip(mono.model.named_parameters(), segm.model.parameters()):
+        d = (pb.detach() - pa.detach()).abs().cpu().numpy()
+        assert d.max() < 2e-3 and (d < 1e-4).mean() > 0.99, (name, d.max())
+    segm.run_update()                    # replay works and stays finite
+    assert all(torch.isfinite(p).all() for p in segm.model.parameters())
+
+
+def test_data_parallel_path_with_real_rccl_calls_on_one_rank(tmp_path):
+    """The data-parallel code path end to end on the 1-GPU box: a 1-rank RCCL ("nccl") process group, BEZ_PPO_FORCE_DIST=1, so
+    every all-reduce is a real RCCL call issued between the graph replays; 5 epochs (2 eager + capture + replays)."""
+    import os
+    import subprocess
+    import sys
+    code = '''
+import os, sys, numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29777", RANK="0", WORLD_SIZE="1", BEZ_PPO_FORCE_DIST="1")
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+from tests.test_gpu_round2 import _agent
+a = _agent(512, 4096)
+a.world = 2
+a.obs = a.env_reset()
+st = [a.train_epoch() for _ in range(5)]
+assert a._seg is not None and a._g_rollout is not None
+assert all(np.isfinite([s["kl"], s["a_loss"], s["c_loss"]]).all() for s in st), st
+assert all(torch.isfinite(p).all() for p in a.model.parameters())
+dist.destroy_process_group()
+print("DP_OK", st[-1]["kl"])
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert "DP_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]

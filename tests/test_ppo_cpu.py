@@ -182,6 +182,34 @@ def test_amp_overflow_on_one_rank_skips_the_step_everywhere():
     assert torch.isfinite(c0).all()
 
 
+def _cli_worker(rank, world, port, out, tmp):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world))
+    os.chdir(tmp)
+    torch.set_num_threads(1)
+    from bez_isaacgym_amd.train import launch
+    seen = {}
+
+    def factory(task_cfg, r):
+        seen.update(rank=task_cfg.get("rank"), offset=task_cfg.get("env_id_offset"), n=task_cfg["env"]["numEnvs"])
+        return FakeVecEnv(int(task_cfg["env"]["numEnvs"]), seed=300 + r)
+    res = launch(["task=bez_kick", "num_envs=32", "headless=True", "multi_gpu=True", "max_iterations=2",
+                  "train.params.config.minibatch_size=128", "train.params.config.horizon_length=8",
+                  "train.params.config.mixed_precision=False", "train.params.config.save_frequency=0"], vec_env_factory=factory)
+    out[rank] = (seen, res[1], os.path.exists(os.path.join(tmp, "runs")))
+
+
+@pytest.mark.timeout(300)
+def test_train_cli_multi_gpu_wiring_on_gloo(tmp_path):
+    """`train.py task=bez_kick multi_gpu=True` under torch.distributed.run's environment (rlgames_utils.py:71-81, config.yaml:40):
+    process group, rank -> env shard (global env-id offset = rank * num_envs), data-parallel agent, rank-0-only run directory."""
+    mgr = mp.Manager()
+    out = mgr.dict()
+    port = 33500 + (os.getpid() % 2000)
+    mp.spawn(_cli_worker, args=(2, port, out, str(tmp_path)), nprocs=2, join=True)
+    assert out[0][0] == {"rank": 0, "offset": 0, "n": 32} and out[1][0] == {"rank": 1, "offset": 32, "n": 32}
+    assert out[0][1] == out[1][1] == 2
+
+
 def test_cli_config_contract():
     """train.py's CLI contract: task=bez_kick num_envs=... sim_device=... pipeline=... headless=... (README.md:46-63)."""
     cfg = load_config(["task=bez_kick", "num_envs=64", "sim_device=cpu", "pipeline=cpu", "headless=True", "max_iterations=7"])
