@@ -14,6 +14,9 @@ rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU --output-format csv -d $O/${TAG}_pmc_sq2 -- $S > $O/${TAG}_pmc_sq2.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/${TAG}_cal_fetch -- python3 tools/pmc_calibrate.py > $O/${TAG}_cal_fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/${TAG}_cal_write -- python3 tools/pmc_calibrate.py > $O/${TAG}_cal_write.log 2>&1
+# size sweep (1 / 8 / 64 / 256 workgroups): separates the per-launch fixed part of FETCH_SIZE (the instruction stream, once per XCD L2) from the per-env part
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/${TAG}_sweep_fetch -- python3 tools/pmc_probe.py > $O/${TAG}_sweep_fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/${TAG}_sweep_write -- python3 tools/pmc_probe.py > $O/${TAG}_sweep_write.log 2>&1
 # keep only the CSVs the summary needs (the merge back is capped at 64 MiB)
 find $O -name "*agent_info.csv" -delete
 echo collected

@@ -10,7 +10,7 @@ from bez_isaacgym_amd.sim import BezSim
 for n in (64, 512, 4096, 16384):
     sim = BezSim(abi.default_config(n, seed=1), 0)
     act = (torch.rand(8, n * 18, device="cuda") * 2 - 1).contiguous()
-    for t in range(24):
+    for t in range(24):  # summarize_profiles.py drops the first 4 launches per size
         sim.step(act[t % 8])
     torch.cuda.synchronize()
     sim.close()

@@ -38,6 +38,39 @@ def counter_mean(directory, counter, kernel_substr):
     return {"mean": sum(v) / len(v), "min": min(v), "max": max(v), "dispatches": len(v)}
 
 
+def kernel_code_bytes(kernel_mangled):
+    """codeLenInByte of one kernel: device-only assembly of its translation unit with the build's own flags."""
+    import tempfile
+    from bez_isaacgym_amd.build import _flags
+    src = os.path.join(ROOT, "bez_isaacgym_amd", "csrc", "bez_step_ws.hip")
+    with tempfile.TemporaryDirectory() as d:
+        out = os.path.join(d, "ws.s")
+        flags = [f for f in _flags() if f != "-fPIC"]
+        r = subprocess.run(["/opt/rocm/bin/hipcc"] + flags + ["--cuda-device-only", "-S", "-o", out, src], capture_output=True, text=True)
+        if r.returncode != 0:
+            return None
+        name = None
+        for line in open(out):
+            if line.startswith("\t.globl\t"):
+                name = line.split()[1]
+            elif line.startswith("; codeLenInByte") and name == kernel_mangled:
+                return int(line.split("=")[1])
+    return None
+
+
+def size_sweep(directory, counter):
+    """mean counter value (KiB) per launch of the step kernel, by number of envs (grid size / 256 x 64)."""
+    f = _one(os.path.join(directory, "**", "*counter_collection.csv"))
+    if not f:
+        return None
+    acc = {}
+    for row in csv.DictReader(open(f)):
+        if row["Counter_Name"] == counter and KERNEL in row["Kernel_Name"]:
+            acc.setdefault(int(row["Grid_Size"]) // 256 * 64, {}).setdefault(row["Dispatch_Id"], 0.0)
+            acc[int(row["Grid_Size"]) // 256 * 64][row["Dispatch_Id"]] += float(row["Counter_Value"])
+    return {n: (lambda v: sum(v) / len(v))(list(d.values())[4:]) for n, d in sorted(acc.items())}
+
+
 def main():
     tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
     src = os.path.join(ROOT, "gpurun_out")
@@ -77,6 +110,33 @@ def main():
                                        "note": "FETCH_SIZE x %.3f, WRITE_SIZE x %.3f (factors measured by the calibration kernels of the same run; "
                                                "MI355X_MICROARCH.md: gfx950 tallies 128-B read requests at 64 B)" % (rf, wf)}
     res["algorithmic_bytes_per_launch"] = 828 * 4096
+    # 3. attribution: FETCH_SIZE(N) = (XCDs touched) x fixed + N x per_env.  The fixed part is the kernel's instruction stream,
+    # fetched once into each XCD's L2 per launch and tallied 1:1 (64-B requests); only the per-env part (4 B per lane, 256-B wave
+    # rows = 128-B requests) takes the x2 correction.
+    sw_r = size_sweep(os.path.join(src, tag + "_sweep_fetch"), "FETCH_SIZE")
+    sw_w = size_sweep(os.path.join(src, tag + "_sweep_write"), "WRITE_SIZE")
+    if sw_r and 4096 in sw_r and 16384 in sw_r:
+        per_env_raw = (sw_r[16384] - sw_r[4096]) * 1024 / (16384 - 4096)
+        fixed_raw = (sw_r[4096] * 1024 - 4096 * per_env_raw) / 8
+        mangled = kernel_name.split("(")[0] if kernel_name else None
+        code = kernel_code_bytes("_ZN3bez14step_kernel_wsILb1ELb1ELb0ELb0EEEvNS_6ParamsE")
+        att = {"FETCH_SIZE_KiB_by_num_envs": sw_r, "WRITE_SIZE_KiB_by_num_envs": sw_w,
+               "fit": "raw FETCH_SIZE bytes = 8 XCDs x fixed + num_envs x per_env (from the 4096 and 16384 points)",
+               "fixed_bytes_per_xcd_raw": fixed_raw, "kernel_codeLenInByte": code,
+               "one_workgroup_launch_raw_bytes": sw_r.get(64) and sw_r[64] * 1024,
+               "per_env_read_bytes_raw": per_env_raw, "per_env_read_bytes_corrected": per_env_raw * rf,
+               "per_env_write_bytes": sw_w and sw_w[4096] * 1024 * wf / 4096,
+               "kernel_stores_per_env": {"state 62 f32": 248, "dof targets": 72, "prev_lin_vel": 12, "net contact force 22x3": 264, "feet flags 8": 32,
+                                         "obs 54": 216, "reward": 4, "reset/progress/timeout": 24, "sum": 872},
+               "algorithmic_read_per_env": 336, "algorithmic_write_per_env": 492}
+        res["attribution"] = att
+        if fetch and write and code and abs(fixed_raw - code) < 0.05 * code:
+            data_raw = fetch["mean"] * 1024 - 8 * fixed_raw
+            rd = 8 * fixed_raw + data_raw * rf
+            res["hbm_bytes_per_launch_naive_x2"] = dict(res["hbm_bytes_per_launch"])
+            res["hbm_bytes_per_launch"] = {"read": rd, "read_instruction_stream": 8 * fixed_raw, "read_data": data_raw * rf, "write": wr, "total": rd + wr,
+                                           "note": "FETCH_SIZE split by the size sweep: instruction stream (%.0f B x 8 XCD L2s, = codeLenInByte %d within 5 %%, "
+                                                   "tallied 1:1) + per-env data x %.3f; WRITE_SIZE x %.3f" % (fixed_raw, code, rf, wf)}
     sq = {}
     for d in glob.glob(os.path.join(src, tag + "_pmc_sq*")):
         f = _one(os.path.join(d, "**", "*counter_collection.csv"))
