@@ -11,7 +11,7 @@ STAMP = OUT + ".buildinfo"  # hash of every source + the compiler flags the .so 
 
 def _deps():
     import glob
-    return sorted(glob.glob(os.path.join(HERE, "csrc", "*.h")) + glob.glob(os.path.join(HERE, "csrc", "*.hip")) +
+    return sorted(glob.glob(os.path.join(HERE, "csrc", "*.h")) + glob.glob(os.path.join(HERE, "csrc", "*.inc")) + glob.glob(os.path.join(HERE, "csrc", "*.hip")) +
                   [os.path.join(HERE, "..", "include", "bez_sim.h")])
 
 

@@ -45,328 +45,18 @@ constexpr int WS_OBS_STRIDE = 54;  // staging sized for the widest row; rows are
 constexpr int WS_ACT_STRIDE = 19;
 constexpr int WS_LDS_FLOATS = X_SLOTS * WS_ENVS + WS_ENVS * WS_OBS_STRIDE;
 
-#define XS(slot) lds[(slot) * WS_ENVS + lane]
 
-BEZ_DEV void ws_barrier() { __syncthreads(); }
-
-// In-kernel stamps (diagnostic build only; the shipped kernel contains none): clock at phase boundaries of
-// workgroup 0, written to a buffer nothing else reads.
-#ifdef BEZ_WS_STAMPS
-#define WS_STAMP(role, k)                                                                         \
-  do {                                                                                            \
-    if (P.stamps && blockIdx.x == 0 && lane == 0) P.stamps[(role) * 32 + (k)] = __builtin_amdgcn_s_memtime(); \
-  } while (0)
-#else
-#define WS_STAMP(role, k) do { } while (0)
-#endif
-
-BEZ_DEV void xs_store_sv(float* lds, int lane, int slot, SV v) {
-  XS(slot + 0) = v.a.x; XS(slot + 1) = v.a.y; XS(slot + 2) = v.a.z; XS(slot + 3) = v.l.x; XS(slot + 4) = v.l.y; XS(slot + 5) = v.l.z;
-}
-BEZ_DEV SV xs_load_sv(const float* lds, int lane, int slot) {
-  return mksv(mk(XS(slot + 0), XS(slot + 1), XS(slot + 2)), mk(XS(slot + 3), XS(slot + 4), XS(slot + 5)));
-}
-BEZ_DEV void xs_store_v3(float* lds, int lane, int slot, V3 v) { XS(slot) = v.x; XS(slot + 1) = v.y; XS(slot + 2) = v.z; }
-BEZ_DEV V3 xs_load_v3(const float* lds, int lane, int slot) { return mk(XS(slot), XS(slot + 1), XS(slot + 2)); }
-BEZ_DEV void xs_store_sym6(float* lds, int lane, int slot, const Sym6& I, SV p) {
-  const float* f = (const float*)&I;
-#pragma unroll
-  for (int i = 0; i < 21; ++i) XS(slot + i) = f[i];
-  xs_store_sv(lds, lane, slot + 21, p);
-}
-BEZ_DEV void xs_add_sym6(const float* lds, int lane, int slot, Sym6& I, SV& p) {
-  float* f = (float*)&I;
-#pragma unroll
-  for (int i = 0; i < 21; ++i) f[i] += XS(slot + i);
-  p = p + xs_load_sv(lds, lane, slot + 21);
-}
-// net-contact-force row of `body`: the first contributing substep stores w * f, later ones add (cf_accum of bez_kernels.h, in LDS)
-BEZ_DEV void ws_cf_acc(float* lds, int lane, int body, V3 f, float w, bool first) {
-  const int s = X_CF + body * 3;
-  if (first) { XS(s) = f.x * w; XS(s + 1) = f.y * w; XS(s + 2) = f.z * w; }
-  else { XS(s) = fmaf(f.x, w, XS(s)); XS(s + 1) = fmaf(f.y, w, XS(s + 1)); XS(s + 2) = fmaf(f.z, w, XS(s + 2)); }
-}
-// the two helper parts' leg<->leg contact results of leg box link k (see ws_self_collision)
-BEZ_DEV SV xs_self_wrench(const float* lds, int lane, int k) { return xs_load_sv(lds, lane, X_SELF + k * 9) + xs_load_sv(lds, lane, X_SELF + 90 + k * 9); }
-BEZ_DEV V3 xs_self_force(const float* lds, int lane, int k) { return xs_load_v3(lds, lane, X_SELF + k * 9 + 6) + xs_load_v3(lds, lane, X_SELF + 90 + k * 9 + 6); }
-// leg box link L (6..10 / 14..18) -> 0..9
-BEZ_DEV constexpr int self_index(int L) { return L < 11 ? L - 6 : 5 + (L - 14); }
-
-// shared (read-only within a substep) root / ball state as the chain roles see it
-struct RootView { M3 E0; SV V0; float root_z; V3 bc, ball_lin, ball_ang; float ball_z; };
-BEZ_DEV RootView load_root_view(const float* lds, int lane) {
-  RootView R;
-  V3 pos = xs_load_v3(lds, lane, X_ROOT);
-  R.E0 = quat_to_mat(XS(X_ROOT + 3), XS(X_ROOT + 4), XS(X_ROOT + 5), XS(X_ROOT + 6));
-  R.V0 = mksv(xs_load_v3(lds, lane, X_ROOT + 10), xs_load_v3(lds, lane, X_ROOT + 7));
-  R.root_z = pos.z;
-  V3 bp = xs_load_v3(lds, lane, X_BALL);
-  R.bc = bp - pos; R.ball_z = bp.z;
-  R.ball_lin = xs_load_v3(lds, lane, X_BALL + 3); R.ball_ang = xs_load_v3(lds, lane, X_BALL + 6);
-  return R;
-}
-
-// per-joint data a chain keeps in registers between pass 2 and pass 3
-struct P3 { SV UD; float uD, Dinv; SV S, cb; };
-// contact rows of a body: F = F0 - (B^T a_ang + C a_lin) for the body's spatial acceleration a
-struct BodyContact { M3 B; Sym3 C; V3 F0; };
-BEZ_DEV BodyContact body_contact_of(const Sym6& Kc, SV pc) { BodyContact b; b.B = Kc.B; b.C = Kc.C; b.F0 = -pc.l; return b; }
-BEZ_DEV V3 body_contact_force(const BodyContact& b, SV a) { return b.F0 - (mulT(b.B, a.a) + mul(b.C, a.l)); }
-
-// `hits` != null (cleats asset, foot links): the per-point records are kept in LDS, every cleat reports its own contact row
-template <int L, bool CL>
-BEZ_DEV void ws_ground_points(const Params& P, float mu, float root_z, const M3& E, V3 r, SV V, Sym6& Kc, SV& pc, float* lds = nullptr, int lane = 0, int hit0 = 0) {
-  int k = 0;
-#pragma unroll
-  for (int i = 0; i < BEZ_NPT; ++i) {
-    if (BEZ_PT_LINK[i] == L) {
-      V3 pl = mk((float)pt_pos<CL>(i, 0), (float)pt_pos<CL>(i, 1), (float)pt_pos<CL>(i, 2));
-      V3 x = r + mul(E, pl);
-      Hit h = ground_contact(P, mu, x, root_z + x.z, V, Kc, pc);
-      if (CL && lds) {
-        const int s0 = hit0 + k * 8;
-        XS(s0) = h.x.x; XS(s0 + 1) = h.x.y; XS(s0 + 2) = h.x.z; XS(s0 + 3) = h.fn0; XS(s0 + 4) = h.kn; XS(s0 + 5) = h.ct; XS(s0 + 6) = h.ftx0; XS(s0 + 7) = h.fty0;
-      }
-      ++k;
-    }
-  }
-}
-// the cleat rows of one foot from the records above and the foot's acceleration
-template <int L>
-BEZ_DEV void ws_cleat_forces(const Params& P, float* lds, int lane, int hit0, SV a, bool first) {
-  int k = 0;
-#pragma unroll
-  for (int i = 0; i < BEZ_NPT; ++i) {
-    if (BEZ_PT_LINK[i] == L) {
-      const int s0 = hit0 + k * 8;
-      Hit h; h.x = mk(XS(s0), XS(s0 + 1), XS(s0 + 2)); h.fn0 = XS(s0 + 3); h.kn = XS(s0 + 4); h.ct = XS(s0 + 5); h.ftx0 = XS(s0 + 6); h.fty0 = XS(s0 + 7);
-      V3 f = h.kn > 0.f ? cf_ground(P, hit_force(P, h, a)) : mk(0, 0, 0);
-      ws_cf_acc(lds, lane, BEZ_PT_BODY_CL[i], f, P.cf_w, first);
-      ++k;
-    }
-  }
-}
-
-// Per-role DR scalars
-struct ChainDyn { float mu; V3 g; };
-
-// ---- passes 1+2 of one serial chain.  Outputs the chain's articulated inertia/bias as seen by the torso (added to
-// IAo/pAo), the pass-3 operands p3[LEN], the contact rows of the chain-end link, and (legs) the ball/box candidate.
-template <int FIRST, int LEN, bool LEG, bool CL>
-BEZ_DEV void ws_chain_pass1(const Params& P, const ChainDyn& D, const float* ms, const RootView& R, const float* q, const float* qd,
-                            LinkInertia* LI, SV* pAl, SV* Sl, SV* cbl, M3& Eend, V3& rend, SV& Vend, BallSel& sel, SV& Vsel) {
-  M3 E = R.E0;
-  V3 r = mk(0, 0, 0);
-  SV V = R.V0;
-  static_for<LEN>([&](auto I) {
-    constexpr int i = decltype(I)::value;
-    constexpr int L = FIRST + i;
-    link_kinematics<L>(q[i], qd[i], E, r, V, Sl[i], cbl[i]);
-    link_inertia<L, CL>(ms[i], D.g, E, r, V, LI[i], pAl[i]);
-    if constexpr (LEG && link_has_box(L)) {
-      test_box<link_box(L)>(E, r, R.bc, sel);
-      if (sel.link == L) Vsel = V;  // this box just became the deepest candidate: keep its link velocity
-    }
-  });
-  Eend = E; rend = r; Vend = V;  // chain-end frame / velocity for the ground points
-}
-
-template <int FIRST, int LEN, bool LEG>
-BEZ_DEV void ws_chain_pass2(const Params& P, const ChainDyn& D, const float* kps, const float* kds, const float* lo, const float* hi,
-                            const float* q, const float* qd, const float* target, const LinkInertia* LI, const SV* pAl, const SV* Sl,
-                            const SV* cbl, const Sym6& Kc, SV pc, bool mine, BallSel& sel, P3* p3, Sym6& IAo, SV& pAo) {
-  Sym6 IA = Kc;
-  SV pA = pc;
-  static_for<LEN>([&](auto I) {
-    constexpr int i = LEN - 1 - decltype(I)::value;
-    constexpr int L = FIRST + i;
-    add_link_inertia(IA, LI[i]);
-    pA = pA + pAl[i];
-    if constexpr (LEG && link_has_box(L)) {
-      if (mine && sel.link == L) {  // contact operands were prepared once, by the root role (X_FOLD)
-        add_point_stiffness(IA, sel.x, sel.A);
-        pA = pA - wrench_at(sel.x, sel.f0p);
-      }
-    }
-    SV U; float Dinv, u;
-    joint_terms<L>(P, kps[i], kds[i], lo[i], hi[i], q[i], qd[i], target[i], IA, pA, Sl[i], cbl[i], U, Dinv, u);
-    p3[i].UD = U * Dinv; p3[i].uD = u * Dinv; p3[i].Dinv = Dinv; p3[i].S = Sl[i]; p3[i].cb = cbl[i];
-    add_outer(IA, U, -Dinv);
-    pA = pA + mul(IA, cbl[i]) + U * p3[i].uD;
-  });
-  add_to(IAo, IA);
-  pAo = pAo + pA;
-}
-
-// The explicit leg<->leg contact wrenches enter AFTER pass 2 (the helper waves compute them while the legs run passes 1-2):
-// an extra bias force dp on link i changes u_i by -S_i . dp and travels up the chain as (1 - U_i S_i^T / D_i) dp, an exact
-// linear correction of pass 2's bias recursion (the drive-saturation predictor does not see these forces: same rule in the oracle).
-template <int LEN>
-BEZ_DEV void ws_chain_self_correction(const float* lds, int lane, int side, P3* p3, SV& pAo) {
-  SV acc = svzero();
-  static_for<LEN>([&](auto I) {
-    constexpr int i = LEN - 1 - decltype(I)::value;
-    if constexpr (i >= 1) acc = acc + xs_self_wrench(lds, lane, side * 5 + i - 1);
-    const float sd = -dot(p3[i].S, acc);
-    p3[i].uD = fmaf(sd, p3[i].Dinv, p3[i].uD);
-    acc = acc + p3[i].UD * sd;
-  });
-  pAo = pAo + acc;
-}
-
-// pass 3: joint accelerations, semi-implicit Euler with the velocity clamp; returns the chain-end acceleration
-template <int FIRST, int LEN, bool LEG, bool CL>
-BEZ_DEV SV ws_chain_pass3(const Params& P, SV a0, const P3* p3, float* q, float* qd, bool mine, const BallSel& sel, V3& fl, V3& f_end,
-                          float* lds, int lane, bool keep, bool first) {
-  SV a = a0;
-  static_for<LEN>([&](auto I) {
-    constexpr int i = decltype(I)::value;
-    constexpr int L = FIRST + i;
-    SV ap = a + p3[i].cb;
-    float qdd = p3[i].uD - dot(p3[i].UD, ap);
-    a = ap + p3[i].S * qdd;
-    float v = fmaf(P.h, qdd, qd[i]);
-    v = fminf(fmaxf(v, -P.vel_limit), P.vel_limit);
-    qd[i] = v;
-    q[i] = fmaf(P.h, v, q[i]);
-    if constexpr (LEG && link_has_box(L)) {
-      V3 f = xs_self_force(lds, lane, self_index(L));  // leg<->leg contacts of this link
-      if (mine && sel.link == L) { fl = sel.f0p - mul(sel.A, point_of(a, sel.x)); f = f + cf_along(P, fl, sel.n); }
-      if (keep) {
-        if constexpr (i == LEN - 1) f_end = f;
-        else ws_cf_acc(lds, lane, link_body<CL>(L), f, P.cf_w, first);
-      }
-    }
-  });
-  return a;
-}
-
-// ---- joint-side post-physics of a chain role (runs in parallel in the three chain waves): the reset draw for ITS joints
-// (kick_env.py:786-791,839-842), the observation slots q / qd (kick_env.py:1409-1410), its share of |default - q|^2, and
-// the stores of its joints' state.
+constexpr int X_STAGE = X_SLOTS;  // action / observation staging block behind the exchange slots
+// joints of the three chain roles (dof index): left leg, right leg, upper (head 0,1; left arm 2,3; right arm 10,11)
+BEZ_DEV constexpr int role_ndof(int) { return 6; }
 BEZ_DEV constexpr int role_dof(int role, int i) { return role == 0 ? 4 + i : (role == 1 ? 12 + i : (i < 4 ? i : 6 + i)); }
-BEZ_DEV constexpr bool role_needs_block(int role, int b) {
-  for (int i = 0; i < 6; ++i) if ((role_dof(role, i) >> 2) == b || ((BEZ_ND + role_dof(role, i)) >> 2) == b) return true;
-  return false;
-}
-template <int ROLE, bool POST>
-BEZ_DEV void ws_chain_epilogue(const Params& P, float* lds, int lane, int e, bool active, bool do_reset, uint32_t episode,
-                               float* q, float* qd, float* target) {
-  const int n = P.n;
-  if (POST) {
-    if (do_reset) {
-      const int64_t genv = P.env_off + e;
-      const uint32_t k0 = (uint32_t)P.seed, k1 = (uint32_t)(P.seed >> 32);
-      static_for<9>([&](auto B) {
-        constexpr int b = decltype(B)::value;
-        if constexpr (role_needs_block(ROLE, b)) {
-          uint32_t c[4] = {(uint32_t)genv, (uint32_t)((uint64_t)genv >> 32), episode, (uint32_t)b};
-          philox4x32_10(c, k0, k1);
-          static_for<6>([&](auto I) {
-            constexpr int i = decltype(I)::value;
-            constexpr int d = role_dof(ROLE, i);
-            if constexpr ((d >> 2) == b) {
-              float u = (float)(c[d & 3] >> 8) * (1.0f / 16777216.0f);
-              float qq = (float)BEZ_DOF_DEFAULT[d] + fmaf(0.3f, u, -0.15f);
-              q[i] = fmaxf(fminf(qq, (float)BEZ_DOF_UPPER[d]), (float)BEZ_DOF_LOWER[d]);
-            }
-            if constexpr (((BEZ_ND + d) >> 2) == b) {
-              float u = (float)(c[(BEZ_ND + d) & 3] >> 8) * (1.0f / 16777216.0f);
-              qd[i] = fmaf(0.2f, u, -0.1f);
-            }
-          });
-        }
-      });
-      static_for<6>([&](auto I) { constexpr int i = decltype(I)::value; target[i] = (float)BEZ_DOF_DEFAULT[role_dof(ROLE, i)]; });
-    }
-    float* obs_row = lds + X_SLOTS * WS_ENVS + lane * P.nobs;
-    float psum = 0.f;
-    static_for<6>([&](auto I) {
-      constexpr int i = decltype(I)::value;
-      constexpr int d = role_dof(ROLE, i);
-      obs_row[d] = q[i]; obs_row[BEZ_ND + d] = qd[i];
-      float dd = (float)BEZ_DOF_DEFAULT[d] - q[i];
-      psum = fmaf(dd, dd, psum);
-    });
-    XS(X_PSUM + ROLE) = psum;
-  }
-  if (active) {
-    float* st = P.state;
-    static_for<6>([&](auto I) {
-      constexpr int i = decltype(I)::value;
-      constexpr int d = role_dof(ROLE, i);
-      st[(size_t)(F_Q + d) * n + e] = q[i]; st[(size_t)(F_QD + d) * n + e] = qd[i]; st[(size_t)(F_TARGET + d) * n + e] = target[i];
-    });
-  }
-}
-
-// ---- leg<->leg self-collision, evaluated by the two waves that would otherwise idle while the leg roles run pass 1:
-// PART 0 (upper role, in the window of the legs' pass 1) owns the hip/thigh x hip/thigh pairs and only walks both legs down to
-// the thigh; PART 1 (root role, in the window of the legs' pass 2) owns every other pair of BEZ_CPAIR.  Forward kinematics of both legs comes from the joint state
-// the leg roles published (X_LEGQ); per-link wrenches / reported forces are summed in registers and written once to this
-// part's LDS block (X_SELF + PART * 90: link k -> wrench 6 floats at k*9, force 3 floats at k*9+6); the legs add both blocks.
+// leg<->leg pairs: PART 0 (upper role, window of the legs' pass 1) owns the hip/thigh x hip/thigh pairs and only walks both legs
+// down to the thigh; PART 1 (root role, window of the legs' pass 2) owns every other pair of BEZ_CPAIR
 BEZ_DEV constexpr bool self_part_owns(int part, int ia, int ib) { return (part == 0) == (ia <= 1 && ib <= BEZ_NCAP / 2 + 1); }
-struct SelfCaps { V3 c0[BEZ_NCAP], c1[BEZ_NCAP]; SV V[BEZ_NCAP]; };  // world end points / link velocity per capsule (left 0..5, right 6..11)
-// stage 1: forward kinematics of both legs (as deep as this part's pairs need) -> capsules
-template <int PART>
-BEZ_DEV void ws_self_fk(const float* lds, int lane, const M3& E0, SV V0, SelfCaps& K) {
-  constexpr int NFK = PART == 0 ? 3 : 6;  // links to walk per leg (hip_side, hip_front, thigh | all)
-  static_for<2>([&](auto SIDE) {
-    constexpr int side = decltype(SIDE)::value;
-    M3 E = E0; V3 r = mk(0, 0, 0); SV V = V0, Sj, cbj;
-    static_for<NFK>([&](auto I) {
-      constexpr int i = decltype(I)::value;
-      constexpr int L = (side == 0 ? 5 : 13) + i;
-      link_kinematics<L>(XS(X_LEGQ + side * 12 + i), XS(X_LEGQ + side * 12 + 6 + i), E, r, V, Sj, cbj);
-      static_for<BEZ_NCAP>([&](auto C) {
-        constexpr int c = decltype(C)::value;
-        if constexpr (BEZ_CAP_LINK[c] == L) {
-          K.c0[c] = r + mul(E, mk((float)BEZ_CAP_P0[c][0], (float)BEZ_CAP_P0[c][1], (float)BEZ_CAP_P0[c][2]));
-          K.c1[c] = r + mul(E, mk((float)BEZ_CAP_P1[c][0], (float)BEZ_CAP_P1[c][1], (float)BEZ_CAP_P1[c][2]));
-          K.V[c] = V;
-        }
-      });
-    });
-  });
-}
-// Keeps stage 1 where it is written: without this the compiler sinks the kinematics past the barriers to their first use,
-// i.e. out of the idle window they are meant to fill.
-BEZ_DEV void pin(float& x) { asm volatile("" : "+v"(x)); }
-BEZ_DEV void pin(V3& v) { pin(v.x); pin(v.y); pin(v.z); }
-template <int PART>
-BEZ_DEV void ws_self_pin(SelfCaps& K) {
-  static_for<BEZ_NCAP>([&](auto C) {
-    constexpr int c = decltype(C)::value;
-    constexpr int depth = BEZ_CAP_LINK[c] < 11 ? BEZ_CAP_LINK[c] - 5 : BEZ_CAP_LINK[c] - 13;
-    if constexpr (PART == 1 || depth < 3) { pin(K.c0[c]); pin(K.c1[c]); pin(K.V[c].a); pin(K.V[c].l); }
-  });
-}
-// stage 2: this part's capsule pairs -> per-link wrench / reported force, one LDS block per part
-template <int PART>
-BEZ_DEV void ws_self_pairs(const Params& P, float mu, float* lds, int lane, const SelfCaps& K) {
-  constexpr int base = X_SELF + PART * 90;
-  SV w[10]; V3 cf[10];
-#pragma unroll
-  for (int k = 0; k < 10; ++k) { w[k] = svzero(); cf[k] = mk(0, 0, 0); }
-  if (!(P.flags & BEZ_FLAG_NO_SELF_COLLISION)) {
-    static_for<BEZ_NCPAIR>([&](auto Q) {
-      constexpr int pr = decltype(Q)::value;
-      constexpr int ia = BEZ_CPAIR[pr][0], ib = BEZ_CPAIR[pr][1];
-      if constexpr (self_part_owns(PART, ia, ib)) {
-        constexpr int sa = self_index(BEZ_CAP_LINK[ia]), sb = self_index(BEZ_CAP_LINK[ib]);
-        V3 x, f, fn;
-        if (self_pair(P, mu, (float)BEZ_CAP_R[ia], (float)BEZ_CAP_R[ib], K.c0[ia], K.c1[ia], K.c0[ib], K.c1[ib], K.V[ia], K.V[ib], x, f, fn)) {
-          const SV wr = wrench_at(x, f);
-          w[sa] = w[sa] - wr; w[sb] = w[sb] + wr;
-          const V3 fr = (P.flags & BEZ_FLAG_CF_WITH_FRICTION) ? f : fn;
-          cf[sa] = cf[sa] + fr; cf[sb] = cf[sb] - fr;
-        }
-      }
-    });
-  }
-#pragma unroll
-  for (int k = 0; k < 10; ++k) { xs_store_sv(lds, lane, base + k * 9, w[k]); xs_store_v3(lds, lane, base + k * 9 + 6, cf[k]); }
-}
+BEZ_DEV constexpr int self_fk_depth(int part, int) { return part == 0 ? 3 : 6; }
+
+#include "bez_ws_common.inc"
+
 
 // ------------------------------------------------------------------------------------------------ roles
 template <int FIRST, bool PRE, bool POST, bool DR, bool CL>

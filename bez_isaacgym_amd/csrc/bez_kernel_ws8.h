@@ -1,0 +1,596 @@
+// bez_kernel_ws8.h -- wave-specialised fused step kernel, 8 role waves per 64 environments (2 waves per SIMD).
+//
+// A lone wave issues one vector instruction every ~5 cycles on a CDNA4 SIMD whatever the other SIMDs do, so the step time of
+// the 4-wave kernel (bez_kernel_ws.h) is the instruction count of its longest role: a leg (forward kinematics, link
+// inertias, ball/box tests, foot ground contact, the articulated-inertia recursion, the leg<->leg correction, pass 3).  Here
+// the leg roles keep only what is serial in the joint chain, and everything that merely NEEDS the leg's kinematics is
+// recomputed from the published joint state by helper waves that share the SIMDs (a second wave on a SIMD issues in the slots
+// the first leaves empty):
+//     role 0  left leg   (links 5..10)    pass 1 (kinematics, inertias), foot ground contact, pass 2, leg<->leg correction, pass 3
+//     role 1  right leg  (links 13..18)   same
+//     role 2  head       (links 1,2)
+//     role 3  torso, ball, ball<->torso-box candidate, 6x6 root solve, integration, post-physics
+//     role 4  ball<->left-leg-box candidate: own forward kinematics of the left leg and the five box tests, the deepest one
+//             -> X_CAND; then the left arm (links 3,4) as a chain of its own; then the sum of the head / arm blocks
+//     role 5  the same for the right leg and the right arm (links 11,12)
+//     role 6  leg<->leg capsule pairs of the left hip/thigh/calf capsules (own forward kinematics of both legs)
+//     role 7  leg<->leg capsule pairs of the left ankle/foot capsules
+// The deepest of the three ball candidates wins (left, right, torso on ties, the box order of the oracle); every owner decides
+// locally from the three published depths whether it is the winner, and only the winner evaluates the contact operands (a leg
+// wave skips that block altogether unless one of its 64 envs has a ball<->leg contact).
+// All roles execute the same barriers (B0, per substep B1 B1c B2 B3 B4 B5, B6, final).  512 threads, <= 256 VGPRs per wave.
+// The action / observation staging block aliases the X_IA slots (actions are consumed before the first X_IA store, the
+// observation rows are staged after the last X_IA load).
+#pragma once
+#include "bez_kernels.h"
+
+namespace bez {
+namespace w8 {
+
+constexpr int WS_BLOCK = 512;
+constexpr int WS_ENVS = 64;
+
+enum : int {
+  X_ROOT = 0,      // pos3 quat4 lin3 ang3
+  X_BALL = 13,     // pos3 lin3 ang3
+  X_A0 = 22,       // torso spatial acceleration
+  X_FL = 28,       // ball<->link force on the link (3) + contact point rel. ball centre (3)
+  X_PSUM = 34,     // per chain-owning role (0,1,2,4,5): sum of (default - q)^2 over its joints
+  X_CAND = 40,     // per leg: depth, link, n(3), P(3), V(6) of its deepest ball/box candidate = 14 floats x 2 (roles 4 / 5)
+  X_TORSO = 68,    // depth of the torso-box candidate (role 3)
+  X_LEGQ = 81,     // per leg: q(6) qd(6) at the start of the substep (read by the helper roles)
+  X_SELF = 105,    // 2 helper parts x [per leg box link (left 5, right 5): bias wrench (6) + reported force (3)] = 2 x 90
+  X_CF = 285,      // net contact force rows, up to BEZ_NBE_MAX = 30 bodies (mean over substeps)
+  X_HIT = 375,     // cleats asset only: per leg 4 ground-point records x 8 floats (x3 fn0 kn ct ftx0 fty0)
+  X_IA = 439,      // 5 chains (left leg, right leg, head, left arm, right arm) x (Sym6 21 + bias 6); block 2 ends up holding head + arms
+  X_BCN = 574,     // per leg: contact rows of the foot (B 9, C 6, F0 3), parked here across pass 2 (register pressure)
+  X_SLOTS = 610
+};
+constexpr int X_STAGE = X_IA;  // staging aliases the chain blocks (see the header comment)
+constexpr int WS_ACT_STRIDE = 19;
+constexpr int WS_LDS_FLOATS = X_SLOTS * WS_ENVS;
+static_assert(WS_LDS_FLOATS * 4 <= 160 * 1024, "LDS budget");
+static_assert(5 * 27 >= 54 && 5 * 27 >= WS_ACT_STRIDE, "staging fits the aliased block");
+
+// joints (dof index) of the chain-owning roles
+BEZ_DEV constexpr int role_ndof(int role) { return role <= 1 ? 6 : 2; }
+BEZ_DEV constexpr int role_dof(int role, int i) { return role == 0 ? 4 + i : (role == 1 ? 12 + i : (role == 2 ? i : (role == 4 ? 2 + i : 10 + i))); }
+// leg<->leg pairs by their LEFT capsule: part 0 = hip / thigh / calf capsules (0,1,2: 13 pairs), part 1 = ankle / foot (3,4,5: 15 pairs)
+BEZ_DEV constexpr bool self_part_owns(int part, int ia, int) { return (part == 0) == (ia <= 2); }
+BEZ_DEV constexpr int self_fk_depth(int part, int side) { return (part == 0 && side == 0) ? 4 : 6; }
+
+#include "bez_ws_common.inc"
+
+BEZ_DEV void xs_load_sym6(const float* lds, int lane, int slot, Sym6& I, SV& p) {
+  float* f = (float*)&I;
+#pragma unroll
+  for (int i = 0; i < 21; ++i) f[i] = XS(slot + i);
+  p = xs_load_sv(lds, lane, slot + 21);
+}
+BEZ_DEV void xs_store_body_contact(float* lds, int lane, int slot, const BodyContact& b) {
+  const float* fb = (const float*)&b.B;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) XS(slot + i) = fb[i];
+  const float* fc = (const float*)&b.C;
+#pragma unroll
+  for (int i = 0; i < 6; ++i) XS(slot + 9 + i) = fc[i];
+  xs_store_v3(lds, lane, slot + 15, b.F0);
+}
+BEZ_DEV BodyContact xs_load_body_contact(const float* lds, int lane, int slot) {
+  BodyContact b;
+  float* fb = (float*)&b.B;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) fb[i] = XS(slot + i);
+  float* fc = (float*)&b.C;
+#pragma unroll
+  for (int i = 0; i < 6; ++i) fc[i] = XS(slot + 9 + i);
+  b.F0 = xs_load_v3(lds, lane, slot + 15);
+  return b;
+}
+
+// ---- the three ball candidates (left leg, right leg, torso): who wins, given the published depths
+struct CandDepths { float dl, dr, dt; };
+BEZ_DEV CandDepths load_cand_depths(const float* lds, int lane) { CandDepths c; c.dl = XS(X_CAND); c.dr = XS(X_CAND + 14); c.dt = XS(X_TORSO); return c; }
+// 0 left, 1 right, 2 torso: the right leg needs strictly more depth than the left, the torso strictly more than the better leg
+BEZ_DEV int cand_winner(const CandDepths& c) { const int sw = (c.dr > c.dl) ? 1 : 0; return (c.dt > (sw ? c.dr : c.dl)) ? 2 : sw; }
+BEZ_DEV void publish_cand(float* lds, int lane, int side, const BallSel& sel, SV Vsel) {
+  const int c0 = X_CAND + side * 14;
+  XS(c0) = sel.depth; XS(c0 + 1) = (float)sel.link;
+  xs_store_v3(lds, lane, c0 + 2, sel.n); xs_store_v3(lds, lane, c0 + 5, sel.P); xs_store_sv(lds, lane, c0 + 8, Vsel);
+}
+
+// per-env DR scalars every role may need
+template <bool DR>
+BEZ_DEV ChainDyn load_chain_dyn(const Params& P, int e) {
+  ChainDyn D; D.mu = P.mu; D.g = mk(P.g[0], P.g[1], P.g[2]);
+  if (DR) {
+    if (P.dr_friction) D.mu = P.dr_friction[e];
+    if (P.dr_gravity) D.g = mk(P.dr_gravity[(size_t)e * 3], P.dr_gravity[(size_t)e * 3 + 1], P.dr_gravity[(size_t)e * 3 + 2]);
+  }
+  return D;
+}
+
+// Inside the substep loop: the same scalars behind an opaque copy, so that products of loop-invariant UNIFORM values (mass x
+// gravity per link, ...) are recomputed per substep instead of being hoisted out of the loop into long-lived VGPRs.
+BEZ_DEV ChainDyn in_loop(const ChainDyn& D) { ChainDyn d = D; pin(d.g); pin(d.mu); return d; }
+
+// joint state / gains of NJ consecutive joints starting at link FIRST (dof FIRST-1)
+template <int FIRST, int NJ, bool DR>
+BEZ_DEV void load_joints(const Params& P, int e, float* q, float* qd, float* kps, float* kds, float* ms, float* lo, float* hi) {
+  const int n = P.n;
+  const float* st = P.state;
+#pragma unroll
+  for (int i = 0; i < NJ; ++i) {
+    constexpr int d0 = FIRST - 1;
+    q[i] = st[(size_t)(F_Q + d0 + i) * n + e]; qd[i] = st[(size_t)(F_QD + d0 + i) * n + e];
+    kps[i] = 1.f; kds[i] = 1.f; ms[i] = 1.f; lo[i] = (float)BEZ_DOF_LOWER[d0 + i]; hi[i] = (float)BEZ_DOF_UPPER[d0 + i];
+    if (DR) {
+      if (P.dr_kp) kps[i] = P.dr_kp[(size_t)e * BEZ_ND + d0 + i];
+      if (P.dr_kd) kds[i] = P.dr_kd[(size_t)e * BEZ_ND + d0 + i];
+      if (P.dr_mass) ms[i] = P.dr_mass[(size_t)e * BEZ_NL + FIRST + i];
+      if (P.dr_lower) lo[i] = P.dr_lower[(size_t)e * BEZ_ND + d0 + i];
+      if (P.dr_upper) hi[i] = P.dr_upper[(size_t)e * BEZ_ND + d0 + i];
+    }
+  }
+}
+// position targets of NJ joints from the staged action row (kick_env.py:410-419) or from the state (physics-only entry point)
+template <int FIRST, int NJ, bool PRE, bool HEAD>
+BEZ_DEV void load_targets(const Params& P, const float* lds, int lane, int e, float* target) {
+  if (PRE) {
+    const float* act = lds + X_STAGE * WS_ENVS + lane * WS_ACT_STRIDE;
+#pragma unroll
+    for (int i = 0; i < NJ; ++i) {
+      constexpr int d0 = FIRST - 1;
+      float a = fminf(fmaxf(act[d0 + i], -P.clip), P.clip);
+      if (HEAD) a = 0.f;  // head frozen (kick_env.py:414)
+      float t = a + (float)BEZ_DOF_DEFAULT[d0 + i];
+      target[i] = fmaxf(fminf(t, (float)BEZ_DOF_UPPER[d0 + i]), (float)BEZ_DOF_LOWER[d0 + i]);
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < NJ; ++i) target[i] = P.state[(size_t)(F_TARGET + FIRST - 1 + i) * P.n + e];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ roles
+template <int FIRST, bool PRE, bool POST, bool DR, bool CL>
+BEZ_DEV void leg_role(const Params& P, float* lds, int lane, int e, bool active, int side) {
+  constexpr int LEN = 6;
+  float q[LEN], qd[LEN], target[LEN], kps[LEN], kds[LEN], ms[LEN], lo[LEN], hi[LEN];
+  load_joints<FIRST, LEN, DR>(P, e, q, qd, kps, kds, ms, lo, hi);
+#pragma unroll
+  for (int i = 0; i < LEN; ++i) { XS(X_LEGQ + side * 12 + i) = q[i]; XS(X_LEGQ + side * 12 + 6 + i) = qd[i]; }
+  const ChainDyn D0 = load_chain_dyn<DR>(P, e);
+  bool do_reset = false;  // reset_buf of the previous step (kick_env.py:433-435) and the episode counter: fetched during the
+  uint32_t episode = 0u;  // last substep (their latency hides behind pass 3 without holding registers through the physics)
+  const bool last_only = (P.flags & BEZ_FLAG_CF_LAST_SUBSTEP) != 0;
+  WS_STAMP(side, 0);
+  ws_barrier();  // B0: actions staged, root/ball and the leg joint state published
+  WS_STAMP(side, 1);
+  load_targets<FIRST, LEN, PRE, false>(P, lds, lane, e, target);
+  for (int s = 0; s < P.substeps; ++s) {
+    const bool keep = last_only ? (s == P.substeps - 1) : true;
+    const bool first = last_only ? true : (s == 0);
+    const ChainDyn D = in_loop(D0);
+    RootView R = load_root_view(lds, lane);
+    LinkInertia LI[LEN]; SV pAl[LEN], Sl[LEN], cbl[LEN];
+    BallSel sel;
+    sel.link = -1; sel.depth = 0.f; sel.n = sel.P = sel.f0p = sel.x = sel.xb = mk(0, 0, 0); sel.A = sym3zero();
+    M3 Eend; V3 rend; SV Vend, Vsel = svzero();
+    ws_chain_pass1<FIRST, LEN, true, CL, false>(P, D, ms, R, q, qd, LI, pAl, Sl, cbl, Eend, rend, Vend, sel, Vsel);
+    Sym6 Kc = sym6zero(); SV pc = svzero();
+    ws_ground_points<FIRST + LEN - 1, CL>(P, D.mu, R.root_z, Eend, rend, Vend, Kc, pc, lds, lane, X_HIT + side * 32);
+    xs_store_body_contact(lds, lane, X_BCN + side * 18, body_contact_of(Kc, pc));
+    WS_STAMP(side, 2 + 8 * s);
+    ws_barrier();  // B1: the three ball candidates (roles 4, 5, 3) are evaluated and published
+    WS_STAMP(side, 3 + 8 * s);
+    // this leg's candidate wins: evaluate the contact now (skipped by the whole wave when no env of the workgroup has one)
+    const int c0 = X_CAND + side * 14;
+    bool mine = (cand_winner(load_cand_depths(lds, lane)) == side) && (XS(c0 + 1) >= 1.f);
+    if (mine) {
+      const RootView Rb = load_root_view(lds, lane);
+      sel.depth = XS(c0); sel.link = (int)XS(c0 + 1);
+      sel.n = xs_load_v3(lds, lane, c0 + 2); sel.P = xs_load_v3(lds, lane, c0 + 5);
+      const SV Vl = xs_load_sv(lds, lane, c0 + 8);
+      const BallBody ball = ball_setup(P, D.mu, D.g, Rb.ball_z, Rb.ball_ang, Rb.ball_lin);
+      ball_link_contact(P, D.mu, Rb.ball_ang, Rb.ball_lin, ball, Rb.bc, Vl, sel);  // may reject the candidate (link = -1)
+      mine = sel.link >= 1;
+    } else {
+      sel.link = -1;
+    }
+    P3 p3[LEN];
+    Sym6 IA = sym6zero(); SV pA = svzero();
+    ws_chain_pass2<FIRST, LEN, true>(P, D, kps, kds, lo, hi, q, qd, target, LI, pAl, Sl, cbl, Kc, pc, mine, sel, p3, IA, pA);
+    WS_STAMP(side, 24 + s);
+    ws_barrier();  // B1c: both helper parts' leg<->leg contact wrenches are in LDS
+    ws_chain_self_correction<LEN>(lds, lane, side, p3, pA);
+    xs_store_sym6(lds, lane, X_IA + side * 27, IA, pA);
+    WS_STAMP(side, 4 + 8 * s);
+    ws_barrier();  // B2
+    WS_STAMP(side, 5 + 8 * s);
+    ws_barrier();  // B3: torso acceleration published
+    WS_STAMP(side, 6 + 8 * s);
+    SV a0 = xs_load_sv(lds, lane, X_A0);
+    V3 fl = mk(0, 0, 0), fend = mk(0, 0, 0);
+    SV aend = ws_chain_pass3<FIRST, LEN, true, CL>(P, a0, p3, q, qd, mine, sel, fl, fend, lds, lane, keep, first);
+    if (mine && sel.link >= 0) { xs_store_v3(lds, lane, X_FL, fl); xs_store_v3(lds, lane, X_FL + 3, sel.xb); }
+    if (keep) {
+      if constexpr (CL) {  // the foot plate only feels the ball / the other leg; the ground acts on the four cleats
+        ws_cf_acc(lds, lane, link_body<CL>(FIRST + LEN - 1), fend, P.cf_w, first);
+        ws_cleat_forces<FIRST + LEN - 1>(P, lds, lane, X_HIT + side * 32, aend, first);
+      } else {
+        const BodyContact bcn = xs_load_body_contact(lds, lane, X_BCN + side * 18);
+        ws_cf_acc(lds, lane, link_body<CL>(FIRST + LEN - 1), fend + cf_ground(P, body_contact_force(bcn, aend)), P.cf_w, first);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < LEN; ++i) { XS(X_LEGQ + side * 12 + i) = q[i]; XS(X_LEGQ + side * 12 + 6 + i) = qd[i]; }
+    if (POST && s == P.substeps - 1) { do_reset = P.reset[e] != 0; episode = P.episode[e]; }
+    WS_STAMP(side, 7 + 8 * s);
+    ws_barrier();  // B4
+    WS_STAMP(side, 8 + 8 * s);
+    ws_barrier();  // B5: new root/ball state published
+    WS_STAMP(side, 9 + 8 * s);
+  }
+  ws_chain_epilogue<(FIRST == 5 ? 0 : 1), POST>(P, lds, lane, e, active, do_reset, episode, q, qd, target);
+  ws_barrier();  // B6
+}
+
+// A 2-link chain (head / one arm) owned by a role: its state and the three passes, split at the barriers by the caller.
+template <int FIRST, int BLOCK_IA, bool CL>
+struct Chain2 {
+  float q[2], qd[2], target[2], kps[2], kds[2], ms[2], lo[2], hi[2];
+  P3 p3[2];
+  BodyContact bcn;
+  Sym6 IAc; SV pAc;  // the chain's contribution as seen by the torso (also stored to its X_IA block)
+  BEZ_DEV void up(const Params& P, const ChainDyn& D, float* lds, int lane) {  // passes 1 + 2, contribution -> X_IA block
+    RootView R = load_root_view(lds, lane);
+    BallSel nosel; nosel.link = -1; nosel.depth = 0.f; nosel.n = nosel.P = nosel.f0p = nosel.x = nosel.xb = mk(0, 0, 0); nosel.A = sym3zero();
+    LinkInertia LI[2]; SV pAl[2], Sl[2], cbl[2]; M3 Ee; V3 re; SV Ve, Vs = svzero();
+    ws_chain_pass1<FIRST, 2, false, CL>(P, D, ms, R, q, qd, LI, pAl, Sl, cbl, Ee, re, Ve, nosel, Vs);
+    Sym6 Kc = sym6zero(); SV pc = svzero();
+    ws_ground_points<FIRST + 1, CL>(P, D.mu, R.root_z, Ee, re, Ve, Kc, pc);
+    Sym6 IA = sym6zero(); SV pA = svzero();
+    ws_chain_pass2<FIRST, 2, false>(P, D, kps, kds, lo, hi, q, qd, target, LI, pAl, Sl, cbl, Kc, pc, false, nosel, p3, IA, pA);
+    bcn = body_contact_of(Kc, pc);
+    IAc = IA; pAc = pA;
+    xs_store_sym6(lds, lane, X_IA + BLOCK_IA * 27, IA, pA);
+  }
+  BEZ_DEV void down(const Params& P, float* lds, int lane, bool keep, bool first) {  // pass 3 + the chain-end contact row
+    BallSel nosel; nosel.link = -1; nosel.depth = 0.f; nosel.n = nosel.P = nosel.f0p = nosel.x = nosel.xb = mk(0, 0, 0); nosel.A = sym3zero();
+    SV a0 = xs_load_sv(lds, lane, X_A0);
+    V3 fl = mk(0, 0, 0), fend = mk(0, 0, 0);
+    SV ae = ws_chain_pass3<FIRST, 2, false, CL>(P, a0, p3, q, qd, false, nosel, fl, fend, lds, lane, keep, first);
+    if (keep) ws_cf_acc(lds, lane, link_body<CL>(FIRST + 1), cf_ground(P, body_contact_force(bcn, ae)), P.cf_w, first);
+  }
+};
+
+template <bool PRE, bool POST, bool DR, bool CL>
+BEZ_DEV void head_role(const Params& P, float* lds, int lane, int e, bool active) {
+  Chain2<1, 2, CL> C;
+  load_joints<1, 2, DR>(P, e, C.q, C.qd, C.kps, C.kds, C.ms, C.lo, C.hi);
+  const ChainDyn D = load_chain_dyn<DR>(P, e);
+  const bool do_reset = POST && P.reset[e] != 0;
+  const uint32_t episode = POST ? P.episode[e] : 0u;
+  const bool last_only = (P.flags & BEZ_FLAG_CF_LAST_SUBSTEP) != 0;
+  ws_barrier();  // B0
+  load_targets<1, 2, PRE, true>(P, lds, lane, e, C.target);
+  for (int s = 0; s < P.substeps; ++s) {
+    const bool keep = last_only ? (s == P.substeps - 1) : true;
+    const bool first = last_only ? true : (s == 0);
+    WS_STAMP(2, 2 + 8 * s);
+    ws_barrier();  // B1  (X_IA is free from here on: the staged actions have been consumed)
+    C.up(P, in_loop(D), lds, lane);
+    WS_STAMP(2, 4 + 8 * s);
+    ws_barrier();  // B1c: head and arm blocks are in LDS (role 4 sums them into block 2 before B2)
+    ws_barrier();  // B2
+    ws_barrier();  // B3
+    C.down(P, lds, lane, keep, first);
+    ws_barrier();  // B4
+    ws_barrier();  // B5
+  }
+  ws_chain_epilogue<2, POST>(P, lds, lane, e, active, do_reset, episode, C.q, C.qd, C.target);
+  ws_barrier();  // B6
+}
+
+// roles 4 / 5: the deepest ball<->leg-box candidate of one leg from this wave's own forward kinematics of that leg (window of
+// the leg's pass 1), then the arm of the same side as a chain of its own (window of the leg's pass 2); role 4 finally adds the head and
+// right-arm blocks to its own and leaves the sum in block 2, so that the root role reads three blocks.
+template <int LEG_FIRST, int ARM_FIRST, bool PRE, bool POST, bool DR, bool CL>
+BEZ_DEV void cand_arm_role(const Params& P, float* lds, int lane, int e, bool active, int side) {
+  constexpr int ROLE = LEG_FIRST == 5 ? 4 : 5;
+  Chain2<ARM_FIRST, 3 + (LEG_FIRST == 5 ? 0 : 1), CL> C;
+  load_joints<ARM_FIRST, 2, DR>(P, e, C.q, C.qd, C.kps, C.kds, C.ms, C.lo, C.hi);
+  const ChainDyn D = load_chain_dyn<DR>(P, e);
+  const bool do_reset = POST && P.reset[e] != 0;
+  const uint32_t episode = POST ? P.episode[e] : 0u;
+  const bool last_only = (P.flags & BEZ_FLAG_CF_LAST_SUBSTEP) != 0;
+  ws_barrier();  // B0
+  load_targets<ARM_FIRST, 2, PRE, false>(P, lds, lane, e, C.target);
+  for (int s = 0; s < P.substeps; ++s) {
+    const bool keep = last_only ? (s == P.substeps - 1) : true;
+    const bool first = last_only ? true : (s == 0);
+    {
+      RootView R = load_root_view(lds, lane);
+      BallSel sel;
+      sel.link = -1; sel.depth = 0.f; sel.n = sel.P = sel.f0p = sel.x = sel.xb = mk(0, 0, 0); sel.A = sym3zero();
+      M3 E = R.E0; V3 r = mk(0, 0, 0); SV V = R.V0, Sj, cbj, Vsel = svzero();
+      static_for<6>([&](auto I) {
+        constexpr int i = decltype(I)::value;
+        constexpr int L = LEG_FIRST + i;
+        link_kinematics<L>(XS(X_LEGQ + side * 12 + i), XS(X_LEGQ + side * 12 + 6 + i), E, r, V, Sj, cbj);
+        if constexpr (link_has_box(L)) {
+          test_box<link_box(L)>(E, r, R.bc, sel);
+          if (sel.link == L) Vsel = V;  // this box just became the deepest candidate: keep its link velocity
+        }
+      });
+      publish_cand(lds, lane, side, sel, Vsel);
+    }
+    WS_STAMP(ROLE, 2 + 8 * s);
+    ws_barrier();  // B1
+    C.up(P, in_loop(D), lds, lane);
+    WS_STAMP(ROLE, 4 + 8 * s);
+    ws_barrier();  // B1c: head and arm blocks are in LDS
+    if (ROLE == 4) {
+      Sym6 I2; SV p2;
+      xs_load_sym6(lds, lane, X_IA + 2 * 27, I2, p2);
+      xs_add_sym6(lds, lane, X_IA + 4 * 27, I2, p2);
+      add_to(I2, C.IAc); p2 = p2 + C.pAc;
+      xs_store_sym6(lds, lane, X_IA + 2 * 27, I2, p2);
+    }
+    ws_barrier();  // B2
+    ws_barrier();  // B3
+    C.down(P, lds, lane, keep, first);
+    ws_barrier();  // B4
+    ws_barrier();  // B5
+  }
+  ws_chain_epilogue<ROLE, POST>(P, lds, lane, e, active, do_reset, episode, C.q, C.qd, C.target);
+  ws_barrier();  // B6
+}
+
+// roles 6 / 7: leg<->leg capsule pairs.  Forward kinematics of both legs from X_LEGQ, then this part's pairs; the wrenches are
+// complete at B1c (the legs apply them after pass 2).
+template <int PART, bool DR>
+BEZ_DEV void self_role(const Params& P, float* lds, int lane, int e) {
+  const ChainDyn D = load_chain_dyn<DR>(P, e);
+  ws_barrier();  // B0
+  for (int s = 0; s < P.substeps; ++s) {
+    SelfCaps K;
+    {
+      const M3 E0 = quat_to_mat(XS(X_ROOT + 3), XS(X_ROOT + 4), XS(X_ROOT + 5), XS(X_ROOT + 6));
+      const SV V0 = mksv(xs_load_v3(lds, lane, X_ROOT + 10), xs_load_v3(lds, lane, X_ROOT + 7));
+      ws_self_fk<PART>(lds, lane, E0, V0, K);
+      ws_self_pin<PART>(K);
+    }
+    WS_STAMP(6 + PART, 2 + 8 * s);
+    ws_barrier();  // B1
+    ws_self_pairs<PART>(P, D.mu, lds, lane, K);
+    WS_STAMP(6 + PART, 4 + 8 * s);
+    ws_barrier();  // B1c
+    ws_barrier();  // B2
+    ws_barrier();  // B3
+    ws_barrier();  // B4
+    ws_barrier();  // B5
+  }
+  ws_barrier();  // B6
+}
+
+template <bool PRE, bool POST, bool DR, bool CL>
+BEZ_DEV void root_role(const Params& P, float* lds, int lane, int e, bool active) {
+  const int n = P.n;
+  float* st = P.state;
+  auto ld = [&](int f) { return st[(size_t)f * n + e]; };
+  V3 root_pos = mk(ld(F_ROOT_POS), ld(F_ROOT_POS + 1), ld(F_ROOT_POS + 2));
+  float rq[4] = {ld(F_ROOT_QUAT), ld(F_ROOT_QUAT + 1), ld(F_ROOT_QUAT + 2), ld(F_ROOT_QUAT + 3)};
+  V3 root_lin = mk(ld(F_ROOT_LIN), ld(F_ROOT_LIN + 1), ld(F_ROOT_LIN + 2));
+  V3 root_ang = mk(ld(F_ROOT_ANG), ld(F_ROOT_ANG + 1), ld(F_ROOT_ANG + 2));
+  V3 ball_pos = mk(ld(F_BALL_POS), ld(F_BALL_POS + 1), ld(F_BALL_POS + 2));
+  float bq[4] = {ld(F_BALL_QUAT), ld(F_BALL_QUAT + 1), ld(F_BALL_QUAT + 2), ld(F_BALL_QUAT + 3)};
+  V3 ball_lin = mk(ld(F_BALL_LIN), ld(F_BALL_LIN + 1), ld(F_BALL_LIN + 2));
+  V3 ball_ang = mk(ld(F_BALL_ANG), ld(F_BALL_ANG + 1), ld(F_BALL_ANG + 2));
+  // bookkeeping inputs of the post-physics, fetched now so that their latency hides behind the physics
+  int64_t progress = 0, reset = 0;
+  float prev[3] = {0.f, 0.f, 0.f};
+  if (POST) {
+    progress = P.progress[e]; reset = P.reset[e];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) prev[i] = ld(F_PREV + i);
+  }
+  const ChainDyn D = load_chain_dyn<DR>(P, e);
+  float ms0 = 1.f;
+  if (DR) { if (P.dr_mass) ms0 = P.dr_mass[(size_t)e * BEZ_NL]; }
+  const bool last_only = (P.flags & BEZ_FLAG_CF_LAST_SUBSTEP) != 0;
+  auto publish = [&]() {
+    xs_store_v3(lds, lane, X_ROOT, root_pos);
+    XS(X_ROOT + 3) = rq[0]; XS(X_ROOT + 4) = rq[1]; XS(X_ROOT + 5) = rq[2]; XS(X_ROOT + 6) = rq[3];
+    xs_store_v3(lds, lane, X_ROOT + 7, root_lin); xs_store_v3(lds, lane, X_ROOT + 10, root_ang);
+    xs_store_v3(lds, lane, X_BALL, ball_pos); xs_store_v3(lds, lane, X_BALL + 3, ball_lin); xs_store_v3(lds, lane, X_BALL + 6, ball_ang);
+  };
+  publish();
+  WS_STAMP(3, 0);
+  ws_barrier();  // B0
+  WS_STAMP(3, 1);
+  for (int s = 0; s < P.substeps; ++s) {
+    const bool keep = last_only ? (s == P.substeps - 1) : true;
+    const bool first = last_only ? true : (s == 0);
+    const M3 E0 = quat_to_mat(rq[0], rq[1], rq[2], rq[3]);
+    const SV V0 = mksv(root_ang, root_lin);
+    const V3 bc = ball_pos - root_pos;
+    xs_store_v3(lds, lane, X_FL, mk(0, 0, 0)); xs_store_v3(lds, lane, X_FL + 3, mk(0, 0, 0));
+    Sym6 IA0 = sym6zero(); SV pA0;
+    LinkInertia I0;
+    link_inertia<0, CL>(ms0, D.g, E0, mk(0, 0, 0), V0, I0, pA0);
+    Sym6 Kc = sym6zero(); SV pc = svzero();
+    ws_ground_points<0, CL>(P, D.mu, root_pos.z, E0, mk(0, 0, 0), V0, Kc, pc);
+    BodyContact bc0 = body_contact_of(Kc, pc);
+    add_link_inertia(IA0, I0);
+    add_to(IA0, Kc); pA0 = pA0 + pc;
+    BallBody ball = ball_setup(P, D.mu, D.g, ball_pos.z, ball_ang, ball_lin);
+    // the torso box as a ball candidate, evaluated now; the winner is decided from the three published depths after B1
+    BallSel sel;
+    sel.link = -1; sel.depth = 0.f; sel.n = sel.P = sel.f0p = sel.x = sel.xb = mk(0, 0, 0); sel.A = sym3zero();
+    test_box<link_box(0)>(E0, mk(0, 0, 0), bc, sel);
+    XS(X_TORSO) = sel.depth;
+    if (sel.link == 0) ball_link_contact(P, D.mu, ball_ang, ball_lin, ball, bc, V0, sel);
+    WS_STAMP(3, 2 + 8 * s);
+    ws_barrier();  // B1: all three candidates are in LDS
+    WS_STAMP(3, 3 + 8 * s);
+    const int winner = cand_winner(load_cand_depths(lds, lane));
+    const bool torso_hit = (winner == 2) && (sel.link == 0);
+    if (torso_hit) { add_point_stiffness(IA0, sel.x, sel.A); pA0 = pA0 - wrench_at(sel.x, sel.f0p); }
+    if (winner != 2) sel.n = xs_load_v3(lds, lane, X_CAND + winner * 14 + 2);  // contact normal of the winning leg box (ball's contact row)
+    WS_STAMP(3, 24 + s);
+    ws_barrier();  // B1c
+    ws_barrier();  // B2: chain contributions published
+    WS_STAMP(3, 5 + 8 * s);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) xs_add_sym6(lds, lane, X_IA + k * 27, IA0, pA0);  // legs + (head + arms, summed by role 4)
+    SV a0 = solve_spd6(IA0, svzero() - pA0);
+    xs_store_sv(lds, lane, X_A0, a0);
+    WS_STAMP(3, 4 + 8 * s);
+    ws_barrier();  // B3
+    WS_STAMP(3, 6 + 8 * s);
+    V3 fl_t = mk(0, 0, 0);
+    if (torso_hit) fl_t = sel.f0p - mul(sel.A, point_of(a0, sel.x));
+    if (keep) ws_cf_acc(lds, lane, 0, cf_along(P, fl_t, sel.n) + cf_ground(P, body_contact_force(bc0, a0)), P.cf_w, first);
+    V3 vdot = a0.l + cross(root_ang, root_lin);
+    root_ang = fma3(a0.a, P.h, root_ang);
+    root_lin = fma3(vdot, P.h, root_lin);
+    root_pos = fma3(root_lin, P.h, root_pos);
+    quat_integrate(rq, root_ang, P.h);
+    WS_STAMP(3, 7 + 8 * s);
+    ws_barrier();  // B4: ball<->link force published
+    WS_STAMP(3, 8 + 8 * s);
+    V3 fl = xs_load_v3(lds, lane, X_FL), xb = xs_load_v3(lds, lane, X_FL + 3);
+    if (torso_hit) { fl = fl_t; xb = sel.xb; }
+    SV ab = ball_minv(ball, svzero() - ball.pb - wrench_at(xb, fl));
+    if (keep) {
+      V3 fb = -cf_along(P, fl, sel.n);
+      if (ball.ground) fb = fb + cf_ground(P, hit_force(P, ball.ghit, ab));
+      ws_cf_acc(lds, lane, nb_of<CL>(), fb, P.cf_w, first);
+    }
+    float damp = fmaxf(1.0f - P.h * P.ball_damp, 0.f);
+    ball_lin = fma3(ab.l, P.h, ball_lin);
+    ball_ang = fma3(ab.a, P.h, ball_ang) * damp;
+    ball_pos = fma3(ball_lin, P.h, ball_pos);
+    quat_integrate(bq, ball_ang, P.h);
+    publish();
+    ws_barrier();  // B5
+    WS_STAMP(3, 9 + 8 * s);
+  }
+  ws_barrier();  // B6: joint obs slots / pose-error sums / contact-force rows of the chain roles are in LDS
+  WS_STAMP(3, 20);
+  if (POST) {
+    CfOut co;
+    co.base = nullptr; co.n = n;
+    co.lf = xs_load_v3(lds, lane, X_CF + lfoot_body<CL>() * 3); co.rf = xs_load_v3(lds, lane, X_CF + rfoot_body<CL>() * 3);
+    float goal_x = P.goal[0], goal_y = P.goal[1];
+    if (P.task != BEZ_TASK_KICK) { goal_x = ld(F_GOAL); goal_y = ld(F_GOAL + 1); }
+    int64_t timeout = (progress >= (int64_t)(P.max_len - 1)) ? 1 : 0;  // vec_task.py:331-332
+    progress += 1;                                                    // kick_env.py:429
+    if (reset != 0) {                                                 // kick_env.py:433-435, 831-850 (root / ball part)
+      root_pos = mk(P.bez_init[0], P.bez_init[1], P.bez_init[2]);
+      ball_pos = mk(P.ball_init[0], P.ball_init[1], P.ball_init[2]);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { rq[i] = P.bez_init[3 + i]; bq[i] = P.ball_init[3 + i]; }
+      root_lin = root_ang = ball_lin = ball_ang = mk(0, 0, 0);
+      co.lf = co.rf = mk(0, 0, 0);
+#pragma unroll
+      for (int k = 0; k < (nb_of<CL>() + 1) * 3; ++k) XS(X_CF + k) = 0.f;
+      if (active) P.episode[e] = P.episode[e] + 1;
+      if (P.task != BEZ_TASK_KICK) {  // walk_env.py:570-575: every env reset by this call receives the same fresh goal
+        goal_x = P.goal_draw[0]; goal_y = P.goal_draw[1];
+        if (active) { st[(size_t)F_GOAL * n + e] = goal_x; st[(size_t)(F_GOAL + 1) * n + e] = goal_y; }
+      }
+      progress = 0; reset = 0;
+    }
+    float pn = (((XS(X_PSUM + 2) + XS(X_PSUM + 4)) + XS(X_PSUM + 5)) + XS(X_PSUM + 0)) + XS(X_PSUM + 1);
+    float feet[8], rew;
+    float* obs_row = lds + X_STAGE * WS_ENVS + lane * P.nobs;
+    float tail[18];
+    float cleats[24];
+    if (CL) {
+#pragma unroll
+      for (int k = 0; k < 12; ++k) { cleats[k] = XS(X_CF + BEZ_LCLEAT_BODY_CL * 3 + k); cleats[12 + k] = XS(X_CF + BEZ_RCLEAT_BODY_CL * 3 + k); }
+    }
+    env_observe_core(P, root_pos, rq, root_lin, root_ang, ball_pos, ball_lin, co, prev, feet, tail, pn, rew, reset, progress, goal_x, goal_y,
+                     CL ? cleats : nullptr);
+#pragma unroll
+    for (int i = 0; i < 18; ++i) if (36 + i < P.nobs) obs_row[36 + i] = tail[i];
+    if (!CL) {  // the no-cleats feet logic filters the two foot rows in place (kick_env.py:987-990)
+      xs_store_v3(lds, lane, X_CF + BEZ_LFOOT_BODY * 3, co.lf); xs_store_v3(lds, lane, X_CF + BEZ_RFOOT_BODY * 3, co.rf);
+    }
+    if (active) {
+#pragma unroll
+      for (int i = 0; i < 3; ++i) st[(size_t)(F_PREV + i) * n + e] = prev[i];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) st[(size_t)(F_FEET + i) * n + e] = feet[i];
+      P.rew[e] = rew; P.reset[e] = reset; P.progress[e] = progress; P.timeout[e] = timeout;
+    }
+  }
+  WS_STAMP(3, 21);
+  if (active) {
+    auto sv = [&](int f, float v) { st[(size_t)f * n + e] = v; };
+    sv(F_ROOT_POS, root_pos.x); sv(F_ROOT_POS + 1, root_pos.y); sv(F_ROOT_POS + 2, root_pos.z);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { sv(F_ROOT_QUAT + i, rq[i]); sv(F_BALL_QUAT + i, bq[i]); }
+    sv(F_ROOT_LIN, root_lin.x); sv(F_ROOT_LIN + 1, root_lin.y); sv(F_ROOT_LIN + 2, root_lin.z);
+    sv(F_ROOT_ANG, root_ang.x); sv(F_ROOT_ANG + 1, root_ang.y); sv(F_ROOT_ANG + 2, root_ang.z);
+    sv(F_BALL_POS, ball_pos.x); sv(F_BALL_POS + 1, ball_pos.y); sv(F_BALL_POS + 2, ball_pos.z);
+    sv(F_BALL_LIN, ball_lin.x); sv(F_BALL_LIN + 1, ball_lin.y); sv(F_BALL_LIN + 2, ball_lin.z);
+    sv(F_BALL_ANG, ball_ang.x); sv(F_BALL_ANG + 1, ball_ang.y); sv(F_BALL_ANG + 2, ball_ang.z);
+  }
+}
+
+// ---- the kernel.  grid = ceil(N / 64) workgroups of 512 threads.
+template <bool PRE, bool POST, bool DR, bool CL>
+__global__ __launch_bounds__(WS_BLOCK) void step_kernel_ws8(Params P) {
+  __shared__ __attribute__((aligned(16))) float lds[WS_LDS_FLOATS];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int role = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int env0 = blockIdx.x * WS_ENVS;
+  const int nloc = min(WS_ENVS, P.n - env0);
+  const bool active = lane < nloc;
+  const int e = env0 + (active ? lane : 0);  // inactive lanes shadow env0 (loads only; every global store is guarded)
+  WS_STAMP(role, 22);
+  if (PRE) {
+    // coalesced stage of this workgroup's contiguous (nloc,18) action block, transposed to [lane][19]
+    float* act = lds + X_STAGE * WS_ENVS;
+    const float* src = P.actions + (size_t)env0 * BEZ_ND;
+    for (int i = tid; i < nloc * BEZ_ND; i += WS_BLOCK) act[(i / BEZ_ND) * WS_ACT_STRIDE + (i % BEZ_ND)] = src[i];
+  }
+  // contact-force rows start from zero: bodies nothing touches are never accumulated into
+  constexpr int NROW = (nb_of<CL>() + 1) * 3;  // contact-force rows of this asset (robot bodies + ball)
+  for (int i = tid; i < NROW * WS_ENVS; i += WS_BLOCK) lds[X_CF * WS_ENVS + i] = 0.f;
+  if (role == 0) leg_role<5, PRE, POST, DR, CL>(P, lds, lane, e, active, 0);
+  else if (role == 1) leg_role<13, PRE, POST, DR, CL>(P, lds, lane, e, active, 1);
+  else if (role == 2) head_role<PRE, POST, DR, CL>(P, lds, lane, e, active);
+  else if (role == 3) root_role<PRE, POST, DR, CL>(P, lds, lane, e, active);
+  else if (role == 4) cand_arm_role<5, 3, PRE, POST, DR, CL>(P, lds, lane, e, active, 0);
+  else if (role == 5) cand_arm_role<13, 11, PRE, POST, DR, CL>(P, lds, lane, e, active, 1);
+  else if (role == 6) self_role<0, DR>(P, lds, lane, e);
+  else self_role<1, DR>(P, lds, lane, e);
+  ws_barrier();  // contact-force rows (and, with POST, the observation rows staged by the chain roles and role 3) are complete in LDS
+  {
+    // net contact force: SoA rows of 64 consecutive envs each -> coalesced
+    float* dst = P.state + (size_t)F_CF * P.n + env0;
+    for (int i = tid; i < NROW * WS_ENVS; i += WS_BLOCK) {
+      const int k = i >> 6, l = i & 63;
+      if (l < nloc) dst[(size_t)k * P.n + l] = lds[(X_CF + k) * WS_ENVS + l];
+    }
+  }
+  if (POST) {
+    // the staged rows are the contiguous (nloc,nobs) image of this workgroup's slice of obs_buf: 16-byte copy-out
+    const float4* rows = reinterpret_cast<const float4*>(lds + X_STAGE * WS_ENVS);
+    float4* dst = reinterpret_cast<float4*>(P.obs + (size_t)env0 * P.nobs);  // 64 * nobs * 4 B per workgroup: 16-B aligned for 54 and 52
+    const int nvec = (nloc * P.nobs) >> 2;
+    for (int i = tid; i < nvec; i += WS_BLOCK) dst[i] = rows[i];
+    for (int i = (nvec << 2) + tid; i < nloc * P.nobs; i += WS_BLOCK) P.obs[(size_t)env0 * P.nobs + i] = lds[X_STAGE * WS_ENVS + i];
+  }
+  WS_STAMP(role, 23);
+}
+
+#undef XS
+}  // namespace w8
+}  // namespace bez

@@ -10,6 +10,8 @@
 namespace bez {
 // fused wave-specialised step: (PRE, POST) = (pre, pre) -- the whole control step, or the physics alone
 void launch_step_ws(const Params& P, bool pre_post, bool dr, bool cleats, hipStream_t stream);
+// the same step with 8 role waves per 64 envs (bez_kernel_ws8.h)
+void launch_step_ws8(const Params& P, bool pre_post, bool dr, bool cleats, hipStream_t stream);
 // one-env-per-lane kernel: split entry points (PRE / SIM / POST alone), the obs-only pass and the A/B reference of the fused step
 void launch_step_lane(const Params& P, bool pre, bool sim, bool post, bool dr, bool cleats, hipStream_t stream);
 constexpr int WS_ENVS_PER_GROUP = 64;

@@ -278,6 +278,11 @@ bool use_ws_kernel() {
   static const bool ws = [] { const char* v = std::getenv("BEZ_SIM_KERNEL"); return !(v && std::string(v) == "lane"); }();
   return ws;
 }
+// BEZ_SIM_KERNEL=ws8 selects the 8-role-wave variant (bez_kernel_ws8.h)
+bool use_ws8_kernel() {
+  static const bool w = [] { const char* v = std::getenv("BEZ_SIM_KERNEL"); return v && std::string(v) == "ws8"; }();
+  return w;
+}
 
 // PMC calibration: dword-per-lane coalesced read of `n` floats (the access shape of the step kernels' state loads)
 __global__ void calib_read_kernel(const float* __restrict__ in, float* __restrict__ out, size_t n) {
@@ -301,7 +306,8 @@ int launch_step(BezSim* s, const float* actions, hipStream_t stream, bool obs_on
   const bool dr = has_dr(s) || s->cleats;
   if constexpr (SIM && PRE == POST) {
     if (use_ws_kernel()) {
-      bez::launch_step_ws(P, PRE, dr, s->cleats, stream);
+      if (use_ws8_kernel()) bez::launch_step_ws8(P, PRE, dr, s->cleats, stream);
+      else bez::launch_step_ws(P, PRE, dr, s->cleats, stream);
       hipError_t e = hipGetLastError();
       if (e != hipSuccess) return fail(s, -2, "step_kernel_ws launch", e);
       if (POST) s->obs_calls += 1;
@@ -574,14 +580,14 @@ int bez_sim_set_env_params(BezSim* s, int param, const float* values_dev, void* 
 }
 
 #ifdef BEZ_WS_STAMPS
-/* diagnostic build only: run one fused step and return the 4 x 32 s_memtime stamps of workgroup 0 */
+/* diagnostic build only: run one fused step and return the 8 x 32 s_memtime stamps (roles x phase boundaries) of workgroup 0 */
 int bez_sim_debug_stamps(BezSim* s, const float* actions_dev, unsigned long long* out_host) {
-  if (!s->stamps) { HIP_TRY(s, hipMalloc((void**)&s->stamps, 128 * sizeof(unsigned long long))); }
-  HIP_TRY(s, hipMemset(s->stamps, 0, 128 * sizeof(unsigned long long)));
+  if (!s->stamps) { HIP_TRY(s, hipMalloc((void**)&s->stamps, 256 * sizeof(unsigned long long))); }
+  HIP_TRY(s, hipMemset(s->stamps, 0, 256 * sizeof(unsigned long long)));
   int rc = bez_sim_step(s, actions_dev, nullptr);
   if (rc) return rc;
   HIP_TRY(s, hipDeviceSynchronize());
-  HIP_TRY(s, hipMemcpy(out_host, s->stamps, 128 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  HIP_TRY(s, hipMemcpy(out_host, s->stamps, 256 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
   return 0;
 }
 #endif
