@@ -8,10 +8,10 @@
 // the first leaves empty):
 //     role 0  left leg   (links 5..10)    pass 1 (kinematics, inertias), foot ground contact, pass 2, leg<->leg correction, pass 3
 //     role 1  right leg  (links 13..18)   same
-//     role 2  head       (links 1,2)
+//     role 2  ball candidates among the hip / thigh boxes of both legs (own forward kinematics down to the thighs), then the
+//             head (links 1,2) as a chain of its own
 //     role 3  torso, ball, ball<->torso-box candidate, 6x6 root solve, integration, post-physics
-//     role 4  ball<->left-leg-box candidate: own forward kinematics of the left leg and the five box tests, the deepest one
-//             -> X_CAND; then the left arm (links 3,4) as a chain of its own; then the sum of the head / arm blocks
+//     role 4  ball candidate among the calf / ankle / foot boxes of the left leg (own forward kinematics of the leg) -> X_CAND; then the left arm (links 3,4) as a chain of its own; then the sum of the head / arm blocks
 //     role 5  the same for the right leg and the right arm (links 11,12)
 //     role 6  leg<->leg capsule pairs of the left hip/thigh/calf capsules (own forward kinematics of both legs)
 //     role 7  leg<->leg capsule pairs of the left ankle/foot capsules
@@ -36,7 +36,7 @@ enum : int {
   X_A0 = 22,       // torso spatial acceleration
   X_FL = 28,       // ball<->link force on the link (3) + contact point rel. ball centre (3)
   X_PSUM = 34,     // per chain-owning role (0,1,2,4,5): sum of (default - q)^2 over its joints
-  X_CAND = 40,     // per leg: depth, link, n(3), P(3), V(6) of its deepest ball/box candidate = 14 floats x 2 (roles 4 / 5)
+  X_CAND = 40,     // per leg: depth, link, n(3), P(3), V(6) of its deepest ball/box candidate among the lower boxes (roles 4 / 5) = 14 x 2
   X_TORSO = 68,    // depth of the torso-box candidate (role 3)
   X_LEGQ = 81,     // per leg: q(6) qd(6) at the start of the substep (read by the helper roles)
   X_SELF = 105,    // 2 helper parts x [per leg box link (left 5, right 5): bias wrench (6) + reported force (3)] = 2 x 90
@@ -44,8 +44,10 @@ enum : int {
   X_HIT = 375,     // cleats asset only: per leg 4 ground-point records x 8 floats (x3 fn0 kn ct ftx0 fty0)
   X_IA = 439,      // 5 chains (left leg, right leg, head, left arm, right arm) x (Sym6 21 + bias 6); block 2 ends up holding head + arms
   X_BCN = 574,     // per leg: contact rows of the foot (B 9, C 6, F0 3), parked here across pass 2 (register pressure)
-  X_SLOTS = 610
+  X_CANDH = 610,   // per leg: the same 14 floats for the upper boxes (hip / thigh links), from role 2
+  X_SLOTS = 638
 };
+constexpr int CAND_SPLIT = 3;  // leg links 0..2 (hip_side, hip_front, thigh) are tested by role 2, links 3..5 (calf, ankle, foot) by roles 4 / 5
 constexpr int X_STAGE = X_IA;  // staging aliases the chain blocks (see the header comment)
 constexpr int WS_ACT_STRIDE = 19;
 constexpr int WS_LDS_FLOATS = X_SLOTS * WS_ENVS;
@@ -88,15 +90,59 @@ BEZ_DEV BodyContact xs_load_body_contact(const float* lds, int lane, int slot) {
   return b;
 }
 
-// ---- the three ball candidates (left leg, right leg, torso): who wins, given the published depths
-struct CandDepths { float dl, dr, dt; };
-BEZ_DEV CandDepths load_cand_depths(const float* lds, int lane) { CandDepths c; c.dl = XS(X_CAND); c.dr = XS(X_CAND + 14); c.dt = XS(X_TORSO); return c; }
-// 0 left, 1 right, 2 torso: the right leg needs strictly more depth than the left, the torso strictly more than the better leg
+// ---- the ball candidates.  Each leg has two partial candidates (upper boxes from role 2, lower boxes from roles 4 / 5); the
+// boxes are ordered hip -> foot and an earlier box keeps a tie, so the lower one wins only if strictly deeper.  Then: left leg,
+// right leg, torso -- the right leg needs strictly more depth than the left, the torso strictly more than the better leg.
+struct CandDepths { float dl, dr, dt; int bl, br; };  // bl / br: slot base of the leg's winning partial candidate
+BEZ_DEV CandDepths load_cand_depths(const float* lds, int lane) {
+  CandDepths c;
+  const float lh = XS(X_CANDH), ll = XS(X_CAND), rh = XS(X_CANDH + 14), rl = XS(X_CAND + 14);
+  c.bl = (ll > lh) ? X_CAND : X_CANDH; c.dl = (ll > lh) ? ll : lh;
+  c.br = (rl > rh) ? X_CAND + 14 : X_CANDH + 14; c.dr = (rl > rh) ? rl : rh;
+  c.dt = XS(X_TORSO);
+  return c;
+}
+// 0 left, 1 right, 2 torso
 BEZ_DEV int cand_winner(const CandDepths& c) { const int sw = (c.dr > c.dl) ? 1 : 0; return (c.dt > (sw ? c.dr : c.dl)) ? 2 : sw; }
-BEZ_DEV void publish_cand(float* lds, int lane, int side, const BallSel& sel, SV Vsel) {
-  const int c0 = X_CAND + side * 14;
+BEZ_DEV void publish_cand(float* lds, int lane, int c0, const BallSel& sel, SV Vsel) {
   XS(c0) = sel.depth; XS(c0 + 1) = (float)sel.link;
   xs_store_v3(lds, lane, c0 + 2, sel.n); xs_store_v3(lds, lane, c0 + 5, sel.P); xs_store_sv(lds, lane, c0 + 8, Vsel);
+}
+// Forward kinematics of leg links [0, NFK) from the published joint state, keeping the frames of the box links [B0, NFK); the
+// box tests follow separately because the ball's new state is published later than the root's (deferred ball update).
+template <int B0, int NFK>
+struct LegFrames { M3 E[NFK - B0]; V3 r[NFK - B0]; SV V[NFK - B0]; };
+template <int LEG_FIRST, int B0, int NFK>
+BEZ_DEV void leg_frames(const float* lds, int lane, int side, const M3& E0, SV V0, LegFrames<B0, NFK>& F) {
+  M3 E = E0; V3 r = mk(0, 0, 0); SV V = V0, Sj, cbj;
+  static_for<NFK>([&](auto I) {
+    constexpr int i = decltype(I)::value;
+    link_kinematics<LEG_FIRST + i>(XS(X_LEGQ + side * 12 + i), XS(X_LEGQ + side * 12 + 6 + i), E, r, V, Sj, cbj);
+    if constexpr (i >= B0) { F.E[i - B0] = E; F.r[i - B0] = r; F.V[i - B0] = V; }
+  });
+}
+template <int LEG_FIRST, int B0, int NFK>
+BEZ_DEV void leg_box_tests(const LegFrames<B0, NFK>& F, V3 bc, float* lds, int lane, int c0) {
+  BallSel sel;
+  sel.link = -1; sel.depth = 0.f; sel.n = sel.P = sel.f0p = sel.x = sel.xb = mk(0, 0, 0); sel.A = sym3zero();
+  SV Vsel = svzero();
+  static_for<NFK - B0>([&](auto I) {
+    constexpr int k = decltype(I)::value;
+    constexpr int L = LEG_FIRST + B0 + k;
+    if constexpr (link_has_box(L)) {
+      test_box<link_box(L)>(F.E[k], F.r[k], bc, sel);
+      if (sel.link == L) Vsel = F.V[k];  // this box just became the deepest candidate: keep its link velocity
+    }
+  });
+  publish_cand(lds, lane, c0, sel, Vsel);
+}
+struct RootOnly { M3 E0; SV V0; V3 pos; };
+BEZ_DEV RootOnly load_root_only(const float* lds, int lane) {
+  RootOnly R;
+  R.pos = xs_load_v3(lds, lane, X_ROOT);
+  R.E0 = quat_to_mat(XS(X_ROOT + 3), XS(X_ROOT + 4), XS(X_ROOT + 5), XS(X_ROOT + 6));
+  R.V0 = mksv(xs_load_v3(lds, lane, X_ROOT + 10), xs_load_v3(lds, lane, X_ROOT + 7));
+  return R;
 }
 
 // per-env DR scalars every role may need
@@ -177,7 +223,7 @@ BEZ_DEV void leg_role(const Params& P, float* lds, int lane, int e, bool active,
     BallSel sel;
     sel.link = -1; sel.depth = 0.f; sel.n = sel.P = sel.f0p = sel.x = sel.xb = mk(0, 0, 0); sel.A = sym3zero();
     M3 Eend; V3 rend; SV Vend, Vsel = svzero();
-    ws_chain_pass1<FIRST, LEN, true, CL, false>(P, D, ms, R, q, qd, LI, pAl, Sl, cbl, Eend, rend, Vend, sel, Vsel);
+    ws_chain_pass1<FIRST, LEN, true, CL, false, 2>(P, D, ms, R, q, qd, LI, pAl, Sl, cbl, Eend, rend, Vend, sel, Vsel, s > 0);  // B5 of the previous substep inside
     Sym6 Kc = sym6zero(); SV pc = svzero();
     ws_ground_points<FIRST + LEN - 1, CL>(P, D.mu, R.root_z, Eend, rend, Vend, Kc, pc, lds, lane, X_HIT + side * 32);
     xs_store_body_contact(lds, lane, X_BCN + side * 18, body_contact_of(Kc, pc));
@@ -185,8 +231,9 @@ BEZ_DEV void leg_role(const Params& P, float* lds, int lane, int e, bool active,
     ws_barrier();  // B1: the three ball candidates (roles 4, 5, 3) are evaluated and published
     WS_STAMP(side, 3 + 8 * s);
     // this leg's candidate wins: evaluate the contact now (skipped by the whole wave when no env of the workgroup has one)
-    const int c0 = X_CAND + side * 14;
-    bool mine = (cand_winner(load_cand_depths(lds, lane)) == side) && (XS(c0 + 1) >= 1.f);
+    const CandDepths cd = load_cand_depths(lds, lane);
+    const int c0 = side ? cd.br : cd.bl;
+    bool mine = (cand_winner(cd) == side) && (XS(c0 + 1) >= 1.f);
     if (mine) {
       const RootView Rb = load_root_view(lds, lane);
       sel.depth = XS(c0); sel.link = (int)XS(c0 + 1);
@@ -229,10 +276,11 @@ BEZ_DEV void leg_role(const Params& P, float* lds, int lane, int e, bool active,
     WS_STAMP(side, 7 + 8 * s);
     ws_barrier();  // B4
     WS_STAMP(side, 8 + 8 * s);
-    ws_barrier();  // B5: new root/ball state published
-    WS_STAMP(side, 9 + 8 * s);
   }
+  ws_barrier();  // B5 of the last substep: final ball state published
+  WS_STAMP(side, 9 + 8 * (P.substeps - 1));
   ws_chain_epilogue<(FIRST == 5 ? 0 : 1), POST>(P, lds, lane, e, active, do_reset, episode, q, qd, target);
+  WS_STAMP(side, 21);
   ws_barrier();  // B6
 }
 
@@ -278,6 +326,16 @@ BEZ_DEV void head_role(const Params& P, float* lds, int lane, int e, bool active
   for (int s = 0; s < P.substeps; ++s) {
     const bool keep = last_only ? (s == P.substeps - 1) : true;
     const bool first = last_only ? true : (s == 0);
+    {  // ball candidates among the hip / thigh boxes of both legs: kinematics first, the tests once the ball's new state is published
+      const RootOnly R = load_root_only(lds, lane);
+      LegFrames<1, CAND_SPLIT> FL, FR;
+      leg_frames<5, 1, CAND_SPLIT>(lds, lane, 0, R.E0, R.V0, FL);
+      leg_frames<13, 1, CAND_SPLIT>(lds, lane, 1, R.E0, R.V0, FR);
+      if (s > 0) ws_barrier();  // B5 of the previous substep
+      const V3 bc = xs_load_v3(lds, lane, X_BALL) - R.pos;
+      leg_box_tests<5, 1, CAND_SPLIT>(FL, bc, lds, lane, X_CANDH);
+      leg_box_tests<13, 1, CAND_SPLIT>(FR, bc, lds, lane, X_CANDH + 14);
+    }
     WS_STAMP(2, 2 + 8 * s);
     ws_barrier();  // B1  (X_IA is free from here on: the staged actions have been consumed)
     C.up(P, in_loop(D), lds, lane);
@@ -287,9 +345,10 @@ BEZ_DEV void head_role(const Params& P, float* lds, int lane, int e, bool active
     ws_barrier();  // B3
     C.down(P, lds, lane, keep, first);
     ws_barrier();  // B4
-    ws_barrier();  // B5
   }
+  ws_barrier();  // B5 of the last substep
   ws_chain_epilogue<2, POST>(P, lds, lane, e, active, do_reset, episode, C.q, C.qd, C.target);
+  WS_STAMP(2, 21);
   ws_barrier();  // B6
 }
 
@@ -310,21 +369,12 @@ BEZ_DEV void cand_arm_role(const Params& P, float* lds, int lane, int e, bool ac
   for (int s = 0; s < P.substeps; ++s) {
     const bool keep = last_only ? (s == P.substeps - 1) : true;
     const bool first = last_only ? true : (s == 0);
-    {
-      RootView R = load_root_view(lds, lane);
-      BallSel sel;
-      sel.link = -1; sel.depth = 0.f; sel.n = sel.P = sel.f0p = sel.x = sel.xb = mk(0, 0, 0); sel.A = sym3zero();
-      M3 E = R.E0; V3 r = mk(0, 0, 0); SV V = R.V0, Sj, cbj, Vsel = svzero();
-      static_for<6>([&](auto I) {
-        constexpr int i = decltype(I)::value;
-        constexpr int L = LEG_FIRST + i;
-        link_kinematics<L>(XS(X_LEGQ + side * 12 + i), XS(X_LEGQ + side * 12 + 6 + i), E, r, V, Sj, cbj);
-        if constexpr (link_has_box(L)) {
-          test_box<link_box(L)>(E, r, R.bc, sel);
-          if (sel.link == L) Vsel = V;  // this box just became the deepest candidate: keep its link velocity
-        }
-      });
-      publish_cand(lds, lane, side, sel, Vsel);
+    {  // ball candidate among the calf / ankle / foot boxes: kinematics first, the tests once the ball's new state is published
+      const RootOnly R = load_root_only(lds, lane);
+      LegFrames<CAND_SPLIT, 6> F;
+      leg_frames<LEG_FIRST, CAND_SPLIT, 6>(lds, lane, side, R.E0, R.V0, F);
+      if (s > 0) ws_barrier();  // B5 of the previous substep
+      leg_box_tests<LEG_FIRST, CAND_SPLIT, 6>(F, xs_load_v3(lds, lane, X_BALL) - R.pos, lds, lane, X_CAND + side * 14);
     }
     WS_STAMP(ROLE, 2 + 8 * s);
     ws_barrier();  // B1
@@ -342,24 +392,101 @@ BEZ_DEV void cand_arm_role(const Params& P, float* lds, int lane, int e, bool ac
     ws_barrier();  // B3
     C.down(P, lds, lane, keep, first);
     ws_barrier();  // B4
-    ws_barrier();  // B5
   }
+  ws_barrier();  // B5 of the last substep
   ws_chain_epilogue<ROLE, POST>(P, lds, lane, e, active, do_reset, episode, C.q, C.qd, C.target);
+  WS_STAMP(ROLE, 21);
   ws_barrier();  // B6
 }
 
+// ---- post-physics shares of the two pair roles (they are idle after B1c): the observation slots that do not depend on
+// the joints.  Both see the state the root role published before the last B5 and apply the pending reset themselves
+// (kick_env.py:433-435 resets BEFORE compute_observations).
+struct PostIn { bool reset; float prev[3], goal_x, goal_y; };  // fetched at kernel entry: the latency hides behind the physics
+template <bool POST>
+BEZ_DEV PostIn load_post_in(const Params& P, int e, bool want_imu) {
+  PostIn in; in.reset = false; in.prev[0] = in.prev[1] = in.prev[2] = 0.f; in.goal_x = P.goal[0]; in.goal_y = P.goal[1];
+  if (POST) {
+    const int n = P.n;
+    in.reset = P.reset[e] != 0;
+    if (want_imu) {
+#pragma unroll
+      for (int i = 0; i < 3; ++i) in.prev[i] = P.state[(size_t)(F_PREV + i) * n + e];
+      if (P.task != BEZ_TASK_KICK) { in.goal_x = P.state[(size_t)F_GOAL * n + e]; in.goal_y = P.state[(size_t)(F_GOAL + 1) * n + e]; }
+    }
+  }
+  return in;
+}
+BEZ_DEV void post_imu_orn(const Params& P, float* lds, int lane, int e, bool active, const PostIn& in) {
+  const int n = P.n;
+  float* st = P.state;
+  const bool reset = in.reset;
+  V3 root_pos = xs_load_v3(lds, lane, X_ROOT);
+  float rq[4] = {XS(X_ROOT + 3), XS(X_ROOT + 4), XS(X_ROOT + 5), XS(X_ROOT + 6)};
+  V3 lin = xs_load_v3(lds, lane, X_ROOT + 7), ang = xs_load_v3(lds, lane, X_ROOT + 10);
+  float prev[3] = {in.prev[0], in.prev[1], in.prev[2]};
+  float goal_x = in.goal_x, goal_y = in.goal_y;
+  if (reset) {
+    root_pos = mk(P.bez_init[0], P.bez_init[1], P.bez_init[2]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) rq[i] = P.bez_init[3 + i];
+    lin = ang = mk(0, 0, 0);
+    if (P.task != BEZ_TASK_KICK) { goal_x = P.goal_draw[0]; goal_y = P.goal_draw[1]; }
+  }
+  float tail[8];
+  obs_imu_orn(P, root_pos, rq, lin, ang, prev, goal_x, goal_y, tail);
+  float* obs_row = lds + X_STAGE * WS_ENVS + lane * P.nobs;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) obs_row[36 + i] = tail[i];
+  if (active) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) st[(size_t)(F_PREV + i) * n + e] = prev[i];
+  }
+}
+template <bool CL>
+BEZ_DEV void post_feet(const Params& P, float* lds, int lane, int e, bool active, const PostIn& in) {
+  const int n = P.n;
+  float* st = P.state;
+  if (in.reset) {  // a reset env reports no contact forces
+#pragma unroll
+    for (int k = 0; k < (nb_of<CL>() + 1) * 3; ++k) XS(X_CF + k) = 0.f;
+  }
+  CfOut co;
+  co.base = nullptr; co.n = n;
+  co.lf = xs_load_v3(lds, lane, X_CF + lfoot_body<CL>() * 3); co.rf = xs_load_v3(lds, lane, X_CF + rfoot_body<CL>() * 3);
+  float cleats[24];
+  if (CL) {
+#pragma unroll
+    for (int k = 0; k < 12; ++k) { cleats[k] = XS(X_CF + BEZ_LCLEAT_BODY_CL * 3 + k); cleats[12 + k] = XS(X_CF + BEZ_RCLEAT_BODY_CL * 3 + k); }
+  }
+  float feet[8], tail[18];
+  obs_feet(P, co, CL ? cleats : nullptr, feet, tail);
+  float* obs_row = lds + X_STAGE * WS_ENVS + lane * P.nobs;
+#pragma unroll
+  for (int i = 8; i < 18; ++i) if (36 + i < P.nobs) obs_row[36 + i] = tail[i];
+  if (!CL) {  // the no-cleats feet logic filters the two foot rows in place (kick_env.py:987-990)
+    xs_store_v3(lds, lane, X_CF + BEZ_LFOOT_BODY * 3, co.lf); xs_store_v3(lds, lane, X_CF + BEZ_RFOOT_BODY * 3, co.rf);
+  }
+  if (active) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) st[(size_t)(F_FEET + i) * n + e] = feet[i];
+  }
+}
+
 // roles 6 / 7: leg<->leg capsule pairs.  Forward kinematics of both legs from X_LEGQ, then this part's pairs; the wrenches are
-// complete at B1c (the legs apply them after pass 2).
-template <int PART, bool DR>
-BEZ_DEV void self_role(const Params& P, float* lds, int lane, int e) {
+// complete at B1c (the legs apply them after pass 2).  After the last substep: role 6 the imu / orientation observation slots,
+// role 7 the feet slots.
+template <int PART, bool POST, bool DR, bool CL>
+BEZ_DEV void self_role(const Params& P, float* lds, int lane, int e, bool active) {
   const ChainDyn D = load_chain_dyn<DR>(P, e);
+  const PostIn pin_ = load_post_in<POST>(P, e, PART == 0);
   ws_barrier();  // B0
   for (int s = 0; s < P.substeps; ++s) {
     SelfCaps K;
-    {
+    {  // kinematics of both legs: one third in, meet the other roles at B5 of the previous substep (this role does not read the ball)
       const M3 E0 = quat_to_mat(XS(X_ROOT + 3), XS(X_ROOT + 4), XS(X_ROOT + 5), XS(X_ROOT + 6));
       const SV V0 = mksv(xs_load_v3(lds, lane, X_ROOT + 10), xs_load_v3(lds, lane, X_ROOT + 7));
-      ws_self_fk<PART>(lds, lane, E0, V0, K);
+      ws_self_fk<PART, 3>(lds, lane, E0, V0, K, s > 0);
       ws_self_pin<PART>(K);
     }
     WS_STAMP(6 + PART, 2 + 8 * s);
@@ -370,8 +497,13 @@ BEZ_DEV void self_role(const Params& P, float* lds, int lane, int e) {
     ws_barrier();  // B2
     ws_barrier();  // B3
     ws_barrier();  // B4
-    ws_barrier();  // B5
   }
+  ws_barrier();  // B5 of the last substep
+  if (POST) {
+    if (PART == 0) post_imu_orn(P, lds, lane, e, active, pin_);
+    else post_feet<CL>(P, lds, lane, e, active, pin_);
+  }
+  WS_STAMP(6 + PART, 21);
   ws_barrier();  // B6
 }
 
@@ -390,77 +522,28 @@ BEZ_DEV void root_role(const Params& P, float* lds, int lane, int e, bool active
   V3 ball_ang = mk(ld(F_BALL_ANG), ld(F_BALL_ANG + 1), ld(F_BALL_ANG + 2));
   // bookkeeping inputs of the post-physics, fetched now so that their latency hides behind the physics
   int64_t progress = 0, reset = 0;
-  float prev[3] = {0.f, 0.f, 0.f};
-  if (POST) {
-    progress = P.progress[e]; reset = P.reset[e];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) prev[i] = ld(F_PREV + i);
-  }
+  if (POST) { progress = P.progress[e]; reset = P.reset[e]; }
   const ChainDyn D = load_chain_dyn<DR>(P, e);
   float ms0 = 1.f;
   if (DR) { if (P.dr_mass) ms0 = P.dr_mass[(size_t)e * BEZ_NL]; }
   const bool last_only = (P.flags & BEZ_FLAG_CF_LAST_SUBSTEP) != 0;
-  auto publish = [&]() {
+  auto publish_root = [&]() {
     xs_store_v3(lds, lane, X_ROOT, root_pos);
     XS(X_ROOT + 3) = rq[0]; XS(X_ROOT + 4) = rq[1]; XS(X_ROOT + 5) = rq[2]; XS(X_ROOT + 6) = rq[3];
     xs_store_v3(lds, lane, X_ROOT + 7, root_lin); xs_store_v3(lds, lane, X_ROOT + 10, root_ang);
+  };
+  auto publish_ball = [&]() {
     xs_store_v3(lds, lane, X_BALL, ball_pos); xs_store_v3(lds, lane, X_BALL + 3, ball_lin); xs_store_v3(lds, lane, X_BALL + 6, ball_ang);
   };
-  publish();
+  publish_root(); publish_ball();
   WS_STAMP(3, 0);
   ws_barrier();  // B0
   WS_STAMP(3, 1);
-  for (int s = 0; s < P.substeps; ++s) {
-    const bool keep = last_only ? (s == P.substeps - 1) : true;
-    const bool first = last_only ? true : (s == 0);
-    const M3 E0 = quat_to_mat(rq[0], rq[1], rq[2], rq[3]);
-    const SV V0 = mksv(root_ang, root_lin);
-    const V3 bc = ball_pos - root_pos;
-    xs_store_v3(lds, lane, X_FL, mk(0, 0, 0)); xs_store_v3(lds, lane, X_FL + 3, mk(0, 0, 0));
-    Sym6 IA0 = sym6zero(); SV pA0;
-    LinkInertia I0;
-    link_inertia<0, CL>(ms0, D.g, E0, mk(0, 0, 0), V0, I0, pA0);
-    Sym6 Kc = sym6zero(); SV pc = svzero();
-    ws_ground_points<0, CL>(P, D.mu, root_pos.z, E0, mk(0, 0, 0), V0, Kc, pc);
-    BodyContact bc0 = body_contact_of(Kc, pc);
-    add_link_inertia(IA0, I0);
-    add_to(IA0, Kc); pA0 = pA0 + pc;
-    BallBody ball = ball_setup(P, D.mu, D.g, ball_pos.z, ball_ang, ball_lin);
-    // the torso box as a ball candidate, evaluated now; the winner is decided from the three published depths after B1
-    BallSel sel;
-    sel.link = -1; sel.depth = 0.f; sel.n = sel.P = sel.f0p = sel.x = sel.xb = mk(0, 0, 0); sel.A = sym3zero();
-    test_box<link_box(0)>(E0, mk(0, 0, 0), bc, sel);
-    XS(X_TORSO) = sel.depth;
-    if (sel.link == 0) ball_link_contact(P, D.mu, ball_ang, ball_lin, ball, bc, V0, sel);
-    WS_STAMP(3, 2 + 8 * s);
-    ws_barrier();  // B1: all three candidates are in LDS
-    WS_STAMP(3, 3 + 8 * s);
-    const int winner = cand_winner(load_cand_depths(lds, lane));
-    const bool torso_hit = (winner == 2) && (sel.link == 0);
-    if (torso_hit) { add_point_stiffness(IA0, sel.x, sel.A); pA0 = pA0 - wrench_at(sel.x, sel.f0p); }
-    if (winner != 2) sel.n = xs_load_v3(lds, lane, X_CAND + winner * 14 + 2);  // contact normal of the winning leg box (ball's contact row)
-    WS_STAMP(3, 24 + s);
-    ws_barrier();  // B1c
-    ws_barrier();  // B2: chain contributions published
-    WS_STAMP(3, 5 + 8 * s);
-#pragma unroll
-    for (int k = 0; k < 3; ++k) xs_add_sym6(lds, lane, X_IA + k * 27, IA0, pA0);  // legs + (head + arms, summed by role 4)
-    SV a0 = solve_spd6(IA0, svzero() - pA0);
-    xs_store_sv(lds, lane, X_A0, a0);
-    WS_STAMP(3, 4 + 8 * s);
-    ws_barrier();  // B3
-    WS_STAMP(3, 6 + 8 * s);
-    V3 fl_t = mk(0, 0, 0);
-    if (torso_hit) fl_t = sel.f0p - mul(sel.A, point_of(a0, sel.x));
-    if (keep) ws_cf_acc(lds, lane, 0, cf_along(P, fl_t, sel.n) + cf_ground(P, body_contact_force(bc0, a0)), P.cf_w, first);
-    V3 vdot = a0.l + cross(root_ang, root_lin);
-    root_ang = fma3(a0.a, P.h, root_ang);
-    root_lin = fma3(vdot, P.h, root_lin);
-    root_pos = fma3(root_lin, P.h, root_pos);
-    quat_integrate(rq, root_ang, P.h);
-    WS_STAMP(3, 7 + 8 * s);
-    ws_barrier();  // B4: ball<->link force published
-    WS_STAMP(3, 8 + 8 * s);
+  // The ball is integrated one barrier late: its update needs the ball<->link force of pass 3 (published at B4), but only the
+  // box tests of the NEXT substep need its result -- so the update runs at the top of the next iteration (and once after the
+  // loop), beside the other roles' forward kinematics, and B5 sits in the middle of their pass-1 window.
+  BallBody ball; BallSel sel; bool torso_hit = false; V3 fl_t = mk(0, 0, 0);
+  auto ball_update = [&](bool keep, bool first) {
     V3 fl = xs_load_v3(lds, lane, X_FL), xb = xs_load_v3(lds, lane, X_FL + 3);
     if (torso_hit) { fl = fl_t; xb = sel.xb; }
     SV ab = ball_minv(ball, svzero() - ball.pb - wrench_at(xb, fl));
@@ -474,29 +557,86 @@ BEZ_DEV void root_role(const Params& P, float* lds, int lane, int e, bool active
     ball_ang = fma3(ab.a, P.h, ball_ang) * damp;
     ball_pos = fma3(ball_lin, P.h, ball_pos);
     quat_integrate(bq, ball_ang, P.h);
-    publish();
-    ws_barrier();  // B5
-    WS_STAMP(3, 9 + 8 * s);
+    publish_ball();
+  };
+  for (int s = 0; s < P.substeps; ++s) {
+    const bool keep = last_only ? (s == P.substeps - 1) : true;
+    const bool first = last_only ? true : (s == 0);
+    if (s > 0) {
+      ball_update(last_only ? false : true, last_only ? true : (s == 1));  // the previous substep's flags
+      ws_barrier();  // B5 of the previous substep
+      WS_STAMP(3, 9 + 8 * (s - 1));
+    }
+    const M3 E0 = quat_to_mat(rq[0], rq[1], rq[2], rq[3]);
+    const SV V0 = mksv(root_ang, root_lin);
+    const V3 bc = ball_pos - root_pos;
+    xs_store_v3(lds, lane, X_FL, mk(0, 0, 0)); xs_store_v3(lds, lane, X_FL + 3, mk(0, 0, 0));
+    Sym6 IA0 = sym6zero(); SV pA0;
+    LinkInertia I0;
+    link_inertia<0, CL>(ms0, D.g, E0, mk(0, 0, 0), V0, I0, pA0);
+    Sym6 Kc = sym6zero(); SV pc = svzero();
+    ws_ground_points<0, CL>(P, D.mu, root_pos.z, E0, mk(0, 0, 0), V0, Kc, pc);
+    BodyContact bc0 = body_contact_of(Kc, pc);
+    add_link_inertia(IA0, I0);
+    add_to(IA0, Kc); pA0 = pA0 + pc;
+    ball = ball_setup(P, D.mu, D.g, ball_pos.z, ball_ang, ball_lin);
+    // the torso box as a ball candidate, evaluated now; the winner is decided from the published depths after B1
+    sel.link = -1; sel.depth = 0.f; sel.n = sel.P = sel.f0p = sel.x = sel.xb = mk(0, 0, 0); sel.A = sym3zero();
+    test_box<link_box(0)>(E0, mk(0, 0, 0), bc, sel);
+    XS(X_TORSO) = sel.depth;
+    if (sel.link == 0) ball_link_contact(P, D.mu, ball_ang, ball_lin, ball, bc, V0, sel);
+    WS_STAMP(3, 2 + 8 * s);
+    ws_barrier();  // B1: all candidates are in LDS
+    WS_STAMP(3, 3 + 8 * s);
+    const CandDepths cd = load_cand_depths(lds, lane);
+    const int winner = cand_winner(cd);
+    torso_hit = (winner == 2) && (sel.link == 0);
+    if (torso_hit) { add_point_stiffness(IA0, sel.x, sel.A); pA0 = pA0 - wrench_at(sel.x, sel.f0p); }
+    if (winner != 2) sel.n = xs_load_v3(lds, lane, (winner ? cd.br : cd.bl) + 2);  // contact normal of the winning leg box (ball's contact row)
+    WS_STAMP(3, 24 + s);
+    ws_barrier();  // B1c
+    ws_barrier();  // B2: chain contributions published
+    WS_STAMP(3, 5 + 8 * s);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) xs_add_sym6(lds, lane, X_IA + k * 27, IA0, pA0);  // legs + (head + arms, summed by role 4)
+    SV a0 = solve_spd6(IA0, svzero() - pA0);
+    xs_store_sv(lds, lane, X_A0, a0);
+    WS_STAMP(3, 4 + 8 * s);
+    ws_barrier();  // B3
+    WS_STAMP(3, 6 + 8 * s);
+    fl_t = mk(0, 0, 0);
+    if (torso_hit) fl_t = sel.f0p - mul(sel.A, point_of(a0, sel.x));
+    if (keep) ws_cf_acc(lds, lane, 0, cf_along(P, fl_t, sel.n) + cf_ground(P, body_contact_force(bc0, a0)), P.cf_w, first);
+    V3 vdot = a0.l + cross(root_ang, root_lin);
+    root_ang = fma3(a0.a, P.h, root_ang);
+    root_lin = fma3(vdot, P.h, root_lin);
+    root_pos = fma3(root_lin, P.h, root_pos);
+    quat_integrate(rq, root_ang, P.h);
+    publish_root();  // the chains' next pass 1 starts right after B4
+    WS_STAMP(3, 7 + 8 * s);
+    ws_barrier();  // B4: ball<->link force published
+    WS_STAMP(3, 8 + 8 * s);
   }
-  ws_barrier();  // B6: joint obs slots / pose-error sums / contact-force rows of the chain roles are in LDS
-  WS_STAMP(3, 20);
+  {
+    const bool keep_l = true, first_l = last_only ? true : (P.substeps == 1);
+    ball_update(keep_l, first_l);
+  }
+  ws_barrier();  // B5 of the last substep: final ball state published
+  WS_STAMP(3, 9 + 8 * (P.substeps - 1));
+  // post-physics, root's share.  Before B6: bookkeeping, the pending reset of the root / ball state, the state stores.  After B6
+  // (pose-error sums of the chain roles are in LDS): the reward and the reset flag of the next step.
+  float goal_x = P.goal[0], goal_y = P.goal[1];
+  int64_t timeout = 0;
   if (POST) {
-    CfOut co;
-    co.base = nullptr; co.n = n;
-    co.lf = xs_load_v3(lds, lane, X_CF + lfoot_body<CL>() * 3); co.rf = xs_load_v3(lds, lane, X_CF + rfoot_body<CL>() * 3);
-    float goal_x = P.goal[0], goal_y = P.goal[1];
     if (P.task != BEZ_TASK_KICK) { goal_x = ld(F_GOAL); goal_y = ld(F_GOAL + 1); }
-    int64_t timeout = (progress >= (int64_t)(P.max_len - 1)) ? 1 : 0;  // vec_task.py:331-332
-    progress += 1;                                                    // kick_env.py:429
-    if (reset != 0) {                                                 // kick_env.py:433-435, 831-850 (root / ball part)
+    timeout = (progress >= (int64_t)(P.max_len - 1)) ? 1 : 0;  // vec_task.py:331-332
+    progress += 1;                                              // kick_env.py:429
+    if (reset != 0) {                                           // kick_env.py:433-435, 831-850 (root / ball part)
       root_pos = mk(P.bez_init[0], P.bez_init[1], P.bez_init[2]);
       ball_pos = mk(P.ball_init[0], P.ball_init[1], P.ball_init[2]);
 #pragma unroll
       for (int i = 0; i < 4; ++i) { rq[i] = P.bez_init[3 + i]; bq[i] = P.ball_init[3 + i]; }
       root_lin = root_ang = ball_lin = ball_ang = mk(0, 0, 0);
-      co.lf = co.rf = mk(0, 0, 0);
-#pragma unroll
-      for (int k = 0; k < (nb_of<CL>() + 1) * 3; ++k) XS(X_CF + k) = 0.f;
       if (active) P.episode[e] = P.episode[e] + 1;
       if (P.task != BEZ_TASK_KICK) {  // walk_env.py:570-575: every env reset by this call receives the same fresh goal
         goal_x = P.goal_draw[0]; goal_y = P.goal_draw[1];
@@ -504,31 +644,7 @@ BEZ_DEV void root_role(const Params& P, float* lds, int lane, int e, bool active
       }
       progress = 0; reset = 0;
     }
-    float pn = (((XS(X_PSUM + 2) + XS(X_PSUM + 4)) + XS(X_PSUM + 5)) + XS(X_PSUM + 0)) + XS(X_PSUM + 1);
-    float feet[8], rew;
-    float* obs_row = lds + X_STAGE * WS_ENVS + lane * P.nobs;
-    float tail[18];
-    float cleats[24];
-    if (CL) {
-#pragma unroll
-      for (int k = 0; k < 12; ++k) { cleats[k] = XS(X_CF + BEZ_LCLEAT_BODY_CL * 3 + k); cleats[12 + k] = XS(X_CF + BEZ_RCLEAT_BODY_CL * 3 + k); }
-    }
-    env_observe_core(P, root_pos, rq, root_lin, root_ang, ball_pos, ball_lin, co, prev, feet, tail, pn, rew, reset, progress, goal_x, goal_y,
-                     CL ? cleats : nullptr);
-#pragma unroll
-    for (int i = 0; i < 18; ++i) if (36 + i < P.nobs) obs_row[36 + i] = tail[i];
-    if (!CL) {  // the no-cleats feet logic filters the two foot rows in place (kick_env.py:987-990)
-      xs_store_v3(lds, lane, X_CF + BEZ_LFOOT_BODY * 3, co.lf); xs_store_v3(lds, lane, X_CF + BEZ_RFOOT_BODY * 3, co.rf);
-    }
-    if (active) {
-#pragma unroll
-      for (int i = 0; i < 3; ++i) st[(size_t)(F_PREV + i) * n + e] = prev[i];
-#pragma unroll
-      for (int i = 0; i < 8; ++i) st[(size_t)(F_FEET + i) * n + e] = feet[i];
-      P.rew[e] = rew; P.reset[e] = reset; P.progress[e] = progress; P.timeout[e] = timeout;
-    }
   }
-  WS_STAMP(3, 21);
   if (active) {
     auto sv = [&](int f, float v) { st[(size_t)f * n + e] = v; };
     sv(F_ROOT_POS, root_pos.x); sv(F_ROOT_POS + 1, root_pos.y); sv(F_ROOT_POS + 2, root_pos.z);
@@ -540,6 +656,21 @@ BEZ_DEV void root_role(const Params& P, float* lds, int lane, int e, bool active
     sv(F_BALL_LIN, ball_lin.x); sv(F_BALL_LIN + 1, ball_lin.y); sv(F_BALL_LIN + 2, ball_lin.z);
     sv(F_BALL_ANG, ball_ang.x); sv(F_BALL_ANG + 1, ball_ang.y); sv(F_BALL_ANG + 2, ball_ang.z);
   }
+  WS_STAMP(3, 19);
+  ws_barrier();  // B6: pose-error sums of the chain roles are in LDS
+  WS_STAMP(3, 20);
+  if (POST) {
+    const float pn = (((XS(X_PSUM + 2) + XS(X_PSUM + 4)) + XS(X_PSUM + 5)) + XS(X_PSUM + 0)) + XS(X_PSUM + 1);
+    OrnOut orn; orn.ux = orn.uy = orn.gn = orn.ang_goal = 0.f;
+    if (P.task != BEZ_TASK_KICK) {  // the walk / orient rewards use the goal direction / heading error (role 6 computes the same for the observation)
+      float dummy_prev[3] = {0.f, 0.f, 0.f}, dummy_tail[8];
+      orn = obs_imu_orn(P, root_pos, rq, root_lin, root_ang, dummy_prev, goal_x, goal_y, dummy_tail);
+    }
+    float rew;
+    reward_of(P, root_pos, rq, root_lin, root_ang, ball_pos, ball_lin, pn, orn, rew, reset, progress, goal_x, goal_y);
+    if (active) { P.rew[e] = rew; P.reset[e] = reset; P.progress[e] = progress; P.timeout[e] = timeout; }
+  }
+  WS_STAMP(3, 21);
 }
 
 // ---- the kernel.  grid = ceil(N / 64) workgroups of 512 threads.
@@ -563,30 +694,36 @@ __global__ __launch_bounds__(WS_BLOCK) void step_kernel_ws8(Params P) {
   // contact-force rows start from zero: bodies nothing touches are never accumulated into
   constexpr int NROW = (nb_of<CL>() + 1) * 3;  // contact-force rows of this asset (robot bodies + ball)
   for (int i = tid; i < NROW * WS_ENVS; i += WS_BLOCK) lds[X_CF * WS_ENVS + i] = 0.f;
+  WS_STAMP(role, 18);
   if (role == 0) leg_role<5, PRE, POST, DR, CL>(P, lds, lane, e, active, 0);
   else if (role == 1) leg_role<13, PRE, POST, DR, CL>(P, lds, lane, e, active, 1);
   else if (role == 2) head_role<PRE, POST, DR, CL>(P, lds, lane, e, active);
   else if (role == 3) root_role<PRE, POST, DR, CL>(P, lds, lane, e, active);
   else if (role == 4) cand_arm_role<5, 3, PRE, POST, DR, CL>(P, lds, lane, e, active, 0);
   else if (role == 5) cand_arm_role<13, 11, PRE, POST, DR, CL>(P, lds, lane, e, active, 1);
-  else if (role == 6) self_role<0, DR>(P, lds, lane, e);
-  else self_role<1, DR>(P, lds, lane, e);
-  ws_barrier();  // contact-force rows (and, with POST, the observation rows staged by the chain roles and role 3) are complete in LDS
-  {
-    // net contact force: SoA rows of 64 consecutive envs each -> coalesced
-    float* dst = P.state + (size_t)F_CF * P.n + env0;
-    for (int i = tid; i < NROW * WS_ENVS; i += WS_BLOCK) {
-      const int k = i >> 6, l = i & 63;
-      if (l < nloc) dst[(size_t)k * P.n + l] = lds[(X_CF + k) * WS_ENVS + l];
+  else if (role == 6) self_role<0, POST, DR, CL>(P, lds, lane, e, active);
+  else self_role<1, POST, DR, CL>(P, lds, lane, e, active);
+  // B6 was the last barrier: the contact-force rows and (with POST) the staged observation rows are complete in LDS.  The seven
+  // other waves copy them out while the root role is still busy with the reward.
+  if (role != 3) {
+    constexpr int NT = WS_BLOCK - 64;
+    const int ctid = tid - (role > 3 ? 64 : 0);
+    {
+      // net contact force: SoA rows of 64 consecutive envs each -> coalesced
+      float* dst = P.state + (size_t)F_CF * P.n + env0;
+      for (int i = ctid; i < NROW * WS_ENVS; i += NT) {
+        const int k = i >> 6, l = i & 63;
+        if (l < nloc) dst[(size_t)k * P.n + l] = lds[(X_CF + k) * WS_ENVS + l];
+      }
     }
-  }
-  if (POST) {
-    // the staged rows are the contiguous (nloc,nobs) image of this workgroup's slice of obs_buf: 16-byte copy-out
-    const float4* rows = reinterpret_cast<const float4*>(lds + X_STAGE * WS_ENVS);
-    float4* dst = reinterpret_cast<float4*>(P.obs + (size_t)env0 * P.nobs);  // 64 * nobs * 4 B per workgroup: 16-B aligned for 54 and 52
-    const int nvec = (nloc * P.nobs) >> 2;
-    for (int i = tid; i < nvec; i += WS_BLOCK) dst[i] = rows[i];
-    for (int i = (nvec << 2) + tid; i < nloc * P.nobs; i += WS_BLOCK) P.obs[(size_t)env0 * P.nobs + i] = lds[X_STAGE * WS_ENVS + i];
+    if (POST) {
+      // the staged rows are the contiguous (nloc,nobs) image of this workgroup's slice of obs_buf: 16-byte copy-out
+      const float4* rows = reinterpret_cast<const float4*>(lds + X_STAGE * WS_ENVS);
+      float4* dst = reinterpret_cast<float4*>(P.obs + (size_t)env0 * P.nobs);  // 64 * nobs * 4 B per workgroup: 16-B aligned for 54 and 52
+      const int nvec = (nloc * P.nobs) >> 2;
+      for (int i = ctid; i < nvec; i += NT) dst[i] = rows[i];
+      for (int i = (nvec << 2) + ctid; i < nloc * P.nobs; i += NT) P.obs[(size_t)env0 * P.nobs + i] = lds[X_STAGE * WS_ENVS + i];
+    }
   }
   WS_STAMP(role, 23);
 }

@@ -419,7 +419,9 @@ BEZ_DEV void link_inertia(float ms, V3 g, const M3& E, V3 r, SV V, LinkInertia& 
   Il.xx = (float)link_inertia_c<CL>(L, 0) * ms; Il.yy = (float)link_inertia_c<CL>(L, 1) * ms; Il.zz = (float)link_inertia_c<CL>(L, 2) * ms;
   Il.xy = (float)link_inertia_c<CL>(L, 3) * ms; Il.xz = (float)link_inertia_c<CL>(L, 4) * ms; Il.yz = (float)link_inertia_c<CL>(L, 5) * ms;
   V3 c = r + mul(E, cl);
-  Sym3 Iw = rotate_inertia(E, Il);
+  // the URDF inertias are diagonal in the link frame for most links: drop the products with structural zeros
+  constexpr bool DIAG = link_inertia_c<CL>(L, 3) == 0. && link_inertia_c<CL>(L, 4) == 0. && link_inertia_c<CL>(L, 5) == 0.;
+  Sym3 Iw = DIAG ? rotate_inertia_diag(E, Il.xx, Il.yy, Il.zz) : rotate_inertia(E, Il);
   float cc = dot(c, c);
   I.m = m; I.h = c * m;
   I.Ibar.xx = fmaf(m, cc - c.x * c.x, Iw.xx); I.Ibar.yy = fmaf(m, cc - c.y * c.y, Iw.yy); I.Ibar.zz = fmaf(m, cc - c.z * c.z, Iw.zz);
@@ -788,13 +790,14 @@ BEZ_DEV void feet_no_cleats(float* f, float* out) {
   out[0] = o0; out[1] = o1; out[2] = o2; out[3] = o3;
 }
 
-// compute_observations + compute_reward (kick_env.py:749-777, 724-747) for this lane's env, everything except the
-// joint slots obs[0:36]: writes tail[18] = imu(6) off_orn(2) feet(8) ball_init(2).  `pn` = sum_j (default_j - q_j)^2.
-// `goal` = this env's goal xy (bez_kick: the configured point; bez_walk: redrawn at reset).  `cleats` = the 8 cleat rows of the
-// net contact force (24 floats) with the cleats asset, else null.
-BEZ_DEV void env_observe_core(const Params& P, V3 root_pos, const float* rq, V3 v, V3 w, V3 ball_pos, V3 ball_lin, CfOut& co,
-                              float* prev, float* feet, float* tail, float pn, float& rew, int64_t& reset, int64_t progress,
-                              float goal_x, float goal_y, const float* cleats) {
+// compute_observations + compute_reward (kick_env.py:749-777, 724-747) for one env, everything except the joint slots
+// obs[0:36], in three independent parts (the 8-wave kernel runs them in different waves; env_observe_core chains them):
+//   obs_imu_orn  tail[0:8]  = imu(6) off_orn(2)         from the root state, prev_lin_vel and the goal
+//   obs_feet     tail[8:18] = feet(8) ball_init(2)      from the two foot rows (or the 8 cleat rows) of the net contact force
+//   reward_of    reward and the reset flag of the NEXT step
+// `pn` = sum_j (default_j - q_j)^2.  `goal` = this env's goal xy (bez_kick: the configured point; bez_walk: redrawn at reset).
+struct OrnOut { float ux, uy, gn, ang_goal; };  // unit vector / distance to the goal, orient task's heading error
+BEZ_DEV OrnOut obs_imu_orn(const Params& P, V3 root_pos, const float* rq, V3 v, V3 w, float* prev, float goal_x, float goal_y, float* tail) {
   // IMU link = torso origin frame (soccerbot_stl.urdf:567-572)
   // compute_imu (kick_env.py:918-930), quaternion_to_matrix fed xyzw as (r,i,j,k) (quirk Q2)
   float pvx = P.use_prev ? prev[0] : v.x, pvy = P.use_prev ? prev[1] : v.y, pvz = P.use_prev ? prev[2] : v.z;
@@ -811,21 +814,26 @@ BEZ_DEV void env_observe_core(const Params& P, V3 root_pos, const float* rq, V3 
   tail[3] = fminf(fmaxf(w.x, -ANG), ANG); tail[4] = fminf(fmaxf(w.y, -ANG), ANG); tail[5] = fminf(fmaxf(w.z, -ANG), ANG);
   prev[0] = v.x; prev[1] = v.y; prev[2] = v.z;
   // compute_off_orn (kick_env.py:941-960)
+  OrnOut o;
   float gx = goal_x - root_pos.x, gy = goal_y - root_pos.y;
-  float gn = sqrtf(gx * gx + gy * gy);
-  float ux = gx / gn, uy = gy / gn;
+  o.gn = sqrtf(gx * gx + gy * gy);
+  o.ux = gx / o.gn; o.uy = gy / o.gn;
   float qx = rq[0], qy = rq[1], qz = rq[2], qw = rq[3];
   // heading (cos yaw, sin yaw) with yaw = atan2(sy, cy) (get_euler_xyz [ext]): the unit vector (cy, sy)/|.| itself --
   // the % 2pi wrap and the atan2/sincos round trip of the reference only cost rounding (checked by the golden tests)
   float sy = 2.0f * (qw * qz + qx * qy), cy = qw * qw + qx * qx - qy * qy - qz * qz;
   float hn = 1.0f / sqrtf(sy * sy + cy * cy);
   float hs = sy * hn, hc = cy * hn;
-  float cosv = hc * ux + hs * uy;
-  float sinv = fabsf(ux * hs - uy * hc);
+  float cosv = hc * o.ux + hs * o.uy;
+  float sinv = fabsf(o.ux * hs - o.uy * hc);
   tail[6] = sinv; tail[7] = -cosv;
   // orient_env.py:719-735 compute_off_angle: (cos, sin) of goal_angle - normalize_angle(yaw)
-  const float ang_goal = P.goal_angle - atan2f(hs, hc);
-  if (P.task == BEZ_TASK_ORIENT) { tail[6] = cosf(ang_goal); tail[7] = sinf(ang_goal); }
+  o.ang_goal = 0.f;
+  if (P.task == BEZ_TASK_ORIENT) { o.ang_goal = P.goal_angle - atan2f(hs, hc); tail[6] = cosf(o.ang_goal); tail[7] = sinf(o.ang_goal); }
+  return o;
+}
+// `cleats` = the 8 cleat rows of the net contact force (24 floats) with the cleats asset, else null
+BEZ_DEV void obs_feet(const Params& P, CfOut& co, const float* cleats, float* feet, float* tail) {
   // feet (kick_env.py:538-576; with cleats kick_env.py:467-495,1044-1069: |force on the cleat| > 1 N)
   if (cleats) {
 #pragma unroll
@@ -842,8 +850,13 @@ BEZ_DEV void env_observe_core(const Params& P, V3 root_pos, const float* rq, V3 
 #pragma unroll
   for (int i = 0; i < 8; ++i) tail[8 + i] = feet[i];
   tail[16] = P.ball_init[0]; tail[17] = P.ball_init[1];  // constant ball_init (quirk Q5, kick_env.py:776); bez_kick only
+}
+BEZ_DEV void reward_of(const Params& P, V3 root_pos, const float* rq, V3 v, V3 w, V3 ball_pos, V3 ball_lin, float pn, const OrnOut& o,
+                       float& rew, int64_t& reset, int64_t progress, float goal_x, float goal_y) {
   if (P.task != BEZ_TASK_KICK) {
     // compute_bez_reward of walk_env.py:826-1031 / orient_env.py:843-1018
+    const float qx = rq[0], qy = rq[1];
+    const float ux = o.ux, uy = o.uy, gn = o.gn, ang_goal = o.ang_goal;
     const float vel_lin = sqrtf(dot(v, v)), vel_ang = sqrtf(dot(w, w)), vel_reward = sqrtf(dot(v, v) + dot(w, w)), pos_reward = sqrtf(pn);
     const float up_proj = 1.f - 2.f * (qx * qx + qy * qy);  // get_basis_vector(q, (0,0,1)).z
     const float dh = fabsf(1.f - up_proj);
@@ -899,6 +912,14 @@ BEZ_DEV void env_observe_core(const Params& P, V3 root_pos, const float* rq, V3 
   if (dgn < 0.05f) { reset = 1; reward = 100.0f - 100.0f * ((float)progress / (float)P.max_len); }
   if (progress >= (int64_t)P.max_len) { reset = 1; reward = 0.f; }
   rew = reward;
+}
+// the three parts in sequence: writes tail[18] = imu(6) off_orn(2) feet(8) ball_init(2)
+BEZ_DEV void env_observe_core(const Params& P, V3 root_pos, const float* rq, V3 v, V3 w, V3 ball_pos, V3 ball_lin, CfOut& co,
+                              float* prev, float* feet, float* tail, float pn, float& rew, int64_t& reset, int64_t progress,
+                              float goal_x, float goal_y, const float* cleats) {
+  const OrnOut o = obs_imu_orn(P, root_pos, rq, v, w, prev, goal_x, goal_y, tail);
+  obs_feet(P, co, cleats, feet, tail);
+  reward_of(P, root_pos, rq, v, w, ball_pos, ball_lin, pn, o, rew, reset, progress, goal_x, goal_y);
 }
 
 BEZ_DEV void env_observe_reward(const Params& P, const EnvState& S, CfOut& co, float* prev, float* feet, float* obs,

@@ -33,6 +33,7 @@ struct BezSim {
   int64_t obs_calls = 0;  // compute_observations passes so far (quirk Q1: only the first sees prev = zeros)
   uint64_t post_calls = 0, reset_calls = 0;  // keys of the shared goal draw (bez_walk / bez_orient)
   bool cleats = false, has_ball = true;
+  int kernel = 0;  // fused-step kernel: 0 = 8 role waves (bez_kernel_ws8.h, default), 1 = 4 role waves (bez_kernel_ws.h), 2 = one env per lane
   int nb = BEZ_NB, nbe = BEZ_NBE, nobs = BEZ_NUM_OBS, nact = 2;  // robot bodies, exported body rows, obs width, actors per env
   std::string err;
   // sim-owned device memory
@@ -272,16 +273,14 @@ __global__ void set_target_indexed_kernel(float* __restrict__ st, const float* _
   st[(size_t)(F_TARGET + j) * n + e] = src[(size_t)e * BEZ_ND + j];
 }
 
-// Kernel choice for launches that include the physics: the wave-specialised kernel (bez_kernel_ws.h) is the
-// production path; BEZ_SIM_KERNEL=lane selects the one-env-per-lane reference kernel (bez_kernels.h) for A/B runs.
-bool use_ws_kernel() {
-  static const bool ws = [] { const char* v = std::getenv("BEZ_SIM_KERNEL"); return !(v && std::string(v) == "lane"); }();
-  return ws;
-}
-// BEZ_SIM_KERNEL=ws8 selects the 8-role-wave variant (bez_kernel_ws8.h)
-bool use_ws8_kernel() {
-  static const bool w = [] { const char* v = std::getenv("BEZ_SIM_KERNEL"); return v && std::string(v) == "ws8"; }();
-  return w;
+// Kernel choice for launches that include the physics, fixed per sim at bez_sim_create from BEZ_SIM_KERNEL: unset / "ws8" = the
+// 8-role-wave kernel (bez_kernel_ws8.h, the production path), "ws4" = its 4-role-wave predecessor (bez_kernel_ws.h), "lane" =
+// the one-env-per-lane reference kernel (bez_kernels.h).  The three are held against each other by tests/test_gpu_round2.py.
+int kernel_from_env() {
+  const char* v = std::getenv("BEZ_SIM_KERNEL");
+  if (!v) return 0;
+  const std::string k(v);
+  return k == "lane" ? 2 : (k == "ws4" || k == "ws") ? 1 : 0;
 }
 
 // PMC calibration: dword-per-lane coalesced read of `n` floats (the access shape of the step kernels' state loads)
@@ -305,8 +304,8 @@ int launch_step(BezSim* s, const float* actions, hipStream_t stream, bool obs_on
   if (POST && !obs_only) goal_draw(s->cfg.seed, s->post_calls++, 0, P.goal_draw);  // the reset inside this post_physics_step
   const bool dr = has_dr(s) || s->cleats;
   if constexpr (SIM && PRE == POST) {
-    if (use_ws_kernel()) {
-      if (use_ws8_kernel()) bez::launch_step_ws8(P, PRE, dr, s->cleats, stream);
+    if (s->kernel != 2) {
+      if (s->kernel == 0) bez::launch_step_ws8(P, PRE, dr, s->cleats, stream);
       else bez::launch_step_ws(P, PRE, dr, s->cleats, stream);
       hipError_t e = hipGetLastError();
       if (e != hipSuccess) return fail(s, -2, "step_kernel_ws launch", e);
@@ -382,6 +381,7 @@ int bez_sim_create(const BezSimConfig* cfg, int device_id, BezSim** out) {
   s->cfg = *cfg; s->device = device_id; s->n = cfg->num_envs;
   if (cfg->task < BEZ_TASK_KICK || cfg->task > BEZ_TASK_ORIENT) { delete s; return fail(nullptr, -1, "bez_sim_create: unknown task"); }
   s->cleats = (cfg->flags & BEZ_FLAG_CLEATS) != 0;
+  s->kernel = kernel_from_env();
   s->has_ball = cfg->task == BEZ_TASK_KICK;                    // walk_env.py / orient_env.py create no ball actor
   s->nb = s->cleats ? BEZ_NB_CL : BEZ_NB;
   s->nbe = s->nb + (s->has_ball ? 1 : 0);

@@ -162,6 +162,19 @@ BEZ_DEV Sym3 rotate_inertia(const M3& E, const Sym3& Il) {
   R.zz = fmaf(T.m20, E.m20, fmaf(T.m21, E.m21, T.m22 * E.m22));
   return R;
 }
+// the same for Il = diag(a, b, c)
+BEZ_DEV Sym3 rotate_inertia_diag(const M3& E, float a, float b, float c) {
+  const float t00 = E.m00 * a, t01 = E.m01 * b, t02 = E.m02 * c, t10 = E.m10 * a, t11 = E.m11 * b, t12 = E.m12 * c;
+  const float t20 = E.m20 * a, t21 = E.m21 * b, t22 = E.m22 * c;
+  Sym3 R;
+  R.xx = fmaf(t00, E.m00, fmaf(t01, E.m01, t02 * E.m02));
+  R.xy = fmaf(t00, E.m10, fmaf(t01, E.m11, t02 * E.m12));
+  R.xz = fmaf(t00, E.m20, fmaf(t01, E.m21, t02 * E.m22));
+  R.yy = fmaf(t10, E.m10, fmaf(t11, E.m11, t12 * E.m12));
+  R.yz = fmaf(t10, E.m20, fmaf(t11, E.m21, t12 * E.m22));
+  R.zz = fmaf(t20, E.m20, fmaf(t21, E.m21, t22 * E.m22));
+  return R;
+}
 // general 3x3 inverse by cofactors
 BEZ_DEV M3 inverse(const M3& a) {
   float c00 = fmaf(a.m11, a.m22, -a.m12 * a.m21), c01 = fmaf(a.m12, a.m20, -a.m10 * a.m22), c02 = fmaf(a.m10, a.m21, -a.m11 * a.m20);

@@ -73,6 +73,50 @@ def test_ws_kernel_post_physics_pinned_against_lane_kernel():
     assert a.reset_buf.sum() + (a.progress_buf < 30).sum() > 0  # resets really happened inside the window
 
 
+@pytest.mark.parametrize("other", ["ws4", "lane"])
+@pytest.mark.parametrize("variant", ["kick", "kick_cleats", "walk"])
+def test_fused_step_kernels_agree(other, variant, monkeypatch):
+    """The three implementations of the fused control step -- 8 role waves (default), 4 role waves (BEZ_SIM_KERNEL=ws4), one env
+    per lane (BEZ_SIM_KERNEL=lane) -- compute the same physics in a different order.  From an identical state, with the same
+    actions, resynchronised every step: integers exact, fp32 quantities to a few ulp of their scale.  N is not a multiple of
+    the 64-env workgroup."""
+    from tests.sim_adapter import SimAdapter
+    from tests.test_tasks import make_cfg
+    n = 200
+    kw = dict(seed=31, task="bez_walk" if variant == "walk" else "bez_kick", cleats=(variant == "kick_cleats"))
+    monkeypatch.delenv("BEZ_SIM_KERNEL", raising=False)
+    a = SimAdapter(make_cfg(n, **kw))
+    monkeypatch.setenv("BEZ_SIM_KERNEL", other)  # read once, at bez_sim_create
+    b = SimAdapter(make_cfg(n, **kw))
+    monkeypatch.delenv("BEZ_SIM_KERNEL", raising=False)
+    rng = np.random.default_rng(8)
+    nres = 0
+    for t in range(40):
+        b.set_root_states(a.root_states); b.set_dof_state(a.dof_state); b.set_contact_forces(a.contact_forces)
+        b.set_targets(a.targets); b.set_reset(a.reset_buf); b.set_progress(a.progress_buf); b.set_prev_lin_vel(a.prev_lin_vel)
+        if variant == "walk": b.set_goal(a.goal)
+        act = rng.uniform(-1, 1, (n, 18)).astype(np.float32)
+        a.step(act); b.step(act)
+        nres += int(a.reset_buf.sum())
+        np.testing.assert_array_equal(b.reset_buf, a.reset_buf)
+        np.testing.assert_array_equal(b.progress_buf, a.progress_buf)
+        np.testing.assert_array_equal(b.timeout_buf, a.timeout_buf)
+        ra, rb = a.root_states, b.root_states
+        # tolerances = 3x the worst difference seen over the 6 combinations (tools/kernel_ab_probe.py)
+        np.testing.assert_allclose(rb[..., 0:7], ra[..., 0:7], atol=2e-5)
+        np.testing.assert_allclose(rb[..., 7:13], ra[..., 7:13], atol=4e-3)
+        da, db = a.dof_state.reshape(n, 18, 2), b.dof_state.reshape(n, 18, 2)
+        np.testing.assert_allclose(db[..., 0], da[..., 0], atol=1e-4)
+        np.testing.assert_allclose(db[..., 1], da[..., 1], atol=1.5e-2)
+        np.testing.assert_allclose(b.contact_forces, a.contact_forces, rtol=4e-3, atol=2.5e-2)
+        np.testing.assert_array_equal(b.obs[:, :36], np.concatenate([db[..., 0], db[..., 1]], axis=1))
+        np.testing.assert_allclose(b.obs[:, 36:42], a.obs[:, 36:42], atol=3e-3)
+        np.testing.assert_allclose(b.obs[:, 42:44], a.obs[:, 42:44], atol=2e-5)
+        assert np.mean(b.obs[:, 44:52] == a.obs[:, 44:52]) > 0.995  # threshold flags: a force within an ulp of 1 N / 0.01 N may flip
+        np.testing.assert_allclose(b.rew, a.rew, atol=4e-4 if variant == "walk" else 2e-5)
+    assert nres > 0
+
+
 def test_partial_workgroup_parity():
     """N = 100 is not a multiple of the 64 envs a workgroup owns: the masked tail lanes must not disturb the others."""
     n = 100
