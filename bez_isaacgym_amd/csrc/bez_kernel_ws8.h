@@ -45,7 +45,8 @@ enum : int {
   X_IA = 439,      // 5 chains (left leg, right leg, head, left arm, right arm) x (Sym6 21 + bias 6); block 2 ends up holding head + arms
   X_BCN = 574,     // per leg: contact rows of the foot (B 9, C 6, F0 3), parked here across pass 2 (register pressure)
   X_CANDH = 610,   // per leg: the same 14 floats for the upper boxes (hip / thigh links), from role 2
-  X_SLOTS = 638
+  X_SELFANY = 638, // per helper part: 1 if this env has a leg<->leg contact in that part's pairs
+  X_SLOTS = 640
 };
 constexpr int CAND_SPLIT = 3;  // leg links 0..2 (hip_side, hip_front, thigh) are tested by role 2, links 3..5 (calf, ankle, foot) by roles 4 / 5
 constexpr int X_STAGE = X_IA;  // staging aliases the chain blocks (see the header comment)
@@ -250,7 +251,10 @@ BEZ_DEV void leg_role(const Params& P, float* lds, int lane, int e, bool active,
     ws_chain_pass2<FIRST, LEN, true>(P, D, kps, kds, lo, hi, q, qd, target, LI, pAl, Sl, cbl, Kc, pc, mine, sel, p3, IA, pA);
     WS_STAMP(side, 24 + s);
     ws_barrier();  // B1c: both helper parts' leg<->leg contact wrenches are in LDS
-    ws_chain_self_correction<LEN>(lds, lane, side, p3, pA);
+    // wave-uniform: did either part find a contact in any env of this workgroup?  (mostly not: the correction and the per-link
+    // force loads of pass 3 are then skipped)
+    const bool sa0 = __any(XS(X_SELFANY) != 0.f), sa1 = __any(XS(X_SELFANY + 1) != 0.f);
+    ws_chain_self_correction<LEN>(lds, lane, side, p3, pA, sa0, sa1);
     xs_store_sym6(lds, lane, X_IA + side * 27, IA, pA);
     WS_STAMP(side, 4 + 8 * s);
     ws_barrier();  // B2
@@ -259,7 +263,7 @@ BEZ_DEV void leg_role(const Params& P, float* lds, int lane, int e, bool active,
     WS_STAMP(side, 6 + 8 * s);
     SV a0 = xs_load_sv(lds, lane, X_A0);
     V3 fl = mk(0, 0, 0), fend = mk(0, 0, 0);
-    SV aend = ws_chain_pass3<FIRST, LEN, true, CL>(P, a0, p3, q, qd, mine, sel, fl, fend, lds, lane, keep, first);
+    SV aend = ws_chain_pass3<FIRST, LEN, true, CL>(P, a0, p3, q, qd, mine, sel, fl, fend, lds, lane, keep, first, sa0, sa1);
     if (mine && sel.link >= 0) { xs_store_v3(lds, lane, X_FL, fl); xs_store_v3(lds, lane, X_FL + 3, sel.xb); }
     if (keep) {
       if constexpr (CL) {  // the foot plate only feels the ball / the other leg; the ground acts on the four cleats
@@ -491,7 +495,7 @@ BEZ_DEV void self_role(const Params& P, float* lds, int lane, int e, bool active
     }
     WS_STAMP(6 + PART, 2 + 8 * s);
     ws_barrier();  // B1
-    ws_self_pairs<PART>(P, D.mu, lds, lane, K);
+    XS(X_SELFANY + PART) = ws_self_pairs<PART, true>(P, D.mu, lds, lane, K) ? 1.f : 0.f;
     WS_STAMP(6 + PART, 4 + 8 * s);
     ws_barrier();  // B1c
     ws_barrier();  // B2
