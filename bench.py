@@ -208,11 +208,11 @@ def main():
                        "envs_per_gpu": n, "total_envs": total_envs, "launch": args.launch, "parallelism": "env-sharded x%d" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "bez::step_kernel_ws<true,true,false,false> (fused control step, default asset)", "kernel_ms": kernel_ms,
+                         "kernel": "bez::w8::step_kernel_ws8<true,true,false,false> (fused control step, default asset, 8 role waves per 64 envs)", "kernel_ms": kernel_ms,
                          "algorithmic_bytes_per_launch": ALGO_BYTES_PER_ENV_STEP * n,
                          "traffic_unit": "bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE; source: profiles/%s)" % traffic_src
                                          if traffic is not None else "no committed PMC profile matches this build's source hash",
-                         "note": "N=4096 is latency-bound (64 workgroups x 4 role waves on 256 CUs, serial ABA chains): see DESIGN.md"},
+                         "note": "N=4096 is latency-bound (64 workgroups x 8 role waves on 256 CUs, serial ABA chains): see DESIGN.md"},
         }
         if ppo is not None:
             out["ppo"] = ppo

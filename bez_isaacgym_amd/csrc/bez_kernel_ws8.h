@@ -8,10 +8,10 @@
 // the first leaves empty):
 //     role 0  left leg   (links 5..10)    pass 1 (kinematics, inertias), foot ground contact, pass 2, leg<->leg correction, pass 3
 //     role 1  right leg  (links 13..18)   same
-//     role 2  ball candidates among the hip / thigh boxes of both legs (own forward kinematics down to the thighs), then the
+//     role 2  ball candidates among the hip / thigh / calf boxes of both legs (own forward kinematics down to the calves), then the
 //             head (links 1,2) as a chain of its own
 //     role 3  torso, ball, ball<->torso-box candidate, 6x6 root solve, integration, post-physics
-//     role 4  ball candidate among the calf / ankle / foot boxes of the left leg (own forward kinematics of the leg) -> X_CAND; then the left arm (links 3,4) as a chain of its own; then the sum of the head / arm blocks
+//     role 4  ball candidate among the ankle / foot boxes of the left leg (own forward kinematics of the leg) -> X_CAND; then the left arm (links 3,4) as a chain of its own; then the sum of the head / arm blocks
 //     role 5  the same for the right leg and the right arm (links 11,12)
 //     role 6  leg<->leg capsule pairs of the left hip/thigh/calf capsules (own forward kinematics of both legs)
 //     role 7  leg<->leg capsule pairs of the left ankle/foot capsules
@@ -45,10 +45,18 @@ enum : int {
   X_IA = 439,      // 5 chains (left leg, right leg, head, left arm, right arm) x (Sym6 21 + bias 6); block 2 ends up holding head + arms
   X_BCN = 574,     // per leg: contact rows of the foot (B 9, C 6, F0 3), parked here across pass 2 (register pressure)
   X_CANDH = 610,   // per leg: the same 14 floats for the upper boxes (hip / thigh links), from role 2
-  X_SELFANY = 638, // per helper part: 1 if this env has a leg<->leg contact in that part's pairs
-  X_SLOTS = 640
+  X_SLOTS = 638
 };
-constexpr int CAND_SPLIT = 3;  // leg links 0..2 (hip_side, hip_front, thigh) are tested by role 2, links 3..5 (calf, ankle, foot) by roles 4 / 5
+#ifndef BEZ_W8_CAND_SPLIT
+#define BEZ_W8_CAND_SPLIT 4
+#endif
+#ifndef BEZ_W8_LEG_BAR
+#define BEZ_W8_LEG_BAR 2
+#endif
+#ifndef BEZ_W8_SELF_BAR
+#define BEZ_W8_SELF_BAR 3
+#endif
+constexpr int CAND_SPLIT = BEZ_W8_CAND_SPLIT;  // leg links 0..3 (hip_side, hip_front, thigh, calf) are tested by role 2, links 4..5 (ankle, foot) by roles 4 / 5 (A/B-tuned: tools/ab_bench.py)
 constexpr int X_STAGE = X_IA;  // staging aliases the chain blocks (see the header comment)
 constexpr int WS_ACT_STRIDE = 19;
 constexpr int WS_LDS_FLOATS = X_SLOTS * WS_ENVS;
@@ -224,7 +232,7 @@ BEZ_DEV void leg_role(const Params& P, float* lds, int lane, int e, bool active,
     BallSel sel;
     sel.link = -1; sel.depth = 0.f; sel.n = sel.P = sel.f0p = sel.x = sel.xb = mk(0, 0, 0); sel.A = sym3zero();
     M3 Eend; V3 rend; SV Vend, Vsel = svzero();
-    ws_chain_pass1<FIRST, LEN, true, CL, false, 2>(P, D, ms, R, q, qd, LI, pAl, Sl, cbl, Eend, rend, Vend, sel, Vsel, s > 0);  // B5 of the previous substep inside
+    ws_chain_pass1<FIRST, LEN, true, CL, false, BEZ_W8_LEG_BAR>(P, D, ms, R, q, qd, LI, pAl, Sl, cbl, Eend, rend, Vend, sel, Vsel, s > 0);  // B5 of the previous substep inside
     Sym6 Kc = sym6zero(); SV pc = svzero();
     ws_ground_points<FIRST + LEN - 1, CL>(P, D.mu, R.root_z, Eend, rend, Vend, Kc, pc, lds, lane, X_HIT + side * 32);
     xs_store_body_contact(lds, lane, X_BCN + side * 18, body_contact_of(Kc, pc));
@@ -251,10 +259,7 @@ BEZ_DEV void leg_role(const Params& P, float* lds, int lane, int e, bool active,
     ws_chain_pass2<FIRST, LEN, true>(P, D, kps, kds, lo, hi, q, qd, target, LI, pAl, Sl, cbl, Kc, pc, mine, sel, p3, IA, pA);
     WS_STAMP(side, 24 + s);
     ws_barrier();  // B1c: both helper parts' leg<->leg contact wrenches are in LDS
-    // wave-uniform: did either part find a contact in any env of this workgroup?  (mostly not: the correction and the per-link
-    // force loads of pass 3 are then skipped)
-    const bool sa0 = __any(XS(X_SELFANY) != 0.f), sa1 = __any(XS(X_SELFANY + 1) != 0.f);
-    ws_chain_self_correction<LEN>(lds, lane, side, p3, pA, sa0, sa1);
+    ws_chain_self_correction<LEN>(lds, lane, side, p3, pA);
     xs_store_sym6(lds, lane, X_IA + side * 27, IA, pA);
     WS_STAMP(side, 4 + 8 * s);
     ws_barrier();  // B2
@@ -263,7 +268,7 @@ BEZ_DEV void leg_role(const Params& P, float* lds, int lane, int e, bool active,
     WS_STAMP(side, 6 + 8 * s);
     SV a0 = xs_load_sv(lds, lane, X_A0);
     V3 fl = mk(0, 0, 0), fend = mk(0, 0, 0);
-    SV aend = ws_chain_pass3<FIRST, LEN, true, CL>(P, a0, p3, q, qd, mine, sel, fl, fend, lds, lane, keep, first, sa0, sa1);
+    SV aend = ws_chain_pass3<FIRST, LEN, true, CL>(P, a0, p3, q, qd, mine, sel, fl, fend, lds, lane, keep, first);
     if (mine && sel.link >= 0) { xs_store_v3(lds, lane, X_FL, fl); xs_store_v3(lds, lane, X_FL + 3, sel.xb); }
     if (keep) {
       if constexpr (CL) {  // the foot plate only feels the ball / the other leg; the ground acts on the four cleats
@@ -490,12 +495,12 @@ BEZ_DEV void self_role(const Params& P, float* lds, int lane, int e, bool active
     {  // kinematics of both legs: one third in, meet the other roles at B5 of the previous substep (this role does not read the ball)
       const M3 E0 = quat_to_mat(XS(X_ROOT + 3), XS(X_ROOT + 4), XS(X_ROOT + 5), XS(X_ROOT + 6));
       const SV V0 = mksv(xs_load_v3(lds, lane, X_ROOT + 10), xs_load_v3(lds, lane, X_ROOT + 7));
-      ws_self_fk<PART, 3>(lds, lane, E0, V0, K, s > 0);
+      ws_self_fk<PART, BEZ_W8_SELF_BAR>(lds, lane, E0, V0, K, s > 0);
       ws_self_pin<PART>(K);
     }
     WS_STAMP(6 + PART, 2 + 8 * s);
     ws_barrier();  // B1
-    XS(X_SELFANY + PART) = ws_self_pairs<PART, true>(P, D.mu, lds, lane, K) ? 1.f : 0.f;
+    ws_self_pairs<PART>(P, D.mu, lds, lane, K);
     WS_STAMP(6 + PART, 4 + 8 * s);
     ws_barrier();  // B1c
     ws_barrier();  // B2
@@ -531,12 +536,12 @@ BEZ_DEV void root_role(const Params& P, float* lds, int lane, int e, bool active
   float ms0 = 1.f;
   if (DR) { if (P.dr_mass) ms0 = P.dr_mass[(size_t)e * BEZ_NL]; }
   const bool last_only = (P.flags & BEZ_FLAG_CF_LAST_SUBSTEP) != 0;
-  auto publish_root = [&]() {
+  auto publish_root = [&]() __attribute__((always_inline)) {
     xs_store_v3(lds, lane, X_ROOT, root_pos);
     XS(X_ROOT + 3) = rq[0]; XS(X_ROOT + 4) = rq[1]; XS(X_ROOT + 5) = rq[2]; XS(X_ROOT + 6) = rq[3];
     xs_store_v3(lds, lane, X_ROOT + 7, root_lin); xs_store_v3(lds, lane, X_ROOT + 10, root_ang);
   };
-  auto publish_ball = [&]() {
+  auto publish_ball = [&]() __attribute__((always_inline)) {
     xs_store_v3(lds, lane, X_BALL, ball_pos); xs_store_v3(lds, lane, X_BALL + 3, ball_lin); xs_store_v3(lds, lane, X_BALL + 6, ball_ang);
   };
   publish_root(); publish_ball();
@@ -547,8 +552,9 @@ BEZ_DEV void root_role(const Params& P, float* lds, int lane, int e, bool active
   // box tests of the NEXT substep need its result -- so the update runs at the top of the next iteration (and once after the
   // loop), beside the other roles' forward kinematics, and B5 sits in the middle of their pass-1 window.
   BallBody ball; BallSel sel; bool torso_hit = false; V3 fl_t = mk(0, 0, 0);
-  auto ball_update = [&](bool keep, bool first) {
+  auto ball_update = [&](bool keep, bool first) __attribute__((always_inline)) {
     V3 fl = xs_load_v3(lds, lane, X_FL), xb = xs_load_v3(lds, lane, X_FL + 3);
+    pin(fl); pin(xb);  // loaded values, not a select between an LDS and a private address (that would put fl_t / sel in scratch)
     if (torso_hit) { fl = fl_t; xb = sel.xb; }
     SV ab = ball_minv(ball, svzero() - ball.pb - wrench_at(xb, fl));
     if (keep) {
@@ -596,7 +602,11 @@ BEZ_DEV void root_role(const Params& P, float* lds, int lane, int e, bool active
     const int winner = cand_winner(cd);
     torso_hit = (winner == 2) && (sel.link == 0);
     if (torso_hit) { add_point_stiffness(IA0, sel.x, sel.A); pA0 = pA0 - wrench_at(sel.x, sel.f0p); }
-    if (winner != 2) sel.n = xs_load_v3(lds, lane, (winner ? cd.br : cd.bl) + 2);  // contact normal of the winning leg box (ball's contact row)
+    {  // contact normal of the winning leg box (for the ball's contact row)
+      V3 nw = xs_load_v3(lds, lane, (winner == 1 ? cd.br : cd.bl) + 2);
+      pin(nw);
+      if (winner != 2) sel.n = nw;
+    }
     WS_STAMP(3, 24 + s);
     ws_barrier();  // B1c
     ws_barrier();  // B2: chain contributions published
@@ -667,8 +677,8 @@ BEZ_DEV void root_role(const Params& P, float* lds, int lane, int e, bool active
     const float pn = (((XS(X_PSUM + 2) + XS(X_PSUM + 4)) + XS(X_PSUM + 5)) + XS(X_PSUM + 0)) + XS(X_PSUM + 1);
     OrnOut orn; orn.ux = orn.uy = orn.gn = orn.ang_goal = 0.f;
     if (P.task != BEZ_TASK_KICK) {  // the walk / orient rewards use the goal direction / heading error (role 6 computes the same for the observation)
-      float dummy_prev[3] = {0.f, 0.f, 0.f}, dummy_tail[8];
-      orn = obs_imu_orn(P, root_pos, rq, root_lin, root_ang, dummy_prev, goal_x, goal_y, dummy_tail);
+      float t6, t7;
+      orn = obs_off_orn(P, root_pos, rq, goal_x, goal_y, t6, t7);
     }
     float rew;
     reward_of(P, root_pos, rq, root_lin, root_ang, ball_pos, ball_lin, pn, orn, rew, reset, progress, goal_x, goal_y);

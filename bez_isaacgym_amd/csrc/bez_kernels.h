@@ -797,6 +797,26 @@ BEZ_DEV void feet_no_cleats(float* f, float* out) {
 //   reward_of    reward and the reset flag of the NEXT step
 // `pn` = sum_j (default_j - q_j)^2.  `goal` = this env's goal xy (bez_kick: the configured point; bez_walk: redrawn at reset).
 struct OrnOut { float ux, uy, gn, ang_goal; };  // unit vector / distance to the goal, orient task's heading error
+// compute_off_orn (kick_env.py:941-960) / orient_env.py:719-735 compute_off_angle: the two orientation slots (t6, t7) and the
+// goal direction / heading error the walk and orient rewards reuse
+BEZ_DEV OrnOut obs_off_orn(const Params& P, V3 root_pos, const float* rq, float goal_x, float goal_y, float& t6, float& t7) {
+  OrnOut o;
+  float gx = goal_x - root_pos.x, gy = goal_y - root_pos.y;
+  o.gn = sqrtf(gx * gx + gy * gy);
+  o.ux = gx / o.gn; o.uy = gy / o.gn;
+  float qx = rq[0], qy = rq[1], qz = rq[2], qw = rq[3];
+  // heading (cos yaw, sin yaw) with yaw = atan2(sy, cy) (get_euler_xyz [ext]): the unit vector (cy, sy)/|.| itself --
+  // the % 2pi wrap and the atan2/sincos round trip of the reference only cost rounding (checked by the golden tests)
+  float sy = 2.0f * (qw * qz + qx * qy), cy = qw * qw + qx * qx - qy * qy - qz * qz;
+  float hn = 1.0f / sqrtf(sy * sy + cy * cy);
+  float hs = sy * hn, hc = cy * hn;
+  float cosv = hc * o.ux + hs * o.uy;
+  float sinv = fabsf(o.ux * hs - o.uy * hc);
+  t6 = sinv; t7 = -cosv;
+  o.ang_goal = 0.f;
+  if (P.task == BEZ_TASK_ORIENT) { o.ang_goal = P.goal_angle - atan2f(hs, hc); t6 = cosf(o.ang_goal); t7 = sinf(o.ang_goal); }
+  return o;
+}
 BEZ_DEV OrnOut obs_imu_orn(const Params& P, V3 root_pos, const float* rq, V3 v, V3 w, float* prev, float goal_x, float goal_y, float* tail) {
   // IMU link = torso origin frame (soccerbot_stl.urdf:567-572)
   // compute_imu (kick_env.py:918-930), quaternion_to_matrix fed xyzw as (r,i,j,k) (quirk Q2)
@@ -813,24 +833,7 @@ BEZ_DEV OrnOut obs_imu_orn(const Params& P, V3 root_pos, const float* rq, V3 v, 
   tail[2] = fminf(fmaxf(m20 * ax + m21 * ay + m22 * az, -LIN), LIN);
   tail[3] = fminf(fmaxf(w.x, -ANG), ANG); tail[4] = fminf(fmaxf(w.y, -ANG), ANG); tail[5] = fminf(fmaxf(w.z, -ANG), ANG);
   prev[0] = v.x; prev[1] = v.y; prev[2] = v.z;
-  // compute_off_orn (kick_env.py:941-960)
-  OrnOut o;
-  float gx = goal_x - root_pos.x, gy = goal_y - root_pos.y;
-  o.gn = sqrtf(gx * gx + gy * gy);
-  o.ux = gx / o.gn; o.uy = gy / o.gn;
-  float qx = rq[0], qy = rq[1], qz = rq[2], qw = rq[3];
-  // heading (cos yaw, sin yaw) with yaw = atan2(sy, cy) (get_euler_xyz [ext]): the unit vector (cy, sy)/|.| itself --
-  // the % 2pi wrap and the atan2/sincos round trip of the reference only cost rounding (checked by the golden tests)
-  float sy = 2.0f * (qw * qz + qx * qy), cy = qw * qw + qx * qx - qy * qy - qz * qz;
-  float hn = 1.0f / sqrtf(sy * sy + cy * cy);
-  float hs = sy * hn, hc = cy * hn;
-  float cosv = hc * o.ux + hs * o.uy;
-  float sinv = fabsf(o.ux * hs - o.uy * hc);
-  tail[6] = sinv; tail[7] = -cosv;
-  // orient_env.py:719-735 compute_off_angle: (cos, sin) of goal_angle - normalize_angle(yaw)
-  o.ang_goal = 0.f;
-  if (P.task == BEZ_TASK_ORIENT) { o.ang_goal = P.goal_angle - atan2f(hs, hc); tail[6] = cosf(o.ang_goal); tail[7] = sinf(o.ang_goal); }
-  return o;
+  return obs_off_orn(P, root_pos, rq, goal_x, goal_y, tail[6], tail[7]);
 }
 // `cleats` = the 8 cleat rows of the net contact force (24 floats) with the cleats asset, else null
 BEZ_DEV void obs_feet(const Params& P, CfOut& co, const float* cleats, float* feet, float* tail) {

@@ -19,8 +19,8 @@ KERNEL = "step_kernel_ws"
 
 
 def _one(pattern):
-    hits = glob.glob(pattern, recursive=True)
-    return hits[0] if hits else None
+    hits = sorted(glob.glob(pattern, recursive=True), key=os.path.getmtime)  # gpurun merges into the old scratch tree: newest wins
+    return hits[-1] if hits else None
 
 
 def counter_mean(directory, counter, kernel_substr):
@@ -42,7 +42,7 @@ def kernel_code_bytes(kernel_mangled):
     """codeLenInByte of one kernel: device-only assembly of its translation unit with the build's own flags."""
     import tempfile
     from bez_isaacgym_amd.build import _flags
-    src = os.path.join(ROOT, "bez_isaacgym_amd", "csrc", "bez_step_ws.hip")
+    src = os.path.join(ROOT, "bez_isaacgym_amd", "csrc", "bez_step_ws8.hip")
     with tempfile.TemporaryDirectory() as d:
         out = os.path.join(d, "ws.s")
         flags = [f for f in _flags() if f != "-fPIC"]
@@ -59,15 +59,15 @@ def kernel_code_bytes(kernel_mangled):
 
 
 def size_sweep(directory, counter):
-    """mean counter value (KiB) per launch of the step kernel, by number of envs (grid size / 256 x 64)."""
+    """mean counter value (KiB) per launch of the step kernel, by number of envs (grid size / 512 threads x 64 envs)."""
     f = _one(os.path.join(directory, "**", "*counter_collection.csv"))
     if not f:
         return None
     acc = {}
     for row in csv.DictReader(open(f)):
         if row["Counter_Name"] == counter and KERNEL in row["Kernel_Name"]:
-            acc.setdefault(int(row["Grid_Size"]) // 256 * 64, {}).setdefault(row["Dispatch_Id"], 0.0)
-            acc[int(row["Grid_Size"]) // 256 * 64][row["Dispatch_Id"]] += float(row["Counter_Value"])
+            acc.setdefault(int(row["Grid_Size"]) // 512 * 64, {}).setdefault(row["Dispatch_Id"], 0.0)
+            acc[int(row["Grid_Size"]) // 512 * 64][row["Dispatch_Id"]] += float(row["Counter_Value"])
     return {n: (lambda v: sum(v) / len(v))(list(d.values())[4:]) for n, d in sorted(acc.items())}
 
 
@@ -119,7 +119,7 @@ def main():
         per_env_raw = (sw_r[16384] - sw_r[4096]) * 1024 / (16384 - 4096)
         fixed_raw = (sw_r[4096] * 1024 - 4096 * per_env_raw) / 8
         mangled = kernel_name.split("(")[0] if kernel_name else None
-        code = kernel_code_bytes("_ZN3bez14step_kernel_wsILb1ELb1ELb0ELb0EEEvNS_6ParamsE")
+        code = kernel_code_bytes("_ZN3bez2w815step_kernel_ws8ILb1ELb1ELb0ELb0EEEvNS_6ParamsE")
         att = {"FETCH_SIZE_KiB_by_num_envs": sw_r, "WRITE_SIZE_KiB_by_num_envs": sw_w,
                "fit": "raw FETCH_SIZE bytes = 8 XCDs x fixed + num_envs x per_env (from the 4096 and 16384 points)",
                "fixed_bytes_per_xcd_raw": fixed_raw, "kernel_codeLenInByte": code,
