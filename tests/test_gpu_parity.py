@@ -11,10 +11,11 @@ from tests import golden_checks as GC
 pytestmark = pytest.mark.gpu
 
 # fp32 HIP kernel vs fp64 oracle after ONE control step (2 substeps) from an identical state.
-# Stated tolerance (DESIGN.md "Parity"): 2e-4 absolute on positions / quaternions / joint angles,
-# 2e-2 on velocities (rad/s, m/s; joint speeds reach the 6.28 rad/s clamp and the oracle's own fp32 build
-# deviates from its fp64 build by 1e-2 on the same inputs), 2% + 0.05 N on contact forces.
-POS_ATOL, VEL_ATOL = 2e-4, 2e-2
+# Stated tolerances (DESIGN.md "Parity") = 2-3x the worst error tools/gpu_probe.py observes (128 envs x 40 resynchronised
+# steps; HIP / the oracle's own fp32 build against the fp64 oracle): root and ball pose 7.5e-6 / 6.2e-6, joint angles 5.5e-5 /
+# 6.6e-5, root and ball velocity 1.5e-3 / 1.1e-3, joint speeds 6.4e-3 / 7.7e-3 (they reach the 6.28 rad/s clamp), contact
+# forces 1.6e-2 / 1.1e-2 N, reward 2.4e-6 / 6.4e-6.
+ROOT_POS_ATOL, POS_ATOL, ROOT_VEL_ATOL, VEL_ATOL = 2e-5, 1.5e-4, 4e-3, 1.5e-2
 
 
 @pytest.fixture(scope="module")
@@ -52,8 +53,8 @@ def test_reset_state_bit_exact():
 
 def _compare_state(o, g, scale=1.0):
     ro, rg = o.root_states.reshape(-1, 2, 13), g.root_states.reshape(-1, 2, 13)
-    np.testing.assert_allclose(rg[:, :, 0:7], ro[:, :, 0:7], atol=POS_ATOL * scale)
-    np.testing.assert_allclose(rg[:, :, 7:13], ro[:, :, 7:13], atol=VEL_ATOL * scale)
+    np.testing.assert_allclose(rg[:, :, 0:7], ro[:, :, 0:7], atol=ROOT_POS_ATOL * scale)
+    np.testing.assert_allclose(rg[:, :, 7:13], ro[:, :, 7:13], atol=ROOT_VEL_ATOL * scale)
     do, dg = o.dof_state.reshape(-1, 18, 2), g.dof_state.reshape(-1, 18, 2)
     np.testing.assert_allclose(dg[:, :, 0], do[:, :, 0], atol=POS_ATOL * scale)
     np.testing.assert_allclose(dg[:, :, 1], do[:, :, 1], atol=VEL_ATOL * scale)
@@ -62,16 +63,22 @@ def _compare_state(o, g, scale=1.0):
 def test_single_step_parity_resynced():
     """For 40 control steps: copy the oracle's state into the HIP sim, step both with the same random actions,
     compare everything the step produces.  Resyncing every step measures the per-step error, not chaos."""
+    from oracle.bez_oracle import Oracle
     n = 128
     o, g = _pair(n, seed=7)
+    o32 = Oracle(abi.default_config(n, seed=7), precision="f32")  # the same C source built in fp32: what plain fp32 rounding costs
     rng = np.random.default_rng(3)
-    worst = {}
+    worst = {"hip": {}, "cpu32": {}}
     for t in range(40):
-        g.set_root_states(o.root_states); g.set_dof_state(o.dof_state)
-        g.set_contact_forces(o.contact_forces); g.set_targets(o.targets)
-        g.set_reset(o.reset_buf); g.set_progress(o.progress_buf)
+        for x in (g, o32):
+            x.set_root_states(o.root_states); x.set_dof_state(o.dof_state)
+            x.set_contact_forces(o.contact_forces); x.set_targets(o.targets)
+            x.set_reset(o.reset_buf); x.set_progress(o.progress_buf)
         act = rng.uniform(-1, 1, (n, 18)).astype(np.float32)
-        o.step(act); g.step(act)
+        o.step(act); g.step(act); o32.step(act)
+        for tag, x in (("hip", g), ("cpu32", o32)):
+            for k, a, b in (("root", o.root_states, x.root_states), ("dof", o.dof_state, x.dof_state), ("rew", o.rew, x.rew)):
+                worst[tag][k] = max(worst[tag].get(k, 0.0), float(np.abs(a - b).max()))
         # envs that were reset this step restart from the (bit-exact) reset draw: still comparable
         _compare_state(o, g)
         np.testing.assert_array_equal(g.reset_buf, o.reset_buf)
@@ -79,14 +86,18 @@ def test_single_step_parity_resynced():
         np.testing.assert_array_equal(g.timeout_buf, o.timeout_buf)
         np.testing.assert_allclose(g.obs[:, :36], o.obs[:, :36], atol=VEL_ATOL)
         np.testing.assert_allclose(g.obs[:, 36:44], o.obs[:, 36:44], atol=VEL_ATOL)
-        np.testing.assert_allclose(g.rew, o.rew, atol=2e-3)
+        np.testing.assert_allclose(g.rew, o.rew, atol=2e-5)
         cf_o, cf_g = o.contact_forces.reshape(n, 22, 3), g.contact_forces.reshape(n, 22, 3)
-        np.testing.assert_allclose(cf_g, cf_o, rtol=0.02, atol=0.05)
+        np.testing.assert_allclose(cf_g, cf_o, rtol=0.01, atol=0.04)
         # the feet flags are threshold functions of the contact force: compare where the oracle is not within
         # tolerance of a threshold (0.01 N noise gate, 1 N load gate)
         fo = cf_o[:, [12, 20]]
         safe = (np.abs(np.abs(fo) - 0.01) > 0.06).all(axis=(1, 2)) & (np.abs(fo[:, :, 2] - 1.0) > 0.08).all(axis=1)
         np.testing.assert_array_equal(g.obs[safe, 44:52], o.obs[safe, 44:52])
+    # the HIP kernel must not be worse than a plain fp32 build of the oracle by more than its own scatter (a regression in the
+    # kernel's numerics shows here long before it reaches the absolute tolerances)
+    for k in worst["hip"]:
+        assert worst["hip"][k] <= 2.5 * worst["cpu32"][k] + 1e-6, (k, worst)
 
 
 def test_rollout_parity_free():
@@ -122,7 +133,7 @@ def test_fused_equals_split():
         b.pre_physics(act); b.simulate(); b.post_physics()
         for name in ("reset_buf", "progress_buf", "timeout_buf", "targets"):
             np.testing.assert_array_equal(getattr(a, name), getattr(b, name), err_msg=name)
-        _compare_state(a, b, scale=0.25)
+        _compare_state(a, b)  # two kernels in fp32 (fused 8-wave vs the lane kernel's split entry points): observed 6e-6 / 1.4e-3 / 4e-5 / 4.7e-3
         np.testing.assert_allclose(a.obs, b.obs, atol=5e-3)
         np.testing.assert_allclose(a.rew, b.rew, atol=5e-4)
 

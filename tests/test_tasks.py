@@ -146,11 +146,11 @@ def test_hip_variant_step_parity(task, cleats):
         np.testing.assert_array_equal(g.reset_buf, o.reset_buf)
         np.testing.assert_array_equal(g.progress_buf, o.progress_buf)
         do, dg = o.dof_state.reshape(n, 18, 2), g.dof_state.reshape(n, 18, 2)
-        np.testing.assert_allclose(dg[..., 0], do[..., 0], atol=2e-4)
-        np.testing.assert_allclose(dg[..., 1], do[..., 1], atol=2e-2)
+        np.testing.assert_allclose(dg[..., 0], do[..., 0], atol=1.5e-4)
+        np.testing.assert_allclose(dg[..., 1], do[..., 1], atol=1.5e-2)
         ro, rg = o.root_states.reshape(n, o.nact, 13), g.root_states.reshape(n, o.nact, 13)
-        np.testing.assert_allclose(rg[..., 0:7], ro[..., 0:7], atol=2e-4)
-        np.testing.assert_allclose(rg[..., 7:13], ro[..., 7:13], atol=2e-2)
+        np.testing.assert_allclose(rg[..., 0:7], ro[..., 0:7], atol=5e-5)
+        np.testing.assert_allclose(rg[..., 7:13], ro[..., 7:13], atol=6e-3)
         np.testing.assert_allclose(g.contact_forces, o.contact_forces, rtol=0.02, atol=0.05)
         np.testing.assert_allclose(g.obs[:, :44], o.obs[:, :44], atol=2e-2)
         np.testing.assert_allclose(g.rew, o.rew, atol=0.2 if task == "bez_walk" else 2e-3, rtol=1e-3)  # bez_walk: 10 * forward speed
