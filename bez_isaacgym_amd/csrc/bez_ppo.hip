@@ -126,34 +126,62 @@ __global__ __launch_bounds__(PPO_TB) void ppo_rollout_post_kernel(const float* _
 // stats (atomically accumulated, caller zeroes): [sum a_loss, sum c_loss, sum b_loss, sum kl, sum entropy]
 // grad_mu / grad_value are d(loss)/d(mu), d(loss)/d(value) times *scale (GradScaler's loss scale, a device scalar; null = 1);
 // grad_logstd (A) is accumulated atomically (caller zeroes).
+// Layout: one sample per thread; the (B,A) row-major operands of a workgroup's 256 consecutive rows are one contiguous block,
+// moved with coalesced accesses and transposed through LDS ([row][A+1]: conflict-free for the per-thread row walk).  A is a
+// template parameter (register arrays, unrolled loops); the per-column / per-term sums are reduced in the workgroup first, so a
+// launch issues 23 atomics per 256 samples.
+template <int A>
 __global__ __launch_bounds__(PPO_TB) void ppo_loss_kernel(const float* __restrict__ mu, const float* __restrict__ logstd, const float* __restrict__ value,
                                                           const float* __restrict__ act, const float* __restrict__ old_logp, const float* __restrict__ adv,
                                                           const float* __restrict__ old_value, const float* __restrict__ ret, const float* __restrict__ old_mu,
-                                                          const float* __restrict__ old_sigma, int64_t B, int A, float e_clip, float critic_coef,
+                                                          const float* __restrict__ old_sigma, int64_t B, float e_clip, float critic_coef,
                                                           float entropy_coef, float bounds_coef, int clip_value, const float* __restrict__ scale,
                                                           float* __restrict__ grad_mu, float* __restrict__ grad_value, float* __restrict__ grad_logstd,
                                                           float* __restrict__ stats) {
-  constexpr int AMAX = 32;
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const bool on = i < B;
+  constexpr int LD = A + 1;
+  __shared__ float tile[PPO_TB * LD];
+  __shared__ float red[4][A + 5];
+  const int tid = threadIdx.x;
+  const int64_t row0 = (int64_t)blockIdx.x * PPO_TB;
+  const int64_t i = row0 + tid;
+  const int nrow = (int)((B - row0) < (int64_t)PPO_TB ? (B - row0) : (int64_t)PPO_TB);
+  const bool on = tid < nrow;
   const float S = scale ? scale[0] : 1.0f, invB = 1.0f / (float)B;
-  float a_l = 0.f, c_l = 0.f, b_l = 0.f, kl = 0.f, ent = 0.f;
-  float gls[AMAX];
+  // coalesced load of this workgroup's (nrow, A) block of `src` into the LDS tile, then this thread's row into registers
+  auto load_rows = [&](const float* __restrict__ src, float* r) {
+    __syncthreads();
+    const float* blk = src + row0 * A;
+    for (int k = tid; k < nrow * A; k += PPO_TB) tile[(k / A) * LD + (k % A)] = blk[k];
+    __syncthreads();
 #pragma unroll
-  for (int j = 0; j < AMAX; ++j) gls[j] = 0.f;
-  if (on) {
-    float z[AMAX], sg[AMAX];
-    float acc = 0.f, ls = 0.f;
-    for (int j = 0; j < A; ++j) {
-      const float l = logstd[j], s = expf(l), m = mu[i * A + j];
-      sg[j] = s;
-      z[j] = (act[i * A + j] - m) / s;
-      acc = fmaf(z[j], z[j], acc); ls += l;
-      ent += 0.5f + 0.5f * LOG_2PI + l;
-      // policy_kl(current, old)
-      const float s1 = old_sigma[i * A + j], dm = old_mu[i * A + j] - m;
-      kl += logf(s1 / s + 1e-5f) + (s * s + dm * dm) / (2.0f * (s1 * s1 + 1e-5f)) - 0.5f;
+    for (int j = 0; j < A; ++j) r[j] = on ? tile[tid * LD + j] : 0.f;
+  };
+  float m[A], z[A], sg[A], gls[A];
+  float a_l = 0.f, c_l = 0.f, b_l = 0.f, kl = 0.f, ent = 0.f;
+  load_rows(mu, m);
+  {
+    float x[A];
+    load_rows(act, x);
+#pragma unroll
+    for (int j = 0; j < A; ++j) { sg[j] = expf(logstd[j]); z[j] = (x[j] - m[j]) / sg[j]; }
+    float om[A];
+    load_rows(old_mu, om);
+    load_rows(old_sigma, x);
+    if (on) {
+#pragma unroll
+      for (int j = 0; j < A; ++j) {  // policy_kl(current, old)
+        const float s = sg[j], s1 = x[j], dm = om[j] - m[j];
+        kl += logf(s1 / s + 1e-5f) + (s * s + dm * dm) / (2.0f * (s1 * s1 + 1e-5f)) - 0.5f;
+      }
     }
+  }
+  float gm[A];
+#pragma unroll
+  for (int j = 0; j < A; ++j) { gls[j] = 0.f; gm[j] = 0.f; }
+  if (on) {
+    float acc = 0.f, ls = 0.f;
+#pragma unroll
+    for (int j = 0; j < A; ++j) { const float l = logstd[j]; acc = fmaf(z[j], z[j], acc); ls += l; ent += 0.5f + 0.5f * LOG_2PI + l; }
     const float neglogp = 0.5f * acc + 0.5f * LOG_2PI * (float)A + ls;
     const float ratio = expf(old_logp[i] - neglogp), ad = adv[i];
     const float rc = fminf(fmaxf(ratio, 1.0f - e_clip), 1.0f + e_clip);
@@ -181,24 +209,94 @@ __global__ __launch_bounds__(PPO_TB) void ppo_loss_kernel(const float* __restric
       g_v = 2.0f * (v - rt);
     }
     grad_value[i] = 0.5f * critic_coef * g_v * invB * S;
+#pragma unroll
     for (int j = 0; j < A; ++j) {
-      const float m = mu[i * A + j];
-      const float hi = fmaxf(m - 1.1f, 0.f), lo = fminf(m + 1.1f, 0.f);
+      const float hi = fmaxf(m[j] - 1.1f, 0.f), lo = fminf(m[j] + 1.1f, 0.f);
       b_l += hi * hi + lo * lo;
       const float g_b = bounds_coef > 0.f ? bounds_coef * 2.0f * (hi + lo) : 0.f;
       // d neglogp / d mu_j = -z_j / sigma_j ; d neglogp / d logstd_j = 1 - z_j^2
-      grad_mu[i * A + j] = (g_nlp * (-z[j] / sg[j]) + g_b) * invB * S;
+      gm[j] = (g_nlp * (-z[j] / sg[j]) + g_b) * invB * S;
       gls[j] = (g_nlp * (1.0f - z[j] * z[j]) - entropy_coef) * invB * S;
     }
     if (!(bounds_coef > 0.f)) b_l = 0.f;
   }
-  for (int j = 0; j < A; ++j) {
-    const float g = wave_sum(gls[j]);
-    if ((threadIdx.x & 63) == 0) atomicAdd(&grad_logstd[j], g);
+  // grad_mu rows back through the tile: coalesced store of the workgroup's contiguous block
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < A; ++j) tile[tid * LD + j] = gm[j];
+  __syncthreads();
+  {
+    float* blk = grad_mu + row0 * A;
+    for (int k = tid; k < nrow * A; k += PPO_TB) blk[k] = tile[(k / A) * LD + (k % A)];
   }
+  // workgroup reduction of the A log-std gradient columns and the five statistics, then one atomic each
+  const int w = tid >> 6, l = tid & 63;
+#pragma unroll
+  for (int j = 0; j < A; ++j) { const float g = wave_sum(gls[j]); if (l == 0) red[w][j] = g; }
   a_l = wave_sum(a_l); c_l = wave_sum(c_l); b_l = wave_sum(b_l); kl = wave_sum(kl); ent = wave_sum(ent);
-  if ((threadIdx.x & 63) == 0) {
-    atomicAdd(&stats[0], a_l); atomicAdd(&stats[1], c_l); atomicAdd(&stats[2], b_l); atomicAdd(&stats[3], kl); atomicAdd(&stats[4], ent);
+  if (l == 0) { red[w][A] = a_l; red[w][A + 1] = c_l; red[w][A + 2] = b_l; red[w][A + 3] = kl; red[w][A + 4] = ent; }
+  __syncthreads();
+  if (tid < A + 5) {
+    const float t = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+    atomicAdd(tid < A ? &grad_logstd[tid] : &stats[tid - A], t);
+  }
+}
+
+// ---- the optimiser tail of one minibatch step on the flat fp32 buffers: GradScaler.unscale_ + clip_grad_norm_ + Adam (torch
+// semantics, no amsgrad) + GradScaler.update, three launches instead of torch's dozen.
+// work[0] = sum of squares of the UNSCALED gradient, work[1] = number of non-finite elements (caller zeroes both).
+__global__ __launch_bounds__(PPO_TB) void adam_norm_kernel(const float* __restrict__ g, int64_t n, const float* __restrict__ scale, float* __restrict__ work) {
+  __shared__ float red[2][4];
+  const float inv = scale ? 1.0f / scale[0] : 1.0f;
+  float s2 = 0.f, bad = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * PPO_TB + threadIdx.x; i < n; i += (int64_t)gridDim.x * PPO_TB) {
+    const float x = g[i] * inv;
+    if (!(fabsf(x) <= 3.4028234e38f)) bad += 1.f;  // inf or nan
+    s2 = fmaf(x, x, s2);
+  }
+  s2 = wave_sum(s2); bad = wave_sum(bad);
+  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s2; red[1][threadIdx.x >> 6] = bad; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    atomicAdd(&work[0], (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]));
+    const float b = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+    if (b > 0.f) atomicAdd(&work[1], b);
+  }
+}
+// p, m, v updated in place; skipped altogether when the scaler is on and the gradient is not finite (GradScaler.step)
+__global__ __launch_bounds__(PPO_TB) void adam_update_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                                             int64_t n, const float* __restrict__ steps, const float* __restrict__ lr, float beta1,
+                                                             float beta2, float eps, float weight_decay, float max_norm,
+                                                             const float* __restrict__ scale, const float* __restrict__ work) {
+  const int64_t i = (int64_t)blockIdx.x * PPO_TB + threadIdx.x;
+  if (i >= n) return;
+  if (scale && work[1] > 0.f) return;
+  const float inv = scale ? 1.0f / scale[0] : 1.0f;
+  float coef = 1.0f;
+  if (max_norm > 0.f) coef = fminf(max_norm / (sqrtf(work[0]) + 1e-6f), 1.0f);  // clip_grad_norm_
+  const float t = steps[0] + 1.0f;
+  const float bc1 = 1.0f - powf(beta1, t), bc2 = 1.0f - powf(beta2, t);
+  float x = g[i] * inv * coef;
+  float w = p[i];
+  if (weight_decay != 0.f) x = fmaf(weight_decay, w, x);
+  const float mi = fmaf(beta1, m[i], (1.0f - beta1) * x);
+  const float vi = fmaf(beta2, v[i], (1.0f - beta2) * x * x);
+  m[i] = mi; v[i] = vi;
+  const float denom = sqrtf(vi) / sqrtf(bc2) + eps;
+  p[i] = w - (lr[0] / bc1) * (mi / denom);
+}
+// step counters (one per parameter tensor, all equal) and the loss-scale schedule (GradScaler.update)
+__global__ void adam_commit_kernel(float* __restrict__ steps, int nsteps, float* __restrict__ scale, int32_t* __restrict__ growth_tracker,
+                                   float growth_factor, float backoff_factor, int32_t growth_interval, const float* __restrict__ work) {
+  const bool bad = scale && work[1] > 0.f;
+  if (threadIdx.x < nsteps && !bad) steps[threadIdx.x] += 1.0f;
+  if (threadIdx.x == 0 && scale) {
+    if (bad) { scale[0] *= backoff_factor; growth_tracker[0] = 0; }
+    else {
+      const int32_t t = growth_tracker[0] + 1;
+      if (t == growth_interval) { scale[0] *= growth_factor; growth_tracker[0] = 0; }
+      else growth_tracker[0] = t;
+    }
   }
 }
 
@@ -253,9 +351,63 @@ int bez_ppo_loss(const float* mu_dev, const float* logstd_dev, const float* valu
       !old_sigma_dev || !grad_mu_dev || !grad_value_dev || !grad_logstd_dev || !stats_dev || batch <= 0 || num_actions <= 0 || num_actions > 32) return -1;
   if (!(clip_value & 2)) (void)hipMemsetAsync(grad_logstd_dev, 0, (size_t)num_actions * sizeof(float), (hipStream_t)stream);  // bit 1: accumulate
   (void)hipMemsetAsync(stats_dev, 0, 5 * sizeof(float), (hipStream_t)stream);
-  hipLaunchKernelGGL(ppo_loss_kernel, dim3(nblk(batch)), dim3(PPO_TB), 0, (hipStream_t)stream, mu_dev, logstd_dev, value_dev, actions_dev, old_logp_dev, adv_dev,
-                     old_value_dev, returns_dev, old_mu_dev, old_sigma_dev, batch, (int)num_actions, e_clip, critic_coef, entropy_coef, bounds_coef,
-                     (int)(clip_value & 1), loss_scale_dev, grad_mu_dev, grad_value_dev, grad_logstd_dev, stats_dev);
+#define BEZ_PPO_LOSS(AA)                                                                                                                             \
+  hipLaunchKernelGGL(ppo_loss_kernel<AA>, dim3(nblk(batch)), dim3(PPO_TB), 0, (hipStream_t)stream, mu_dev, logstd_dev, value_dev, actions_dev, old_logp_dev,  \
+                     adv_dev, old_value_dev, returns_dev, old_mu_dev, old_sigma_dev, batch, e_clip, critic_coef, entropy_coef, bounds_coef,              \
+                     (int)(clip_value & 1), loss_scale_dev, grad_mu_dev, grad_value_dev, grad_logstd_dev, stats_dev)
+  switch (num_actions) {  // the action width is a compile-time constant of the kernel (register arrays, unrolled loops): bez has 18
+    case 1: BEZ_PPO_LOSS(1); break;
+    case 2: BEZ_PPO_LOSS(2); break;
+    case 3: BEZ_PPO_LOSS(3); break;
+    case 4: BEZ_PPO_LOSS(4); break;
+    case 5: BEZ_PPO_LOSS(5); break;
+    case 6: BEZ_PPO_LOSS(6); break;
+    case 7: BEZ_PPO_LOSS(7); break;
+    case 8: BEZ_PPO_LOSS(8); break;
+    case 9: BEZ_PPO_LOSS(9); break;
+    case 10: BEZ_PPO_LOSS(10); break;
+    case 11: BEZ_PPO_LOSS(11); break;
+    case 12: BEZ_PPO_LOSS(12); break;
+    case 13: BEZ_PPO_LOSS(13); break;
+    case 14: BEZ_PPO_LOSS(14); break;
+    case 15: BEZ_PPO_LOSS(15); break;
+    case 16: BEZ_PPO_LOSS(16); break;
+    case 17: BEZ_PPO_LOSS(17); break;
+    case 18: BEZ_PPO_LOSS(18); break;
+    case 19: BEZ_PPO_LOSS(19); break;
+    case 20: BEZ_PPO_LOSS(20); break;
+    case 21: BEZ_PPO_LOSS(21); break;
+    case 22: BEZ_PPO_LOSS(22); break;
+    case 23: BEZ_PPO_LOSS(23); break;
+    case 24: BEZ_PPO_LOSS(24); break;
+    case 25: BEZ_PPO_LOSS(25); break;
+    case 26: BEZ_PPO_LOSS(26); break;
+    case 27: BEZ_PPO_LOSS(27); break;
+    case 28: BEZ_PPO_LOSS(28); break;
+    case 29: BEZ_PPO_LOSS(29); break;
+    case 30: BEZ_PPO_LOSS(30); break;
+    case 31: BEZ_PPO_LOSS(31); break;
+    case 32: BEZ_PPO_LOSS(32); break;
+    default: return -1;
+  }
+#undef BEZ_PPO_LOSS
+  return launch_ok();
+}
+
+int bez_ppo_adam_step(float* params_dev, const float* grads_dev, float* exp_avg_dev, float* exp_avg_sq_dev, int64_t n, float* steps_dev,
+                      int32_t nsteps, const float* lr_dev, float beta1, float beta2, float eps, float weight_decay, float max_norm, float* scale_dev,
+                      int32_t* growth_tracker_dev, float growth_factor, float backoff_factor, int32_t growth_interval, float* work_dev, void* stream) {
+  if (!params_dev || !grads_dev || !exp_avg_dev || !exp_avg_sq_dev || !steps_dev || !lr_dev || !work_dev || n <= 0 || nsteps <= 0 || nsteps > 64 ||
+      (scale_dev && !growth_tracker_dev)) return -1;
+  hipStream_t st = (hipStream_t)stream;
+  (void)hipMemsetAsync(work_dev, 0, 2 * sizeof(float), st);
+  unsigned g = nblk(n);
+  if (g > 256) g = 256;
+  hipLaunchKernelGGL(adam_norm_kernel, dim3(g), dim3(PPO_TB), 0, st, grads_dev, n, (const float*)scale_dev, work_dev);
+  hipLaunchKernelGGL(adam_update_kernel, dim3(nblk(n)), dim3(PPO_TB), 0, st, params_dev, grads_dev, exp_avg_dev, exp_avg_sq_dev, n, (const float*)steps_dev,
+                     lr_dev, beta1, beta2, eps, weight_decay, max_norm, (const float*)scale_dev, (const float*)work_dev);
+  hipLaunchKernelGGL(adam_commit_kernel, dim3(1), dim3(64), 0, st, steps_dev, (int)nsteps, scale_dev, growth_tracker_dev, growth_factor, backoff_factor,
+                     growth_interval, (const float*)work_dev);
   return launch_ok();
 }
 

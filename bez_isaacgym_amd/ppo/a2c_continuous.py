@@ -306,6 +306,7 @@ class A2CAgent:
         self._flat_grad = None
         # HIP glue kernels (csrc/bez_ppo.hip) for everything around the MLP: on by default on a GPU, `fused_ops: False` keeps
         # the plain torch formulation (the one the CPU path runs and the kernels are tested against)
+        self._fused_opt = False
         self.fused = bool(on_gpu and c.get("fused_ops", True))
         if self.fused:
             from . import fused as F
@@ -316,6 +317,9 @@ class A2CAgent:
             if self.half_path:
                 self.model.a2c_network.enable_half_path(int(c.get("wgrad_splits", 64)))
             self._bind_flat_grads()
+            self._fused_opt = bool(c.get("fused_optimizer", True))
+            if self._fused_opt:
+                self._bind_flat_optimizer()
         if world > 1 and not self.fused:
             self.use_graphs = False  # the plain torch path has collectives in the middle of autograd-heavy code: eager only
         self._seg = None  # segmented graphs of the data-parallel update
@@ -494,6 +498,44 @@ class A2CAgent:
             off += p.numel()
         self._flat_kl = self._flat[n:n + 1]
 
+    def _bind_flat_optimizer(self):
+        """Parameters and Adam's moments become fixed views of three static fp32 buffers laid out like the flat gradient, so the
+        optimiser tail (unscale, clip, Adam, scaler update) is ONE pass over them (fused.adam_step) instead of torch's
+        dozen foreach launches.  `self.optimizer` stays a real torch.optim.Adam whose state tensors ARE those views: state_dict /
+        load_state_dict and the checkpoint format are unchanged."""
+        params = list(self.model.parameters())
+        n = sum(p.numel() for p in params)
+        dev = self.device
+        self._pflat = torch.empty(n, device=dev, dtype=torch.float32)
+        self._mflat = torch.zeros(n, device=dev, dtype=torch.float32)
+        self._vflat = torch.zeros(n, device=dev, dtype=torch.float32)
+        self._steps = torch.zeros(len(params), device=dev, dtype=torch.float32)
+        self._opt_work = torch.zeros(2, device=dev, dtype=torch.float32)
+        off = 0
+        with torch.no_grad():
+            for k, p in enumerate(params):
+                sl = slice(off, off + p.numel())
+                self._pflat[sl].copy_(p.data.reshape(-1))
+                p.data = self._pflat[sl].view_as(p)
+                self.optimizer.state[p] = {"step": self._steps[k], "exp_avg": self._mflat[sl].view_as(p), "exp_avg_sq": self._vflat[sl].view_as(p)}
+                off += p.numel()
+        if self.scaler.is_enabled() and self.scaler._scale is None:
+            self.scaler._lazy_init_scale_growth_tracker(dev)
+
+    def _rebind_optimizer_state(self):
+        """After Optimizer.load_state_dict (which installs fresh tensors): copy the loaded moments / step counts into the flat
+        buffers and make the state entries views of them again."""
+        off = 0
+        with torch.no_grad():
+            for k, p in enumerate(self.model.parameters()):
+                sl = slice(off, off + p.numel())
+                st = self.optimizer.state.get(p)
+                if st:
+                    self._mflat[sl].copy_(st["exp_avg"].reshape(-1)); self._vflat[sl].copy_(st["exp_avg_sq"].reshape(-1))
+                    self._steps[k].copy_(torch.as_tensor(st["step"], dtype=torch.float32))
+                self.optimizer.state[p] = {"step": self._steps[k], "exp_avg": self._mflat[sl].view_as(p), "exp_avg_sq": self._vflat[sl].view_as(p)}
+                off += p.numel()
+
     def _allreduce_grads(self):
         """ONE fused all-reduce of the flat fp32 gradient (124 237 elements = 497 KB) per optimiser step: the message
         is latency-bound on xGMI, so bucketing per parameter would only multiply the latency."""
@@ -543,11 +585,19 @@ class A2CAgent:
     def _phase_c(self, kl_out, loss_out):
         if _dist_on():
             self._flat.div_(dist.get_world_size())  # mean of the (still scaled) gradients and of the KL
-        if self.truncate_grads:
-            self.scaler.unscale_(self.optimizer)
-            nn.utils.clip_grad_norm_(self.model.parameters(), self.grad_norm)
-        self.scaler.step(self.optimizer)
-        self.scaler.update()
+        if self._fused_opt:
+            g0 = self.optimizer.param_groups[0]
+            amp = self.scaler.is_enabled()
+            self._F.adam_step(self._pflat, self._flat[:-1], self._mflat, self._vflat, self._steps, self.lr_t, g0["betas"], g0["eps"],
+                              g0["weight_decay"], self.grad_norm if self.truncate_grads else 0.0, self.scaler._scale if amp else None,
+                              self.scaler._growth_tracker if amp else None, self.scaler.get_growth_factor(), self.scaler.get_backoff_factor(),
+                              self.scaler.get_growth_interval(), self._opt_work)
+        else:
+            if self.truncate_grads:
+                self.scaler.unscale_(self.optimizer)
+                nn.utils.clip_grad_norm_(self.model.parameters(), self.grad_norm)
+            self.scaler.step(self.optimizer)
+            self.scaler.update()
         with torch.no_grad():
             inv_b = 1.0 / float(self.minibatch_size)
             kl_out.add_(self._flat_kl[0] / self.num_minibatches)
@@ -758,6 +808,8 @@ class A2CAgent:
                 for g in self.optimizer.param_groups:
                     g["lr"] = self.lr_t
             self.last_lr = lr
+            if getattr(self, "_fused_opt", False):
+                self._rebind_optimizer_state()
         self.epoch_num = int(state.get("epoch", 0))
         self.frame = int(state.get("frame", 0))
         self.last_mean_rewards = float(state.get("last_mean_rewards", -100500.0))

@@ -79,11 +79,11 @@ def _torch_loss(mu, logstd, value, mb, e, critic_coef, entropy_coef, bounds_coef
     return loss, a_loss.mean(), c_loss.mean(), b_loss.mean(), kl, entropy.mean()
 
 
+@pytest.mark.parametrize("b,a", [(32768, 18), (1000, 7)])  # config 3's minibatch; a ragged batch (partial workgroup) of another action width
 @pytest.mark.parametrize("clip_value,entropy_coef", [(True, 0.0), (False, 0.01)])
-def test_loss_kernel_value_and_gradient(clip_value, entropy_coef):
+def test_loss_kernel_value_and_gradient(clip_value, entropy_coef, b, a):
     from bez_isaacgym_amd.ppo import fused as F
     torch.manual_seed(2)
-    b, a = 32768, 18
     mu = (torch.randn(b, a, device=DEV) * 0.8).requires_grad_()
     logstd = (torch.randn(a, device=DEV) * 0.3 - 1.0).requires_grad_()
     value = torch.randn(b, 1, device=DEV).requires_grad_()
@@ -106,6 +106,46 @@ def test_loss_kernel_value_and_gradient(clip_value, entropy_coef):
     np.testing.assert_allclose(gmu.cpu(), mu.grad.cpu(), atol=2e-5 * scale, rtol=1e-4)
     np.testing.assert_allclose(gval.cpu(), value.grad.cpu(), atol=2e-5 * float(value.grad.abs().max()), rtol=1e-4)
     np.testing.assert_allclose(glog.cpu(), logstd.grad.cpu(), rtol=2e-3, atol=2e-4 * float(logstd.grad.abs().max()))
+
+
+def test_adam_step_kernel_matches_torch_amp_clip_adam():
+    """unscale + clip_grad_norm_ + Adam + GradScaler.update in one call vs the torch objects it replaces, over 7 steps: clean
+    steps, a step whose gradient holds an inf (skipped by both, scale backed off), and a growth of the scale (interval 3)."""
+    from bez_isaacgym_amd.ppo import fused as F
+    torch.manual_seed(5)
+    shapes = [(400, 54), (400,), (200, 400), (200,), (18,)]
+    n = sum(int(np.prod(sh)) for sh in shapes)
+    ref = [torch.nn.Parameter(torch.randn(sh, device=DEV) * 0.1) for sh in shapes]
+    lr = torch.tensor(3e-4, device=DEV)
+    opt = torch.optim.Adam(ref, lr=lr, eps=1e-8, capturable=True, fused=True)
+    scaler = torch.amp.GradScaler("cuda", init_scale=1024.0, growth_interval=3)
+    scaler._lazy_init_scale_growth_tracker(torch.device(DEV))  # what scaler.scale(loss) would do
+    pflat = torch.cat([p.detach().reshape(-1) for p in ref]).clone()
+    mflat, vflat = torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    steps, work = torch.zeros(len(shapes), device=DEV), torch.zeros(2, device=DEV)
+    scale, tracker = torch.tensor([1024.0], device=DEV), torch.zeros(1, device=DEV, dtype=torch.int32)
+    seen = []
+    for it in range(7):
+        g = [torch.randn(sh, device=DEV) * (3.0 if it % 2 else 0.02) for sh in shapes]  # norms above and below the clip threshold
+        if it == 4:
+            g[2][3, 7] = float("inf")
+        s_ref = scaler.get_scale()
+        for p, gi in zip(ref, g):
+            p.grad = gi * s_ref
+        gflat = torch.cat([(gi * float(scale)).reshape(-1) for gi in g]).contiguous()
+        scaler.unscale_(opt)
+        torch.nn.utils.clip_grad_norm_(ref, 1.0)
+        scaler.step(opt)
+        scaler.update()
+        F.adam_step(pflat, gflat, mflat, vflat, steps, lr, (0.9, 0.999), 1e-8, 0.0, 1.0, scale, tracker, 2.0, 0.5, 3, work)
+        assert float(scale) == scaler.get_scale(), (it, float(scale), scaler.get_scale())
+        seen.append(float(scale))
+        want = torch.cat([p.detach().reshape(-1) for p in ref])
+        np.testing.assert_allclose(pflat.cpu(), want.cpu(), rtol=0, atol=3e-7, err_msg="step %d" % it)
+        assert float(steps[0]) == float(opt.state[ref[0]]["step"]) and bool((steps == steps[0]).all())
+    assert seen == [1024.0, 1024.0, 2048.0, 2048.0, 1024.0, 1024.0, 1024.0]  # grown after 3 clean steps, backed off by the inf step
+    want_m = torch.cat([opt.state[p]["exp_avg"].reshape(-1) for p in ref])
+    np.testing.assert_allclose(mflat.cpu(), want_m.cpu(), rtol=1e-5, atol=1e-8)
 
 
 def test_fused_and_plain_optimiser_step_agree():
