@@ -4,6 +4,7 @@
 // update, normalise + clamp), the whole PPO loss with its analytic gradient, action sampling and the rollout bookkeeping.
 // Semantics restate rl_games' a2c_continuous (bez_isaacgym_amd/ppo/a2c_continuous.py is the readable reference, and the
 // tests compare these kernels with it term by term).
+#include <hip/hip_fp16.h>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -242,6 +243,69 @@ __global__ __launch_bounds__(PPO_TB) void ppo_loss_kernel(const float* __restric
   }
 }
 
+// ---- gradient reductions of the explicit-fp16 linear layers (a2c_continuous.py _HalfLinearFn), written straight into the fp32
+// master gradient: (1) the sum over the S split-K partial products of dW = dY^T X (fp16, [S][n]), (2) the bias gradient = column
+// sums of dY (fp16, [B][D]).  Replaces torch's .float() copy + sum(0) + AccumulateGrad add per tensor.
+// 256 threads = 64 element pairs x 4 split lanes: each thread sums every 4th partial of its half2 (independent loads, unrolled),
+// the four split lanes meet in LDS (odd n: scalar loads).
+__global__ __launch_bounds__(PPO_TB) void wgrad_sum_kernel(const __half* __restrict__ part, int S, int64_t n, float* __restrict__ out, int accumulate) {
+  __shared__ float2 sh[4][64];
+  const int l = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  const int64_t i = ((int64_t)blockIdx.x * 64 + l) * 2;
+  float2 a = make_float2(0.f, 0.f);
+  if ((n & 1) == 0) {  // every partial starts 4-byte aligned: half2 loads
+    if (i < n) {
+#pragma unroll 8
+      for (int s = sl; s < S; s += 4) {
+        const float2 v = __half22float2(*reinterpret_cast<const __half2*>(part + (int64_t)s * n + i));
+        a.x += v.x; a.y += v.y;
+      }
+    }
+  } else {
+    for (int s = sl; s < S; s += 4) {
+      if (i < n) a.x += __half2float(part[(int64_t)s * n + i]);
+      if (i + 1 < n) a.y += __half2float(part[(int64_t)s * n + i + 1]);
+    }
+  }
+  sh[sl][l] = a;
+  __syncthreads();
+  if (sl == 0 && i < n) {
+    float2 t = make_float2((sh[0][l].x + sh[1][l].x) + (sh[2][l].x + sh[3][l].x), (sh[0][l].y + sh[1][l].y) + (sh[2][l].y + sh[3][l].y));
+    if (accumulate) { t.x += out[i]; if (i + 1 < n) t.y += out[i + 1]; }
+    out[i] = t.x;
+    if (i + 1 < n) out[i + 1] = t.y;
+  }
+}
+// grid (column tiles of 128, row slabs); 256 threads = 4 row lanes x 64 column pairs (half2 loads, 8 rows in flight per thread);
+// partial column sums meet in `out` by atomics (one per column per slab).  D must be even for the half2 path (odd D: scalar).
+__global__ __launch_bounds__(PPO_TB) void colsum_half_kernel(const __half* __restrict__ y, int64_t B, int D, int64_t rows_per_block, float* __restrict__ out) {
+  __shared__ float2 sh[4][64];
+  const int l = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int c = (blockIdx.x * 64 + l) * 2;
+  const int64_t r0 = (int64_t)blockIdx.y * rows_per_block, r1 = (r0 + rows_per_block < B) ? r0 + rows_per_block : B;
+  float2 a = make_float2(0.f, 0.f);
+  if ((D & 1) == 0) {
+    if (c < D) {
+#pragma unroll 8
+      for (int64_t r = r0 + rl; r < r1; r += 4) {
+        const float2 v = __half22float2(*reinterpret_cast<const __half2*>(y + r * D + c));
+        a.x += v.x; a.y += v.y;
+      }
+    }
+  } else {
+    for (int64_t r = r0 + rl; r < r1; r += 4) {
+      if (c < D) a.x += __half2float(y[r * D + c]);
+      if (c + 1 < D) a.y += __half2float(y[r * D + c + 1]);
+    }
+  }
+  sh[rl][l] = a;
+  __syncthreads();
+  if (rl == 0 && c < D) {
+    atomicAdd(&out[c], (sh[0][l].x + sh[1][l].x) + (sh[2][l].x + sh[3][l].x));
+    if (c + 1 < D) atomicAdd(&out[c + 1], (sh[0][l].y + sh[1][l].y) + (sh[2][l].y + sh[3][l].y));
+  }
+}
+
 // ---- the optimiser tail of one minibatch step on the flat fp32 buffers: GradScaler.unscale_ + clip_grad_norm_ + Adam (torch
 // semantics, no amsgrad) + GradScaler.update, three launches instead of torch's dozen.
 // work[0] = sum of squares of the UNSCALED gradient, work[1] = number of non-finite elements (caller zeroes both).
@@ -391,6 +455,22 @@ int bez_ppo_loss(const float* mu_dev, const float* logstd_dev, const float* valu
     default: return -1;
   }
 #undef BEZ_PPO_LOSS
+  return launch_ok();
+}
+
+int bez_ppo_wgrad_sum(const void* partials_f16_dev, int32_t splits, int64_t n, float* out_dev, int32_t accumulate, void* stream) {
+  if (!partials_f16_dev || !out_dev || splits <= 0 || n <= 0) return -1;
+  hipLaunchKernelGGL(wgrad_sum_kernel, dim3((unsigned)((n + 127) / 128)), dim3(PPO_TB), 0, (hipStream_t)stream, (const __half*)partials_f16_dev,
+                     (int)splits, n, out_dev, (int)accumulate);
+  return launch_ok();
+}
+
+int bez_ppo_colsum_f16(const void* y_f16_dev, int64_t rows, int32_t cols, float* out_dev, int32_t accumulate, void* stream) {
+  if (!y_f16_dev || !out_dev || rows <= 0 || cols <= 0) return -1;
+  if (!accumulate) (void)hipMemsetAsync(out_dev, 0, (size_t)cols * sizeof(float), (hipStream_t)stream);
+  const int64_t rpb = 256;
+  hipLaunchKernelGGL(colsum_half_kernel, dim3((unsigned)((cols + 127) / 128), (unsigned)((rows + rpb - 1) / rpb)), dim3(PPO_TB), 0, (hipStream_t)stream,
+                     (const __half*)y_f16_dev, rows, (int)cols, rpb, out_dev);
   return launch_ok();
 }
 

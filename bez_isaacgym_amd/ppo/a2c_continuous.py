@@ -84,6 +84,7 @@ class _HalfLinearFn(torch.autograd.Function):
     def forward(ctx, x, w32, b32, w16, b16, splits):
         ctx.save_for_backward(x, w16)
         ctx.splits = splits
+        ctx.master = (w32, b32)
         return torch.addmm(b16, x, w16.t())
 
     @staticmethod
@@ -92,7 +93,17 @@ class _HalfLinearFn(torch.autograd.Function):
         gy = gy.contiguous()
         gx = gy @ w16 if ctx.needs_input_grad[0] else None
         k, s = x.shape[0], ctx.splits
-        if s > 1 and k % s == 0 and k // s >= 64:
+        split = s > 1 and k % s == 0 and k // s >= 64
+        w32, b32 = ctx.master
+        if split and gy.is_cuda and w32.grad is not None and b32.grad is not None and w32.grad.is_contiguous() and b32.grad.is_contiguous():
+            # the agent's static flat gradient: reduce straight into the master .grad views (HIP kernels, csrc/bez_ppo.hip) and hand
+            # autograd nothing to accumulate -- no fp32 copies of dY / of the partial products, no sum(0), no AccumulateGrad add
+            from . import fused as F
+            part = torch.bmm(gy.view(s, k // s, -1).transpose(1, 2), x.view(s, k // s, -1))
+            F.wgrad_sum(part, w32.grad, accumulate=True)
+            F.colsum_f16(gy, b32.grad, accumulate=True)
+            return gx, None, None, None, None, None
+        if split:
             gw = torch.bmm(gy.view(s, k // s, -1).transpose(1, 2), x.view(s, k // s, -1)).float().sum(0)
         else:
             gw = (gy.t() @ x).float()

@@ -16,6 +16,8 @@ _SIGS = {
     "bez_ppo_sample": [_vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp],
     "bez_ppo_rollout_post": [_vp, _vp, _vp, _vp, _i64, _f, _f, _i32, _vp, _vp, _vp, _vp, _vp, _vp],
     "bez_ppo_loss": [_vp] * 10 + [_i64, _i32, _f, _f, _f, _f, _i32] + [_vp] * 6,
+    "bez_ppo_wgrad_sum": [_vp, _i32, _i64, _vp, _i32, _vp],
+    "bez_ppo_colsum_f16": [_vp, _i64, _i32, _vp, _i32, _vp],
     "bez_ppo_adam_step": [_vp, _vp, _vp, _vp, _i64, _vp, _i32, _vp, _f, _f, _f, _f, _f, _vp, _vp, _f, _f, _i32, _vp, _vp],
 }
 _lib = None
@@ -110,3 +112,17 @@ def adam_step(params, grads, exp_avg, exp_avg_sq, steps, lr, betas, eps, weight_
                                  float(betas[1]), float(eps), float(weight_decay), float(max_norm), None if scale is None else _p(scale),
                                  None if growth_tracker is None else _p(growth_tracker, torch.int32), float(growth_factor), float(backoff_factor),
                                  int(growth_interval), _p(work), _stream(params)), "bez_ppo_adam_step")
+
+
+def wgrad_sum(partials, out, accumulate=False):
+    """out (fp32, any shape with n elements) <- (+=) sum over dim 0 of partials (fp16, [S, ...n elements])."""
+    s_, n = partials.shape[0], out.numel()
+    assert partials.numel() == s_ * n and out.is_contiguous()
+    _chk(lib().bez_ppo_wgrad_sum(_p(partials, torch.float16), s_, n, _p(out), 1 if accumulate else 0, _stream(out)), "bez_ppo_wgrad_sum")
+
+
+def colsum_f16(y, out, accumulate=False):
+    """out (fp32, D) <- (+=) column sums of y (fp16, (B, D))."""
+    b, d = y.shape
+    assert out.numel() == d and out.is_contiguous()
+    _chk(lib().bez_ppo_colsum_f16(_p(y, torch.float16), b, d, _p(out), 1 if accumulate else 0, _stream(out)), "bez_ppo_colsum_f16")

@@ -240,6 +240,11 @@ int bez_ppo_loss(const float* mu_dev, const float* logstd_dev, const float* valu
                  float bounds_coef, int32_t clip_value, const float* loss_scale_dev, float* grad_mu_dev, float* grad_value_dev,
                  float* grad_logstd_dev, float* stats_dev, void* stream);
 
+/* Gradient reductions of explicit-fp16 linear layers into the fp32 master gradient: the sum over `splits` split-K partial
+ * products ([splits][n] fp16) and the bias gradient = column sums of dY ((rows, cols) fp16).  accumulate != 0 adds to out_dev. */
+int bez_ppo_wgrad_sum(const void* partials_f16_dev, int32_t splits, int64_t n, float* out_dev, int32_t accumulate, void* stream);
+int bez_ppo_colsum_f16(const void* y_f16_dev, int64_t rows, int32_t cols, float* out_dev, int32_t accumulate, void* stream);
+
 /* The optimiser tail of one minibatch step on flat fp32 buffers of n elements (replaces rl_games' scaler.unscale_ +
  * clip_grad_norm_ + scaler.step(Adam) + scaler.update, a2c_common.py [ext] via train.py:89-113): the gradient is divided by
  * *scale_dev (NULL = no loss scaling), clipped to max_norm (<= 0: no clipping), applied with torch's Adam formula; a non-finite

@@ -108,6 +108,30 @@ def test_loss_kernel_value_and_gradient(clip_value, entropy_coef, b, a):
     np.testing.assert_allclose(glog.cpu(), logstd.grad.cpu(), rtol=2e-3, atol=2e-4 * float(logstd.grad.abs().max()))
 
 
+def test_half_linear_gradient_reductions():
+    """split-K partial sums and bias column sums of the fp16 linear layers, reduced straight into an fp32 gradient."""
+    from bez_isaacgym_amd.ppo import fused as F
+    torch.manual_seed(9)
+    part = torch.randn(64, 200, 400, device=DEV).half()
+    out = torch.randn(200, 400, device=DEV)
+    want = out + part.float().sum(0)
+    F.wgrad_sum(part, out, accumulate=True)
+    np.testing.assert_allclose(out.cpu(), want.cpu(), rtol=1e-5, atol=1e-4)
+    F.wgrad_sum(part, out, accumulate=False)
+    np.testing.assert_allclose(out.cpu(), part.float().sum(0).cpu(), rtol=1e-5, atol=1e-4)
+    part = torch.randn(16, 7, 9, device=DEV).half()  # odd element count: scalar loads
+    out = torch.zeros(7, 9, device=DEV)
+    F.wgrad_sum(part, out)
+    np.testing.assert_allclose(out.cpu(), part.float().sum(0).cpu(), rtol=1e-5, atol=1e-4)
+    for b, d in ((32768, 400), (1000, 19), (513, 100), (32768, 1)):
+        y = torch.randn(b, d, device=DEV).half()
+        o = torch.ones(d, device=DEV)
+        F.colsum_f16(y, o, accumulate=True)
+        np.testing.assert_allclose(o.cpu(), (1.0 + y.float().sum(0)).cpu(), rtol=1e-4, atol=2e-2)
+        F.colsum_f16(y, o, accumulate=False)
+        np.testing.assert_allclose(o.cpu(), y.float().sum(0).cpu(), rtol=1e-4, atol=2e-2)
+
+
 def test_adam_step_kernel_matches_torch_amp_clip_adam():
     """unscale + clip_grad_norm_ + Adam + GradScaler.update in one call vs the torch objects it replaces, over 7 steps: clean
     steps, a step whose gradient holds an inf (skipped by both, scale backed off), and a growth of the scale (interval 3)."""
