@@ -331,7 +331,7 @@ __global__ __launch_bounds__(PPO_TB) void adam_norm_kernel(const float* __restri
 __global__ __launch_bounds__(PPO_TB) void adam_update_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                                                              int64_t n, const float* __restrict__ steps, const float* __restrict__ lr, float beta1,
                                                              float beta2, float eps, float weight_decay, float max_norm,
-                                                             const float* __restrict__ scale, const float* __restrict__ work) {
+                                                             const float* __restrict__ scale, const float* __restrict__ work, __half* __restrict__ p16) {
   const int64_t i = (int64_t)blockIdx.x * PPO_TB + threadIdx.x;
   if (i >= n) return;
   if (scale && work[1] > 0.f) return;
@@ -347,7 +347,9 @@ __global__ __launch_bounds__(PPO_TB) void adam_update_kernel(float* __restrict__
   const float vi = fmaf(beta2, v[i], (1.0f - beta2) * x * x);
   m[i] = mi; v[i] = vi;
   const float denom = sqrtf(vi) / sqrtf(bc2) + eps;
-  p[i] = w - (lr[0] / bc1) * (mi / denom);
+  w -= (lr[0] / bc1) * (mi / denom);
+  p[i] = w;
+  if (p16) p16[i] = __float2half(w);  // the fp16 working copy of the master weights, refreshed in the same pass
 }
 // step counters (one per parameter tensor, all equal) and the loss-scale schedule (GradScaler.update)
 __global__ void adam_commit_kernel(float* __restrict__ steps, int nsteps, float* __restrict__ scale, int32_t* __restrict__ growth_tracker,
@@ -476,7 +478,8 @@ int bez_ppo_colsum_f16(const void* y_f16_dev, int64_t rows, int32_t cols, float*
 
 int bez_ppo_adam_step(float* params_dev, const float* grads_dev, float* exp_avg_dev, float* exp_avg_sq_dev, int64_t n, float* steps_dev,
                       int32_t nsteps, const float* lr_dev, float beta1, float beta2, float eps, float weight_decay, float max_norm, float* scale_dev,
-                      int32_t* growth_tracker_dev, float growth_factor, float backoff_factor, int32_t growth_interval, float* work_dev, void* stream) {
+                      int32_t* growth_tracker_dev, float growth_factor, float backoff_factor, int32_t growth_interval, float* work_dev,
+                      void* params_f16_dev, void* stream) {
   if (!params_dev || !grads_dev || !exp_avg_dev || !exp_avg_sq_dev || !steps_dev || !lr_dev || !work_dev || n <= 0 || nsteps <= 0 || nsteps > 64 ||
       (scale_dev && !growth_tracker_dev)) return -1;
   hipStream_t st = (hipStream_t)stream;
@@ -485,7 +488,7 @@ int bez_ppo_adam_step(float* params_dev, const float* grads_dev, float* exp_avg_
   if (g > 256) g = 256;
   hipLaunchKernelGGL(adam_norm_kernel, dim3(g), dim3(PPO_TB), 0, st, grads_dev, n, (const float*)scale_dev, work_dev);
   hipLaunchKernelGGL(adam_update_kernel, dim3(nblk(n)), dim3(PPO_TB), 0, st, params_dev, grads_dev, exp_avg_dev, exp_avg_sq_dev, n, (const float*)steps_dev,
-                     lr_dev, beta1, beta2, eps, weight_decay, max_norm, (const float*)scale_dev, (const float*)work_dev);
+                     lr_dev, beta1, beta2, eps, weight_decay, max_norm, (const float*)scale_dev, (const float*)work_dev, (__half*)params_f16_dev);
   hipLaunchKernelGGL(adam_commit_kernel, dim3(1), dim3(64), 0, st, steps_dev, (int)nsteps, scale_dev, growth_tracker_dev, growth_factor, backoff_factor,
                      growth_interval, (const float*)work_dev);
   return launch_ok();

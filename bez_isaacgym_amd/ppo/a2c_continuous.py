@@ -532,6 +532,21 @@ class A2CAgent:
                 off += p.numel()
         if self.scaler.is_enabled() and self.scaler._scale is None:
             self.scaler._lazy_init_scale_growth_tracker(dev)
+        # the fp16 working copies of the half path become views of one flat fp16 buffer with the same layout: the Adam kernel
+        # writes them in the pass that updates the masters (no per-step multi-tensor cast)
+        self._hflat = None
+        net = self.model.a2c_network
+        if getattr(self, "half_path", False) and getattr(net, "_p16", None) is not None:
+            self._hflat = torch.empty(n, device=dev, dtype=torch.float16)
+            offs, off = {}, 0
+            for p in params:
+                offs[id(p)] = off
+                off += p.numel()
+            with torch.no_grad():
+                for j, p32 in enumerate(net._p32):
+                    o = offs[id(p32)]
+                    net._p16[j] = self._hflat[o:o + p32.numel()].view_as(p32)
+            net.refresh_half()
 
     def _rebind_optimizer_state(self):
         """After Optimizer.load_state_dict (which installs fresh tensors): copy the loaded moments / step counts into the flat
@@ -577,8 +592,8 @@ class A2CAgent:
         if self.normalize_input:
             self._f_obs_rms.apply()
             obs = self._f_obs_rms.normalize(obs, fx["mb_obs_n"])
-        if self.half_path:
-            net.refresh_half()
+        if self.half_path and getattr(self, "_hflat", None) is None:
+            net.refresh_half()  # (with the fused optimiser the Adam kernel keeps the fp16 copies current)
         with torch.autocast("cuda", dtype=torch.float16, enabled=self.mixed_precision and not self.half_path):
             mu, _logstd, value = net(obs)
         mu32, v32 = mu.float().contiguous(), value.float().contiguous()
@@ -602,7 +617,7 @@ class A2CAgent:
             self._F.adam_step(self._pflat, self._flat[:-1], self._mflat, self._vflat, self._steps, self.lr_t, g0["betas"], g0["eps"],
                               g0["weight_decay"], self.grad_norm if self.truncate_grads else 0.0, self.scaler._scale if amp else None,
                               self.scaler._growth_tracker if amp else None, self.scaler.get_growth_factor(), self.scaler.get_backoff_factor(),
-                              self.scaler.get_growth_interval(), self._opt_work)
+                              self.scaler.get_growth_interval(), self._opt_work, self._hflat)
         else:
             if self.truncate_grads:
                 self.scaler.unscale_(self.optimizer)

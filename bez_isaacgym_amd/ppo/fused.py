@@ -18,7 +18,7 @@ _SIGS = {
     "bez_ppo_loss": [_vp] * 10 + [_i64, _i32, _f, _f, _f, _f, _i32] + [_vp] * 6,
     "bez_ppo_wgrad_sum": [_vp, _i32, _i64, _vp, _i32, _vp],
     "bez_ppo_colsum_f16": [_vp, _i64, _i32, _vp, _i32, _vp],
-    "bez_ppo_adam_step": [_vp, _vp, _vp, _vp, _i64, _vp, _i32, _vp, _f, _f, _f, _f, _f, _vp, _vp, _f, _f, _i32, _vp, _vp],
+    "bez_ppo_adam_step": [_vp, _vp, _vp, _vp, _i64, _vp, _i32, _vp, _f, _f, _f, _f, _f, _vp, _vp, _f, _f, _i32, _vp, _vp, _vp],
 }
 _lib = None
 
@@ -105,13 +105,15 @@ def loss(mu, logstd, value, mb, e_clip, critic_coef, entropy_coef, bounds_coef, 
 
 
 def adam_step(params, grads, exp_avg, exp_avg_sq, steps, lr, betas, eps, weight_decay, max_norm, scale, growth_tracker, growth_factor,
-              backoff_factor, growth_interval, work):
-    """unscale + clip + Adam + scaler update on the flat buffers (csrc/bez_ppo.hip adam_*_kernel); scale / growth_tracker None = no AMP."""
+              backoff_factor, growth_interval, work, params_f16=None):
+    """unscale + clip + Adam + scaler update on the flat buffers (csrc/bez_ppo.hip adam_*_kernel); scale / growth_tracker None = no AMP;
+    params_f16 (flat fp16, same layout) receives the updated parameters in the same pass."""
     n = params.numel()
     _chk(lib().bez_ppo_adam_step(_p(params), _p(grads), _p(exp_avg), _p(exp_avg_sq), n, _p(steps), steps.numel(), _p(lr), float(betas[0]),
                                  float(betas[1]), float(eps), float(weight_decay), float(max_norm), None if scale is None else _p(scale),
                                  None if growth_tracker is None else _p(growth_tracker, torch.int32), float(growth_factor), float(backoff_factor),
-                                 int(growth_interval), _p(work), _stream(params)), "bez_ppo_adam_step")
+                                 int(growth_interval), _p(work), None if params_f16 is None else _p(params_f16, torch.float16), _stream(params)),
+         "bez_ppo_adam_step")
 
 
 def wgrad_sum(partials, out, accumulate=False):

@@ -249,10 +249,12 @@ int bez_ppo_colsum_f16(const void* y_f16_dev, int64_t rows, int32_t cols, float*
  * clip_grad_norm_ + scaler.step(Adam) + scaler.update, a2c_common.py [ext] via train.py:89-113): the gradient is divided by
  * *scale_dev (NULL = no loss scaling), clipped to max_norm (<= 0: no clipping), applied with torch's Adam formula; a non-finite
  * gradient skips the step and backs the scale off, growth_interval clean steps grow it.  steps_dev[nsteps] are the per-tensor
- * step counters of the optimiser state (all equal).  work_dev[2]: squared norm of the unscaled gradient / non-finite count. */
+ * step counters of the optimiser state (all equal).  work_dev[2]: squared norm of the unscaled gradient / non-finite count.
+ * params_f16_dev (NULL or n fp16): receives the updated parameters as fp16 in the same pass (the AMP working copy). */
 int bez_ppo_adam_step(float* params_dev, const float* grads_dev, float* exp_avg_dev, float* exp_avg_sq_dev, int64_t n, float* steps_dev,
                       int32_t nsteps, const float* lr_dev, float beta1, float beta2, float eps, float weight_decay, float max_norm, float* scale_dev,
-                      int32_t* growth_tracker_dev, float growth_factor, float backoff_factor, int32_t growth_interval, float* work_dev, void* stream);
+                      int32_t* growth_tracker_dev, float growth_factor, float backoff_factor, int32_t growth_interval, float* work_dev,
+                      void* params_f16_dev, void* stream);
 
 #ifdef __cplusplus
 }

@@ -147,6 +147,7 @@ def test_adam_step_kernel_matches_torch_amp_clip_adam():
     pflat = torch.cat([p.detach().reshape(-1) for p in ref]).clone()
     mflat, vflat = torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
     steps, work = torch.zeros(len(shapes), device=DEV), torch.zeros(2, device=DEV)
+    hflat = torch.zeros(n, device=DEV, dtype=torch.float16)
     scale, tracker = torch.tensor([1024.0], device=DEV), torch.zeros(1, device=DEV, dtype=torch.int32)
     seen = []
     for it in range(7):
@@ -161,7 +162,9 @@ def test_adam_step_kernel_matches_torch_amp_clip_adam():
         torch.nn.utils.clip_grad_norm_(ref, 1.0)
         scaler.step(opt)
         scaler.update()
-        F.adam_step(pflat, gflat, mflat, vflat, steps, lr, (0.9, 0.999), 1e-8, 0.0, 1.0, scale, tracker, 2.0, 0.5, 3, work)
+        F.adam_step(pflat, gflat, mflat, vflat, steps, lr, (0.9, 0.999), 1e-8, 0.0, 1.0, scale, tracker, 2.0, 0.5, 3, work, hflat)
+        if it != 4:
+            assert torch.equal(hflat, pflat.half())  # the fp16 working copy written in the same pass
         assert float(scale) == scaler.get_scale(), (it, float(scale), scaler.get_scale())
         seen.append(float(scale))
         want = torch.cat([p.detach().reshape(-1) for p in ref])
