@@ -99,6 +99,39 @@ __global__ __launch_bounds__(PPO_TB) void ppo_sample_kernel(const float* __restr
   neglogp[i] = 0.5f * acc + 0.5f * LOG_2PI * (float)A + ls;
 }
 
+// ---- everything of one rollout step between the policy forward and the env step, in one launch: the fp32 copies of the
+// network outputs, the de-normalised value (RunningMeanStd(unnorm=True): clamp to +-5, x sqrt(var + eps) + mean), the rollout
+// buffer rows (obs, dones, mu, value), and the action sampling of ppo_sample_kernel.  IN = __half (explicit fp16 path) or float.
+template <typename IN>
+__global__ __launch_bounds__(PPO_TB) void ppo_rollout_pre_kernel(const IN* __restrict__ mu_in, const IN* __restrict__ value_in, const float* __restrict__ logstd,
+                                                                 const float* __restrict__ noise, const float* __restrict__ obs, const float* __restrict__ dones,
+                                                                 const double* __restrict__ vmean, const double* __restrict__ vvar, float veps, int64_t N, int A,
+                                                                 int D, float* __restrict__ mb_obs, float* __restrict__ mb_dones, float* __restrict__ mb_mu,
+                                                                 float* __restrict__ mb_val, float* __restrict__ act, float* __restrict__ act_env,
+                                                                 float* __restrict__ neglogp, float* __restrict__ sigma_out) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, nt = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t k = t; k < N * D; k += nt) mb_obs[k] = obs[k];  // flat coalesced copy of the observation block
+  if (t >= N) return;
+  const int64_t i = t;
+  mb_dones[i] = dones[i];
+  float v = (float)value_in[i];
+  if (vmean) v = sqrtf((float)vvar[0] + veps) * fminf(fmaxf(v, -5.0f), 5.0f) + (float)vmean[0];
+  mb_val[i] = v;
+  float acc = 0.f, ls = 0.f;
+  for (int j = 0; j < A; ++j) {
+    const float m = (float)mu_in[i * A + j];
+    mb_mu[i * A + j] = m;
+    const float l = logstd[j], sg = expf(l), z = noise[i * A + j];
+    const float a = fmaf(sg, z, m);
+    act[i * A + j] = a;
+    act_env[i * A + j] = fminf(fmaxf(a, -1.0f), 1.0f);
+    sigma_out[i * A + j] = sg;
+    const float zz = (a - m) / sg;  // as the reference computes it from the stored action
+    acc = fmaf(zz, zz, acc); ls += l;
+  }
+  neglogp[i] = 0.5f * acc + 0.5f * LOG_2PI * (float)A + ls;
+}
+
 // ---- rollout bookkeeping of one env step (a2c_continuous.py _rollout_impl): shaped reward with the time-out bootstrap, done
 // flags as floats, running episode return / length and the finished-episode statistics
 __global__ __launch_bounds__(PPO_TB) void ppo_rollout_post_kernel(const float* __restrict__ rew, const int64_t* __restrict__ dones, const int64_t* __restrict__ timeouts,
@@ -399,6 +432,26 @@ int bez_ppo_sample(const float* mu_dev, const float* logstd_dev, const float* no
   if (!mu_dev || !logstd_dev || !noise_dev || !actions_dev || !env_actions_dev || !neglogp_dev || !sigma_dev || n <= 0 || num_actions <= 0) return -1;
   hipLaunchKernelGGL(ppo_sample_kernel, dim3(nblk(n)), dim3(PPO_TB), 0, (hipStream_t)stream, mu_dev, logstd_dev, noise_dev, n, (int)num_actions, actions_dev,
                      env_actions_dev, neglogp_dev, sigma_dev);
+  return launch_ok();
+}
+int bez_ppo_rollout_pre(const void* mu_dev, const void* value_dev, int32_t inputs_f16, const float* logstd_dev, const float* noise_dev, const float* obs_dev,
+                        const float* dones_dev, const double* value_mean_dev, const double* value_var_dev, float value_eps, int64_t n, int32_t num_actions,
+                        int32_t num_obs, float* mb_obs_dev, float* mb_dones_dev, float* mb_mu_dev, float* mb_val_dev, float* actions_dev,
+                        float* env_actions_dev, float* neglogp_dev, float* sigma_dev, void* stream) {
+  if (!mu_dev || !value_dev || !logstd_dev || !noise_dev || !obs_dev || !dones_dev || !mb_obs_dev || !mb_dones_dev || !mb_mu_dev || !mb_val_dev ||
+      !actions_dev || !env_actions_dev || !neglogp_dev || !sigma_dev || n <= 0 || num_actions <= 0 || num_obs <= 0 || (value_mean_dev && !value_var_dev)) return -1;
+  int64_t work = n * num_obs;
+  unsigned g = nblk(work > n ? work : n);
+  if (g > 1024) g = 1024;
+  if (g < nblk(n)) g = nblk(n);
+  if (inputs_f16)
+    hipLaunchKernelGGL(ppo_rollout_pre_kernel<__half>, dim3(g), dim3(PPO_TB), 0, (hipStream_t)stream, (const __half*)mu_dev, (const __half*)value_dev, logstd_dev,
+                       noise_dev, obs_dev, dones_dev, value_mean_dev, value_var_dev, value_eps, n, (int)num_actions, (int)num_obs, mb_obs_dev, mb_dones_dev,
+                       mb_mu_dev, mb_val_dev, actions_dev, env_actions_dev, neglogp_dev, sigma_dev);
+  else
+    hipLaunchKernelGGL(ppo_rollout_pre_kernel<float>, dim3(g), dim3(PPO_TB), 0, (hipStream_t)stream, (const float*)mu_dev, (const float*)value_dev, logstd_dev,
+                       noise_dev, obs_dev, dones_dev, value_mean_dev, value_var_dev, value_eps, n, (int)num_actions, (int)num_obs, mb_obs_dev, mb_dones_dev,
+                       mb_mu_dev, mb_val_dev, actions_dev, env_actions_dev, neglogp_dev, sigma_dev);
   return launch_ok();
 }
 int bez_ppo_rollout_post(const float* rew_dev, const int64_t* dones_dev, const int64_t* timeouts_dev, const float* values_dev, int64_t n, float reward_scale,

@@ -397,21 +397,28 @@ class A2CAgent:
         self.model.eval()
         if self.half_path:
             net.refresh_half()
+        cur = self.obs  # step 0 reads the agent's copy; later steps read the env's own observation buffer (no per-step copy)
+        vrms = self.value_mean_std if self.normalize_value else None
         for n in range(self.horizon):
-            x = self._f_obs_rms.normalize(self.obs, fx["obs_n"]) if self.normalize_input else self.obs
+            x = self._f_obs_rms.normalize(cur, fx["obs_n"]) if self.normalize_input else cur
             with torch.autocast("cuda", dtype=torch.float16, enabled=self.mixed_precision and not self.half_path):
                 mu, _logstd, value = net(x)
-            mu32, v32 = mu.float().contiguous(), value.float()
-            if self.normalize_value:
-                self.value_mean_std.eval()
-                v32 = self.value_mean_std(v32, True)
-            mb["obs"][n].copy_(self.obs); mb["dones"][n].copy_(self.dones); mb["mu"][n].copy_(mu32); mb["val"][n].copy_(v32)
+            if mu.dtype not in (torch.float16, torch.float32):
+                mu, value = mu.float(), value.float()
             fx["noise"].normal_()
-            F.sample(mu32, net.sigma.detach(), fx["noise"], mb["act"][n], fx["env_act"], mb["neglogp"][n], mb["sigma"][n])
+            # fp32 rows of obs / dones / mu / de-normalised value + sampling + neglogp + clamp: one launch
+            F.rollout_pre(mu.contiguous(), value.contiguous(), net.sigma.detach(), fx["noise"], cur, self.dones, vrms, mb["obs"][n], mb["dones"][n],
+                          mb["mu"][n], mb["val"][n], mb["act"][n], fx["env_act"], mb["neglogp"][n], mb["sigma"][n])
             obs_dict, rew, dones, infos = self.vec_env.step(fx["env_act"])
             F.rollout_post(rew, dones, infos["time_outs"], mb["val"][n], self.reward_scale, self.gamma, self.value_bootstrap and "time_outs" in infos,
                            mb["rew"][n], self.dones, self.current_rewards, self.current_lengths, self.ep_stats)
-            self.obs.copy_(obs_dict["obs"])
+            o = obs_dict["obs"]
+            if o.dtype == torch.float32 and o.is_contiguous() and o.device == self.obs.device:
+                cur = o  # the env's persistent buffer (vec_task.py _clipped_obs): valid until the next step()
+            else:
+                self.obs.copy_(o); cur = self.obs
+        if cur is not self.obs:
+            self.obs.copy_(cur)
 
     @torch.no_grad()
     def _rollout_impl(self, steps_done=False):

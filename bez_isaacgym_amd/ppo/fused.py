@@ -16,6 +16,7 @@ _SIGS = {
     "bez_ppo_sample": [_vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp],
     "bez_ppo_rollout_post": [_vp, _vp, _vp, _vp, _i64, _f, _f, _i32, _vp, _vp, _vp, _vp, _vp, _vp],
     "bez_ppo_loss": [_vp] * 10 + [_i64, _i32, _f, _f, _f, _f, _i32] + [_vp] * 6,
+    "bez_ppo_rollout_pre": [_vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _f, _i64, _i32, _i32] + [_vp] * 9,
     "bez_ppo_wgrad_sum": [_vp, _i32, _i64, _vp, _i32, _vp],
     "bez_ppo_colsum_f16": [_vp, _i64, _i32, _vp, _i32, _vp],
     "bez_ppo_adam_step": [_vp, _vp, _vp, _vp, _i64, _vp, _i32, _vp, _f, _f, _f, _f, _f, _vp, _vp, _f, _f, _i32, _vp, _vp, _vp],
@@ -128,3 +129,15 @@ def colsum_f16(y, out, accumulate=False):
     b, d = y.shape
     assert out.numel() == d and out.is_contiguous()
     _chk(lib().bez_ppo_colsum_f16(_p(y, torch.float16), b, d, _p(out), 1 if accumulate else 0, _stream(out)), "bez_ppo_colsum_f16")
+
+
+def rollout_pre(mu, value, logstd, noise, obs, dones, value_rms, mb_obs, mb_dones, mb_mu, mb_val, act, env_act, neglogp, sigma):
+    """fp32 rows of the rollout buffers (obs, dones, mu, de-normalised value) + action sampling, one launch; mu / value fp16 or fp32."""
+    n, a = mu.shape
+    half = mu.dtype == torch.float16
+    assert value.dtype == mu.dtype and value.numel() == n and mu.is_contiguous() and value.is_contiguous()
+    vm = None if value_rms is None else _p(value_rms.running_mean, torch.float64)
+    vv = None if value_rms is None else _p(value_rms.running_var, torch.float64)
+    _chk(lib().bez_ppo_rollout_pre(C.c_void_p(mu.data_ptr()), C.c_void_p(value.data_ptr()), 1 if half else 0, _p(logstd), _p(noise), _p(obs), _p(dones), vm, vv,
+                                   0.0 if value_rms is None else float(value_rms.epsilon), n, a, obs.shape[1], _p(mb_obs), _p(mb_dones), _p(mb_mu), _p(mb_val),
+                                   _p(act), _p(env_act), _p(neglogp), _p(sigma), _stream(mu)), "bez_ppo_rollout_pre")

@@ -225,6 +225,15 @@ int bez_ppo_rms_normalize(const float* x_dev, int64_t rows, int32_t cols, const 
 /* rollout: actions = mu + exp(logstd) * noise, neglogp(actions), env_actions = clamp(actions, -1, 1), sigma broadcast */
 int bez_ppo_sample(const float* mu_dev, const float* logstd_dev, const float* noise_dev, int64_t n, int32_t num_actions,
                    float* actions_dev, float* env_actions_dev, float* neglogp_dev, float* sigma_dev, void* stream);
+/* One rollout step between the policy forward and the env step (rl_games a2c_common.play_steps [ext] via train.py:89-113):
+ * network outputs mu (n, num_actions) / value (n) as fp16 (inputs_f16 != 0) or fp32; the value is de-normalised with the running
+ * value statistics (NULL = none); rows of the rollout buffers obs / dones / mu / value are written; actions are sampled as
+ * bez_ppo_sample does. */
+int bez_ppo_rollout_pre(const void* mu_dev, const void* value_dev, int32_t inputs_f16, const float* logstd_dev, const float* noise_dev, const float* obs_dev,
+                        const float* dones_dev, const double* value_mean_dev, const double* value_var_dev, float value_eps, int64_t n, int32_t num_actions,
+                        int32_t num_obs, float* mb_obs_dev, float* mb_dones_dev, float* mb_mu_dev, float* mb_val_dev, float* actions_dev,
+                        float* env_actions_dev, float* neglogp_dev, float* sigma_dev, void* stream);
+
 /* rollout bookkeeping of one env step: shaped = rew * reward_scale (+ gamma * value * time_out, value_bootstrap),
  * dones as float, running episode return / length, ep_stats[3] += (finished, sum of returns, sum of lengths) in fp64 */
 int bez_ppo_rollout_post(const float* rew_dev, const int64_t* dones_dev, const int64_t* timeouts_dev, const float* values_dev, int64_t n,

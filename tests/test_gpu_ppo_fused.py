@@ -61,6 +61,35 @@ def test_sample_and_rollout_bookkeeping_kernels():
     np.testing.assert_allclose(stats.cpu(), torch.stack([d.sum(), ((r0 + rew) * d).sum(), ((l0 + 1) * d).sum()]).double().cpu(), rtol=1e-5)
 
 
+@pytest.mark.parametrize("half", [True, False])
+def test_rollout_pre_kernel(half):
+    """One launch = .float() of the network outputs + RunningMeanStd(unnorm) of the value + four rollout-buffer rows + sampling."""
+    from bez_isaacgym_amd.ppo import fused as F
+    from bez_isaacgym_amd.ppo.a2c_continuous import ModelA2CContinuousLogStd, RunningMeanStd
+    torch.manual_seed(4)
+    n, a, d = 1000, 18, 54
+    dt = torch.float16 if half else torch.float32
+    mu, value = (torch.randn(n, a, device=DEV) * 0.7).to(dt), (torch.randn(n, 1, device=DEV) * 4).to(dt)
+    logstd, noise = torch.randn(a, device=DEV) * 0.2 - 0.5, torch.randn(n, a, device=DEV)
+    obs, dones = torch.randn(n, d, device=DEV), (torch.rand(n, device=DEV) < 0.1).float()
+    rms = RunningMeanStd((1,)).to(DEV)
+    rms.running_mean.fill_(0.3); rms.running_var.fill_(2.5)
+    z = lambda *s: torch.full(s, -7.0, device=DEV)
+    mb_obs, mb_dones, mb_mu, mb_val, act, env_act, nlp, sig = z(n, d), z(n), z(n, a), z(n, 1), z(n, a), z(n, a), z(n), z(n, a)
+    F.rollout_pre(mu, value, logstd, noise, obs, dones, rms, mb_obs, mb_dones, mb_mu, mb_val, act, env_act, nlp, sig)
+    mu32, sigma = mu.float(), torch.exp(logstd).expand(n, a)
+    assert torch.equal(mb_obs, obs) and torch.equal(mb_dones, dones) and torch.equal(mb_mu, mu32)
+    rms.eval()
+    np.testing.assert_allclose(mb_val.cpu(), rms(value.float(), True).cpu(), rtol=1e-6, atol=1e-6)
+    want = mu32 + sigma * noise
+    np.testing.assert_allclose(act.cpu(), want.cpu(), rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(env_act.cpu(), want.clamp(-1, 1).cpu(), rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(sig.cpu(), sigma.cpu(), rtol=1e-6)
+    np.testing.assert_allclose(nlp.cpu(), ModelA2CContinuousLogStd.neglogp(act, mu32, sigma, logstd.expand(n, a)).cpu(), rtol=1e-5, atol=1e-4)
+    F.rollout_pre(mu, value, logstd, noise, obs, dones, None, mb_obs, mb_dones, mb_mu, mb_val, act, env_act, nlp, sig)
+    assert torch.equal(mb_val, value.float())
+
+
 def _torch_loss(mu, logstd, value, mb, e, critic_coef, entropy_coef, bounds_coef, clip_value):
     from bez_isaacgym_amd.ppo.a2c_continuous import ModelA2CContinuousLogStd, policy_kl
     sigma = torch.exp(logstd).unsqueeze(0).expand_as(mu)
