@@ -339,6 +339,48 @@ __global__ __launch_bounds__(PPO_TB) void colsum_half_kernel(const __half* __res
   }
 }
 
+// ELU backward + bias gradient in one pass over dY: gz = gy * (y > 0 ? 1 : y + 1)  (alpha = 1; y = the layer's ELU output), written
+// as fp16 for the following GEMMs, and its column sums accumulated into the fp32 bias gradient.  Same tiling as colsum_half_kernel.
+__global__ __launch_bounds__(PPO_TB) void elu_bwd_colsum_kernel(const __half* __restrict__ gy, const __half* __restrict__ y, __half* __restrict__ gz, int64_t B,
+                                                                int D, int64_t rows_per_block, float* __restrict__ out) {
+  __shared__ float2 sh[4][64];
+  const int l = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int c = (blockIdx.x * 64 + l) * 2;
+  const int64_t r0 = (int64_t)blockIdx.y * rows_per_block, r1 = (r0 + rows_per_block < B) ? r0 + rows_per_block : B;
+  float2 a = make_float2(0.f, 0.f);
+  if ((D & 1) == 0) {
+    if (c < D) {
+#pragma unroll 4
+      for (int64_t r = r0 + rl; r < r1; r += 4) {
+        const float2 g = __half22float2(*reinterpret_cast<const __half2*>(gy + r * D + c));
+        const float2 v = __half22float2(*reinterpret_cast<const __half2*>(y + r * D + c));
+        const __half2 z = __floats2half2_rn(g.x * (v.x > 0.f ? 1.f : v.x + 1.f), g.y * (v.y > 0.f ? 1.f : v.y + 1.f));
+        *reinterpret_cast<__half2*>(gz + r * D + c) = z;
+        const float2 zf = __half22float2(z);  // the bias gradient sums what the GEMMs will see
+        a.x += zf.x; a.y += zf.y;
+      }
+    }
+  } else {
+    for (int64_t r = r0 + rl; r < r1; r += 4) {
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        if (c + k < D) {
+          const float g = __half2float(gy[r * D + c + k]), v = __half2float(y[r * D + c + k]);
+          const __half z = __float2half(g * (v > 0.f ? 1.f : v + 1.f));
+          gz[r * D + c + k] = z;
+          (k ? a.y : a.x) += __half2float(z);
+        }
+      }
+    }
+  }
+  sh[rl][l] = a;
+  __syncthreads();
+  if (rl == 0 && c < D) {
+    atomicAdd(&out[c], (sh[0][l].x + sh[1][l].x) + (sh[2][l].x + sh[3][l].x));
+    if (c + 1 < D) atomicAdd(&out[c + 1], (sh[0][l].y + sh[1][l].y) + (sh[2][l].y + sh[3][l].y));
+  }
+}
+
 // ---- the optimiser tail of one minibatch step on the flat fp32 buffers: GradScaler.unscale_ + clip_grad_norm_ + Adam (torch
 // semantics, no amsgrad) + GradScaler.update, three launches instead of torch's dozen.
 // work[0] = sum of squares of the UNSCALED gradient, work[1] = number of non-finite elements (caller zeroes both).
@@ -526,6 +568,16 @@ int bez_ppo_colsum_f16(const void* y_f16_dev, int64_t rows, int32_t cols, float*
   const int64_t rpb = 256;
   hipLaunchKernelGGL(colsum_half_kernel, dim3((unsigned)((cols + 127) / 128), (unsigned)((rows + rpb - 1) / rpb)), dim3(PPO_TB), 0, (hipStream_t)stream,
                      (const __half*)y_f16_dev, rows, (int)cols, rpb, out_dev);
+  return launch_ok();
+}
+
+int bez_ppo_elu_bwd_colsum_f16(const void* gy_f16_dev, const void* y_f16_dev, void* gz_f16_dev, int64_t rows, int32_t cols, float* bias_grad_dev,
+                               int32_t accumulate, void* stream) {
+  if (!gy_f16_dev || !y_f16_dev || !gz_f16_dev || !bias_grad_dev || rows <= 0 || cols <= 0) return -1;
+  if (!accumulate) (void)hipMemsetAsync(bias_grad_dev, 0, (size_t)cols * sizeof(float), (hipStream_t)stream);
+  const int64_t rpb = 256;
+  hipLaunchKernelGGL(elu_bwd_colsum_kernel, dim3((unsigned)((cols + 127) / 128), (unsigned)((rows + rpb - 1) / rpb)), dim3(PPO_TB), 0, (hipStream_t)stream,
+                     (const __half*)gy_f16_dev, (const __half*)y_f16_dev, (__half*)gz_f16_dev, rows, (int)cols, rpb, bias_grad_dev);
   return launch_ok();
 }
 

@@ -110,6 +110,39 @@ class _HalfLinearFn(torch.autograd.Function):
         return gx, gw, gy.float().sum(0), None, None, None
 
 
+class _HalfLinearEluFn(torch.autograd.Function):
+    """elu(x @ W^T + b) of a hidden layer on explicit fp16 operands.  Forward = torch (GEMM with bias epilogue + ELU); backward
+    = ONE HIP pass over dY for the ELU derivative and the bias gradient (csrc/bez_ppo.hip elu_bwd_colsum_kernel), then the same
+    input-gradient GEMM and split-K weight gradient as _HalfLinearFn, reduced straight into the master .grad views."""
+
+    @staticmethod
+    def forward(ctx, x, w32, b32, w16, b16, splits):
+        y = torch.nn.functional.elu(torch.addmm(b16, x, w16.t()))
+        ctx.save_for_backward(x, w16, y)
+        ctx.splits = splits
+        ctx.master = (w32, b32)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        from . import fused as F
+        x, w16, y = ctx.saved_tensors
+        w32, b32 = ctx.master
+        gz = torch.empty_like(y)
+        F.elu_bwd_colsum_f16(gy.contiguous(), y, gz, b32.grad, accumulate=True)
+        gx = gz @ w16 if ctx.needs_input_grad[0] else None
+        k, s = x.shape[0], ctx.splits
+        part = torch.bmm(gz.view(s, k // s, -1).transpose(1, 2), x.view(s, k // s, -1))
+        F.wgrad_sum(part, w32.grad, accumulate=True)
+        return gx, None, None, None, None, None
+
+    @staticmethod
+    def usable(x, w32, b32, splits):
+        k = x.shape[0]
+        return (x.is_cuda and splits > 1 and k % splits == 0 and k // splits >= 64 and w32.grad is not None and b32.grad is not None
+                and w32.grad.is_contiguous() and b32.grad.is_contiguous() and torch.is_grad_enabled())
+
+
 class A2CNetwork(nn.Module):
     """Parameter names match rl_games' a2c_network.* so state dicts interoperate."""
 
@@ -144,7 +177,11 @@ class A2CNetwork(nn.Module):
             h = obs
             n_hidden = len(self._lin) - 2
             for i in range(n_hidden):
-                h = torch.nn.functional.elu(self._half_linear(i, h))
+                m = self._lin[i]
+                if _HalfLinearEluFn.usable(h, m.weight, m.bias, self._splits):
+                    h = _HalfLinearEluFn.apply(h, m.weight, m.bias, self._p16[2 * i], self._p16[2 * i + 1], self._splits)
+                else:
+                    h = torch.nn.functional.elu(self._half_linear(i, h))
             return self._half_linear(n_hidden, h), self.sigma.unsqueeze(0).expand(obs.shape[0], -1), self._half_linear(n_hidden + 1, h)
         h = self.actor_mlp(obs)
         return self.mu(h), self.sigma.unsqueeze(0).expand(obs.shape[0], -1), self.value(h)

@@ -19,6 +19,7 @@ _SIGS = {
     "bez_ppo_rollout_pre": [_vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _f, _i64, _i32, _i32] + [_vp] * 9,
     "bez_ppo_wgrad_sum": [_vp, _i32, _i64, _vp, _i32, _vp],
     "bez_ppo_colsum_f16": [_vp, _i64, _i32, _vp, _i32, _vp],
+    "bez_ppo_elu_bwd_colsum_f16": [_vp, _vp, _vp, _i64, _i32, _vp, _i32, _vp],
     "bez_ppo_adam_step": [_vp, _vp, _vp, _vp, _i64, _vp, _i32, _vp, _f, _f, _f, _f, _f, _vp, _vp, _f, _f, _i32, _vp, _vp, _vp],
 }
 _lib = None
@@ -141,3 +142,11 @@ def rollout_pre(mu, value, logstd, noise, obs, dones, value_rms, mb_obs, mb_done
     _chk(lib().bez_ppo_rollout_pre(C.c_void_p(mu.data_ptr()), C.c_void_p(value.data_ptr()), 1 if half else 0, _p(logstd), _p(noise), _p(obs), _p(dones), vm, vv,
                                    0.0 if value_rms is None else float(value_rms.epsilon), n, a, obs.shape[1], _p(mb_obs), _p(mb_dones), _p(mb_mu), _p(mb_val),
                                    _p(act), _p(env_act), _p(neglogp), _p(sigma), _stream(mu)), "bez_ppo_rollout_pre")
+
+
+def elu_bwd_colsum_f16(gy, y, gz, bias_grad, accumulate=False):
+    """gz (fp16) <- gy * elu'(y) (y = the ELU output); bias_grad (fp32, D) <- (+=) column sums of gz."""
+    b, d = y.shape
+    assert gy.shape == y.shape == gz.shape and gy.is_contiguous() and y.is_contiguous() and gz.is_contiguous() and bias_grad.numel() == d
+    _chk(lib().bez_ppo_elu_bwd_colsum_f16(_p(gy, torch.float16), _p(y, torch.float16), _p(gz, torch.float16), b, d, _p(bias_grad), 1 if accumulate else 0,
+                                          _stream(y)), "bez_ppo_elu_bwd_colsum_f16")

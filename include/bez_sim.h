@@ -253,6 +253,10 @@ int bez_ppo_loss(const float* mu_dev, const float* logstd_dev, const float* valu
  * products ([splits][n] fp16) and the bias gradient = column sums of dY ((rows, cols) fp16).  accumulate != 0 adds to out_dev. */
 int bez_ppo_wgrad_sum(const void* partials_f16_dev, int32_t splits, int64_t n, float* out_dev, int32_t accumulate, void* stream);
 int bez_ppo_colsum_f16(const void* y_f16_dev, int64_t rows, int32_t cols, float* out_dev, int32_t accumulate, void* stream);
+/* ELU (alpha 1) backward fused with the bias gradient: gz = gy * elu'(y) from the layer's ELU OUTPUT y, all (rows, cols) fp16;
+ * the column sums of gz go to bias_grad_dev (fp32, cols). */
+int bez_ppo_elu_bwd_colsum_f16(const void* gy_f16_dev, const void* y_f16_dev, void* gz_f16_dev, int64_t rows, int32_t cols, float* bias_grad_dev,
+                               int32_t accumulate, void* stream);
 
 /* The optimiser tail of one minibatch step on flat fp32 buffers of n elements (replaces rl_games' scaler.unscale_ +
  * clip_grad_norm_ + scaler.step(Adam) + scaler.update, a2c_common.py [ext] via train.py:89-113): the gradient is divided by

@@ -161,6 +161,20 @@ def test_half_linear_gradient_reductions():
         np.testing.assert_allclose(o.cpu(), y.float().sum(0).cpu(), rtol=1e-4, atol=2e-2)
 
 
+def test_elu_backward_fused_with_bias_gradient():
+    from bez_isaacgym_amd.ppo import fused as F
+    torch.manual_seed(11)
+    for b, d in ((32768, 400), (777, 101)):
+        pre = (torch.randn(b, d, device=DEV) * 1.5).half().requires_grad_()
+        y = torch.nn.functional.elu(pre)
+        gy = torch.randn(b, d, device=DEV).half()
+        (want,) = torch.autograd.grad(y, pre, gy)
+        gz, gb = torch.empty_like(gy), torch.full((d,), 2.0, device=DEV)
+        F.elu_bwd_colsum_f16(gy, y.detach(), gz, gb, accumulate=True)
+        np.testing.assert_allclose(gz.float().cpu(), want.float().cpu(), rtol=2e-3, atol=1e-3)  # one fp16 ulp: torch derives elu' from the input
+        np.testing.assert_allclose(gb.cpu(), (2.0 + gz.float().sum(0)).cpu(), rtol=1e-4, atol=2e-2)
+
+
 def test_adam_step_kernel_matches_torch_amp_clip_adam():
     """unscale + clip_grad_norm_ + Adam + GradScaler.update in one call vs the torch objects it replaces, over 7 steps: clean
     steps, a step whose gradient holds an inf (skipped by both, scale backed off), and a growth of the scale (interval 3)."""
