@@ -188,6 +188,24 @@ BEZ_DEV void load_joints(const Params& P, int e, float* q, float* qd, float* kps
     }
   }
 }
+// the per-env (domain-randomisation) part alone.  The leg roles call this INSIDE the substep loop with an opaque env index: 30
+// values per leg that are only read once per joint would otherwise live in registers through the whole physics (the
+// 256-VGPR roles spill); re-fetched per substep the loads sit next to their uses and hit in L2.
+template <int FIRST, int NJ, bool DR>
+BEZ_DEV void load_joint_params(const Params& P, int e, float* kps, float* kds, float* ms, float* lo, float* hi) {
+#pragma unroll
+  for (int i = 0; i < NJ; ++i) {
+    constexpr int d0 = FIRST - 1;
+    kps[i] = 1.f; kds[i] = 1.f; ms[i] = 1.f; lo[i] = (float)BEZ_DOF_LOWER[d0 + i]; hi[i] = (float)BEZ_DOF_UPPER[d0 + i];
+    if (DR) {
+      if (P.dr_kp) kps[i] = P.dr_kp[(size_t)e * BEZ_ND + d0 + i];
+      if (P.dr_kd) kds[i] = P.dr_kd[(size_t)e * BEZ_ND + d0 + i];
+      if (P.dr_mass) ms[i] = P.dr_mass[(size_t)e * BEZ_NL + FIRST + i];
+      if (P.dr_lower) lo[i] = P.dr_lower[(size_t)e * BEZ_ND + d0 + i];
+      if (P.dr_upper) hi[i] = P.dr_upper[(size_t)e * BEZ_ND + d0 + i];
+    }
+  }
+}
 // position targets of NJ joints from the staged action row (kick_env.py:410-419) or from the state (physics-only entry point)
 template <int FIRST, int NJ, bool PRE, bool HEAD>
 BEZ_DEV void load_targets(const Params& P, const float* lds, int lane, int e, float* target) {
@@ -211,8 +229,11 @@ BEZ_DEV void load_targets(const Params& P, const float* lds, int lane, int e, fl
 template <int FIRST, bool PRE, bool POST, bool DR, bool CL>
 BEZ_DEV void leg_role(const Params& P, float* lds, int lane, int e, bool active, int side) {
   constexpr int LEN = 6;
-  float q[LEN], qd[LEN], target[LEN], kps[LEN], kds[LEN], ms[LEN], lo[LEN], hi[LEN];
-  load_joints<FIRST, LEN, DR>(P, e, q, qd, kps, kds, ms, lo, hi);
+  float q[LEN], qd[LEN], target[LEN];
+  {
+    float kps[LEN], kds[LEN], ms[LEN], lo[LEN], hi[LEN];  // (re-fetched inside the substep loop)
+    load_joints<FIRST, LEN, false>(P, e, q, qd, kps, kds, ms, lo, hi);
+  }
 #pragma unroll
   for (int i = 0; i < LEN; ++i) { XS(X_LEGQ + side * 12 + i) = q[i]; XS(X_LEGQ + side * 12 + 6 + i) = qd[i]; }
   const ChainDyn D0 = load_chain_dyn<DR>(P, e);
@@ -227,6 +248,12 @@ BEZ_DEV void leg_role(const Params& P, float* lds, int lane, int e, bool active,
     const bool keep = last_only ? (s == P.substeps - 1) : true;
     const bool first = last_only ? true : (s == 0);
     const ChainDyn D = in_loop(D0);
+    float kps[LEN], kds[LEN], ms[LEN], lo[LEN], hi[LEN];
+    {
+      int ei = e;
+      if (DR) asm volatile("" : "+v"(ei));  // not hoisted out of the loop (see load_joint_params)
+      load_joint_params<FIRST, LEN, DR>(P, ei, kps, kds, ms, lo, hi);
+    }
     RootView R = load_root_view(lds, lane);
     LinkInertia LI[LEN]; SV pAl[LEN], Sl[LEN], cbl[LEN];
     BallSel sel;
