@@ -210,7 +210,7 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "bez::w8::step_kernel_ws8<true,true,false,false> (fused control step, default asset, 8 role waves per 64 envs)", "kernel_ms": kernel_ms,
                          "algorithmic_bytes_per_launch": ALGO_BYTES_PER_ENV_STEP * n,
-                         "traffic_unit": "bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE; source: profiles/%s)" % traffic_src
+                         "traffic_unit": "bytes per launch (rocprofv3 FETCH_SIZE: instruction stream x1 + data x2, + WRITE_SIZE; source: profiles/%s)" % traffic_src
                                          if traffic is not None else "no committed PMC profile matches this build's source hash",
                          "note": "N=4096 is latency-bound (64 workgroups x 8 role waves on 256 CUs, serial ABA chains): see DESIGN.md"},
         }
