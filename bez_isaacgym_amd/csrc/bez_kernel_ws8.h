@@ -56,7 +56,14 @@ enum : int {
 #ifndef BEZ_W8_SELF_BAR
 #define BEZ_W8_SELF_BAR 3
 #endif
-constexpr int CAND_SPLIT = BEZ_W8_CAND_SPLIT;  // leg links 0..3 (hip_side, hip_front, thigh, calf) are tested by role 2, links 4..5 (ankle, foot) by roles 4 / 5 (A/B-tuned: tools/ab_bench.py)
+constexpr int CAND_SPLIT_CL = BEZ_W8_CAND_SPLIT;
+// default asset: role 2 tests leg links 0..2 (hip_side, hip_front, thigh), roles 4 / 5 links 3..4 (calf, ankle), the leg role its
+// own foot box; cleats asset (X_HIT in use): role 2 links 0..3, roles 4 / 5 links 4..5
+template <bool CL> BEZ_DEV constexpr int cand_split() { return CL ? CAND_SPLIT_CL : 3; }
+template <bool CL> BEZ_DEV constexpr int cand_lo_end() { return CL ? 6 : 5; }
+// The default asset has no cleat records: its kernels use the X_HIT slots for a third partial ball candidate per leg (the foot
+// box, tested by the leg role itself: 2 x 14 floats).
+constexpr int X_CANDF = X_HIT;
 constexpr int X_STAGE = X_IA;  // staging aliases the chain blocks (see the header comment)
 constexpr int WS_ACT_STRIDE = 19;
 constexpr int WS_LDS_FLOATS = X_SLOTS * WS_ENVS;
@@ -103,11 +110,17 @@ BEZ_DEV BodyContact xs_load_body_contact(const float* lds, int lane, int slot) {
 // boxes are ordered hip -> foot and an earlier box keeps a tie, so the lower one wins only if strictly deeper.  Then: left leg,
 // right leg, torso -- the right leg needs strictly more depth than the left, the torso strictly more than the better leg.
 struct CandDepths { float dl, dr, dt; int bl, br; };  // bl / br: slot base of the leg's winning partial candidate
+template <bool CL>
 BEZ_DEV CandDepths load_cand_depths(const float* lds, int lane) {
   CandDepths c;
   const float lh = XS(X_CANDH), ll = XS(X_CAND), rh = XS(X_CANDH + 14), rl = XS(X_CAND + 14);
   c.bl = (ll > lh) ? X_CAND : X_CANDH; c.dl = (ll > lh) ? ll : lh;
   c.br = (rl > rh) ? X_CAND + 14 : X_CANDH + 14; c.dr = (rl > rh) ? rl : rh;
+  if (!CL) {  // the foot boxes, last in the box order
+    const float lf = XS(X_CANDF), rf = XS(X_CANDF + 14);
+    if (lf > c.dl) { c.bl = X_CANDF; c.dl = lf; }
+    if (rf > c.dr) { c.br = X_CANDF + 14; c.dr = rf; }
+  }
   c.dt = XS(X_TORSO);
   return c;
 }
@@ -260,6 +273,12 @@ BEZ_DEV void leg_role(const Params& P, float* lds, int lane, int e, bool active,
     sel.link = -1; sel.depth = 0.f; sel.n = sel.P = sel.f0p = sel.x = sel.xb = mk(0, 0, 0); sel.A = sym3zero();
     M3 Eend; V3 rend; SV Vend, Vsel = svzero();
     ws_chain_pass1<FIRST, LEN, true, CL, false, BEZ_W8_LEG_BAR>(P, D, ms, R, q, qd, LI, pAl, Sl, cbl, Eend, rend, Vend, sel, Vsel, s > 0);  // B5 of the previous substep inside
+    if (!CL) {  // this leg's foot box as a ball candidate (the ball's new state was published at the barrier inside pass 1)
+      BallSel fs;
+      fs.link = -1; fs.depth = 0.f; fs.n = fs.P = fs.f0p = fs.x = fs.xb = mk(0, 0, 0); fs.A = sym3zero();
+      test_box<link_box(FIRST + LEN - 1)>(Eend, rend, xs_load_v3(lds, lane, X_BALL) - xs_load_v3(lds, lane, X_ROOT), fs);
+      publish_cand(lds, lane, X_CANDF + side * 14, fs, Vend);
+    }
     Sym6 Kc = sym6zero(); SV pc = svzero();
     ws_ground_points<FIRST + LEN - 1, CL>(P, D.mu, R.root_z, Eend, rend, Vend, Kc, pc, lds, lane, X_HIT + side * 32);
     xs_store_body_contact(lds, lane, X_BCN + side * 18, body_contact_of(Kc, pc));
@@ -267,7 +286,7 @@ BEZ_DEV void leg_role(const Params& P, float* lds, int lane, int e, bool active,
     ws_barrier();  // B1: the three ball candidates (roles 4, 5, 3) are evaluated and published
     WS_STAMP(side, 3 + 8 * s);
     // this leg's candidate wins: evaluate the contact now (skipped by the whole wave when no env of the workgroup has one)
-    const CandDepths cd = load_cand_depths(lds, lane);
+    const CandDepths cd = load_cand_depths<CL>(lds, lane);
     const int c0 = side ? cd.br : cd.bl;
     bool mine = (cand_winner(cd) == side) && (XS(c0 + 1) >= 1.f);
     if (mine) {
@@ -364,13 +383,14 @@ BEZ_DEV void head_role(const Params& P, float* lds, int lane, int e, bool active
     const bool first = last_only ? true : (s == 0);
     {  // ball candidates among the hip / thigh boxes of both legs: kinematics first, the tests once the ball's new state is published
       const RootOnly R = load_root_only(lds, lane);
-      LegFrames<1, CAND_SPLIT> FL, FR;
-      leg_frames<5, 1, CAND_SPLIT>(lds, lane, 0, R.E0, R.V0, FL);
-      leg_frames<13, 1, CAND_SPLIT>(lds, lane, 1, R.E0, R.V0, FR);
+      constexpr int HI = cand_split<CL>();
+      LegFrames<1, HI> FL, FR;
+      leg_frames<5, 1, HI>(lds, lane, 0, R.E0, R.V0, FL);
+      leg_frames<13, 1, HI>(lds, lane, 1, R.E0, R.V0, FR);
       if (s > 0) ws_barrier();  // B5 of the previous substep
       const V3 bc = xs_load_v3(lds, lane, X_BALL) - R.pos;
-      leg_box_tests<5, 1, CAND_SPLIT>(FL, bc, lds, lane, X_CANDH);
-      leg_box_tests<13, 1, CAND_SPLIT>(FR, bc, lds, lane, X_CANDH + 14);
+      leg_box_tests<5, 1, HI>(FL, bc, lds, lane, X_CANDH);
+      leg_box_tests<13, 1, HI>(FR, bc, lds, lane, X_CANDH + 14);
     }
     WS_STAMP(2, 2 + 8 * s);
     ws_barrier();  // B1  (X_IA is free from here on: the staged actions have been consumed)
@@ -407,10 +427,11 @@ BEZ_DEV void cand_arm_role(const Params& P, float* lds, int lane, int e, bool ac
     const bool first = last_only ? true : (s == 0);
     {  // ball candidate among the calf / ankle / foot boxes: kinematics first, the tests once the ball's new state is published
       const RootOnly R = load_root_only(lds, lane);
-      LegFrames<CAND_SPLIT, 6> F;
-      leg_frames<LEG_FIRST, CAND_SPLIT, 6>(lds, lane, side, R.E0, R.V0, F);
+      constexpr int LO0 = cand_split<CL>(), LO1 = cand_lo_end<CL>();
+      LegFrames<LO0, LO1> F;
+      leg_frames<LEG_FIRST, LO0, LO1>(lds, lane, side, R.E0, R.V0, F);
       if (s > 0) ws_barrier();  // B5 of the previous substep
-      leg_box_tests<LEG_FIRST, CAND_SPLIT, 6>(F, xs_load_v3(lds, lane, X_BALL) - R.pos, lds, lane, X_CAND + side * 14);
+      leg_box_tests<LEG_FIRST, LO0, LO1>(F, xs_load_v3(lds, lane, X_BALL) - R.pos, lds, lane, X_CAND + side * 14);
     }
     WS_STAMP(ROLE, 2 + 8 * s);
     ws_barrier();  // B1
@@ -608,14 +629,6 @@ BEZ_DEV void root_role(const Params& P, float* lds, int lane, int e, bool active
     const SV V0 = mksv(root_ang, root_lin);
     const V3 bc = ball_pos - root_pos;
     xs_store_v3(lds, lane, X_FL, mk(0, 0, 0)); xs_store_v3(lds, lane, X_FL + 3, mk(0, 0, 0));
-    Sym6 IA0 = sym6zero(); SV pA0;
-    LinkInertia I0;
-    link_inertia<0, CL>(ms0, D.g, E0, mk(0, 0, 0), V0, I0, pA0);
-    Sym6 Kc = sym6zero(); SV pc = svzero();
-    ws_ground_points<0, CL>(P, D.mu, root_pos.z, E0, mk(0, 0, 0), V0, Kc, pc);
-    BodyContact bc0 = body_contact_of(Kc, pc);
-    add_link_inertia(IA0, I0);
-    add_to(IA0, Kc); pA0 = pA0 + pc;
     ball = ball_setup(P, D.mu, D.g, ball_pos.z, ball_ang, ball_lin);
     // the torso box as a ball candidate, evaluated now; the winner is decided from the published depths after B1
     sel.link = -1; sel.depth = 0.f; sel.n = sel.P = sel.f0p = sel.x = sel.xb = mk(0, 0, 0); sel.A = sym3zero();
@@ -625,15 +638,25 @@ BEZ_DEV void root_role(const Params& P, float* lds, int lane, int e, bool active
     WS_STAMP(3, 2 + 8 * s);
     ws_barrier();  // B1: all candidates are in LDS
     WS_STAMP(3, 3 + 8 * s);
-    const CandDepths cd = load_cand_depths(lds, lane);
+    const CandDepths cd = load_cand_depths<CL>(lds, lane);
     const int winner = cand_winner(cd);
     torso_hit = (winner == 2) && (sel.link == 0);
-    if (torso_hit) { add_point_stiffness(IA0, sel.x, sel.A); pA0 = pA0 - wrench_at(sel.x, sel.f0p); }
     {  // contact normal of the winning leg box (for the ball's contact row)
       V3 nw = xs_load_v3(lds, lane, (winner == 1 ? cd.br : cd.bl) + 2);
       pin(nw);
       if (winner != 2) sel.n = nw;
     }
+    // the torso's own inertia and guard points: nobody needs them before B2, so they run in this role's idle window beside the
+    // legs' pass 2 instead of ahead of B1
+    Sym6 IA0 = sym6zero(); SV pA0;
+    LinkInertia I0;
+    link_inertia<0, CL>(ms0, D.g, E0, mk(0, 0, 0), V0, I0, pA0);
+    Sym6 Kc = sym6zero(); SV pc = svzero();
+    ws_ground_points<0, CL>(P, D.mu, root_pos.z, E0, mk(0, 0, 0), V0, Kc, pc);
+    BodyContact bc0 = body_contact_of(Kc, pc);
+    add_link_inertia(IA0, I0);
+    add_to(IA0, Kc); pA0 = pA0 + pc;
+    if (torso_hit) { add_point_stiffness(IA0, sel.x, sel.A); pA0 = pA0 - wrench_at(sel.x, sel.f0p); }
     WS_STAMP(3, 24 + s);
     ws_barrier();  // B1c
     ws_barrier();  // B2: chain contributions published
