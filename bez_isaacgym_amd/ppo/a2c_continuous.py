@@ -422,7 +422,7 @@ class A2CAgent:
         if self.fused:
             hd = torch.float16 if self.mixed_precision else torch.float32
             A, D, MB = self.act_dim, self.obs_dim, self.minibatch_size
-            self._fx = dict(obs_n=torch.zeros(N, D, device=dev, dtype=hd), env_act=z(N, A), noise=z(N, A),
+            self._fx = dict(obs_n=torch.zeros(N, D, device=dev, dtype=hd), env_act=z(N, A), noise=z(H, N, A),
                             mb_obs_n=torch.zeros(MB, D, device=dev, dtype=hd), gmu=z(MB, A), gval=z(MB, 1), glog=z(A), stats=z(5))
 
     @torch.no_grad()
@@ -436,15 +436,15 @@ class A2CAgent:
             net.refresh_half()
         cur = self.obs  # step 0 reads the agent's copy; later steps read the env's own observation buffer (no per-step copy)
         vrms = self.value_mean_std if self.normalize_value else None
+        fx["noise"].normal_()  # the whole horizon's action noise in one launch
         for n in range(self.horizon):
             x = self._f_obs_rms.normalize(cur, fx["obs_n"]) if self.normalize_input else cur
             with torch.autocast("cuda", dtype=torch.float16, enabled=self.mixed_precision and not self.half_path):
                 mu, _logstd, value = net(x)
             if mu.dtype not in (torch.float16, torch.float32):
                 mu, value = mu.float(), value.float()
-            fx["noise"].normal_()
             # fp32 rows of obs / dones / mu / de-normalised value + sampling + neglogp + clamp: one launch
-            F.rollout_pre(mu.contiguous(), value.contiguous(), net.sigma.detach(), fx["noise"], cur, self.dones, vrms, mb["obs"][n], mb["dones"][n],
+            F.rollout_pre(mu.contiguous(), value.contiguous(), net.sigma.detach(), fx["noise"][n], cur, self.dones, vrms, mb["obs"][n], mb["dones"][n],
                           mb["mu"][n], mb["val"][n], mb["act"][n], fx["env_act"], mb["neglogp"][n], mb["sigma"][n])
             obs_dict, rew, dones, infos = self.vec_env.step(fx["env_act"])
             F.rollout_post(rew, dones, infos["time_outs"], mb["val"][n], self.reward_scale, self.gamma, self.value_bootstrap and "time_outs" in infos,
