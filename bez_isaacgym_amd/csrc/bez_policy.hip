@@ -1,0 +1,263 @@
+// bez_policy.hip -- the rollout's policy forward pass as ONE gfx950 kernel (C ABI: bez_ppo_policy_forward, include/bez_sim.h).
+//
+// What it replaces: per env step of the PPO rollout, rl_games' get_action_values runs the observation normaliser, five
+// Linear layers and three ELUs as ~14 launches of 5-25 us each on a (4096 x 54) batch -- tiny GEMMs that leave the chip idle.
+// Here one workgroup (8 waves) carries 64 envs through the whole MLP: activations live in LDS (two 64 x 416 fp16 buffers),
+// the fp16 weights (247 KB for 54-400-200-100-(18+1), L2-resident) stream from global memory straight into MFMA B fragments,
+// products are v_mfma_f32_32x32x16_f16 with fp32 accumulators, bias + fp16 rounding + ELU + fp16 rounding in the epilogue (the
+// arithmetic of torch's fp16 Linear / ELU on the explicit-fp16 path of a2c_continuous.py).  Training's forward / backward stay
+// PyTorch-ROCm GEMMs; this kernel only serves the no-grad rollout.
+//
+// Fragment maps (MI355X guide, checked by tests/test_gpu_ppo_fused.py against torch on asymmetric data):
+//   A (32 x 16): lane l holds A[row l & 31][k = 8 (l >> 5) + j], j = 0..7      -> the activations of 32 envs
+//   B (16 x 32): lane l holds B[k = 8 (l >> 5) + j][col l & 31] = W[col][k]    -> 8 consecutive fp16 of one weight row
+//   C (32 x 32): lane l holds C[row (r & 3) + 8 (r >> 2) + 4 (l >> 5)][col l & 31], r = 0..15
+#include <hip/hip_fp16.h>
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <type_traits>
+
+#include "../../include/bez_sim.h"
+
+namespace {
+
+using half8 = __attribute__((ext_vector_type(8))) _Float16;
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+constexpr int PF_ROWS = 64;         // envs per workgroup
+constexpr int PF_MAXW = 416;        // widest layer the LDS buffers hold (13 blocks of 32 columns)
+constexpr int PF_LD = PF_MAXW + 8;  // row stride in halfs: 848 B = 53 x 16 B (16-byte fragment reads, conflict-free row walk)
+constexpr int PF_MAXL = 6;          // hidden layers supported
+constexpr int PF_WAVES = 8;         // waves per workgroup: the column blocks of a layer are dealt round-robin
+
+struct PolicyArgs {
+  const float* obs; int64_t n; int d_in;
+  const double* mean; const double* var; float eps;  // RunningMeanStd of the observations (mean == null: obs are used as they are)
+  int nhid;
+  const _Float16* w[PF_MAXL]; const _Float16* b[PF_MAXL]; int width[PF_MAXL];  // hidden layers: (width[i], width[i-1] or d_in)
+  const _Float16* w_mu; const _Float16* b_mu; int num_actions;                // mu head (num_actions, width[nhid-1])
+  const _Float16* w_val; const _Float16* b_val;                               // value head (1, width[nhid-1])
+  float* mu; float* value;
+  // rollout step (ROLL): everything between the forward pass and the env step, fused behind it (bez_ppo_rollout_pre's work)
+  const float* logstd; const float* noise; const float* dones; const double* vmean; const double* vvar; float veps;
+  float* mb_obs; float* mb_dones; float* mb_mu; float* mb_val; float* act; float* act_env; float* neglogp; float* sigma;
+};
+
+struct __attribute__((packed, aligned(4))) H8 { _Float16 v[8]; };
+
+// 8 consecutive fp16 of a weight row starting at column k0; columns >= cols read as zero; rows are only 4-byte aligned in general
+__device__ __forceinline__ half8 load_w8(const _Float16* row, int k0, int cols) {
+  half8 f;
+  if (k0 + 8 <= cols && (cols & 1) == 0) {
+    const H8 t = *reinterpret_cast<const H8*>(row + k0);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f[j] = t.v[j];
+  } else {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f[j] = (k0 + j < cols) ? row[k0 + j] : (_Float16)0.f;
+  }
+  return f;
+}
+
+// acc0 / acc1 (rows 0..31 / 32..63 of the workgroup) += src[:, 0:in] * wrow[0:in] for this lane's column (wrow = its weight row,
+// live = the column exists).  The weight fragments of up to twelve k-steps are fetched before the first of their MFMAs: the loop
+// is bound by the latency of those L2 reads, not by the matrix pipe.
+__device__ __forceinline__ void gemm_col_block(const _Float16 (*src)[PF_LD], const _Float16* wrow, bool live, int in, int r, int h, f32x16& acc0, f32x16& acc1) {
+  const int full = ((in & 1) == 0) ? (in >> 4) : 0;  // k-steps whose 16 columns all exist (and whose rows are 4-byte aligned)
+  const int ksteps = (in + 15) >> 4;
+  int ks = 0;
+  auto group = [&](auto G) {
+    constexpr int g = decltype(G)::value;
+    half8 bf[g];
+#pragma unroll
+    for (int u = 0; u < g; ++u) {
+      if (live) {
+        const H8 t = *reinterpret_cast<const H8*>(wrow + (ks + u) * 16 + 8 * h);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) bf[u][j] = t.v[j];
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) bf[u][j] = (_Float16)0.f;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < g; ++u) {
+      const int k0 = (ks + u) * 16 + 8 * h;
+      const half8 a0 = *reinterpret_cast<const half8*>(&src[r][k0]);
+      const half8 a1 = *reinterpret_cast<const half8*>(&src[32 + r][k0]);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, bf[u], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, bf[u], acc1, 0, 0, 0);
+    }
+    ks += g;
+  };
+  while (ks + 12 <= full) group(std::integral_constant<int, 12>{});
+  while (ks + 4 <= full) group(std::integral_constant<int, 4>{});
+  while (ks + 1 <= full) group(std::integral_constant<int, 1>{});
+  for (; ks < ksteps; ++ks) {  // the remaining (possibly partial) k-steps
+    const int k0 = ks * 16 + 8 * h;
+    const half8 bf = load_w8(wrow, k0, live ? in : 0);
+    const half8 a0 = *reinterpret_cast<const half8*>(&src[r][k0]);
+    const half8 a1 = *reinterpret_cast<const half8*>(&src[32 + r][k0]);
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, bf, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, bf, acc1, 0, 0, 0);
+  }
+}
+
+// dst[:, 0:Npad] = act(src[:, 0:K] W^T + b) for the 64 rows of the workgroup; this wave takes column blocks wave, wave + PF_WAVES, ...
+template <bool ELU>
+__device__ __forceinline__ void layer(const _Float16 (*src)[PF_LD], _Float16 (*dst)[PF_LD], const _Float16* W, const _Float16* B, int in, int out, int wave,
+                                      int lane) {
+  const int r = lane & 31, h = lane >> 5;
+  const int nblk = (out + 31) >> 5;
+  for (int nb = wave; nb < nblk; nb += PF_WAVES) {
+    const int n = nb * 32 + r;
+    const _Float16* wrow = W + (size_t)(n < out ? n : 0) * in;
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
+    gemm_col_block(src, wrow, n < out, in, r, h, acc0, acc1);
+    const float bias = n < out ? (float)B[n] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int row = (i & 3) + 8 * (i >> 2) + 4 * h;
+      float v0 = (float)(_Float16)(acc0[i] + bias), v1 = (float)(_Float16)(acc1[i] + bias);  // the fp16 output of the Linear
+      if (ELU) { v0 = v0 > 0.f ? v0 : __expf(v0) - 1.f; v1 = v1 > 0.f ? v1 : __expf(v1) - 1.f; }  // (v_exp_f32: the result is rounded to fp16 anyway)
+      dst[row][n] = (_Float16)v0;
+      dst[32 + row][n] = (_Float16)v1;
+    }
+  }
+}
+
+template <bool ROLL>
+__global__ __launch_bounds__(PF_WAVES * 64) void policy_forward_kernel(PolicyArgs a) {
+  __shared__ __attribute__((aligned(16))) _Float16 buf[2][PF_ROWS][PF_LD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t row0 = (int64_t)blockIdx.x * PF_ROWS;
+  const int nrow = (int)((a.n - row0) < (int64_t)PF_ROWS ? (a.n - row0) : (int64_t)PF_ROWS);
+  // stage the (normalised) observations as fp16, zero-padded to a multiple of 16 columns
+  const int kpad0 = (a.d_in + 15) & ~15;
+  for (int idx = tid; idx < PF_ROWS * kpad0; idx += PF_WAVES * 64) {
+    const int rr = idx / kpad0, k = idx - rr * kpad0;
+    float v = 0.f;
+    if (rr < nrow && k < a.d_in) {
+      v = a.obs[(row0 + rr) * a.d_in + k];
+      if (ROLL) a.mb_obs[(row0 + rr) * a.d_in + k] = v;  // the rollout buffer keeps the raw observation
+      if (a.mean) {
+        v = (v - (float)a.mean[k]) / sqrtf((float)a.var[k] + a.eps);
+        v = fminf(fmaxf(v, -5.0f), 5.0f);
+      }
+    }
+    buf[0][rr][k] = (_Float16)v;
+  }
+  __syncthreads();
+  int cur = 0, in = a.d_in;
+  for (int L = 0; L < a.nhid; ++L) {
+    layer<true>(buf[cur], buf[cur ^ 1], a.w[L], a.b[L], in, a.width[L], wave, lane);
+    // the next layer reads K padded to 16: columns width..pad16(width) were written as elu(0 + 0) = 0 by the padded column block
+    __syncthreads();
+    cur ^= 1; in = a.width[L];
+  }
+  // heads: one column block (num_actions + 1 <= 32 columns), wave 0; results to global memory as fp32 of the fp16 outputs
+  float* tile = reinterpret_cast<float*>(&buf[cur ^ 1][0][0]);
+  if (wave == 0) {
+    const int r = lane & 31, h = lane >> 5, A = a.num_actions;
+    const _Float16* wrow = r < A ? a.w_mu + (size_t)r * in : a.w_val;
+    const bool live = r <= A;
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
+    gemm_col_block(buf[cur], wrow, live, in, r, h, acc0, acc1);
+    const float bias = r < A ? (float)a.b_mu[r] : (r == A ? (float)a.b_val[0] : 0.f);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int row = (i & 3) + 8 * (i >> 2) + 4 * h;
+      const float v0 = (float)(_Float16)(acc0[i] + bias), v1 = (float)(_Float16)(acc1[i] + bias);
+      if (ROLL) {  // (row, column) tile of the head outputs for the sampling pass below: the free LDS buffer, fp32 view, 33-float rows
+        if (r <= A) { tile[row * 33 + r] = v0; tile[(32 + row) * 33 + r] = v1; }
+      } else {
+        if (row < nrow) { if (r < A) a.mu[(row0 + row) * A + r] = v0; else if (r == A) a.value[row0 + row] = v0; }
+        if (32 + row < nrow) { if (r < A) a.mu[(row0 + 32 + row) * A + r] = v1; else if (r == A) a.value[row0 + 32 + row] = v1; }
+      }
+    }
+  }
+  if (ROLL) {
+    // sampling, neglogp, clamp, rollout-buffer rows: one thread per (env, action), the per-env sum through the same LDS tile
+    __syncthreads();
+    const int A = a.num_actions;
+    float* zz = tile + PF_ROWS * 33;  // (64, 32) squared standardised actions
+    for (int idx = tid; idx < nrow * A; idx += PF_WAVES * 64) {
+      const int rr = idx / A, j = idx - rr * A;
+      const float m = tile[rr * 33 + j];
+      const float l = a.logstd[j], sg = expf(l), z = a.noise[(row0 + rr) * A + j];
+      const float x = fmaf(sg, z, m);
+      const int64_t o = (row0 + rr) * A + j;
+      a.mb_mu[o] = m; a.act[o] = x; a.act_env[o] = fminf(fmaxf(x, -1.0f), 1.0f); a.sigma[o] = sg;
+      const float q = (x - m) / sg;  // as the reference computes it from the stored action
+      zz[rr * 32 + j] = q * q;
+    }
+    __syncthreads();
+    if (tid < nrow) {
+      float acc = 0.f, ls = 0.f;
+      for (int j = 0; j < A; ++j) { acc += zz[tid * 32 + j]; ls += a.logstd[j]; }
+      a.neglogp[row0 + tid] = 0.5f * acc + 0.5f * 1.8378770664093453f * (float)A + ls;
+      float v = tile[tid * 33 + A];
+      if (a.vmean) v = sqrtf((float)a.vvar[0] + a.veps) * fminf(fmaxf(v, -5.0f), 5.0f) + (float)a.vmean[0];
+      a.mb_val[row0 + tid] = v;
+      a.mb_dones[row0 + tid] = a.dones[row0 + tid];
+    }
+  }
+}
+
+}  // namespace
+
+static int fill_args(PolicyArgs& a, const float* obs_dev, int64_t n, int32_t num_obs, const double* obs_mean_dev, const double* obs_var_dev, float obs_eps,
+                     int32_t num_hidden, const void* const* hidden_w_f16_dev, const void* const* hidden_b_f16_dev, const int32_t* hidden_width,
+                     const void* mu_w_f16_dev, const void* mu_b_f16_dev, int32_t num_actions, const void* value_w_f16_dev, const void* value_b_f16_dev) {
+  if (!obs_dev || n <= 0 || num_obs <= 0 || num_obs > PF_MAXW || num_hidden <= 0 || num_hidden > PF_MAXL || !hidden_w_f16_dev || !hidden_b_f16_dev ||
+      !hidden_width || !mu_w_f16_dev || !mu_b_f16_dev || !value_w_f16_dev || !value_b_f16_dev || num_actions <= 0 || num_actions > 31 ||
+      (obs_mean_dev && !obs_var_dev)) return -1;
+  a.obs = obs_dev; a.n = n; a.d_in = num_obs; a.mean = obs_mean_dev; a.var = obs_var_dev; a.eps = obs_eps; a.nhid = num_hidden;
+  for (int i = 0; i < PF_MAXL; ++i) { a.w[i] = nullptr; a.b[i] = nullptr; a.width[i] = 0; }
+  for (int i = 0; i < num_hidden; ++i) {
+    if (!hidden_w_f16_dev[i] || !hidden_b_f16_dev[i] || hidden_width[i] <= 0 || hidden_width[i] > PF_MAXW) return -1;
+    a.w[i] = (const _Float16*)hidden_w_f16_dev[i]; a.b[i] = (const _Float16*)hidden_b_f16_dev[i]; a.width[i] = hidden_width[i];
+  }
+  a.w_mu = (const _Float16*)mu_w_f16_dev; a.b_mu = (const _Float16*)mu_b_f16_dev; a.num_actions = num_actions;
+  a.w_val = (const _Float16*)value_w_f16_dev; a.b_val = (const _Float16*)value_b_f16_dev;
+  a.mu = nullptr; a.value = nullptr;
+  a.logstd = a.noise = a.dones = nullptr; a.vmean = a.vvar = nullptr; a.veps = 0.f;
+  a.mb_obs = a.mb_dones = a.mb_mu = a.mb_val = a.act = a.act_env = a.neglogp = a.sigma = nullptr;
+  return 0;
+}
+
+extern "C" int bez_ppo_policy_forward(const float* obs_dev, int64_t n, int32_t num_obs, const double* obs_mean_dev, const double* obs_var_dev, float obs_eps,
+                                      int32_t num_hidden, const void* const* hidden_w_f16_dev, const void* const* hidden_b_f16_dev, const int32_t* hidden_width,
+                                      const void* mu_w_f16_dev, const void* mu_b_f16_dev, int32_t num_actions, const void* value_w_f16_dev,
+                                      const void* value_b_f16_dev, float* mu_dev, float* value_dev, void* stream) {
+  PolicyArgs a;
+  if (!mu_dev || !value_dev || fill_args(a, obs_dev, n, num_obs, obs_mean_dev, obs_var_dev, obs_eps, num_hidden, hidden_w_f16_dev, hidden_b_f16_dev, hidden_width,
+                                         mu_w_f16_dev, mu_b_f16_dev, num_actions, value_w_f16_dev, value_b_f16_dev)) return -1;
+  a.mu = mu_dev; a.value = value_dev;
+  hipLaunchKernelGGL(policy_forward_kernel<false>, dim3((unsigned)((n + PF_ROWS - 1) / PF_ROWS)), dim3(PF_WAVES * 64), 0, (hipStream_t)stream, a);
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+extern "C" int bez_ppo_policy_rollout_step(const float* obs_dev, int64_t n, int32_t num_obs, const double* obs_mean_dev, const double* obs_var_dev, float obs_eps,
+                                           int32_t num_hidden, const void* const* hidden_w_f16_dev, const void* const* hidden_b_f16_dev,
+                                           const int32_t* hidden_width, const void* mu_w_f16_dev, const void* mu_b_f16_dev, int32_t num_actions,
+                                           const void* value_w_f16_dev, const void* value_b_f16_dev, const float* logstd_dev, const float* noise_dev,
+                                           const float* dones_dev, const double* value_mean_dev, const double* value_var_dev, float value_eps, float* mb_obs_dev,
+                                           float* mb_dones_dev, float* mb_mu_dev, float* mb_val_dev, float* actions_dev, float* env_actions_dev,
+                                           float* neglogp_dev, float* sigma_dev, void* stream) {
+  PolicyArgs a;
+  if (!logstd_dev || !noise_dev || !dones_dev || !mb_obs_dev || !mb_dones_dev || !mb_mu_dev || !mb_val_dev || !actions_dev || !env_actions_dev || !neglogp_dev ||
+      !sigma_dev || (value_mean_dev && !value_var_dev) ||
+      fill_args(a, obs_dev, n, num_obs, obs_mean_dev, obs_var_dev, obs_eps, num_hidden, hidden_w_f16_dev, hidden_b_f16_dev, hidden_width, mu_w_f16_dev,
+                mu_b_f16_dev, num_actions, value_w_f16_dev, value_b_f16_dev)) return -1;
+  a.logstd = logstd_dev; a.noise = noise_dev; a.dones = dones_dev; a.vmean = value_mean_dev; a.vvar = value_var_dev; a.veps = value_eps;
+  a.mb_obs = mb_obs_dev; a.mb_dones = mb_dones_dev; a.mb_mu = mb_mu_dev; a.mb_val = mb_val_dev; a.act = actions_dev; a.act_env = env_actions_dev;
+  a.neglogp = neglogp_dev; a.sigma = sigma_dev;
+  hipLaunchKernelGGL(policy_forward_kernel<true>, dim3((unsigned)((n + PF_ROWS - 1) / PF_ROWS)), dim3(PF_WAVES * 64), 0, (hipStream_t)stream, a);
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}

@@ -355,6 +355,7 @@ class A2CAgent:
         # HIP glue kernels (csrc/bez_ppo.hip) for everything around the MLP: on by default on a GPU, `fused_ops: False` keeps
         # the plain torch formulation (the one the CPU path runs and the kernels are tested against)
         self._fused_opt = False
+        self._policy_fwd = None
         self.fused = bool(on_gpu and c.get("fused_ops", True))
         if self.fused:
             from . import fused as F
@@ -368,6 +369,15 @@ class A2CAgent:
             self._fused_opt = bool(c.get("fused_optimizer", True))
             if self._fused_opt:
                 self._bind_flat_optimizer()
+            # the rollout's policy forward as one MFMA kernel on the fp16 working weights (csrc/bez_policy.hip); training's forward /
+            # backward stay torch GEMMs
+            self._policy_fwd = None
+            net = self.model.a2c_network
+            if self.half_path and c.get("fused_policy_forward", True) and getattr(net, "_p16", None) is not None:
+                nh = len(net._lin) - 2
+                wb = [(net._p16[2 * i], net._p16[2 * i + 1]) for i in range(nh + 2)]
+                if all(w.shape[0] <= 416 for w, _ in wb[:nh]) and obs_dim <= 416 and act_dim <= 31 and nh <= 6:
+                    self._policy_fwd = F.PolicyForward(wb[:nh], wb[nh], wb[nh + 1], self.running_mean_std if self.normalize_input else None)
         if world > 1 and not self.fused:
             self.use_graphs = False  # the plain torch path has collectives in the middle of autograd-heavy code: eager only
         self._seg = None  # segmented graphs of the data-parallel update
@@ -427,8 +437,8 @@ class A2CAgent:
 
     @torch.no_grad()
     def _rollout_steps_fused(self):
-        """The horizon loop with the HIP glue kernels: normalise (1 launch), MLP forward (torch), sample + neglogp + clamp
-        (1 launch), env step (1 launch), reward shaping + episode statistics (1 launch)."""
+        """The horizon loop on HIP kernels: policy forward + sampling + neglogp + clamp + rollout rows (1 launch, bez_policy.hip;
+        without it: normalise, torch MLP, rollout_pre), env step (1 launch), reward shaping + episode statistics (1 launch)."""
         mb, F, fx = self.mb, self._F, self._fx
         net = self.model.a2c_network
         self.model.eval()
@@ -438,14 +448,19 @@ class A2CAgent:
         vrms = self.value_mean_std if self.normalize_value else None
         fx["noise"].normal_()  # the whole horizon's action noise in one launch
         for n in range(self.horizon):
-            x = self._f_obs_rms.normalize(cur, fx["obs_n"]) if self.normalize_input else cur
-            with torch.autocast("cuda", dtype=torch.float16, enabled=self.mixed_precision and not self.half_path):
-                mu, _logstd, value = net(x)
-            if mu.dtype not in (torch.float16, torch.float32):
-                mu, value = mu.float(), value.float()
-            # fp32 rows of obs / dones / mu / de-normalised value + sampling + neglogp + clamp: one launch
-            F.rollout_pre(mu.contiguous(), value.contiguous(), net.sigma.detach(), fx["noise"][n], cur, self.dones, vrms, mb["obs"][n], mb["dones"][n],
-                          mb["mu"][n], mb["val"][n], mb["act"][n], fx["env_act"], mb["neglogp"][n], mb["sigma"][n])
+            if self._policy_fwd is not None:
+                # normaliser + 5 Linear + 3 ELU + sampling + neglogp + clamp + the rollout-buffer rows: one launch
+                self._policy_fwd.rollout_step(cur, net.sigma.detach(), fx["noise"][n], self.dones, vrms, mb["obs"][n], mb["dones"][n], mb["mu"][n],
+                                              mb["val"][n], mb["act"][n], fx["env_act"], mb["neglogp"][n], mb["sigma"][n])
+            else:
+                x = self._f_obs_rms.normalize(cur, fx["obs_n"]) if self.normalize_input else cur
+                with torch.autocast("cuda", dtype=torch.float16, enabled=self.mixed_precision and not self.half_path):
+                    mu, _logstd, value = net(x)
+                if mu.dtype not in (torch.float16, torch.float32):
+                    mu, value = mu.float(), value.float()
+                # fp32 rows of obs / dones / mu / de-normalised value + sampling + neglogp + clamp: one launch
+                F.rollout_pre(mu.contiguous(), value.contiguous(), net.sigma.detach(), fx["noise"][n], cur, self.dones, vrms, mb["obs"][n], mb["dones"][n],
+                              mb["mu"][n], mb["val"][n], mb["act"][n], fx["env_act"], mb["neglogp"][n], mb["sigma"][n])
             obs_dict, rew, dones, infos = self.vec_env.step(fx["env_act"])
             F.rollout_post(rew, dones, infos["time_outs"], mb["val"][n], self.reward_scale, self.gamma, self.value_bootstrap and "time_outs" in infos,
                            mb["rew"][n], self.dones, self.current_rewards, self.current_lengths, self.ep_stats)

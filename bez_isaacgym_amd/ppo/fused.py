@@ -17,6 +17,8 @@ _SIGS = {
     "bez_ppo_rollout_post": [_vp, _vp, _vp, _vp, _i64, _f, _f, _i32, _vp, _vp, _vp, _vp, _vp, _vp],
     "bez_ppo_loss": [_vp] * 10 + [_i64, _i32, _f, _f, _f, _f, _i32] + [_vp] * 6,
     "bez_ppo_rollout_pre": [_vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _f, _i64, _i32, _i32] + [_vp] * 9,
+    "bez_ppo_policy_forward": [_vp, _i64, _i32, _vp, _vp, _f, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp],
+    "bez_ppo_policy_rollout_step": [_vp, _i64, _i32, _vp, _vp, _f, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f] + [_vp] * 9,
     "bez_ppo_wgrad_sum": [_vp, _i32, _i64, _vp, _i32, _vp],
     "bez_ppo_colsum_f16": [_vp, _i64, _i32, _vp, _i32, _vp],
     "bez_ppo_elu_bwd_colsum_f16": [_vp, _vp, _vp, _i64, _i32, _vp, _i32, _vp],
@@ -150,3 +152,45 @@ def elu_bwd_colsum_f16(gy, y, gz, bias_grad, accumulate=False):
     assert gy.shape == y.shape == gz.shape and gy.is_contiguous() and y.is_contiguous() and gz.is_contiguous() and bias_grad.numel() == d
     _chk(lib().bez_ppo_elu_bwd_colsum_f16(_p(gy, torch.float16), _p(y, torch.float16), _p(gz, torch.float16), b, d, _p(bias_grad), 1 if accumulate else 0,
                                           _stream(y)), "bez_ppo_elu_bwd_colsum_f16")
+
+
+class PolicyForward:
+    """One-launch rollout forward of the actor-critic MLP on its fp16 working weights (csrc/bez_policy.hip).  `hidden` = list of
+    (w16, b16) of the ELU layers, then the mu and value heads; the pointer tables are built once (the tensors are static views)."""
+
+    def __init__(self, hidden, mu_wb, value_wb, obs_rms):
+        self.keep = (hidden, mu_wb, value_wb, obs_rms)
+        k = len(hidden)
+        for w, b in list(hidden) + [mu_wb, value_wb]:
+            assert w.dtype == torch.float16 and b.dtype == torch.float16 and w.is_contiguous() and b.is_contiguous() and w.is_cuda
+        self.hw = (C.c_void_p * k)(*[w.data_ptr() for w, _ in hidden])
+        self.hb = (C.c_void_p * k)(*[b.data_ptr() for _, b in hidden])
+        self.widths = (C.c_int32 * k)(*[w.shape[0] for w, _ in hidden])
+        self.k, self.d_in, self.num_actions = k, hidden[0][0].shape[1], mu_wb[0].shape[0]
+        assert value_wb[0].shape[0] == 1 and mu_wb[0].shape[1] == hidden[-1][0].shape[0] == value_wb[0].shape[1]
+
+    def __call__(self, obs, mu_out, value_out):
+        hidden, mu_wb, value_wb, rms = self.keep
+        n = obs.shape[0]
+        assert obs.shape[1] == self.d_in and mu_out.shape == (n, self.num_actions) and value_out.numel() == n
+        _chk(lib().bez_ppo_policy_forward(_p(obs), n, self.d_in, None if rms is None else _p(rms.running_mean, torch.float64),
+                                          None if rms is None else _p(rms.running_var, torch.float64), 0.0 if rms is None else float(rms.epsilon), self.k,
+                                          C.cast(self.hw, C.c_void_p), C.cast(self.hb, C.c_void_p), C.cast(self.widths, C.c_void_p),
+                                          _p(mu_wb[0], torch.float16), _p(mu_wb[1], torch.float16), self.num_actions, _p(value_wb[0], torch.float16),
+                                          _p(value_wb[1], torch.float16), _p(mu_out), _p(value_out), _stream(obs)), "bez_ppo_policy_forward")
+
+    def rollout_step(self, obs, logstd, noise, dones, value_rms, mb_obs, mb_dones, mb_mu, mb_val, actions, env_actions, neglogp, sigma):
+        """Forward + everything up to the env step in the same launch (bez_ppo_policy_rollout_step): same outputs as
+        `self(obs, mu, v); rollout_pre(mu, v, ...)`."""
+        hidden, mu_wb, value_wb, rms = self.keep
+        n, A = obs.shape[0], self.num_actions
+        assert obs.shape[1] == self.d_in and noise.shape == (n, A) and logstd.numel() == A and dones.numel() == n
+        assert mb_obs.shape == obs.shape and mb_mu.shape == (n, A) and actions.shape == (n, A) and env_actions.shape == (n, A) and sigma.shape == (n, A)
+        assert mb_dones.numel() == n and mb_val.numel() == n and neglogp.numel() == n
+        _chk(lib().bez_ppo_policy_rollout_step(
+            _p(obs), n, self.d_in, None if rms is None else _p(rms.running_mean, torch.float64), None if rms is None else _p(rms.running_var, torch.float64),
+            0.0 if rms is None else float(rms.epsilon), self.k, C.cast(self.hw, C.c_void_p), C.cast(self.hb, C.c_void_p), C.cast(self.widths, C.c_void_p),
+            _p(mu_wb[0], torch.float16), _p(mu_wb[1], torch.float16), A, _p(value_wb[0], torch.float16), _p(value_wb[1], torch.float16), _p(logstd), _p(noise),
+            _p(dones), None if value_rms is None else _p(value_rms.running_mean, torch.float64),
+            None if value_rms is None else _p(value_rms.running_var, torch.float64), 0.0 if value_rms is None else float(value_rms.epsilon), _p(mb_obs),
+            _p(mb_dones), _p(mb_mu), _p(mb_val), _p(actions), _p(env_actions), _p(neglogp), _p(sigma), _stream(obs)), "bez_ppo_policy_rollout_step")

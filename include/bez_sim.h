@@ -249,6 +249,26 @@ int bez_ppo_loss(const float* mu_dev, const float* logstd_dev, const float* valu
                  float bounds_coef, int32_t clip_value, const float* loss_scale_dev, float* grad_mu_dev, float* grad_value_dev,
                  float* grad_logstd_dev, float* stats_dev, void* stream);
 
+/* The rollout's policy forward pass (rl_games get_action_values [ext] via train.py:89-113) in one launch: observation normaliser
+ * (NULL mean = none), num_hidden Linear + ELU layers, the mu head (num_actions <= 31) and the value head, on fp16 weights /
+ * biases in torch layout ((out, in) row-major; hidden_* are HOST arrays of num_hidden device pointers / widths <= 416), fp32
+ * accumulation, fp16 rounding after every Linear and ELU as torch's fp16 path does.  Outputs fp32: mu (n, num_actions), value (n). */
+int bez_ppo_policy_forward(const float* obs_dev, int64_t n, int32_t num_obs, const double* obs_mean_dev, const double* obs_var_dev, float obs_eps,
+                           int32_t num_hidden, const void* const* hidden_w_f16_dev, const void* const* hidden_b_f16_dev, const int32_t* hidden_width,
+                           const void* mu_w_f16_dev, const void* mu_b_f16_dev, int32_t num_actions, const void* value_w_f16_dev,
+                           const void* value_b_f16_dev, float* mu_dev, float* value_dev, void* stream);
+
+/* The fused rollout step: bez_ppo_policy_forward followed, inside the same launch, by bez_ppo_rollout_pre's work (rollout-buffer
+ * rows of obs / dones / mu / de-normalised value, a = mu + exp(logstd) * noise, neglogp, the clamped env action).  mu / value
+ * never visit HBM in fp16; replaces a2c_common.py:1105-1135's per-step get_action_values + buffer updates. */
+int bez_ppo_policy_rollout_step(const float* obs_dev, int64_t n, int32_t num_obs, const double* obs_mean_dev, const double* obs_var_dev, float obs_eps,
+                                int32_t num_hidden, const void* const* hidden_w_f16_dev, const void* const* hidden_b_f16_dev, const int32_t* hidden_width,
+                                const void* mu_w_f16_dev, const void* mu_b_f16_dev, int32_t num_actions, const void* value_w_f16_dev,
+                                const void* value_b_f16_dev, const float* logstd_dev, const float* noise_dev, const float* dones_dev,
+                                const double* value_mean_dev, const double* value_var_dev, float value_eps, float* mb_obs_dev, float* mb_dones_dev,
+                                float* mb_mu_dev, float* mb_val_dev, float* actions_dev, float* env_actions_dev, float* neglogp_dev, float* sigma_dev,
+                                void* stream);
+
 /* Gradient reductions of explicit-fp16 linear layers into the fp32 master gradient: the sum over `splits` split-K partial
  * products ([splits][n] fp16) and the bias gradient = column sums of dY ((rows, cols) fp16).  accumulate != 0 adds to out_dev. */
 int bez_ppo_wgrad_sum(const void* partials_f16_dev, int32_t splits, int64_t n, float* out_dev, int32_t accumulate, void* stream);

@@ -90,6 +90,77 @@ def test_rollout_pre_kernel(half):
     assert torch.equal(mb_val, value.float())
 
 
+@pytest.mark.parametrize("n,d,units,a", [(4096, 54, (400, 200, 100), 18), (1000, 54, (400, 200, 100), 18), (130, 33, (96, 50), 7)])
+def test_policy_forward_kernel_matches_torch_fp16_path(n, d, units, a):
+    """The one-launch MFMA forward of the rollout against the same network evaluated by torch on the same fp16 weights
+    (addmm + ELU per layer, fp16 tensors).  Asymmetric random weights: a swapped fragment map cannot pass."""
+    from bez_isaacgym_amd.ppo import fused as F
+    from bez_isaacgym_amd.ppo.a2c_continuous import RunningMeanStd
+    torch.manual_seed(13)
+    dims = [d] + list(units)
+    hidden = [((torch.randn(dims[i + 1], dims[i], device=DEV) / dims[i] ** 0.5).half().contiguous(), (torch.randn(dims[i + 1], device=DEV) * 0.1).half())
+              for i in range(len(units))]
+    mu_wb = ((torch.randn(a, dims[-1], device=DEV) / dims[-1] ** 0.5).half().contiguous(), (torch.randn(a, device=DEV) * 0.1).half())
+    val_wb = ((torch.randn(1, dims[-1], device=DEV) / dims[-1] ** 0.5).half().contiguous(), (torch.randn(1, device=DEV) * 0.1).half())
+    rms = RunningMeanStd((d,)).to(DEV)
+    rms.running_mean.copy_(torch.randn(d, dtype=torch.float64) * 0.3); rms.running_var.copy_(torch.rand(d, dtype=torch.float64) + 0.5)
+    obs = torch.randn(n, d, device=DEV) * 1.5
+    mu, val = torch.full((n, a), 7.0, device=DEV), torch.full((n, 1), 7.0, device=DEV)
+    F.PolicyForward(hidden, mu_wb, val_wb, rms)(obs, mu, val)
+    rms.eval()
+    h = rms(obs).half()
+    for w, b in hidden:
+        h = torch.nn.functional.elu(torch.addmm(b, h, w.t()))
+    want_mu, want_v = torch.addmm(mu_wb[1], h, mu_wb[0].t()).float(), torch.addmm(val_wb[1], h, val_wb[0].t()).float()
+    # fp16 outputs of O(1): one or two fp16 ulps (different accumulation order inside the GEMMs, then rounding at every layer)
+    np.testing.assert_allclose(mu.cpu(), want_mu.cpu(), rtol=4e-3, atol=4e-3)
+    np.testing.assert_allclose(val.cpu(), want_v.cpu(), rtol=4e-3, atol=4e-3)
+    assert float((mu - want_mu).abs().mean()) < 4e-4
+
+
+@pytest.mark.parametrize("n,normalize_value", [(4096, True), (333, False)])
+def test_policy_rollout_step_equals_forward_then_rollout_pre(n, normalize_value):
+    """bez_ppo_policy_rollout_step = bez_ppo_policy_forward + bez_ppo_rollout_pre in one launch: same mu / value / action /
+    clamp / sigma / obs / dones rows bit for bit; neglogp differs only by the order of an 18-term fp32 sum."""
+    from bez_isaacgym_amd.ppo import fused as F
+    from bez_isaacgym_amd.ppo.a2c_continuous import RunningMeanStd
+    torch.manual_seed(21)
+    d, units, a = 54, (400, 400, 200, 100), 18
+    dims = [d] + list(units)
+    hidden = [((torch.randn(dims[i + 1], dims[i], device=DEV) / dims[i] ** 0.5).half().contiguous(), (torch.randn(dims[i + 1], device=DEV) * 0.1).half())
+              for i in range(len(units))]
+    mu_wb = ((torch.randn(a, dims[-1], device=DEV) / dims[-1] ** 0.5).half().contiguous(), (torch.randn(a, device=DEV) * 0.1).half())
+    val_wb = ((torch.randn(1, dims[-1], device=DEV) * 3 / dims[-1] ** 0.5).half().contiguous(), (torch.randn(1, device=DEV) * 0.1).half())
+    rms = RunningMeanStd((d,)).to(DEV)
+    rms.running_mean.copy_(torch.randn(d, dtype=torch.float64) * 0.3); rms.running_var.copy_(torch.rand(d, dtype=torch.float64) + 0.5)
+    vrms = None
+    if normalize_value:
+        vrms = RunningMeanStd((1,)).to(DEV)
+        vrms.running_mean.fill_(0.7); vrms.running_var.fill_(2.5)
+    obs = torch.randn(n, d, device=DEV) * 1.5
+    logstd = torch.randn(a, device=DEV) * 0.3 - 0.5
+    noise = torch.randn(n, a, device=DEV)
+    dones = (torch.rand(n, device=DEV) < 0.1).float()
+    pf = F.PolicyForward(hidden, mu_wb, val_wb, rms)
+
+    def bufs():
+        z = lambda *s: torch.full(s, 7.0, device=DEV)
+        return dict(mb_obs=z(n, d), mb_dones=z(n), mb_mu=z(n, a), mb_val=z(n, 1), act=z(n, a), env_act=z(n, a), neglogp=z(n), sigma=z(n, a))
+    want, got = bufs(), bufs()
+    mu, val = torch.empty(n, a, device=DEV), torch.empty(n, 1, device=DEV)
+    pf(obs, mu, val)
+    F.rollout_pre(mu, val, logstd, noise, obs, dones, vrms, want["mb_obs"], want["mb_dones"], want["mb_mu"], want["mb_val"], want["act"], want["env_act"],
+                  want["neglogp"], want["sigma"])
+    pf.rollout_step(obs, logstd, noise, dones, vrms, got["mb_obs"], got["mb_dones"], got["mb_mu"], got["mb_val"], got["act"], got["env_act"], got["neglogp"],
+                    got["sigma"])
+    for k in want:
+        if k == "neglogp":
+            np.testing.assert_allclose(got[k].cpu(), want[k].cpu(), rtol=2e-6, atol=1e-5)
+        else:
+            np.testing.assert_array_equal(got[k].cpu().numpy(), want[k].cpu().numpy(), err_msg=k)
+    assert float(got["env_act"].abs().max()) <= 1.0 and float((got["act"].abs() > 1.0).float().mean()) > 0.01  # the clamp did something
+
+
 def _torch_loss(mu, logstd, value, mb, e, critic_coef, entropy_coef, bounds_coef, clip_value):
     from bez_isaacgym_amd.ppo.a2c_continuous import ModelA2CContinuousLogStd, policy_kl
     sigma = torch.exp(logstd).unsqueeze(0).expand_as(mu)
