@@ -20,6 +20,7 @@ FLAG_CF_WITH_FRICTION = 2
 FLAG_CF_LAST_SUBSTEP = 4
 FLAG_NO_SELF_COLLISION = 8
 FLAG_CLEATS = 16
+FLAG_BOX_ASSET = 32
 TASK_KICK, TASK_WALK, TASK_ORIENT = 0, 1, 2
 TASK_IDS = {"bez_kick": TASK_KICK, "bez_walk": TASK_WALK, "bez_orient": TASK_ORIENT}
 
@@ -136,4 +137,6 @@ def config_from_task_cfg(cfg, seed=42, env_id_offset=0, strict_reference_quirks=
     c.flags = FLAG_IMU_PREV_ALIAS if strict_reference_quirks else 0
     if env.get("asset", {}).get("cleats", False):
         c.flags |= FLAG_CLEATS
+    if not env.get("asset", {}).get("stl", True):  # kick_env.py:266-276: soccerbot_box*.urdf
+        c.flags |= FLAG_BOX_ASSET
     return c

@@ -339,7 +339,7 @@ BEZ_DEV void ws_root_role(const Params& P, float* lds, int lane, int e, bool act
       sel.n = xs_load_v3(lds, lane, c0 + 2); sel.P = xs_load_v3(lds, lane, c0 + 5);
       sel.A = sym3zero(); sel.f0p = sel.x = sel.xb = mk(0, 0, 0);
       SV Vl = xs_load_sv(lds, lane, c0 + 8);
-      test_box<link_box(0)>(E0, mk(0, 0, 0), bc, sel);
+      test_torso_box(P, E0, mk(0, 0, 0), bc, sel);
       if (sel.link == 0) Vl = V0;
       if (sel.link >= 0) ball_link_contact(P, D.mu, ball_ang, ball_lin, ball, bc, Vl, sel);
       XS(X_FOLD) = (float)side_w; XS(X_FOLD + 1) = (float)sel.link;  // link 0 / -1: neither leg folds anything

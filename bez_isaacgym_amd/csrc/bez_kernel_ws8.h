@@ -632,7 +632,7 @@ BEZ_DEV void root_role(const Params& P, float* lds, int lane, int e, bool active
     ball = ball_setup(P, D.mu, D.g, ball_pos.z, ball_ang, ball_lin);
     // the torso box as a ball candidate, evaluated now; the winner is decided from the published depths after B1
     sel.link = -1; sel.depth = 0.f; sel.n = sel.P = sel.f0p = sel.x = sel.xb = mk(0, 0, 0); sel.A = sym3zero();
-    test_box<link_box(0)>(E0, mk(0, 0, 0), bc, sel);
+    test_torso_box(P, E0, mk(0, 0, 0), bc, sel);
     XS(X_TORSO) = sel.depth;
     if (sel.link == 0) ball_link_contact(P, D.mu, ball_ang, ball_lin, ball, bc, V0, sel);
     WS_STAMP(3, 2 + 8 * s);

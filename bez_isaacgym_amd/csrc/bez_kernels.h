@@ -80,6 +80,15 @@ template <bool CL> BEZ_DEV constexpr double link_mass(int l) { return CL ? BEZ_L
 template <bool CL> BEZ_DEV constexpr double link_com(int l, int k) { return CL ? BEZ_LINK_COM_CL[l][k] : BEZ_LINK_COM[l][k]; }
 template <bool CL> BEZ_DEV constexpr double link_inertia_c(int l, int k) { return CL ? BEZ_LINK_INERTIA_CL[l][k] : BEZ_LINK_INERTIA[l][k]; }
 template <bool CL> BEZ_DEV constexpr double pt_pos(int i, int k) { return CL ? BEZ_PT_POS_CL[i][k] : BEZ_PT_POS[i][k]; }
+// the same coordinate for the asset the sim was created with: the box asset (BEZ_FLAG_BOX_ASSET) moves the upper-body guard
+// points only; where the two tables agree (feet) this folds to the constant, elsewhere it is one scalar select of two literals
+template <bool CL> BEZ_DEV float pt_pos_of(const Params& P, int i, int k) {
+  if constexpr (CL) return (float)BEZ_PT_POS_CL[i][k];
+  else {
+    const float a = (float)BEZ_PT_POS[i][k], b = (float)BEZ_PT_POS_BOX[i][k];
+    return a == b ? a : ((P.flags & BEZ_FLAG_BOX_ASSET) ? b : a);
+  }
+}
 template <bool CL> BEZ_DEV constexpr int pt_body(int i) { return CL ? BEZ_PT_BODY_CL[i] : BEZ_PT_BODY[i]; }
 template <bool CL> BEZ_DEV constexpr int lfoot_body() { return CL ? BEZ_LFOOT_BODY_CL : BEZ_LFOOT_BODY; }
 template <bool CL> BEZ_DEV constexpr int rfoot_body() { return CL ? BEZ_RFOOT_BODY_CL : BEZ_RFOOT_BODY; }
@@ -220,11 +229,7 @@ struct BallSel {
 };
 
 // sphere (centre bc rel. O) against box `b` of a link with frame (E, r)
-template <int B>
-BEZ_DEV void test_box(const M3& E, V3 r, V3 bc, BallSel& sel) {
-  constexpr int l = BEZ_BOX_LINK[B];
-  const V3 cl = mk((float)BEZ_BOX_CENTER[B][0], (float)BEZ_BOX_CENTER[B][1], (float)BEZ_BOX_CENTER[B][2]);
-  const V3 he = mk((float)BEZ_BOX_HALF[B][0], (float)BEZ_BOX_HALF[B][1], (float)BEZ_BOX_HALF[B][2]);
+BEZ_DEV void test_box_at(int l, V3 cl, V3 he, const M3& E, V3 r, V3 bc, BallSel& sel) {
   const float R = (float)BEZ_BALL_RADIUS;
   V3 ql = mulT(E, bc - r) - cl;
   V3 cp = mk(fminf(fmaxf(ql.x, -he.x), he.x), fminf(fmaxf(ql.y, -he.y), he.y), fminf(fmaxf(ql.z, -he.z), he.z));
@@ -253,6 +258,22 @@ BEZ_DEV void test_box(const M3& E, V3 r, V3 bc, BallSel& sel) {
     sel.n = mul(E, nl);
     sel.P = r + mul(E, cp + cl);
   }
+}
+template <int B>
+BEZ_DEV void test_box(const M3& E, V3 r, V3 bc, BallSel& sel) {
+  test_box_at(BEZ_BOX_LINK[B], mk((float)BEZ_BOX_CENTER[B][0], (float)BEZ_BOX_CENTER[B][1], (float)BEZ_BOX_CENTER[B][2]),
+              mk((float)BEZ_BOX_HALF[B][0], (float)BEZ_BOX_HALF[B][1], (float)BEZ_BOX_HALF[B][2]), E, r, bc, sel);
+}
+// ball <-> torso: the stl asset's bounding box of the torso mesh, or the box asset's own torso box (BEZ_FLAG_BOX_ASSET)
+BEZ_DEV void test_torso_box(const Params& P, const M3& E, V3 r, V3 bc, BallSel& sel) {
+  constexpr int B = BEZ_TORSO_BOX;
+  static_assert(BEZ_BOX_LINK[B] == 0, "the torso box is the last entry of the box table");
+  const bool bx = (P.flags & BEZ_FLAG_BOX_ASSET) != 0;
+  auto pick = [&](double a, double b) { return (float)a == (float)b ? (float)a : (bx ? (float)b : (float)a); };
+  test_box_at(0, mk(pick(BEZ_BOX_CENTER[B][0], BEZ_TORSO_BOX_CENTER_BOX[0]), pick(BEZ_BOX_CENTER[B][1], BEZ_TORSO_BOX_CENTER_BOX[1]),
+                    pick(BEZ_BOX_CENTER[B][2], BEZ_TORSO_BOX_CENTER_BOX[2])),
+              mk(pick(BEZ_BOX_HALF[B][0], BEZ_TORSO_BOX_HALF_BOX[0]), pick(BEZ_BOX_HALF[B][1], BEZ_TORSO_BOX_HALF_BOX[1]),
+                 pick(BEZ_BOX_HALF[B][2], BEZ_TORSO_BOX_HALF_BOX[2])), E, r, bc, sel);
 }
 
 // The free ball about its own centre with its (implicit) ground contact folded in: the 6x6 "mass" is
@@ -445,7 +466,7 @@ BEZ_DEV void link_ground_points(const Params& P, float mu, float root_z, const M
 #pragma unroll
   for (int i = 0; i < BEZ_NPT; ++i) {
     if (BEZ_PT_LINK[i] == L) {
-      V3 pl = mk((float)pt_pos<CL>(i, 0), (float)pt_pos<CL>(i, 1), (float)pt_pos<CL>(i, 2));
+      V3 pl = mk(pt_pos_of<CL>(P, i, 0), pt_pos_of<CL>(P, i, 1), pt_pos_of<CL>(P, i, 2));
       V3 x = r + mul(E, pl);
       Hit hit = ground_contact(P, mu, x, root_z + x.z, V, IA, pA);
       if (keep) lds_store_hit(lds, lane, i, hit);
@@ -653,7 +674,7 @@ BEZ_DEV void substep(const Params& P, const EnvDyn& D, EnvState& S, const float*
       link_kinematics<L>(S.q[L - 1], S.qd[L - 1], E, r, V, Sj, cbj);
       if constexpr (link_has_box(L)) { test_box<link_box(L)>(E, r, bc, sel); link_capsules<L>(E, r, V, cap0, cap1, capV); }
     });
-    test_box<link_box(0)>(E0, mk(0, 0, 0), bc, sel);
+    test_torso_box(P, E0, mk(0, 0, 0), bc, sel);
   }
   SV selfw[BEZ_NL]; V3 selfcf[BEZ_NL];
 #pragma unroll

@@ -381,6 +381,10 @@ int bez_sim_create(const BezSimConfig* cfg, int device_id, BezSim** out) {
   s->cfg = *cfg; s->device = device_id; s->n = cfg->num_envs;
   if (cfg->task < BEZ_TASK_KICK || cfg->task > BEZ_TASK_ORIENT) { delete s; return fail(nullptr, -1, "bez_sim_create: unknown task"); }
   s->cleats = (cfg->flags & BEZ_FLAG_CLEATS) != 0;
+  if (s->cleats && (cfg->flags & BEZ_FLAG_BOX_ASSET)) {
+    delete s;
+    return fail(nullptr, -1, "bez_sim_create: BEZ_FLAG_BOX_ASSET with BEZ_FLAG_CLEATS (soccerbot_box_sensor.urdf) is not compiled in: that URDF moves the right ankle joint");
+  }
   s->kernel = kernel_from_env();
   s->has_ball = cfg->task == BEZ_TASK_KICK;                    // walk_env.py / orient_env.py create no ball actor
   s->nb = s->cleats ? BEZ_NB_CL : BEZ_NB;
@@ -503,7 +507,12 @@ int bez_sim_set_prev_lin_vel_tensor(BezSim* s, const float* prev_dev, void* stre
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : fail(s, -2, "set_prev launch", e);
 }
-int bez_sim_set_flags(BezSim* s, uint32_t flags) { if (!s) return -1; s->cfg.flags = flags; return 0; }
+int bez_sim_set_flags(BezSim* s, uint32_t flags) {
+  if (!s) return -1;
+  const uint32_t asset = BEZ_FLAG_CLEATS | BEZ_FLAG_BOX_ASSET;  // the asset is fixed at creation (buffer shapes, kernel variant)
+  s->cfg.flags = (flags & ~asset) | (s->cfg.flags & asset);
+  return 0;
+}
 int bez_sim_set_obs_calls(BezSim* s, int64_t calls) { if (!s) return -1; s->obs_calls = calls; return 0; }
 
 int bez_sim_pre_physics(BezSim* s, const float* actions_dev, void* stream) {

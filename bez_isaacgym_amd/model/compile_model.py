@@ -108,7 +108,7 @@ def merge_inertia(m1, c1, I1, m2, c2, I2):
     return m, c, shift(m1, c1, I1) + shift(m2, c2, I2)
 
 
-def build(urdf=None, cleats=False):
+def build(urdf=None, cleats=False, box=False):
     links, joints = parse_urdf(urdf or URDF_BEZ)
     ball_links, _ = parse_urdf(URDF_BALL)
     cfg = yaml.safe_load(open(YAML_TASK))
@@ -189,10 +189,15 @@ def build(urdf=None, cleats=False):
     # collision boxes used for ball contact: foot, ankle, calve, thigh, hip_front per leg (+ the torso box, appended below)
     boxes = []
     for li, d in enumerate(dyn):
-        if d["box"] is not None and min(d["box"]["half"]) > 1e-3 and "cleat" not in d["name"]:
+        if d["box"] is not None and min(d["box"]["half"]) > 1e-3 and "cleat" not in d["name"] and ("_leg" in (d["joint_name"] or "") if box else True):
             boxes.append({"link": li, "center": d["box"]["center"], "half": d["box"]["half"]})
-    # ball <-> torso: the torso collision mesh is approximated by its bounding box (same vertex data as the guard points below)
-    boxes.append({"link": 0, "center": [0.012, 0.0, -0.033], "half": [0.052, 0.0725, 0.095]})
+    # ball <-> torso: the torso collision mesh is approximated by its bounding box (same vertex data as the guard points below);
+    # the soccerbot_box*.urdf variants (asset.stl: False, kick_env.py:272-276) give the torso an explicit box
+    if box:
+        tb = links["/torso"]["box"]
+        boxes.append({"link": 0, "center": list(tb["center"]), "half": list(tb["half"])})
+    else:
+        boxes.append({"link": 0, "center": [0.012, 0.0, -0.033], "half": [0.052, 0.0725, 0.095]})
     # ground contact points: foot box bottom corners + guard points on the torso and on the other
     # chain-end links (head, forearms).  Mid-chain links carry no ground points: an episode ends at
     # torso z < 0.275 (kick_env.py:1331) long before a knee could reach the floor.
@@ -217,16 +222,31 @@ def build(urdf=None, cleats=False):
             for sx in (+1, -1):
                 for sy in (+1, -1):
                     add("/%s_foot" % side, [c[0] + sx * h[0], c[1] + sy * h[1], c[2] - h[2]], "foot")
-    for sx in (-0.040, 0.064):
-        for sy in (-0.0725, 0.0725):
-            for sz in (-0.128, 0.062):
-                add("/torso", [sx, sy, sz], "guard")
-    hc = [-0.013, 0.0, 0.025]  # head collision origin (urdf:530)
-    for sx in (-0.04775, 0.02345):
-        for sy in (-0.04555, 0.04845):
-            add("/head", [hc[0] + sx, hc[1] + sy, hc[2] + 0.0619], "guard")
-    for side, sgn in (("left", 1.0), ("right", -1.0)):
-        add("/%s_forearm" % side, [-0.0055 - 0.005, sgn * (0.005 + 0.0245), -0.131], "guard")
+    if box:
+        # box assets: the same guard points taken from the URDF's own collision boxes -- the torso box's eight corners, the
+        # four top corners of the head box, the bottom-face centre of each forearm box
+        tb, hb = links["/torso"]["box"], links["/head"]["box"]
+        for sx in (-1, 1):
+            for sy in (-1, 1):
+                for sz in (-1, 1):
+                    add("/torso", [tb["center"][k] + sgn * tb["half"][k] for k, sgn in enumerate((sx, sy, sz))], "guard")
+        for sx in (-1, 1):
+            for sy in (-1, 1):
+                add("/head", [hb["center"][0] + sx * hb["half"][0], hb["center"][1] + sy * hb["half"][1], hb["center"][2] + hb["half"][2]], "guard")
+        for side in ("left", "right"):
+            fb = links["/%s_forearm" % side]["box"]
+            add("/%s_forearm" % side, [fb["center"][0], fb["center"][1], fb["center"][2] - fb["half"][2]], "guard")
+    else:
+        for sx in (-0.040, 0.064):
+            for sy in (-0.0725, 0.0725):
+                for sz in (-0.128, 0.062):
+                    add("/torso", [sx, sy, sz], "guard")
+        hc = [-0.013, 0.0, 0.025]  # head collision origin (urdf:530)
+        for sx in (-0.04775, 0.02345):
+            for sy in (-0.04555, 0.04845):
+                add("/head", [hc[0] + sx, hc[1] + sy, hc[2] + 0.0619], "guard")
+        for side, sgn in (("left", 1.0), ("right", -1.0)):
+            add("/%s_forearm" % side, [-0.0055 - 0.005, sgn * (0.005 + 0.0245), -0.131], "guard")
 
     # leg <-> leg self-collision shapes (the reference enables self-collision: kick_env.py:365-366, collision_filter 0):
     # every leg box becomes a capsule along its longest axis with the larger cross-section half-extent as radius;
@@ -305,7 +325,7 @@ def arr(vals):
     return "{" + ", ".join(fmt(v) for v in vals) + "}"
 
 
-def emit_header(m, mc=None):
+def emit_header(m, mc=None, mb=None, mbc=None):
     L = m["links"]
     o = []
     o.append("/* GENERATED by bez_isaacgym_amd/model/compile_model.py -- do not edit.\n"
@@ -385,6 +405,40 @@ def emit_header(m, mc=None):
     o.append("BEZ_TBL double BEZ_DEFAULT_BEZ_INIT[7] = %s;" % arr(c["bez_init"]))
     o.append("BEZ_TBL double BEZ_DEFAULT_BALL_INIT[7] = %s;" % arr(c["ball_init"]))
     o.append("BEZ_TBL double BEZ_DEFAULT_GOAL[2] = %s;" % arr(c["goal"]))
+    if mb is not None:
+        # asset.stl: False (kick_env.py:266-276): soccerbot_box.urdf / soccerbot_box_sensor.urdf.  Same tree, inertias, joints and
+        # leg boxes as the stl assets (asserted here); only the collision shapes of the torso / head / arms differ, i.e. the
+        # upper-body guard points and the ball <-> torso box
+        def same_dynamics(a, b, known=()):
+            assert len(a["links"]) == len(b["links"])
+            for la, lb in zip(a["links"], b["links"]):
+                for k in ("name", "parent", "body"):
+                    assert la[k] == lb[k], (k, la, lb)
+                for k in ("axis", "xyz", "com", "inertia"):
+                    assert (la["name"], k) in known or np.allclose(la[k], lb[k], rtol=0, atol=1e-12), (k, la["name"], la[k], lb[k])
+                assert abs(la["mass"] - lb["mass"]) < 1e-15
+            assert a["boxes"][:-1] == b["boxes"][:-1] and a["boxes"][-1]["link"] == b["boxes"][-1]["link"] == 0
+            assert a["capsules"] == b["capsules"] and a["capsule_pairs"] == b["capsule_pairs"]
+            assert [(q["link"], q["body"]) for q in a["ground_points"]] == [(q["link"], q["body"]) for q in b["ground_points"]]
+            for qa, qb in zip(a["ground_points"], b["ground_points"]):
+                if qa["kind"] != "guard":
+                    assert qa["p"] == qb["p"]
+            assert a["body_names"] == b["body_names"] and a["dof_lower"] == b["dof_lower"] and a["dof_upper"] == b["dof_upper"]
+        same_dynamics(m, mb)
+        # soccerbot_box_sensor.urdf (box + cleats) is NOT the same robot: its right ankle joint sits at z = -0.0827 instead of
+        # -0.0865 (urdf right_leg_motor_4); everything else matches.  That variant is not compiled in (bez_sim_create rejects it).
+        same_dynamics(mc, mbc, known=(("/right_ankle", "xyz"),))
+        ra = [l for l in mbc["links"] if l["name"] == "/right_ankle"][0]["xyz"]
+        assert ra == [0.0, 0.0, -0.0827], ra
+        o.append("/* ---- box assets (asset.stl: False -> soccerbot_box.urdf / soccerbot_box_sensor.urdf, kick_env.py:266-276; BEZ_FLAG_BOX_ASSET):\n"
+                 " * dynamics, leg boxes, capsules and foot / cleat points are those of the stl assets; the upper-body guard points come from the\n"
+                 " * URDF's own torso / head / forearm collision boxes and the ball <-> torso box is the URDF's torso box.  soccerbot_box.urdf only:\n"
+                 " * soccerbot_box_sensor.urdf moves the right ankle joint (z -0.0827 instead of -0.0865) and is not compiled in. */")
+        o.append("#define BEZ_TORSO_BOX %d" % (len(m["boxes"]) - 1))
+        o.append("BEZ_TBL double BEZ_PT_POS_BOX[BEZ_NPT][3] = {%s};" % ", ".join(arr(q["p"]) for q in mb["ground_points"]))
+        o.append("BEZ_TBL double BEZ_TORSO_BOX_CENTER_BOX[3] = %s;" % arr(mb["boxes"][-1]["center"]))
+        o.append("BEZ_TBL double BEZ_TORSO_BOX_HALF_BOX[3] = %s;" % arr(mb["boxes"][-1]["half"]))
+        assert mb["boxes"][-1] == mbc["boxes"][-1]
     o.append("#endif /* BEZ_MODEL_GEN_H */\n")
     return "\n".join(o)
 
@@ -393,10 +447,13 @@ def main():
     m = build()
     mc = build(os.path.join(REF, "resources/assets/bez/model/soccerbot_stl_sensor.urdf"), cleats=True)
     m["cleats"] = {k: mc[k] for k in ("num_bodies", "body_names", "body_link", "body_offset", "links", "ground_points", "total_mass")}
+    mb = build(os.path.join(REF, "resources/assets/bez/model/soccerbot_box.urdf"), box=True)
+    mbc = build(os.path.join(REF, "resources/assets/bez/model/soccerbot_box_sensor.urdf"), cleats=True, box=True)
+    m["box_asset"] = {"ground_points": mb["ground_points"], "torso_box": mb["boxes"][-1]}
     with open(OUT_JSON, "w") as f:
         json.dump(m, f, indent=1)
     with open(OUT_H, "w") as f:
-        f.write(emit_header(m, mc))
+        f.write(emit_header(m, mc, mb, mbc))
     print("links:")
     for i, l in enumerate(m["links"]):
         print(i, l["name"], "parent", l["parent"], "axis", l["axis"], "xyz", l["xyz"], "m=%.6f" % l["mass"])

@@ -55,6 +55,10 @@ extern "C" {
 
 #define BEZ_FLAG_CLEATS 16u /* asset.cleats: True -> soccerbot_stl_sensor.urdf: 29 robot bodies, per-cleat contact rows \
                                13:17 / 25:29 and compute_feet_sensors_cleats (kick_env.py:187-191,267-276,1044-1069) */
+#define BEZ_FLAG_BOX_ASSET 32u /* asset.stl: False -> soccerbot_box.urdf (kick_env.py:266-276): the stl asset's dynamics with the \
+                                  URDF's own torso / head / forearm collision boxes (upper-body ground points, ball <-> torso box). \
+                                  Not combinable with BEZ_FLAG_CLEATS: soccerbot_box_sensor.urdf is a different robot (right ankle \
+                                  joint 3.8 mm higher) and is not compiled in -- bez_sim_create returns an error */
 
 /* Tasks sharing the robot, the physics and the tensor API; they differ in the post-physics logic (observation tail,
  * reward, reset conditions, goal sampling) and in the ball actor (bez_kick only). */
@@ -191,7 +195,7 @@ int bez_sim_set_env_params(BezSim* sim, int param, const float* values_dev, void
 
 /* Test hooks (state injection for the parity tests; no reference counterpart). */
 int bez_sim_set_prev_lin_vel_tensor(BezSim* sim, const float* prev_dev, void* stream); /* (N,3) */
-int bez_sim_set_flags(BezSim* sim, uint32_t flags);
+int bez_sim_set_flags(BezSim* sim, uint32_t flags);  /* the asset bits (BEZ_FLAG_CLEATS, BEZ_FLAG_BOX_ASSET) keep their creation value */
 /* compute_observations + compute_reward on the current state, without timeout/progress/reset bookkeeping */
 int bez_sim_observe_reward(BezSim* sim, void* stream);
 /* writes the per-env goal (N,2) of bez_walk / bez_orient */

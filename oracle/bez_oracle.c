@@ -55,7 +55,12 @@ static int m_link_body(const BezSimConfig* c, int l) { return m_cl(c) ? BEZ_LINK
 static real m_mass(const BezSimConfig* c, int l) { return (real)(m_cl(c) ? BEZ_LINK_MASS_CL[l] : BEZ_LINK_MASS[l]); }
 static const double* m_com(const BezSimConfig* c, int l) { return m_cl(c) ? BEZ_LINK_COM_CL[l] : BEZ_LINK_COM[l]; }
 static const double* m_inertia(const BezSimConfig* c, int l) { return m_cl(c) ? BEZ_LINK_INERTIA_CL[l] : BEZ_LINK_INERTIA[l]; }
-static const double* m_pt_pos(const BezSimConfig* c, int i) { return m_cl(c) ? BEZ_PT_POS_CL[i] : BEZ_PT_POS[i]; }
+/* box asset (BEZ_FLAG_BOX_ASSET, asset.stl: False, kick_env.py:266-276): soccerbot_box.urdf -- the default asset's dynamics with
+ * the URDF's own torso / head / forearm collision boxes (upper-body ground points, ball <-> torso box); never with cleats */
+static int m_box(const BezSimConfig* c) { return (c->flags & BEZ_FLAG_BOX_ASSET) != 0; }
+static const double* m_pt_pos(const BezSimConfig* c, int i) { return m_cl(c) ? BEZ_PT_POS_CL[i] : (m_box(c) ? BEZ_PT_POS_BOX[i] : BEZ_PT_POS[i]); }
+static const double* m_box_center(const BezSimConfig* c, int b) { return (b == BEZ_TORSO_BOX && m_box(c)) ? BEZ_TORSO_BOX_CENTER_BOX : BEZ_BOX_CENTER[b]; }
+static const double* m_box_half(const BezSimConfig* c, int b) { return (b == BEZ_TORSO_BOX && m_box(c)) ? BEZ_TORSO_BOX_HALF_BOX : BEZ_BOX_HALF[b]; }
 static int m_pt_body(const BezSimConfig* c, int i) { return m_cl(c) ? BEZ_PT_BODY_CL[i] : BEZ_PT_BODY[i]; }
 static int m_body_link(const BezSimConfig* c, int b) { return m_cl(c) ? BEZ_BODY_LINK_CL[b] : BEZ_BODY_LINK[b]; }
 static const double* m_body_offset(const BezSimConfig* c, int b) { return m_cl(c) ? BEZ_BODY_OFFSET_CL[b] : BEZ_BODY_OFFSET[b]; }
@@ -452,8 +457,8 @@ static void dynamics(const BezSimConfig* c, const Env* e, real h, int mode, cons
     V3 bn = v3(0, 0, 0), bP = v3(0, 0, 0);
     for (int b = 0; b < BEZ_NBOX; ++b) {
       int l = BEZ_BOX_LINK[b];
-      V3 cl = v3((real)BEZ_BOX_CENTER[b][0], (real)BEZ_BOX_CENTER[b][1], (real)BEZ_BOX_CENTER[b][2]);
-      V3 he = v3((real)BEZ_BOX_HALF[b][0], (real)BEZ_BOX_HALF[b][1], (real)BEZ_BOX_HALF[b][2]);
+      V3 cl = v3((real)m_box_center(c, b)[0], (real)m_box_center(c, b)[1], (real)m_box_center(c, b)[2]);
+      V3 he = v3((real)m_box_half(c, b)[0], (real)m_box_half(c, b)[1], (real)m_box_half(c, b)[2]);
       V3 ql = v3sub(m3Tmulv(&k.E[l], v3sub(bc, k.r[l])), cl); /* ball centre in box frame */
       V3 cp; int inside = 1;
       for (int i = 0; i < 3; ++i) {
@@ -1093,7 +1098,11 @@ void bez_oracle_reset_idx(void* h, const int32_t* ids, int n) {
   for (int k = 0; k < n; ++k) env_reset(&o->cfg, &o->env[ids[k]], o->cfg.env_id_offset + ids[k], goal);
 }
 void bez_oracle_seed(void* h, uint64_t seed) { ((Oracle*)h)->cfg.seed = seed; }
-void bez_oracle_set_flags(void* h, uint32_t flags) { ((Oracle*)h)->cfg.flags = flags; }
+void bez_oracle_set_flags(void* h, uint32_t flags) { /* the asset bits are fixed at creation, as in bez_sim_set_flags */
+  Oracle* o = (Oracle*)h;
+  const uint32_t asset = BEZ_FLAG_CLEATS | BEZ_FLAG_BOX_ASSET;
+  o->cfg.flags = (flags & ~asset) | (o->cfg.flags & asset);
+}
 void bez_oracle_set_obs_calls(void* h, int64_t n) { ((Oracle*)h)->obs_calls = n; }
 
 /* Known-answer hooks: bare dynamics of env 0 in double-precision interface.

@@ -18,7 +18,7 @@ def TG():
     return np.load(os.path.join(ROOT, "tests", "golden", "tasks_golden.npz"))
 
 
-def make_cfg(n, task="bez_kick", cleats=False, seed=42, **kw):
+def make_cfg(n, task="bez_kick", cleats=False, seed=42, box=False, **kw):
     c = abi.default_config(n, seed=seed, **kw)
     c.task = abi.TASK_IDS[task]
     if task != "bez_kick":
@@ -27,6 +27,8 @@ def make_cfg(n, task="bez_kick", cleats=False, seed=42, **kw):
         c.goal_angle = 1.5708
     if cleats:
         c.flags |= abi.FLAG_CLEATS
+    if box:
+        c.flags |= abi.FLAG_BOX_ASSET
     return c
 
 
@@ -122,6 +124,64 @@ def test_oracle_walk_goal_is_shared_per_reset_call_and_shard_invariant():
 def test_hip_cleats_feet(TG): check_cleats_feet(hip(N, cleats=True), TG)
 
 
+def _lie_on_back(b, n, count=None):
+    """The first `count` envs (default: all): robot on its back (torso -x down), ball far away, joints at rest."""
+    m = n if count is None else count
+    rs = np.array(b.root_states, dtype=np.float32).reshape(n, b.nact, 13).copy()
+    rs[:m, 0, 0:3] = [0.0, 0.0, 0.12]
+    rs[:m, 0, 3:7] = [0.0, -np.sin(np.pi / 4), 0.0, np.cos(np.pi / 4)]   # xyzw: -90 deg about y -> torso +x points up
+    rs[:m, 0, 7:13] = 0
+    if b.nact > 1:
+        rs[:m, 1, 0:3] = [5.0, 5.0, 0.0795]; rs[:m, 1, 7:13] = 0   # resting in contact (exactly z = R would sit on the contact on/off edge)
+    b.set_root_states(rs.reshape(-1, 13))
+    ds = np.array(b.dof_state, dtype=np.float32).reshape(n, 18, 2).copy(); ds[:m, :, 1] = 0
+    b.set_dof_state(ds.reshape(-1, 2))
+    b.set_reset(np.zeros(n, np.int64)); b.set_progress(np.zeros(n, np.int64))
+
+
+def check_box_asset_rest_height(make):
+    """asset.stl: False (kick_env.py:266-276, soccerbot_box.urdf): the torso rests on its URDF collision box (back face 65 mm
+    behind the torso origin) instead of the stl mesh's bounding box (40 mm): lying on the back the root settles 25 mm higher."""
+    n = 4
+    z = {}
+    for box in (False, True):
+        b = make(n, box=box, seed=5)
+        _lie_on_back(b, n)
+        for _ in range(90):
+            b.set_reset(np.zeros(n, np.int64))   # the fall would end the episode: keep the state, watch the physics only
+            b.step(np.zeros((n, 18), np.float32))
+        z[box] = np.array(b.root_states).reshape(n, b.nact, 13)[:, 0, 2].copy()
+    assert np.all(np.abs(z[False] - 0.040) < 0.006), z
+    assert np.all(np.abs(z[True] - 0.065) < 0.006), z
+    np.testing.assert_allclose(z[True] - z[False], 0.025, atol=0.003)
+
+
+def test_oracle_box_asset_rest_height(): check_box_asset_rest_height(oracle)
+
+
+def test_oracle_box_asset_equals_stl_without_upper_body_contact():
+    """The box asset changes collision shapes of the torso / head / arms only: a standing, kicking robot whose upper body touches
+    nothing follows the stl asset's trajectory bit for bit (same dynamics, leg boxes, foot points)."""
+    n = 8
+    a, b = oracle(n, seed=9), oracle(n, seed=9, box=True)
+    rng = np.random.default_rng(1)
+    for t in range(12):
+        act = rng.uniform(-0.3, 0.3, (n, 18)).astype(np.float32)
+        a.step(act); b.step(act)
+    np.testing.assert_array_equal(a.dof_state, b.dof_state)
+    np.testing.assert_array_equal(a.root_states, b.root_states)
+    np.testing.assert_array_equal(a.obs, b.obs)
+
+
+def test_box_with_cleats_is_rejected_by_the_env_class():
+    from bez_isaacgym_amd.tasks.kick_env import KickEnv
+    from bez_isaacgym_amd.utils.config import load_config
+    cfg = load_config(["task=bez_kick", "num_envs=64", "headless=True"])["task"]
+    cfg["env"]["asset"]["stl"] = False; cfg["env"]["asset"]["cleats"] = True
+    with pytest.raises(NotImplementedError, match="soccerbot_box_sensor"):   # raised before any device is touched
+        KickEnv(cfg, sim_device="cuda:0", graphics_device_id=-1, headless=True)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("task", ["walk", "orient"])
 @pytest.mark.parametrize("tag", ["normal", "edge"])
@@ -129,14 +189,28 @@ def test_hip_task_golden(TG, task, tag): check_task(hip(N, task="bez_" + task), 
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("task,cleats", VARIANTS)
-def test_hip_variant_step_parity(task, cleats):
-    """The whole fused step of every variant against the oracle, resynchronised each step (same bars as bez_kick)."""
+def test_hip_box_asset_rest_height(): check_box_asset_rest_height(hip)
+
+
+@pytest.mark.gpu
+def test_hip_box_with_cleats_is_rejected():
+    from bez_isaacgym_amd.sim import BezSim
+    with pytest.raises(RuntimeError, match="soccerbot_box_sensor"):
+        BezSim(make_cfg(64, cleats=True, box=True))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("task,cleats,box", [(t, c, False) for t, c in VARIANTS] + [("bez_kick", False, True), ("bez_walk", False, True)])
+def test_hip_variant_step_parity(task, cleats, box):
+    """The whole fused step of every variant against the oracle, resynchronised each step (same bars as bez_kick).  The box-asset
+    cases start from fallen poses too (half the envs lie on their back): their upper-body contact points are what differs."""
     n = 128
-    o, g = oracle(n, task=task, cleats=cleats, seed=7), hip(n, task=task, cleats=cleats, seed=7)
+    o, g = oracle(n, task=task, cleats=cleats, box=box, seed=7), hip(n, task=task, cleats=cleats, box=box, seed=7)
     np.testing.assert_array_equal(o.dof_state, g.dof_state)
     if task != "bez_kick":
         np.testing.assert_array_equal(o.goal, g.goal)
+    if box:
+        _lie_on_back(o, n, n // 2)   # the other half keeps the reset state of the other variants
     rng = np.random.default_rng(3)
     for t in range(25):
         g.set_root_states(o.root_states); g.set_dof_state(o.dof_state); g.set_contact_forces(o.contact_forces)
@@ -167,8 +241,8 @@ def test_hip_variant_step_parity(task, cleats):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("task,cleats", [("bez_walk", False), ("bez_orient", False), ("bez_kick", True)])
-def test_hip_task_env_surface_and_ppo(task, cleats):
+@pytest.mark.parametrize("task,cleats,box", [("bez_walk", False, False), ("bez_orient", False, False), ("bez_kick", True, False), ("bez_kick", False, True)])
+def test_hip_task_env_surface_and_ppo(task, cleats, box):
     """Walk/Orient/Kick(cleats) env classes: registry, shapes, a few PPO epochs through the reference's CLI contract."""
     import torch
     from bez_isaacgym_amd.ppo.a2c_continuous import A2CAgent
@@ -178,6 +252,7 @@ def test_hip_task_env_surface_and_ppo(task, cleats):
     cfg = load_config(["task=%s" % task, "num_envs=256", "headless=True"])
     cfg["task"]["seed"] = 42
     cfg["task"]["env"]["asset"]["cleats"] = cleats
+    cfg["task"]["env"]["asset"]["stl"] = not box   # kick_env.py:266-276: stl False -> soccerbot_box.urdf
     venv = RLGPUEnv("rlgpu", 256, env_creator=get_rlgames_env_creator(cfg["task"], task, "cuda:0", "cuda:0", 0, True))
     env = venv.env
     assert type(env) is isaacgym_task_map[task]
