@@ -218,7 +218,7 @@ BEZ_DEV void ws_upper_role(const Params& P, float* lds, int lane, int e, bool ac
     RootView R = load_root_view(lds, lane);
     {  // leg<->leg self-collision, part 0: overlaps the legs' pass 1
       SelfCaps K;
-      ws_self_fk<0>(lds, lane, R.E0, R.V0, K);
+      ws_self_fk<0>(lds, lane, R.E0, R.V0, K, false, quirk_rz<CL>(P.flags));
       ws_self_pairs<0>(P, D.mu, lds, lane, K);
     }
     P3 p3[6];
@@ -323,7 +323,7 @@ BEZ_DEV void ws_root_role(const Params& P, float* lds, int lane, int e, bool act
     add_to(IA0, Kc); pA0 = pA0 + pc;
     BallBody ball = ball_setup(P, D.mu, D.g, ball_pos.z, ball_ang, ball_lin);
     SelfCaps K;  // this wave's share of the leg<->leg self-collision: kinematics now (the legs run pass 1), pairs after B1b
-    ws_self_fk<1>(lds, lane, E0, V0, K);
+    ws_self_fk<1>(lds, lane, E0, V0, K, false, quirk_rz<CL>(P.flags));
     ws_self_pin<1>(K);
     WS_STAMP(3, 2 + 8 * s);
     ws_barrier();  // B1: both legs' ball/box candidates are in LDS

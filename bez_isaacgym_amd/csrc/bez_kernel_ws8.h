@@ -135,11 +135,11 @@ BEZ_DEV void publish_cand(float* lds, int lane, int c0, const BallSel& sel, SV V
 template <int B0, int NFK>
 struct LegFrames { M3 E[NFK - B0]; V3 r[NFK - B0]; SV V[NFK - B0]; };
 template <int LEG_FIRST, int B0, int NFK>
-BEZ_DEV void leg_frames(const float* lds, int lane, int side, const M3& E0, SV V0, LegFrames<B0, NFK>& F) {
+BEZ_DEV void leg_frames(const float* lds, int lane, int side, const M3& E0, SV V0, LegFrames<B0, NFK>& F, float quirk_z = BEZ_QUIRK_RZ) {
   M3 E = E0; V3 r = mk(0, 0, 0); SV V = V0, Sj, cbj;
   static_for<NFK>([&](auto I) {
     constexpr int i = decltype(I)::value;
-    link_kinematics<LEG_FIRST + i>(XS(X_LEGQ + side * 12 + i), XS(X_LEGQ + side * 12 + 6 + i), E, r, V, Sj, cbj);
+    link_kinematics<LEG_FIRST + i>(XS(X_LEGQ + side * 12 + i), XS(X_LEGQ + side * 12 + 6 + i), E, r, V, Sj, cbj, quirk_z);
     if constexpr (i >= B0) { F.E[i - B0] = E; F.r[i - B0] = r; F.V[i - B0] = V; }
   });
 }
@@ -386,7 +386,7 @@ BEZ_DEV void head_role(const Params& P, float* lds, int lane, int e, bool active
       constexpr int HI = cand_split<CL>();
       LegFrames<1, HI> FL, FR;
       leg_frames<5, 1, HI>(lds, lane, 0, R.E0, R.V0, FL);
-      leg_frames<13, 1, HI>(lds, lane, 1, R.E0, R.V0, FR);
+      leg_frames<13, 1, HI>(lds, lane, 1, R.E0, R.V0, FR, quirk_rz<CL>(P.flags));
       if (s > 0) ws_barrier();  // B5 of the previous substep
       const V3 bc = xs_load_v3(lds, lane, X_BALL) - R.pos;
       leg_box_tests<5, 1, HI>(FL, bc, lds, lane, X_CANDH);
@@ -429,7 +429,7 @@ BEZ_DEV void cand_arm_role(const Params& P, float* lds, int lane, int e, bool ac
       const RootOnly R = load_root_only(lds, lane);
       constexpr int LO0 = cand_split<CL>(), LO1 = cand_lo_end<CL>();
       LegFrames<LO0, LO1> F;
-      leg_frames<LEG_FIRST, LO0, LO1>(lds, lane, side, R.E0, R.V0, F);
+      leg_frames<LEG_FIRST, LO0, LO1>(lds, lane, side, R.E0, R.V0, F, quirk_rz<CL>(P.flags));
       if (s > 0) ws_barrier();  // B5 of the previous substep
       leg_box_tests<LEG_FIRST, LO0, LO1>(F, xs_load_v3(lds, lane, X_BALL) - R.pos, lds, lane, X_CAND + side * 14);
     }
@@ -543,7 +543,7 @@ BEZ_DEV void self_role(const Params& P, float* lds, int lane, int e, bool active
     {  // kinematics of both legs: one third in, meet the other roles at B5 of the previous substep (this role does not read the ball)
       const M3 E0 = quat_to_mat(XS(X_ROOT + 3), XS(X_ROOT + 4), XS(X_ROOT + 5), XS(X_ROOT + 6));
       const SV V0 = mksv(xs_load_v3(lds, lane, X_ROOT + 10), xs_load_v3(lds, lane, X_ROOT + 7));
-      ws_self_fk<PART, BEZ_W8_SELF_BAR>(lds, lane, E0, V0, K, s > 0);
+      ws_self_fk<PART, BEZ_W8_SELF_BAR>(lds, lane, E0, V0, K, s > 0, quirk_rz<CL>(P.flags));
       ws_self_pin<PART>(K);
     }
     WS_STAMP(6 + PART, 2 + 8 * s);

@@ -83,11 +83,17 @@ template <bool CL> BEZ_DEV constexpr double pt_pos(int i, int k) { return CL ? B
 // the same coordinate for the asset the sim was created with: the box asset (BEZ_FLAG_BOX_ASSET) moves the upper-body guard
 // points only; where the two tables agree (feet) this folds to the constant, elsewhere it is one scalar select of two literals
 template <bool CL> BEZ_DEV float pt_pos_of(const Params& P, int i, int k) {
-  if constexpr (CL) return (float)BEZ_PT_POS_CL[i][k];
-  else {
-    const float a = (float)BEZ_PT_POS[i][k], b = (float)BEZ_PT_POS_BOX[i][k];
-    return a == b ? a : ((P.flags & BEZ_FLAG_BOX_ASSET) ? b : a);
-  }
+  // foot / cleat points (the first 8) are the stl assets'; the upper-body points are the same with and without cleats
+  const float a = CL ? (float)BEZ_PT_POS_CL[i][k] : (float)BEZ_PT_POS[i][k], b = i < 8 ? a : (float)BEZ_PT_POS_BOX[i][k];
+  return a == b ? a : ((P.flags & BEZ_FLAG_BOX_ASSET) ? b : a);
+}
+// soccerbot_box_sensor.urdf (box asset WITH cleats) also moves one joint origin: z of link BEZ_BOXCL_LINK's joint in its parent.
+// link_kinematics takes it as an argument whose default is the common constant: only CL code pays the scalar select.
+constexpr float BEZ_QUIRK_RZ = (float)BEZ_LINK_XYZ[BEZ_BOXCL_LINK][2];
+static_assert(BEZ_LINK_XYZ[BEZ_BOXCL_LINK][0] == 0.0 && BEZ_LINK_XYZ[BEZ_BOXCL_LINK][1] == 0.0, "the quirk joint origin is a pure z offset");
+template <bool CL> BEZ_DEV float quirk_rz(uint32_t flags) {
+  if constexpr (!CL) return BEZ_QUIRK_RZ;
+  else return (flags & BEZ_FLAG_BOX_ASSET) ? (float)BEZ_BOXCL_LINK_Z : BEZ_QUIRK_RZ;
 }
 template <bool CL> BEZ_DEV constexpr int pt_body(int i) { return CL ? BEZ_PT_BODY_CL[i] : BEZ_PT_BODY[i]; }
 template <bool CL> BEZ_DEV constexpr int lfoot_body() { return CL ? BEZ_LFOOT_BODY_CL : BEZ_LFOOT_BODY; }
@@ -401,14 +407,15 @@ BEZ_DEV void link_capsules(const M3& E, V3 r, SV V, V3* c0, V3* c1, SV* cV) {
 
 // ---- one kinematic step down the tree: child frame / joint axis / velocity from the parent's
 template <int L>
-BEZ_DEV void link_kinematics(float q, float qd, M3& E, V3& r, SV& V, SV& S, SV& cb) {
+BEZ_DEV void link_kinematics(float q, float qd, M3& E, V3& r, SV& V, SV& S, SV& cb, float quirk_z = BEZ_QUIRK_RZ) {
   constexpr int ax = axis_index(L);
   constexpr float sg = axis_sign(L);
   V3 a = col(E, ax) * sg;  // joint axis in world (parent frame column; unchanged by the joint rotation)
   constexpr float tx = (float)BEZ_LINK_XYZ[L][0], ty = (float)BEZ_LINK_XYZ[L][1], tz = (float)BEZ_LINK_XYZ[L][2];
   if (tx != 0.f) r = fma3(col(E, 0), tx, r);
   if (ty != 0.f) r = fma3(col(E, 1), ty, r);
-  if (tz != 0.f) r = fma3(col(E, 2), tz, r);
+  if constexpr (L == BEZ_BOXCL_LINK) r = fma3(col(E, 2), quirk_z, r);  // see quirk_rz
+  else if (tz != 0.f) r = fma3(col(E, 2), tz, r);
   float s, c;
   fsincos(sg * q, &s, &c);
   E = rotate_about(E, ax, s, c);
@@ -416,18 +423,6 @@ BEZ_DEV void link_kinematics(float q, float qd, M3& E, V3& r, SV& V, SV& S, SV& 
   SV vj = S * qd;
   V = V + vj;
   cb = crm(V, vj);
-}
-template <int L>
-BEZ_DEV void link_frame_only(float q, M3& E, V3& r) {
-  constexpr int ax = axis_index(L);
-  constexpr float sg = axis_sign(L);
-  constexpr float tx = (float)BEZ_LINK_XYZ[L][0], ty = (float)BEZ_LINK_XYZ[L][1], tz = (float)BEZ_LINK_XYZ[L][2];
-  if (tx != 0.f) r = fma3(col(E, 0), tx, r);
-  if (ty != 0.f) r = fma3(col(E, 1), ty, r);
-  if (tz != 0.f) r = fma3(col(E, 2), tz, r);
-  float s, c;
-  fsincos(sg * q, &s, &c);
-  E = rotate_about(E, ax, s, c);
 }
 
 // rigid-body inertia of link L about O in compact form + its bias force (velocity product - gravity)
@@ -544,7 +539,7 @@ BEZ_DEV void chain_up(const Params& P, const EnvDyn& D, const EnvState& S, const
   static_for<LEN>([&](auto I) {
     constexpr int i = decltype(I)::value;
     constexpr int L = FIRST + i;
-    link_kinematics<L>(S.q[L - 1], S.qd[L - 1], E, r, V, Sl[i], cbl[i]);
+    link_kinematics<L>(S.q[L - 1], S.qd[L - 1], E, r, V, Sl[i], cbl[i], quirk_rz<CL>(P.flags));
     link_inertia<L, CL>(D.mass_scale[L], D.g, E, r, V, LI[i], pAl[i]);
     if constexpr (link_has_box(L)) {
       if (sel.link == L) ball_link_contact(P, D.mu, S.ball_ang, S.ball_lin, ball, bc, V, sel);
@@ -671,7 +666,7 @@ BEZ_DEV void substep(const Params& P, const EnvDyn& D, EnvState& S, const float*
     E = E0; r = mk(0, 0, 0); V = V0;
     static_for<6>([&](auto I) {
       constexpr int L = 13 + decltype(I)::value;
-      link_kinematics<L>(S.q[L - 1], S.qd[L - 1], E, r, V, Sj, cbj);
+      link_kinematics<L>(S.q[L - 1], S.qd[L - 1], E, r, V, Sj, cbj, quirk_rz<CL>(P.flags));
       if constexpr (link_has_box(L)) { test_box<link_box(L)>(E, r, bc, sel); link_capsules<L>(E, r, V, cap0, cap1, capV); }
     });
     test_torso_box(P, E0, mk(0, 0, 0), bc, sel);

@@ -206,7 +206,7 @@ BEZ_DEV void mat_to_quat(const M3& R, float q[4]) {
 
 // gym.refresh_rigid_body_state_tensor: forward kinematics of all 21 robot bodies + the ball row
 template <bool CL>
-__global__ void refresh_rigid_body_kernel(const float* __restrict__ st, float* __restrict__ out, int n, int has_ball) {
+__global__ void refresh_rigid_body_kernel(const float* __restrict__ st, float* __restrict__ out, int n, int has_ball, uint32_t flags) {
   int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= n) return;
   EnvState S;
@@ -220,7 +220,7 @@ __global__ void refresh_rigid_body_kernel(const float* __restrict__ st, float* _
     constexpr int p = BEZ_LINK_PARENT[L];
     E[L] = E[p]; r[L] = r[p]; V[L] = V[p];
     SV Sj, cb;
-    link_kinematics<L>(S.q[L - 1], S.qd[L - 1], E[L], r[L], V[L], Sj, cb);
+    link_kinematics<L>(S.q[L - 1], S.qd[L - 1], E[L], r[L], V[L], Sj, cb, quirk_rz<CL>(flags));
   });
   constexpr int NB = nb_of<CL>();
   const int nbe = NB + (has_ball ? 1 : 0);
@@ -381,10 +381,6 @@ int bez_sim_create(const BezSimConfig* cfg, int device_id, BezSim** out) {
   s->cfg = *cfg; s->device = device_id; s->n = cfg->num_envs;
   if (cfg->task < BEZ_TASK_KICK || cfg->task > BEZ_TASK_ORIENT) { delete s; return fail(nullptr, -1, "bez_sim_create: unknown task"); }
   s->cleats = (cfg->flags & BEZ_FLAG_CLEATS) != 0;
-  if (s->cleats && (cfg->flags & BEZ_FLAG_BOX_ASSET)) {
-    delete s;
-    return fail(nullptr, -1, "bez_sim_create: BEZ_FLAG_BOX_ASSET with BEZ_FLAG_CLEATS (soccerbot_box_sensor.urdf) is not compiled in: that URDF moves the right ankle joint");
-  }
   s->kernel = kernel_from_env();
   s->has_ball = cfg->task == BEZ_TASK_KICK;                    // walk_env.py / orient_env.py create no ball actor
   s->nb = s->cleats ? BEZ_NB_CL : BEZ_NB;
@@ -451,8 +447,8 @@ int bez_sim_refresh_tensor(BezSim* s, int which, void* stream_) {
     case BEZ_TENSOR_ROOT_STATE: hipLaunchKernelGGL(refresh_root_kernel, blocks((size_t)n * 13 * s->nact), dim3(TB), 0, stream, s->state, s->root_states, n, s->nact); break;
     case BEZ_TENSOR_DOF_STATE: hipLaunchKernelGGL(refresh_dof_kernel, blocks((size_t)n * BEZ_ND * 2), dim3(TB), 0, stream, s->state, s->dof_state, n); break;
     case BEZ_TENSOR_RIGID_BODY_STATE:
-      if (s->cleats) hipLaunchKernelGGL(refresh_rigid_body_kernel<true>, dim3((n + 63) / 64), dim3(64), 0, stream, s->state, s->rigid_body, n, (int)s->has_ball);
-      else hipLaunchKernelGGL(refresh_rigid_body_kernel<false>, dim3((n + 63) / 64), dim3(64), 0, stream, s->state, s->rigid_body, n, (int)s->has_ball);
+      if (s->cleats) hipLaunchKernelGGL(refresh_rigid_body_kernel<true>, dim3((n + 63) / 64), dim3(64), 0, stream, s->state, s->rigid_body, n, (int)s->has_ball, s->cfg.flags);
+      else hipLaunchKernelGGL(refresh_rigid_body_kernel<false>, dim3((n + 63) / 64), dim3(64), 0, stream, s->state, s->rigid_body, n, (int)s->has_ball, s->cfg.flags);
       break;
     case BEZ_TENSOR_NET_CONTACT_FORCE: hipLaunchKernelGGL(refresh_rows_kernel, blocks((size_t)n * s->nbe * 3), dim3(TB), 0, stream, s->state, s->contact, n, (int)F_CF, s->nbe * 3); break;
     case BEZ_TENSOR_DOF_TARGET: hipLaunchKernelGGL(refresh_rows_kernel, blocks((size_t)n * BEZ_ND), dim3(TB), 0, stream, s->state, s->targets_aos, n, (int)F_TARGET, BEZ_ND); break;

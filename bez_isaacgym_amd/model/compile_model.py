@@ -425,15 +425,19 @@ def emit_header(m, mc=None, mb=None, mbc=None):
                     assert qa["p"] == qb["p"]
             assert a["body_names"] == b["body_names"] and a["dof_lower"] == b["dof_lower"] and a["dof_upper"] == b["dof_upper"]
         same_dynamics(m, mb)
-        # soccerbot_box_sensor.urdf (box + cleats) is NOT the same robot: its right ankle joint sits at z = -0.0827 instead of
-        # -0.0865 (urdf right_leg_motor_4); everything else matches.  That variant is not compiled in (bez_sim_create rejects it).
+        # soccerbot_box_sensor.urdf (box + cleats) differs from soccerbot_stl_sensor.urdf in ONE dynamic constant: its right ankle
+        # joint sits at z = -0.0827 instead of -0.0865 (urdf right_leg_motor_4).  Everything else matches (asserted).
         same_dynamics(mc, mbc, known=(("/right_ankle", "xyz"),))
-        ra = [l for l in mbc["links"] if l["name"] == "/right_ankle"][0]["xyz"]
-        assert ra == [0.0, 0.0, -0.0827], ra
+        qi = [i for i, l in enumerate(mbc["links"]) if l["name"] == "/right_ankle"][0]
+        ra, rs_ = mbc["links"][qi]["xyz"], mc["links"][qi]["xyz"]
+        assert ra[0] == rs_[0] == 0.0 and ra[1] == rs_[1] == 0.0 and ra[2] != rs_[2], (ra, rs_)
+        assert [q["p"] for q in mbc["ground_points"]][8:] == [q["p"] for q in mb["ground_points"]][8:]   # upper-body points: the box asset's
+        assert [q["p"] for q in mbc["ground_points"]][:8] == [q["p"] for q in mc["ground_points"]][:8]   # cleat points: the cleats asset's
         o.append("/* ---- box assets (asset.stl: False -> soccerbot_box.urdf / soccerbot_box_sensor.urdf, kick_env.py:266-276; BEZ_FLAG_BOX_ASSET):\n"
                  " * dynamics, leg boxes, capsules and foot / cleat points are those of the stl assets; the upper-body guard points come from the\n"
-                 " * URDF's own torso / head / forearm collision boxes and the ball <-> torso box is the URDF's torso box.  soccerbot_box.urdf only:\n"
-                 " * soccerbot_box_sensor.urdf moves the right ankle joint (z -0.0827 instead of -0.0865) and is not compiled in. */")
+                 " * URDF's own torso / head / forearm collision boxes and the ball <-> torso box is the URDF's torso box.  With cleats\n"
+                 " * (soccerbot_box_sensor.urdf) one joint origin differs as well: link BEZ_BOXCL_LINK sits at z = BEZ_BOXCL_LINK_Z. */")
+        o.append("#define BEZ_BOXCL_LINK %d\n#define BEZ_BOXCL_LINK_Z %s" % (qi, fmt(ra[2])))
         o.append("#define BEZ_TORSO_BOX %d" % (len(m["boxes"]) - 1))
         o.append("BEZ_TBL double BEZ_PT_POS_BOX[BEZ_NPT][3] = {%s};" % ", ".join(arr(q["p"]) for q in mb["ground_points"]))
         o.append("BEZ_TBL double BEZ_TORSO_BOX_CENTER_BOX[3] = %s;" % arr(mb["boxes"][-1]["center"]))
@@ -449,7 +453,8 @@ def main():
     m["cleats"] = {k: mc[k] for k in ("num_bodies", "body_names", "body_link", "body_offset", "links", "ground_points", "total_mass")}
     mb = build(os.path.join(REF, "resources/assets/bez/model/soccerbot_box.urdf"), box=True)
     mbc = build(os.path.join(REF, "resources/assets/bez/model/soccerbot_box_sensor.urdf"), cleats=True, box=True)
-    m["box_asset"] = {"ground_points": mb["ground_points"], "torso_box": mb["boxes"][-1]}
+    m["box_asset"] = {"ground_points": mb["ground_points"], "torso_box": mb["boxes"][-1],
+                      "cleats_right_ankle_xyz": [l for l in mbc["links"] if l["name"] == "/right_ankle"][0]["xyz"]}
     with open(OUT_JSON, "w") as f:
         json.dump(m, f, indent=1)
     with open(OUT_H, "w") as f:

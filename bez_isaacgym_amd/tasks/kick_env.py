@@ -63,13 +63,9 @@ class KickEnv(VecTask):
                 env["ballInitState"]["vLinear"] + env["ballInitState"]["vAngular"]
         goal = env["goalState"]["goal"]
         self.cleats = bool(env["asset"]["cleats"])  # True -> soccerbot_stl_sensor.urdf: 29 bodies, per-cleat contact rows
-        # asset.stl: False -> soccerbot_box.urdf (kick_env.py:272-276): the same robot with box collision shapes on the torso /
-        # head / arms (BEZ_FLAG_BOX_ASSET).  soccerbot_box_sensor.urdf (box + cleats) is a different robot -- its right ankle joint
-        # sits 3.8 mm higher -- and is the one asset of the four that is not compiled into the kernels.
+        # asset.stl: False -> soccerbot_box.urdf / soccerbot_box_sensor.urdf (kick_env.py:272-276): the same robot with box
+        # collision shapes on the torso / head / arms (BEZ_FLAG_BOX_ASSET, set by abi.config_from_task_cfg)
         self.box_asset = not bool(env["asset"]["stl"])
-        if self.box_asset and self.cleats:
-            raise NotImplementedError("asset.stl: False with asset.cleats: True selects soccerbot_box_sensor.urdf, whose right ankle joint "
-                                      "differs from the other three assets; it is not compiled into the kernels")
         self.debug_rewards = env["debug"]["rewards"]
         self.named_default_joint_angles = env["readyJointAngles"]
         self.max_episode_length_s = env["learn"]["episodeLength_s"]

@@ -55,10 +55,9 @@ extern "C" {
 
 #define BEZ_FLAG_CLEATS 16u /* asset.cleats: True -> soccerbot_stl_sensor.urdf: 29 robot bodies, per-cleat contact rows \
                                13:17 / 25:29 and compute_feet_sensors_cleats (kick_env.py:187-191,267-276,1044-1069) */
-#define BEZ_FLAG_BOX_ASSET 32u /* asset.stl: False -> soccerbot_box.urdf (kick_env.py:266-276): the stl asset's dynamics with the \
-                                  URDF's own torso / head / forearm collision boxes (upper-body ground points, ball <-> torso box). \
-                                  Not combinable with BEZ_FLAG_CLEATS: soccerbot_box_sensor.urdf is a different robot (right ankle \
-                                  joint 3.8 mm higher) and is not compiled in -- bez_sim_create returns an error */
+#define BEZ_FLAG_BOX_ASSET 32u /* asset.stl: False -> soccerbot_box.urdf / soccerbot_box_sensor.urdf (kick_env.py:266-276): the stl \
+                                  asset's dynamics with the URDF's own torso / head / forearm collision boxes (upper-body ground \
+                                  points, ball <-> torso box); with BEZ_FLAG_CLEATS also that URDF's right ankle joint origin */
 
 /* Tasks sharing the robot, the physics and the tensor API; they differ in the post-physics logic (observation tail,
  * reward, reset conditions, goal sampling) and in the ball actor (bez_kick only). */

@@ -56,9 +56,12 @@ static real m_mass(const BezSimConfig* c, int l) { return (real)(m_cl(c) ? BEZ_L
 static const double* m_com(const BezSimConfig* c, int l) { return m_cl(c) ? BEZ_LINK_COM_CL[l] : BEZ_LINK_COM[l]; }
 static const double* m_inertia(const BezSimConfig* c, int l) { return m_cl(c) ? BEZ_LINK_INERTIA_CL[l] : BEZ_LINK_INERTIA[l]; }
 /* box asset (BEZ_FLAG_BOX_ASSET, asset.stl: False, kick_env.py:266-276): soccerbot_box.urdf -- the default asset's dynamics with
- * the URDF's own torso / head / forearm collision boxes (upper-body ground points, ball <-> torso box); never with cleats */
+ * the URDF's own torso / head / forearm collision boxes (upper-body ground points, ball <-> torso box) */
 static int m_box(const BezSimConfig* c) { return (c->flags & BEZ_FLAG_BOX_ASSET) != 0; }
-static const double* m_pt_pos(const BezSimConfig* c, int i) { return m_cl(c) ? BEZ_PT_POS_CL[i] : (m_box(c) ? BEZ_PT_POS_BOX[i] : BEZ_PT_POS[i]); }
+/* foot / cleat points (the first 8): the stl assets'; upper-body points: the box asset's, with and without cleats */
+static const double* m_pt_pos(const BezSimConfig* c, int i) { return (m_box(c) && i >= 8) ? BEZ_PT_POS_BOX[i] : (m_cl(c) ? BEZ_PT_POS_CL[i] : BEZ_PT_POS[i]); }
+/* soccerbot_box_sensor.urdf (box + cleats) moves one joint origin: link BEZ_BOXCL_LINK sits at z = BEZ_BOXCL_LINK_Z in its parent */
+static double m_link_z(const BezSimConfig* c, int l) { return (l == BEZ_BOXCL_LINK && m_box(c) && m_cl(c)) ? BEZ_BOXCL_LINK_Z : BEZ_LINK_XYZ[l][2]; }
 static const double* m_box_center(const BezSimConfig* c, int b) { return (b == BEZ_TORSO_BOX && m_box(c)) ? BEZ_TORSO_BOX_CENTER_BOX : BEZ_BOX_CENTER[b]; }
 static const double* m_box_half(const BezSimConfig* c, int b) { return (b == BEZ_TORSO_BOX && m_box(c)) ? BEZ_TORSO_BOX_HALF_BOX : BEZ_BOX_HALF[b]; }
 static int m_pt_body(const BezSimConfig* c, int i) { return m_cl(c) ? BEZ_PT_BODY_CL[i] : BEZ_PT_BODY[i]; }
@@ -275,14 +278,14 @@ typedef struct {
   V3 a[NL];  /* joint axis in world */
 } Kin;
 
-static void forward_kinematics(const Env* e, Kin* k) {
+static void forward_kinematics(const BezSimConfig* c, const Env* e, Kin* k) {
   k->E[0] = quat_to_mat(e->root_quat);
   k->r[0] = v3(0, 0, 0);
   k->a[0] = v3(0, 0, 0);
   for (int l = 1; l < NL; ++l) {
     int p = BEZ_LINK_PARENT[l];
     V3 ax = v3((real)BEZ_LINK_AXIS_VEC[l][0], (real)BEZ_LINK_AXIS_VEC[l][1], (real)BEZ_LINK_AXIS_VEC[l][2]);
-    V3 t = v3((real)BEZ_LINK_XYZ[l][0], (real)BEZ_LINK_XYZ[l][1], (real)BEZ_LINK_XYZ[l][2]);
+    V3 t = v3((real)BEZ_LINK_XYZ[l][0], (real)BEZ_LINK_XYZ[l][1], (real)m_link_z(c, l));
     k->r[l] = v3add(k->r[p], m3mulv(&k->E[p], t));
     M3 Rj = rot_axis(ax, e->q[l - 1]);
     k->E[l] = m3mul(&k->E[p], &Rj);
@@ -387,7 +390,7 @@ static void self_collision(const BezSimConfig* c, real mu, const Kin* k, const S
  * known-answer tests, with tau_in as the applied joint torques). */
 static void dynamics(const BezSimConfig* c, const Env* e, real h, int mode, const real* tau_in, Dyn* out) {
   Kin k;
-  forward_kinematics(e, &k);
+  forward_kinematics(c, e, &k);
   const int nb = m_nb(c); /* row of the ball */
   V3 g = v3(e->gravity[0], e->gravity[1], e->gravity[2]);
   SV V[NL], S[NL], cb[NL], pA[NL];
@@ -1030,7 +1033,7 @@ void bez_oracle_get_rigid_body_states(void* h, float* out) {
   for (int i = 0; i < o->n; ++i) {
     const Env* e = &o->env[i];
     Kin k;
-    forward_kinematics(e, &k);
+    forward_kinematics(&o->cfg, e, &k);
     SV V[NL];
     V[0] = sv(v3(e->root_ang[0], e->root_ang[1], e->root_ang[2]), v3(e->root_lin[0], e->root_lin[1], e->root_lin[2]));
     for (int l = 1; l < NL; ++l) V[l] = sv_add(V[BEZ_LINK_PARENT[l]], sv_scale(sv(k.a[l], v3cross(k.r[l], k.a[l])), e->qd[l - 1]));

@@ -173,13 +173,18 @@ def test_oracle_box_asset_equals_stl_without_upper_body_contact():
     np.testing.assert_array_equal(a.obs, b.obs)
 
 
-def test_box_with_cleats_is_rejected_by_the_env_class():
-    from bez_isaacgym_amd.tasks.kick_env import KickEnv
-    from bez_isaacgym_amd.utils.config import load_config
-    cfg = load_config(["task=bez_kick", "num_envs=64", "headless=True"])["task"]
-    cfg["env"]["asset"]["stl"] = False; cfg["env"]["asset"]["cleats"] = True
-    with pytest.raises(NotImplementedError, match="soccerbot_box_sensor"):   # raised before any device is touched
-        KickEnv(cfg, sim_device="cuda:0", graphics_device_id=-1, headless=True)
+def test_oracle_box_cleats_asset_right_ankle():
+    """soccerbot_box_sensor.urdf (asset.stl: False, asset.cleats: True) is soccerbot_stl_sensor.urdf with box collision shapes and
+    ONE different joint origin: the right ankle sits 3.8 mm higher in the calve.  Body positions of the right ankle / foot / cleats
+    move by exactly that along the calve's z axis, the left leg and everything above stay put."""
+    n = 2
+    a, b = oracle(n, cleats=True, seed=3), oracle(n, cleats=True, box=True, seed=3)
+    pa, pb = (np.array(x.rigid_body_states).reshape(n, x.nbe, 13)[:, :, 0:3] for x in (a, b))
+    moved = np.linalg.norm(pb - pa, axis=2)
+    right_lower = [23] + list(range(24, 29))     # right ankle, right foot + its four cleats (Isaac order of the 29-body asset)
+    np.testing.assert_allclose(moved[:, right_lower], 0.0865 - 0.0827, atol=1e-6)
+    rest = [i for i in range(a.nbe) if i not in right_lower]
+    np.testing.assert_allclose(moved[:, rest], 0.0, atol=1e-7)
 
 
 @pytest.mark.gpu
@@ -192,15 +197,9 @@ def test_hip_task_golden(TG, task, tag): check_task(hip(N, task="bez_" + task), 
 def test_hip_box_asset_rest_height(): check_box_asset_rest_height(hip)
 
 
-@pytest.mark.gpu
-def test_hip_box_with_cleats_is_rejected():
-    from bez_isaacgym_amd.sim import BezSim
-    with pytest.raises(RuntimeError, match="soccerbot_box_sensor"):
-        BezSim(make_cfg(64, cleats=True, box=True))
-
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("task,cleats,box", [(t, c, False) for t, c in VARIANTS] + [("bez_kick", False, True), ("bez_walk", False, True)])
+@pytest.mark.parametrize("task,cleats,box", [(t, c, False) for t, c in VARIANTS] + [("bez_kick", False, True), ("bez_walk", False, True), ("bez_kick", True, True)])
 def test_hip_variant_step_parity(task, cleats, box):
     """The whole fused step of every variant against the oracle, resynchronised each step (same bars as bez_kick).  The box-asset
     cases start from fallen poses too (half the envs lie on their back): their upper-body contact points are what differs."""
@@ -220,13 +219,16 @@ def test_hip_variant_step_parity(task, cleats, box):
         np.testing.assert_array_equal(g.reset_buf, o.reset_buf)
         np.testing.assert_array_equal(g.progress_buf, o.progress_buf)
         do, dg = o.dof_state.reshape(n, 18, 2), g.dof_state.reshape(n, 18, 2)
-        np.testing.assert_allclose(dg[..., 0], do[..., 0], atol=1.5e-4)
-        np.testing.assert_allclose(dg[..., 1], do[..., 1], atol=1.5e-2)
+        # box cases: a relative term on top of the common bars.  Their trajectories visit one fast joint event the other variants do
+        # not (box + cleats, step 19, a standing env: knee at -5.04 rad/s, HIP - oracle = 2.0e-2 rad/s = 0.4 %, 1.7e-4 rad on the angle)
+        br = 5e-3 if box else 0.0
+        np.testing.assert_allclose(dg[..., 0], do[..., 0], atol=1.5e-4, rtol=br * 0.04)
+        np.testing.assert_allclose(dg[..., 1], do[..., 1], atol=1.5e-2, rtol=br)
         ro, rg = o.root_states.reshape(n, o.nact, 13), g.root_states.reshape(n, o.nact, 13)
         np.testing.assert_allclose(rg[..., 0:7], ro[..., 0:7], atol=5e-5)
         np.testing.assert_allclose(rg[..., 7:13], ro[..., 7:13], atol=6e-3)
         np.testing.assert_allclose(g.contact_forces, o.contact_forces, rtol=0.02, atol=0.05)
-        np.testing.assert_allclose(g.obs[:, :44], o.obs[:, :44], atol=2e-2)
+        np.testing.assert_allclose(g.obs[:, :44], o.obs[:, :44], atol=2e-2, rtol=br)
         np.testing.assert_allclose(g.rew, o.rew, atol=0.2 if task == "bez_walk" else 2e-3, rtol=1e-3)  # bez_walk: 10 * forward speed
         if task != "bez_kick":
             np.testing.assert_array_equal(g.goal, o.goal)
@@ -241,7 +243,7 @@ def test_hip_variant_step_parity(task, cleats, box):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("task,cleats,box", [("bez_walk", False, False), ("bez_orient", False, False), ("bez_kick", True, False), ("bez_kick", False, True)])
+@pytest.mark.parametrize("task,cleats,box", [("bez_walk", False, False), ("bez_orient", False, False), ("bez_kick", True, False), ("bez_kick", False, True), ("bez_kick", True, True)])
 def test_hip_task_env_surface_and_ppo(task, cleats, box):
     """Walk/Orient/Kick(cleats) env classes: registry, shapes, a few PPO epochs through the reference's CLI contract."""
     import torch
