@@ -18,7 +18,7 @@
 // The deepest of the three ball candidates wins (left, right, torso on ties, the box order of the oracle); every owner decides
 // locally from the three published depths whether it is the winner, and only the winner evaluates the contact operands (a leg
 // wave skips that block altogether unless one of its 64 envs has a ball<->leg contact).
-// All roles execute the same barriers (B0, per substep B1 B1c B2 B3 B4 B5, B6, final).  512 threads, <= 256 VGPRs per wave.
+// All roles execute the same barriers (B0, per substep B1 B1c B2 B3 B4 B5).  512 threads, <= 256 VGPRs per wave.
 // The action / observation staging block aliases the X_IA slots (actions are consumed before the first X_IA store, the
 // observation rows are staged after the last X_IA load).
 #pragma once
@@ -35,7 +35,7 @@ enum : int {
   X_BALL = 13,     // pos3 lin3 ang3
   X_A0 = 22,       // torso spatial acceleration
   X_FL = 28,       // ball<->link force on the link (3) + contact point rel. ball centre (3)
-  X_PSUM = 34,     // per chain-owning role (0,1,2,4,5): sum of (default - q)^2 over its joints
+  X_PSUM = 34,     // per chain-owning role (0,1,2,4,5): sum of (default - q)^2 over its joints; slot 3 (no chain): X_RESETF
   X_CAND = 40,     // per leg: depth, link, n(3), P(3), V(6) of its deepest ball/box candidate among the lower boxes (roles 4 / 5) = 14 x 2
   X_TORSO = 68,    // depth of the torso-box candidate (role 3)
   X_LEGQ = 81,     // per leg: q(6) qd(6) at the start of the substep (read by the helper roles)
@@ -45,7 +45,8 @@ enum : int {
   X_IA = 439,      // 5 chains (left leg, right leg, head, left arm, right arm) x (Sym6 21 + bias 6); block 2 ends up holding head + arms
   X_BCN = 574,     // per leg: contact rows of the foot (B 9, C 6, F0 3), parked here across pass 2 (register pressure)
   X_CANDH = 610,   // per leg: the same 14 floats for the upper boxes (hip / thigh links), from role 2
-  X_SLOTS = 638
+  X_SLOTS = 638,
+  X_RESETF = X_PSUM + 3  // 1.0 where this step resets the env: its contact rows leave the kernel as zeros (written by role 7, read by the copy-out)
 };
 #ifndef BEZ_W8_CAND_SPLIT
 #define BEZ_W8_CAND_SPLIT 4
@@ -332,11 +333,11 @@ BEZ_DEV void leg_role(const Params& P, float* lds, int lane, int e, bool active,
     ws_barrier();  // B4
     WS_STAMP(side, 8 + 8 * s);
   }
-  ws_barrier();  // B5 of the last substep: final ball state published
-  WS_STAMP(side, 9 + 8 * (P.substeps - 1));
+  // joint-side post-physics in the window of the root's last ball update (needs nothing the ball publishes)
   ws_chain_epilogue<(FIRST == 5 ? 0 : 1), POST>(P, lds, lane, e, active, do_reset, episode, q, qd, target);
   WS_STAMP(side, 21);
-  ws_barrier();  // B6
+  ws_barrier();  // B5 of the last substep = the last barrier: contact rows, staged observation rows and pose-error sums complete
+  WS_STAMP(side, 9 + 8 * (P.substeps - 1));
 }
 
 // A 2-link chain (head / one arm) owned by a role: its state and the three passes, split at the barriers by the caller.
@@ -402,10 +403,9 @@ BEZ_DEV void head_role(const Params& P, float* lds, int lane, int e, bool active
     C.down(P, lds, lane, keep, first);
     ws_barrier();  // B4
   }
-  ws_barrier();  // B5 of the last substep
   ws_chain_epilogue<2, POST>(P, lds, lane, e, active, do_reset, episode, C.q, C.qd, C.target);
   WS_STAMP(2, 21);
-  ws_barrier();  // B6
+  ws_barrier();  // B5 of the last substep
 }
 
 // roles 4 / 5: the deepest ball<->leg-box candidate of one leg from this wave's own forward kinematics of that leg (window of
@@ -450,10 +450,9 @@ BEZ_DEV void cand_arm_role(const Params& P, float* lds, int lane, int e, bool ac
     C.down(P, lds, lane, keep, first);
     ws_barrier();  // B4
   }
-  ws_barrier();  // B5 of the last substep
   ws_chain_epilogue<ROLE, POST>(P, lds, lane, e, active, do_reset, episode, C.q, C.qd, C.target);
   WS_STAMP(ROLE, 21);
-  ws_barrier();  // B6
+  ws_barrier();  // B5 of the last substep
 }
 
 // ---- post-physics shares of the two pair roles (they are idle after B1c): the observation slots that do not depend on
@@ -504,17 +503,21 @@ template <bool CL>
 BEZ_DEV void post_feet(const Params& P, float* lds, int lane, int e, bool active, const PostIn& in) {
   const int n = P.n;
   float* st = P.state;
-  if (in.reset) {  // a reset env reports no contact forces
-#pragma unroll
-    for (int k = 0; k < (nb_of<CL>() + 1) * 3; ++k) XS(X_CF + k) = 0.f;
-  }
+  // a reset env reports no contact forces (kick_env.py:433-438: reset before the observation): its rows are zeroed on their way
+  // out (X_RESETF, the copy-out at the end of the kernel), and the feet logic below sees zeros
+  XS(X_RESETF) = in.reset ? 1.f : 0.f;
   CfOut co;
   co.base = nullptr; co.n = n;
   co.lf = xs_load_v3(lds, lane, X_CF + lfoot_body<CL>() * 3); co.rf = xs_load_v3(lds, lane, X_CF + rfoot_body<CL>() * 3);
+  if (in.reset) co.lf = co.rf = mk(0, 0, 0);
   float cleats[24];
   if (CL) {
 #pragma unroll
     for (int k = 0; k < 12; ++k) { cleats[k] = XS(X_CF + BEZ_LCLEAT_BODY_CL * 3 + k); cleats[12 + k] = XS(X_CF + BEZ_RCLEAT_BODY_CL * 3 + k); }
+    if (in.reset) {
+#pragma unroll
+      for (int k = 0; k < 24; ++k) cleats[k] = 0.f;
+    }
   }
   float feet[8], tail[18];
   obs_feet(P, co, CL ? cleats : nullptr, feet, tail);
@@ -555,13 +558,12 @@ BEZ_DEV void self_role(const Params& P, float* lds, int lane, int e, bool active
     ws_barrier();  // B3
     ws_barrier();  // B4
   }
-  ws_barrier();  // B5 of the last substep
-  if (POST) {
+  if (POST) {  // after B4 of the last substep: the root state (published before B4) and the robot's contact rows are final
     if (PART == 0) post_imu_orn(P, lds, lane, e, active, pin_);
     else post_feet<CL>(P, lds, lane, e, active, pin_);
   }
   WS_STAMP(6 + PART, 21);
-  ws_barrier();  // B6
+  ws_barrier();  // B5 of the last substep
 }
 
 template <bool PRE, bool POST, bool DR, bool CL>
@@ -685,10 +687,9 @@ BEZ_DEV void root_role(const Params& P, float* lds, int lane, int e, bool active
     const bool keep_l = true, first_l = last_only ? true : (P.substeps == 1);
     ball_update(keep_l, first_l);
   }
-  ws_barrier();  // B5 of the last substep: final ball state published
-  WS_STAMP(3, 9 + 8 * (P.substeps - 1));
-  // post-physics, root's share.  Before B6: bookkeeping, the pending reset of the root / ball state, the state stores.  After B6
-  // (pose-error sums of the chain roles are in LDS): the reward and the reset flag of the next step.
+  // post-physics, root's share.  Before the last B5 (the chain roles are busy with their joints' post-physics): bookkeeping, the
+  // pending reset of the root / ball state, the state stores.  After it (pose-error sums of the chain roles are in LDS): the
+  // reward and the reset flag of the next step, beside the other waves' copy-out.
   float goal_x = P.goal[0], goal_y = P.goal[1];
   int64_t timeout = 0;
   if (POST) {
@@ -721,8 +722,8 @@ BEZ_DEV void root_role(const Params& P, float* lds, int lane, int e, bool active
     sv(F_BALL_ANG, ball_ang.x); sv(F_BALL_ANG + 1, ball_ang.y); sv(F_BALL_ANG + 2, ball_ang.z);
   }
   WS_STAMP(3, 19);
-  ws_barrier();  // B6: pose-error sums of the chain roles are in LDS
-  WS_STAMP(3, 20);
+  ws_barrier();  // B5 of the last substep = the last barrier
+  WS_STAMP(3, 9 + 8 * (P.substeps - 1));
   if (POST) {
     const float pn = (((XS(X_PSUM + 2) + XS(X_PSUM + 4)) + XS(X_PSUM + 5)) + XS(X_PSUM + 0)) + XS(X_PSUM + 1);
     OrnOut orn; orn.ux = orn.uy = orn.gn = orn.ang_goal = 0.f;
@@ -767,17 +768,19 @@ __global__ __launch_bounds__(WS_BLOCK) void step_kernel_ws8(Params P) {
   else if (role == 5) cand_arm_role<13, 11, PRE, POST, DR, CL>(P, lds, lane, e, active, 1);
   else if (role == 6) self_role<0, POST, DR, CL>(P, lds, lane, e, active);
   else self_role<1, POST, DR, CL>(P, lds, lane, e, active);
-  // B6 was the last barrier: the contact-force rows and (with POST) the staged observation rows are complete in LDS.  The seven
-  // other waves copy them out while the root role is still busy with the reward.
+  // The last substep's B5 was the last barrier: the contact-force rows and (with POST) the staged observation rows are complete in
+  // LDS.  The seven other waves copy them out while the root role is still busy with the reward.
   if (role != 3) {
     constexpr int NT = WS_BLOCK - 64;
     const int ctid = tid - (role > 3 ? 64 : 0);
     {
       // net contact force: SoA rows of 64 consecutive envs each -> coalesced
       float* dst = P.state + (size_t)F_CF * P.n + env0;
+      static_assert(NT % WS_ENVS == 0, "a copy-out thread stays on one env lane");
+      const bool zero = POST && lds[X_RESETF * WS_ENVS + (ctid & 63)] != 0.f;  // env reset by this step: no contact forces
       for (int i = ctid; i < NROW * WS_ENVS; i += NT) {
         const int k = i >> 6, l = i & 63;
-        if (l < nloc) dst[(size_t)k * P.n + l] = lds[(X_CF + k) * WS_ENVS + l];
+        if (l < nloc) dst[(size_t)k * P.n + l] = zero ? 0.f : lds[(X_CF + k) * WS_ENVS + l];
       }
     }
     if (POST) {
