@@ -5,8 +5,10 @@
 // Here one workgroup (8 waves) carries 64 envs through the whole MLP: activations live in LDS (two 64 x 416 fp16 buffers),
 // the fp16 weights (247 KB for 54-400-200-100-(18+1), L2-resident) stream from global memory straight into MFMA B fragments,
 // products are v_mfma_f32_32x32x16_f16 with fp32 accumulators, bias + fp16 rounding + ELU + fp16 rounding in the epilogue (the
-// arithmetic of torch's fp16 Linear / ELU on the explicit-fp16 path of a2c_continuous.py).  Training's forward / backward stay
-// PyTorch-ROCm GEMMs; this kernel only serves the no-grad rollout.
+// arithmetic of torch's fp16 Linear / ELU on the explicit-fp16 path of a2c_continuous.py).  The same kernel serves the rollout
+// (mode 1: sampling and the rollout-buffer rows fused behind it) and the forward half of a PPO minibatch step (mode 2: every ELU
+// output and the normalised input are also written to HBM, which is all the backward pass needs); the backward pass stays
+// PyTorch-ROCm GEMMs + the reduction kernels of bez_ppo.hip.
 //
 // Fragment maps (MI355X guide, checked by tests/test_gpu_ppo_fused.py against torch on asymmetric data):
 //   A (32 x 16): lane l holds A[row l & 31][k = 8 (l >> 5) + j], j = 0..7      -> the activations of 32 envs
@@ -42,7 +44,19 @@ struct PolicyArgs {
   // rollout step (ROLL): everything between the forward pass and the env step, fused behind it (bez_ppo_rollout_pre's work)
   const float* logstd; const float* noise; const float* dones; const double* vmean; const double* vvar; float veps;
   float* mb_obs; float* mb_dones; float* mb_mu; float* mb_val; float* act; float* act_env; float* neglogp; float* sigma;
+  // training forward (mode 2): what the backward pass needs -- the fp16 input of the first Linear and every ELU output, row-major
+  _Float16* x0_out; _Float16* act_out[PF_MAXL];
 };
+
+// rows [0, nrow) x columns [0, cols) of an LDS activation tile -> global (row-major, `cols` halfs per row, cols even): half2 per
+// lane, consecutive lanes on consecutive columns (256 B per wave instruction)
+__device__ __forceinline__ void store_tile(const _Float16 (*src)[PF_LD], _Float16* dst, int64_t row0, int nrow, int cols, int tid) {
+  const int c2 = cols >> 1;
+  for (int idx = tid; idx < nrow * c2; idx += PF_WAVES * 64) {
+    const int rr = idx / c2, c = idx - rr * c2;
+    *reinterpret_cast<uint32_t*>(dst + (row0 + rr) * cols + 2 * c) = *reinterpret_cast<const uint32_t*>(&src[rr][2 * c]);
+  }
+}
 
 struct __attribute__((packed, aligned(4))) H8 { _Float16 v[8]; };
 
@@ -129,8 +143,10 @@ __device__ __forceinline__ void layer(const _Float16 (*src)[PF_LD], _Float16 (*d
   }
 }
 
-template <bool ROLL>
+// MODE 0: forward only; 1: rollout step (ROLL); 2: training forward (activations kept for the backward pass)
+template <int MODE>
 __global__ __launch_bounds__(PF_WAVES * 64) void policy_forward_kernel(PolicyArgs a) {
+  constexpr bool ROLL = MODE == 1, TRAIN = MODE == 2;
   __shared__ __attribute__((aligned(16))) _Float16 buf[2][PF_ROWS][PF_LD];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int64_t row0 = (int64_t)blockIdx.x * PF_ROWS;
@@ -151,12 +167,14 @@ __global__ __launch_bounds__(PF_WAVES * 64) void policy_forward_kernel(PolicyArg
     buf[0][rr][k] = (_Float16)v;
   }
   __syncthreads();
+  if (TRAIN) store_tile(buf[0], a.x0_out, row0, nrow, a.d_in, tid);
   int cur = 0, in = a.d_in;
   for (int L = 0; L < a.nhid; ++L) {
     layer<true>(buf[cur], buf[cur ^ 1], a.w[L], a.b[L], in, a.width[L], wave, lane);
     // the next layer reads K padded to 16: columns width..pad16(width) were written as elu(0 + 0) = 0 by the padded column block
     __syncthreads();
     cur ^= 1; in = a.width[L];
+    if (TRAIN) store_tile(buf[cur], a.act_out[L], row0, nrow, in, tid);  // (the stores drain behind the next layer's MFMAs)
   }
   // heads: one column block (num_actions + 1 <= 32 columns), wave 0; results to global memory as fp32 of the fp16 outputs
   float* tile = reinterpret_cast<float*>(&buf[cur ^ 1][0][0]);
@@ -228,6 +246,8 @@ static int fill_args(PolicyArgs& a, const float* obs_dev, int64_t n, int32_t num
   a.mu = nullptr; a.value = nullptr;
   a.logstd = a.noise = a.dones = nullptr; a.vmean = a.vvar = nullptr; a.veps = 0.f;
   a.mb_obs = a.mb_dones = a.mb_mu = a.mb_val = a.act = a.act_env = a.neglogp = a.sigma = nullptr;
+  a.x0_out = nullptr;
+  for (int i = 0; i < PF_MAXL; ++i) a.act_out[i] = nullptr;
   return 0;
 }
 
@@ -239,7 +259,7 @@ extern "C" int bez_ppo_policy_forward(const float* obs_dev, int64_t n, int32_t n
   if (!mu_dev || !value_dev || fill_args(a, obs_dev, n, num_obs, obs_mean_dev, obs_var_dev, obs_eps, num_hidden, hidden_w_f16_dev, hidden_b_f16_dev, hidden_width,
                                          mu_w_f16_dev, mu_b_f16_dev, num_actions, value_w_f16_dev, value_b_f16_dev)) return -1;
   a.mu = mu_dev; a.value = value_dev;
-  hipLaunchKernelGGL(policy_forward_kernel<false>, dim3((unsigned)((n + PF_ROWS - 1) / PF_ROWS)), dim3(PF_WAVES * 64), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(policy_forward_kernel<0>, dim3((unsigned)((n + PF_ROWS - 1) / PF_ROWS)), dim3(PF_WAVES * 64), 0, (hipStream_t)stream, a);
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
@@ -258,6 +278,24 @@ extern "C" int bez_ppo_policy_rollout_step(const float* obs_dev, int64_t n, int3
   a.logstd = logstd_dev; a.noise = noise_dev; a.dones = dones_dev; a.vmean = value_mean_dev; a.vvar = value_var_dev; a.veps = value_eps;
   a.mb_obs = mb_obs_dev; a.mb_dones = mb_dones_dev; a.mb_mu = mb_mu_dev; a.mb_val = mb_val_dev; a.act = actions_dev; a.act_env = env_actions_dev;
   a.neglogp = neglogp_dev; a.sigma = sigma_dev;
-  hipLaunchKernelGGL(policy_forward_kernel<true>, dim3((unsigned)((n + PF_ROWS - 1) / PF_ROWS)), dim3(PF_WAVES * 64), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(policy_forward_kernel<1>, dim3((unsigned)((n + PF_ROWS - 1) / PF_ROWS)), dim3(PF_WAVES * 64), 0, (hipStream_t)stream, a);
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+extern "C" int bez_ppo_policy_forward_train(const float* obs_dev, int64_t n, int32_t num_obs, const double* obs_mean_dev, const double* obs_var_dev, float obs_eps,
+                                            int32_t num_hidden, const void* const* hidden_w_f16_dev, const void* const* hidden_b_f16_dev,
+                                            const int32_t* hidden_width, const void* mu_w_f16_dev, const void* mu_b_f16_dev, int32_t num_actions,
+                                            const void* value_w_f16_dev, const void* value_b_f16_dev, void* x0_f16_dev, void* const* act_f16_dev,
+                                            float* mu_dev, float* value_dev, void* stream) {
+  PolicyArgs a;
+  if (!mu_dev || !value_dev || !x0_f16_dev || !act_f16_dev || (num_obs & 1) ||
+      fill_args(a, obs_dev, n, num_obs, obs_mean_dev, obs_var_dev, obs_eps, num_hidden, hidden_w_f16_dev, hidden_b_f16_dev, hidden_width, mu_w_f16_dev,
+                mu_b_f16_dev, num_actions, value_w_f16_dev, value_b_f16_dev)) return -1;
+  for (int i = 0; i < num_hidden; ++i) {
+    if (!act_f16_dev[i] || (hidden_width[i] & 1)) return -1;  // half2 stores: even widths
+    a.act_out[i] = (_Float16*)act_f16_dev[i];
+  }
+  a.x0_out = (_Float16*)x0_f16_dev; a.mu = mu_dev; a.value = value_dev;
+  hipLaunchKernelGGL(policy_forward_kernel<2>, dim3((unsigned)((n + PF_ROWS - 1) / PF_ROWS)), dim3(PF_WAVES * 64), 0, (hipStream_t)stream, a);
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }

@@ -650,12 +650,21 @@ class A2CAgent:
         obs = mb["obs"]
         if self.normalize_input:
             self._f_obs_rms.apply()
-            obs = self._f_obs_rms.normalize(obs, fx["mb_obs_n"])
         if self.half_path and getattr(self, "_hflat", None) is None:
             net.refresh_half()  # (with the fused optimiser the Adam kernel keeps the fp16 copies current)
-        with torch.autocast("cuda", dtype=torch.float16, enabled=self.mixed_precision and not self.half_path):
-            mu, _logstd, value = net(obs)
-        mu32, v32 = mu.float().contiguous(), value.float().contiguous()
+        manual = self._train_fwd_ok(obs)
+        if manual:
+            # forward of the whole MLP as one MFMA kernel that keeps the ELU outputs (csrc/bez_policy.hip, mode 2); the backward pass
+            # below is the chain autograd would run through _HalfLinearEluFn / _HalfLinearFn, called directly
+            tf = self._train_bufs(obs.shape[0])
+            self._policy_fwd.train_forward(obs, tf["x0"], tf["act"], tf["mu"], tf["v"])
+            mu32, v32 = tf["mu"], tf["v"]
+        else:
+            if self.normalize_input:
+                obs = self._f_obs_rms.normalize(obs, fx["mb_obs_n"])
+            with torch.autocast("cuda", dtype=torch.float16, enabled=self.mixed_precision and not self.half_path):
+                mu, _logstd, value = net(obs)
+            mu32, v32 = mu.float().contiguous(), value.float().contiguous()
         scale = None
         if self.scaler.is_enabled():
             if self.scaler._scale is None:
@@ -664,8 +673,62 @@ class A2CAgent:
         self._flat.zero_()
         F.loss(mu32.detach(), net.sigma.detach(), v32.detach(), mb, self.e_clip, self.critic_coef, self.entropy_coef, self.bounds_loss_coef,
                self.clip_value, scale, fx["gmu"], fx["gval"], net.sigma.grad, fx["stats"], zero_glog=False)
-        torch.autograd.backward([mu32, v32], [fx["gmu"], fx["gval"]])
+        if manual:
+            self._manual_backward(tf, fx["gmu"], fx["gval"])
+        else:
+            torch.autograd.backward([mu32, v32], [fx["gmu"], fx["gval"]])
         self._flat_kl.copy_(fx["stats"][3:4] / float(mu32.shape[0]))
+
+    def _train_fwd_ok(self, obs):
+        net = self.model.a2c_network
+        if self._policy_fwd is None or not self.normalize_input or not self.cfg.get("fused_train_forward", True):
+            return False
+        k, s = obs.shape[0], net._splits
+        lin = net._lin
+        return (obs.dtype == torch.float32 and obs.is_contiguous() and s > 1 and k % s == 0 and k // s >= 64 and obs.shape[1] % 2 == 0
+                and all(m.weight.shape[0] % 2 == 0 for m in lin[:-2])
+                and all(m.weight.grad is not None and m.bias.grad is not None and m.weight.grad.is_contiguous() and m.bias.grad.is_contiguous() for m in lin))
+
+    def _train_bufs(self, k):
+        tf = getattr(self, "_tf", None)
+        if tf is None or tf["k"] != k:
+            net, dev = self.model.a2c_network, self.device
+            widths = [m.weight.shape[0] for m in net._lin[:-2]]
+            h = lambda *sh: torch.empty(*sh, device=dev, dtype=torch.float16)
+            tf = dict(k=k, x0=h(k, self.obs_dim), act=[h(k, w) for w in widths], gz=[h(k, w) for w in widths], g=[h(k, w) for w in widths],
+                      mu=torch.empty(k, self.act_dim, device=dev), v=torch.empty(k, 1, device=dev),
+                      gmu16=h(k, self.act_dim), gv16=h(k, 1))
+            self._tf = tf
+        return tf
+
+    def _manual_backward(self, tf, gmu, gval):
+        """d(loss)/d(parameters) from the loss kernel's d/d(mu), d/d(value): per layer one input-gradient GEMM, the split-K weight
+        gradient reduced straight into the fp32 master .grad views, and the fused ELU-derivative / bias-gradient pass -- the same
+        launches _HalfLinearFn / _HalfLinearEluFn issue under autograd (tests hold the two against each other)."""
+        F, net = self._F, self.model.a2c_network
+        lin, p16, s = net._lin, net._p16, net._splits
+        nh = len(lin) - 2
+        k = gmu.shape[0]
+        ks = k // s
+
+        def wgrad(g16, x16, m):
+            part = torch.bmm(g16.view(s, ks, -1).transpose(1, 2), x16.view(s, ks, -1))
+            F.wgrad_sum(part, m.weight.grad, accumulate=True)
+        h_last = tf["act"][nh - 1]
+        tf["gmu16"].copy_(gmu); tf["gv16"].copy_(gval)           # the cast node's backward: fp32 -> fp16
+        g = tf["g"][nh - 1]
+        torch.mm(tf["gmu16"], p16[2 * nh], out=g)                 # d/d(h): mu head ...
+        g.addmm_(tf["gv16"], p16[2 * (nh + 1)])                   # ... + value head (autograd sums the two branches in fp16 as well)
+        wgrad(tf["gmu16"], h_last, lin[nh]); F.colsum_f16(tf["gmu16"], lin[nh].bias.grad, accumulate=True)
+        wgrad(tf["gv16"], h_last, lin[nh + 1]); F.colsum_f16(tf["gv16"], lin[nh + 1].bias.grad, accumulate=True)
+        for L in range(nh - 1, -1, -1):
+            gz = tf["gz"][L]
+            F.elu_bwd_colsum_f16(g, tf["act"][L], gz, lin[L].bias.grad, accumulate=True)
+            x = tf["act"][L - 1] if L > 0 else tf["x0"]
+            if L > 0:
+                g = tf["g"][L - 1]
+                torch.mm(gz, p16[2 * L], out=g)
+            wgrad(gz, x, lin[L])
 
     def _phase_c(self, kl_out, loss_out):
         if _dist_on():

@@ -19,6 +19,7 @@ _SIGS = {
     "bez_ppo_rollout_pre": [_vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _f, _i64, _i32, _i32] + [_vp] * 9,
     "bez_ppo_policy_forward": [_vp, _i64, _i32, _vp, _vp, _f, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp],
     "bez_ppo_policy_rollout_step": [_vp, _i64, _i32, _vp, _vp, _f, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f] + [_vp] * 9,
+    "bez_ppo_policy_forward_train": [_vp, _i64, _i32, _vp, _vp, _f, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "bez_ppo_wgrad_sum": [_vp, _i32, _i64, _vp, _i32, _vp],
     "bez_ppo_colsum_f16": [_vp, _i64, _i32, _vp, _i32, _vp],
     "bez_ppo_elu_bwd_colsum_f16": [_vp, _vp, _vp, _i64, _i32, _vp, _i32, _vp],
@@ -178,6 +179,20 @@ class PolicyForward:
                                           C.cast(self.hw, C.c_void_p), C.cast(self.hb, C.c_void_p), C.cast(self.widths, C.c_void_p),
                                           _p(mu_wb[0], torch.float16), _p(mu_wb[1], torch.float16), self.num_actions, _p(value_wb[0], torch.float16),
                                           _p(value_wb[1], torch.float16), _p(mu_out), _p(value_out), _stream(obs)), "bez_ppo_policy_forward")
+
+    def train_forward(self, obs, x0, acts, mu_out, value_out):
+        """Forward of a training minibatch that keeps the backward pass's operands: x0 (n, d_in) fp16, acts[i] (n, width_i) fp16."""
+        hidden, mu_wb, value_wb, rms = self.keep
+        n = obs.shape[0]
+        assert obs.shape[1] == self.d_in and x0.shape == (n, self.d_in) and len(acts) == self.k and mu_out.shape == (n, self.num_actions) and value_out.numel() == n
+        for a, (w, _) in zip(acts, hidden):
+            assert a.shape == (n, w.shape[0]) and a.dtype == torch.float16 and a.is_contiguous()
+        tab = (C.c_void_p * self.k)(*[a.data_ptr() for a in acts])
+        _chk(lib().bez_ppo_policy_forward_train(
+            _p(obs), n, self.d_in, None if rms is None else _p(rms.running_mean, torch.float64), None if rms is None else _p(rms.running_var, torch.float64),
+            0.0 if rms is None else float(rms.epsilon), self.k, C.cast(self.hw, C.c_void_p), C.cast(self.hb, C.c_void_p), C.cast(self.widths, C.c_void_p),
+            _p(mu_wb[0], torch.float16), _p(mu_wb[1], torch.float16), self.num_actions, _p(value_wb[0], torch.float16), _p(value_wb[1], torch.float16),
+            _p(x0, torch.float16), C.cast(tab, C.c_void_p), _p(mu_out), _p(value_out), _stream(obs)), "bez_ppo_policy_forward_train")
 
     def rollout_step(self, obs, logstd, noise, dones, value_rms, mb_obs, mb_dones, mb_mu, mb_val, actions, env_actions, neglogp, sigma):
         """Forward + everything up to the env step in the same launch (bez_ppo_policy_rollout_step): same outputs as

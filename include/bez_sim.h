@@ -272,6 +272,14 @@ int bez_ppo_policy_rollout_step(const float* obs_dev, int64_t n, int32_t num_obs
                                 float* mb_mu_dev, float* mb_val_dev, float* actions_dev, float* env_actions_dev, float* neglogp_dev, float* sigma_dev,
                                 void* stream);
 
+/* The forward half of a PPO minibatch step (a2c_common.py calc_gradients: model(batch) under autocast): bez_ppo_policy_forward
+ * that also keeps what the backward pass needs -- x0 (n, num_obs) fp16 = the normalised, clamped input of the first Linear, and
+ * act[i] (n, hidden_width[i]) fp16 = the output of ELU i.  num_obs and the widths must be even. */
+int bez_ppo_policy_forward_train(const float* obs_dev, int64_t n, int32_t num_obs, const double* obs_mean_dev, const double* obs_var_dev, float obs_eps,
+                                 int32_t num_hidden, const void* const* hidden_w_f16_dev, const void* const* hidden_b_f16_dev, const int32_t* hidden_width,
+                                 const void* mu_w_f16_dev, const void* mu_b_f16_dev, int32_t num_actions, const void* value_w_f16_dev,
+                                 const void* value_b_f16_dev, void* x0_f16_dev, void* const* act_f16_dev, float* mu_dev, float* value_dev, void* stream);
+
 /* Gradient reductions of explicit-fp16 linear layers into the fp32 master gradient: the sum over `splits` split-K partial
  * products ([splits][n] fp16) and the bias gradient = column sums of dY ((rows, cols) fp16).  accumulate != 0 adds to out_dev. */
 int bez_ppo_wgrad_sum(const void* partials_f16_dev, int32_t splits, int64_t n, float* out_dev, int32_t accumulate, void* stream);

@@ -324,6 +324,38 @@ def test_fused_and_plain_optimiser_step_agree():
     assert len(fused2.game_rewards) > 0
 
 
+def test_train_forward_kernel_and_manual_backward_match_autograd_path():
+    """A PPO minibatch's gradient through (a) the one-launch MFMA forward that keeps the ELU outputs + the backward chain called
+    directly and (b) the torch GEMM forward + autograd through _HalfLinearEluFn / _HalfLinearFn: same dataset, same weights.
+    The forwards differ by fp16 roundings of the ELU (exp in fp32 either way) -- the flat gradients agree to that level."""
+    from tests.test_gpu_round2 import _agent
+    a = _agent(512, 4096, hip_graphs=False, fused_train_forward=False)
+    b = _agent(512, 4096, hip_graphs=False, fused_train_forward=True)
+    b.model.load_state_dict(a.model.state_dict())
+    a.obs = a.env_reset()
+    a.play_steps()
+    b._alloc_static()
+    for k in a.dataset:
+        b.dataset[k].copy_(a.dataset[k])
+    for ra, rb in ((a.running_mean_std, b.running_mean_std), (a.value_mean_std, b.value_mean_std)):
+        rb.load_state_dict(ra.state_dict())
+    if getattr(b, "_hflat", None) is not None:   # fp16 working copies follow the loaded masters
+        b.model.a2c_network.refresh_half()
+    grads = []
+    for ag in (a, b):
+        mb = ag._minibatch(0)
+        ag._phase_a(mb)
+        assert ag._train_fwd_ok(mb["obs"]) == (ag is b)
+        ag._phase_b(mb)
+        grads.append(ag._flat.detach().float().cpu().numpy().copy())
+    ga, gb = grads
+    scale = np.abs(ga).max()
+    assert scale > 0 and np.isfinite(gb).all()
+    np.testing.assert_allclose(gb, ga, atol=2e-3 * scale, rtol=2e-2)
+    cos = float((ga * gb).sum() / np.sqrt((ga * ga).sum() * (gb * gb).sum()))
+    assert cos > 0.9999, cos
+
+
 def test_segmented_graphs_equal_the_monolithic_update():
     """World > 1 replays collective-free graph SEGMENTS with the RCCL calls in between.  Forced on one GPU (world = 2 pretended,
     no process group): from identical weights and an identical dataset the segmented update must leave the same parameters
