@@ -33,7 +33,8 @@ __global__ __launch_bounds__(PPO_TB) void rms_moments_kernel(const float* __rest
   __shared__ double sh[2][4][64];
   double s1 = 0.0, s2 = 0.0;
   if (col < D) {
-    for (int64_t r = (int64_t)blockIdx.x * 4 + rl; r < B; r += (int64_t)gridDim.x * 4) {
+#pragma unroll 8
+    for (int64_t r = (int64_t)blockIdx.x * 4 + rl; r < B; r += (int64_t)gridDim.x * 4) {  // (unrolled: eight rows in flight per thread)
       const double v = (double)x[r * D + col];
       s1 += v; s2 += v * v;
     }
@@ -341,17 +342,18 @@ __global__ __launch_bounds__(PPO_TB) void colsum_half_kernel(const __half* __res
 
 // ELU backward + bias gradient in one pass over dY: gz = gy * (y > 0 ? 1 : y + 1)  (alpha = 1; y = the layer's ELU output), written
 // as fp16 for the following GEMMs, and its column sums accumulated into the fp32 bias gradient.  Same tiling as colsum_half_kernel.
-__global__ __launch_bounds__(PPO_TB) void elu_bwd_colsum_kernel(const __half* __restrict__ gy, const __half* __restrict__ y, __half* __restrict__ gz, int64_t B,
-                                                                int D, int64_t rows_per_block, float* __restrict__ out) {
-  __shared__ float2 sh[4][64];
+constexpr int ELU_RL = 8;  // row lanes of the ELU-backward kernel: 512 threads = 8 x 64 column pairs, eight rows in flight per thread
+__global__ __launch_bounds__(ELU_RL * 64) void elu_bwd_colsum_kernel(const __half* __restrict__ gy, const __half* __restrict__ y, __half* __restrict__ gz, int64_t B,
+                                                                     int D, int64_t rows_per_block, float* __restrict__ out) {
+  __shared__ float2 sh[ELU_RL][64];
   const int l = threadIdx.x & 63, rl = threadIdx.x >> 6;
   const int c = (blockIdx.x * 64 + l) * 2;
   const int64_t r0 = (int64_t)blockIdx.y * rows_per_block, r1 = (r0 + rows_per_block < B) ? r0 + rows_per_block : B;
   float2 a = make_float2(0.f, 0.f);
   if ((D & 1) == 0) {
     if (c < D) {
-#pragma unroll 4
-      for (int64_t r = r0 + rl; r < r1; r += 4) {
+#pragma unroll 8
+      for (int64_t r = r0 + rl; r < r1; r += ELU_RL) {
         const float2 g = __half22float2(*reinterpret_cast<const __half2*>(gy + r * D + c));
         const float2 v = __half22float2(*reinterpret_cast<const __half2*>(y + r * D + c));
         const __half2 z = __floats2half2_rn(g.x * (v.x > 0.f ? 1.f : v.x + 1.f), g.y * (v.y > 0.f ? 1.f : v.y + 1.f));
@@ -361,7 +363,7 @@ __global__ __launch_bounds__(PPO_TB) void elu_bwd_colsum_kernel(const __half* __
       }
     }
   } else {
-    for (int64_t r = r0 + rl; r < r1; r += 4) {
+    for (int64_t r = r0 + rl; r < r1; r += ELU_RL) {
 #pragma unroll
       for (int k = 0; k < 2; ++k) {
         if (c + k < D) {
@@ -376,9 +378,49 @@ __global__ __launch_bounds__(PPO_TB) void elu_bwd_colsum_kernel(const __half* __
   sh[rl][l] = a;
   __syncthreads();
   if (rl == 0 && c < D) {
-    atomicAdd(&out[c], (sh[0][l].x + sh[1][l].x) + (sh[2][l].x + sh[3][l].x));
-    if (c + 1 < D) atomicAdd(&out[c + 1], (sh[0][l].y + sh[1][l].y) + (sh[2][l].y + sh[3][l].y));
+    float sx = 0.f, sy = 0.f;
+#pragma unroll
+    for (int q = 0; q < ELU_RL; ++q) { sx += sh[q][l].x; sy += sh[q][l].y; }
+    atomicAdd(&out[c], sx);
+    if (c + 1 < D) atomicAdd(&out[c + 1], sy);
   }
+}
+
+// ---- the two heads' backward inputs in one pass: fp16 copies of d loss / d mu (B,A) and d loss / d value (B,1) (what autocast's cast
+// nodes hand the head GEMMs) and the column sums of those fp16 values = the head bias gradients (accumulated)
+__global__ __launch_bounds__(PPO_TB) void head_grads_kernel(const float* __restrict__ gmu, const float* __restrict__ gval, int64_t B, int A,
+                                                            __half* __restrict__ gmu16, __half* __restrict__ gv16, float* __restrict__ bmu_grad,
+                                                            float* __restrict__ bv_grad, int64_t rows_per_block) {
+  __shared__ float sh[PPO_TB];
+  const int tid = threadIdx.x;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block, r1 = (r0 + rows_per_block < B) ? r0 + rows_per_block : B;
+  // thread tid owns column tid % A of rows tid / A, tid / A + TB / A, ...: consecutive threads on consecutive elements of the slab
+  const int rows_par = PPO_TB / A;  // rows a pass of the workgroup covers
+  const int col = tid % A, rsub = tid / A;
+  float acc = 0.f;
+  if (rsub < rows_par) {
+#pragma unroll 4
+    for (int64_t r = r0 + rsub; r < r1; r += rows_par) {
+      const __half h = __float2half(gmu[r * A + col]);
+      gmu16[r * A + col] = h;
+      acc += __half2float(h);
+    }
+  }
+  sh[tid] = acc;
+  float vacc = 0.f;
+  for (int64_t r = r0 + tid; r < r1; r += PPO_TB) {
+    const __half h = __float2half(gval[r]);
+    gv16[r] = h;
+    vacc += __half2float(h);
+  }
+  __syncthreads();
+  if (tid < A) {
+    float s = 0.f;
+    for (int q = 0; q < rows_par; ++q) s += sh[q * A + tid];
+    atomicAdd(&bmu_grad[tid], s);
+  }
+  vacc = wave_sum(vacc);
+  if ((tid & 63) == 0) atomicAdd(bv_grad, vacc);
 }
 
 // ---- the optimiser tail of one minibatch step on the flat fp32 buffers: GradScaler.unscale_ + clip_grad_norm_ + Adam (torch
@@ -576,8 +618,18 @@ int bez_ppo_elu_bwd_colsum_f16(const void* gy_f16_dev, const void* y_f16_dev, vo
   if (!gy_f16_dev || !y_f16_dev || !gz_f16_dev || !bias_grad_dev || rows <= 0 || cols <= 0) return -1;
   if (!accumulate) (void)hipMemsetAsync(bias_grad_dev, 0, (size_t)cols * sizeof(float), (hipStream_t)stream);
   const int64_t rpb = 256;
-  hipLaunchKernelGGL(elu_bwd_colsum_kernel, dim3((unsigned)((cols + 127) / 128), (unsigned)((rows + rpb - 1) / rpb)), dim3(PPO_TB), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL(elu_bwd_colsum_kernel, dim3((unsigned)((cols + 127) / 128), (unsigned)((rows + rpb - 1) / rpb)), dim3(ELU_RL * 64), 0, (hipStream_t)stream,
                      (const __half*)gy_f16_dev, (const __half*)y_f16_dev, (__half*)gz_f16_dev, rows, (int)cols, rpb, bias_grad_dev);
+  return launch_ok();
+}
+
+int bez_ppo_head_grads_f16(const float* grad_mu_dev, const float* grad_value_dev, int64_t rows, int32_t num_actions, void* grad_mu_f16_dev,
+                           void* grad_value_f16_dev, float* mu_bias_grad_dev, float* value_bias_grad_dev, void* stream) {
+  if (!grad_mu_dev || !grad_value_dev || !grad_mu_f16_dev || !grad_value_f16_dev || !mu_bias_grad_dev || !value_bias_grad_dev || rows <= 0 ||
+      num_actions <= 0 || num_actions > PPO_TB) return -1;
+  const int64_t rpb = 256;
+  hipLaunchKernelGGL(head_grads_kernel, dim3((unsigned)((rows + rpb - 1) / rpb)), dim3(PPO_TB), 0, (hipStream_t)stream, grad_mu_dev, grad_value_dev, rows,
+                     (int)num_actions, (__half*)grad_mu_f16_dev, (__half*)grad_value_f16_dev, mu_bias_grad_dev, value_bias_grad_dev, rpb);
   return launch_ok();
 }
 

@@ -677,7 +677,7 @@ class A2CAgent:
             self._manual_backward(tf, fx["gmu"], fx["gval"])
         else:
             torch.autograd.backward([mu32, v32], [fx["gmu"], fx["gval"]])
-        self._flat_kl.copy_(fx["stats"][3:4] / float(mu32.shape[0]))
+        torch.mul(fx["stats"][3:4], 1.0 / float(mu32.shape[0]), out=self._flat_kl)
 
     def _train_fwd_ok(self, obs):
         net = self.model.a2c_network
@@ -715,12 +715,13 @@ class A2CAgent:
             part = torch.bmm(g16.view(s, ks, -1).transpose(1, 2), x16.view(s, ks, -1))
             F.wgrad_sum(part, m.weight.grad, accumulate=True)
         h_last = tf["act"][nh - 1]
-        tf["gmu16"].copy_(gmu); tf["gv16"].copy_(gval)           # the cast node's backward: fp32 -> fp16
+        # the cast nodes' backward (fp32 -> fp16) and both head bias gradients: one launch
+        F.head_grads_f16(gmu, gval, tf["gmu16"], tf["gv16"], lin[nh].bias.grad, lin[nh + 1].bias.grad)
         g = tf["g"][nh - 1]
         torch.mm(tf["gmu16"], p16[2 * nh], out=g)                 # d/d(h): mu head ...
         g.addmm_(tf["gv16"], p16[2 * (nh + 1)])                   # ... + value head (autograd sums the two branches in fp16 as well)
-        wgrad(tf["gmu16"], h_last, lin[nh]); F.colsum_f16(tf["gmu16"], lin[nh].bias.grad, accumulate=True)
-        wgrad(tf["gv16"], h_last, lin[nh + 1]); F.colsum_f16(tf["gv16"], lin[nh + 1].bias.grad, accumulate=True)
+        wgrad(tf["gmu16"], h_last, lin[nh])
+        wgrad(tf["gv16"], h_last, lin[nh + 1])
         for L in range(nh - 1, -1, -1):
             gz = tf["gz"][L]
             F.elu_bwd_colsum_f16(g, tf["act"][L], gz, lin[L].bias.grad, accumulate=True)
@@ -747,9 +748,9 @@ class A2CAgent:
             self.scaler.step(self.optimizer)
             self.scaler.update()
         with torch.no_grad():
-            inv_b = 1.0 / float(self.minibatch_size)
-            kl_out.add_(self._flat_kl[0] / self.num_minibatches)
-            loss_out[0] += self._fx["stats"][0] * inv_b; loss_out[1] += self._fx["stats"][1] * inv_b
+            # (one launch each: add with a scalar multiplier)
+            kl_out.add_(self._flat_kl[0], alpha=1.0 / self.num_minibatches)
+            loss_out.add_(self._fx["stats"][0:2], alpha=1.0 / float(self.minibatch_size))
 
     def _calc_gradients_fused(self, mb, kl_out, loss_out):
         """calc_gradients with the HIP glue kernels: observation moments + running update + normalise (3 launches), MLP

@@ -20,6 +20,7 @@ _SIGS = {
     "bez_ppo_policy_forward": [_vp, _i64, _i32, _vp, _vp, _f, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp],
     "bez_ppo_policy_rollout_step": [_vp, _i64, _i32, _vp, _vp, _f, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f] + [_vp] * 9,
     "bez_ppo_policy_forward_train": [_vp, _i64, _i32, _vp, _vp, _f, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "bez_ppo_head_grads_f16": [_vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp],
     "bez_ppo_wgrad_sum": [_vp, _i32, _i64, _vp, _i32, _vp],
     "bez_ppo_colsum_f16": [_vp, _i64, _i32, _vp, _i32, _vp],
     "bez_ppo_elu_bwd_colsum_f16": [_vp, _vp, _vp, _i64, _i32, _vp, _i32, _vp],
@@ -145,6 +146,14 @@ def rollout_pre(mu, value, logstd, noise, obs, dones, value_rms, mb_obs, mb_done
     _chk(lib().bez_ppo_rollout_pre(C.c_void_p(mu.data_ptr()), C.c_void_p(value.data_ptr()), 1 if half else 0, _p(logstd), _p(noise), _p(obs), _p(dones), vm, vv,
                                    0.0 if value_rms is None else float(value_rms.epsilon), n, a, obs.shape[1], _p(mb_obs), _p(mb_dones), _p(mb_mu), _p(mb_val),
                                    _p(act), _p(env_act), _p(neglogp), _p(sigma), _stream(mu)), "bez_ppo_rollout_pre")
+
+
+def head_grads_f16(gmu, gval, gmu16, gv16, mu_bias_grad, value_bias_grad):
+    """fp16 copies of the loss gradients w.r.t. mu (B,A) / value (B,1) + their column sums added to the head bias gradients."""
+    b, a = gmu.shape
+    assert gval.numel() == b and gmu16.shape == (b, a) and gv16.numel() == b and mu_bias_grad.numel() == a and value_bias_grad.numel() == 1
+    _chk(lib().bez_ppo_head_grads_f16(_p(gmu), _p(gval), b, a, _p(gmu16, torch.float16), _p(gv16, torch.float16), _p(mu_bias_grad), _p(value_bias_grad),
+                                      _stream(gmu)), "bez_ppo_head_grads_f16")
 
 
 def elu_bwd_colsum_f16(gy, y, gz, bias_grad, accumulate=False):

@@ -289,6 +289,12 @@ int bez_ppo_colsum_f16(const void* y_f16_dev, int64_t rows, int32_t cols, float*
 int bez_ppo_elu_bwd_colsum_f16(const void* gy_f16_dev, const void* y_f16_dev, void* gz_f16_dev, int64_t rows, int32_t cols, float* bias_grad_dev,
                                int32_t accumulate, void* stream);
 
+/* The backward inputs of the two heads in one pass over the loss gradients (torch.autocast's cast nodes + the bias-gradient sums of
+ * nn.Linear's backward): fp16 copies of d loss / d mu (rows, num_actions) and d loss / d value (rows, 1), and the column sums of those
+ * fp16 values ADDED to the fp32 bias gradients of the mu and value heads. */
+int bez_ppo_head_grads_f16(const float* grad_mu_dev, const float* grad_value_dev, int64_t rows, int32_t num_actions, void* grad_mu_f16_dev,
+                           void* grad_value_f16_dev, float* mu_bias_grad_dev, float* value_bias_grad_dev, void* stream);
+
 /* The optimiser tail of one minibatch step on flat fp32 buffers of n elements (replaces rl_games' scaler.unscale_ +
  * clip_grad_norm_ + scaler.step(Adam) + scaler.update, a2c_common.py [ext] via train.py:89-113): the gradient is divided by
  * *scale_dev (NULL = no loss scaling), clipped to max_norm (<= 0: no clipping), applied with torch's Adam formula; a non-finite

@@ -324,6 +324,19 @@ def test_fused_and_plain_optimiser_step_agree():
     assert len(fused2.game_rewards) > 0
 
 
+def test_head_grads_kernel():
+    from bez_isaacgym_amd.ppo import fused as F
+    torch.manual_seed(4)
+    for b, a in ((32768, 18), (1000, 7)):
+        gmu, gval = torch.randn(b, a, device=DEV) * 1e-3, torch.randn(b, 1, device=DEV) * 1e-3
+        g16, v16 = torch.zeros(b, a, device=DEV, dtype=torch.float16), torch.zeros(b, 1, device=DEV, dtype=torch.float16)
+        bm, bv = torch.full((a,), 0.5, device=DEV), torch.full((1,), -0.25, device=DEV)
+        F.head_grads_f16(gmu, gval, g16, v16, bm, bv)
+        assert torch.equal(g16, gmu.half()) and torch.equal(v16, gval.half())
+        np.testing.assert_allclose(bm.cpu(), (0.5 + gmu.half().double().sum(0)).float().cpu(), rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(bv.cpu(), (-0.25 + gval.half().double().sum(0)).float().cpu(), rtol=1e-5, atol=1e-6)
+
+
 def test_train_forward_kernel_and_manual_backward_match_autograd_path():
     """A PPO minibatch's gradient through (a) the one-launch MFMA forward that keeps the ELU outputs + the backward chain called
     directly and (b) the torch GEMM forward + autograd through _HalfLinearEluFn / _HalfLinearFn: same dataset, same weights.
