@@ -423,6 +423,25 @@ __global__ __launch_bounds__(PPO_TB) void head_grads_kernel(const float* __restr
   if ((tid & 63) == 0) atomicAdd(bv_grad, vacc);
 }
 
+// ---- GAE backward scan over the horizon (rl_games a2c_common.discount_values): one thread per env walks t = H-1 .. 0 with the
+// same fp32 operations, in the same order, as the 8 elementwise launches per step of the torch formulation
+__global__ __launch_bounds__(PPO_TB) void gae_kernel(const float* __restrict__ rew, const float* __restrict__ val, const float* __restrict__ mb_dones,
+                                                     const float* __restrict__ dones, const float* __restrict__ last_values, int H, int64_t N,
+                                                     float gamma, float tau, float* __restrict__ advs, float* __restrict__ returns) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  float last = 0.f;
+  float nnt = 1.0f - dones[i], nv = last_values[i];
+  for (int t = H - 1; t >= 0; --t) {
+    const float v = val[(int64_t)t * N + i];
+    const float delta = rew[(int64_t)t * N + i] + gamma * nv * nnt - v;
+    last = delta + gamma * tau * nnt * last;
+    advs[(int64_t)t * N + i] = last;
+    if (returns) returns[(int64_t)t * N + i] = last + v;
+    nnt = 1.0f - mb_dones[(int64_t)t * N + i]; nv = v;  // for step t-1: "next" = step t
+  }
+}
+
 // ---- the optimiser tail of one minibatch step on the flat fp32 buffers: GradScaler.unscale_ + clip_grad_norm_ + Adam (torch
 // semantics, no amsgrad) + GradScaler.update, three launches instead of torch's dozen.
 // work[0] = sum of squares of the UNSCALED gradient, work[1] = number of non-finite elements (caller zeroes both).
@@ -620,6 +639,14 @@ int bez_ppo_elu_bwd_colsum_f16(const void* gy_f16_dev, const void* y_f16_dev, vo
   const int64_t rpb = 256;
   hipLaunchKernelGGL(elu_bwd_colsum_kernel, dim3((unsigned)((cols + 127) / 128), (unsigned)((rows + rpb - 1) / rpb)), dim3(ELU_RL * 64), 0, (hipStream_t)stream,
                      (const __half*)gy_f16_dev, (const __half*)y_f16_dev, (__half*)gz_f16_dev, rows, (int)cols, rpb, bias_grad_dev);
+  return launch_ok();
+}
+
+int bez_ppo_gae(const float* rewards_dev, const float* values_dev, const float* mb_dones_dev, const float* dones_dev, const float* last_values_dev,
+                int32_t horizon, int64_t num_envs, float gamma, float tau, float* advantages_dev, float* returns_dev, void* stream) {
+  if (!rewards_dev || !values_dev || !mb_dones_dev || !dones_dev || !last_values_dev || !advantages_dev || horizon <= 0 || num_envs <= 0) return -1;
+  hipLaunchKernelGGL(gae_kernel, dim3(nblk(num_envs)), dim3(PPO_TB), 0, (hipStream_t)stream, rewards_dev, values_dev, mb_dones_dev, dones_dev, last_values_dev,
+                     (int)horizon, num_envs, gamma, tau, advantages_dev, returns_dev);
   return launch_ok();
 }
 

@@ -433,7 +433,8 @@ class A2CAgent:
             hd = torch.float16 if self.mixed_precision else torch.float32
             A, D, MB = self.act_dim, self.obs_dim, self.minibatch_size
             self._fx = dict(obs_n=torch.zeros(N, D, device=dev, dtype=hd), env_act=z(N, A), noise=z(H, N, A),
-                            mb_obs_n=torch.zeros(MB, D, device=dev, dtype=hd), gmu=z(MB, A), gval=z(MB, 1), glog=z(A), stats=z(5))
+                            mb_obs_n=torch.zeros(MB, D, device=dev, dtype=hd), gmu=z(MB, A), gval=z(MB, 1), glog=z(A), stats=z(5),
+                            last_mu=z(N, A), last_v=z(N, 1), advs=z(H, N, 1), rets=z(H, N, 1))
 
     @torch.no_grad()
     def _rollout_steps_fused(self):
@@ -499,9 +500,17 @@ class A2CAgent:
             self.current_lengths *= not_done
         if self.fused and not steps_done:
             self._rollout_steps_fused()
-        last_values = self.get_values(self.obs)
-        advs = discount_values(self.gamma, self.tau, self.dones, last_values, mb["dones"], mb["val"], mb["rew"])
-        returns = advs + mb["val"]
+        if self.fused and self._policy_fwd is not None:
+            # bootstrap values: the one-launch forward; GAE: one thread per env instead of eight elementwise launches per step
+            fx = self._fx
+            self._policy_fwd(self.obs, fx["last_mu"], fx["last_v"])
+            last_values = self.value_mean_std(fx["last_v"], unnorm=True) if self.normalize_value else fx["last_v"]
+            advs, returns = fx["advs"], fx["rets"]
+            self._F.gae(mb["rew"], mb["val"], mb["dones"], self.dones, last_values.contiguous(), self.gamma, self.tau, advs, returns)
+        else:
+            last_values = self.get_values(self.obs)
+            advs = discount_values(self.gamma, self.tau, self.dones, last_values, mb["dones"], mb["val"], mb["rew"])
+            returns = advs + mb["val"]
         # ---- prepare_dataset (rl_games a2c_continuous.prepare_dataset)
         values, returns = swap_and_flatten01(mb["val"]), swap_and_flatten01(returns)
         if self.normalize_value:

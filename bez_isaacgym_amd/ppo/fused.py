@@ -20,6 +20,7 @@ _SIGS = {
     "bez_ppo_policy_forward": [_vp, _i64, _i32, _vp, _vp, _f, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp],
     "bez_ppo_policy_rollout_step": [_vp, _i64, _i32, _vp, _vp, _f, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f] + [_vp] * 9,
     "bez_ppo_policy_forward_train": [_vp, _i64, _i32, _vp, _vp, _f, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "bez_ppo_gae": [_vp, _vp, _vp, _vp, _vp, _i32, _i64, _f, _f, _vp, _vp, _vp],
     "bez_ppo_head_grads_f16": [_vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp],
     "bez_ppo_wgrad_sum": [_vp, _i32, _i64, _vp, _i32, _vp],
     "bez_ppo_colsum_f16": [_vp, _i64, _i32, _vp, _i32, _vp],
@@ -146,6 +147,15 @@ def rollout_pre(mu, value, logstd, noise, obs, dones, value_rms, mb_obs, mb_done
     _chk(lib().bez_ppo_rollout_pre(C.c_void_p(mu.data_ptr()), C.c_void_p(value.data_ptr()), 1 if half else 0, _p(logstd), _p(noise), _p(obs), _p(dones), vm, vv,
                                    0.0 if value_rms is None else float(value_rms.epsilon), n, a, obs.shape[1], _p(mb_obs), _p(mb_dones), _p(mb_mu), _p(mb_val),
                                    _p(act), _p(env_act), _p(neglogp), _p(sigma), _stream(mu)), "bez_ppo_rollout_pre")
+
+
+def gae(rewards, values, mb_dones, dones, last_values, gamma, tau, advs, returns=None):
+    """GAE backward scan: rewards / values / mb_dones (H,N[,1]) fp32, dones / last_values (N[,1]); writes advs (and returns = advs + values)."""
+    h = rewards.shape[0]
+    n = rewards.numel() // h
+    assert values.numel() == h * n and mb_dones.numel() == h * n and dones.numel() == n and last_values.numel() == n and advs.numel() == h * n
+    _chk(lib().bez_ppo_gae(_p(rewards), _p(values), _p(mb_dones), _p(dones), _p(last_values), h, n, float(gamma), float(tau), _p(advs),
+                           None if returns is None else _p(returns), _stream(rewards)), "bez_ppo_gae")
 
 
 def head_grads_f16(gmu, gval, gmu16, gv16, mu_bias_grad, value_bias_grad):

@@ -289,6 +289,12 @@ int bez_ppo_colsum_f16(const void* y_f16_dev, int64_t rows, int32_t cols, float*
 int bez_ppo_elu_bwd_colsum_f16(const void* gy_f16_dev, const void* y_f16_dev, void* gz_f16_dev, int64_t rows, int32_t cols, float* bias_grad_dev,
                                int32_t accumulate, void* stream);
 
+/* GAE (rl_games a2c_common.py discount_values, called from play_steps): advantages (H,N) from rewards / values (H,N), the done
+ * flags recorded BEFORE each step (H,N), the current done flags (N) and the bootstrap values (N); returns_dev (optional) = advantages +
+ * values.  One thread per env, the reference's operation order. */
+int bez_ppo_gae(const float* rewards_dev, const float* values_dev, const float* mb_dones_dev, const float* dones_dev, const float* last_values_dev,
+                int32_t horizon, int64_t num_envs, float gamma, float tau, float* advantages_dev, float* returns_dev, void* stream);
+
 /* The backward inputs of the two heads in one pass over the loss gradients (torch.autocast's cast nodes + the bias-gradient sums of
  * nn.Linear's backward): fp16 copies of d loss / d mu (rows, num_actions) and d loss / d value (rows, 1), and the column sums of those
  * fp16 values ADDED to the fp32 bias gradients of the mu and value heads. */

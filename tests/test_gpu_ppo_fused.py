@@ -324,6 +324,21 @@ def test_fused_and_plain_optimiser_step_agree():
     assert len(fused2.game_rewards) > 0
 
 
+def test_gae_kernel_matches_discount_values():
+    from bez_isaacgym_amd.ppo import fused as F
+    from bez_isaacgym_amd.ppo.a2c_continuous import discount_values
+    torch.manual_seed(6)
+    for h, n in ((32, 4096), (5, 333)):
+        rew, val = torch.randn(h, n, 1, device=DEV), torch.randn(h, n, 1, device=DEV)
+        mbd, d = (torch.rand(h, n, device=DEV) < 0.1).float(), (torch.rand(n, device=DEV) < 0.1).float()
+        last = torch.randn(n, 1, device=DEV)
+        want = discount_values(0.99, 0.95, d, last, mbd, val, rew)
+        advs, rets = torch.full((h, n, 1), 7.0, device=DEV), torch.full((h, n, 1), 7.0, device=DEV)
+        F.gae(rew, val, mbd, d, last, 0.99, 0.95, advs, rets)
+        np.testing.assert_allclose(advs.cpu(), want.cpu(), rtol=1e-5, atol=1e-5)   # same operations; the compiler contracts a*b+c (1.4e-6 over 32 steps)
+        np.testing.assert_allclose(rets.cpu(), (want + val).cpu(), rtol=1e-5, atol=1e-5)
+
+
 def test_head_grads_kernel():
     from bez_isaacgym_amd.ppo import fused as F
     torch.manual_seed(4)
