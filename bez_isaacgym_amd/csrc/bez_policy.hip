@@ -131,7 +131,7 @@ __device__ __forceinline__ void layer(const _Float16 (*src)[PF_LD], _Float16 (*d
 #pragma unroll
     for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
     gemm_col_block(src, wrow, n < out, in, r, h, acc0, acc1);
-    const float bias = n < out ? (float)B[n] : 0.f;
+    const float bias = (B && n < out) ? (float)B[n] : 0.f;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const int row = (i & 3) + 8 * (i >> 2) + 4 * h;
@@ -227,6 +227,99 @@ __global__ __launch_bounds__(PF_WAVES * 64) void policy_forward_kernel(PolicyArg
   }
 }
 
+// ---- the input-gradient half of the backward pass of one minibatch as ONE kernel (bez_ppo_policy_backward): per 64-row tile, from
+// d loss / d mu and d loss / d value down to d loss / d (pre-activation) of every hidden layer.  What it replaces per layer: the ELU
+// derivative + bias-gradient pass over (rows, width) and the input-gradient GEMM of torch's Linear backward -- the tile's gradient
+// never leaves LDS between them.  The weight gradients stay split-K GEMMs on the gz tensors written here.
+// B operands are TRANSPOSED weights (8 consecutive k per lane must be contiguous): wt[L] = W_L^T (width[L-1], width[L]) and the two
+// heads as one (width[last], 32) matrix; a scatter of the fp16 working copy refreshes them once per optimiser step.
+struct BackwardArgs {
+  int64_t n; int nhid; int width[PF_MAXL]; int num_actions;
+  const float* gmu; const float* gval;
+  const _Float16* act[PF_MAXL];
+  const _Float16* wt[PF_MAXL];
+  const _Float16* wht;
+  _Float16* gz[PF_MAXL];
+  _Float16* gmu16; _Float16* gv16;
+  float* bgrad[PF_MAXL]; float* bmu_grad; float* bv_grad;
+};
+
+__global__ __launch_bounds__(PF_WAVES * 64) void policy_backward_kernel(BackwardArgs a) {
+  __shared__ __attribute__((aligned(16))) _Float16 buf[2][PF_ROWS][PF_LD];
+  __shared__ float2 red[PF_WAVES * 64];
+  constexpr int NT = PF_WAVES * 64;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t row0 = (int64_t)blockIdx.x * PF_ROWS;
+  const int nrow = (int)((a.n - row0) < (int64_t)PF_ROWS ? (a.n - row0) : (int64_t)PF_ROWS);
+  const int A = a.num_actions;
+  {  // heads: the (64, 32) tile [d/d mu | d/d value | 0] as fp16 (= the cast nodes of autocast), its copies for the head weight-gradient
+     // GEMMs, and its column sums = the head bias gradients.  Thread -> column tid & 31, rows tid >> 5, + 16, ...
+    const int k = tid & 31, rsub = tid >> 5;
+    float acc = 0.f;
+#pragma unroll
+    for (int j = 0; j < PF_ROWS / (NT / 32); ++j) {
+      const int rr = rsub + j * (NT / 32);
+      float v = 0.f;
+      if (rr < nrow) v = k < A ? a.gmu[(row0 + rr) * A + k] : (k == A ? a.gval[row0 + rr] : 0.f);
+      const _Float16 hv = (_Float16)v;
+      buf[0][rr][k] = hv;
+      if (rr < nrow) {
+        if (k < A) a.gmu16[(row0 + rr) * A + k] = hv; else if (k == A) a.gv16[row0 + rr] = hv;
+        acc += (float)hv;
+      }
+    }
+    red[tid].x = acc;
+    __syncthreads();
+    if (tid <= A) {
+      float sum = 0.f;
+      for (int q = 0; q < NT / 32; ++q) sum += red[q * 32 + tid].x;
+      atomicAdd(tid < A ? &a.bmu_grad[tid] : a.bv_grad, sum);
+    }
+  }
+  int cur = 1;
+  layer<false>(buf[0], buf[1], a.wht, nullptr, 32, a.width[a.nhid - 1], wave, lane);  // d/d h_last = [gmu | gval] [Wmu; Wv]
+  __syncthreads();
+  for (int L = a.nhid - 1; L >= 0; --L) {
+    const int W = a.width[L], ncp = W >> 1, nparts = NT / ncp;
+    const int part = tid / ncp, cp = tid - part * ncp;
+    float2 acc = make_float2(0.f, 0.f);
+    if (part < nparts) {  // gz = g * elu'(y), in place in the tile and out to HBM; consecutive threads on consecutive column pairs of a row
+      for (int rr = part; rr < nrow; rr += nparts) {
+        const uint32_t gy = *reinterpret_cast<const uint32_t*>(&buf[cur][rr][2 * cp]);
+        const uint32_t yy = *reinterpret_cast<const uint32_t*>(a.act[L] + (row0 + rr) * W + 2 * cp);
+        const _Float16 g0 = reinterpret_cast<const _Float16*>(&gy)[0], g1 = reinterpret_cast<const _Float16*>(&gy)[1];
+        const float y0 = (float)reinterpret_cast<const _Float16*>(&yy)[0], y1 = (float)reinterpret_cast<const _Float16*>(&yy)[1];
+        _Float16 z[2];
+        z[0] = (_Float16)((float)g0 * (y0 > 0.f ? 1.f : y0 + 1.f));
+        z[1] = (_Float16)((float)g1 * (y1 > 0.f ? 1.f : y1 + 1.f));
+        const uint32_t zz = *reinterpret_cast<const uint32_t*>(z);
+        *reinterpret_cast<uint32_t*>(&buf[cur][rr][2 * cp]) = zz;
+        *reinterpret_cast<uint32_t*>(a.gz[L] + (row0 + rr) * W + 2 * cp) = zz;
+        acc.x += (float)z[0]; acc.y += (float)z[1];  // the bias gradient sums what the GEMMs see
+      }
+    }
+    red[tid] = acc;
+    __syncthreads();
+    if (tid < ncp) {
+      float sx = 0.f, sy = 0.f;
+      for (int q = 0; q < nparts; ++q) { sx += red[q * ncp + tid].x; sy += red[q * ncp + tid].y; }
+      atomicAdd(&a.bgrad[L][2 * tid], sx);
+      atomicAdd(&a.bgrad[L][2 * tid + 1], sy);
+    }
+    if (L > 0) {
+      layer<false>(buf[cur], buf[cur ^ 1], a.wt[L], nullptr, W, a.width[L - 1], wave, lane);  // d/d h_{L-1} = gz W_L
+      __syncthreads();
+      cur ^= 1;
+    }
+  }
+}
+
+// dst[map[i]] = src[i] for the entries with map[i] >= 0: refreshes the transposed weight copies from the flat fp16 working copy
+__global__ void scatter_f16_kernel(const _Float16* __restrict__ src, const int32_t* __restrict__ map, int64_t n, _Float16* __restrict__ dst) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) { const int32_t m = map[i]; if (m >= 0) dst[m] = src[i]; }
+}
+
 }  // namespace
 
 static int fill_args(PolicyArgs& a, const float* obs_dev, int64_t n, int32_t num_obs, const double* obs_mean_dev, const double* obs_var_dev, float obs_eps,
@@ -297,5 +390,35 @@ extern "C" int bez_ppo_policy_forward_train(const float* obs_dev, int64_t n, int
   }
   a.x0_out = (_Float16*)x0_f16_dev; a.mu = mu_dev; a.value = value_dev;
   hipLaunchKernelGGL(policy_forward_kernel<2>, dim3((unsigned)((n + PF_ROWS - 1) / PF_ROWS)), dim3(PF_WAVES * 64), 0, (hipStream_t)stream, a);
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+extern "C" int bez_ppo_policy_backward(const float* grad_mu_dev, const float* grad_value_dev, int64_t n, int32_t num_hidden, const int32_t* hidden_width,
+                                       int32_t num_actions, const void* const* act_f16_dev, const void* const* wt_f16_dev, const void* heads_t_f16_dev,
+                                       void* const* gz_f16_dev, void* grad_mu_f16_dev, void* grad_value_f16_dev, float* const* bias_grad_dev,
+                                       float* mu_bias_grad_dev, float* value_bias_grad_dev, void* stream) {
+  if (!grad_mu_dev || !grad_value_dev || n <= 0 || num_hidden <= 0 || num_hidden > PF_MAXL || !hidden_width || num_actions <= 0 || num_actions > 31 ||
+      !act_f16_dev || !wt_f16_dev || !heads_t_f16_dev || !gz_f16_dev || !grad_mu_f16_dev || !grad_value_f16_dev || !bias_grad_dev || !mu_bias_grad_dev ||
+      !value_bias_grad_dev) return -1;
+  BackwardArgs a;
+  a.n = n; a.nhid = num_hidden; a.num_actions = num_actions; a.gmu = grad_mu_dev; a.gval = grad_value_dev;
+  for (int i = 0; i < PF_MAXL; ++i) { a.width[i] = 0; a.act[i] = nullptr; a.wt[i] = nullptr; a.gz[i] = nullptr; a.bgrad[i] = nullptr; }
+  for (int i = 0; i < num_hidden; ++i) {
+    // even widths (half2 rows), at most one column pair per thread, and at least 32 columns of K for the 16-byte fragment reads
+    if (hidden_width[i] < 32 || hidden_width[i] > PF_MAXW || (hidden_width[i] & 1) || !act_f16_dev[i] || !gz_f16_dev[i] || !bias_grad_dev[i] ||
+        (i > 0 && !wt_f16_dev[i])) return -1;
+    a.width[i] = hidden_width[i]; a.act[i] = (const _Float16*)act_f16_dev[i]; a.wt[i] = (const _Float16*)wt_f16_dev[i];
+    a.gz[i] = (_Float16*)gz_f16_dev[i]; a.bgrad[i] = bias_grad_dev[i];
+  }
+  a.wht = (const _Float16*)heads_t_f16_dev; a.gmu16 = (_Float16*)grad_mu_f16_dev; a.gv16 = (_Float16*)grad_value_f16_dev;
+  a.bmu_grad = mu_bias_grad_dev; a.bv_grad = value_bias_grad_dev;
+  hipLaunchKernelGGL(policy_backward_kernel, dim3((unsigned)((n + PF_ROWS - 1) / PF_ROWS)), dim3(PF_WAVES * 64), 0, (hipStream_t)stream, a);
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+extern "C" int bez_ppo_scatter_f16(const void* src_f16_dev, const int32_t* map_dev, int64_t n, void* dst_f16_dev, void* stream) {
+  if (!src_f16_dev || !map_dev || !dst_f16_dev || n <= 0) return -1;
+  hipLaunchKernelGGL(scatter_f16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const _Float16*)src_f16_dev, map_dev, n,
+                     (_Float16*)dst_f16_dev);
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }

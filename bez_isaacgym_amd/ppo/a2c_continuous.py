@@ -356,6 +356,7 @@ class A2CAgent:
         # the plain torch formulation (the one the CPU path runs and the kernels are tested against)
         self._fused_opt = False
         self._policy_fwd = None
+        self._policy_bwd = None
         self.fused = bool(on_gpu and c.get("fused_ops", True))
         if self.fused:
             from . import fused as F
@@ -378,6 +379,11 @@ class A2CAgent:
                 wb = [(net._p16[2 * i], net._p16[2 * i + 1]) for i in range(nh + 2)]
                 if all(w.shape[0] <= 416 for w, _ in wb[:nh]) and obs_dim <= 416 and act_dim <= 31 and nh <= 6:
                     self._policy_fwd = F.PolicyForward(wb[:nh], wb[nh], wb[nh + 1], self.running_mean_std if self.normalize_input else None)
+                    # ... and the input-gradient chain of the minibatch backward pass as one kernel on transposed fp16 copies
+                    hflat = getattr(self, "_hflat", None)
+                    if (hflat is not None and c.get("fused_policy_backward", True) and all(32 <= w.shape[0] <= 416 and w.shape[0] % 2 == 0 for w, _ in wb[:nh])):
+                        layout = [((w.data_ptr() - hflat.data_ptr()) // 2, w.shape[0], w.shape[1]) for w, _ in wb]
+                        self._policy_bwd = F.PolicyBackward(hflat, layout, act_dim)
         if world > 1 and not self.fused:
             self.use_graphs = False  # the plain torch path has collectives in the middle of autograd-heavy code: eager only
         self._seg = None  # segmented graphs of the data-parallel update
@@ -724,6 +730,17 @@ class A2CAgent:
             part = torch.bmm(g16.view(s, ks, -1).transpose(1, 2), x16.view(s, ks, -1))
             F.wgrad_sum(part, m.weight.grad, accumulate=True)
         h_last = tf["act"][nh - 1]
+        if self._policy_bwd is not None:
+            # the whole input-gradient chain (head casts + bias sums, per layer ELU derivative + bias sum + dgrad GEMM) in one launch on
+            # the transposed weight copies (refreshed by one scatter of the fp16 working copy); the weight gradients follow as GEMMs
+            self._policy_bwd.refresh()
+            self._policy_bwd(gmu, gval, tf["act"], tf["gz"], tf["gmu16"], tf["gv16"], [lin[L].bias.grad for L in range(nh)],
+                             lin[nh].bias.grad, lin[nh + 1].bias.grad)
+            wgrad(tf["gmu16"], h_last, lin[nh])
+            wgrad(tf["gv16"], h_last, lin[nh + 1])
+            for L in range(nh - 1, -1, -1):
+                wgrad(tf["gz"][L], tf["act"][L - 1] if L > 0 else tf["x0"], lin[L])
+            return
         # the cast nodes' backward (fp32 -> fp16) and both head bias gradients: one launch
         F.head_grads_f16(gmu, gval, tf["gmu16"], tf["gv16"], lin[nh].bias.grad, lin[nh + 1].bias.grad)
         g = tf["g"][nh - 1]

@@ -4,6 +4,7 @@ d loss / d value and d loss / d log-std; the MLP's own backward stays PyTorch's)
 keeps the plain torch formulation these kernels are tested against."""
 import ctypes as C
 
+import numpy as np
 import torch
 
 from ..sim import load_library
@@ -20,6 +21,8 @@ _SIGS = {
     "bez_ppo_policy_forward": [_vp, _i64, _i32, _vp, _vp, _f, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp],
     "bez_ppo_policy_rollout_step": [_vp, _i64, _i32, _vp, _vp, _f, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f] + [_vp] * 9,
     "bez_ppo_policy_forward_train": [_vp, _i64, _i32, _vp, _vp, _f, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "bez_ppo_policy_backward": [_vp, _vp, _i64, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "bez_ppo_scatter_f16": [_vp, _vp, _i64, _vp, _vp],
     "bez_ppo_gae": [_vp, _vp, _vp, _vp, _vp, _i32, _i64, _f, _f, _vp, _vp, _vp],
     "bez_ppo_head_grads_f16": [_vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp],
     "bez_ppo_wgrad_sum": [_vp, _i32, _i64, _vp, _i32, _vp],
@@ -147,6 +150,56 @@ def rollout_pre(mu, value, logstd, noise, obs, dones, value_rms, mb_obs, mb_done
     _chk(lib().bez_ppo_rollout_pre(C.c_void_p(mu.data_ptr()), C.c_void_p(value.data_ptr()), 1 if half else 0, _p(logstd), _p(noise), _p(obs), _p(dones), vm, vv,
                                    0.0 if value_rms is None else float(value_rms.epsilon), n, a, obs.shape[1], _p(mb_obs), _p(mb_dones), _p(mb_mu), _p(mb_val),
                                    _p(act), _p(env_act), _p(neglogp), _p(sigma), _stream(mu)), "bez_ppo_rollout_pre")
+
+
+class PolicyBackward:
+    """One-launch input-gradient chain of the MLP's backward pass (csrc/bez_policy.hip policy_backward_kernel) + the transposed fp16
+    weight copies it reads, refreshed from the flat fp16 working copy `hflat` by one scatter launch.  `layout` = [(offset in hflat,
+    out, in)] of the weight of every Linear in network order (hidden layers, mu head, value head)."""
+
+    def __init__(self, hflat, layout, num_actions):
+        dev = hflat.device
+        nh = len(layout) - 2
+        self.nh, self.A, self.hflat = nh, num_actions, hflat
+        self.widths = [o for _, o, _ in layout[:nh]]
+        assert all(32 <= w <= 416 and w % 2 == 0 for w in self.widths) and num_actions <= 31
+        last = self.widths[-1]
+        sizes = [0] + [layout[i][1] * layout[i][2] for i in range(1, nh)]
+        offs = np.cumsum([0] + sizes).tolist()           # wt[i] at offs[i] (i >= 1), the heads matrix behind them
+        total = offs[nh] + last * 32
+        self.flat_t = torch.zeros(total, device=dev, dtype=torch.float16)
+        m = np.full(hflat.numel(), -1, dtype=np.int32)
+        for i in range(1, nh):                               # W_i (out, in) -> W_i^T (in, out)
+            off, o, k = layout[i]
+            src = off + np.arange(o * k).reshape(o, k)
+            m[src] = offs[i] + (np.arange(k)[None, :] * o + np.arange(o)[:, None])
+        off_mu, a, k = layout[nh]
+        assert a == num_actions and k == last and layout[nh + 1][1] == 1 and layout[nh + 1][2] == last
+        m[off_mu + np.arange(a * k).reshape(a, k)] = offs[nh] + (np.arange(k)[None, :] * 32 + np.arange(a)[:, None])
+        m[layout[nh + 1][0] + np.arange(k)] = offs[nh] + np.arange(k) * 32 + a
+        self.map = torch.from_numpy(m).to(dev)
+        self.wt = [None] + [self.flat_t[offs[i]:offs[i] + sizes[i]] for i in range(1, nh)]
+        self.wht = self.flat_t[offs[nh]:]
+        self.c_widths = (C.c_int32 * nh)(*self.widths)
+        self.c_wt = (C.c_void_p * nh)(*[None if w is None else w.data_ptr() for w in self.wt])
+
+    def refresh(self):
+        _chk(lib().bez_ppo_scatter_f16(_p(self.hflat, torch.float16), C.c_void_p(self.map.data_ptr()), self.hflat.numel(), _p(self.flat_t, torch.float16),
+                                       _stream(self.hflat)), "bez_ppo_scatter_f16")
+
+    def __call__(self, gmu, gval, acts, gz, gmu16, gv16, bias_grads, mu_bias_grad, value_bias_grad):
+        n = gmu.shape[0]
+        assert gmu.shape == (n, self.A) and gval.numel() == n and len(acts) == len(gz) == len(bias_grads) == self.nh
+        for a, z, b, w in zip(acts, gz, bias_grads, self.widths):
+            assert a.shape == (n, w) and z.shape == (n, w) and a.dtype == z.dtype == torch.float16 and a.is_contiguous() and z.is_contiguous()
+            assert b.dtype == torch.float32 and b.numel() == w and b.is_contiguous()
+        t_act = (C.c_void_p * self.nh)(*[a.data_ptr() for a in acts])
+        t_gz = (C.c_void_p * self.nh)(*[z.data_ptr() for z in gz])
+        t_b = (C.c_void_p * self.nh)(*[b.data_ptr() for b in bias_grads])
+        _chk(lib().bez_ppo_policy_backward(_p(gmu), _p(gval), n, self.nh, C.cast(self.c_widths, C.c_void_p), self.A, C.cast(t_act, C.c_void_p),
+                                           C.cast(self.c_wt, C.c_void_p), _p(self.wht, torch.float16), C.cast(t_gz, C.c_void_p), _p(gmu16, torch.float16),
+                                           _p(gv16, torch.float16), C.cast(t_b, C.c_void_p), _p(mu_bias_grad), _p(value_bias_grad), _stream(gmu)),
+             "bez_ppo_policy_backward")
 
 
 def gae(rewards, values, mb_dones, dones, last_values, gamma, tau, advs, returns=None):

@@ -352,13 +352,15 @@ def test_head_grads_kernel():
         np.testing.assert_allclose(bv.cpu(), (-0.25 + gval.half().double().sum(0)).float().cpu(), rtol=1e-5, atol=1e-6)
 
 
-def test_train_forward_kernel_and_manual_backward_match_autograd_path():
+@pytest.mark.parametrize("fused_backward", [False, True])
+def test_train_forward_kernel_and_manual_backward_match_autograd_path(fused_backward):
     """A PPO minibatch's gradient through (a) the one-launch MFMA forward that keeps the ELU outputs + the backward chain called
-    directly and (b) the torch GEMM forward + autograd through _HalfLinearEluFn / _HalfLinearFn: same dataset, same weights.
+    directly (its input-gradient half per layer, or as the one-launch MFMA backward kernel) and (b) the torch GEMM forward + autograd through _HalfLinearEluFn / _HalfLinearFn: same dataset, same weights.
     The forwards differ by fp16 roundings of the ELU (exp in fp32 either way) -- the flat gradients agree to that level."""
     from tests.test_gpu_round2 import _agent
     a = _agent(512, 4096, hip_graphs=False, fused_train_forward=False)
-    b = _agent(512, 4096, hip_graphs=False, fused_train_forward=True)
+    b = _agent(512, 4096, hip_graphs=False, fused_train_forward=True, fused_policy_backward=fused_backward)
+    assert (b._policy_bwd is not None) == fused_backward
     b.model.load_state_dict(a.model.state_dict())
     a.obs = a.env_reset()
     a.play_steps()
