@@ -242,6 +242,7 @@ struct BackwardArgs {
   _Float16* gz[PF_MAXL];
   _Float16* gmu16; _Float16* gv16;
   float* bgrad[PF_MAXL]; float* bmu_grad; float* bv_grad;
+  float* partial; int ptotal; int poff[PF_MAXL];  // per-workgroup column sums of gz (ceil(n / 64), ptotal = sum of the widths), layer L at poff[L]
 };
 
 __global__ __launch_bounds__(PF_WAVES * 64) void policy_backward_kernel(BackwardArgs a) {
@@ -284,18 +285,34 @@ __global__ __launch_bounds__(PF_WAVES * 64) void policy_backward_kernel(Backward
     const int part = tid / ncp, cp = tid - part * ncp;
     float2 acc = make_float2(0.f, 0.f);
     if (part < nparts) {  // gz = g * elu'(y), in place in the tile and out to HBM; consecutive threads on consecutive column pairs of a row
-      for (int rr = part; rr < nrow; rr += nparts) {
-        const uint32_t gy = *reinterpret_cast<const uint32_t*>(&buf[cur][rr][2 * cp]);
-        const uint32_t yy = *reinterpret_cast<const uint32_t*>(a.act[L] + (row0 + rr) * W + 2 * cp);
-        const _Float16 g0 = reinterpret_cast<const _Float16*>(&gy)[0], g1 = reinterpret_cast<const _Float16*>(&gy)[1];
-        const float y0 = (float)reinterpret_cast<const _Float16*>(&yy)[0], y1 = (float)reinterpret_cast<const _Float16*>(&yy)[1];
-        _Float16 z[2];
-        z[0] = (_Float16)((float)g0 * (y0 > 0.f ? 1.f : y0 + 1.f));
-        z[1] = (_Float16)((float)g1 * (y1 > 0.f ? 1.f : y1 + 1.f));
-        const uint32_t zz = *reinterpret_cast<const uint32_t*>(z);
-        *reinterpret_cast<uint32_t*>(&buf[cur][rr][2 * cp]) = zz;
-        *reinterpret_cast<uint32_t*>(a.gz[L] + (row0 + rr) * W + 2 * cp) = zz;
-        acc.x += (float)z[0]; acc.y += (float)z[1];  // the bias gradient sums what the GEMMs see
+      // eight rows per batch: all loads of the batch (ELU outputs from HBM, gradients from the tile) before its first store -- the
+      // stores may alias the loads as far as the compiler knows, so a plain loop would serialise one HBM latency per row
+      for (int rb = part; rb < nrow; rb += 8 * nparts) {
+        uint32_t yy[8], gy[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int rr = rb + u * nparts;
+          yy[u] = 0u; gy[u] = 0u;
+          if (rr < nrow) {
+            yy[u] = *reinterpret_cast<const uint32_t*>(a.act[L] + (row0 + rr) * W + 2 * cp);
+            gy[u] = *reinterpret_cast<const uint32_t*>(&buf[cur][rr][2 * cp]);
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int rr = rb + u * nparts;
+          if (rr < nrow) {
+            const _Float16 g0 = reinterpret_cast<const _Float16*>(&gy[u])[0], g1 = reinterpret_cast<const _Float16*>(&gy[u])[1];
+            const float y0 = (float)reinterpret_cast<const _Float16*>(&yy[u])[0], y1 = (float)reinterpret_cast<const _Float16*>(&yy[u])[1];
+            _Float16 z[2];
+            z[0] = (_Float16)((float)g0 * (y0 > 0.f ? 1.f : y0 + 1.f));
+            z[1] = (_Float16)((float)g1 * (y1 > 0.f ? 1.f : y1 + 1.f));
+            const uint32_t zz = *reinterpret_cast<const uint32_t*>(z);
+            *reinterpret_cast<uint32_t*>(&buf[cur][rr][2 * cp]) = zz;
+            *reinterpret_cast<uint32_t*>(a.gz[L] + (row0 + rr) * W + 2 * cp) = zz;
+            acc.x += (float)z[0]; acc.y += (float)z[1];  // the bias gradient sums what the GEMMs see
+          }
+        }
       }
     }
     red[tid] = acc;
@@ -303,14 +320,38 @@ __global__ __launch_bounds__(PF_WAVES * 64) void policy_backward_kernel(Backward
     if (tid < ncp) {
       float sx = 0.f, sy = 0.f;
       for (int q = 0; q < nparts; ++q) { sx += red[q * ncp + tid].x; sy += red[q * ncp + tid].y; }
-      atomicAdd(&a.bgrad[L][2 * tid], sx);
-      atomicAdd(&a.bgrad[L][2 * tid + 1], sy);
+      // (512 workgroups adding to the same 700 addresses cost 20 us of the kernel: per-workgroup partials + one small reduction instead)
+      float* dst = a.partial + (size_t)blockIdx.x * a.ptotal + a.poff[L] + 2 * tid;
+      dst[0] = sx; dst[1] = sy;
     }
     if (L > 0) {
       layer<false>(buf[cur], buf[cur ^ 1], a.wt[L], nullptr, W, a.width[L - 1], wave, lane);  // d/d h_{L-1} = gz W_L
       __syncthreads();
       cur ^= 1;
     }
+  }
+}
+
+// bias gradients of the hidden layers: column c of layer L += sum over the workgroups' partials.  1024 threads = 16 row lanes x 64
+// columns; a row lane sums every 16th partial (eight loads in flight), the lanes meet in LDS in a fixed order (deterministic)
+__global__ __launch_bounds__(1024) void policy_bias_reduce_kernel(BackwardArgs a, int nwg) {
+  __shared__ float sh[16][64];
+  const int l = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + l;
+  float s = 0.f;
+  if (c < a.ptotal) {
+#pragma unroll 8
+    for (int w = rl; w < nwg; w += 16) s += a.partial[(size_t)w * a.ptotal + c];
+  }
+  sh[rl][l] = s;
+  __syncthreads();
+  if (rl == 0 && c < a.ptotal) {
+    float t = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) t += sh[q][l];
+    int L = 0;
+    while (L + 1 < a.nhid && c >= a.poff[L + 1]) ++L;
+    a.bgrad[L][c - a.poff[L]] += t;
   }
 }
 
@@ -396,7 +437,8 @@ extern "C" int bez_ppo_policy_forward_train(const float* obs_dev, int64_t n, int
 extern "C" int bez_ppo_policy_backward(const float* grad_mu_dev, const float* grad_value_dev, int64_t n, int32_t num_hidden, const int32_t* hidden_width,
                                        int32_t num_actions, const void* const* act_f16_dev, const void* const* wt_f16_dev, const void* heads_t_f16_dev,
                                        void* const* gz_f16_dev, void* grad_mu_f16_dev, void* grad_value_f16_dev, float* const* bias_grad_dev,
-                                       float* mu_bias_grad_dev, float* value_bias_grad_dev, void* stream) {
+                                       float* mu_bias_grad_dev, float* value_bias_grad_dev, float* partial_dev, void* stream) {
+  if (!partial_dev) return -1;
   if (!grad_mu_dev || !grad_value_dev || n <= 0 || num_hidden <= 0 || num_hidden > PF_MAXL || !hidden_width || num_actions <= 0 || num_actions > 31 ||
       !act_f16_dev || !wt_f16_dev || !heads_t_f16_dev || !gz_f16_dev || !grad_mu_f16_dev || !grad_value_f16_dev || !bias_grad_dev || !mu_bias_grad_dev ||
       !value_bias_grad_dev) return -1;
@@ -412,7 +454,12 @@ extern "C" int bez_ppo_policy_backward(const float* grad_mu_dev, const float* gr
   }
   a.wht = (const _Float16*)heads_t_f16_dev; a.gmu16 = (_Float16*)grad_mu_f16_dev; a.gv16 = (_Float16*)grad_value_f16_dev;
   a.bmu_grad = mu_bias_grad_dev; a.bv_grad = value_bias_grad_dev;
-  hipLaunchKernelGGL(policy_backward_kernel, dim3((unsigned)((n + PF_ROWS - 1) / PF_ROWS)), dim3(PF_WAVES * 64), 0, (hipStream_t)stream, a);
+  a.partial = partial_dev; a.ptotal = 0;
+  for (int i = 0; i < PF_MAXL; ++i) a.poff[i] = 0;
+  for (int i = 0; i < num_hidden; ++i) { a.poff[i] = a.ptotal; a.ptotal += hidden_width[i]; }
+  const unsigned nwg = (unsigned)((n + PF_ROWS - 1) / PF_ROWS);
+  hipLaunchKernelGGL(policy_backward_kernel, dim3(nwg), dim3(PF_WAVES * 64), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(policy_bias_reduce_kernel, dim3((unsigned)((a.ptotal + 63) / 64)), dim3(1024), 0, (hipStream_t)stream, a, (int)nwg);
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 

@@ -21,7 +21,7 @@ _SIGS = {
     "bez_ppo_policy_forward": [_vp, _i64, _i32, _vp, _vp, _f, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp],
     "bez_ppo_policy_rollout_step": [_vp, _i64, _i32, _vp, _vp, _f, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f] + [_vp] * 9,
     "bez_ppo_policy_forward_train": [_vp, _i64, _i32, _vp, _vp, _f, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
-    "bez_ppo_policy_backward": [_vp, _vp, _i64, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "bez_ppo_policy_backward": [_vp, _vp, _i64, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "bez_ppo_scatter_f16": [_vp, _vp, _i64, _vp, _vp],
     "bez_ppo_gae": [_vp, _vp, _vp, _vp, _vp, _i32, _i64, _f, _f, _vp, _vp, _vp],
     "bez_ppo_head_grads_f16": [_vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp],
@@ -196,9 +196,12 @@ class PolicyBackward:
         t_act = (C.c_void_p * self.nh)(*[a.data_ptr() for a in acts])
         t_gz = (C.c_void_p * self.nh)(*[z.data_ptr() for z in gz])
         t_b = (C.c_void_p * self.nh)(*[b.data_ptr() for b in bias_grads])
+        need = ((n + 63) // 64) * sum(self.widths)
+        if getattr(self, "_partial", None) is None or self._partial.numel() < need:
+            self._partial = torch.empty(need, device=gmu.device, dtype=torch.float32)
         _chk(lib().bez_ppo_policy_backward(_p(gmu), _p(gval), n, self.nh, C.cast(self.c_widths, C.c_void_p), self.A, C.cast(t_act, C.c_void_p),
                                            C.cast(self.c_wt, C.c_void_p), _p(self.wht, torch.float16), C.cast(t_gz, C.c_void_p), _p(gmu16, torch.float16),
-                                           _p(gv16, torch.float16), C.cast(t_b, C.c_void_p), _p(mu_bias_grad), _p(value_bias_grad), _stream(gmu)),
+                                           _p(gv16, torch.float16), C.cast(t_b, C.c_void_p), _p(mu_bias_grad), _p(value_bias_grad), _p(self._partial), _stream(gmu)),
              "bez_ppo_policy_backward")
 
 

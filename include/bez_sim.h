@@ -295,11 +295,12 @@ int bez_ppo_elu_bwd_colsum_f16(const void* gy_f16_dev, const void* y_f16_dev, vo
  * the two loss gradients (operands of the head weight-gradient GEMMs); ADDED by atomics: the bias gradients of every hidden layer and of the
  * two heads.  Weight operands are transposed fp16 copies: wt[i] = W_i^T (hidden_width[i-1], hidden_width[i]) for i >= 1 (wt[0] unused) and
  * heads_t (hidden_width[last], 32) = [Wmu^T | Wvalue^T | 0]; bez_ppo_scatter_f16 refreshes them from a flat fp16 copy through an index map.
+ * partial_dev: scratch of ceil(n / 64) * sum(hidden_width) floats (per-workgroup column sums, reduced by a second small launch).
  * Widths even, 32 <= width <= 416. */
 int bez_ppo_policy_backward(const float* grad_mu_dev, const float* grad_value_dev, int64_t n, int32_t num_hidden, const int32_t* hidden_width,
                             int32_t num_actions, const void* const* act_f16_dev, const void* const* wt_f16_dev, const void* heads_t_f16_dev,
                             void* const* gz_f16_dev, void* grad_mu_f16_dev, void* grad_value_f16_dev, float* const* bias_grad_dev,
-                            float* mu_bias_grad_dev, float* value_bias_grad_dev, void* stream);
+                            float* mu_bias_grad_dev, float* value_bias_grad_dev, float* partial_dev, void* stream);
 int bez_ppo_scatter_f16(const void* src_f16_dev, const int32_t* map_dev, int64_t n, void* dst_f16_dev, void* stream); /* dst[map[i]] = src[i], map[i] >= 0 */
 
 /* GAE (rl_games a2c_common.py discount_values, called from play_steps): advantages (H,N) from rewards / values (H,N), the done
