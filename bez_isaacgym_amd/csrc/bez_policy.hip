@@ -50,7 +50,8 @@ struct PolicyArgs {
 
 // rows [0, nrow) x columns [0, cols) of an LDS activation tile -> global (row-major, `cols` halfs per row, cols even): half2 per
 // lane, consecutive lanes on consecutive columns (256 B per wave instruction)
-__device__ __forceinline__ void store_tile(const _Float16 (*src)[PF_LD], _Float16* dst, int64_t row0, int nrow, int cols, int tid) {
+template <int LD>
+__device__ __forceinline__ void store_tile(const _Float16 (*src)[LD], _Float16* dst, int64_t row0, int nrow, int cols, int tid) {
   const int c2 = cols >> 1;
   for (int idx = tid; idx < nrow * c2; idx += PF_WAVES * 64) {
     const int rr = idx / c2, c = idx - rr * c2;
@@ -77,7 +78,8 @@ __device__ __forceinline__ half8 load_w8(const _Float16* row, int k0, int cols) 
 // acc0 / acc1 (rows 0..31 / 32..63 of the workgroup) += src[:, 0:in] * wrow[0:in] for this lane's column (wrow = its weight row,
 // live = the column exists).  The weight fragments of up to twelve k-steps are fetched before the first of their MFMAs: the loop
 // is bound by the latency of those L2 reads, not by the matrix pipe.
-__device__ __forceinline__ void gemm_col_block(const _Float16 (*src)[PF_LD], const _Float16* wrow, bool live, int in, int r, int h, f32x16& acc0, f32x16& acc1) {
+template <int LD>
+__device__ __forceinline__ void gemm_col_block(const _Float16 (*src)[LD], const _Float16* wrow, bool live, int in, int r, int h, f32x16& acc0, f32x16& acc1) {
   const int full = ((in & 1) == 0) ? (in >> 4) : 0;  // k-steps whose 16 columns all exist (and whose rows are 4-byte aligned)
   const int ksteps = (in + 15) >> 4;
   int ks = 0;
@@ -119,11 +121,11 @@ __device__ __forceinline__ void gemm_col_block(const _Float16 (*src)[PF_LD], con
 }
 
 // dst[:, 0:Npad] = act(src[:, 0:K] W^T + b) for the 64 rows of the workgroup; this wave takes column blocks wave, wave + PF_WAVES, ...
-template <bool ELU>
-__device__ __forceinline__ void layer(const _Float16 (*src)[PF_LD], _Float16 (*dst)[PF_LD], const _Float16* W, const _Float16* B, int in, int out, int wave,
+template <bool ELU, int LDS, int LDD>
+__device__ __forceinline__ void layer(const _Float16 (*src)[LDS], _Float16 (*dst)[LDD], const _Float16* W, const _Float16* B, int in, int out, int wave,
                                       int lane) {
   const int r = lane & 31, h = lane >> 5;
-  const int nblk = (out + 31) >> 5;
+  const int nblk = (out + 31) >> 5, npad = (out + 15) & ~15;  // (a narrow tile only covers the width padded to 16 columns)
   for (int nb = wave; nb < nblk; nb += PF_WAVES) {
     const int n = nb * 32 + r;
     const _Float16* wrow = W + (size_t)(n < out ? n : 0) * in;
@@ -137,17 +139,48 @@ __device__ __forceinline__ void layer(const _Float16 (*src)[PF_LD], _Float16 (*d
       const int row = (i & 3) + 8 * (i >> 2) + 4 * h;
       float v0 = (float)(_Float16)(acc0[i] + bias), v1 = (float)(_Float16)(acc1[i] + bias);  // the fp16 output of the Linear
       if (ELU) { v0 = v0 > 0.f ? v0 : __expf(v0) - 1.f; v1 = v1 > 0.f ? v1 : __expf(v1) - 1.f; }  // (v_exp_f32: the result is rounded to fp16 anyway)
-      dst[row][n] = (_Float16)v0;
-      dst[32 + row][n] = (_Float16)v1;
+      if (LDD >= PF_LD || n < npad) {
+        dst[row][n] = (_Float16)v0;
+        dst[32 + row][n] = (_Float16)v1;
+      }
     }
   }
 }
 
-// MODE 0: forward only; 1: rollout step (ROLL); 2: training forward (activations kept for the backward pass)
-template <int MODE>
+// the two heads on the last hidden activations `src`: one column block (num_actions + 1 <= 32 columns), wave 0; results as fp32 of the
+// fp16 outputs, to global memory or (rollout mode) into `tile`, the free activation tile viewed as 33-float rows
+template <bool ROLL, int LD>
+__device__ __forceinline__ void heads(const PolicyArgs& a, const _Float16 (*src)[LD], int in, float* tile, int64_t row0, int nrow, int lane) {
+  const int r = lane & 31, h = lane >> 5, A = a.num_actions;
+  const _Float16* wrow = r < A ? a.w_mu + (size_t)r * in : a.w_val;
+  const bool live = r <= A;
+  f32x16 acc0, acc1;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
+  gemm_col_block(src, wrow, live, in, r, h, acc0, acc1);
+  const float bias = r < A ? (float)a.b_mu[r] : (r == A ? (float)a.b_val[0] : 0.f);
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int row = (i & 3) + 8 * (i >> 2) + 4 * h;
+    const float v0 = (float)(_Float16)(acc0[i] + bias), v1 = (float)(_Float16)(acc1[i] + bias);
+    if (ROLL) {
+      if (r <= A) { tile[row * 33 + r] = v0; tile[(32 + row) * 33 + r] = v1; }
+    } else {
+      if (row < nrow) { if (r < A) a.mu[(row0 + row) * A + r] = v0; else if (r == A) a.value[row0 + row] = v0; }
+      if (32 + row < nrow) { if (r < A) a.mu[(row0 + 32 + row) * A + r] = v1; else if (r == A) a.value[row0 + 32 + row] = v1; }
+    }
+  }
+}
+
+// MODE 0: forward only; 1: rollout step (ROLL); 2: training forward (activations kept for the backward pass).  LD0 / LD1: row strides
+// (halfs) of the two LDS activation tiles -- tile 0 holds the staged input and the outputs of layers 1, 3, 5, tile 1 those of layers
+// 0, 2, 4.  (424, 424) fits every supported width; (216, 424) is 80 KB, so that two workgroups share a CU (training forward of
+// 54-400-200-100: 512 workgroups, each one's MFMAs cover the other's weight-fetch latency).
+template <int MODE, int LD0, int LD1>
 __global__ __launch_bounds__(PF_WAVES * 64) void policy_forward_kernel(PolicyArgs a) {
   constexpr bool ROLL = MODE == 1, TRAIN = MODE == 2;
-  __shared__ __attribute__((aligned(16))) _Float16 buf[2][PF_ROWS][PF_LD];
+  __shared__ __attribute__((aligned(16))) _Float16 t0[PF_ROWS][LD0];
+  __shared__ __attribute__((aligned(16))) _Float16 t1[PF_ROWS][LD1];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int64_t row0 = (int64_t)blockIdx.x * PF_ROWS;
   const int nrow = (int)((a.n - row0) < (int64_t)PF_ROWS ? (a.n - row0) : (int64_t)PF_ROWS);
@@ -164,40 +197,29 @@ __global__ __launch_bounds__(PF_WAVES * 64) void policy_forward_kernel(PolicyArg
         v = fminf(fmaxf(v, -5.0f), 5.0f);
       }
     }
-    buf[0][rr][k] = (_Float16)v;
+    t0[rr][k] = (_Float16)v;
   }
   __syncthreads();
-  if (TRAIN) store_tile(buf[0], a.x0_out, row0, nrow, a.d_in, tid);
-  int cur = 0, in = a.d_in;
-  for (int L = 0; L < a.nhid; ++L) {
-    layer<true>(buf[cur], buf[cur ^ 1], a.w[L], a.b[L], in, a.width[L], wave, lane);
+  if (TRAIN) store_tile(t0, a.x0_out, row0, nrow, a.d_in, tid);
+  int in = a.d_in;
+  for (int L = 0; L < a.nhid; L += 2) {
+    layer<true>(t0, t1, a.w[L], a.b[L], in, a.width[L], wave, lane);
     // the next layer reads K padded to 16: columns width..pad16(width) were written as elu(0 + 0) = 0 by the padded column block
     __syncthreads();
-    cur ^= 1; in = a.width[L];
-    if (TRAIN) store_tile(buf[cur], a.act_out[L], row0, nrow, in, tid);  // (the stores drain behind the next layer's MFMAs)
-  }
-  // heads: one column block (num_actions + 1 <= 32 columns), wave 0; results to global memory as fp32 of the fp16 outputs
-  float* tile = reinterpret_cast<float*>(&buf[cur ^ 1][0][0]);
-  if (wave == 0) {
-    const int r = lane & 31, h = lane >> 5, A = a.num_actions;
-    const _Float16* wrow = r < A ? a.w_mu + (size_t)r * in : a.w_val;
-    const bool live = r <= A;
-    f32x16 acc0, acc1;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
-    gemm_col_block(buf[cur], wrow, live, in, r, h, acc0, acc1);
-    const float bias = r < A ? (float)a.b_mu[r] : (r == A ? (float)a.b_val[0] : 0.f);
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int row = (i & 3) + 8 * (i >> 2) + 4 * h;
-      const float v0 = (float)(_Float16)(acc0[i] + bias), v1 = (float)(_Float16)(acc1[i] + bias);
-      if (ROLL) {  // (row, column) tile of the head outputs for the sampling pass below: the free LDS buffer, fp32 view, 33-float rows
-        if (r <= A) { tile[row * 33 + r] = v0; tile[(32 + row) * 33 + r] = v1; }
-      } else {
-        if (row < nrow) { if (r < A) a.mu[(row0 + row) * A + r] = v0; else if (r == A) a.value[row0 + row] = v0; }
-        if (32 + row < nrow) { if (r < A) a.mu[(row0 + 32 + row) * A + r] = v1; else if (r == A) a.value[row0 + 32 + row] = v1; }
-      }
+    in = a.width[L];
+    if (TRAIN) store_tile(t1, a.act_out[L], row0, nrow, in, tid);  // (the stores drain behind the next layer's MFMAs)
+    if (L + 1 < a.nhid) {
+      layer<true>(t1, t0, a.w[L + 1], a.b[L + 1], in, a.width[L + 1], wave, lane);
+      __syncthreads();
+      in = a.width[L + 1];
+      if (TRAIN) store_tile(t0, a.act_out[L + 1], row0, nrow, in, tid);
     }
+  }
+  const bool in_t1 = (a.nhid & 1) != 0;  // where the last hidden activations are; the other tile is free
+  float* tile = in_t1 ? reinterpret_cast<float*>(&t0[0][0]) : reinterpret_cast<float*>(&t1[0][0]);
+  if (wave == 0) {
+    if (in_t1) heads<ROLL>(a, t1, in, tile, row0, nrow, lane);
+    else heads<ROLL>(a, t0, in, tile, row0, nrow, lane);
   }
   if (ROLL) {
     // sampling, neglogp, clamp, rollout-buffer rows: one thread per (env, action), the per-env sum through the same LDS tile
@@ -245,9 +267,70 @@ struct BackwardArgs {
   float* partial; int ptotal; int poff[PF_MAXL];  // per-workgroup column sums of gz (ceil(n / 64), ptotal = sum of the widths), layer L at poff[L]
 };
 
-__global__ __launch_bounds__(PF_WAVES * 64) void policy_backward_kernel(BackwardArgs a) {
-  __shared__ __attribute__((aligned(16))) _Float16 buf[2][PF_ROWS][PF_LD];
-  __shared__ float2 red[PF_WAVES * 64];
+// one layer of the chain: gz = g * elu'(y) in place in tile A (and out to HBM), its per-workgroup column sums, then d/d h_{L-1} = gz W_L
+// into tile B.  The reduction scratch lives in tile B, which is free until the GEMM writes it.
+template <int LA, int LB>
+__device__ __forceinline__ void backward_stage(const BackwardArgs& a, _Float16 (*A)[LA], _Float16 (*B)[LB], int L, int64_t row0, int nrow, int tid,
+                                               int wave, int lane) {
+  constexpr int NT = PF_WAVES * 64;
+  float2* red = reinterpret_cast<float2*>(&B[0][0]);
+  static_assert(sizeof(_Float16) * PF_ROWS * LB >= sizeof(float2) * NT, "the free tile holds the reduction scratch");
+  const int W = a.width[L], ncp = W >> 1, nparts = NT / ncp;
+  const int part = tid / ncp, cp = tid - part * ncp;
+  float2 acc = make_float2(0.f, 0.f);
+  if (part < nparts) {  // consecutive threads on consecutive column pairs of a row
+    // eight rows per batch: all loads of the batch (ELU outputs from HBM, gradients from the tile) before its first store -- the
+    // stores may alias the loads as far as the compiler knows, so a plain loop would serialise one HBM latency per row
+    for (int rb = part; rb < nrow; rb += 8 * nparts) {
+      uint32_t yy[8], gy[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int rr = rb + u * nparts;
+        yy[u] = 0u; gy[u] = 0u;
+        if (rr < nrow) {
+          yy[u] = *reinterpret_cast<const uint32_t*>(a.act[L] + (row0 + rr) * W + 2 * cp);
+          gy[u] = *reinterpret_cast<const uint32_t*>(&A[rr][2 * cp]);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int rr = rb + u * nparts;
+        if (rr < nrow) {
+          const _Float16 g0 = reinterpret_cast<const _Float16*>(&gy[u])[0], g1 = reinterpret_cast<const _Float16*>(&gy[u])[1];
+          const float y0 = (float)reinterpret_cast<const _Float16*>(&yy[u])[0], y1 = (float)reinterpret_cast<const _Float16*>(&yy[u])[1];
+          _Float16 z[2];
+          z[0] = (_Float16)((float)g0 * (y0 > 0.f ? 1.f : y0 + 1.f));
+          z[1] = (_Float16)((float)g1 * (y1 > 0.f ? 1.f : y1 + 1.f));
+          const uint32_t zz = *reinterpret_cast<const uint32_t*>(z);
+          *reinterpret_cast<uint32_t*>(&A[rr][2 * cp]) = zz;
+          *reinterpret_cast<uint32_t*>(a.gz[L] + (row0 + rr) * W + 2 * cp) = zz;
+          acc.x += (float)z[0]; acc.y += (float)z[1];  // the bias gradient sums what the GEMMs see
+        }
+      }
+    }
+  }
+  red[tid] = acc;
+  __syncthreads();
+  if (tid < ncp) {
+    float sx = 0.f, sy = 0.f;
+    for (int q = 0; q < nparts; ++q) { sx += red[q * ncp + tid].x; sy += red[q * ncp + tid].y; }
+    // (512 workgroups adding to the same 700 addresses cost 20 us of the kernel: per-workgroup partials + one small reduction instead)
+    float* dst = a.partial + (size_t)blockIdx.x * a.ptotal + a.poff[L] + 2 * tid;
+    dst[0] = sx; dst[1] = sy;
+  }
+  if (L > 0) {
+    __syncthreads();  // the scratch has been read: tile B may be overwritten
+    layer<false>(A, B, a.wt[L], nullptr, W, a.width[L - 1], wave, lane);  // d/d h_{L-1} = gz W_L
+    __syncthreads();
+  }
+}
+
+// LD0 / LD1: row strides of the two LDS tiles.  Tile 0 holds the (64, 32) head-gradient tile and d/d h_L for L = nhid-2, nhid-4, ...;
+// tile 1 holds d/d h_L for L = nhid-1, nhid-3, ...  (216, 424) = 80 KB: two workgroups per CU for 54-400-200-100.
+template <int LD0, int LD1>
+__global__ __launch_bounds__(PF_WAVES * 64, 4) void policy_backward_kernel(BackwardArgs a) {  // 4 waves per SIMD = two workgroups per CU: <= 128 VGPRs
+  __shared__ __attribute__((aligned(16))) _Float16 t0[PF_ROWS][LD0];
+  __shared__ __attribute__((aligned(16))) _Float16 t1[PF_ROWS][LD1];
   constexpr int NT = PF_WAVES * 64;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int64_t row0 = (int64_t)blockIdx.x * PF_ROWS;
@@ -255,6 +338,7 @@ __global__ __launch_bounds__(PF_WAVES * 64) void policy_backward_kernel(Backward
   const int A = a.num_actions;
   {  // heads: the (64, 32) tile [d/d mu | d/d value | 0] as fp16 (= the cast nodes of autocast), its copies for the head weight-gradient
      // GEMMs, and its column sums = the head bias gradients.  Thread -> column tid & 31, rows tid >> 5, + 16, ...
+    float* red = reinterpret_cast<float*>(&t1[0][0]);  // (tile 1 is free until the first GEMM)
     const int k = tid & 31, rsub = tid >> 5;
     float acc = 0.f;
 #pragma unroll
@@ -263,72 +347,28 @@ __global__ __launch_bounds__(PF_WAVES * 64) void policy_backward_kernel(Backward
       float v = 0.f;
       if (rr < nrow) v = k < A ? a.gmu[(row0 + rr) * A + k] : (k == A ? a.gval[row0 + rr] : 0.f);
       const _Float16 hv = (_Float16)v;
-      buf[0][rr][k] = hv;
+      t0[rr][k] = hv;
       if (rr < nrow) {
         if (k < A) a.gmu16[(row0 + rr) * A + k] = hv; else if (k == A) a.gv16[row0 + rr] = hv;
         acc += (float)hv;
       }
     }
-    red[tid].x = acc;
+    red[tid] = acc;
     __syncthreads();
     if (tid <= A) {
       float sum = 0.f;
-      for (int q = 0; q < NT / 32; ++q) sum += red[q * 32 + tid].x;
+      for (int q = 0; q < NT / 32; ++q) sum += red[q * 32 + tid];
       atomicAdd(tid < A ? &a.bmu_grad[tid] : a.bv_grad, sum);
     }
-  }
-  int cur = 1;
-  layer<false>(buf[0], buf[1], a.wht, nullptr, 32, a.width[a.nhid - 1], wave, lane);  // d/d h_last = [gmu | gval] [Wmu; Wv]
-  __syncthreads();
-  for (int L = a.nhid - 1; L >= 0; --L) {
-    const int W = a.width[L], ncp = W >> 1, nparts = NT / ncp;
-    const int part = tid / ncp, cp = tid - part * ncp;
-    float2 acc = make_float2(0.f, 0.f);
-    if (part < nparts) {  // gz = g * elu'(y), in place in the tile and out to HBM; consecutive threads on consecutive column pairs of a row
-      // eight rows per batch: all loads of the batch (ELU outputs from HBM, gradients from the tile) before its first store -- the
-      // stores may alias the loads as far as the compiler knows, so a plain loop would serialise one HBM latency per row
-      for (int rb = part; rb < nrow; rb += 8 * nparts) {
-        uint32_t yy[8], gy[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const int rr = rb + u * nparts;
-          yy[u] = 0u; gy[u] = 0u;
-          if (rr < nrow) {
-            yy[u] = *reinterpret_cast<const uint32_t*>(a.act[L] + (row0 + rr) * W + 2 * cp);
-            gy[u] = *reinterpret_cast<const uint32_t*>(&buf[cur][rr][2 * cp]);
-          }
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const int rr = rb + u * nparts;
-          if (rr < nrow) {
-            const _Float16 g0 = reinterpret_cast<const _Float16*>(&gy[u])[0], g1 = reinterpret_cast<const _Float16*>(&gy[u])[1];
-            const float y0 = (float)reinterpret_cast<const _Float16*>(&yy[u])[0], y1 = (float)reinterpret_cast<const _Float16*>(&yy[u])[1];
-            _Float16 z[2];
-            z[0] = (_Float16)((float)g0 * (y0 > 0.f ? 1.f : y0 + 1.f));
-            z[1] = (_Float16)((float)g1 * (y1 > 0.f ? 1.f : y1 + 1.f));
-            const uint32_t zz = *reinterpret_cast<const uint32_t*>(z);
-            *reinterpret_cast<uint32_t*>(&buf[cur][rr][2 * cp]) = zz;
-            *reinterpret_cast<uint32_t*>(a.gz[L] + (row0 + rr) * W + 2 * cp) = zz;
-            acc.x += (float)z[0]; acc.y += (float)z[1];  // the bias gradient sums what the GEMMs see
-          }
-        }
-      }
-    }
-    red[tid] = acc;
     __syncthreads();
-    if (tid < ncp) {
-      float sx = 0.f, sy = 0.f;
-      for (int q = 0; q < nparts; ++q) { sx += red[q * ncp + tid].x; sy += red[q * ncp + tid].y; }
-      // (512 workgroups adding to the same 700 addresses cost 20 us of the kernel: per-workgroup partials + one small reduction instead)
-      float* dst = a.partial + (size_t)blockIdx.x * a.ptotal + a.poff[L] + 2 * tid;
-      dst[0] = sx; dst[1] = sy;
-    }
-    if (L > 0) {
-      layer<false>(buf[cur], buf[cur ^ 1], a.wt[L], nullptr, W, a.width[L - 1], wave, lane);  // d/d h_{L-1} = gz W_L
-      __syncthreads();
-      cur ^= 1;
-    }
+  }
+  layer<false>(t0, t1, a.wht, nullptr, 32, a.width[a.nhid - 1], wave, lane);  // d/d h_last = [gmu | gval] [Wmu; Wv]
+  __syncthreads();
+  bool in1 = true;
+  for (int L = a.nhid - 1; L >= 0; --L) {
+    if (in1) backward_stage(a, t1, t0, L, row0, nrow, tid, wave, lane);
+    else backward_stage(a, t0, t1, L, row0, nrow, tid, wave, lane);
+    in1 = !in1;
   }
 }
 
@@ -393,7 +433,7 @@ extern "C" int bez_ppo_policy_forward(const float* obs_dev, int64_t n, int32_t n
   if (!mu_dev || !value_dev || fill_args(a, obs_dev, n, num_obs, obs_mean_dev, obs_var_dev, obs_eps, num_hidden, hidden_w_f16_dev, hidden_b_f16_dev, hidden_width,
                                          mu_w_f16_dev, mu_b_f16_dev, num_actions, value_w_f16_dev, value_b_f16_dev)) return -1;
   a.mu = mu_dev; a.value = value_dev;
-  hipLaunchKernelGGL(policy_forward_kernel<0>, dim3((unsigned)((n + PF_ROWS - 1) / PF_ROWS)), dim3(PF_WAVES * 64), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL((policy_forward_kernel<0, PF_LD, PF_LD>), dim3((unsigned)((n + PF_ROWS - 1) / PF_ROWS)), dim3(PF_WAVES * 64), 0, (hipStream_t)stream, a);
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
@@ -412,7 +452,7 @@ extern "C" int bez_ppo_policy_rollout_step(const float* obs_dev, int64_t n, int3
   a.logstd = logstd_dev; a.noise = noise_dev; a.dones = dones_dev; a.vmean = value_mean_dev; a.vvar = value_var_dev; a.veps = value_eps;
   a.mb_obs = mb_obs_dev; a.mb_dones = mb_dones_dev; a.mb_mu = mb_mu_dev; a.mb_val = mb_val_dev; a.act = actions_dev; a.act_env = env_actions_dev;
   a.neglogp = neglogp_dev; a.sigma = sigma_dev;
-  hipLaunchKernelGGL(policy_forward_kernel<1>, dim3((unsigned)((n + PF_ROWS - 1) / PF_ROWS)), dim3(PF_WAVES * 64), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL((policy_forward_kernel<1, PF_LD, PF_LD>), dim3((unsigned)((n + PF_ROWS - 1) / PF_ROWS)), dim3(PF_WAVES * 64), 0, (hipStream_t)stream, a);
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
@@ -430,7 +470,13 @@ extern "C" int bez_ppo_policy_forward_train(const float* obs_dev, int64_t n, int
     a.act_out[i] = (_Float16*)act_f16_dev[i];
   }
   a.x0_out = (_Float16*)x0_f16_dev; a.mu = mu_dev; a.value = value_dev;
-  hipLaunchKernelGGL(policy_forward_kernel<2>, dim3((unsigned)((n + PF_ROWS - 1) / PF_ROWS)), dim3(PF_WAVES * 64), 0, (hipStream_t)stream, a);
+  // tile 0 holds the input and the outputs of the odd layers, tile 1 those of the even layers: with strides (216, 424) the tiles are
+  // 80 KB and two workgroups share a CU
+  int w0 = num_obs, w1 = 0;
+  for (int i = 0; i < num_hidden; ++i) { int& w = (i & 1) ? w0 : w1; if (hidden_width[i] > w) w = hidden_width[i]; }
+  const dim3 grid((unsigned)((n + PF_ROWS - 1) / PF_ROWS)), block(PF_WAVES * 64);
+  if (((w0 + 15) & ~15) + 8 <= 216) hipLaunchKernelGGL((policy_forward_kernel<2, 216, PF_LD>), grid, block, 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL((policy_forward_kernel<2, PF_LD, PF_LD>), grid, block, 0, (hipStream_t)stream, a);
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
@@ -458,7 +504,10 @@ extern "C" int bez_ppo_policy_backward(const float* grad_mu_dev, const float* gr
   for (int i = 0; i < PF_MAXL; ++i) a.poff[i] = 0;
   for (int i = 0; i < num_hidden; ++i) { a.poff[i] = a.ptotal; a.ptotal += hidden_width[i]; }
   const unsigned nwg = (unsigned)((n + PF_ROWS - 1) / PF_ROWS);
-  hipLaunchKernelGGL(policy_backward_kernel, dim3(nwg), dim3(PF_WAVES * 64), 0, (hipStream_t)stream, a);
+  int w0 = 32, w1 = 0;  // widest tenant of each tile (see policy_backward_kernel)
+  for (int i = 0; i < num_hidden; ++i) { int& w = ((num_hidden - 1 - i) & 1) ? w0 : w1; if (hidden_width[i] > w) w = hidden_width[i]; }
+  if (((w0 + 15) & ~15) + 8 <= 216) hipLaunchKernelGGL((policy_backward_kernel<216, PF_LD>), dim3(nwg), dim3(PF_WAVES * 64), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL((policy_backward_kernel<PF_LD, PF_LD>), dim3(nwg), dim3(PF_WAVES * 64), 0, (hipStream_t)stream, a);
   hipLaunchKernelGGL(policy_bias_reduce_kernel, dim3((unsigned)((a.ptotal + 63) / 64)), dim3(1024), 0, (hipStream_t)stream, a, (int)nwg);
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
