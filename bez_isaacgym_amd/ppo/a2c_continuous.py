@@ -365,7 +365,7 @@ class A2CAgent:
             self._f_obs_rms = F.FusedRunningMeanStd(self.running_mean_std, red) if self.normalize_input else None
             self.half_path = bool(self.mixed_precision and self.normalize_input and c.get("half_path", True))
             if self.half_path:
-                self.model.a2c_network.enable_half_path(int(c.get("wgrad_splits", 64)))
+                self.model.a2c_network.enable_half_path(int(c.get("wgrad_splits", 32)))
             self._bind_flat_grads()
             self._fused_opt = bool(c.get("fused_optimizer", True))
             if self._fused_opt:
