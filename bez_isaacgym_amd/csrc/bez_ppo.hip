@@ -423,6 +423,17 @@ __global__ __launch_bounds__(PPO_TB) void head_grads_kernel(const float* __restr
   if ((tid & 63) == 0) atomicAdd(bv_grad, vacc);
 }
 
+// ---- rl_games AdaptiveScheduler.update on device scalars: lr /= 1.5 (floor min_lr) when kl > 2 thr, lr *= 1.5 (cap max_lr) when
+// kl < thr / 2, in the reference's order (both tests see the lr the first one left)
+__global__ void adaptive_lr_kernel(float* __restrict__ lr, const float* __restrict__ kl, float thr, float min_lr, float max_lr) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  float v = lr[0];
+  const float k = kl[0];
+  if (k > 2.0f * thr) v = fmaxf(v / 1.5f, min_lr);
+  if (k < 0.5f * thr) v = fminf(v * 1.5f, max_lr);
+  lr[0] = v;
+}
+
 // ---- GAE backward scan over the horizon (rl_games a2c_common.discount_values): one thread per env walks t = H-1 .. 0 with the
 // same fp32 operations, in the same order, as the 8 elementwise launches per step of the torch formulation
 __global__ __launch_bounds__(PPO_TB) void gae_kernel(const float* __restrict__ rew, const float* __restrict__ val, const float* __restrict__ mb_dones,
@@ -639,6 +650,12 @@ int bez_ppo_elu_bwd_colsum_f16(const void* gy_f16_dev, const void* y_f16_dev, vo
   const int64_t rpb = 256;
   hipLaunchKernelGGL(elu_bwd_colsum_kernel, dim3((unsigned)((cols + 127) / 128), (unsigned)((rows + rpb - 1) / rpb)), dim3(ELU_RL * 64), 0, (hipStream_t)stream,
                      (const __half*)gy_f16_dev, (const __half*)y_f16_dev, (__half*)gz_f16_dev, rows, (int)cols, rpb, bias_grad_dev);
+  return launch_ok();
+}
+
+int bez_ppo_adaptive_lr(float* lr_dev, const float* kl_dev, float kl_threshold, float min_lr, float max_lr, void* stream) {
+  if (!lr_dev || !kl_dev) return -1;
+  hipLaunchKernelGGL(adaptive_lr_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, lr_dev, kl_dev, kl_threshold, min_lr, max_lr);
   return launch_ok();
 }
 

@@ -228,6 +228,9 @@ class AdaptiveScheduler:
 
     @torch.no_grad()
     def update_(self, lr_t, kl_t):
+        if isinstance(lr_t, torch.Tensor) and lr_t.is_cuda and lr_t.dtype == torch.float32 and kl_t.dtype == torch.float32 and lr_t.is_contiguous():
+            from . import fused as F   # one launch instead of ten elementwise ones
+            return F.adaptive_lr(lr_t, kl_t, self.kl_threshold, self.min_lr, self.max_lr)
         cur = lr_t.value if hasattr(lr_t, "value") else lr_t
         down = torch.clamp(cur / 1.5, min=self.min_lr)
         lr1 = torch.where(kl_t > 2.0 * self.kl_threshold, down, cur)

@@ -23,6 +23,7 @@ _SIGS = {
     "bez_ppo_policy_forward_train": [_vp, _i64, _i32, _vp, _vp, _f, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "bez_ppo_policy_backward": [_vp, _vp, _i64, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "bez_ppo_scatter_f16": [_vp, _vp, _i64, _vp, _vp],
+    "bez_ppo_adaptive_lr": [_vp, _vp, _f, _f, _f, _vp],
     "bez_ppo_gae": [_vp, _vp, _vp, _vp, _vp, _i32, _i64, _f, _f, _vp, _vp, _vp],
     "bez_ppo_head_grads_f16": [_vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp],
     "bez_ppo_wgrad_sum": [_vp, _i32, _i64, _vp, _i32, _vp],
@@ -203,6 +204,12 @@ class PolicyBackward:
                                            C.cast(self.c_wt, C.c_void_p), _p(self.wht, torch.float16), C.cast(t_gz, C.c_void_p), _p(gmu16, torch.float16),
                                            _p(gv16, torch.float16), C.cast(t_b, C.c_void_p), _p(mu_bias_grad), _p(value_bias_grad), _p(self._partial), _stream(gmu)),
              "bez_ppo_policy_backward")
+
+
+def adaptive_lr(lr, kl, kl_threshold, min_lr, max_lr):
+    """AdaptiveScheduler.update on the device-resident lr (0-dim / 1-element fp32 tensors)."""
+    assert lr.numel() == 1 and kl.numel() == 1
+    _chk(lib().bez_ppo_adaptive_lr(_p(lr), _p(kl), float(kl_threshold), float(min_lr), float(max_lr), _stream(lr)), "bez_ppo_adaptive_lr")
 
 
 def gae(rewards, values, mb_dones, dones, last_values, gamma, tau, advs, returns=None):

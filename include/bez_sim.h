@@ -303,6 +303,10 @@ int bez_ppo_policy_backward(const float* grad_mu_dev, const float* grad_value_de
                             float* mu_bias_grad_dev, float* value_bias_grad_dev, float* partial_dev, void* stream);
 int bez_ppo_scatter_f16(const void* src_f16_dev, const int32_t* map_dev, int64_t n, void* dst_f16_dev, void* stream); /* dst[map[i]] = src[i], map[i] >= 0 */
 
+/* rl_games AdaptiveScheduler.update (the `lr_schedule: adaptive` rule of bez_kickPPO.yaml) on device scalars: *lr /= 1.5 when *kl > 2 *
+ * kl_threshold (floor min_lr), then *lr *= 1.5 when *kl < kl_threshold / 2 (cap max_lr).  No host round trip. */
+int bez_ppo_adaptive_lr(float* lr_dev, const float* kl_dev, float kl_threshold, float min_lr, float max_lr, void* stream);
+
 /* GAE (rl_games a2c_common.py discount_values, called from play_steps): advantages (H,N) from rewards / values (H,N), the done
  * flags recorded BEFORE each step (H,N), the current done flags (N) and the bootstrap values (N); returns_dev (optional) = advantages +
  * values.  One thread per env, the reference's operation order. */

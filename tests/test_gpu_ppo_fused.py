@@ -324,6 +324,16 @@ def test_fused_and_plain_optimiser_step_agree():
     assert len(fused2.game_rewards) > 0
 
 
+def test_adaptive_lr_kernel_matches_the_scheduler_rule():
+    from bez_isaacgym_amd.ppo import fused as F
+    from bez_isaacgym_amd.ppo.a2c_continuous import AdaptiveScheduler
+    sch = AdaptiveScheduler(0.008)
+    for lr0, kl in ((3e-4, 0.02), (3e-4, 0.001), (3e-4, 0.008), (1e-6, 0.5), (1e-2, 0.0), (9e-3, 0.0039), (1.2e-6, 0.0161)):
+        lr = torch.tensor([lr0], device=DEV)
+        F.adaptive_lr(lr, torch.tensor([kl], device=DEV), sch.kl_threshold, sch.min_lr, sch.max_lr)
+        np.testing.assert_allclose(float(lr), sch.update(lr0, kl), rtol=1e-6)
+
+
 def test_gae_kernel_matches_discount_values():
     from bez_isaacgym_amd.ppo import fused as F
     from bez_isaacgym_amd.ppo.a2c_continuous import discount_values
