@@ -46,6 +46,7 @@ struct PolicyArgs {
   float* mb_obs; float* mb_dones; float* mb_mu; float* mb_val; float* act; float* act_env; float* neglogp; float* sigma;
   // training forward (mode 2): what the backward pass needs -- the fp16 input of the first Linear and every ELU output, row-major
   _Float16* x0_out; _Float16* act_out[PF_MAXL];
+  int packed;  // weights are fragment-major copies (see gemm_col_block_packed): w[L] and w_mu (= the packed [mu; value] block)
 };
 
 // rows [0, nrow) x columns [0, cols) of an LDS activation tile -> global (row-major, `cols` halfs per row, cols even): half2 per
@@ -120,8 +121,37 @@ __device__ __forceinline__ void gemm_col_block(const _Float16 (*src)[LD], const 
   }
 }
 
+// The same product on FRAGMENT-MAJOR weights: block nb / k-step ks of a Linear (out, in) is one 1 KB chunk in which lane l = 32 h + r
+// holds W[32 nb + r][16 ks + 8 h + 0..7] (zero beyond out / in), i.e. exactly its B fragment -- one fully coalesced 16-byte load per lane.
+// Read from the row-major matrix the same fragment touches 64 different cache lines per wave instruction (a row per lane), eight waves
+// thrash the 16 KB L1 and every prefetch group costs ~2 k cycles of L2 round trips: the packed copy (kept current by one scatter of the
+// flat fp16 working copy per optimiser step) is what makes the weight stream cheap.
+template <int LD>
+__device__ __forceinline__ void gemm_col_block_packed(const _Float16 (*src)[LD], const _Float16* wblk, int ksteps, int r, int h, f32x16& acc0, f32x16& acc1) {
+  const _Float16* p = wblk + (h * 32 + r) * 8;
+  int ks = 0;
+  auto group = [&](auto G) {
+    constexpr int g = decltype(G)::value;
+    half8 bf[g];
+#pragma unroll
+    for (int u = 0; u < g; ++u) bf[u] = *reinterpret_cast<const half8*>(p + (size_t)(ks + u) * 512);
+#pragma unroll
+    for (int u = 0; u < g; ++u) {
+      const int k0 = (ks + u) * 16 + 8 * h;
+      const half8 a0 = *reinterpret_cast<const half8*>(&src[r][k0]);
+      const half8 a1 = *reinterpret_cast<const half8*>(&src[32 + r][k0]);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, bf[u], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, bf[u], acc1, 0, 0, 0);
+    }
+    ks += g;
+  };
+  while (ks + 12 <= ksteps) group(std::integral_constant<int, 12>{});
+  while (ks + 4 <= ksteps) group(std::integral_constant<int, 4>{});
+  while (ks + 1 <= ksteps) group(std::integral_constant<int, 1>{});
+}
+
 // dst[:, 0:Npad] = act(src[:, 0:K] W^T + b) for the 64 rows of the workgroup; this wave takes column blocks wave, wave + PF_WAVES, ...
-template <bool ELU, int LDS, int LDD>
+template <bool ELU, bool PK, int LDS, int LDD>
 __device__ __forceinline__ void layer(const _Float16 (*src)[LDS], _Float16 (*dst)[LDD], const _Float16* W, const _Float16* B, int in, int out, int wave,
                                       int lane) {
   const int r = lane & 31, h = lane >> 5;
@@ -132,7 +162,8 @@ __device__ __forceinline__ void layer(const _Float16 (*src)[LDS], _Float16 (*dst
     f32x16 acc0, acc1;
 #pragma unroll
     for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
-    gemm_col_block(src, wrow, n < out, in, r, h, acc0, acc1);
+    if constexpr (PK) { const int ksteps = (in + 15) >> 4; gemm_col_block_packed(src, W + (size_t)nb * ksteps * 512, ksteps, r, h, acc0, acc1); }
+    else gemm_col_block(src, wrow, n < out, in, r, h, acc0, acc1);
     const float bias = (B && n < out) ? (float)B[n] : 0.f;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
@@ -149,7 +180,7 @@ __device__ __forceinline__ void layer(const _Float16 (*src)[LDS], _Float16 (*dst
 
 // the two heads on the last hidden activations `src`: one column block (num_actions + 1 <= 32 columns), wave 0; results as fp32 of the
 // fp16 outputs, to global memory or (rollout mode) into `tile`, the free activation tile viewed as 33-float rows
-template <bool ROLL, int LD>
+template <bool ROLL, bool PK, int LD>
 __device__ __forceinline__ void heads(const PolicyArgs& a, const _Float16 (*src)[LD], int in, float* tile, int64_t row0, int nrow, int lane) {
   const int r = lane & 31, h = lane >> 5, A = a.num_actions;
   const _Float16* wrow = r < A ? a.w_mu + (size_t)r * in : a.w_val;
@@ -157,7 +188,8 @@ __device__ __forceinline__ void heads(const PolicyArgs& a, const _Float16 (*src)
   f32x16 acc0, acc1;
 #pragma unroll
   for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
-  gemm_col_block(src, wrow, live, in, r, h, acc0, acc1);
+  if constexpr (PK) gemm_col_block_packed(src, a.w_mu, (in + 15) >> 4, r, h, acc0, acc1);
+  else gemm_col_block(src, wrow, live, in, r, h, acc0, acc1);
   const float bias = r < A ? (float)a.b_mu[r] : (r == A ? (float)a.b_val[0] : 0.f);
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
@@ -176,7 +208,7 @@ __device__ __forceinline__ void heads(const PolicyArgs& a, const _Float16 (*src)
 // (halfs) of the two LDS activation tiles -- tile 0 holds the staged input and the outputs of layers 1, 3, 5, tile 1 those of layers
 // 0, 2, 4.  (424, 424) fits every supported width; (216, 424) is 80 KB, so that two workgroups share a CU (training forward of
 // 54-400-200-100: 512 workgroups, each one's MFMAs cover the other's weight-fetch latency).
-template <int MODE, int LD0, int LD1>
+template <int MODE, int LD0, int LD1, bool PK>
 __global__ __launch_bounds__(PF_WAVES * 64) void policy_forward_kernel(PolicyArgs a) {
   constexpr bool ROLL = MODE == 1, TRAIN = MODE == 2;
   __shared__ __attribute__((aligned(16))) _Float16 t0[PF_ROWS][LD0];
@@ -203,13 +235,13 @@ __global__ __launch_bounds__(PF_WAVES * 64) void policy_forward_kernel(PolicyArg
   if (TRAIN) store_tile(t0, a.x0_out, row0, nrow, a.d_in, tid);
   int in = a.d_in;
   for (int L = 0; L < a.nhid; L += 2) {
-    layer<true>(t0, t1, a.w[L], a.b[L], in, a.width[L], wave, lane);
+    layer<true, PK>(t0, t1, a.w[L], a.b[L], in, a.width[L], wave, lane);
     // the next layer reads K padded to 16: columns width..pad16(width) were written as elu(0 + 0) = 0 by the padded column block
     __syncthreads();
     in = a.width[L];
     if (TRAIN) store_tile(t1, a.act_out[L], row0, nrow, in, tid);  // (the stores drain behind the next layer's MFMAs)
     if (L + 1 < a.nhid) {
-      layer<true>(t1, t0, a.w[L + 1], a.b[L + 1], in, a.width[L + 1], wave, lane);
+      layer<true, PK>(t1, t0, a.w[L + 1], a.b[L + 1], in, a.width[L + 1], wave, lane);
       __syncthreads();
       in = a.width[L + 1];
       if (TRAIN) store_tile(t0, a.act_out[L + 1], row0, nrow, in, tid);
@@ -218,8 +250,8 @@ __global__ __launch_bounds__(PF_WAVES * 64) void policy_forward_kernel(PolicyArg
   const bool in_t1 = (a.nhid & 1) != 0;  // where the last hidden activations are; the other tile is free
   float* tile = in_t1 ? reinterpret_cast<float*>(&t0[0][0]) : reinterpret_cast<float*>(&t1[0][0]);
   if (wave == 0) {
-    if (in_t1) heads<ROLL>(a, t1, in, tile, row0, nrow, lane);
-    else heads<ROLL>(a, t0, in, tile, row0, nrow, lane);
+    if (in_t1) heads<ROLL, PK>(a, t1, in, tile, row0, nrow, lane);
+    else heads<ROLL, PK>(a, t0, in, tile, row0, nrow, lane);
   }
   if (ROLL) {
     // sampling, neglogp, clamp, rollout-buffer rows: one thread per (env, action), the per-env sum through the same LDS tile
@@ -264,12 +296,13 @@ struct BackwardArgs {
   _Float16* gz[PF_MAXL];
   _Float16* gmu16; _Float16* gv16;
   float* bgrad[PF_MAXL]; float* bmu_grad; float* bv_grad;
+  int packed;  // wt[L] / wht are fragment-major (packed as Linear(out = width[L-1], in = width[L]) and Linear(out = width[last], in = 32))
   float* partial; int ptotal; int poff[PF_MAXL];  // per-workgroup column sums of gz (ceil(n / 64), ptotal = sum of the widths), layer L at poff[L]
 };
 
 // one layer of the chain: gz = g * elu'(y) in place in tile A (and out to HBM), its per-workgroup column sums, then d/d h_{L-1} = gz W_L
 // into tile B.  The reduction scratch lives in tile B, which is free until the GEMM writes it.
-template <int LA, int LB>
+template <bool PK, int LA, int LB>
 __device__ __forceinline__ void backward_stage(const BackwardArgs& a, _Float16 (*A)[LA], _Float16 (*B)[LB], int L, int64_t row0, int nrow, int tid,
                                                int wave, int lane) {
   constexpr int NT = PF_WAVES * 64;
@@ -320,14 +353,14 @@ __device__ __forceinline__ void backward_stage(const BackwardArgs& a, _Float16 (
   }
   if (L > 0) {
     __syncthreads();  // the scratch has been read: tile B may be overwritten
-    layer<false>(A, B, a.wt[L], nullptr, W, a.width[L - 1], wave, lane);  // d/d h_{L-1} = gz W_L
+    layer<false, PK>(A, B, a.wt[L], nullptr, W, a.width[L - 1], wave, lane);  // d/d h_{L-1} = gz W_L
     __syncthreads();
   }
 }
 
 // LD0 / LD1: row strides of the two LDS tiles.  Tile 0 holds the (64, 32) head-gradient tile and d/d h_L for L = nhid-2, nhid-4, ...;
 // tile 1 holds d/d h_L for L = nhid-1, nhid-3, ...  (216, 424) = 80 KB: two workgroups per CU for 54-400-200-100.
-template <int LD0, int LD1>
+template <int LD0, int LD1, bool PK>
 __global__ __launch_bounds__(PF_WAVES * 64, 4) void policy_backward_kernel(BackwardArgs a) {  // 4 waves per SIMD = two workgroups per CU: <= 128 VGPRs
   __shared__ __attribute__((aligned(16))) _Float16 t0[PF_ROWS][LD0];
   __shared__ __attribute__((aligned(16))) _Float16 t1[PF_ROWS][LD1];
@@ -362,12 +395,12 @@ __global__ __launch_bounds__(PF_WAVES * 64, 4) void policy_backward_kernel(Backw
     }
     __syncthreads();
   }
-  layer<false>(t0, t1, a.wht, nullptr, 32, a.width[a.nhid - 1], wave, lane);  // d/d h_last = [gmu | gval] [Wmu; Wv]
+  layer<false, PK>(t0, t1, a.wht, nullptr, 32, a.width[a.nhid - 1], wave, lane);  // d/d h_last = [gmu | gval] [Wmu; Wv]
   __syncthreads();
   bool in1 = true;
   for (int L = a.nhid - 1; L >= 0; --L) {
-    if (in1) backward_stage(a, t1, t0, L, row0, nrow, tid, wave, lane);
-    else backward_stage(a, t0, t1, L, row0, nrow, tid, wave, lane);
+    if (in1) backward_stage<PK>(a, t1, t0, L, row0, nrow, tid, wave, lane);
+    else backward_stage<PK>(a, t0, t1, L, row0, nrow, tid, wave, lane);
     in1 = !in1;
   }
 }
@@ -393,6 +426,13 @@ __global__ __launch_bounds__(1024) void policy_bias_reduce_kernel(BackwardArgs a
     while (L + 1 < a.nhid && c >= a.poff[L + 1]) ++L;
     a.bgrad[L][c - a.poff[L]] += t;
   }
+}
+
+// two destinations per source element (forward and backward copies of the same weight): dst[map_a[i]] = dst[map_b[i]] = src[i]
+__global__ void scatter2_f16_kernel(const _Float16* __restrict__ src, const int32_t* __restrict__ ma, const int32_t* __restrict__ mb, int64_t n,
+                                    _Float16* __restrict__ dst) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) { const _Float16 v = src[i]; const int32_t a = ma[i], b = mb[i]; if (a >= 0) dst[a] = v; if (b >= 0) dst[b] = v; }
 }
 
 // dst[map[i]] = src[i] for the entries with map[i] >= 0: refreshes the transposed weight copies from the flat fp16 working copy
@@ -422,18 +462,20 @@ static int fill_args(PolicyArgs& a, const float* obs_dev, int64_t n, int32_t num
   a.mb_obs = a.mb_dones = a.mb_mu = a.mb_val = a.act = a.act_env = a.neglogp = a.sigma = nullptr;
   a.x0_out = nullptr;
   for (int i = 0; i < PF_MAXL; ++i) a.act_out[i] = nullptr;
+  a.packed = 0;
   return 0;
 }
 
 extern "C" int bez_ppo_policy_forward(const float* obs_dev, int64_t n, int32_t num_obs, const double* obs_mean_dev, const double* obs_var_dev, float obs_eps,
                                       int32_t num_hidden, const void* const* hidden_w_f16_dev, const void* const* hidden_b_f16_dev, const int32_t* hidden_width,
                                       const void* mu_w_f16_dev, const void* mu_b_f16_dev, int32_t num_actions, const void* value_w_f16_dev,
-                                      const void* value_b_f16_dev, float* mu_dev, float* value_dev, void* stream) {
+                                      const void* value_b_f16_dev, float* mu_dev, float* value_dev, int32_t weights_packed, void* stream) {
   PolicyArgs a;
   if (!mu_dev || !value_dev || fill_args(a, obs_dev, n, num_obs, obs_mean_dev, obs_var_dev, obs_eps, num_hidden, hidden_w_f16_dev, hidden_b_f16_dev, hidden_width,
                                          mu_w_f16_dev, mu_b_f16_dev, num_actions, value_w_f16_dev, value_b_f16_dev)) return -1;
-  a.mu = mu_dev; a.value = value_dev;
-  hipLaunchKernelGGL((policy_forward_kernel<0, PF_LD, PF_LD>), dim3((unsigned)((n + PF_ROWS - 1) / PF_ROWS)), dim3(PF_WAVES * 64), 0, (hipStream_t)stream, a);
+  a.mu = mu_dev; a.value = value_dev; a.packed = weights_packed;
+  if (weights_packed) hipLaunchKernelGGL((policy_forward_kernel<0, PF_LD, PF_LD, true>), dim3((unsigned)((n + PF_ROWS - 1) / PF_ROWS)), dim3(PF_WAVES * 64), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL((policy_forward_kernel<0, PF_LD, PF_LD, false>), dim3((unsigned)((n + PF_ROWS - 1) / PF_ROWS)), dim3(PF_WAVES * 64), 0, (hipStream_t)stream, a);
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
@@ -443,7 +485,7 @@ extern "C" int bez_ppo_policy_rollout_step(const float* obs_dev, int64_t n, int3
                                            const void* value_w_f16_dev, const void* value_b_f16_dev, const float* logstd_dev, const float* noise_dev,
                                            const float* dones_dev, const double* value_mean_dev, const double* value_var_dev, float value_eps, float* mb_obs_dev,
                                            float* mb_dones_dev, float* mb_mu_dev, float* mb_val_dev, float* actions_dev, float* env_actions_dev,
-                                           float* neglogp_dev, float* sigma_dev, void* stream) {
+                                           float* neglogp_dev, float* sigma_dev, int32_t weights_packed, void* stream) {
   PolicyArgs a;
   if (!logstd_dev || !noise_dev || !dones_dev || !mb_obs_dev || !mb_dones_dev || !mb_mu_dev || !mb_val_dev || !actions_dev || !env_actions_dev || !neglogp_dev ||
       !sigma_dev || (value_mean_dev && !value_var_dev) ||
@@ -451,8 +493,9 @@ extern "C" int bez_ppo_policy_rollout_step(const float* obs_dev, int64_t n, int3
                 mu_b_f16_dev, num_actions, value_w_f16_dev, value_b_f16_dev)) return -1;
   a.logstd = logstd_dev; a.noise = noise_dev; a.dones = dones_dev; a.vmean = value_mean_dev; a.vvar = value_var_dev; a.veps = value_eps;
   a.mb_obs = mb_obs_dev; a.mb_dones = mb_dones_dev; a.mb_mu = mb_mu_dev; a.mb_val = mb_val_dev; a.act = actions_dev; a.act_env = env_actions_dev;
-  a.neglogp = neglogp_dev; a.sigma = sigma_dev;
-  hipLaunchKernelGGL((policy_forward_kernel<1, PF_LD, PF_LD>), dim3((unsigned)((n + PF_ROWS - 1) / PF_ROWS)), dim3(PF_WAVES * 64), 0, (hipStream_t)stream, a);
+  a.neglogp = neglogp_dev; a.sigma = sigma_dev; a.packed = weights_packed;
+  if (weights_packed) hipLaunchKernelGGL((policy_forward_kernel<1, PF_LD, PF_LD, true>), dim3((unsigned)((n + PF_ROWS - 1) / PF_ROWS)), dim3(PF_WAVES * 64), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL((policy_forward_kernel<1, PF_LD, PF_LD, false>), dim3((unsigned)((n + PF_ROWS - 1) / PF_ROWS)), dim3(PF_WAVES * 64), 0, (hipStream_t)stream, a);
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
@@ -460,7 +503,7 @@ extern "C" int bez_ppo_policy_forward_train(const float* obs_dev, int64_t n, int
                                             int32_t num_hidden, const void* const* hidden_w_f16_dev, const void* const* hidden_b_f16_dev,
                                             const int32_t* hidden_width, const void* mu_w_f16_dev, const void* mu_b_f16_dev, int32_t num_actions,
                                             const void* value_w_f16_dev, const void* value_b_f16_dev, void* x0_f16_dev, void* const* act_f16_dev,
-                                            float* mu_dev, float* value_dev, void* stream) {
+                                            float* mu_dev, float* value_dev, int32_t weights_packed, void* stream) {
   PolicyArgs a;
   if (!mu_dev || !value_dev || !x0_f16_dev || !act_f16_dev || (num_obs & 1) ||
       fill_args(a, obs_dev, n, num_obs, obs_mean_dev, obs_var_dev, obs_eps, num_hidden, hidden_w_f16_dev, hidden_b_f16_dev, hidden_width, mu_w_f16_dev,
@@ -469,21 +512,24 @@ extern "C" int bez_ppo_policy_forward_train(const float* obs_dev, int64_t n, int
     if (!act_f16_dev[i] || (hidden_width[i] & 1)) return -1;  // half2 stores: even widths
     a.act_out[i] = (_Float16*)act_f16_dev[i];
   }
-  a.x0_out = (_Float16*)x0_f16_dev; a.mu = mu_dev; a.value = value_dev;
+  a.x0_out = (_Float16*)x0_f16_dev; a.mu = mu_dev; a.value = value_dev; a.packed = weights_packed;
   // tile 0 holds the input and the outputs of the odd layers, tile 1 those of the even layers: with strides (216, 424) the tiles are
   // 80 KB and two workgroups share a CU
   int w0 = num_obs, w1 = 0;
   for (int i = 0; i < num_hidden; ++i) { int& w = (i & 1) ? w0 : w1; if (hidden_width[i] > w) w = hidden_width[i]; }
   const dim3 grid((unsigned)((n + PF_ROWS - 1) / PF_ROWS)), block(PF_WAVES * 64);
-  if (((w0 + 15) & ~15) + 8 <= 216) hipLaunchKernelGGL((policy_forward_kernel<2, 216, PF_LD>), grid, block, 0, (hipStream_t)stream, a);
-  else hipLaunchKernelGGL((policy_forward_kernel<2, PF_LD, PF_LD>), grid, block, 0, (hipStream_t)stream, a);
+  const bool narrow = ((w0 + 15) & ~15) + 8 <= 216;
+  if (narrow && weights_packed) hipLaunchKernelGGL((policy_forward_kernel<2, 216, PF_LD, true>), grid, block, 0, (hipStream_t)stream, a);
+  else if (narrow) hipLaunchKernelGGL((policy_forward_kernel<2, 216, PF_LD, false>), grid, block, 0, (hipStream_t)stream, a);
+  else if (weights_packed) hipLaunchKernelGGL((policy_forward_kernel<2, PF_LD, PF_LD, true>), grid, block, 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL((policy_forward_kernel<2, PF_LD, PF_LD, false>), grid, block, 0, (hipStream_t)stream, a);
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
 extern "C" int bez_ppo_policy_backward(const float* grad_mu_dev, const float* grad_value_dev, int64_t n, int32_t num_hidden, const int32_t* hidden_width,
                                        int32_t num_actions, const void* const* act_f16_dev, const void* const* wt_f16_dev, const void* heads_t_f16_dev,
                                        void* const* gz_f16_dev, void* grad_mu_f16_dev, void* grad_value_f16_dev, float* const* bias_grad_dev,
-                                       float* mu_bias_grad_dev, float* value_bias_grad_dev, float* partial_dev, void* stream) {
+                                       float* mu_bias_grad_dev, float* value_bias_grad_dev, float* partial_dev, int32_t weights_packed, void* stream) {
   if (!partial_dev) return -1;
   if (!grad_mu_dev || !grad_value_dev || n <= 0 || num_hidden <= 0 || num_hidden > PF_MAXL || !hidden_width || num_actions <= 0 || num_actions > 31 ||
       !act_f16_dev || !wt_f16_dev || !heads_t_f16_dev || !gz_f16_dev || !grad_mu_f16_dev || !grad_value_f16_dev || !bias_grad_dev || !mu_bias_grad_dev ||
@@ -500,15 +546,25 @@ extern "C" int bez_ppo_policy_backward(const float* grad_mu_dev, const float* gr
   }
   a.wht = (const _Float16*)heads_t_f16_dev; a.gmu16 = (_Float16*)grad_mu_f16_dev; a.gv16 = (_Float16*)grad_value_f16_dev;
   a.bmu_grad = mu_bias_grad_dev; a.bv_grad = value_bias_grad_dev;
-  a.partial = partial_dev; a.ptotal = 0;
+  a.partial = partial_dev; a.ptotal = 0; a.packed = weights_packed;
   for (int i = 0; i < PF_MAXL; ++i) a.poff[i] = 0;
   for (int i = 0; i < num_hidden; ++i) { a.poff[i] = a.ptotal; a.ptotal += hidden_width[i]; }
   const unsigned nwg = (unsigned)((n + PF_ROWS - 1) / PF_ROWS);
   int w0 = 32, w1 = 0;  // widest tenant of each tile (see policy_backward_kernel)
   for (int i = 0; i < num_hidden; ++i) { int& w = ((num_hidden - 1 - i) & 1) ? w0 : w1; if (hidden_width[i] > w) w = hidden_width[i]; }
-  if (((w0 + 15) & ~15) + 8 <= 216) hipLaunchKernelGGL((policy_backward_kernel<216, PF_LD>), dim3(nwg), dim3(PF_WAVES * 64), 0, (hipStream_t)stream, a);
-  else hipLaunchKernelGGL((policy_backward_kernel<PF_LD, PF_LD>), dim3(nwg), dim3(PF_WAVES * 64), 0, (hipStream_t)stream, a);
+  const bool narrow = ((w0 + 15) & ~15) + 8 <= 216;
+  if (narrow && weights_packed) hipLaunchKernelGGL((policy_backward_kernel<216, PF_LD, true>), dim3(nwg), dim3(PF_WAVES * 64), 0, (hipStream_t)stream, a);
+  else if (narrow) hipLaunchKernelGGL((policy_backward_kernel<216, PF_LD, false>), dim3(nwg), dim3(PF_WAVES * 64), 0, (hipStream_t)stream, a);
+  else if (weights_packed) hipLaunchKernelGGL((policy_backward_kernel<PF_LD, PF_LD, true>), dim3(nwg), dim3(PF_WAVES * 64), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL((policy_backward_kernel<PF_LD, PF_LD, false>), dim3(nwg), dim3(PF_WAVES * 64), 0, (hipStream_t)stream, a);
   hipLaunchKernelGGL(policy_bias_reduce_kernel, dim3((unsigned)((a.ptotal + 63) / 64)), dim3(1024), 0, (hipStream_t)stream, a, (int)nwg);
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+extern "C" int bez_ppo_scatter2_f16(const void* src_f16_dev, const int32_t* map_a_dev, const int32_t* map_b_dev, int64_t n, void* dst_f16_dev, void* stream) {
+  if (!src_f16_dev || !map_a_dev || !map_b_dev || !dst_f16_dev || n <= 0) return -1;
+  hipLaunchKernelGGL(scatter2_f16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const _Float16*)src_f16_dev, map_a_dev, map_b_dev, n,
+                     (_Float16*)dst_f16_dev);
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 

@@ -360,6 +360,7 @@ class A2CAgent:
         self._fused_opt = False
         self._policy_fwd = None
         self._policy_bwd = None
+        self._packed = None
         self.fused = bool(on_gpu and c.get("fused_ops", True))
         if self.fused:
             from . import fused as F
@@ -382,12 +383,14 @@ class A2CAgent:
                 nh = len(net._lin) - 2
                 wb = [(net._p16[2 * i], net._p16[2 * i + 1]) for i in range(nh + 2)]
                 if all(w.shape[0] <= 416 for w, _ in wb[:nh]) and obs_dim <= 416 and act_dim <= 31 and nh <= 6:
-                    self._policy_fwd = F.PolicyForward(wb[:nh], wb[nh], wb[nh + 1], self.running_mean_std if self.normalize_input else None)
-                    # ... and the input-gradient chain of the minibatch backward pass as one kernel on transposed fp16 copies
+                    # fragment-major copies of the weights (coalesced MFMA operand loads), refreshed by one scatter of the fp16 working copy
                     hflat = getattr(self, "_hflat", None)
+                    layout = None if hflat is None else [((w.data_ptr() - hflat.data_ptr()) // 2, w.shape[0], w.shape[1]) for w, _ in wb]
+                    self._packed = F.PackedWeights(hflat, layout, act_dim) if (hflat is not None and c.get("packed_weights", True)) else None
+                    self._policy_fwd = F.PolicyForward(wb[:nh], wb[nh], wb[nh + 1], self.running_mean_std if self.normalize_input else None, self._packed)
+                    # ... and the input-gradient chain of the minibatch backward pass as one kernel on transposed copies
                     if (hflat is not None and c.get("fused_policy_backward", True) and all(32 <= w.shape[0] <= 416 and w.shape[0] % 2 == 0 for w, _ in wb[:nh])):
-                        layout = [((w.data_ptr() - hflat.data_ptr()) // 2, w.shape[0], w.shape[1]) for w, _ in wb]
-                        self._policy_bwd = F.PolicyBackward(hflat, layout, act_dim)
+                        self._policy_bwd = F.PolicyBackward(hflat, layout, act_dim, self._packed)
         if world > 1 and not self.fused:
             self.use_graphs = False  # the plain torch path has collectives in the middle of autograd-heavy code: eager only
         self._seg = None  # segmented graphs of the data-parallel update
@@ -457,6 +460,8 @@ class A2CAgent:
             net.refresh_half()
         cur = self.obs  # step 0 reads the agent's copy; later steps read the env's own observation buffer (no per-step copy)
         vrms = self.value_mean_std if self.normalize_value else None
+        if self._packed is not None:
+            self._packed.refresh()  # the last optimiser step changed the weights
         fx["noise"].normal_()  # the whole horizon's action noise in one launch
         for n in range(self.horizon):
             if self._policy_fwd is not None:
@@ -683,6 +688,8 @@ class A2CAgent:
             # forward of the whole MLP as one MFMA kernel that keeps the ELU outputs (csrc/bez_policy.hip, mode 2); the backward pass
             # below is the chain autograd would run through _HalfLinearEluFn / _HalfLinearFn, called directly
             tf = self._train_bufs(obs.shape[0])
+            if self._packed is not None:
+                self._packed.refresh()  # forward and backward copies of this step's weights, one launch
             self._policy_fwd.train_forward(obs, tf["x0"], tf["act"], tf["mu"], tf["v"])
             mu32, v32 = tf["mu"], tf["v"]
         else:
@@ -744,7 +751,8 @@ class A2CAgent:
         if self._policy_bwd is not None:
             # the whole input-gradient chain (head casts + bias sums, per layer ELU derivative + bias sum + dgrad GEMM) in one launch on
             # the transposed weight copies (refreshed by one scatter of the fp16 working copy); the weight gradients follow as GEMMs
-            self._policy_bwd.refresh()
+            if self._packed is None:
+                self._policy_bwd.refresh()
             self._policy_bwd(gmu, gval, tf["act"], tf["gz"], tf["gmu16"], tf["gv16"], [lin[L].bias.grad for L in range(nh)],
                              lin[nh].bias.grad, lin[nh + 1].bias.grad)
             wgrad(tf["gmu16"], h_last, lin[nh])

@@ -18,11 +18,12 @@ _SIGS = {
     "bez_ppo_rollout_post": [_vp, _vp, _vp, _vp, _i64, _f, _f, _i32, _vp, _vp, _vp, _vp, _vp, _vp],
     "bez_ppo_loss": [_vp] * 10 + [_i64, _i32, _f, _f, _f, _f, _i32] + [_vp] * 6,
     "bez_ppo_rollout_pre": [_vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _f, _i64, _i32, _i32] + [_vp] * 9,
-    "bez_ppo_policy_forward": [_vp, _i64, _i32, _vp, _vp, _f, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp],
-    "bez_ppo_policy_rollout_step": [_vp, _i64, _i32, _vp, _vp, _f, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f] + [_vp] * 9,
-    "bez_ppo_policy_forward_train": [_vp, _i64, _i32, _vp, _vp, _f, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
-    "bez_ppo_policy_backward": [_vp, _vp, _i64, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "bez_ppo_policy_forward": [_vp, _i64, _i32, _vp, _vp, _f, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _vp],
+    "bez_ppo_policy_rollout_step": [_vp, _i64, _i32, _vp, _vp, _f, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f] + [_vp] * 8 + [_i32, _vp],
+    "bez_ppo_policy_forward_train": [_vp, _i64, _i32, _vp, _vp, _f, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp],
+    "bez_ppo_policy_backward": [_vp, _vp, _i64, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp],
     "bez_ppo_scatter_f16": [_vp, _vp, _i64, _vp, _vp],
+    "bez_ppo_scatter2_f16": [_vp, _vp, _vp, _i64, _vp, _vp],
     "bez_ppo_adaptive_lr": [_vp, _vp, _f, _f, _f, _vp],
     "bez_ppo_gae": [_vp, _vp, _vp, _vp, _vp, _i32, _i64, _f, _f, _vp, _vp, _vp],
     "bez_ppo_head_grads_f16": [_vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp],
@@ -158,12 +159,19 @@ class PolicyBackward:
     weight copies it reads, refreshed from the flat fp16 working copy `hflat` by one scatter launch.  `layout` = [(offset in hflat,
     out, in)] of the weight of every Linear in network order (hidden layers, mu head, value head)."""
 
-    def __init__(self, hflat, layout, num_actions):
+    def __init__(self, hflat, layout, num_actions, packed=None):
         dev = hflat.device
         nh = len(layout) - 2
         self.nh, self.A, self.hflat = nh, num_actions, hflat
         self.widths = [o for _, o, _ in layout[:nh]]
         assert all(32 <= w <= 416 and w % 2 == 0 for w in self.widths) and num_actions <= 31
+        self.c_widths = (C.c_int32 * nh)(*self.widths)
+        self.packed = packed
+        if packed is not None:  # fragment-major transposed copies owned (and refreshed) by the shared PackedWeights
+            self.flag, self.wht = 1, packed.bwd_heads
+            self.c_wt = (C.c_void_p * nh)(*[None if w is None else w.data_ptr() for w in packed.bwd])
+            return
+        self.flag = 0
         last = self.widths[-1]
         sizes = [0] + [layout[i][1] * layout[i][2] for i in range(1, nh)]
         offs = np.cumsum([0] + sizes).tolist()           # wt[i] at offs[i] (i >= 1), the heads matrix behind them
@@ -185,6 +193,8 @@ class PolicyBackward:
         self.c_wt = (C.c_void_p * nh)(*[None if w is None else w.data_ptr() for w in self.wt])
 
     def refresh(self):
+        if self.packed is not None:
+            return self.packed.refresh()
         _chk(lib().bez_ppo_scatter_f16(_p(self.hflat, torch.float16), C.c_void_p(self.map.data_ptr()), self.hflat.numel(), _p(self.flat_t, torch.float16),
                                        _stream(self.hflat)), "bez_ppo_scatter_f16")
 
@@ -201,8 +211,9 @@ class PolicyBackward:
         if getattr(self, "_partial", None) is None or self._partial.numel() < need:
             self._partial = torch.empty(need, device=gmu.device, dtype=torch.float32)
         _chk(lib().bez_ppo_policy_backward(_p(gmu), _p(gval), n, self.nh, C.cast(self.c_widths, C.c_void_p), self.A, C.cast(t_act, C.c_void_p),
-                                           C.cast(self.c_wt, C.c_void_p), _p(self.wht, torch.float16), C.cast(t_gz, C.c_void_p), _p(gmu16, torch.float16),
-                                           _p(gv16, torch.float16), C.cast(t_b, C.c_void_p), _p(mu_bias_grad), _p(value_bias_grad), _p(self._partial), _stream(gmu)),
+                                           C.cast(self.c_wt, C.c_void_p), C.c_void_p(self.wht.data_ptr()), C.cast(t_gz, C.c_void_p), _p(gmu16, torch.float16),
+                                           _p(gv16, torch.float16), C.cast(t_b, C.c_void_p), _p(mu_bias_grad), _p(value_bias_grad), _p(self._partial), self.flag,
+                                           _stream(gmu)),
              "bez_ppo_policy_backward")
 
 
@@ -237,16 +248,71 @@ def elu_bwd_colsum_f16(gy, y, gz, bias_grad, accumulate=False):
                                           _stream(y)), "bez_ppo_elu_bwd_colsum_f16")
 
 
+def _pack_index(out, k):
+    """position of element (n, c) of a Linear (out, k) in its fragment-major copy (include/bez_sim.h, weights_packed) and the copy's size"""
+    ks = (k + 15) // 16
+    n, c = np.arange(out)[:, None], np.arange(k)[None, :]
+    idx = (((n // 32) * ks + c // 16) * 64 + ((c // 8) % 2) * 32 + n % 32) * 8 + c % 8
+    return idx.astype(np.int64), ((out + 31) // 32) * ks * 512
+
+
+class PackedWeights:
+    """Fragment-major fp16 copies of every weight the MFMA policy kernels read, kept current from the flat fp16 working copy `hflat` by
+    ONE scatter launch (bez_ppo_scatter2_f16: each source element has a destination in the forward set and one in the backward set).
+    `layout` = [(offset in hflat, out, in)] of the Linears in network order: hidden layers, mu head, value head."""
+
+    def __init__(self, hflat, layout, num_actions):
+        nh, a = len(layout) - 2, num_actions
+        self.hflat, self.nh, self.A = hflat, nh, a
+        last = layout[nh - 1][1]
+        assert layout[nh][1] == a and layout[nh][2] == last and layout[nh + 1][1] == 1 and layout[nh + 1][2] == last and a <= 31
+        ma = np.full(hflat.numel(), -1, dtype=np.int64)   # forward copies
+        mb = np.full(hflat.numel(), -1, dtype=np.int64)   # backward (transposed) copies
+        pos, fwd_off, bwd_off = 0, [], [None]
+        for off, o, k in layout[:nh]:                    # forward: W_i as it is
+            idx, size = _pack_index(o, k)
+            ma[off + np.arange(o * k).reshape(o, k)] = pos + idx
+            fwd_off.append(pos); pos += size
+        idx, size = _pack_index(a + 1, last)             # forward heads: [W_mu; W_value]
+        ma[layout[nh][0] + np.arange(a * last).reshape(a, last)] = pos + idx[:a]
+        ma[layout[nh + 1][0] + np.arange(last)] = pos + idx[a]
+        fwd_heads = pos; pos += size
+        for off, o, k in layout[1:nh]:                   # backward: W_i^T = Linear (out' = in, in' = out)
+            idx, size = _pack_index(k, o)                # idx[c, n] = position of element (c, n) of W^T, i.e. of W[n, c]
+            mb[off + np.arange(o * k).reshape(o, k)] = pos + idx.T
+            bwd_off.append(pos); pos += size
+        idx, size = _pack_index(last, 32)                # backward heads: (out' = last, in' = 32) = [W_mu; W_value]^T
+        mb[layout[nh][0] + np.arange(a * last).reshape(a, last)] = pos + idx[:, :a].T
+        mb[layout[nh + 1][0] + np.arange(last)] = pos + idx[:, a]
+        bwd_heads = pos; pos += size
+        dev = hflat.device
+        self.flat = torch.zeros(pos, device=dev, dtype=torch.float16)   # (padding stays zero)
+        self.map_a = torch.from_numpy(ma.astype(np.int32)).to(dev)
+        self.map_b = torch.from_numpy(mb.astype(np.int32)).to(dev)
+        self.fwd = [self.flat[o:] for o in fwd_off]
+        self.fwd_heads = self.flat[fwd_heads:]
+        self.bwd = [None] + [self.flat[o:] for o in bwd_off[1:]]
+        self.bwd_heads = self.flat[bwd_heads:]
+        self.refresh()
+
+    def refresh(self):
+        _chk(lib().bez_ppo_scatter2_f16(_p(self.hflat, torch.float16), C.c_void_p(self.map_a.data_ptr()), C.c_void_p(self.map_b.data_ptr()),
+                                        self.hflat.numel(), _p(self.flat, torch.float16), _stream(self.hflat)), "bez_ppo_scatter2_f16")
+
+
 class PolicyForward:
     """One-launch rollout forward of the actor-critic MLP on its fp16 working weights (csrc/bez_policy.hip).  `hidden` = list of
     (w16, b16) of the ELU layers, then the mu and value heads; the pointer tables are built once (the tensors are static views)."""
 
-    def __init__(self, hidden, mu_wb, value_wb, obs_rms):
+    def __init__(self, hidden, mu_wb, value_wb, obs_rms, packed=None):
         self.keep = (hidden, mu_wb, value_wb, obs_rms)
+        self.packed = packed  # PackedWeights: the kernels read the fragment-major copies (the caller keeps them refreshed)
         k = len(hidden)
         for w, b in list(hidden) + [mu_wb, value_wb]:
             assert w.dtype == torch.float16 and b.dtype == torch.float16 and w.is_contiguous() and b.is_contiguous() and w.is_cuda
-        self.hw = (C.c_void_p * k)(*[w.data_ptr() for w, _ in hidden])
+        self.hw = (C.c_void_p * k)(*([w.data_ptr() for w, _ in hidden] if packed is None else [w.data_ptr() for w in packed.fwd]))
+        self.flag = 0 if packed is None else 1
+        self.mu_w = mu_wb[0] if packed is None else packed.fwd_heads
         self.hb = (C.c_void_p * k)(*[b.data_ptr() for _, b in hidden])
         self.widths = (C.c_int32 * k)(*[w.shape[0] for w, _ in hidden])
         self.k, self.d_in, self.num_actions = k, hidden[0][0].shape[1], mu_wb[0].shape[0]
@@ -259,8 +325,8 @@ class PolicyForward:
         _chk(lib().bez_ppo_policy_forward(_p(obs), n, self.d_in, None if rms is None else _p(rms.running_mean, torch.float64),
                                           None if rms is None else _p(rms.running_var, torch.float64), 0.0 if rms is None else float(rms.epsilon), self.k,
                                           C.cast(self.hw, C.c_void_p), C.cast(self.hb, C.c_void_p), C.cast(self.widths, C.c_void_p),
-                                          _p(mu_wb[0], torch.float16), _p(mu_wb[1], torch.float16), self.num_actions, _p(value_wb[0], torch.float16),
-                                          _p(value_wb[1], torch.float16), _p(mu_out), _p(value_out), _stream(obs)), "bez_ppo_policy_forward")
+                                          C.c_void_p(self.mu_w.data_ptr()), _p(mu_wb[1], torch.float16), self.num_actions, _p(value_wb[0], torch.float16),
+                                          _p(value_wb[1], torch.float16), _p(mu_out), _p(value_out), self.flag, _stream(obs)), "bez_ppo_policy_forward")
 
     def train_forward(self, obs, x0, acts, mu_out, value_out):
         """Forward of a training minibatch that keeps the backward pass's operands: x0 (n, d_in) fp16, acts[i] (n, width_i) fp16."""
@@ -273,8 +339,8 @@ class PolicyForward:
         _chk(lib().bez_ppo_policy_forward_train(
             _p(obs), n, self.d_in, None if rms is None else _p(rms.running_mean, torch.float64), None if rms is None else _p(rms.running_var, torch.float64),
             0.0 if rms is None else float(rms.epsilon), self.k, C.cast(self.hw, C.c_void_p), C.cast(self.hb, C.c_void_p), C.cast(self.widths, C.c_void_p),
-            _p(mu_wb[0], torch.float16), _p(mu_wb[1], torch.float16), self.num_actions, _p(value_wb[0], torch.float16), _p(value_wb[1], torch.float16),
-            _p(x0, torch.float16), C.cast(tab, C.c_void_p), _p(mu_out), _p(value_out), _stream(obs)), "bez_ppo_policy_forward_train")
+            C.c_void_p(self.mu_w.data_ptr()), _p(mu_wb[1], torch.float16), self.num_actions, _p(value_wb[0], torch.float16), _p(value_wb[1], torch.float16),
+            _p(x0, torch.float16), C.cast(tab, C.c_void_p), _p(mu_out), _p(value_out), self.flag, _stream(obs)), "bez_ppo_policy_forward_train")
 
     def rollout_step(self, obs, logstd, noise, dones, value_rms, mb_obs, mb_dones, mb_mu, mb_val, actions, env_actions, neglogp, sigma):
         """Forward + everything up to the env step in the same launch (bez_ppo_policy_rollout_step): same outputs as
@@ -287,7 +353,7 @@ class PolicyForward:
         _chk(lib().bez_ppo_policy_rollout_step(
             _p(obs), n, self.d_in, None if rms is None else _p(rms.running_mean, torch.float64), None if rms is None else _p(rms.running_var, torch.float64),
             0.0 if rms is None else float(rms.epsilon), self.k, C.cast(self.hw, C.c_void_p), C.cast(self.hb, C.c_void_p), C.cast(self.widths, C.c_void_p),
-            _p(mu_wb[0], torch.float16), _p(mu_wb[1], torch.float16), A, _p(value_wb[0], torch.float16), _p(value_wb[1], torch.float16), _p(logstd), _p(noise),
+            C.c_void_p(self.mu_w.data_ptr()), _p(mu_wb[1], torch.float16), A, _p(value_wb[0], torch.float16), _p(value_wb[1], torch.float16), _p(logstd), _p(noise),
             _p(dones), None if value_rms is None else _p(value_rms.running_mean, torch.float64),
             None if value_rms is None else _p(value_rms.running_var, torch.float64), 0.0 if value_rms is None else float(value_rms.epsilon), _p(mb_obs),
-            _p(mb_dones), _p(mb_mu), _p(mb_val), _p(actions), _p(env_actions), _p(neglogp), _p(sigma), _stream(obs)), "bez_ppo_policy_rollout_step")
+            _p(mb_dones), _p(mb_mu), _p(mb_val), _p(actions), _p(env_actions), _p(neglogp), _p(sigma), self.flag, _stream(obs)), "bez_ppo_policy_rollout_step")

@@ -259,7 +259,7 @@ int bez_ppo_loss(const float* mu_dev, const float* logstd_dev, const float* valu
 int bez_ppo_policy_forward(const float* obs_dev, int64_t n, int32_t num_obs, const double* obs_mean_dev, const double* obs_var_dev, float obs_eps,
                            int32_t num_hidden, const void* const* hidden_w_f16_dev, const void* const* hidden_b_f16_dev, const int32_t* hidden_width,
                            const void* mu_w_f16_dev, const void* mu_b_f16_dev, int32_t num_actions, const void* value_w_f16_dev,
-                           const void* value_b_f16_dev, float* mu_dev, float* value_dev, void* stream);
+                           const void* value_b_f16_dev, float* mu_dev, float* value_dev, int32_t weights_packed, void* stream);
 
 /* The fused rollout step: bez_ppo_policy_forward followed, inside the same launch, by bez_ppo_rollout_pre's work (rollout-buffer
  * rows of obs / dones / mu / de-normalised value, a = mu + exp(logstd) * noise, neglogp, the clamped env action).  mu / value
@@ -270,7 +270,7 @@ int bez_ppo_policy_rollout_step(const float* obs_dev, int64_t n, int32_t num_obs
                                 const void* value_b_f16_dev, const float* logstd_dev, const float* noise_dev, const float* dones_dev,
                                 const double* value_mean_dev, const double* value_var_dev, float value_eps, float* mb_obs_dev, float* mb_dones_dev,
                                 float* mb_mu_dev, float* mb_val_dev, float* actions_dev, float* env_actions_dev, float* neglogp_dev, float* sigma_dev,
-                                void* stream);
+                                int32_t weights_packed, void* stream);
 
 /* The forward half of a PPO minibatch step (a2c_common.py calc_gradients: model(batch) under autocast): bez_ppo_policy_forward
  * that also keeps what the backward pass needs -- x0 (n, num_obs) fp16 = the normalised, clamped input of the first Linear, and
@@ -278,7 +278,7 @@ int bez_ppo_policy_rollout_step(const float* obs_dev, int64_t n, int32_t num_obs
 int bez_ppo_policy_forward_train(const float* obs_dev, int64_t n, int32_t num_obs, const double* obs_mean_dev, const double* obs_var_dev, float obs_eps,
                                  int32_t num_hidden, const void* const* hidden_w_f16_dev, const void* const* hidden_b_f16_dev, const int32_t* hidden_width,
                                  const void* mu_w_f16_dev, const void* mu_b_f16_dev, int32_t num_actions, const void* value_w_f16_dev,
-                                 const void* value_b_f16_dev, void* x0_f16_dev, void* const* act_f16_dev, float* mu_dev, float* value_dev, void* stream);
+                                 const void* value_b_f16_dev, void* x0_f16_dev, void* const* act_f16_dev, float* mu_dev, float* value_dev, int32_t weights_packed, void* stream);
 
 /* Gradient reductions of explicit-fp16 linear layers into the fp32 master gradient: the sum over `splits` split-K partial
  * products ([splits][n] fp16) and the bias gradient = column sums of dY ((rows, cols) fp16).  accumulate != 0 adds to out_dev. */
@@ -300,8 +300,17 @@ int bez_ppo_elu_bwd_colsum_f16(const void* gy_f16_dev, const void* y_f16_dev, vo
 int bez_ppo_policy_backward(const float* grad_mu_dev, const float* grad_value_dev, int64_t n, int32_t num_hidden, const int32_t* hidden_width,
                             int32_t num_actions, const void* const* act_f16_dev, const void* const* wt_f16_dev, const void* heads_t_f16_dev,
                             void* const* gz_f16_dev, void* grad_mu_f16_dev, void* grad_value_f16_dev, float* const* bias_grad_dev,
-                            float* mu_bias_grad_dev, float* value_bias_grad_dev, float* partial_dev, void* stream);
+                            float* mu_bias_grad_dev, float* value_bias_grad_dev, float* partial_dev, int32_t weights_packed, void* stream);
 int bez_ppo_scatter_f16(const void* src_f16_dev, const int32_t* map_dev, int64_t n, void* dst_f16_dev, void* stream); /* dst[map[i]] = src[i], map[i] >= 0 */
+int bez_ppo_scatter2_f16(const void* src_f16_dev, const int32_t* map_a_dev, const int32_t* map_b_dev, int64_t n, void* dst_f16_dev, void* stream);
+
+/* weights_packed (last int argument of the four bez_ppo_policy_* functions above): 0 = the weight pointers are the row-major (out, in) fp16
+ * matrices of nn.Linear (transposed ones for the backward function, as described there); 1 = they are FRAGMENT-MAJOR copies: for a Linear
+ * (out, in), block nb = n / 32 and k-step ks = k / 16 form one 1 KB chunk at halfs ((nb * ceil(in / 16) + ks) * 512), in which element
+ * (n, k) sits at ((k / 8 % 2) * 32 + n % 32) * 8 + k % 8, zero-padded beyond out / in -- a wave's MFMA B fragment as one coalesced load.
+ * Forward: hidden_w[i] packs W_i, mu_w packs the (num_actions + 1, width_last) matrix [W_mu; W_value] (value_w unused).  Backward: wt[i]
+ * packs W_i^T as a Linear (out = hidden_width[i-1], in = hidden_width[i]), heads_t packs [W_mu; W_value]^T as (out = width_last, in = 32).
+ * bez_ppo_scatter2_f16 refreshes both sets from one flat fp16 copy of the parameters (two index maps) in one launch. */
 
 /* rl_games AdaptiveScheduler.update (the `lr_schedule: adaptive` rule of bez_kickPPO.yaml) on device scalars: *lr /= 1.5 when *kl > 2 *
  * kl_threshold (floor min_lr), then *lr *= 1.5 when *kl < kl_threshold / 2 (cap max_lr).  No host round trip. */

@@ -324,6 +324,53 @@ def test_fused_and_plain_optimiser_step_agree():
     assert len(fused2.game_rewards) > 0
 
 
+def test_packed_weights_give_the_same_forward_and_backward_as_row_major():
+    """The fragment-major weight copies (coalesced MFMA operand loads) feed the same products in the same order: forward outputs,
+    kept activations, input gradients and bias gradients of the packed path equal the row-major path's bit for bit."""
+    from bez_isaacgym_amd.ppo import fused as F
+    from bez_isaacgym_amd.ppo.a2c_continuous import RunningMeanStd
+    torch.manual_seed(17)
+    n, d, units, a = 2048 + 77, 54, (400, 200, 100), 18
+    dims = [d] + list(units)
+    shapes = [(dims[i + 1], dims[i]) for i in range(3)] + [(a, dims[-1]), (1, dims[-1])]
+    sizes = []
+    for o, k in shapes:
+        sizes += [o * k, o]
+    hflat = (torch.randn(sum(sizes), device=DEV) * 0.08).half()
+    views, layout, off = [], [], 0
+    for o, k in shapes:
+        w = hflat[off:off + o * k].view(o, k); layout.append((off, o, k)); off += o * k
+        b = hflat[off:off + o]; off += o
+        views.append((w, b))
+    rms = RunningMeanStd((d,)).to(DEV)
+    rms.running_mean.copy_(torch.randn(d, dtype=torch.float64) * 0.3); rms.running_var.copy_(torch.rand(d, dtype=torch.float64) + 0.5)
+    packed = F.PackedWeights(hflat, layout, a)
+    obs = torch.randn(n, d, device=DEV) * 1.5
+    outs = []
+    for pk in (None, packed):
+        pf = F.PolicyForward(views[:3], views[3], views[4], rms, pk)
+        x0 = torch.zeros(n, d, device=DEV, dtype=torch.float16)
+        acts = [torch.zeros(n, w, device=DEV, dtype=torch.float16) for w in units]
+        mu, v = torch.zeros(n, a, device=DEV), torch.zeros(n, 1, device=DEV)
+        pf.train_forward(obs, x0, acts, mu, v)
+        mu2, v2 = torch.zeros(n, a, device=DEV), torch.zeros(n, 1, device=DEV)
+        pf(obs, mu2, v2)
+        assert torch.equal(mu, mu2) and torch.equal(v, v2)
+        pb = F.PolicyBackward(hflat, layout, a, pk)
+        pb.refresh()
+        gmu, gval = torch.randn(n, a, device=DEV) * 1e-2, torch.randn(n, 1, device=DEV) * 1e-2
+        torch.manual_seed(5); gmu.normal_(0, 1e-2); gval.normal_(0, 1e-2)
+        gz = [torch.zeros(n, w, device=DEV, dtype=torch.float16) for w in units]
+        g16, v16 = torch.zeros(n, a, device=DEV, dtype=torch.float16), torch.zeros(n, 1, device=DEV, dtype=torch.float16)
+        bg = [torch.zeros(w, device=DEV) for w in units]
+        bm, bv = torch.zeros(a, device=DEV), torch.zeros(1, device=DEV)
+        pb(gmu, gval, acts, gz, g16, v16, bg, bm, bv)
+        outs.append([mu, v, x0] + acts + gz + [g16, v16] + bg)
+    assert float(outs[0][0].abs().max()) > 0 and float(outs[0][6].abs().max()) > 0
+    for t0, t1 in zip(outs[0], outs[1]):
+        assert torch.equal(t0, t1)
+
+
 def test_adaptive_lr_kernel_matches_the_scheduler_rule():
     from bez_isaacgym_amd.ppo import fused as F
     from bez_isaacgym_amd.ppo.a2c_continuous import AdaptiveScheduler

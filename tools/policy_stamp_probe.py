@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+"""Diagnostic: where the one-launch policy forward (csrc/bez_policy.hip) spends its time.  Builds bez_policy.hip with -DBEZ_PF_STAMPS,
+runs the forward on 4096 x 54 -> 400 -> 200 -> 100 -> (18 + 1) and prints s_memtime of workgroup 0 / thread 0 at the phase boundaries."""
+import ctypes as C, os, subprocess, sys
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+sys.path.insert(0, ROOT)
+import torch
+so = os.path.join(ROOT, "gpurun_out", "libbez_policy_stamps.so")
+os.makedirs(os.path.dirname(so), exist_ok=True)
+subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fno-slp-vectorize", "-DBEZ_PF_STAMPS", "-o", so,
+                os.path.join(ROOT, "bez_isaacgym_amd", "csrc", "bez_policy.hip")], check=True)
+lib = C.CDLL(so)
+dev = "cuda:0"
+torch.manual_seed(0)
+n, d, units, a = int(os.environ.get("N", 4096)), 54, (400, 200, 100), 18
+dims = [d] + list(units)
+hid = [((torch.randn(dims[i + 1], dims[i], device=dev) / dims[i] ** 0.5).half().contiguous(), (torch.randn(dims[i + 1], device=dev) * 0.1).half()) for i in range(3)]
+mu_w, mu_b = (torch.randn(a, 100, device=dev) / 10).half().contiguous(), torch.zeros(a, device=dev).half()
+v_w, v_b = (torch.randn(1, 100, device=dev) / 10).half().contiguous(), torch.zeros(1, device=dev).half()
+obs = torch.randn(n, d, device=dev)
+mu, val = torch.empty(n, a, device=dev), torch.empty(n, 1, device=dev)
+stamps = torch.zeros(16, dtype=torch.int64, device=dev)
+lib.bez_ppo_policy_debug_stamps(C.c_void_p(stamps.data_ptr()))
+hw = (C.c_void_p * 3)(*[w.data_ptr() for w, _ in hid]); hb = (C.c_void_p * 3)(*[b.data_ptr() for _, b in hid]); wd = (C.c_int32 * 3)(*units)
+vp = C.c_void_p
+lib.bez_ppo_policy_forward.argtypes = [vp, C.c_int64, C.c_int32, vp, vp, C.c_float, C.c_int32, vp, vp, vp, vp, vp, C.c_int32, vp, vp, vp, vp, vp]
+def run():
+    return lib.bez_ppo_policy_forward(vp(obs.data_ptr()), n, d, None, None, 0.0, 3, C.cast(hw, vp), C.cast(hb, vp), C.cast(wd, vp), vp(mu_w.data_ptr()), vp(mu_b.data_ptr()),
+                                      a, vp(v_w.data_ptr()), vp(v_b.data_ptr()), vp(mu.data_ptr()), vp(val.data_ptr()), None)
+for _ in range(20):
+    assert run() == 0
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(200):
+    run()
+e1.record(); torch.cuda.synchronize()
+print("kernel %.2f us per launch (n = %d)" % (e0.elapsed_time(e1) * 1e3 / 200, n))
+s = stamps.cpu().numpy()
+names = {0: "entry", 1: "obs staged + sync", 2: "layer 0 done (wave 0)", 3: "after sync", 4: "layer 1 done", 5: "after sync", 6: "layer 2 done", 7: "after sync", 14: "heads done", 15: "end"}
+for k in sorted(names):
+    if s[k]:
+        print("%-24s %8d" % (names[k], s[k] - s[0]))
