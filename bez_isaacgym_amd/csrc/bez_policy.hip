@@ -47,7 +47,15 @@ struct PolicyArgs {
   // training forward (mode 2): what the backward pass needs -- the fp16 input of the first Linear and every ELU output, row-major
   _Float16* x0_out; _Float16* act_out[PF_MAXL];
   int packed;  // weights are fragment-major copies (see gemm_col_block_packed): w[L] and w_mu (= the packed [mu; value] block)
+#ifdef BEZ_PF_STAMPS
+  unsigned long long* stamps;  // diagnostic build only: s_memtime of workgroup 0 / thread 0 at the phase boundaries
+#endif
 };
+#ifdef BEZ_PF_STAMPS
+#define PF_STAMP(k) do { if (a.stamps && blockIdx.x == 0 && threadIdx.x == 0) a.stamps[k] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define PF_STAMP(k) do { } while (0)
+#endif
 
 // rows [0, nrow) x columns [0, cols) of an LDS activation tile -> global (row-major, `cols` halfs per row, cols even): half2 per
 // lane, consecutive lanes on consecutive columns (256 B per wave instruction)
@@ -216,6 +224,7 @@ __global__ __launch_bounds__(PF_WAVES * 64) void policy_forward_kernel(PolicyArg
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int64_t row0 = (int64_t)blockIdx.x * PF_ROWS;
   const int nrow = (int)((a.n - row0) < (int64_t)PF_ROWS ? (a.n - row0) : (int64_t)PF_ROWS);
+  PF_STAMP(0);
   // stage the (normalised) observations as fp16, zero-padded to a multiple of 16 columns
   const int kpad0 = (a.d_in + 15) & ~15;
   for (int idx = tid; idx < PF_ROWS * kpad0; idx += PF_WAVES * 64) {
@@ -232,17 +241,22 @@ __global__ __launch_bounds__(PF_WAVES * 64) void policy_forward_kernel(PolicyArg
     t0[rr][k] = (_Float16)v;
   }
   __syncthreads();
+  PF_STAMP(1);
   if (TRAIN) store_tile(t0, a.x0_out, row0, nrow, a.d_in, tid);
   int in = a.d_in;
   for (int L = 0; L < a.nhid; L += 2) {
     layer<true, PK>(t0, t1, a.w[L], a.b[L], in, a.width[L], wave, lane);
+    PF_STAMP(2 + 2 * L);
     // the next layer reads K padded to 16: columns width..pad16(width) were written as elu(0 + 0) = 0 by the padded column block
     __syncthreads();
+    PF_STAMP(3 + 2 * L);
     in = a.width[L];
     if (TRAIN) store_tile(t1, a.act_out[L], row0, nrow, in, tid);  // (the stores drain behind the next layer's MFMAs)
     if (L + 1 < a.nhid) {
       layer<true, PK>(t1, t0, a.w[L + 1], a.b[L + 1], in, a.width[L + 1], wave, lane);
+      PF_STAMP(4 + 2 * L);
       __syncthreads();
+      PF_STAMP(5 + 2 * L);
       in = a.width[L + 1];
       if (TRAIN) store_tile(t0, a.act_out[L + 1], row0, nrow, in, tid);
     }
@@ -253,6 +267,7 @@ __global__ __launch_bounds__(PF_WAVES * 64) void policy_forward_kernel(PolicyArg
     if (in_t1) heads<ROLL, PK>(a, t1, in, tile, row0, nrow, lane);
     else heads<ROLL, PK>(a, t0, in, tile, row0, nrow, lane);
   }
+  PF_STAMP(14);
   if (ROLL) {
     // sampling, neglogp, clamp, rollout-buffer rows: one thread per (env, action), the per-env sum through the same LDS tile
     __syncthreads();
@@ -279,6 +294,7 @@ __global__ __launch_bounds__(PF_WAVES * 64) void policy_forward_kernel(PolicyArg
       a.mb_dones[row0 + tid] = a.dones[row0 + tid];
     }
   }
+  PF_STAMP(15);
 }
 
 // ---- the input-gradient half of the backward pass of one minibatch as ONE kernel (bez_ppo_policy_backward): per 64-row tile, from
@@ -443,6 +459,10 @@ __global__ void scatter_f16_kernel(const _Float16* __restrict__ src, const int32
 
 }  // namespace
 
+#ifdef BEZ_PF_STAMPS
+static unsigned long long* g_pf_stamps = nullptr;  // diagnostic build: device buffer of 16 stamps (tools/policy_stamp_probe.py)
+extern "C" void bez_ppo_policy_debug_stamps(unsigned long long* dev) { g_pf_stamps = dev; }
+#endif
 static int fill_args(PolicyArgs& a, const float* obs_dev, int64_t n, int32_t num_obs, const double* obs_mean_dev, const double* obs_var_dev, float obs_eps,
                      int32_t num_hidden, const void* const* hidden_w_f16_dev, const void* const* hidden_b_f16_dev, const int32_t* hidden_width,
                      const void* mu_w_f16_dev, const void* mu_b_f16_dev, int32_t num_actions, const void* value_w_f16_dev, const void* value_b_f16_dev) {
@@ -463,6 +483,9 @@ static int fill_args(PolicyArgs& a, const float* obs_dev, int64_t n, int32_t num
   a.x0_out = nullptr;
   for (int i = 0; i < PF_MAXL; ++i) a.act_out[i] = nullptr;
   a.packed = 0;
+#ifdef BEZ_PF_STAMPS
+  a.stamps = g_pf_stamps;
+#endif
   return 0;
 }
 

@@ -23,10 +23,10 @@ stamps = torch.zeros(16, dtype=torch.int64, device=dev)
 lib.bez_ppo_policy_debug_stamps(C.c_void_p(stamps.data_ptr()))
 hw = (C.c_void_p * 3)(*[w.data_ptr() for w, _ in hid]); hb = (C.c_void_p * 3)(*[b.data_ptr() for _, b in hid]); wd = (C.c_int32 * 3)(*units)
 vp = C.c_void_p
-lib.bez_ppo_policy_forward.argtypes = [vp, C.c_int64, C.c_int32, vp, vp, C.c_float, C.c_int32, vp, vp, vp, vp, vp, C.c_int32, vp, vp, vp, vp, vp]
+lib.bez_ppo_policy_forward.argtypes = [vp, C.c_int64, C.c_int32, vp, vp, C.c_float, C.c_int32, vp, vp, vp, vp, vp, C.c_int32, vp, vp, vp, vp, C.c_int32, vp]
 def run():
     return lib.bez_ppo_policy_forward(vp(obs.data_ptr()), n, d, None, None, 0.0, 3, C.cast(hw, vp), C.cast(hb, vp), C.cast(wd, vp), vp(mu_w.data_ptr()), vp(mu_b.data_ptr()),
-                                      a, vp(v_w.data_ptr()), vp(v_b.data_ptr()), vp(mu.data_ptr()), vp(val.data_ptr()), None)
+                                      a, vp(v_w.data_ptr()), vp(v_b.data_ptr()), vp(mu.data_ptr()), vp(val.data_ptr()), 0, None)  # row-major weights (weights_packed = 0)
 for _ in range(20):
     assert run() == 0
 torch.cuda.synchronize()
