@@ -27,6 +27,21 @@ lib.bez_ppo_policy_forward.argtypes = [vp, C.c_int64, C.c_int32, vp, vp, C.c_flo
 def run():
     return lib.bez_ppo_policy_forward(vp(obs.data_ptr()), n, d, None, None, 0.0, 3, C.cast(hw, vp), C.cast(hb, vp), C.cast(wd, vp), vp(mu_w.data_ptr()), vp(mu_b.data_ptr()),
                                       a, vp(v_w.data_ptr()), vp(v_b.data_ptr()), vp(mu.data_ptr()), vp(val.data_ptr()), 0, None)  # row-major weights (weights_packed = 0)
+PACKED = int(os.environ.get("PACKED", "0"))
+if PACKED:  # fragment-major copies (the layout of include/bez_sim.h, weights_packed), built with the product's own index helper
+    import numpy as np
+    from bez_isaacgym_amd.ppo.fused import _pack_index
+    def pack(w):
+        idx, size = _pack_index(*w.shape)
+        out = torch.zeros(size, device=dev, dtype=torch.float16)
+        out[torch.from_numpy(idx.reshape(-1)).to(dev)] = w.reshape(-1)
+        return out
+    pk = [pack(w) for w, _ in hid]
+    heads_pk = pack(torch.cat([mu_w, v_w], 0))
+    hw = (C.c_void_p * 3)(*[w.data_ptr() for w in pk])
+    def run():
+        return lib.bez_ppo_policy_forward(vp(obs.data_ptr()), n, d, None, None, 0.0, 3, C.cast(hw, vp), C.cast(hb, vp), C.cast(wd, vp), vp(heads_pk.data_ptr()),
+                                          vp(mu_b.data_ptr()), a, vp(v_w.data_ptr()), vp(v_b.data_ptr()), vp(mu.data_ptr()), vp(val.data_ptr()), 1, None)
 for _ in range(20):
     assert run() == 0
 torch.cuda.synchronize()
@@ -35,7 +50,7 @@ e0.record()
 for _ in range(200):
     run()
 e1.record(); torch.cuda.synchronize()
-print("kernel %.2f us per launch (n = %d)" % (e0.elapsed_time(e1) * 1e3 / 200, n))
+print("kernel %.2f us per launch (n = %d, weights %s)" % (e0.elapsed_time(e1) * 1e3 / 200, n, "fragment-major" if PACKED else "row-major"))
 s = stamps.cpu().numpy()
 names = {0: "entry", 1: "obs staged + sync", 2: "layer 0 done (wave 0)", 3: "after sync", 4: "layer 1 done", 5: "after sync", 6: "layer 2 done", 7: "after sync", 14: "heads done", 15: "end"}
 for k in sorted(names):
