@@ -41,9 +41,11 @@ def pmc_traffic(num_envs):
     return None, None
 
 
-def cpu_baseline(num_envs, seconds_target=12.0):
+def cpu_baseline(num_envs, seconds_target=9.0, seconds_single=3.0):
     """The oracle (kind 'port': this build's CPU restatement; the reference's own CPU pipeline is the closed
-    PhysX binary and cannot run) on the host cores, bounded sample of the same workload."""
+    PhysX binary and cannot run) on the host cores, bounded sample of the same workload: all cores of the box's
+    share, then one thread (BASELINE.md 3 asks for both), with mean / p50 / p99 step times."""
+    import ctypes
     import numpy as np
     from oracle.bez_oracle import Oracle, build
     from bez_isaacgym_amd import abi
@@ -51,24 +53,59 @@ def cpu_baseline(num_envs, seconds_target=12.0):
     cores = min(len(os.sched_getaffinity(0)), 16)  # a 1-GPU box's CPU share is 16 cores
     os.environ["OMP_NUM_THREADS"] = str(cores)  # read by libgomp when the oracle library is first loaded
     orc = Oracle(abi.default_config(num_envs))
+    gomp = ctypes.CDLL("libgomp.so.1")
     rng = np.random.default_rng(0)
     acts = rng.uniform(-1, 1, (8, num_envs, 18)).astype(np.float32)
-    orc.step(acts[0])
-    t0 = time.perf_counter()
-    orc.step(acts[1])
-    one = time.perf_counter() - t0
-    steps = int(max(6, min(2000, seconds_target / max(one, 1e-6))))
-    seg, rates, dt = max(steps // 4, 1), [], 0.0
-    for k in range(4):  # four segments: the host cores of a shared box are noisy, report the spread with the mean
+
+    def sample(threads, budget):
+        gomp.omp_set_num_threads(threads)
+        orc.step(acts[0])
         t0 = time.perf_counter()
-        for t in range(seg):
-            orc.step(acts[t % 8])
-        d = time.perf_counter() - t0
-        dt += d
-        rates.append(num_envs * seg / d)
-    return {"value": num_envs * seg * 4 / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
-            "spread": [min(rates), max(rates)],
-            "sample": "%d envs x %d control steps in 4 segments, fp64 C oracle, OpenMP over envs (%.1f s)" % (num_envs, seg * 4, dt)}
+        orc.step(acts[1])
+        one = time.perf_counter() - t0
+        steps = int(max(8, min(2000, budget / max(one, 1e-6))))
+        seg, rates, times = max(steps // 4, 2), [], []
+        for k in range(4):  # four segments: the host cores of a shared box are noisy, report the spread with the mean
+            t0 = time.perf_counter()
+            for t in range(seg):
+                t1 = time.perf_counter()
+                orc.step(acts[t % 8])
+                times.append(time.perf_counter() - t1)
+            rates.append(num_envs * seg / (time.perf_counter() - t0))
+        times = np.array(times)
+        return {"value": num_envs * times.size / float(times.sum()), "spread": [min(rates), max(rates)], "steps": int(times.size), "seconds": float(times.sum()),
+                "ms_per_step": {"mean": float(times.mean() * 1e3), "p50": float(np.percentile(times, 50) * 1e3), "p99": float(np.percentile(times, 99) * 1e3)}}
+    multi = sample(cores, seconds_target)
+    single = sample(1, seconds_single)
+    return {"value": multi["value"], "unit": "env-steps/s", "cores": cores, "kind": "port", "spread": multi["spread"],
+            "ms_per_step": multi["ms_per_step"],
+            "single_thread": {"value": single["value"], "cores": 1, "ms_per_step": single["ms_per_step"],
+                              "sample": "%d control steps (%.1f s)" % (single["steps"], single["seconds"])},
+            "sample": "%d envs x %d control steps in 4 segments, fp64 C oracle, OpenMP over envs (%.1f s)" % (num_envs, multi["steps"], multi["seconds"])}
+
+
+def launch_ranks(n, argv, env=None, python=sys.executable):
+    """`python bench.py --gpus N` without a launcher: start N ranks of this script (one per GPU: RANK = LOCAL_RANK = i,
+    WORLD_SIZE = N, rendezvous on 127.0.0.1) BEFORE anything in this process touches a GPU, let rank 0's stdout through
+    (its ONE JSON line), and return the worst exit code.  The reference picks the device the same way, from the rank
+    (utils/rlgames_utils.py:71-81).  torch.distributed.run does exactly this when the driver uses it; then WORLD_SIZE is
+    already set and this function is not reached."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        e = dict(os.environ if env is None else env)
+        e.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        e.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([python, os.path.abspath(__file__)] + list(argv), env=e,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    return rc
 
 
 def ppo_leg(args, rank, local_rank, world, n):
@@ -114,6 +151,36 @@ def ppo_leg(args, rank, local_rank, world, n):
             "minibatch": agent.minibatch_size, "mini_epochs": agent.mini_epochs}
 
 
+def stub_main(args, rank, world):
+    """The multi-rank skeleton of main() on the CPU (gloo), the env step replaced by a no-op: rendezvous, barrier-bracketed timed
+    region, MAX over ranks, one JSON line from rank 0.  Exercised by tests/test_bench_launcher.py."""
+    import torch
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group("gloo")
+        assert dist.get_world_size() == args.gpus
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        pass
+    elapsed = time.perf_counter() - t0 + 1e-9
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        ranks = torch.zeros(world, dtype=torch.int64)
+        ranks[rank] = 1
+        dist.all_reduce(ranks)
+        assert int(ranks.sum()) == world
+    if rank == 0:
+        print(json.dumps({"metric": "stub", "value": args.num_envs * world * args.steps / elapsed, "n_gpus": world, "steps": args.steps,
+                          "warmup": args.warmup, "scaling": "weak", "config": {"parallelism": "env-sharded x%d" % world}}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -125,19 +192,29 @@ def main():
                     "'PPO samples/s' half of BASELINE.json's metric (0 = skip)")
     ap.add_argument("--launch", choices=["python", "c"], default="python",
                     help="python: one bez_sim_step call per step from Python; c: bez_sim_step_many (C loop)")
+    ap.add_argument("--stub-cpu", action="store_true", help="launcher self-test: gloo on the CPU, the env step replaced by a no-op "
+                    "(tests/test_bench_launcher.py); prints the same JSON skeleton with metric 'stub'")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))  # nothing above this line has touched a GPU
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d: launch one rank per GPU (python bench.py --gpus N does)" % (args.gpus, world))
+    if args.stub_cpu:
+        return stub_main(args, rank, world)
 
     import torch
     import torch.distributed as dist
     from bez_isaacgym_amd import abi
     from bez_isaacgym_amd.sim import BezSim
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        assert dist.get_world_size() == args.gpus, (dist.get_world_size(), args.gpus)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     n = args.num_envs
@@ -180,6 +257,16 @@ def main():
     # sanity: the rollout really ran (resets happen with random actions; everything finite)
     obs = sim.tensor(abi.TENSOR_OBS)
     assert torch.isfinite(obs).all()
+    # step-time distribution (mean / p50 / p99), measured AFTER the timed region so that the per-step events do not
+    # sit inside it: 400 steps, one HIP event pair each, read back at the end
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(401)]
+    evs[0].record()
+    for t in range(400):
+        sim.step(actions[t % ACTION_RING])
+        evs[t + 1].record()
+    torch.cuda.synchronize()
+    per = sorted(evs[t].elapsed_time(evs[t + 1]) for t in range(400))
+    step_ms = {"mean": sum(per) / len(per), "p50": per[200], "p99": per[396], "what": "400 extra steps outside the timed region, HIP event pair per step"}
 
     ppo = None
     if args.ppo_epochs > 0:
@@ -198,6 +285,7 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
+            "step_ms": step_ms,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,

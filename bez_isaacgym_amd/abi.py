@@ -7,7 +7,7 @@ reference).  Loading / calling the library is in `bez_isaacgym_amd.sim`.
 import ctypes as C
 import math
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 NUM_OBS = 54
 NUM_ACTIONS = 18
 NUM_DOFS = 18
@@ -21,6 +21,7 @@ FLAG_CF_LAST_SUBSTEP = 4
 FLAG_NO_SELF_COLLISION = 8
 FLAG_CLEATS = 16
 FLAG_BOX_ASSET = 32
+FLAG_HARD_CONTACT = 64
 TASK_KICK, TASK_WALK, TASK_ORIENT = 0, 1, 2
 TASK_IDS = {"bez_kick": TASK_KICK, "bez_walk": TASK_WALK, "bez_orient": TASK_ORIENT}
 
@@ -63,6 +64,8 @@ class BezSimConfig(C.Structure):
         ("ball_ang_damping", C.c_float),
         ("self_kn", C.c_float),
         ("self_cn", C.c_float),
+        ("ball_kn", C.c_float),
+        ("ball_cn", C.c_float),
         ("tune", C.c_float * 8),
         ("task", C.c_int32),
         ("goal_angle", C.c_float),
@@ -82,7 +85,7 @@ class BezSimConfig(C.Structure):
 # Contact / limit model constants of this build (no reference counterpart; DESIGN.md "Physics model")
 CONTACT_DEFAULTS = dict(contact_kn=2.0e4, contact_cn=20.0, contact_ct=1.0e3, contact_veps=0.01,
                         limit_k=200.0, limit_d=2.0, jfric_veps=0.1, ball_ang_damping=0.5,
-                        self_kn=3000.0, self_cn=5.0)
+                        self_kn=3000.0, self_cn=5.0, ball_kn=0.0, ball_cn=0.0)
 
 
 def default_config(num_envs=4096, seed=42, env_id_offset=0):

@@ -46,34 +46,54 @@ def needs_build():
 
 
 def build(force=False, verbose=False):
+    """Compile + link under an inter-process lock: every rank of a torchrun job imports the package and may find a stale tree at
+    the same moment; only the first one builds, the others wait and then see the fresh stamp.  Objects go to a per-process
+    directory and the finished library / stamp are moved into place atomically, so a reader never maps a half-written file."""
+    import fcntl
+    import shutil
+    import tempfile
     if not force and not needs_build():
         return OUT
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
-    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    # -fno-slp-vectorize: hipcc's SLP pass packs adjacent scalar f32 ops into v_pk_* and pays for it in v_mov shuffles
-    # (23.1k -> 16.4k VALU instructions in the fused kernel, 33.2 -> 29.1 us per step on MI355X)
-    if os.path.exists(STAMP):
-        os.remove(STAMP)
-    # one translation unit per .hip file, compiled side by side, then linked into the one shared library
-    objdir = os.path.join(HERE, "lib", "obj")
-    os.makedirs(objdir, exist_ok=True)
-    procs, objs = [], []
-    for src in _sources():
-        obj = os.path.join(objdir, os.path.basename(src)[:-4] + ".o")
-        cmd = [hipcc] + _flags() + ["-c", "-o", obj, src]
-        if verbose:
-            print(" ".join(cmd))
-        procs.append((cmd, subprocess.Popen(cmd)))
-        objs.append(obj)
-    for cmd, p in procs:
-        if p.wait() != 0:
-            raise subprocess.CalledProcessError(p.returncode, cmd)
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.run(cmd, check=True)
-    with open(STAMP, "w") as f:
-        f.write(source_hash() + "\n")
+    with open(os.path.join(os.path.dirname(OUT), ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and not needs_build():  # another process built it while this one waited
+                return OUT
+            hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+            # -fno-slp-vectorize: hipcc's SLP pass packs adjacent scalar f32 ops into v_pk_* and pays for it in v_mov shuffles
+            # (23.1k -> 16.4k VALU instructions in the fused kernel, 33.2 -> 29.1 us per step on MI355X)
+            # one translation unit per .hip file, compiled side by side, then linked into the one shared library
+            objdir = tempfile.mkdtemp(prefix="obj.%d." % os.getpid(), dir=os.path.dirname(OUT))
+            try:
+                procs, objs = [], []
+                for src in _sources():
+                    obj = os.path.join(objdir, os.path.basename(src)[:-4] + ".o")
+                    cmd = [hipcc] + _flags() + ["-c", "-o", obj, src]
+                    if verbose:
+                        print(" ".join(cmd))
+                    procs.append((cmd, subprocess.Popen(cmd)))
+                    objs.append(obj)
+                for cmd, p in procs:
+                    if p.wait() != 0:
+                        raise subprocess.CalledProcessError(p.returncode, cmd)
+                tmp_so = os.path.join(objdir, "libbez_sim.so")
+                cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp_so] + objs
+                if verbose:
+                    print(" ".join(cmd))
+                subprocess.run(cmd, check=True)
+                h = source_hash()
+                if os.path.exists(STAMP):
+                    os.remove(STAMP)  # never a fresh stamp beside an old library
+                os.replace(tmp_so, OUT)
+                tmp_stamp = os.path.join(objdir, "stamp")
+                with open(tmp_stamp, "w") as f:
+                    f.write(h + "\n")
+                os.replace(tmp_stamp, STAMP)
+            finally:
+                shutil.rmtree(objdir, ignore_errors=True)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
     return OUT
 
 

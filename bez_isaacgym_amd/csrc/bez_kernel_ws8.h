@@ -1,7 +1,7 @@
 // bez_kernel_ws8.h -- wave-specialised fused step kernel, 8 role waves per 64 environments (2 waves per SIMD).
 //
 // A lone wave issues one vector instruction every ~5 cycles on a CDNA4 SIMD whatever the other SIMDs do, so the step time of
-// the 4-wave kernel (bez_kernel_ws.h) is the instruction count of its longest role: a leg (forward kinematics, link
+// a kernel with one wave per chain (round 1's 4-wave kernel) is the instruction count of its longest role: a leg (forward kinematics, link
 // inertias, ball/box tests, foot ground contact, the articulated-inertia recursion, the leg<->leg correction, pass 3).  Here
 // the leg roles keep only what is serial in the joint chain, and everything that merely NEEDS the leg's kinematics is
 // recomputed from the published joint state by helper waves that share the SIMDs (a second wave on a SIMD issues in the slots
@@ -487,7 +487,7 @@ BEZ_DEV void post_imu_orn(const Params& P, float* lds, int lane, int e, bool act
 #pragma unroll
     for (int i = 0; i < 4; ++i) rq[i] = P.bez_init[3 + i];
     lin = ang = mk(0, 0, 0);
-    if (P.task != BEZ_TASK_KICK) { goal_x = P.goal_draw[0]; goal_y = P.goal_draw[1]; }
+    if (P.task != BEZ_TASK_KICK) { goal_x = reset_goal(P, 0); goal_y = reset_goal(P, 1); }
   }
   float tail[8];
   obs_imu_orn(P, root_pos, rq, lin, ang, prev, goal_x, goal_y, tail);
@@ -704,7 +704,7 @@ BEZ_DEV void root_role(const Params& P, float* lds, int lane, int e, bool active
       root_lin = root_ang = ball_lin = ball_ang = mk(0, 0, 0);
       if (active) P.episode[e] = P.episode[e] + 1;
       if (P.task != BEZ_TASK_KICK) {  // walk_env.py:570-575: every env reset by this call receives the same fresh goal
-        goal_x = P.goal_draw[0]; goal_y = P.goal_draw[1];
+        goal_x = reset_goal(P, 0); goal_y = reset_goal(P, 1);
         if (active) { st[(size_t)F_GOAL * n + e] = goal_x; st[(size_t)(F_GOAL + 1) * n + e] = goal_y; }
       }
       progress = 0; reset = 0;

@@ -47,11 +47,15 @@ struct Params {
   float kp, kd, armature, effort, vel_limit, jfric, mu, clip;
   float bez_init[7], ball_init[7], goal[2];
   float kn, cn, ct, veps, lim_k, lim_d, jf_veps, ball_damp;
+  float bkn, bcn;  // ball <-> ground / ball <-> robot spring and damper (BezSimConfig.ball_kn / ball_cn, defaulting to kn / cn)
   float self_kn, self_cn;
   float cf_w;  // weight of one substep in the net-contact-force mean (1/substeps, or 1 with BEZ_FLAG_CF_LAST_SUBSTEP)
   int task, nobs;       // BEZ_TASK_*; observation width (54 kick, 52 walk / orient)
   float goal_angle;     // bez_orient
   float goal_draw[2];   // bez_walk / bez_orient: the ONE goal every env reset by this launch receives (walk_env.py:570-575)
+  const float* goal_dev; // != null: that goal lives in device memory, written by goal_draw_kernel just before this launch from a
+                         // DEVICE-resident call counter -- a HIP-graph replay then draws a fresh goal per step (by-value kernel
+                         // arguments are frozen at capture)
   uint32_t flags;
   uint64_t seed;
   int64_t env_off;
@@ -72,6 +76,9 @@ struct Params {
   const float* dr_upper;     // (N,18)   or null
   unsigned long long* stamps; // diagnostic builds only (-DBEZ_WS_STAMPS): s_memtime per role / phase of workgroup 0
 };
+// the goal an env reset by this launch receives (bez_walk / bez_orient)
+BEZ_DEV float reset_goal(const Params& P, int k) { return P.goal_dev ? P.goal_dev[k] : P.goal_draw[k]; }
+
 
 // ---- model variant: CL = the cleats asset (BEZ_FLAG_CLEATS): same tree, heavier feet, 8 cleat bodies, per-cleat ground points
 template <bool CL> BEZ_DEV constexpr int nb_of() { return CL ? BEZ_NB_CL : BEZ_NB; }   // robot bodies; the ball's row follows
@@ -169,13 +176,13 @@ struct EnvDyn {
 struct Hit { V3 x; float fn0, kn, ct, ftx0, fty0; };
 BEZ_DEV Hit hit_none() { Hit h; h.x = mk(0, 0, 0); h.fn0 = h.kn = h.ct = h.ftx0 = h.fty0 = 0.f; return h; }
 
-BEZ_DEV Hit ground_contact(const Params& P, float mu, V3 x, float z, SV V, Sym6& IA, SV& pA) {
+BEZ_DEV Hit ground_contact(const Params& P, float ckn, float ccn, float mu, V3 x, float z, SV V, Sym6& IA, SV& pA) {
   Hit hit = hit_none();
   float d = -z;
   if (d > 0.f) {
     V3 vp = point_of(V, x);
-    float kd = fmaf(P.h, P.kn, P.cn);
-    float fn0 = fmaf(P.kn, d, -kd * vp.z);
+    float kd = fmaf(P.h, ckn, ccn);
+    float fn0 = fmaf(ckn, d, -kd * vp.z);
     if (fn0 > 0.f) {
       float kn = P.h * kd;
       float vt = fsqrt(fmaf(vp.x, vp.x, vp.y * vp.y));
@@ -304,7 +311,7 @@ BEZ_DEV BallBody ball_setup(const Params& P, float mu, V3 g, float ball_z, V3 ba
   B.pb = mksv(mk(0, 0, 0), g * (-mb));
   Sym6 dummy = sym6zero();
   SV Vb = mksv(ball_ang, ball_lin);
-  B.ghit = ground_contact(P, mu, mk(0, 0, -R), ball_z - R, Vb, dummy, B.pb);
+  B.ghit = ground_contact(P, P.bkn, P.bcn, mu, mk(0, 0, -R), ball_z - R, Vb, dummy, B.pb);
   B.ground = B.ghit.kn > 0.f;
   float kt = P.h * B.ghit.ct, kn = B.ghit.kn;
   // det = (Ib + kt R^2)(m + kt) - kt^2 R^2 = Ib m + Ib kt + m kt R^2  (expanded: no cancellation)
@@ -322,8 +329,8 @@ BEZ_DEV void ball_link_contact(const Params& P, float mu, V3 ball_ang, V3 ball_l
   SV Vb = mksv(ball_ang, ball_lin);
   V3 u = point_of(Vl, x) - point_of(Vb, xb);
   float un = dot(u, n);
-  float kd = fmaf(P.h, P.kn, P.cn);
-  float fmag = fmaf(P.kn, sel.depth, kd * un);
+  float kd = fmaf(P.h, P.bkn, P.bcn);
+  float fmag = fmaf(P.bkn, sel.depth, kd * un);
   if (!(fmag > 0.f)) { sel.link = -1; return; }
   V3 ut = u - n * un;
   float vt = fsqrt(dot(ut, ut));
@@ -463,7 +470,7 @@ BEZ_DEV void link_ground_points(const Params& P, float mu, float root_z, const M
     if (BEZ_PT_LINK[i] == L) {
       V3 pl = mk(pt_pos_of<CL>(P, i, 0), pt_pos_of<CL>(P, i, 1), pt_pos_of<CL>(P, i, 2));
       V3 x = r + mul(E, pl);
-      Hit hit = ground_contact(P, mu, x, root_z + x.z, V, IA, pA);
+      Hit hit = ground_contact(P, P.kn, P.cn, mu, x, root_z + x.z, V, IA, pA);
       if (keep) lds_store_hit(lds, lane, i, hit);
     }
   }
@@ -1033,7 +1040,7 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(Params P) {
         env_reset(P, S, target, co, episode, P.env_off + e);
         progress = 0; reset = 0;
         P.episode[e] = episode;
-        if (P.task != BEZ_TASK_KICK) { st[(size_t)F_GOAL * n + e] = P.goal_draw[0]; st[(size_t)(F_GOAL + 1) * n + e] = P.goal_draw[1]; }  // walk_env.py:570-575
+        if (P.task != BEZ_TASK_KICK) { st[(size_t)F_GOAL * n + e] = reset_goal(P, 0); st[(size_t)(F_GOAL + 1) * n + e] = reset_goal(P, 1); }  // walk_env.py:570-575
       }
     }
     float prev[3], feet[8], obs[BEZ_NUM_OBS], rew;

@@ -33,7 +33,7 @@ struct BezSim {
   int64_t obs_calls = 0;  // compute_observations passes so far (quirk Q1: only the first sees prev = zeros)
   uint64_t post_calls = 0, reset_calls = 0;  // keys of the shared goal draw (bez_walk / bez_orient)
   bool cleats = false, has_ball = true;
-  int kernel = 0;  // fused-step kernel: 0 = 8 role waves (bez_kernel_ws8.h, default), 1 = 4 role waves (bez_kernel_ws.h), 2 = one env per lane
+  int kernel = 0;  // fused-step kernel: 0 = 8 role waves (bez_kernel_ws8.h, default), 2 = one env per lane (bez_kernels.h)
   int nb = BEZ_NB, nbe = BEZ_NBE, nobs = BEZ_NUM_OBS, nact = 2;  // robot bodies, exported body rows, obs width, actors per env
   std::string err;
   // sim-owned device memory
@@ -54,6 +54,8 @@ struct BezSim {
   float* feet_aos = nullptr;     // (N,8)
   float* goal_aos = nullptr;     // (N,2)
   float* dr[BEZ_PARAM_COUNT] = {};
+  float* goal_draw_dev = nullptr;            // [2] the goal of the current post-physics reset (bez_walk / bez_orient)
+  unsigned long long* post_calls_dev = nullptr;  // device-resident call counter keying that draw (HIP-graph replay safe)
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   unsigned long long* stamps = nullptr;  // diagnostic builds only
 };
@@ -90,6 +92,18 @@ void goal_draw(uint64_t seed, uint64_t counter, uint32_t kind, float out[2]) {
   for (int k = 0; k < 2; ++k) out[k] = std::fmaf(4.0f, (float)(c[k] >> 8) * (1.0f / 16777216.0f), -2.0f);
 }
 
+// device twin of goal_draw(seed, counter, 0, out) with the counter in device memory: one thread, launched in front of every step
+// that contains the post-physics of bez_walk / bez_orient.  A captured HIP graph replays kernel arguments verbatim, so a goal
+// passed by value would repeat the captured horizon's 32 goals forever; the counter here advances on every replay.
+__global__ void goal_draw_kernel(uint64_t seed, unsigned long long* counter, float* out) {
+  const unsigned long long cnt = *counter;
+  uint32_t c[4] = {(uint32_t)cnt, (uint32_t)(cnt >> 32), 0x474f414cu, 0u};
+  bez::philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+  out[0] = fmaf(4.0f, (float)(c[0] >> 8) * (1.0f / 16777216.0f), -2.0f);
+  out[1] = fmaf(4.0f, (float)(c[1] >> 8) * (1.0f / 16777216.0f), -2.0f);
+  *counter = cnt + 1;
+}
+
 Params make_params(const BezSim* s, const float* actions) {
   const BezSimConfig& c = s->cfg;
   Params P;
@@ -108,6 +122,7 @@ Params make_params(const BezSim* s, const float* actions) {
   for (int i = 0; i < 7; ++i) { P.bez_init[i] = c.bez_init[i]; P.ball_init[i] = c.ball_init[i]; }
   P.goal[0] = c.goal[0]; P.goal[1] = c.goal[1];
   P.kn = c.contact_kn; P.cn = c.contact_cn; P.ct = c.contact_ct; P.veps = c.contact_veps;
+  P.bkn = c.ball_kn > 0.f ? c.ball_kn : c.contact_kn; P.bcn = c.ball_cn > 0.f ? c.ball_cn : c.contact_cn;
   P.lim_k = c.limit_k; P.lim_d = c.limit_d; P.jf_veps = c.jfric_veps; P.ball_damp = c.ball_ang_damping;
   P.self_kn = c.self_kn; P.self_cn = c.self_cn;
   P.cf_w = (c.flags & BEZ_FLAG_CF_LAST_SUBSTEP) ? 1.0f : 1.0f / (float)c.substeps;
@@ -274,13 +289,13 @@ __global__ void set_target_indexed_kernel(float* __restrict__ st, const float* _
 }
 
 // Kernel choice for launches that include the physics, fixed per sim at bez_sim_create from BEZ_SIM_KERNEL: unset / "ws8" = the
-// 8-role-wave kernel (bez_kernel_ws8.h, the production path), "ws4" = its 4-role-wave predecessor (bez_kernel_ws.h), "lane" =
-// the one-env-per-lane reference kernel (bez_kernels.h).  The three are held against each other by tests/test_gpu_round2.py.
+// 8-role-wave kernel (bez_kernel_ws8.h, the production path), "lane" = the one-env-per-lane reference kernel (bez_kernels.h).
+// The two are held against each other by tests/test_gpu_round2.py.
 int kernel_from_env() {
   const char* v = std::getenv("BEZ_SIM_KERNEL");
   if (!v) return 0;
   const std::string k(v);
-  return k == "lane" ? 2 : (k == "ws4" || k == "ws") ? 1 : 0;
+  return k == "lane" ? 2 : 0;
 }
 
 // PMC calibration: dword-per-lane coalesced read of `n` floats (the access shape of the step kernels' state loads)
@@ -301,12 +316,15 @@ template <bool PRE, bool SIM, bool POST>
 int launch_step(BezSim* s, const float* actions, hipStream_t stream, bool obs_only = false) {
   Params P = make_params(s, actions);
   P.obs_only = obs_only ? 1 : 0;
-  if (POST && !obs_only) goal_draw(s->cfg.seed, s->post_calls++, 0, P.goal_draw);  // the reset inside this post_physics_step
+  if (POST && !obs_only && s->cfg.task != BEZ_TASK_KICK) {  // the reset inside this post_physics_step draws its goal on the device
+    goal_draw_kernel<<<1, 1, 0, stream>>>(s->cfg.seed, s->post_calls_dev, s->goal_draw_dev);
+    P.goal_dev = s->goal_draw_dev;
+    s->post_calls++;
+  }
   const bool dr = has_dr(s) || s->cleats;
   if constexpr (SIM && PRE == POST) {
     if (s->kernel != 2) {
-      if (s->kernel == 0) bez::launch_step_ws8(P, PRE, dr, s->cleats, stream);
-      else bez::launch_step_ws(P, PRE, dr, s->cleats, stream);
+      bez::launch_step_ws8(P, PRE, dr, s->cleats, stream);
       hipError_t e = hipGetLastError();
       if (e != hipSuccess) return fail(s, -2, "step_kernel_ws launch", e);
       if (POST) s->obs_calls += 1;
@@ -343,6 +361,7 @@ int bez_sim_default_config(BezSimConfig* c, int32_t num_envs) {
   c->contact_kn = 2.0e4f; c->contact_cn = 20.0f; c->contact_ct = 1.0e3f; c->contact_veps = 0.01f;
   c->limit_k = 200.0f; c->limit_d = 2.0f; c->jfric_veps = 0.1f; c->ball_ang_damping = 0.5f;
   c->self_kn = 3000.0f; c->self_cn = 5.0f;
+  c->ball_kn = 0.0f; c->ball_cn = 0.0f;
   c->flags = BEZ_FLAG_IMU_PREV_ALIAS;
   c->seed = 42;
   c->env_id_offset = 0;
@@ -355,7 +374,7 @@ int bez_sim_destroy(BezSim* s) {
   if (!s) return 0;
   (void)hipSetDevice(s->device);
   void* bufs[] = {s->state, s->obs, s->rew, s->reset, s->progress, s->timeout, s->episode, s->root_states, s->dof_state,
-                  s->rigid_body, s->contact, s->targets_aos, s->prev_aos, s->feet_aos, s->goal_aos};
+                  s->rigid_body, s->contact, s->targets_aos, s->prev_aos, s->feet_aos, s->goal_aos, s->goal_draw_dev, s->post_calls_dev};
   for (void* b : bufs) if (b) (void)hipFree(b);
   for (int i = 0; i < BEZ_PARAM_COUNT; ++i) if (s->dr[i]) (void)hipFree(s->dr[i]);
   if (s->ev0) (void)hipEventDestroy(s->ev0);
@@ -396,7 +415,8 @@ int bez_sim_create(const BezSimConfig* cfg, int device_id, BezSim** out) {
       {(void**)&s->root_states, n * 26 * sizeof(float)}, {(void**)&s->dof_state, n * BEZ_ND * 2 * sizeof(float)},
       {(void**)&s->rigid_body, n * BEZ_NBE_MAX * 13 * sizeof(float)}, {(void**)&s->contact, n * BEZ_NBE_MAX * 3 * sizeof(float)},
       {(void**)&s->targets_aos, n * BEZ_ND * sizeof(float)}, {(void**)&s->prev_aos, n * 3 * sizeof(float)},
-      {(void**)&s->feet_aos, n * 8 * sizeof(float)}, {(void**)&s->goal_aos, n * 2 * sizeof(float)}};
+      {(void**)&s->feet_aos, n * 8 * sizeof(float)}, {(void**)&s->goal_aos, n * 2 * sizeof(float)},
+      {(void**)&s->goal_draw_dev, 2 * sizeof(float)}, {(void**)&s->post_calls_dev, sizeof(unsigned long long)}};
   for (auto& a : allocs) {
     e = hipMalloc(a.p, a.bytes);
     if (e == hipSuccess) e = hipMemset(*a.p, 0, a.bytes);

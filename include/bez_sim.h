@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define BEZ_SIM_ABI_VERSION 3
+#define BEZ_SIM_ABI_VERSION 4
 
 #define BEZ_NUM_OBS 54       /* bez_kick; bez_walk / bez_orient: 52 (no ball tail)  walk_env.py:104 */
 #define BEZ_NUM_OBS_WALK 52
@@ -58,6 +58,9 @@ extern "C" {
 #define BEZ_FLAG_BOX_ASSET 32u /* asset.stl: False -> soccerbot_box.urdf / soccerbot_box_sensor.urdf (kick_env.py:266-276): the stl \
                                   asset's dynamics with the URDF's own torso / head / forearm collision boxes (upper-body ground \
                                   points, ball <-> torso box); with BEZ_FLAG_CLEATS also that URDF's right ankle joint origin */
+
+#define BEZ_FLAG_HARD_CONTACT 64u /* rigid contact: velocity-level impulses with Coulomb stiction and restitution 0 (projected Gauss-Seidel on \
+                                     the articulated-body impulse responses) instead of the implicit spring-dampers; knobs in `tune` */
 
 /* Tasks sharing the robot, the physics and the tensor API; they differ in the post-physics logic (observation tail,
  * reward, reset conditions, goal sampling) and in the ball actor (bez_kick only). */
@@ -94,7 +97,10 @@ typedef struct BezSimConfig {
   float ball_ang_damping; /* Isaac asset default angular_damping 0.5 [ext] for the ball actor */
   float self_kn;       /* leg<->leg self-collision (kick_env.py:365-366, filter 0): spring [N/m]   */
   float self_cn;       /*                                                     damper [N*s/m] */
-  float tune[8];       /* calibration knobs of the physics model; 0 = default behaviour */
+  float ball_kn;       /* ball <-> ground / ball <-> robot contact spring [N/m]; 0 = contact_kn */
+  float ball_cn;       /* and damper [N*s/m]; 0 = contact_cn.  PhysX restitution is 0 (bez_kick.yaml:16): critical damping of the 0.3 kg
+                          ball against contact_kn is 2 sqrt(kn m) = 155 N*s/m */
+  float tune[8];       /* knobs of the rigid-contact model (BEZ_FLAG_HARD_CONTACT; oracle/bez_oracle.c documents the slots); 0 = default */
   int32_t task;        /* BEZ_TASK_*: which env logic POST runs (tasks/__init__.py:10-16)                */
   float goal_angle;    /* bez_orient: env.goalState.goal_angle                       orient_env.py:61 */
   uint32_t flags;      /* BEZ_FLAG_* */

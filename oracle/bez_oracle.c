@@ -187,8 +187,8 @@ static M6 rb_inertia(real m, V3 c, const M3* Ic) {
     }
   return I;
 }
-/* solve A x = b for SPD 6x6 by Cholesky (A is destroyed) */
-static int chol6_solve(M6* A, SV* b, int nrhs) {
+/* Cholesky of an SPD 6x6 in place (lower triangle); chol6_subst solves with the factor */
+static int chol6_factor(M6* A) {
   for (int j = 0; j < 6; ++j) {
     real d = A->m[j][j];
     for (int k = 0; k < j; ++k) d -= A->m[j][k] * A->m[j][k];
@@ -201,11 +201,19 @@ static int chol6_solve(M6* A, SV* b, int nrhs) {
       A->m[i][j] = s / d;
     }
   }
+  return 0;
+}
+static void chol6_subst(const M6* A, SV* b, int nrhs) {
   for (int r = 0; r < nrhs; ++r) {
     real* x = b[r].v;
     for (int i = 0; i < 6; ++i) { real s = x[i]; for (int k = 0; k < i; ++k) s -= A->m[i][k] * x[k]; x[i] = s / A->m[i][i]; }
     for (int i = 5; i >= 0; --i) { real s = x[i]; for (int k = i + 1; k < 6; ++k) s -= A->m[k][i] * x[k]; x[i] = s / A->m[i][i]; }
   }
+}
+/* solve A x = b for SPD 6x6 by Cholesky (A is destroyed) */
+static int chol6_solve(M6* A, SV* b, int nrhs) {
+  if (chol6_factor(A)) return -1;
+  chol6_subst(A, b, nrhs);
   return 0;
 }
 /* general 3x3 inverse by cofactors */
@@ -305,12 +313,14 @@ typedef struct { int link, body; V3 x; real fn0, kn, ct, ftx0, fty0; } GroundHit
 
 /* Adds the implicit ground contact of a point at x (rel. O) on a body with velocity V (about O) whose
  * world height is z.  Returns 1 if active and fills hit.  IA/pA are the body's inertia and bias. */
-static int ground_contact(const BezSimConfig* c, real mu, real h, V3 x, real z, SV V, M6* IA, SV* pA, GroundHit* hit) {
+static real m_ball_kn(const BezSimConfig* c) { return c->ball_kn > 0 ? (real)c->ball_kn : (real)c->contact_kn; }
+static real m_ball_cn(const BezSimConfig* c) { return c->ball_cn > 0 ? (real)c->ball_cn : (real)c->contact_cn; }
+static int ground_contact(const BezSimConfig* c, real ckn, real ccn, real mu, real h, V3 x, real z, SV V, M6* IA, SV* pA, GroundHit* hit) {
   real d = -z;
   if (!(d > 0)) return 0;
   V3 vp = v3add(sv_lin(V), v3cross(sv_ang(V), x));
-  real kd = h * (real)c->contact_kn + (real)c->contact_cn;
-  real fn0 = (real)c->contact_kn * d - kd * vp.v[2];
+  real kd = h * ckn + ccn;
+  real fn0 = ckn * d - kd * vp.v[2];
   if (!(fn0 > 0)) return 0;
   real kn = h * kd;
   SV wn = wrench_at(x, v3(0, 0, 1));
@@ -385,40 +395,33 @@ static void self_collision(const BezSimConfig* c, real mu, const Kin* k, const S
   }
 }
 
-/* One evaluation of the build's dynamics model for one env at substep size h.
- * `mode` 0 = full model; 1 = bare ABA (no PD / friction / limits / contact / armature: used by the
- * known-answer tests, with tau_in as the applied joint torques). */
-static void dynamics(const BezSimConfig* c, const Env* e, real h, int mode, const real* tau_in, Dyn* out) {
-  Kin k;
-  forward_kinematics(c, e, &k);
-  const int nb = m_nb(c); /* row of the ball */
+/* pass 1 of the ABA: kinematics, link velocities, bias accelerations, rigid-body inertias and bias forces (gravity included) */
+typedef struct { Kin k; SV V[NL], S[NL], cb[NL], pA[NL]; M6 IA[NL]; } Pass1;
+static void aba_pass1(const BezSimConfig* c, const Env* e, Pass1* P) {
+  Kin* k = &P->k;
+  SV *V = P->V, *S = P->S, *cb = P->cb, *pA = P->pA;
+  M6* IA = P->IA;
+  forward_kinematics(c, e, k);
   V3 g = v3(e->gravity[0], e->gravity[1], e->gravity[2]);
-  SV V[NL], S[NL], cb[NL], pA[NL];
-  SV pS[NL]; /* explicit leg<->leg contact wrenches, propagated next to pA: the drive-saturation predictor below does not see them */
-  M6 IA[NL];
-  memset(pS, 0, sizeof(pS));
-  memset(out->contact_force, 0, sizeof(out->contact_force));
-
-  /* pass 1: velocities, bias accelerations, rigid-body inertias and bias forces */
   V[0] = sv(v3(e->root_ang[0], e->root_ang[1], e->root_ang[2]), v3(e->root_lin[0], e->root_lin[1], e->root_lin[2]));
   memset(&S[0], 0, sizeof(SV));
   memset(&cb[0], 0, sizeof(SV));
   for (int l = 0; l < NL; ++l) {
     if (l > 0) {
       int p = BEZ_LINK_PARENT[l];
-      S[l] = sv(k.a[l], v3cross(k.r[l], k.a[l]));
+      S[l] = sv(k->a[l], v3cross(k->r[l], k->a[l]));
       SV vj = sv_scale(S[l], e->qd[l - 1]);
       V[l] = sv_add(V[p], vj);
       cb[l] = crm(V[l], vj);
     }
     real m = m_mass(c, l) * e->mass_scale[l];
     V3 cl = v3((real)m_com(c, l)[0], (real)m_com(c, l)[1], (real)m_com(c, l)[2]);
-    V3 cw = v3add(k.r[l], m3mulv(&k.E[l], cl));
+    V3 cw = v3add(k->r[l], m3mulv(&k->E[l], cl));
     const double* il = m_inertia(c, l);
     M3 Il = {{{(real)il[0], (real)il[3], (real)il[4]}, {(real)il[3], (real)il[1], (real)il[5]}, {(real)il[4], (real)il[5], (real)il[2]}}};
     for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) Il.m[i][j] *= e->mass_scale[l];
-    M3 ET = m3T(&k.E[l]);
-    M3 tmp = m3mul(&k.E[l], &Il);
+    M3 ET = m3T(&k->E[l]);
+    M3 tmp = m3mul(&k->E[l], &Il);
     M3 Iw = m3mul(&tmp, &ET);
     IA[l] = rb_inertia(m, cw, &Iw);
     SV hmom = m6mulv(&IA[l], V[l]);
@@ -426,6 +429,22 @@ static void dynamics(const BezSimConfig* c, const Env* e, real h, int mode, cons
     SV fg = wrench_at(cw, v3scale(g, m));
     pA[l] = sv_add(pA[l], sv_scale(fg, -1));
   }
+}
+
+/* One evaluation of the build's dynamics model for one env at substep size h.
+ * `mode` 0 = full model; 1 = bare ABA (no PD / friction / limits / contact / armature: used by the
+ * known-answer tests, with tau_in as the applied joint torques). */
+static void dynamics(const BezSimConfig* c, const Env* e, real h, int mode, const real* tau_in, Dyn* out) {
+  Pass1 P1;
+  aba_pass1(c, e, &P1);
+  const Kin k = P1.k;
+  const int nb = m_nb(c); /* row of the ball */
+  V3 g = v3(e->gravity[0], e->gravity[1], e->gravity[2]);
+  SV *V = P1.V, *S = P1.S, *cb = P1.cb, *pA = P1.pA;
+  SV pS[NL]; /* explicit leg<->leg contact wrenches, propagated next to pA: the drive-saturation predictor below does not see them */
+  M6* IA = P1.IA;
+  memset(pS, 0, sizeof(pS));
+  memset(out->contact_force, 0, sizeof(out->contact_force));
 
   /* contacts (implicit spring-dampers folded into IA / pA) */
   GroundHit hits[BEZ_NPT];
@@ -443,7 +462,7 @@ static void dynamics(const BezSimConfig* c, const Env* e, real h, int mode, cons
       V3 pl = v3((real)m_pt_pos(c, i)[0], (real)m_pt_pos(c, i)[1], (real)m_pt_pos(c, i)[2]);
       V3 x = v3add(k.r[l], m3mulv(&k.E[l], pl));
       real z = e->root_pos[2] + x.v[2];
-      if (ground_contact(c, mu, h, x, z, V[l], &IA[l], &pA[l], &hits[nhit])) { hits[nhit].link = l; hits[nhit].body = m_pt_body(c, i); ++nhit; }
+      if (ground_contact(c, (real)c->contact_kn, (real)c->contact_cn, mu, h, x, z, V[l], &IA[l], &pA[l], &hits[nhit])) { hits[nhit].link = l; hits[nhit].body = m_pt_body(c, i); ++nhit; }
     }
     if (!(c->flags & BEZ_FLAG_NO_SELF_COLLISION)) {
       self_collision(c, mu, &k, V, pS, out->contact_force, (c->flags & BEZ_FLAG_CF_WITH_FRICTION) != 0);
@@ -453,7 +472,7 @@ static void dynamics(const BezSimConfig* c, const Env* e, real h, int mode, cons
     for (int i = 0; i < 3; ++i) { Mb.m[i][i] = Ib; Mb.m[i + 3][i + 3] = mb; }
     pb = sv(v3(0, 0, 0), v3scale(g, -mb));
     SV Vb = sv(v3(e->ball_ang[0], e->ball_ang[1], e->ball_ang[2]), v3(e->ball_lin[0], e->ball_lin[1], e->ball_lin[2]));
-    ball_ground = ground_contact(c, mu, h, v3(0, 0, -R), e->ball_pos[2] - R, Vb, &Mb, &pb, &bhit);
+    ball_ground = ground_contact(c, m_ball_kn(c), m_ball_cn(c), mu, h, v3(0, 0, -R), e->ball_pos[2] - R, Vb, &Mb, &pb, &bhit);
     /* ball vs leg boxes: deepest penetration only */
     real best = 0;
     V3 bc = v3(e->ball_pos[0] - e->root_pos[0], e->ball_pos[1] - e->root_pos[1], e->ball_pos[2] - e->root_pos[2]); /* rel. O */
@@ -495,8 +514,8 @@ static void dynamics(const BezSimConfig* c, const Env* e, real h, int mode, cons
       V3 x = bP, xb = v3sub(bP, bc);
       V3 u = v3sub(v3add(sv_lin(V[l]), v3cross(sv_ang(V[l]), x)), v3add(sv_lin(Vb), v3cross(sv_ang(Vb), xb)));
       real un = v3dot(u, bn);
-      real kd = h * (real)c->contact_kn + (real)c->contact_cn;
-      real fmag = (real)c->contact_kn * best + kd * un;
+      real kd = h * m_ball_kn(c) + m_ball_cn(c);
+      real fmag = m_ball_kn(c) * best + kd * un;
       if (fmag > 0) {
         V3 ut = v3sub(u, v3scale(bn, un));
         real vt = sqrt(v3dot(ut, ut));
@@ -635,6 +654,316 @@ static void dynamics(const BezSimConfig* c, const Env* e, real h, int mode, cons
   }
 }
 
+/* ================================================================== rigid contact (BEZ_FLAG_HARD_CONTACT)
+ * Velocity-level contact with Coulomb stiction and restitution 0, as the reference configures PhysX (plane static = dynamic
+ * friction 1, restitution 0: bez_kick.yaml:13-16, kick_env.py:250-256; rest_offset 0, contact_offset 0.02, max depenetration
+ * velocity: bez_kick.yaml:139-144).  PhysX's TGS solver itself is a closed binary; this is the textbook formulation it
+ * belongs to (SURVEY.md 7 "Contact"): contact impulses p at points, solved by projected Gauss-Seidel on the Delassus matrix
+ * W = J M~^-1 J^T whose columns are the articulated-body impulse responses (Featherstone, RBDA 11.2 style) of the SAME factorisation the forward dynamics used
+ * -- M~ contains the implicit drive / limit / joint-friction terms, so the drives react to a contact impulse inside the step.
+ * The drive's effort limit is then re-checked against the torque the solved step implies, and the step is repeated with
+ * the corrected saturation set (active-set iteration; PhysX clamps the drive impulse inside its iterations).
+ *   knobs (BezSimConfig.tune, 0 = default): [0] PGS sweeps (16)  [1] penetration ERP (0.2)  [2] detection margin m (0.01)
+ *   [3] max depenetration speed m/s (1)  [4] constraint-force mixing (1e-6)  [5] effort active-set passes (3)  [6] contact-normal compliance */
+#define HC_MAXC 48
+#define HC_BALL NL   /* body index of the ball; -1 = the world */
+typedef struct {
+  int a, b;        /* bodies: link index, HC_BALL, or -1 (world, b only).  The impulse +p acts on a, -p on b */
+  V3 xa, xb;       /* contact point relative to the body's reference point (O for links, the centre for the ball) */
+  V3 d[3];         /* normal (from b towards a), two tangents */
+  real phi, mu;    /* signed distance (negative: penetration), friction coefficient */
+  int row_a, row_b;/* rows of the net-contact-force tensor (-1: none) */
+  real p[3];
+} HContact;
+
+static V3 point_vel(SV V, V3 x) { return v3add(sv_lin(V), v3cross(sv_ang(V), x)); }
+
+typedef struct { SV S[NL], U[NL]; real Dinv[NL]; M6 L0; int lock[NL]; /* joint rate prescribed (speed limit active): rigid for impulses */ } AbaFactor;
+/* velocity response of every link to impulsive wrenches Pin[l] (about O): dV[l], and the joint-rate part dqd */
+static void impulse_response(const AbaFactor* F, const SV* Pin, SV* dV, real* dqd) {
+  SV pI[NL]; real u[NL];
+  for (int l = 0; l < NL; ++l) pI[l] = sv_scale(Pin[l], -1);
+  for (int l = NL - 1; l >= 1; --l) {
+    int p = BEZ_LINK_PARENT[l];
+    if (F->lock[l]) { u[l] = 0; pI[p] = sv_add(pI[p], pI[l]); continue; }
+    u[l] = -sv_dot(F->S[l], pI[l]);
+    pI[p] = sv_add(pI[p], sv_add(pI[l], sv_scale(F->U[l], u[l] * F->Dinv[l])));
+  }
+  dV[0] = sv_scale(pI[0], -1);
+  chol6_subst(&F->L0, &dV[0], 1);
+  for (int l = 1; l < NL; ++l) {
+    int p = BEZ_LINK_PARENT[l];
+    real r = F->lock[l] ? 0 : (u[l] - sv_dot(F->U[l], dV[p])) * F->Dinv[l];
+    if (dqd) dqd[l - 1] = r;
+    dV[l] = sv_add(dV[p], sv_scale(F->S[l], r));
+  }
+}
+
+static void tangent_basis(V3 n, V3* t1, V3* t2) {
+  V3 a = fabs(n.v[0]) < (real)0.7 ? v3(1, 0, 0) : v3(0, 1, 0);
+  V3 t = v3sub(a, v3scale(n, v3dot(a, n)));
+  *t1 = v3scale(t, 1 / sqrt(v3dot(t, t)));
+  *t2 = v3cross(n, *t1);
+}
+
+typedef struct {
+  SV a0; real qdd[ND];                 /* contact-free accelerations */
+  SV dV0; real dqd[ND];                /* velocity change by the contact impulses */
+  V3 ball_lin_acc, ball_dlin, ball_dang;
+  real contact_force[NBMAX][3];
+} DynH;
+
+static real hc_knob(const BezSimConfig* c, int i, real dflt) { return c->tune[i] != 0 ? (real)c->tune[i] : dflt; }
+
+static void dynamics_hard(const BezSimConfig* c, const Env* e, real h, DynH* out) {
+  Pass1 P1;
+  aba_pass1(c, e, &P1);
+  const Kin* k = &P1.k;
+  const int nb = m_nb(c);
+  const SV* V = P1.V; const SV* cb = P1.cb;
+  const real mu = e->friction;
+  const real margin = hc_knob(c, 2, (real)0.01), erp = hc_knob(c, 1, (real)0.2), vdepen = hc_knob(c, 3, (real)1.0);
+  const real cfm = hc_knob(c, 4, (real)1e-6);
+  const int sweeps = (int)hc_knob(c, 0, 16), npass = (int)hc_knob(c, 5, 3);
+  const real R = (real)BEZ_BALL_RADIUS, mb = (real)BEZ_BALL_MASS, Ib = (real)BEZ_BALL_INERTIA;
+  const real ro_r = (real)c->tune[6], ro_b = 2 * (real)c->tune[6]; /* EXPERIMENT: shape rest offsets (asset thickness) */
+  V3 g = v3(e->gravity[0], e->gravity[1], e->gravity[2]);
+  memset(out, 0, sizeof(*out));
+
+  /* explicit leg <-> leg penalty contact, as in the compliant model */
+  SV pS[NL]; memset(pS, 0, sizeof(pS));
+  if (!(c->flags & BEZ_FLAG_NO_SELF_COLLISION))
+    self_collision(c, mu, k, V, pS, out->contact_force, (c->flags & BEZ_FLAG_CF_WITH_FRICTION) != 0);
+
+  /* ---- contact detection */
+  HContact C[HC_MAXC]; int nc = 0;
+  for (int i = 0; i < BEZ_NPT; ++i) { /* ground points of the feet / cleats and of the upper body */
+    int l = BEZ_PT_LINK[i];
+    V3 pl = v3((real)m_pt_pos(c, i)[0], (real)m_pt_pos(c, i)[1], (real)m_pt_pos(c, i)[2]);
+    V3 x = v3add(k->r[l], m3mulv(&k->E[l], pl));
+    real z = e->root_pos[2] + x.v[2] - ro_r;
+    if (!(z < margin)) continue;
+    HContact* q = &C[nc++];
+    q->a = l; q->b = -1; q->xa = x; q->xb = v3(0, 0, 0); q->d[0] = v3(0, 0, 1); q->phi = z; q->mu = mu; q->row_a = m_pt_body(c, i); q->row_b = -1;
+  }
+  V3 bc = v3(e->ball_pos[0] - e->root_pos[0], e->ball_pos[1] - e->root_pos[1], e->ball_pos[2] - e->root_pos[2]); /* ball centre rel. O */
+  if (m_has_ball(c)) {
+    if (e->ball_pos[2] - R - ro_b < margin) {
+      HContact* q = &C[nc++];
+      q->a = HC_BALL; q->b = -1; q->xa = v3(0, 0, -R); q->xb = v3(0, 0, 0); q->d[0] = v3(0, 0, 1); q->phi = e->ball_pos[2] - R - ro_b; q->mu = mu; q->row_a = nb; q->row_b = -1;
+    }
+    /* ball vs the leg boxes and the torso box: every box within the margin is a contact */
+    for (int b = 0; b < BEZ_NBOX && nc < HC_MAXC; ++b) {
+      int l = BEZ_BOX_LINK[b];
+      V3 cl = v3((real)m_box_center(c, b)[0], (real)m_box_center(c, b)[1], (real)m_box_center(c, b)[2]);
+      V3 he = v3((real)m_box_half(c, b)[0], (real)m_box_half(c, b)[1], (real)m_box_half(c, b)[2]);
+      V3 ql = v3sub(m3Tmulv(&k->E[l], v3sub(bc, k->r[l])), cl);
+      V3 cp; int inside = 1;
+      for (int i = 0; i < 3; ++i) {
+        real t = ql.v[i];
+        if (t > he.v[i]) { t = he.v[i]; inside = 0; }
+        if (t < -he.v[i]) { t = -he.v[i]; inside = 0; }
+        cp.v[i] = t;
+      }
+      V3 nl; real depth;
+      if (!inside) {
+        V3 dlt = v3sub(ql, cp);
+        real dist = sqrt(v3dot(dlt, dlt));
+        depth = R + ro_r + ro_b - dist;
+        if (!(depth > -margin)) continue;
+        nl = v3scale(dlt, 1 / dist);
+      } else {
+        int ax = 0; real md = he.v[0] - fabs(ql.v[0]);
+        for (int i = 1; i < 3; ++i) { real di = he.v[i] - fabs(ql.v[i]); if (di < md) { md = di; ax = i; } }
+        nl = v3(0, 0, 0); nl.v[ax] = ql.v[ax] >= 0 ? 1 : -1;
+        cp = ql; cp.v[ax] = nl.v[ax] * he.v[ax];
+        depth = R + ro_r + ro_b + md;
+      }
+      V3 bP = v3add(k->r[l], m3mulv(&k->E[l], v3add(cp, cl)));
+      HContact* q = &C[nc++];
+      q->a = HC_BALL; q->b = l; q->xa = v3sub(bP, bc); q->xb = bP; q->d[0] = m3mulv(&k->E[l], nl); q->phi = -depth; q->mu = mu;
+      q->row_a = nb; q->row_b = m_link_body(c, l);
+    }
+  }
+  for (int i = 0; i < nc; ++i) { tangent_basis(C[i].d[0], &C[i].d[1], &C[i].d[2]); C[i].p[0] = C[i].p[1] = C[i].p[2] = 0; }
+
+  /* ---- drive terms per joint (implicit PD, joint friction, limit spring), and the first saturation guess */
+  real tau_pd0[ND], k_pd[ND], tau_o[ND], k_o[ND];
+  int sat[ND];
+  for (int d = 0; d < ND; ++d) {
+    real kp = (real)c->kp * e->kp_scale[d], kdm = (real)c->kd * e->kd_scale[d];
+    tau_pd0[d] = kp * (e->target[d] - e->q[d] - h * e->qd[d]) - kdm * e->qd[d];
+    k_pd[d] = h * h * kp + h * kdm;
+    real cf = (real)c->joint_friction / fmax(fabs(e->qd[d]), (real)c->jfric_veps);
+    real k_l = 0, tau_l0 = 0;
+    real lo = e->lim_lo[d], hi = e->lim_hi[d];
+    if (e->q[d] < lo) { tau_l0 = (real)c->limit_k * (lo - e->q[d] - h * e->qd[d]) - (real)c->limit_d * e->qd[d]; k_l = h * h * (real)c->limit_k + h * (real)c->limit_d; }
+    else if (e->q[d] > hi) { tau_l0 = (real)c->limit_k * (hi - e->q[d] - h * e->qd[d]) - (real)c->limit_d * e->qd[d]; k_l = h * h * (real)c->limit_k + h * (real)c->limit_d; }
+    tau_o[d] = -cf * e->qd[d] + tau_l0;
+    k_o[d] = h * cf + k_l;
+    sat[d] = 2; /* 2 = not decided yet: pass 0 uses the held-parent predictor of the compliant model */
+  }
+
+  AbaFactor F;
+  memcpy(F.S, P1.S, sizeof(F.S));
+  memset(F.lock, 0, sizeof(F.lock));
+  real qdd_fix[ND]; /* prescribed joint acceleration of a speed-limited joint */
+  const int consistent_vlim = c->tune[7] == 1; /* [7] != 0: the joint speed limit is a constraint (prescribed-rate joint), not a post-hoc clamp */
+  for (int pass = 0; pass < npass; ++pass) {
+    /* pass 2 */
+    M6 IA[NL]; SV pA[NL], pSl[NL]; real u[NL];
+    memcpy(IA, P1.IA, sizeof(IA)); memcpy(pA, P1.pA, sizeof(pA)); memcpy(pSl, pS, sizeof(pSl));
+    for (int l = NL - 1; l >= 1; --l) {
+      int p = BEZ_LINK_PARENT[l], d = l - 1;
+      F.U[l] = m6mulv(&IA[l], F.S[l]);
+      if (F.lock[l]) { /* hybrid dynamics: known joint acceleration, the articulated inertia passes through unprojected */
+        SV pa = sv_add(pA[l], m6mulv(&IA[l], sv_add(cb[l], sv_scale(F.S[l], qdd_fix[d]))));
+        for (int i = 0; i < 6; ++i) for (int j = 0; j < 6; ++j) IA[p].m[i][j] += IA[l].m[i][j];
+        pA[p] = sv_add(pA[p], pa);
+        pSl[p] = sv_add(pSl[p], pSl[l]);
+        F.Dinv[l] = 0; u[l] = 0;
+        if (sat[d] == 2) sat[d] = 0;
+        continue;
+      }
+      real J = sv_dot(F.S[l], F.U[l]) + (real)c->armature;
+      if (sat[d] == 2) {
+        real bias = sv_dot(F.S[l], pA[l]) + sv_dot(F.U[l], cb[l]);
+        real qdd_est = (tau_pd0[d] + tau_o[d] - bias) / (J + k_pd[d] + k_o[d]);
+        real tau_drive = tau_pd0[d] - k_pd[d] * qdd_est;
+        sat[d] = tau_drive > (real)c->effort ? 1 : (tau_drive < -(real)c->effort ? -1 : 0);
+      }
+      real tau, D;
+      if (sat[d] != 0) { tau = sat[d] * (real)c->effort + tau_o[d]; D = J + k_o[d]; }
+      else { tau = tau_pd0[d] + tau_o[d]; D = J + k_pd[d] + k_o[d]; }
+      F.Dinv[l] = 1 / D;
+      real u_main = tau - sv_dot(F.S[l], pA[l]), du = -sv_dot(F.S[l], pSl[l]);
+      u[l] = u_main + du;
+      M6 Ia = IA[l];
+      for (int i = 0; i < 6; ++i) for (int j = 0; j < 6; ++j) Ia.m[i][j] -= F.U[l].v[i] * F.U[l].v[j] * F.Dinv[l];
+      SV pa = sv_add(pA[l], sv_add(m6mulv(&Ia, cb[l]), sv_scale(F.U[l], u_main * F.Dinv[l])));
+      for (int i = 0; i < 6; ++i) for (int j = 0; j < 6; ++j) IA[p].m[i][j] += Ia.m[i][j];
+      pA[p] = sv_add(pA[p], pa);
+      pSl[p] = sv_add(pSl[p], sv_add(pSl[l], sv_scale(F.U[l], du * F.Dinv[l])));
+    }
+    F.L0 = IA[0];
+    chol6_factor(&F.L0);
+    SV a0 = sv_scale(sv_add(pA[0], pSl[0]), -1);
+    chol6_subst(&F.L0, &a0, 1);
+    out->a0 = a0;
+    /* pass 3 */
+    SV acc[NL];
+    acc[0] = a0;
+    for (int l = 1; l < NL; ++l) {
+      int p = BEZ_LINK_PARENT[l];
+      SV ap = sv_add(acc[p], cb[l]);
+      real qdd = F.lock[l] ? qdd_fix[l - 1] : (u[l] - sv_dot(F.U[l], ap)) * F.Dinv[l];
+      out->qdd[l - 1] = qdd;
+      acc[l] = sv_add(ap, sv_scale(F.S[l], qdd));
+    }
+    out->ball_lin_acc = g;
+    memset(&out->dV0, 0, sizeof(SV)); memset(out->dqd, 0, sizeof(out->dqd));
+    out->ball_dlin = out->ball_dang = v3(0, 0, 0);
+
+    if (nc > 0) {
+      /* contact-free end-of-step velocities */
+      SV Vf[NL + 1];
+      for (int l = 0; l < NL; ++l) Vf[l] = sv_add(V[l], sv_scale(acc[l], h));
+      Vf[HC_BALL] = sv(v3(e->ball_ang[0], e->ball_ang[1], e->ball_ang[2]),
+                       v3(e->ball_lin[0] + h * g.v[0], e->ball_lin[1] + h * g.v[1], e->ball_lin[2] + h * g.v[2]));
+      static const SV SV0 = {{0, 0, 0, 0, 0, 0}};
+      const int m3n = 3 * nc;
+      real W[3 * HC_MAXC][3 * HC_MAXC], bf[3 * HC_MAXC];
+      for (int i = 0; i < nc; ++i) for (int kx = 0; kx < 3; ++kx) {
+        const HContact* ci = &C[i];
+        V3 dir = ci->d[kx];
+        SV Pin[NL], dV[NL + 1];
+        for (int l = 0; l < NL; ++l) Pin[l] = SV0;
+        dV[HC_BALL] = SV0;
+        int tree = 0;
+        if (ci->a == HC_BALL) dV[HC_BALL] = sv(v3scale(v3cross(ci->xa, dir), 1 / Ib), v3scale(dir, 1 / mb));
+        else { Pin[ci->a] = sv_add(Pin[ci->a], wrench_at(ci->xa, dir)); tree = 1; }
+        if (ci->b >= 0) { Pin[ci->b] = sv_add(Pin[ci->b], sv_scale(wrench_at(ci->xb, dir), -1)); tree = 1; }
+        if (tree) impulse_response(&F, Pin, dV, NULL); else for (int l = 0; l < NL; ++l) dV[l] = SV0;
+        for (int j = 0; j < nc; ++j) {
+          const HContact* cj = &C[j];
+          V3 du = point_vel(dV[cj->a], cj->xa);
+          if (cj->b >= 0) du = v3sub(du, point_vel(dV[cj->b], cj->xb));
+          for (int mx = 0; mx < 3; ++mx) W[3 * j + mx][3 * i + kx] = v3dot(cj->d[mx], du);
+        }
+      }
+      for (int j = 0; j < nc; ++j) {
+        const HContact* cj = &C[j];
+        V3 uf = point_vel(Vf[cj->a], cj->xa);
+        if (cj->b >= 0) uf = v3sub(uf, point_vel(Vf[cj->b], cj->xb));
+        for (int mx = 0; mx < 3; ++mx) bf[3 * j + mx] = v3dot(cj->d[mx], uf);
+        /* restitution 0; penetration is pushed out with ERP (capped), a gap may close within the step */
+        real vt = cj->phi < 0 ? fmin(-erp * cj->phi / h, vdepen) : -cj->phi / h;
+        bf[3 * j] -= vt;
+      }
+      real pv[3 * HC_MAXC];
+      for (int i = 0; i < nc; ++i) for (int kx = 0; kx < 3; ++kx) pv[3 * i + kx] = C[i].p[kx]; /* warm start from the previous pass */
+      for (int it = 0; it < sweeps; ++it) {
+        for (int i = 0; i < nc; ++i) {
+          int r0 = 3 * i;
+          real un = bf[r0];
+          for (int j = 0; j < m3n; ++j) un += W[r0][j] * pv[j];
+          real pn = pv[r0] - un / (W[r0][r0] + cfm);
+          if (pn < 0) pn = 0;
+          pv[r0] = pn;
+          for (int kx = 1; kx < 3; ++kx) {
+            int r = r0 + kx;
+            real ut = bf[r];
+            for (int j = 0; j < m3n; ++j) ut += W[r][j] * pv[j];
+            pv[r] -= ut / (W[r][r] + cfm);
+          }
+          real lim = C[i].mu * pn, pt = sqrt(pv[r0 + 1] * pv[r0 + 1] + pv[r0 + 2] * pv[r0 + 2]);
+          if (pt > lim) { real sc = pt > 0 ? lim / pt : 0; pv[r0 + 1] *= sc; pv[r0 + 2] *= sc; }
+        }
+      }
+      for (int i = 0; i < nc; ++i) for (int kx = 0; kx < 3; ++kx) C[i].p[kx] = pv[3 * i + kx];
+      /* apply the impulses */
+      SV Pin[NL], dV[NL];
+      for (int l = 0; l < NL; ++l) Pin[l] = SV0;
+      V3 bl = v3(0, 0, 0), ba = v3(0, 0, 0);
+      for (int i = 0; i < nc; ++i) {
+        const HContact* ci = &C[i];
+        V3 imp = v3add(v3scale(ci->d[0], ci->p[0]), v3add(v3scale(ci->d[1], ci->p[1]), v3scale(ci->d[2], ci->p[2])));
+        if (ci->a == HC_BALL) { bl = v3add(bl, v3scale(imp, 1 / mb)); ba = v3add(ba, v3scale(v3cross(ci->xa, imp), 1 / Ib)); }
+        else Pin[ci->a] = sv_add(Pin[ci->a], wrench_at(ci->xa, imp));
+        if (ci->b >= 0) Pin[ci->b] = sv_add(Pin[ci->b], sv_scale(wrench_at(ci->xb, imp), -1));
+      }
+      impulse_response(&F, Pin, dV, out->dqd);
+      out->dV0 = dV[0];
+      out->ball_dlin = bl; out->ball_dang = ba;
+    }
+    /* effort limit against the torque the solved step implies */
+    int changed = 0;
+    for (int d = 0; d < ND; ++d) {
+      if (F.lock[d + 1]) continue;
+      if (consistent_vlim) {
+        real vn = e->qd[d] + h * out->qdd[d] + out->dqd[d];
+        if (fabs(vn) > (real)c->vel_limit) { F.lock[d + 1] = 1; qdd_fix[d] = ((vn > 0 ? (real)c->vel_limit : -(real)c->vel_limit) - e->qd[d]) / h; changed = 1; continue; }
+      }
+      real qdd_tot = out->qdd[d] + out->dqd[d] / h;
+      real tau_u = tau_pd0[d] - k_pd[d] * qdd_tot; /* what the unsaturated implicit PD would apply at this acceleration */
+      int ns = tau_u > (real)c->effort ? 1 : (tau_u < -(real)c->effort ? -1 : 0);
+      if (ns != sat[d]) { sat[d] = ns; changed = 1; }
+    }
+    if (!changed) break;
+  }
+  /* net contact force rows: normal parts (BEZ_FLAG_CF_WITH_FRICTION: whole impulse), as forces over the substep */
+  const int with_fric = (c->flags & BEZ_FLAG_CF_WITH_FRICTION) != 0;
+  for (int i = 0; i < nc; ++i) {
+    const HContact* ci = &C[i];
+    V3 imp = v3scale(ci->d[0], ci->p[0]);
+    if (with_fric) imp = v3add(imp, v3add(v3scale(ci->d[1], ci->p[1]), v3scale(ci->d[2], ci->p[2])));
+    for (int a = 0; a < 3; ++a) {
+      if (ci->row_a >= 0) out->contact_force[ci->row_a][a] += imp.v[a] / h;
+      if (ci->row_b >= 0) out->contact_force[ci->row_b][a] -= imp.v[a] / h;
+    }
+  }
+}
+
 static void quat_integrate(real q[4], const real w[3], real h) {
   /* q <- normalize(q + h/2 * (w,0) (x) q), xyzw, world-frame angular velocity */
   real x = q[0], y = q[1], z = q[2], s = q[3];
@@ -648,7 +977,41 @@ static void quat_integrate(real q[4], const real w[3], real h) {
   q[0] = x * n; q[1] = y * n; q[2] = z * n; q[3] = s * n;
 }
 
+static void substep_hard(const BezSimConfig* c, Env* e, real h, int first, real wgt) {
+  DynH d;
+  const int pre_clamp = c->tune[7] == 2; /* EXPERIMENT: speed limit applied to the incoming joint rates only */
+  if (pre_clamp) for (int j = 0; j < ND; ++j) { real vl = (real)c->vel_limit; if (e->qd[j] > vl) e->qd[j] = vl; if (e->qd[j] < -vl) e->qd[j] = -vl; }
+  dynamics_hard(c, e, h, &d);
+  for (int j = 0; j < ND; ++j) {
+    real v = e->qd[j] + h * d.qdd[j] + d.dqd[j];
+    real vl = pre_clamp ? (real)1e9 : (real)c->vel_limit;
+    if (v > vl) v = vl;
+    if (v < -vl) v = -vl;
+    e->qd[j] = v;
+    e->q[j] += h * v;
+  }
+  V3 w = v3(e->root_ang[0], e->root_ang[1], e->root_ang[2]), v = v3(e->root_lin[0], e->root_lin[1], e->root_lin[2]);
+  V3 vdot = v3add(sv_lin(d.a0), v3cross(w, v));
+  V3 wdot = sv_ang(d.a0);
+  for (int i = 0; i < 3; ++i) {
+    e->root_ang[i] += h * wdot.v[i] + d.dV0.v[i];
+    e->root_lin[i] += h * vdot.v[i] + d.dV0.v[3 + i];
+    e->root_pos[i] += h * e->root_lin[i];
+  }
+  quat_integrate(e->root_quat, e->root_ang, h);
+  real damp = 1 - h * (real)c->ball_ang_damping;
+  if (damp < 0) damp = 0;
+  for (int i = 0; i < 3; ++i) {
+    e->ball_lin[i] += h * d.ball_lin_acc.v[i] + d.ball_dlin.v[i];
+    e->ball_ang[i] = (e->ball_ang[i] + d.ball_dang.v[i]) * damp;
+    e->ball_pos[i] += h * e->ball_lin[i];
+  }
+  quat_integrate(e->ball_quat, e->ball_ang, h);
+  for (int b = 0; b < NBMAX; ++b) for (int i = 0; i < 3; ++i) e->contact_force[b][i] = first ? d.contact_force[b][i] * wgt : e->contact_force[b][i] + d.contact_force[b][i] * wgt;
+}
+
 static void substep(const BezSimConfig* c, Env* e, real h, int first, real wgt) {
+  if (c->flags & BEZ_FLAG_HARD_CONTACT) { substep_hard(c, e, h, first, wgt); return; }
   Dyn d;
   dynamics(c, e, h, 0, NULL, &d);
   /* joints: semi-implicit Euler + velocity clamp (kick_env.py:327 velocity limit) */

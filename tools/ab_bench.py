@@ -9,7 +9,7 @@ import torch
 from bez_isaacgym_amd import abi
 N, STEPS, ROUNDS = 4096, 1500, 4
 libs = []
-for spec in sys.argv[1:]:  # build_ab/x.so or build_ab/x.so:ws4 (BEZ_SIM_KERNEL for that sim)
+for spec in sys.argv[1:]:  # build_ab/x.so or build_ab/x.so:lane (BEZ_SIM_KERNEL for that sim)
     path, _, kern = spec.partition(":")
     os.environ.pop("BEZ_SIM_KERNEL", None)
     if kern: os.environ["BEZ_SIM_KERNEL"] = kern

@@ -6,9 +6,10 @@ import numpy as np
 from tests.sim_adapter import SimAdapter
 from tests.test_tasks import make_cfg
 n = 200
-for variant in ("kick", "kick_cleats", "walk"):
-    for other in ("ws4", "lane"):
-        kw = dict(seed=31, task="bez_walk" if variant == "walk" else "bez_kick", cleats=(variant == "kick_cleats"))
+for variant in ("kick", "kick_cleats", "walk", "orient", "orient_cleats"):
+    for other in ("lane",):
+        task = "bez_walk" if variant.startswith("walk") else ("bez_orient" if variant.startswith("orient") else "bez_kick")
+        kw = dict(seed=31, task=task, cleats=variant.endswith("_cleats"))
         os.environ.pop("BEZ_SIM_KERNEL", None)
         a = SimAdapter(make_cfg(n, **kw))
         os.environ["BEZ_SIM_KERNEL"] = other
@@ -21,7 +22,7 @@ for variant in ("kick", "kick_cleats", "walk"):
         for t in range(40):
             b.set_root_states(a.root_states); b.set_dof_state(a.dof_state); b.set_contact_forces(a.contact_forces)
             b.set_targets(a.targets); b.set_reset(a.reset_buf); b.set_progress(a.progress_buf); b.set_prev_lin_vel(a.prev_lin_vel)
-            if variant == "walk": b.set_goal(a.goal)
+            if task != "bez_kick": b.set_goal(a.goal)
             act = rng.uniform(-1, 1, (n, 18)).astype(np.float32)
             a.step(act); b.step(act)
             ra, rb = a.root_states, b.root_states

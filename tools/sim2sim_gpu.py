@@ -54,6 +54,7 @@ def evaluate(player, overrides=None, n=4096, steps=900, seed=1, flags=None, devi
     ret = torch.zeros(n, device=dev); length = torch.zeros(n, device=dev)
     acc = dict(episodes=0, ret=0.0, len=0.0, goal=0, timeout=0, fall=0, oob=0, angle=0, goal_len=0.0)
     osum = torch.zeros(54, device=dev, dtype=torch.float64); osq = torch.zeros(54, device=dev, dtype=torch.float64); ocount = 0
+    miss_y, miss_v = [], []  # where / how fast the ball passes the goal line when an episode ends by the goal-angle test
     for t in range(steps):
         a = player.get_action(obs)
         if collect_obs:
@@ -74,12 +75,19 @@ def evaluate(player, overrides=None, n=4096, steps=900, seed=1, flags=None, devi
             acc["goal"] += int(goal.sum()); acc["timeout"] += int(tmo.sum()); acc["fall"] += int(fall.sum()); acc["oob"] += int(oob.sum())
             acc["angle"] += int(d.numel()) - int(goal.sum() + tmo.sum() + fall.sum() + oob.sum())
             acc["goal_len"] += float(length[d][goal].sum())
+            ang = (~goal) & (~tmo) & (~fall) & (~oob)
+            if bool(ang.any()):
+                miss_y.append(root[d, 1, 1][ang].cpu()); miss_v.append(torch.linalg.norm(root[d, 1, 7:9][ang], dim=1).cpu())
             ret[d] = 0; length[d] = 0
     torch.cuda.synchronize()
     e = max(acc["episodes"], 1)
     out = dict(episodes=acc["episodes"], goal_rate=acc["goal"] / e, mean_return=acc["ret"] / e, mean_length=acc["len"] / e,
                goal_length=acc["goal_len"] / max(acc["goal"], 1),
                reasons={k: acc[k] for k in ("goal", "fall", "oob", "angle", "timeout")})
+    if miss_y:
+        my, mv = torch.cat(miss_y).abs().numpy(), torch.cat(miss_v).numpy()
+        out["angle_miss_abs_y_m"] = {"p10": float(np.percentile(my, 10)), "p50": float(np.percentile(my, 50)), "p90": float(np.percentile(my, 90))}
+        out["angle_miss_ball_speed"] = {"p10": float(np.percentile(mv, 10)), "p50": float(np.percentile(mv, 50)), "p90": float(np.percentile(mv, 90))}
     if collect_obs:
         ck = player.checkpoint["running_mean_std"]
         rm, rv = np.asarray(ck["running_mean"], np.float64), np.asarray(ck["running_var"], np.float64)
