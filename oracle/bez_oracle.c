@@ -663,7 +663,7 @@ static void dynamics(const BezSimConfig* c, const Env* e, real h, int mode, cons
  * -- M~ contains the implicit drive / limit / joint-friction terms, so the drives react to a contact impulse inside the step.
  * The drive's effort limit is then re-checked against the torque the solved step implies, and the step is repeated with
  * the corrected saturation set (active-set iteration; PhysX clamps the drive impulse inside its iterations).
- *   knobs (BezSimConfig.tune, 0 = default): [0] PGS sweeps (16)  [1] penetration ERP (0.2)  [2] detection margin m (0.01)
+ *   knobs (BezSimConfig.tune, 0 = default): [0] PGS sweeps (16)  [1] penetration ERP (0.2)  [2] detection margin m (0.02 = physx.contact_offset, bez_kick.yaml:139)
  *   [3] max depenetration speed m/s (1)  [4] constraint-force mixing (1e-6)  [5] effort active-set passes (3)  [6] contact-normal compliance */
 #define HC_MAXC 48
 #define HC_BALL NL   /* body index of the ball; -1 = the world */
@@ -722,7 +722,7 @@ static void dynamics_hard(const BezSimConfig* c, const Env* e, real h, DynH* out
   const int nb = m_nb(c);
   const SV* V = P1.V; const SV* cb = P1.cb;
   const real mu = e->friction;
-  const real margin = hc_knob(c, 2, (real)0.01), erp = hc_knob(c, 1, (real)0.2), vdepen = hc_knob(c, 3, (real)1.0);
+  const real margin = hc_knob(c, 2, (real)0.02), erp = hc_knob(c, 1, (real)0.2), vdepen = hc_knob(c, 3, (real)1.0);
   const real cfm = hc_knob(c, 4, (real)1e-6);
   const int sweeps = (int)hc_knob(c, 0, 16), npass = (int)hc_knob(c, 5, 3);
   const real R = (real)BEZ_BALL_RADIUS, mb = (real)BEZ_BALL_MASS, Ib = (real)BEZ_BALL_INERTIA;

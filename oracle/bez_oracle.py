@@ -15,10 +15,15 @@ sys.path.insert(0, os.path.dirname(_HERE))
 from bez_isaacgym_amd.abi import BezSimConfig, default_config, NUM_OBS, NUM_DOFS, NUM_BODIES  # noqa: E402
 
 
-def build(force=False):
-    """Compile libbez_oracle_{f64,f32}.so with gcc (the recipe is oracle/Makefile)."""
-    args = ["make", "-C", _HERE] + (["-B"] if force else [])
+def build(force=False, target=None):
+    """Compile libbez_oracle_{f64,f32}.so with gcc (the recipe is oracle/Makefile); target "asan" = the sanitizer build."""
+    args = ["make", "-C", _HERE] + (["-B"] if force else []) + ([target] if target else [])
     subprocess.run(args, check=True, stdout=subprocess.DEVNULL)
+
+
+# BEZ_ORACLE_VARIANT=asan: load libbez_oracle_*_asan.so (gcc -fsanitize=address,undefined; the process needs libasan preloaded,
+# tests/test_oracle_sanitizers.py re-runs the golden and known-answer suites that way)
+_VARIANT = os.environ.get("BEZ_ORACLE_VARIANT", "")
 
 
 _LIBS = {}
@@ -26,9 +31,9 @@ _LIBS = {}
 
 def _lib(precision):
     if precision not in _LIBS:
-        path = os.path.join(_HERE, "libbez_oracle_%s.so" % precision)
+        path = os.path.join(_HERE, "libbez_oracle_%s%s.so" % (precision, "_" + _VARIANT if _VARIANT else ""))
         if not os.path.exists(path):
-            build()
+            build(target=_VARIANT or None)
         lib = C.CDLL(path)
         lib.bez_oracle_create.restype = C.c_void_p
         lib.bez_oracle_create.argtypes = [C.POINTER(BezSimConfig)]

@@ -45,16 +45,23 @@ def test_rigid_body_refresh_matches_oracle():
     np.testing.assert_allclose(rg[:, 1, 0:7], g.root_states.reshape(n, 2, 13)[:, 0, 0:7], atol=1e-6)
 
 
-def test_ws_kernel_post_physics_pinned_against_lane_kernel():
+@pytest.mark.parametrize("task", ["bez_kick", "bez_walk", "bez_orient"])
+@pytest.mark.parametrize("asset", ["default", "cleats", "box"])
+def test_ws_kernel_post_physics_pinned_against_lane_kernel(task, asset):
     """The golden vectors run through the lane kernel's PRE/POST entry points; the production kernel has its own POST
-    (per-role obs slots, partial pose-error sums, root bookkeeping).  After a fused step, recompute observations and reward
-    with the LANE kernel's obs-only pass on the very same resulting state: obs[0:36] must equal the dof state exactly,
-    obs[36:54] and the reward to 1e-6, the reset flags exactly."""
+    (per-role obs slots, partial pose-error sums, root bookkeeping, the task select of walk_env.py:826-1050 /
+    orient_env.py:719-735,843-1018, the cleat flags of kick_env.py:1044-1069).  After a fused step, recompute observations and
+    reward with the LANE kernel's obs-only pass on the very same resulting state -- for every task x asset: obs[0:36] must equal
+    the dof state exactly, the remaining slots and the reward to 1e-6 of their scale, reset flags and feet flags exactly."""
     from tests.sim_adapter import SimAdapter
+    from tests.test_tasks import make_cfg
     n = 448
-    a, b = SimAdapter(abi.default_config(n, seed=23)), SimAdapter(abi.default_config(n, seed=23))
+    kw = dict(task=task, cleats=(asset == "cleats"), box=(asset == "box"), seed=23)
+    a, b = SimAdapter(make_cfg(n, **kw)), SimAdapter(make_cfg(n, **kw))
+    nobs = a.nobs
     rng = np.random.default_rng(12)
     a.set_obs_calls(1)  # past the process's first compute_imu call (quirk Q1): prev_lin_vel aliases the live velocity
+    resets = 0
     for t in range(30):
         act = rng.uniform(-1, 1, (n, 18)).astype(np.float32)
         a.step(act)
@@ -63,14 +70,17 @@ def test_ws_kernel_post_physics_pinned_against_lane_kernel():
         np.testing.assert_array_equal(obs[:, 0:18], ds[:, :, 0])
         np.testing.assert_array_equal(obs[:, 18:36], ds[:, :, 1])
         b.set_root_states(a.root_states); b.set_dof_state(a.dof_state); b.set_contact_forces(a.contact_forces)
+        if task != "bez_kick": b.set_goal(a.goal)
         b.set_progress(a.progress_buf); b.set_reset(np.zeros(n, np.int64)); b.set_obs_calls(1)
         b.observe_reward()
-        np.testing.assert_allclose(b.obs[:, 36:54], obs[:, 36:54], atol=1e-6)
+        np.testing.assert_allclose(b.obs[:, 36:nobs], obs[:, 36:nobs], atol=1e-6)
         np.testing.assert_array_equal(b.obs[:, 0:36], obs[:, 0:36])
-        np.testing.assert_allclose(b.rew, a.rew, atol=1e-6)
+        rew_a, rew_b = a.rew, b.rew
+        np.testing.assert_allclose(rew_b, rew_a, atol=1e-6, rtol=1e-6)   # relative to its scale: walk / orient terminal rewards reach 1000
         np.testing.assert_array_equal(b.reset_buf, a.reset_buf)
         np.testing.assert_array_equal(b.feet, a.feet)
-    assert a.reset_buf.sum() + (a.progress_buf < 30).sum() > 0  # resets really happened inside the window
+        resets += int(a.reset_buf.sum())
+    assert resets + (a.progress_buf < 30).sum() > 0  # resets really happened inside the window
 
 
 @pytest.mark.parametrize("other", ["lane"])

@@ -203,32 +203,44 @@ def test_hip_box_asset_rest_height(): check_box_asset_rest_height(hip)
 def test_hip_variant_step_parity(task, cleats, box):
     """The whole fused step of every variant against the oracle, resynchronised each step (same bars as bez_kick).  The box-asset
     cases start from fallen poses too (half the envs lie on their back): their upper-body contact points are what differs."""
+    from oracle.bez_oracle import Oracle
     n = 128
     o, g = oracle(n, task=task, cleats=cleats, box=box, seed=7), hip(n, task=task, cleats=cleats, box=box, seed=7)
+    o32 = Oracle(make_cfg(n, task=task, cleats=cleats, box=box, seed=7), precision="f32")  # what plain fp32 rounding costs on the same step
     np.testing.assert_array_equal(o.dof_state, g.dof_state)
     if task != "bez_kick":
         np.testing.assert_array_equal(o.goal, g.goal)
     if box:
         _lie_on_back(o, n, n // 2)   # the other half keeps the reset state of the other variants
     rng = np.random.default_rng(3)
+    worst = {"hip": {}, "cpu32": {}}
+
+    def close(name, got, ref, got32, atol, rtol=0.0):
+        """Common absolute bar -- OR, where a fast joint event exceeds it (round 2 found one: box + cleats, a knee at -5.04 rad/s,
+        HIP - oracle = 2.0e-2 rad/s), the oracle's own fp32 build must deviate from the fp64 oracle on that very element by at least
+        40 % as much: the excess is then fp32 rounding of the model, not the kernel."""
+        got, ref, got32 = (np.asarray(x, np.float64) for x in (got, ref, got32))
+        err, err32 = np.abs(got - ref), np.abs(got32 - ref)
+        worst["hip"][name] = max(worst["hip"].get(name, 0.0), float(err.max())); worst["cpu32"][name] = max(worst["cpu32"].get(name, 0.0), float(err32.max()))
+        bad = err > atol + rtol * np.abs(ref)
+        assert not np.any(bad & (err > 2.5 * err32)), (name, t, float(err[bad].max()), float(err32[bad].max()), np.argwhere(bad)[:4])
+
     for t in range(25):
-        g.set_root_states(o.root_states); g.set_dof_state(o.dof_state); g.set_contact_forces(o.contact_forces)
-        g.set_targets(o.targets); g.set_reset(o.reset_buf); g.set_progress(o.progress_buf)
+        for x in (g, o32):
+            x.set_root_states(o.root_states); x.set_dof_state(o.dof_state); x.set_contact_forces(o.contact_forces)
+            x.set_targets(o.targets); x.set_reset(o.reset_buf); x.set_progress(o.progress_buf)
         act = rng.uniform(-1, 1, (n, 18)).astype(np.float32)
-        o.step(act); g.step(act)
+        o.step(act); g.step(act); o32.step(act)
         np.testing.assert_array_equal(g.reset_buf, o.reset_buf)
         np.testing.assert_array_equal(g.progress_buf, o.progress_buf)
-        do, dg = o.dof_state.reshape(n, 18, 2), g.dof_state.reshape(n, 18, 2)
-        # box cases: a relative term on top of the common bars.  Their trajectories visit one fast joint event the other variants do
-        # not (box + cleats, step 19, a standing env: knee at -5.04 rad/s, HIP - oracle = 2.0e-2 rad/s = 0.4 %, 1.7e-4 rad on the angle)
-        br = 5e-3 if box else 0.0
-        np.testing.assert_allclose(dg[..., 0], do[..., 0], atol=1.5e-4, rtol=br * 0.04)
-        np.testing.assert_allclose(dg[..., 1], do[..., 1], atol=1.5e-2, rtol=br)
-        ro, rg = o.root_states.reshape(n, o.nact, 13), g.root_states.reshape(n, o.nact, 13)
-        np.testing.assert_allclose(rg[..., 0:7], ro[..., 0:7], atol=5e-5)
-        np.testing.assert_allclose(rg[..., 7:13], ro[..., 7:13], atol=6e-3)
+        do, dg, d32 = o.dof_state.reshape(n, 18, 2), g.dof_state.reshape(n, 18, 2), o32.dof_state.reshape(n, 18, 2)
+        close("q", dg[..., 0], do[..., 0], d32[..., 0], 1.5e-4)
+        close("qd", dg[..., 1], do[..., 1], d32[..., 1], 1.5e-2)
+        ro, rg, r32 = (x.root_states.reshape(n, o.nact, 13) for x in (o, g, o32))
+        close("root_pose", rg[..., 0:7], ro[..., 0:7], r32[..., 0:7], 5e-5)
+        close("root_vel", rg[..., 7:13], ro[..., 7:13], r32[..., 7:13], 6e-3)
         np.testing.assert_allclose(g.contact_forces, o.contact_forces, rtol=0.02, atol=0.05)
-        np.testing.assert_allclose(g.obs[:, :44], o.obs[:, :44], atol=2e-2, rtol=br)
+        close("obs", g.obs[:, :44], o.obs[:, :44], o32.obs[:, :44], 2e-2)
         np.testing.assert_allclose(g.rew, o.rew, atol=0.2 if task == "bez_walk" else 2e-3, rtol=1e-3)  # bez_walk: 10 * forward speed
         if task != "bez_kick":
             np.testing.assert_array_equal(g.goal, o.goal)
@@ -236,6 +248,9 @@ def test_hip_variant_step_parity(task, cleats, box):
             fo = np.linalg.norm(o.contact_forces.reshape(n, o.nbe, 3)[:, list(range(13, 17)) + list(range(25, 29))], axis=2)
             safe = (np.abs(fo - 1.0) > 0.1).all(axis=1)
             np.testing.assert_array_equal(g.obs[safe, 44:52], o.obs[safe, 44:52])
+    # over the whole window the kernel's worst error stays within 2.5x that of the fp32 oracle (a numerics regression shows here first)
+    for k in worst["hip"]:
+        assert worst["hip"][k] <= 2.5 * worst["cpu32"][k] + 1e-6, (k, worst)
     rb_o, rb_g = o.rigid_body_states, g.rigid_body_states
     assert rb_o.shape == rb_g.shape == (n * o.nbe, 13)
     g.set_root_states(o.root_states); g.set_dof_state(o.dof_state)
