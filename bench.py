@@ -116,7 +116,7 @@ def ppo_leg(args, rank, local_rank, world, n):
     from bez_isaacgym_amd.ppo.a2c_continuous import A2CAgent
     from bez_isaacgym_amd.utils.config import load_config
     from bez_isaacgym_amd.utils.rlgames_utils import RLGPUEnv, get_rlgames_env_creator
-    cfg = load_config(["task=bez_kick", "num_envs=%d" % n, "headless=True"])
+    cfg = load_config(["task=bez_kick", "num_envs=%d" % n, "headless=True"] + (["task.task.randomize=True"] if args.randomize else []))
     task = cfg["task"]
     task["seed"] = 42
     dev = "cuda:%d" % local_rank
@@ -148,6 +148,7 @@ def ppo_leg(args, rank, local_rank, world, n):
     return {"metric": "PPO samples/s (rollout + update)", "value": samples / dt, "unit": "samples/s", "epochs": args.ppo_epochs,
             "samples_per_epoch": agent.batch_size * world, "epoch_ms": dt / args.ppo_epochs * 1e3,
             "rollout_share": play / dt, "dtype": "fp16 autocast (AMP, as bez_kickPPO.yaml mixed_precision) + f32 sim",
+            "randomize": bool(args.randomize), "hip_graphs": bool(agent.use_graphs),
             "minibatch": agent.minibatch_size, "mini_epochs": agent.mini_epochs}
 
 
@@ -192,6 +193,8 @@ def main():
                     "'PPO samples/s' half of BASELINE.json's metric (0 = skip)")
     ap.add_argument("--launch", choices=["python", "c"], default="python",
                     help="python: one bez_sim_step call per step from Python; c: bez_sim_step_many (C loop)")
+    ap.add_argument("--randomize", action="store_true", help="PPO leg with task.randomize=True (BASELINE.json configs[4]: domain-randomised "
+                    "friction / gains / limits / gravity + observation and action noise, redrawn on the device at reset time)")
     ap.add_argument("--stub-cpu", action="store_true", help="launcher self-test: gloo on the CPU, the env step replaced by a no-op "
                     "(tests/test_bench_launcher.py); prints the same JSON skeleton with metric 'stub'")
     args = ap.parse_args()

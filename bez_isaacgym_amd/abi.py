@@ -27,7 +27,7 @@ TASK_IDS = {"bez_kick": TASK_KICK, "bez_walk": TASK_WALK, "bez_orient": TASK_ORI
 
 (TENSOR_ROOT_STATE, TENSOR_DOF_STATE, TENSOR_RIGID_BODY_STATE, TENSOR_NET_CONTACT_FORCE, TENSOR_OBS,
  TENSOR_REW, TENSOR_RESET, TENSOR_PROGRESS, TENSOR_TIMEOUT, TENSOR_DOF_TARGET, TENSOR_PREV_LIN_VEL,
- TENSOR_FEET, TENSOR_GOAL, TENSOR_COUNT) = range(14)
+ TENSOR_FEET, TENSOR_GOAL, TENSOR_RANDOMIZE_BUF, TENSOR_DR_NOISE, TENSOR_COUNT) = range(16)
 DTYPE_F32, DTYPE_I64 = 0, 1
 (PARAM_FRICTION, PARAM_KP_SCALE, PARAM_KD_SCALE, PARAM_MASS_SCALE, PARAM_GRAVITY, PARAM_DOF_LOWER, PARAM_DOF_UPPER,
  PARAM_COUNT) = range(8)
@@ -80,6 +80,50 @@ class BezSimConfig(C.Structure):
             v = getattr(self, name)
             out[name] = list(v) if hasattr(v, "__len__") else v
         return out
+
+
+class BezDrRange(C.Structure):
+    _fields_ = [("a", C.c_float), ("b", C.c_float), ("enabled", C.c_int32), ("schedule_steps", C.c_int32)]
+
+
+class BezDrConfig(C.Structure):
+    """device-side domain randomisation (include/bez_sim.h); one BezDrRange per entry of bez_kick.yaml:151-219"""
+    _fields_ = [("frequency", C.c_int32), ("friction_buckets", C.c_int32), ("friction", BezDrRange), ("stiffness", BezDrRange),
+                ("damping", BezDrRange), ("lower", BezDrRange), ("upper", BezDrRange), ("gravity", BezDrRange),
+                ("observations", BezDrRange), ("actions", BezDrRange)]
+
+
+def dr_config_from_params(dr_params):
+    """randomization_params of cfg/task/bez_kick.yaml:151-219 -> BezDrConfig.  Distribution / operation per parameter are the ones
+    that file uses; anything else is refused rather than silently reinterpreted."""
+    d = BezDrConfig()
+    d.frequency = int(dr_params.get("frequency", 1))
+
+    def put(dst, attr, dist, op):
+        if attr is None:
+            return
+        if attr.get("distribution") != dist or attr.get("operation") != op:
+            raise ValueError("domain randomisation: %s must be %s / %s as in bez_kick.yaml (got %s / %s)" % (dst, dist, op, attr.get("distribution"), attr.get("operation")))
+        r = getattr(d, dst)
+        r.a, r.b = float(attr["range"][0]), float(attr["range"][1])
+        r.enabled = 1
+        sch = attr.get("schedule")
+        if sch not in (None, "linear"):
+            raise ValueError("domain randomisation: only `schedule: linear` is supported (%s)" % dst)
+        r.schedule_steps = int(attr["schedule_steps"]) if sch == "linear" else 0
+    put("observations", dr_params.get("observations"), "gaussian", "additive")
+    put("actions", dr_params.get("actions"), "gaussian", "additive")
+    put("gravity", (dr_params.get("sim_params") or {}).get("gravity"), "gaussian", "additive")
+    ap = ((dr_params.get("actor_params") or {}).get("bez") or {})
+    fr = (ap.get("rigid_shape_properties") or {}).get("friction")
+    put("friction", fr, "uniform", "scaling")
+    d.friction_buckets = int((fr or {}).get("num_buckets", 0) or 0)
+    dp = ap.get("dof_properties") or {}
+    put("stiffness", dp.get("stiffness"), "uniform", "scaling")
+    put("damping", dp.get("damping"), "uniform", "scaling")
+    put("lower", dp.get("lower"), "gaussian", "additive")
+    put("upper", dp.get("upper"), "gaussian", "additive")
+    return d
 
 
 # Contact / limit model constants of this build (no reference counterpart; DESIGN.md "Physics model")

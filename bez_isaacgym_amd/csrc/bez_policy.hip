@@ -377,7 +377,9 @@ __device__ __forceinline__ void backward_stage(const BackwardArgs& a, _Float16 (
 // LD0 / LD1: row strides of the two LDS tiles.  Tile 0 holds the (64, 32) head-gradient tile and d/d h_L for L = nhid-2, nhid-4, ...;
 // tile 1 holds d/d h_L for L = nhid-1, nhid-3, ...  (216, 424) = 80 KB: two workgroups per CU for 54-400-200-100.
 template <int LD0, int LD1, bool PK>
-__global__ __launch_bounds__(PF_WAVES * 64, 4) void policy_backward_kernel(BackwardArgs a) {  // 4 waves per SIMD = two workgroups per CU: <= 128 VGPRs
+// 4 waves per SIMD = two workgroups per CU (<= 128 VGPRs) only where the two tiles fit twice into the CU's LDS: the (424, 424)
+// fallback for wider networks holds 106 KB and runs one workgroup per CU, so it does not ask for an occupancy it cannot have
+__global__ __launch_bounds__(PF_WAVES * 64, ((LD0 + LD1) * PF_ROWS * 2 <= 80 * 1024) ? 4 : 2) void policy_backward_kernel(BackwardArgs a) {
   __shared__ __attribute__((aligned(16))) _Float16 t0[PF_ROWS][LD0];
   __shared__ __attribute__((aligned(16))) _Float16 t1[PF_ROWS][LD1];
   constexpr int NT = PF_WAVES * 64;

@@ -26,6 +26,8 @@ struct DevBuf {
 
 }  // namespace
 
+struct DrState { unsigned long long frame, last_rand; float noise[4]; };
+
 struct BezSim {
   BezSimConfig cfg;
   int device = 0;
@@ -54,6 +56,11 @@ struct BezSim {
   float* feet_aos = nullptr;     // (N,8)
   float* goal_aos = nullptr;     // (N,2)
   float* dr[BEZ_PARAM_COUNT] = {};
+  // device-side domain randomisation (bez_sim_set_randomization)
+  bool dr_on = false;
+  BezDrConfig drc = {};
+  int64_t* randomize = nullptr;   // (N) randomize_buf, vec_task.py:247
+  struct DrState* dr_state = nullptr;  // device: frame counter, frame of the last non-env randomisation, noise parameters
   float* goal_draw_dev = nullptr;            // [2] the goal of the current post-physics reset (bez_walk / bez_orient)
   unsigned long long* post_calls_dev = nullptr;  // device-resident call counter keying that draw (HIP-graph replay safe)
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -102,6 +109,121 @@ __global__ void goal_draw_kernel(uint64_t seed, unsigned long long* counter, flo
   out[0] = fmaf(4.0f, (float)(c[0] >> 8) * (1.0f / 16777216.0f), -2.0f);
   out[1] = fmaf(4.0f, (float)(c[1] >> 8) * (1.0f / 16777216.0f), -2.0f);
   *counter = cnt + 1;
+}
+
+// ---- device-side domain randomisation: what reset_idx's apply_randomizations call does (vec_task.py:505-725, kick_env.py:781-782),
+// for the whole batch, in ONE workgroup in front of the step kernel (so that "did any env reset" and the frame counter need no
+// grid-wide synchronisation): thread t looks after envs t, t + 1024, ...  The word map of an env's Philox draw, keyed by
+// (seed, global env id, episode): 0 friction; 1..18 stiffness; 19..36 damping; 37..72 lower limits (pairs, Box-Muller); 73..108 upper.
+struct DrArgs {
+  BezDrConfig c;
+  int n, first;
+  uint64_t seed;
+  int64_t env_off;
+  float plane_friction, gravity[3];
+  const int64_t* reset;
+  const uint32_t* episode;
+  int64_t* randomize;
+  DrState* st;
+  float *friction, *kp, *kd, *lower, *upper, *gravity_rows;
+};
+__device__ inline float dr_uniform(uint64_t seed, int64_t key, uint32_t key2, uint32_t tag, int k) {
+  uint32_t c[4] = {(uint32_t)key, (uint32_t)((uint64_t)key >> 32), key2, tag + (uint32_t)(k >> 2)};
+  bez::philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+  return (float)(c[k & 3] >> 8) * (1.0f / 16777216.0f);
+}
+__device__ inline float dr_sched(const BezDrRange& r, unsigned long long frame) {
+  if (r.schedule_steps <= 0) return 1.0f;
+  unsigned long long f = frame < (unsigned long long)r.schedule_steps ? frame : (unsigned long long)r.schedule_steps;
+  return (float)f / (float)r.schedule_steps;
+}
+__device__ inline float dr_scaling(const BezDrRange& r, float s, float u) {
+  float lo = fmaf(r.a, s, 1.0f - s), hi = fmaf(r.b, s, 1.0f - s);
+  return fmaf(u, hi - lo, lo);
+}
+__device__ inline float dr_normal(float u1, float u2) { return sqrtf(-2.0f * logf(1.0f - u1)) * cosf(6.2831853f * u2); }
+constexpr uint32_t DR_TAG_ENV = 0x44520000u, DR_TAG_GRAVITY = 0x47520000u;
+constexpr int DR_THREADS = 1024;
+
+__global__ void __launch_bounds__(DR_THREADS) dr_kernel(DrArgs A) {
+  const unsigned long long frame = A.first ? 0ull : A.st->frame + 1;   // gym.get_frame_count: this step's simulate has run
+  const unsigned long long last_rand = A.st->last_rand;
+  int any = 0;
+  for (int e = threadIdx.x; e < A.n; e += DR_THREADS) {
+    long long rb = A.first ? 0 : A.randomize[e] + 1;   // kick_env.py:430
+    bool draw = A.first != 0;
+    if (!A.first && A.reset[e] != 0) {
+      any = 1;
+      if (rb >= A.c.frequency) { draw = true; rb = 0; }   // vec_task.py:525-530
+    }
+    A.randomize[e] = rb;
+    if (!draw) continue;
+    const int64_t genv = A.env_off + e;
+    const uint32_t ep = A.episode[e];
+    if (A.c.friction.enabled) {
+      float u = dr_uniform(A.seed, genv, ep, DR_TAG_ENV, 0);
+      if (A.c.friction_buckets > 1) u = rintf(u * (float)(A.c.friction_buckets - 1)) / (float)(A.c.friction_buckets - 1);
+      A.friction[e] = A.plane_friction * dr_scaling(A.c.friction, dr_sched(A.c.friction, frame), u);
+    }
+    for (int j = 0; j < BEZ_ND; ++j) {
+      if (A.c.stiffness.enabled) A.kp[(size_t)e * BEZ_ND + j] = dr_scaling(A.c.stiffness, dr_sched(A.c.stiffness, frame), dr_uniform(A.seed, genv, ep, DR_TAG_ENV, 1 + j));
+      if (A.c.damping.enabled) A.kd[(size_t)e * BEZ_ND + j] = dr_scaling(A.c.damping, dr_sched(A.c.damping, frame), dr_uniform(A.seed, genv, ep, DR_TAG_ENV, 19 + j));
+      if (A.c.lower.enabled) {
+        float sc = dr_sched(A.c.lower, frame), z = dr_normal(dr_uniform(A.seed, genv, ep, DR_TAG_ENV, 37 + 2 * j), dr_uniform(A.seed, genv, ep, DR_TAG_ENV, 38 + 2 * j));
+        A.lower[(size_t)e * BEZ_ND + j] = (float)BEZ_DOF_LOWER[j] + fmaf(z, A.c.lower.b * sc, A.c.lower.a * sc);
+      }
+      if (A.c.upper.enabled) {
+        float sc = dr_sched(A.c.upper, frame), z = dr_normal(dr_uniform(A.seed, genv, ep, DR_TAG_ENV, 73 + 2 * j), dr_uniform(A.seed, genv, ep, DR_TAG_ENV, 74 + 2 * j));
+        A.upper[(size_t)e * BEZ_ND + j] = (float)BEZ_DOF_UPPER[j] + fmaf(z, A.c.upper.b * sc, A.c.upper.a * sc);
+      }
+    }
+  }
+  any = __syncthreads_or(any);   // also orders every thread's read of A.st before thread 0's update below
+  const bool nonenv = A.first || (any && frame - last_rand >= (unsigned long long)A.c.frequency);   // vec_task.py:524,532-533
+  if (nonenv && A.c.gravity.enabled) {   // one draw for the whole sim (sim_params, vec_task.py:620-632), keyed by the frame
+    float sc = dr_sched(A.c.gravity, frame), g[3];
+    for (int k = 0; k < 3; ++k) {
+      float z = dr_normal(dr_uniform(A.seed, (int64_t)frame, 0, DR_TAG_GRAVITY, 2 * k), dr_uniform(A.seed, (int64_t)frame, 0, DR_TAG_GRAVITY, 2 * k + 1));
+      g[k] = A.gravity[k] + fmaf(z, A.c.gravity.b * sc, A.c.gravity.a * sc);
+    }
+    for (int e = threadIdx.x; e < A.n; e += DR_THREADS) { A.gravity_rows[(size_t)e * 3] = g[0]; A.gravity_rows[(size_t)e * 3 + 1] = g[1]; A.gravity_rows[(size_t)e * 3 + 2] = g[2]; }
+  }
+  if (threadIdx.x == 0) {
+    if (nonenv) {
+      float so = dr_sched(A.c.observations, frame), sa = dr_sched(A.c.actions, frame);
+      A.st->noise[0] = A.c.observations.enabled ? A.c.observations.a * so : 0.0f; A.st->noise[1] = A.c.observations.enabled ? A.c.observations.b * so : 0.0f;
+      A.st->noise[2] = A.c.actions.enabled ? A.c.actions.a * sa : 0.0f; A.st->noise[3] = A.c.actions.enabled ? A.c.actions.b * sa : 0.0f;
+      A.st->last_rand = frame;
+    }
+    A.st->frame = frame;
+  }
+}
+
+// vec_task.py:544-618 noise lambdas: x += mean + std * N(0,1); 4 elements per thread from one Philox block (two Box-Muller pairs)
+__global__ void dr_noise_kernel(float* __restrict__ x, long long n, const DrState* __restrict__ st, int which, uint64_t seed, int64_t env_off) {
+  const long long i4 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i4 * 4 >= n) return;
+  const float mean = st->noise[2 * which], sd = st->noise[2 * which + 1];
+  const unsigned long long frame = st->frame;
+  const unsigned long long key = (unsigned long long)(env_off * 64 + i4);   // distinct per shard: 54 / 18 floats per env < 64 * 4
+  uint32_t c[4] = {(uint32_t)key, (uint32_t)(key >> 32), (uint32_t)frame, 0x4e4f4953u + (uint32_t)which + ((uint32_t)(frame >> 32) << 8)};
+  bez::philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+  float u[4];
+  for (int k = 0; k < 4; ++k) u[k] = (float)(c[k] >> 8) * (1.0f / 16777216.0f);
+  float r0 = sqrtf(-2.0f * logf(1.0f - u[0])), r1 = sqrtf(-2.0f * logf(1.0f - u[2]));
+  float z[4] = {r0 * cosf(6.2831853f * u[1]), r0 * sinf(6.2831853f * u[1]), r1 * cosf(6.2831853f * u[3]), r1 * sinf(6.2831853f * u[3])};
+  for (int k = 0; k < 4; ++k) if (i4 * 4 + k < n) x[i4 * 4 + k] += fmaf(z[k], sd, mean);
+}
+
+void launch_dr(BezSim* s, bool first, hipStream_t stream) {
+  DrArgs A;
+  A.c = s->drc; A.n = s->n; A.first = first ? 1 : 0; A.seed = s->cfg.seed; A.env_off = s->cfg.env_id_offset;
+  A.plane_friction = s->cfg.plane_friction;
+  for (int k = 0; k < 3; ++k) A.gravity[k] = s->cfg.gravity[k];
+  A.reset = s->reset; A.episode = s->episode; A.randomize = s->randomize; A.st = s->dr_state;
+  A.friction = s->dr[BEZ_PARAM_FRICTION]; A.kp = s->dr[BEZ_PARAM_KP_SCALE]; A.kd = s->dr[BEZ_PARAM_KD_SCALE];
+  A.lower = s->dr[BEZ_PARAM_DOF_LOWER]; A.upper = s->dr[BEZ_PARAM_DOF_UPPER]; A.gravity_rows = s->dr[BEZ_PARAM_GRAVITY];
+  dr_kernel<<<1, DR_THREADS, 0, stream>>>(A);
 }
 
 Params make_params(const BezSim* s, const float* actions) {
@@ -316,6 +438,7 @@ template <bool PRE, bool SIM, bool POST>
 int launch_step(BezSim* s, const float* actions, hipStream_t stream, bool obs_only = false) {
   Params P = make_params(s, actions);
   P.obs_only = obs_only ? 1 : 0;
+  if (POST && !obs_only && s->dr_on) launch_dr(s, false, stream);  // reset_idx's apply_randomizations (kick_env.py:781-782), on the device
   if (POST && !obs_only && s->cfg.task != BEZ_TASK_KICK) {  // the reset inside this post_physics_step draws its goal on the device
     goal_draw_kernel<<<1, 1, 0, stream>>>(s->cfg.seed, s->post_calls_dev, s->goal_draw_dev);
     P.goal_dev = s->goal_draw_dev;
@@ -374,7 +497,7 @@ int bez_sim_destroy(BezSim* s) {
   if (!s) return 0;
   (void)hipSetDevice(s->device);
   void* bufs[] = {s->state, s->obs, s->rew, s->reset, s->progress, s->timeout, s->episode, s->root_states, s->dof_state,
-                  s->rigid_body, s->contact, s->targets_aos, s->prev_aos, s->feet_aos, s->goal_aos, s->goal_draw_dev, s->post_calls_dev};
+                  s->rigid_body, s->contact, s->targets_aos, s->prev_aos, s->feet_aos, s->goal_aos, s->goal_draw_dev, s->post_calls_dev, s->randomize, s->dr_state};
   for (void* b : bufs) if (b) (void)hipFree(b);
   for (int i = 0; i < BEZ_PARAM_COUNT; ++i) if (s->dr[i]) (void)hipFree(s->dr[i]);
   if (s->ev0) (void)hipEventDestroy(s->ev0);
@@ -416,7 +539,8 @@ int bez_sim_create(const BezSimConfig* cfg, int device_id, BezSim** out) {
       {(void**)&s->rigid_body, n * BEZ_NBE_MAX * 13 * sizeof(float)}, {(void**)&s->contact, n * BEZ_NBE_MAX * 3 * sizeof(float)},
       {(void**)&s->targets_aos, n * BEZ_ND * sizeof(float)}, {(void**)&s->prev_aos, n * 3 * sizeof(float)},
       {(void**)&s->feet_aos, n * 8 * sizeof(float)}, {(void**)&s->goal_aos, n * 2 * sizeof(float)},
-      {(void**)&s->goal_draw_dev, 2 * sizeof(float)}, {(void**)&s->post_calls_dev, sizeof(unsigned long long)}};
+      {(void**)&s->goal_draw_dev, 2 * sizeof(float)}, {(void**)&s->post_calls_dev, sizeof(unsigned long long)},
+      {(void**)&s->randomize, n * sizeof(int64_t)}, {(void**)&s->dr_state, sizeof(DrState)}};
   for (auto& a : allocs) {
     e = hipMalloc(a.p, a.bytes);
     if (e == hipSuccess) e = hipMemset(*a.p, 0, a.bytes);
@@ -453,6 +577,8 @@ int bez_sim_get_tensor(BezSim* s, int which, void** dev_ptr, int64_t shape[3], i
     case BEZ_TENSOR_PREV_LIN_VEL: *dev_ptr = s->prev_aos; shape[0] = n; shape[1] = 3; *ndim = 2; break;
     case BEZ_TENSOR_FEET: *dev_ptr = s->feet_aos; shape[0] = n; shape[1] = 8; *ndim = 2; break;
     case BEZ_TENSOR_GOAL: *dev_ptr = s->goal_aos; shape[0] = n; shape[1] = 2; *ndim = 2; break;
+    case BEZ_TENSOR_RANDOMIZE_BUF: *dev_ptr = s->randomize; shape[0] = n; *ndim = 1; *dtype = BEZ_DTYPE_I64; break;
+    case BEZ_TENSOR_DR_NOISE: *dev_ptr = s->dr_state->noise; shape[0] = 4; *ndim = 1; break;
     default: return fail(s, -1, "bez_sim_get_tensor: unknown tensor id");
   }
   return 0;
@@ -601,6 +727,74 @@ int bez_sim_set_env_params(BezSim* s, int param, const float* values_dev, void* 
   size_t bytes = (size_t)s->n * width[param] * sizeof(float);
   if (!s->dr[param]) HIP_TRY(s, hipMalloc((void**)&s->dr[param], bytes));
   HIP_TRY(s, hipMemcpyAsync(s->dr[param], values_dev, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  return 0;
+}
+
+__global__ void fill_rows_kernel(float* out, const float* row, int width, size_t total) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < total) out[i] = row[i % width];
+}
+
+int bez_sim_get_env_params(BezSim* s, int param, float* out_dev, void* stream_) {
+  if (!s || !out_dev || param < 0 || param >= BEZ_PARAM_COUNT) return fail(s, -1, "bez_sim_get_env_params: bad argument");
+  static const int width[BEZ_PARAM_COUNT] = {1, BEZ_ND, BEZ_ND, BEZ_NL, 3, BEZ_ND, BEZ_ND};
+  hipStream_t stream = (hipStream_t)stream_;
+  const size_t total = (size_t)s->n * width[param];
+  if (s->dr[param]) { HIP_TRY(s, hipMemcpyAsync(out_dev, s->dr[param], total * sizeof(float), hipMemcpyDeviceToDevice, stream)); return 0; }
+  float row[BEZ_NL];
+  for (int k = 0; k < width[param]; ++k) {
+    switch (param) {
+      case BEZ_PARAM_FRICTION: row[k] = s->cfg.plane_friction; break;
+      case BEZ_PARAM_GRAVITY: row[k] = s->cfg.gravity[k]; break;
+      case BEZ_PARAM_DOF_LOWER: row[k] = (float)BEZ_DOF_LOWER[k]; break;
+      case BEZ_PARAM_DOF_UPPER: row[k] = (float)BEZ_DOF_UPPER[k]; break;
+      default: row[k] = 1.0f; break;
+    }
+  }
+  float* row_dev = nullptr;
+  HIP_TRY(s, hipMalloc((void**)&row_dev, sizeof(row)));
+  HIP_TRY(s, hipMemcpy(row_dev, row, sizeof(row), hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(fill_rows_kernel, dim3((unsigned)((total + TB - 1) / TB)), dim3(TB), 0, stream, out_dev, row_dev, width[param], total);
+  HIP_TRY(s, hipStreamSynchronize(stream));
+  (void)hipFree(row_dev);
+  return 0;
+}
+
+int bez_sim_add_dr_noise(BezSim* s, float* x_dev, int64_t n, int32_t which, void* stream_) {
+  if (!s || !x_dev || n < 0 || which < 0 || which > 1) return fail(s, -1, "bez_sim_add_dr_noise: bad argument");
+  if (n == 0) return 0;
+  const long long quads = (n + 3) / 4;
+  hipLaunchKernelGGL(dr_noise_kernel, dim3((unsigned)((quads + TB - 1) / TB)), dim3(TB), 0, (hipStream_t)stream_, x_dev, (long long)n, s->dr_state, (int)which,
+                     s->cfg.seed, s->cfg.env_id_offset);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(s, -2, "dr_noise_kernel launch", e);
+  return 0;
+}
+
+int bez_sim_set_randomization(BezSim* s, const BezDrConfig* dr, void* stream_) {
+  if (!s) return -1;
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!dr) { s->dr_on = false; return 0; }
+  if (dr->frequency < 1) return fail(s, -1, "bez_sim_set_randomization: frequency must be >= 1");
+  s->drc = *dr;
+  // the per-env arrays the kernel writes: created with the defaults (bez_sim_get_env_params fills them) where not set yet
+  const struct { int param; int on; } need[] = {{BEZ_PARAM_FRICTION, dr->friction.enabled}, {BEZ_PARAM_KP_SCALE, dr->stiffness.enabled},
+                                                {BEZ_PARAM_KD_SCALE, dr->damping.enabled}, {BEZ_PARAM_DOF_LOWER, dr->lower.enabled},
+                                                {BEZ_PARAM_DOF_UPPER, dr->upper.enabled}, {BEZ_PARAM_GRAVITY, dr->gravity.enabled}};
+  static const int width[BEZ_PARAM_COUNT] = {1, BEZ_ND, BEZ_ND, BEZ_NL, 3, BEZ_ND, BEZ_ND};
+  for (const auto& nd : need) {
+    if (!nd.on || s->dr[nd.param]) continue;
+    float* buf = nullptr;
+    HIP_TRY(s, hipMalloc((void**)&buf, (size_t)s->n * width[nd.param] * sizeof(float)));
+    int rc = bez_sim_get_env_params(s, nd.param, buf, stream_);
+    if (rc) { (void)hipFree(buf); return rc; }
+    s->dr[nd.param] = buf;
+  }
+  HIP_TRY(s, hipMemsetAsync(s->dr_state, 0, sizeof(DrState), stream));
+  s->dr_on = true;
+  launch_dr(s, true, stream);   // first_randomization (vec_task.py:521-523): every env, frame 0
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(s, -2, "dr_kernel launch", e);
   return 0;
 }
 

@@ -576,6 +576,7 @@ class A2CAgent:
             self._g_rollout = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self._g_rollout, pool=self._graph_pool()):
                 self._rollout_impl()
+            self._g_rollout.replay()  # capture only records: the epoch that captures still has to run its rollout
         else:
             self._g_rollout.replay()
         return self.dataset
@@ -914,6 +915,7 @@ class A2CAgent:
             self._g_update = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self._g_update, pool=self._graph_pool()):
                 self._update_impl()
+            self._g_update.replay()  # (same: the capturing epoch performs its update by replaying the fresh graph)
         else:
             self._g_update.replay()
 

@@ -51,6 +51,9 @@ def load_library():
         "bez_sim_step_many": (C.c_int, [vp, fp, i32, vp]),
         "bez_sim_reset_indexed": (C.c_int, [vp, vp, i32, vp]),
         "bez_sim_set_env_params": (C.c_int, [vp, C.c_int, fp, vp]),
+        "bez_sim_get_env_params": (C.c_int, [vp, C.c_int, fp, vp]),
+        "bez_sim_set_randomization": (C.c_int, [vp, C.POINTER(abi.BezDrConfig), vp]),
+        "bez_sim_add_dr_noise": (C.c_int, [vp, fp, i64, i32, vp]),
         "bez_sim_seed": (C.c_int, [vp, u64]),
         "bez_sim_calibrate": (C.c_int, [vp, u64, i32, vp]),
         "bez_sim_time_steps": (C.c_int, [vp, fp, i32, vp, C.POINTER(C.c_float)]),
@@ -67,7 +70,7 @@ EXPORTS = ["bez_sim_default_config", "bez_sim_create", "bez_sim_destroy", "bez_s
            "bez_sim_set_dof_position_target_tensor", "bez_sim_set_dof_position_target_tensor_indexed",
            "bez_sim_set_net_contact_force_tensor", "bez_sim_set_prev_lin_vel_tensor", "bez_sim_set_goal_tensor", "bez_sim_set_flags",
            "bez_sim_set_obs_calls", "bez_sim_pre_physics", "bez_sim_simulate", "bez_sim_post_physics", "bez_sim_observe_reward", "bez_sim_step",
-           "bez_sim_step_many", "bez_sim_reset_indexed", "bez_sim_set_env_params", "bez_sim_seed", "bez_sim_time_steps",
+           "bez_sim_step_many", "bez_sim_reset_indexed", "bez_sim_set_env_params", "bez_sim_get_env_params", "bez_sim_set_randomization", "bez_sim_add_dr_noise", "bez_sim_seed", "bez_sim_time_steps",
            "bez_sim_calibrate"]
 
 
@@ -218,6 +221,22 @@ class BezSim:
         else:
             self._check(self.lib.bez_sim_set_env_params(
                 self.h, param, self._ptr(values, torch.float32, self.num_envs * abi.PARAM_WIDTH[param]), self._stream()))
+
+    def get_env_params(self, param):
+        """current (N, width) array of a domain-randomisation parameter (defaults where never set)"""
+        out = torch.empty(self.num_envs, abi.PARAM_WIDTH[param], device=self.device, dtype=torch.float32)
+        self._check(self.lib.bez_sim_get_env_params(self.h, param, C.c_void_p(out.data_ptr()), self._stream()))
+        return out
+
+    def set_randomization(self, dr):
+        """device-side VecTask.apply_randomizations: `dr` is an abi.BezDrConfig (abi.dr_config_from_params) or None (off)"""
+        self._dr_cfg = dr  # keep the struct alive for the call
+        self._check(self.lib.bez_sim_set_randomization(self.h, None if dr is None else C.byref(dr), self._stream()))
+
+    def add_dr_noise(self, x, which):
+        """in place: x += mean + std * N(0, 1) with the device-resident noise parameters (which: 0 observations, 1 actions)"""
+        self._check(self.lib.bez_sim_add_dr_noise(self.h, self._ptr(x, torch.float32), x.numel(), int(which), self._stream()))
+        return x
 
     def seed(self, seed):
         self._check(self.lib.bez_sim_seed(self.h, int(seed)))

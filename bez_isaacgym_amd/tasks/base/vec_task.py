@@ -128,7 +128,7 @@ class VecTask(Env):
         self.reset_buf = s.tensor(abi.TENSOR_RESET)
         self.timeout_buf = s.tensor(abi.TENSOR_TIMEOUT)
         self.progress_buf = s.tensor(abi.TENSOR_PROGRESS)
-        self.randomize_buf = torch.zeros(self.num_envs, device=self.device, dtype=torch.long)
+        self.randomize_buf = s.tensor(abi.TENSOR_RANDOMIZE_BUF)
         self.extras = {}
 
     def get_state(self):
@@ -148,7 +148,9 @@ class VecTask(Env):
         actions = actions.to(self.device, torch.float32).contiguous()
         self._fused_step(actions)
         if self.dr_randomizations.get('observations', None):
-            self.obs_buf.copy_(self.dr_randomizations['observations']['noise_lambda'](self.obs_buf))
+            out = self.dr_randomizations['observations']['noise_lambda'](self.obs_buf)
+            if out.data_ptr() != self.obs_buf.data_ptr():
+                self.obs_buf.copy_(out)
         self.extras["time_outs"] = self.timeout_buf.to(self.rl_device)
         self.obs_dict["obs"] = self._clipped_obs()
         if self.num_states > 0:
@@ -190,92 +192,34 @@ class VecTask(Env):
     def get_number_of_agents(self):
         return self.num_agents
 
-    # ---- domain randomisation (vec_task.py:505-725) -> per-env parameter arrays read by the kernel
+    # ---- domain randomisation (vec_task.py:505-725), device-side: bez_sim_set_randomization
     def apply_randomizations(self, dr_params):
+        """The reference calls this from reset_idx on every step in which some env resets (kick_env.py:781-782); what it does
+        there -- per-env redraws at reset time once `frequency` steps have passed, gravity and the noise parameters on the same
+        clock, all scaled by the linear schedule -- now happens inside the simulator, in a small kernel in front of the step
+        kernel (include/bez_sim.h: bez_sim_set_randomization), keyed by (seed, global env id, episode).  The first call hands
+        the parameters over (and randomises every env at frame 0, first_randomization); later calls have nothing left to do,
+        so the step never syncs with the host and stays HIP-graph capturable with randomize: True."""
         from ... import abi
-        rand_freq = dr_params.get("frequency", 1)
-        self.last_step += 1
-        do_nonenv = (self.last_step - self.last_rand_step) >= rand_freq or self.first_randomization
-        if do_nonenv:
-            self.last_rand_step = self.last_step
-        if self.first_randomization:
-            env_ids = torch.arange(self.num_envs, device=self.device)
-        else:
-            mask = (self.randomize_buf >= rand_freq) & (self.reset_buf > 0)
-            env_ids = mask.nonzero(as_tuple=False).squeeze(-1)
-            self.randomize_buf[mask] = 0
-
-        def sched(attr):  # vec_task.py:560-566 linear schedule
-            if attr.get("schedule") == "linear":
-                return min(self.last_step, attr["schedule_steps"]) / attr["schedule_steps"]
-            return 1.0
-
-        if do_nonenv:
-            for key in ("observations", "actions"):  # vec_task.py:544-618 (gaussian additive noise lambdas)
-                if key in dr_params:
-                    attr = dr_params[key]
-                    mu, var = attr["range"]
-                    s = sched(attr)
-                    if attr["operation"] == "additive":
-                        mu, var = mu * s, var * s
-                    else:
-                        mu, var = mu * s + 1.0 * (1 - s), var * s + 1.0 * (1 - s)
-                    std = float(var) if attr["distribution"] == "gaussian" else None  # vec_task.py:589: randn * params['var']
-                    op = (lambda a, b: a + b) if attr["operation"] == "additive" else (lambda a, b: a * b)
-                    if std is not None:
-                        fn = (lambda t, op=op, mu=mu, std=std: op(t, torch.randn_like(t) * std + mu))
-                    else:
-                        lo, hi = attr["range"]
-                        fn = (lambda t, op=op, lo=lo, hi=hi: op(t, torch.rand_like(t) * (hi - lo) + lo))
-                    self.dr_randomizations[key] = {"noise_lambda": fn}
-            if "sim_params" in dr_params and "gravity" in dr_params["sim_params"]:  # vec_task.py:620-632
-                attr = dr_params["sim_params"]["gravity"]
-                s = sched(attr)
-                g0 = torch.tensor(list(self.cfg["sim"]["gravity"]), device=self.device, dtype=torch.float32)
-                # gymutil.apply_random_samples [ext]: np.random.normal(mu, var) -- the second number of `range` is used as the std
-                noise = torch.randn(3, device=self.device) * float(attr["range"][1] * s) + attr["range"][0] * s
-                self.sim.set_env_params(abi.PARAM_GRAVITY, (g0 + noise).repeat(self.num_envs, 1).contiguous())
-        if len(env_ids) and "actor_params" in dr_params and "bez" in dr_params["actor_params"]:
-            ap = dr_params["actor_params"]["bez"]
-
-            def uniform_scale(attr, width):
-                lo, hi = attr["range"]
-                s = sched(attr)
-                lo, hi = lo * s + 1.0 * (1 - s), hi * s + 1.0 * (1 - s)
-                u = torch.rand(len(env_ids), width, device=self.device)
-                nb = int(attr.get("num_buckets", 0) or 0)
-                if nb > 1:  # bez_kick.yaml:180 num_buckets 500: PhysX material limit -> samples snap to nb evenly spaced values [ext]
-                    u = torch.round(u * (nb - 1)) / (nb - 1)
-                return u * (hi - lo) + lo
-
-            def update(name, param, attr, width, base=1.0):
-                if not hasattr(self, name):
-                    setattr(self, name, torch.full((self.num_envs, width), base, device=self.device, dtype=torch.float32))
-                buf = getattr(self, name)
-                buf[env_ids] = base * uniform_scale(attr, width)
-                self.sim.set_env_params(param, buf.contiguous())
-
-            rsp = ap.get("rigid_shape_properties", {})
-            if "friction" in rsp:
-                update("_dr_friction", abi.PARAM_FRICTION, rsp["friction"], 1, base=float(self.cfg["env"]["plane"]["dynamicFriction"]))
-            dp = ap.get("dof_properties", {})
-            if "stiffness" in dp:
-                update("_dr_kp", abi.PARAM_KP_SCALE, dp["stiffness"], 18)
-            if "damping" in dp:
-                update("_dr_kd", abi.PARAM_KD_SCALE, dp["damping"], 18)
-            for key, param, name in (("lower", abi.PARAM_DOF_LOWER, "_dr_lower"), ("upper", abi.PARAM_DOF_UPPER, "_dr_upper")):
-                if key in dp:  # bez_kick.yaml:206-219: additive gaussian jitter of the PHYSICAL joint limits; the target clamp keeps
-                    attr = dp[key]  # the limits read once at creation (kick_env.py:393-400)
-                    base = self.dof_pos_limits_lower if key == "lower" else self.dof_pos_limits_upper
-                    if not hasattr(self, name):
-                        setattr(self, name, base.repeat(self.num_envs, 1).contiguous())
-                    s = sched(attr)
-                    buf = getattr(self, name)
-                    buf[env_ids] = base + torch.randn(len(env_ids), 18, device=self.device) * float(attr["range"][1] * s) + attr["range"][0] * s
-                    self.sim.set_env_params(param, buf.contiguous())
-            # rigid_shape_properties.restitution (bez_kick.yaml:187-192) SCALES the asset's restitution, which is 0 (plane
-            # restitution 0, bez_kick.yaml:16; asset default 0 [ext]): 0 * U(0, 0.7) = 0 -- nothing to randomise.
-            rbp = ap.get("rigid_body_properties", {})
-            if "mass" in rbp and (self.first_randomization or not rbp["mass"].get("setup_only", False)):
-                update("_dr_mass", abi.PARAM_MASS_SCALE, rbp["mass"], 19)
+        if not self.first_randomization:
+            return
+        self.sim.set_randomization(abi.dr_config_from_params(dr_params))
+        self.randomize_buf = self.sim.tensor(abi.TENSOR_RANDOMIZE_BUF)     # the kernel counts it (kick_env.py:430)
+        # vec_task.py:544-618 noise lambdas (gaussian additive, range_correlated absent in bez_kick.yaml): one launch each, the mean /
+        # std (BEZ_TENSOR_DR_NOISE, moved by the schedule) are read on the device.  The caller's action tensor is not modified.
+        sim = self.sim
+        if "observations" in dr_params:
+            self.dr_randomizations["observations"] = {"noise_lambda": lambda t: sim.add_dr_noise(t if t.is_contiguous() else t.contiguous(), 0)}
+        if "actions" in dr_params:
+            self.dr_randomizations["actions"] = {"noise_lambda": lambda t: sim.add_dr_noise(t.to(self.device, torch.float32).clone(memory_format=torch.contiguous_format), 1)}
+        # rigid_shape_properties.restitution (bez_kick.yaml:187-192) SCALES the asset's restitution, which is 0 (plane
+        # restitution 0, bez_kick.yaml:16; asset default 0 [ext]): 0 * U(0, 0.7) = 0 -- nothing to randomise.
+        # rigid_body_properties.mass is setup_only (bez_kick.yaml:175): drawn once, here, at frame 0 -- where its linear schedule
+        # still interpolates to "no randomisation" (scale 1); without a schedule it is a real one-time draw.
+        rbp = (((dr_params.get("actor_params") or {}).get("bez") or {}).get("rigid_body_properties") or {})
+        if "mass" in rbp and rbp["mass"].get("schedule") != "linear":
+            lo, hi = rbp["mass"]["range"]
+            g = torch.Generator(device=self.device)
+            g.manual_seed(int(self.cfg.get("seed", 42)) + 7919 * int(self.cfg.get("env_id_offset", 0)))
+            self.sim.set_env_params(abi.PARAM_MASS_SCALE, (torch.rand(self.num_envs, 19, device=self.device, generator=g) * (hi - lo) + lo).contiguous())
         self.first_randomization = False

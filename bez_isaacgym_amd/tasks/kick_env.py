@@ -191,17 +191,14 @@ class KickEnv(VecTask):
 
     @property
     def graph_safe(self):
-        """False when step() may sync with the host / allocate (domain randomisation resamples at reset time): the PPO
-        loop must not capture such a step into a HIP graph."""
-        return not self.randomize
+        """True: step() never syncs with the host nor reads host-side state that changes between steps -- domain randomisation
+        resamples inside the simulator (bez_sim_set_randomization), the bez_walk / bez_orient goal is drawn from a device-resident
+        counter -- so the PPO loop may capture it into a HIP graph."""
+        return True
 
     def _fused_step(self, actions):
         self._raw_actions = actions  # borrowed until the next step (see `actions`)
-        if self.randomize:
-            self.randomize_buf += 1
-            if (self.reset_buf > 0).any():  # DR only happens at reset time (kick_env.py:781-782)
-                self.apply_randomizations(self.randomization_params)
-        self.sim.step(actions)
+        self.sim.step(actions)  # with randomize: True the kernel in front of the step counts randomize_buf and redraws at reset time
         self._stale = True
 
     def pre_physics_step(self, actions):
@@ -211,7 +208,8 @@ class KickEnv(VecTask):
 
     def post_physics_step(self):
         self.sim.post_physics()
-        self.randomize_buf += 1
+        if not self.randomize:
+            self.randomize_buf += 1   # kick_env.py:430; with randomize: True the simulator counts it (and clears it at a redraw)
         self._stale = True
 
     def compute_observations(self):

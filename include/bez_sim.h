@@ -128,7 +128,10 @@ enum BezTensor {
   BEZ_TENSOR_PREV_LIN_VEL = 10,     /* f32 (N,3)      prev_lin_vel  kick_env.py:183 */
   BEZ_TENSOR_FEET = 11,             /* f32 (N,8)      self.feet     kick_env.py:185 */
   BEZ_TENSOR_GOAL = 12,             /* f32 (N,2)      self.goal     walk_env.py:143 (bez_walk / bez_orient: redrawn at reset) */
-  BEZ_TENSOR_COUNT = 13
+  BEZ_TENSOR_RANDOMIZE_BUF = 13,    /* i64 (N)        randomize_buf vec_task.py:247 (device-side domain randomisation) */
+  BEZ_TENSOR_DR_NOISE = 14,         /* f32 (4)        mean / std of the observation noise, mean / std of the action noise as the schedule
+                                                      currently has them (vec_task.py:544-618): the caller's noise lambdas read them on the device */
+  BEZ_TENSOR_COUNT = 15
 };
 enum BezDtype { BEZ_DTYPE_F32 = 0, BEZ_DTYPE_I64 = 1 };
 
@@ -197,6 +200,41 @@ enum BezEnvParam {
   BEZ_PARAM_COUNT = 7
 };
 int bez_sim_set_env_params(BezSim* sim, int param, const float* values_dev, void* stream);
+/* copies the current (N, count) array of `param` into out_dev (defaults if the parameter was never set) */
+int bez_sim_get_env_params(BezSim* sim, int param, float* out_dev, void* stream);
+
+/* Device-side domain randomisation: VecTask.apply_randomizations (vec_task.py:505-725, called from reset_idx, kick_env.py:781-782)
+ * without the host.  One entry of cfg/task/bez_kick.yaml:151-219 per BezDrRange: a, b = `range`; distribution and operation are
+ * fixed per parameter as that file has them (uniform scaling: friction, stiffness, damping; gaussian additive, b = the number
+ * numpy uses as the std: lower, upper, gravity, observations, actions); schedule_steps > 0 = `schedule: linear` (the range is
+ * interpolated from "no randomisation" by min(frame, schedule_steps) / schedule_steps, vec_task.py:560-566 and gymutil [ext]).
+ * Once set, every call that contains the post-physics first runs one small kernel that does what reset_idx's call does:
+ * randomize_buf += 1; an env with reset_buf != 0 and randomize_buf >= frequency draws new friction / Kp / Kd / joint limits from
+ * the Philox stream keyed by (seed, GLOBAL env id, episode, parameter) and clears its randomize_buf; if any env resets and
+ * `frequency` frames have passed since the last time, gravity (one draw for the whole sim) and the noise parameters are
+ * refreshed.  Nothing syncs with the host: the step stays HIP-graph capturable.  The first call randomises every env at
+ * frame 0 (first_randomization, vec_task.py:521-523).  NULL switches it off (arrays keep their values). */
+typedef struct BezDrRange {
+  float a, b;
+  int32_t enabled;
+  int32_t schedule_steps;
+} BezDrRange;
+typedef struct BezDrConfig {
+  int32_t frequency;        /* randomization_params.frequency                     bez_kick.yaml:153 */
+  int32_t friction_buckets; /* rigid_shape_properties.friction.num_buckets        bez_kick.yaml:180 */
+  BezDrRange friction;      /* bez_kick.yaml:179-186 */
+  BezDrRange stiffness;     /* bez_kick.yaml:200-205 */
+  BezDrRange damping;       /* bez_kick.yaml:194-199 */
+  BezDrRange lower, upper;  /* bez_kick.yaml:206-219 */
+  BezDrRange gravity;       /* bez_kick.yaml:162-167 */
+  BezDrRange observations;  /* bez_kick.yaml:154-157 */
+  BezDrRange actions;       /* bez_kick.yaml:158-161 */
+} BezDrConfig;
+int bez_sim_set_randomization(BezSim* sim, const BezDrConfig* dr, void* stream);
+/* The noise lambdas of vec_task.py:544-618 in one launch: x[i] += mean + std * N(0,1) for n floats, mean / std = the current
+ * entries of BEZ_TENSOR_DR_NOISE for `which` (0 = observations, 1 = actions), normals from Philox keyed by (seed, frame, which,
+ * i / 4) -- one call per control step and kind. */
+int bez_sim_add_dr_noise(BezSim* sim, float* x_dev, int64_t n, int32_t which, void* stream);
 
 /* Test hooks (state injection for the parity tests; no reference counterpart). */
 int bez_sim_set_prev_lin_vel_tensor(BezSim* sim, const float* prev_dev, void* stream); /* (N,3) */

@@ -265,7 +265,7 @@ typedef struct {
   real feet[8];
   real obs[BEZ_NUM_OBS];
   real rew;
-  int64_t reset, progress, timeout;
+  int64_t reset, progress, timeout, randomize;
   uint32_t episode;
   /* DR */
   real friction, kp_scale[ND], kd_scale[ND], mass_scale[NL], gravity[3], lim_lo[ND], lim_hi[ND];
@@ -277,6 +277,8 @@ typedef struct {
   Env* env;
   int64_t obs_calls; /* number of compute_observations passes so far (quirk Q1 bookkeeping) */
   uint64_t post_calls, reset_calls; /* keys of the shared goal draw (bez_walk / bez_orient) */
+  /* device-side domain randomisation restated (bez_sim_set_randomization): vec_task.py:505-725 */
+  int dr_on; BezDrConfig dr; uint64_t dr_frame, dr_last_rand; float dr_noise[4];
 } Oracle;
 
 /* kinematics of one env: link frames relative to O = root_pos, world axes */
@@ -1280,6 +1282,87 @@ static void env_simulate(const BezSimConfig* c, Env* e) {
   }
 }
 
+/* ------------------------------------------------------------------ domain randomisation (vec_task.py:505-725)
+ * apply_randomizations is called from reset_idx (kick_env.py:781-782), i.e. once per control step in which some env resets,
+ * after `randomize_buf += 1` (kick_env.py:430).  Restated for the whole batch in front of the env loop of that step:
+ *   - an env with reset_buf != 0 and randomize_buf >= frequency redraws its friction / Kp / Kd / joint limits and clears
+ *     randomize_buf (vec_task.py:525-530, 646-714); the draws are Philox words keyed by (seed, GLOBAL env id, episode) so
+ *     that they depend neither on the shard nor on the order envs are visited in;
+ *   - if any env resets and `frequency` frames have passed since the last time, gravity (vec_task.py:620-632) and the noise
+ *     parameters of the observation / action lambdas (vec_task.py:544-618) are refreshed, scaled by the linear schedule
+ *     min(frame, schedule_steps) / schedule_steps where frame = gym.get_frame_count (vec_task.py:521).
+ * Word map of an env's draw: 0 friction; 1..18 stiffness; 19..36 damping; 37..72 lower (pairs: Box-Muller); 73..108 upper. */
+static float dr_word_uniform(uint64_t seed, int64_t key, uint32_t key2, uint32_t tag, int k) {
+  uint32_t c[4] = {(uint32_t)key, (uint32_t)((uint64_t)key >> 32), key2, tag + (uint32_t)(k >> 2)};
+  philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+  return (float)(c[k & 3] >> 8) * (1.0f / 16777216.0f);
+}
+#define DR_TAG_ENV 0x44520000u
+#define DR_TAG_GRAVITY 0x47520000u
+static float dr_sched(const BezDrRange* r, uint64_t frame) {
+  if (r->schedule_steps <= 0) return 1.0f;
+  uint64_t f = frame < (uint64_t)r->schedule_steps ? frame : (uint64_t)r->schedule_steps;
+  return (float)f / (float)r->schedule_steps;
+}
+static float dr_scaling(const BezDrRange* r, float s, float u) { /* uniform `scaling`: range interpolated from [1, 1] */
+  float lo = fmaf(r->a, s, 1.0f - s), hi = fmaf(r->b, s, 1.0f - s);
+  return fmaf(u, hi - lo, lo);
+}
+static float dr_normal(float u1, float u2) { return sqrtf(-2.0f * logf(1.0f - u1)) * cosf(6.2831853f * u2); }
+static void dr_resample_env(Oracle* o, Env* e, int64_t genv) {
+  const BezDrConfig* d = &o->dr;
+  const uint64_t seed = o->cfg.seed, fr = o->dr_frame;
+  if (d->friction.enabled) {
+    float u = dr_word_uniform(seed, genv, e->episode, DR_TAG_ENV, 0);
+    if (d->friction_buckets > 1) u = rintf(u * (float)(d->friction_buckets - 1)) / (float)(d->friction_buckets - 1);
+    e->friction = (real)(o->cfg.plane_friction * dr_scaling(&d->friction, dr_sched(&d->friction, fr), u));
+  }
+  for (int j = 0; j < ND; ++j) {
+    if (d->stiffness.enabled) e->kp_scale[j] = (real)dr_scaling(&d->stiffness, dr_sched(&d->stiffness, fr), dr_word_uniform(seed, genv, e->episode, DR_TAG_ENV, 1 + j));
+    if (d->damping.enabled) e->kd_scale[j] = (real)dr_scaling(&d->damping, dr_sched(&d->damping, fr), dr_word_uniform(seed, genv, e->episode, DR_TAG_ENV, 19 + j));
+    if (d->lower.enabled) {
+      float s = dr_sched(&d->lower, fr), z = dr_normal(dr_word_uniform(seed, genv, e->episode, DR_TAG_ENV, 37 + 2 * j), dr_word_uniform(seed, genv, e->episode, DR_TAG_ENV, 38 + 2 * j));
+      e->lim_lo[j] = (real)((float)BEZ_DOF_LOWER[j] + fmaf(z, d->lower.b * s, d->lower.a * s));
+    }
+    if (d->upper.enabled) {
+      float s = dr_sched(&d->upper, fr), z = dr_normal(dr_word_uniform(seed, genv, e->episode, DR_TAG_ENV, 73 + 2 * j), dr_word_uniform(seed, genv, e->episode, DR_TAG_ENV, 74 + 2 * j));
+      e->lim_hi[j] = (real)((float)BEZ_DOF_UPPER[j] + fmaf(z, d->upper.b * s, d->upper.a * s));
+    }
+  }
+}
+static void dr_refresh_global(Oracle* o) {
+  const BezDrConfig* d = &o->dr;
+  const uint64_t fr = o->dr_frame;
+  if (d->gravity.enabled) {
+    float s = dr_sched(&d->gravity, fr), g[3];
+    for (int k = 0; k < 3; ++k) {
+      float z = dr_normal(dr_word_uniform(o->cfg.seed, (int64_t)fr, 0, DR_TAG_GRAVITY, 2 * k), dr_word_uniform(o->cfg.seed, (int64_t)fr, 0, DR_TAG_GRAVITY, 2 * k + 1));
+      g[k] = o->cfg.gravity[k] + fmaf(z, d->gravity.b * s, d->gravity.a * s);
+    }
+    for (int i = 0; i < o->n; ++i) for (int k = 0; k < 3; ++k) o->env[i].gravity[k] = (real)g[k];
+  }
+  float so = dr_sched(&d->observations, fr), sa = dr_sched(&d->actions, fr);
+  o->dr_noise[0] = d->observations.enabled ? d->observations.a * so : 0.0f; o->dr_noise[1] = d->observations.enabled ? d->observations.b * so : 0.0f;
+  o->dr_noise[2] = d->actions.enabled ? d->actions.a * sa : 0.0f; o->dr_noise[3] = d->actions.enabled ? d->actions.b * sa : 0.0f;
+  o->dr_last_rand = fr;
+}
+/* in front of the env loop of every step that contains the post-physics */
+static void oracle_dr_step(Oracle* o) {
+  if (!o->dr_on) return;
+  o->dr_frame += 1; /* gym.get_frame_count: this step's simulate has run */
+  int any = 0;
+  for (int i = 0; i < o->n; ++i) {
+    Env* e = &o->env[i];
+    int64_t rb = e->randomize + 1; /* kick_env.py:430 */
+    if (e->reset != 0) {
+      any = 1;
+      if (rb >= o->dr.frequency) { dr_resample_env(o, e, o->cfg.env_id_offset + i); rb = 0; }
+    }
+    e->randomize = rb;
+  }
+  if (any && o->dr_frame - o->dr_last_rand >= (uint64_t)o->dr.frequency) dr_refresh_global(o);
+}
+
 /* ------------------------------------------------------------------ exported API (ctypes) */
 void* bez_oracle_create(const BezSimConfig* cfg) {
   Oracle* o = (Oracle*)calloc(1, sizeof(Oracle));
@@ -1430,6 +1513,7 @@ void bez_oracle_simulate(void* h) {
 }
 void bez_oracle_post_physics(void* h) {
   Oracle* o = (Oracle*)h;
+  oracle_dr_step(o);
   int up = oracle_use_prev(o);
   float goal[2];
   goal_draw(o->cfg.seed, o->post_calls++, 0, goal);
@@ -1445,6 +1529,7 @@ void bez_oracle_observe_reward(void* h) {
 }
 void bez_oracle_step(void* h, const float* actions) {
   Oracle* o = (Oracle*)h;
+  oracle_dr_step(o);
   int up = oracle_use_prev(o);
   float goal[2];
   goal_draw(o->cfg.seed, o->post_calls++, 0, goal);
@@ -1462,6 +1547,33 @@ void bez_oracle_reset_idx(void* h, const int32_t* ids, int n) {
   float goal[2];
   goal_draw(o->cfg.seed, o->reset_calls++, 1, goal);
   for (int k = 0; k < n; ++k) env_reset(&o->cfg, &o->env[ids[k]], o->cfg.env_id_offset + ids[k], goal);
+}
+/* bez_sim_set_randomization: NULL = off.  The first call randomises every env at frame 0 (first_randomization, vec_task.py:521-523) */
+void bez_oracle_set_randomization(void* h, const BezDrConfig* dr) {
+  Oracle* o = (Oracle*)h;
+  if (!dr) { o->dr_on = 0; return; }
+  o->dr = *dr; o->dr_on = 1; o->dr_frame = 0;
+  for (int i = 0; i < o->n; ++i) { dr_resample_env(o, &o->env[i], o->cfg.env_id_offset + i); o->env[i].randomize = 0; }
+  dr_refresh_global(o);
+}
+void bez_oracle_get_randomize(void* h, int64_t* out) { Oracle* o = (Oracle*)h; for (int i = 0; i < o->n; ++i) out[i] = o->env[i].randomize; }
+void bez_oracle_set_randomize(void* h, const int64_t* in) { Oracle* o = (Oracle*)h; for (int i = 0; i < o->n; ++i) o->env[i].randomize = in[i]; }
+void bez_oracle_get_dr_noise(void* h, float* out) { Oracle* o = (Oracle*)h; for (int k = 0; k < 4; ++k) out[k] = o->dr_noise[k]; }
+void bez_oracle_get_env_params(void* h, int param, float* v) {
+  Oracle* o = (Oracle*)h;
+  for (int i = 0; i < o->n; ++i) {
+    const Env* e = &o->env[i];
+    switch (param) {
+      case BEZ_PARAM_FRICTION: v[i] = (float)e->friction; break;
+      case BEZ_PARAM_KP_SCALE: for (int j = 0; j < ND; ++j) v[(size_t)i * ND + j] = (float)e->kp_scale[j]; break;
+      case BEZ_PARAM_KD_SCALE: for (int j = 0; j < ND; ++j) v[(size_t)i * ND + j] = (float)e->kd_scale[j]; break;
+      case BEZ_PARAM_MASS_SCALE: for (int l = 0; l < NL; ++l) v[(size_t)i * NL + l] = (float)e->mass_scale[l]; break;
+      case BEZ_PARAM_GRAVITY: for (int k = 0; k < 3; ++k) v[(size_t)i * 3 + k] = (float)e->gravity[k]; break;
+      case BEZ_PARAM_DOF_LOWER: for (int j = 0; j < ND; ++j) v[(size_t)i * ND + j] = (float)e->lim_lo[j]; break;
+      case BEZ_PARAM_DOF_UPPER: for (int j = 0; j < ND; ++j) v[(size_t)i * ND + j] = (float)e->lim_hi[j]; break;
+      default: break;
+    }
+  }
 }
 void bez_oracle_seed(void* h, uint64_t seed) { ((Oracle*)h)->cfg.seed = seed; }
 void bez_oracle_set_flags(void* h, uint32_t flags) { /* the asset bits are fixed at creation, as in bez_sim_set_flags */

@@ -100,6 +100,21 @@ class Oracle:
     def set_reset(self, a): self._set("reset", a, np.int64)
     def set_progress(self, a): self._set("progress", a, np.int64)
 
+    randomize_buf = property(lambda s: s._get("randomize", (s.n,), np.int64))
+    dr_noise = property(lambda s: s._get("dr_noise", (4,)))
+
+    def set_randomize(self, a): self._set("randomize", a, np.int64)
+
+    def set_randomization(self, dr):
+        """BezDrConfig (abi.dr_config_from_params) or None"""
+        self.lib.bez_oracle_set_randomization(self.h, None if dr is None else C.byref(dr))
+
+    def get_env_params(self, param):
+        from bez_isaacgym_amd.abi import PARAM_WIDTH
+        out = np.zeros((self.n, PARAM_WIDTH[param]), np.float32)
+        self.lib.bez_oracle_get_env_params(self.h, C.c_int(param), _fp(out))
+        return out
+
     def set_env_params(self, param, values):
         if values is None:
             self.lib.bez_oracle_set_env_params(self.h, C.c_int(param), None)

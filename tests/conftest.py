@@ -4,6 +4,8 @@ import sys
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# the oracle's OpenMP loop runs over envs; the tests use tens of envs, where more than a few threads only add spin-wait time
+os.environ.setdefault("OMP_NUM_THREADS", "2")
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 

@@ -38,6 +38,12 @@ class SimAdapter:
     reset_buf = property(lambda s: s._get(abi.TENSOR_RESET))
     progress_buf = property(lambda s: s._get(abi.TENSOR_PROGRESS))
     timeout_buf = property(lambda s: s._get(abi.TENSOR_TIMEOUT))
+    randomize_buf = property(lambda s: s.sim.tensor(abi.TENSOR_RANDOMIZE_BUF).detach().cpu().numpy().copy())
+    dr_noise = property(lambda s: s.sim.tensor(abi.TENSOR_DR_NOISE).detach().cpu().numpy().copy())
+
+    def set_randomize(self, a): self.sim.tensor(abi.TENSOR_RANDOMIZE_BUF).copy_(self._t(a, torch.int64))
+    def set_randomization(self, dr): self.sim.set_randomization(dr)
+    def get_env_params(self, param): return self.sim.get_env_params(param).detach().cpu().numpy().copy()
 
     def set_root_states(self, a): self.sim.set_actor_root_state_tensor_indexed(self._t(a).reshape(-1), self._all_ids)
     def set_dof_state(self, a): self.sim.set_dof_state_tensor_indexed(self._t(a).reshape(-1), self._robot_ids)

@@ -464,8 +464,7 @@ def test_segmented_graphs_equal_the_monolithic_update():
         ag.play_steps()
     for k in mono.dataset:
         segm.dataset[k].copy_(mono.dataset[k])
-    mono.run_update()                    # capture only (records, does not execute)
-    mono.run_update()                    # replay: one real update
+    mono.run_update()                    # captures the whole update, then replays it: one real update
     segm.run_update()                    # captures the segments, then replays them: one real update
     torch.cuda.synchronize()
     assert segm._seg is not None and len(segm._seg["b"]) == segm.num_minibatches and mono._g_update is not None
