@@ -44,15 +44,17 @@ class RunningMeanStd(nn.Module):
         self.register_buffer("count", torch.ones((), dtype=torch.float64))
 
     @torch.no_grad()
-    def update(self, x):
+    def moments(self, x):
+        """[column sums | column sums of squares | rows] in fp64: what an update needs to know about a batch.  Additive over
+        ranks, so a data-parallel job all-reduces THESE (for all minibatches of an epoch at once) and not the statistics."""
         x = x.reshape(-1, *self.running_mean.shape).double()
-        n = torch.full((), float(x.shape[0]), dtype=torch.float64, device=x.device)  # fill kernel: graph-capturable
-        s1, s2 = x.sum(0), (x * x).sum(0)
-        if _dist_on():  # moments of the GLOBAL batch: every rank ends with identical statistics
-            flat = torch.cat([s1.reshape(-1), s2.reshape(-1), n.reshape(1)])
-            dist.all_reduce(flat)
-            k = s1.numel()
-            s1, s2, n = flat[:k].reshape(s1.shape), flat[k:2 * k].reshape(s2.shape), flat[2 * k]
+        n = torch.full((1,), float(x.shape[0]), dtype=torch.float64, device=x.device)  # fill kernel: graph-capturable
+        return torch.cat([x.sum(0).reshape(-1), (x * x).sum(0).reshape(-1), n])
+
+    @torch.no_grad()
+    def update_from_moments(self, flat):
+        k = self.running_mean.numel()
+        s1, s2, n = flat[:k].reshape(self.running_mean.shape), flat[k:2 * k].reshape(self.running_mean.shape), flat[2 * k]
         b_mean = s1 / n
         b_var = (s2 / n - b_mean * b_mean).clamp_min(0.0) * (n / (n - 1).clamp_min(1.0))  # unbiased, as torch.var
         delta = b_mean - self.running_mean
@@ -61,6 +63,13 @@ class RunningMeanStd(nn.Module):
         m2 = self.running_var * self.count + b_var * n + delta * delta * self.count * n / tot
         self.running_var.copy_(m2 / tot)
         self.count.copy_(tot)
+
+    @torch.no_grad()
+    def update(self, x):
+        flat = self.moments(x)
+        if _dist_on():  # moments of the GLOBAL batch: every rank ends with identical statistics
+            dist.all_reduce(flat)
+        self.update_from_moments(flat)
 
     def forward(self, x, unnorm=False):
         if self.training and not unnorm:
@@ -442,6 +451,14 @@ class A2CAgent:
         self.ep_stats = torch.zeros(3, device=dev, dtype=torch.float64)  # [finished episodes, sum of returns, sum of lengths]
         self.kl_acc = torch.zeros(self.mini_epochs, device=dev)
         self.loss_acc = torch.zeros(2, device=dev)
+        # the epoch's data-only moments in ONE fp64 buffer = one all-reduce per epoch when data parallel: the
+        # observation moments of every minibatch (rl_games updates the input normaliser at every minibatch forward, and what
+        # it adds depends on the dataset alone, not on the weights), then the moments of the values and of the returns
+        w = 2 * self.obs_dim + 1
+        self._mom_pack = torch.zeros(self.num_minibatches * w + 6, device=dev, dtype=torch.float64)
+        self._obs_mom = self._mom_pack[:self.num_minibatches * w].view(self.num_minibatches, w)
+        self._val_mom, self._ret_mom = self._mom_pack[-6:-3], self._mom_pack[-3:]
+        self._adv_pack = torch.zeros(6, device=dev, dtype=torch.float64)  # second (and last) epoch collective: advantage moments + episode statistics
         if self.fused:
             hd = torch.float16 if self.mixed_precision else torch.float32
             A, D, MB = self.act_dim, self.obs_dim, self.minibatch_size
@@ -527,33 +544,51 @@ class A2CAgent:
             advs = discount_values(self.gamma, self.tau, self.dones, last_values, mb["dones"], mb["val"], mb["rew"])
             returns = advs + mb["val"]
         # ---- prepare_dataset (rl_games a2c_continuous.prepare_dataset)
+        ds = self.dataset
         values, returns = swap_and_flatten01(mb["val"]), swap_and_flatten01(returns)
-        if self.normalize_value and self.fused and getattr(self, "_f_val_rms", None) is not None:
-            # RunningMeanStd.forward in train mode, twice (values, then returns): moments -> [all-reduce] -> update -> normalise, three
-            # launches each instead of ~25 elementwise fp64 ones
-            fx, vr = self._fx, self._f_val_rms
+        ds["obs"].copy_(swap_and_flatten01(mb["obs"]))
+        fused_v = self.normalize_value and self.fused and getattr(self, "_f_val_rms", None) is not None
+        # epoch collective 1 of 2: every moment that depends on the data alone, for the whole epoch
+        if self.normalize_input:
+            for i in range(self.num_minibatches):
+                x = ds["obs"][i * self.minibatch_size:(i + 1) * self.minibatch_size]
+                if self.fused:
+                    self._f_obs_rms.moments(x, out=self._obs_mom[i])
+                else:
+                    self._obs_mom[i].copy_(self.running_mean_std.moments(x))
+        if fused_v:
             values, returns = values.contiguous(), returns.contiguous()
-            vr.update(values); values = vr.normalize(values, fx["val_n"])
-            vr.update(returns); returns = vr.normalize(returns, fx["ret_n"])
+            self._f_val_rms.moments(values, out=self._val_mom); self._f_val_rms.moments(returns, out=self._ret_mom)
         elif self.normalize_value:
-            self.value_mean_std.train()
-            values = self.value_mean_std(values)
-            returns = self.value_mean_std(returns)
+            self._val_mom.copy_(self.value_mean_std.moments(values)); self._ret_mom.copy_(self.value_mean_std.moments(returns))
+        if _dist_on():
+            dist.all_reduce(self._mom_pack)
+        if fused_v:
+            # RunningMeanStd.forward in train mode, twice (values, then returns): update -> normalise, two launches each
+            fx, vr = self._fx, self._f_val_rms
+            vr.apply(self._val_mom); values = vr.normalize(values, fx["val_n"])
+            vr.apply(self._ret_mom); returns = vr.normalize(returns, fx["ret_n"])
+        elif self.normalize_value:
             self.value_mean_std.eval()
+            self.value_mean_std.update_from_moments(self._val_mom); values = self.value_mean_std(values)
+            self.value_mean_std.update_from_moments(self._ret_mom); returns = self.value_mean_std(returns)
         adv = (returns - values).sum(dim=1)
         if self.normalize_advantage:
             if _dist_on():
-                st = torch.stack([adv.sum(), (adv * adv).sum(), torch.full((), float(adv.numel()), device=adv.device)]).double()
+                # epoch collective 2 of 2: the advantage moments need the normalised values, i.e. the first collective's result; the
+                # episode statistics ride along (every rank then reports the job's mean reward, not its shard's)
+                st = self._adv_pack
+                st[0] = adv.sum(); st[1] = (adv * adv).sum(); st[2] = float(adv.numel()); st[3:6] = self.ep_stats
                 dist.all_reduce(st)
+                self.ep_stats.copy_(st[3:6])
                 mean = st[0] / st[2]
                 std = torch.sqrt(((st[1] / st[2] - mean * mean) * st[2] / (st[2] - 1)).clamp_min(0))
                 adv = (adv - mean.float()) / (std.float() + 1e-8)
             else:
                 adv = (adv - adv.mean()) / (adv.std() + 1e-8)
-        ds = self.dataset
         ds["old_values"].copy_(values); ds["returns"].copy_(returns); ds["advantages"].copy_(adv)
         ds["old_logp"].copy_(swap_and_flatten01(mb["neglogp"])); ds["actions"].copy_(swap_and_flatten01(mb["act"]))
-        ds["obs"].copy_(swap_and_flatten01(mb["obs"])); ds["mu"].copy_(swap_and_flatten01(mb["mu"]))
+        ds["mu"].copy_(swap_and_flatten01(mb["mu"]))
         ds["sigma"].copy_(swap_and_flatten01(mb["sigma"]))
 
     def play_steps(self):
@@ -653,35 +688,35 @@ class A2CAgent:
                 self.optimizer.state[p] = {"step": self._steps[k], "exp_avg": self._mflat[sl].view_as(p), "exp_avg_sq": self._vflat[sl].view_as(p)}
                 off += p.numel()
 
-    def _allreduce_grads(self):
-        """ONE fused all-reduce of the flat fp32 gradient (124 237 elements = 497 KB) per optimiser step: the message
-        is latency-bound on xGMI, so bucketing per parameter would only multiply the latency."""
+    def _allreduce_grads(self, kl):
+        """ONE fused all-reduce per optimiser step: the flat fp32 gradient (124 237 elements = 497 KB) and the minibatch KL in
+        its last slot.  The message is latency-bound on xGMI, so bucketing per parameter would only multiply the latency.
+        Returns the mean KL."""
         params = [p for p in self.model.parameters() if p.grad is not None]
         n = sum(p.numel() for p in params)
-        if self._flat_grad is None or self._flat_grad.numel() != n:
-            self._flat_grad = torch.empty(n, device=self.device, dtype=torch.float32)
+        if self._flat_grad is None or self._flat_grad.numel() != n + 1:
+            self._flat_grad = torch.empty(n + 1, device=self.device, dtype=torch.float32)
         off = 0
         for p in params:
             self._flat_grad[off:off + p.numel()].copy_(p.grad.reshape(-1))
             off += p.numel()
+        self._flat_grad[n] = kl
         dist.all_reduce(self._flat_grad)
         self._flat_grad.div_(dist.get_world_size())
         off = 0
         for p in params:
             p.grad.copy_(self._flat_grad[off:off + p.numel()].view_as(p.grad))
             off += p.numel()
+        return self._flat_grad[n].clone()
 
-    # ---- the fused optimiser step in three collective-free phases (A | all-reduce moments | B | all-reduce grads+KL | C)
-    def _phase_a(self, mb):
-        if self.normalize_input:
-            self._f_obs_rms.moments(mb["obs"])
-
+    # ---- the fused optimiser step in two collective-free phases around its ONE collective (B | all-reduce grads + KL | C); the
+    # observation moments the input normaliser absorbs at this step were computed -- and all-reduced -- once per epoch, after the rollout
     def _phase_b(self, mb):
         F, fx, net = self._F, self._fx, self.model.a2c_network
         self.model.train()
         obs = mb["obs"]
         if self.normalize_input:
-            self._f_obs_rms.apply()
+            self._f_obs_rms.apply(self._obs_mom[mb["_i"]])
         if self.half_path and getattr(self, "_hflat", None) is None:
             net.refresh_half()  # (with the fused optimiser the Adam kernel keeps the fp16 copies current)
         manual = self._train_fwd_ok(obs)
@@ -799,12 +834,9 @@ class A2CAgent:
             loss_out.add_(self._fx["stats"][0:2], alpha=1.0 / float(self.minibatch_size))
 
     def _calc_gradients_fused(self, mb, kl_out, loss_out):
-        """calc_gradients with the HIP glue kernels: observation moments + running update + normalise (3 launches), MLP
+        """calc_gradients with the HIP glue kernels: running update of the input normaliser from the epoch's precomputed moments, MLP
         forward (torch), the whole loss and its gradient w.r.t. mu / value / log-std (1 launch), MLP backward (torch, into the
         static flat gradient), then the all-reduce / unscale / clip / Adam / scaler tail."""
-        self._phase_a(mb)
-        if _dist_on() and self.normalize_input:
-            dist.all_reduce(self._f_obs_rms.mom)
         self._phase_b(mb)
         if _dist_on():
             # ONE all-reduce of the flat STILL-SCALED gradient + KL (124 238 fp32 = 497 KB, latency-bound on xGMI): an fp16
@@ -818,7 +850,10 @@ class A2CAgent:
             return self._calc_gradients_fused(mb, kl_out, loss_out)
         self.model.train()
         if self.normalize_input:
-            self.running_mean_std.train()
+            # rl_games runs the input normaliser in train mode here (every minibatch forward updates it); what it absorbs are this
+            # minibatch's moments, computed and all-reduced once per epoch after the rollout
+            self.running_mean_std.eval()
+            self.running_mean_std.update_from_moments(self._obs_mom[mb["_i"]])
         obs = self._preproc_obs(mb["obs"])
         e = self.e_clip
         with torch.autocast("cuda", dtype=torch.float16, enabled=self.mixed_precision):
@@ -842,26 +877,25 @@ class A2CAgent:
             loss = a_l + 0.5 * c_l * self.critic_coef - ent * self.entropy_coef + b_l * self.bounds_loss_coef
         self.optimizer.zero_grad(set_to_none=True)
         self.scaler.scale(loss).backward()
+        kl = policy_kl(mu.detach(), sigma.detach(), mb["mu"], mb["sigma"])
         if _dist_on():
-            # all-reduce the STILL-SCALED gradients (as DDP does): an fp16 overflow on any rank reaches every rank, so
-            # unscale_ below records the same found_inf everywhere and all replicas skip (or take) the step together.
-            self._allreduce_grads()
+            # the step's ONE collective: the STILL-SCALED gradients (as DDP does: an fp16 overflow on any rank reaches every rank, so
+            # unscale_ below records the same found_inf everywhere and all replicas skip or take the step together) + the KL
+            kl = self._allreduce_grads(kl)
         if self.truncate_grads:
             self.scaler.unscale_(self.optimizer)
             nn.utils.clip_grad_norm_(self.model.parameters(), self.grad_norm)
         self.scaler.step(self.optimizer)
         self.scaler.update()
         with torch.no_grad():
-            kl = policy_kl(mu.detach(), sigma.detach(), mb["mu"], mb["sigma"])
-            if _dist_on():
-                dist.all_reduce(kl)
-                kl /= dist.get_world_size()
             kl_out.add_(kl / self.num_minibatches)
             loss_out[0] += a_l.detach(); loss_out[1] += c_l.detach()
 
     def _minibatch(self, i):
         sl = slice(i * self.minibatch_size, (i + 1) * self.minibatch_size)
-        return {k: v[sl] for k, v in self.dataset.items()}
+        mb = {k: v[sl] for k, v in self.dataset.items()}
+        mb["_i"] = i  # row of the epoch's precomputed observation moments
+        return mb
 
     def _update_impl(self):
         """mini_epochs x num_minibatches optimiser steps + the adaptive LR rule, all on the device."""
@@ -873,19 +907,18 @@ class A2CAgent:
                 self.scheduler.update_(self.lr_t, self.kl_acc[ep])
 
     def _update_segmented(self):
-        """Data-parallel update with HIP graphs: per minibatch a moments graph and a forward/backward graph, one shared
-        optimiser graph; the two RCCL all-reduces of a step run eagerly between the replays (no collective is ever captured).
+        """Data-parallel update with HIP graphs: per minibatch a forward/backward graph, one shared optimiser graph; the step's ONE
+        RCCL all-reduce (gradient + KL) runs eagerly between the two replays (no collective is ever captured).
         The first call captures the segments (capture records, it does not execute) and then replays them like every later call."""
         if self._seg is None:
             torch.cuda.synchronize()
-            seg = dict(a=[], b=[], c=torch.cuda.CUDAGraph(), kl=torch.zeros((), device=self.device))
+            seg = dict(b=[], c=torch.cuda.CUDAGraph(), kl=torch.zeros((), device=self.device))
             for i in range(self.num_minibatches):
                 mb = self._minibatch(i)
-                for key, fn in (("a", self._phase_a), ("b", self._phase_b)):
-                    g = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g, pool=self._graph_pool()):
-                        fn(mb)
-                    seg[key].append(g)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, pool=self._graph_pool()):
+                    self._phase_b(mb)
+                seg["b"].append(g)
             with torch.cuda.graph(seg["c"], pool=self._graph_pool()):
                 self._phase_c(seg["kl"], self.loss_acc)
             self._seg = seg
@@ -894,9 +927,6 @@ class A2CAgent:
         for ep in range(self.mini_epochs):
             seg["kl"].zero_()
             for i in range(self.num_minibatches):
-                seg["a"][i].replay()
-                if self.normalize_input and _dist_on():
-                    dist.all_reduce(self._f_obs_rms.mom)
                 seg["b"][i].replay()
                 if _dist_on():
                     dist.all_reduce(self._flat)

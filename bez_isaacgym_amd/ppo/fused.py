@@ -70,14 +70,18 @@ class FusedRunningMeanStd:
         self.mom = torch.zeros(2 * d + 1, dtype=torch.float64, device=rms.running_mean.device)
         self.reduce_fn = reduce_fn  # e.g. dist.all_reduce for data-parallel training
 
-    def moments(self, x):
+    def moments(self, x, out=None):
+        """[column sums | sums of squares | rows] of x into `out` (default: the object's own buffer)"""
         rows = x.numel() // self.d
-        _chk(lib().bez_ppo_rms_moments(_p(x), rows, self.d, _p(self.mom, torch.float64), _stream(x)), "bez_ppo_rms_moments")
+        out = self.mom if out is None else out
+        assert out.numel() == 2 * self.d + 1 and out.is_contiguous()
+        _chk(lib().bez_ppo_rms_moments(_p(x), rows, self.d, _p(out, torch.float64), _stream(x)), "bez_ppo_rms_moments")
 
-    def apply(self):
+    def apply(self, mom=None):
         r = self.rms
-        _chk(lib().bez_ppo_rms_apply(_p(self.mom, torch.float64), self.d, _p(r.running_mean, torch.float64), _p(r.running_var, torch.float64),
-                                     _p(r.count.view(1), torch.float64), _stream(self.mom)), "bez_ppo_rms_apply")
+        mom = self.mom if mom is None else mom
+        _chk(lib().bez_ppo_rms_apply(_p(mom, torch.float64), self.d, _p(r.running_mean, torch.float64), _p(r.running_var, torch.float64),
+                                     _p(r.count.view(1), torch.float64), _stream(mom)), "bez_ppo_rms_apply")
 
     def update(self, x):
         self.moments(x)

@@ -302,6 +302,7 @@ def test_fused_and_plain_optimiser_step_agree():
     fused._alloc_static()
     for k in plain.dataset:                 # ... shared with the fused one
         fused.dataset[k].copy_(plain.dataset[k])
+    fused._mom_pack.copy_(plain._mom_pack)  # (the epoch's precomputed observation / value moments belong to the dataset)
     for rms_a, rms_b in ((plain.running_mean_std, fused.running_mean_std), (plain.value_mean_std, fused.value_mean_std)):
         rms_b.load_state_dict(rms_a.state_dict())
     kl_a, kl_b = torch.zeros((), device=DEV), torch.zeros((), device=DEV)
@@ -424,6 +425,7 @@ def test_train_forward_kernel_and_manual_backward_match_autograd_path(fused_back
     b._alloc_static()
     for k in a.dataset:
         b.dataset[k].copy_(a.dataset[k])
+    b._mom_pack.copy_(a._mom_pack)
     for ra, rb in ((a.running_mean_std, b.running_mean_std), (a.value_mean_std, b.value_mean_std)):
         rb.load_state_dict(ra.state_dict())
     if getattr(b, "_hflat", None) is not None:   # fp16 working copies follow the loaded masters
@@ -431,7 +433,7 @@ def test_train_forward_kernel_and_manual_backward_match_autograd_path(fused_back
     grads = []
     for ag in (a, b):
         mb = ag._minibatch(0)
-        ag._phase_a(mb)
+        ag._f_obs_rms.moments(mb["obs"], out=ag._obs_mom[0])   # (play_steps does this for every minibatch of the epoch)
         assert ag._train_fwd_ok(mb["obs"]) == (ag is b)
         ag._phase_b(mb)
         grads.append(ag._flat.detach().float().cpu().numpy().copy())
@@ -464,6 +466,7 @@ def test_segmented_graphs_equal_the_monolithic_update():
         ag.play_steps()
     for k in mono.dataset:
         segm.dataset[k].copy_(mono.dataset[k])
+    segm._mom_pack.copy_(mono._mom_pack)
     mono.run_update()                    # captures the whole update, then replays it: one real update
     segm.run_update()                    # captures the segments, then replays them: one real update
     torch.cuda.synchronize()
@@ -496,6 +499,12 @@ st = [a.train_epoch() for _ in range(5)]
 assert a._seg is not None and a._g_rollout is not None
 assert all(np.isfinite([s["kl"], s["a_loss"], s["c_loss"]]).all() for s in st), st
 assert all(torch.isfinite(p).all() for p in a.model.parameters())
+calls, real = [], dist.all_reduce
+dist.all_reduce = lambda t, *ar, **k: (calls.append(int(t.numel())), real(t, *ar, **k))[1]
+a.train_epoch()
+dist.all_reduce = real
+steps = a.mini_epochs * a.num_minibatches
+assert len(calls) == steps + 2 and calls[2:] == [a._flat.numel()] * steps, calls   # SURVEY.md 5.8: ONE collective per optimiser step (+ 2 per epoch)
 dist.destroy_process_group()
 print("DP_OK", st[-1]["kl"])
 ''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -100,6 +100,15 @@ def _dp_worker(rank, world, port, out):
         agent.train_epoch()
     flat = torch.cat([p.detach().reshape(-1) for p in agent.model.parameters()])
     out[rank] = (flat.clone(), agent.running_mean_std.running_mean.clone(), agent.last_lr, agent.frame)
+    # SURVEY.md 5.8 / VERDICT round 2 item 5: collectives of ONE more epoch = 2 for the epoch's data-only moments + 1 per optimiser step
+    calls = []
+    real = dist.all_reduce
+    dist.all_reduce = lambda t, *a, **k: (calls.append(int(t.numel())), real(t, *a, **k))[1]
+    try:
+        agent.train_epoch()
+    finally:
+        dist.all_reduce = real
+    out["calls%d" % rank] = (calls, agent.mini_epochs * agent.num_minibatches)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -116,6 +125,12 @@ def test_data_parallel_gloo_world2_replicas_stay_identical():
     assert torch.equal(p0, p1)
     assert torch.equal(m0, m1)
     assert lr0 == lr1 and f0 == f1 == 3 * 8 * 32 * 2
+    calls, steps = out["calls0"]
+    assert out["calls1"][0] == calls
+    assert len(calls) == steps + 2, calls            # one collective per optimiser step + two per epoch (was two per step + three)
+    nparam = p0.numel()
+    assert calls[2:] == [nparam + 1] * steps         # gradient + KL in one message
+    assert calls[1] == 6                             # advantage moments + episode statistics
 
 
 def test_restore_foreign_checkpoint_never_unpickles(tmp_path):
