@@ -1,0 +1,303 @@
+// bez_wgrad.hip -- the weight gradients of a PPO minibatch step as ONE split-K MFMA kernel + one deterministic reduction.
+//
+// rl_games' backward pass (torch autograd through the actor-critic MLP, a2c_common.py calc_gradients [ext] via train.py:89-113)
+// computes dW_L = dY_L^T X_L for the five Linear layers: outputs of 400x54 ... 1x100 elements with a reduction over the
+// 32768 rows of the minibatch.  As GEMM-library calls these are either 7-workgroup launches (108 us each) or, reshaped into a
+// 32-way batched GEMM + a sum (round 2), ~95 us of a 243 us minibatch step.  Here:
+//   * both operands are row-major with the REDUCTION index as the row (dY is (K, out), X is (K, in)), while an MFMA lane wants 8
+//     consecutive k of ONE column: the tiles are staged row-major into LDS with coalesced 16-byte loads and read back through
+//     gfx950's transposing LDS read (ds_read_b64_tr_b16: a 4-row x 16-column block delivered column-major), so neither operand
+//     is ever transposed in memory;
+//   * a workgroup owns one output block (<= 4 x 8 tiles of 32 x 32) of one layer for one K-chunk and keeps it in registers.  The
+//     launch is ONE round of ~250 workgroups on 256 CUs: every block is split along K in proportion to the bytes it has to
+//     stream, so all workgroups carry the same load, and each keeps two stages of its operand stream in flight in registers
+//     (the kernel is a stream of ~150 MB through LDS; what has to be hidden is HBM latency, not MFMA time);
+//   * every workgroup writes its fp32 partial block once; a second small kernel adds a block's splits IN FIXED ORDER straight into
+//     the fp32 master gradient (deterministic -- no float atomics).
+// LDS row strides are chosen so that the four rows of a transposed-read block fall into disjoint bank ranges (stride in bytes
+// = 64 or 192 mod 256, cdna_hip_programming.md T10 / MI355X_MICROARCH.md LDS).
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+
+#include "../../include/bez_sim.h"
+
+namespace {
+
+using half8 = __attribute__((ext_vector_type(8))) _Float16;
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+typedef __fp16 fp16x4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
+
+constexpr int WG_THREADS = 512;   // 8 waves
+constexpr int WG_WAVES = 8;
+constexpr int KT = 64;            // rows of the reduction staged per step
+constexpr int MAX_PARTS = 24;
+constexpr int MAX_TPW = 4;        // output tiles a wave keeps in registers
+constexpr int MAX_UNITS = 4;      // 16-byte slots a thread prefetches per operand and stage
+
+struct Part {
+  const _Float16* g; int ldg, g0, gcols;   // dY (K, ldg): columns [g0, g0 + gcols) = output rows of this block
+  const _Float16* x; int ldx, x0, xcols;   // X  (K, ldx): columns [x0, x0 + xcols) = output columns of this block
+  int gu, xu;                               // load unit (halfs per load: 8, 4, 2 or 1) of the two operands
+  int mt, nt;                               // tiles of 32 along the output rows (1, 2 or 4) and columns (<= 8 * 4 / mt)
+  int gs, xs;                               // LDS row strides in halfs
+  int splits, wg_begin;                     // K-splits of this block, index of its first workgroup
+  long long partial_off;                    // floats: this block's [splits][gcols][xcols] partial images
+  float* dst; int dst_ld;                   // the layer's fp32 gradient (out, in) and its row length
+};
+struct Args {
+  Part part[MAX_PARTS];
+  int nparts, nstage_total;                 // stages of KT rows in the whole reduction
+  float* partial;
+  int accumulate;
+};
+
+// one load unit of U halfs (16, 8, 4 or 2 bytes): the width is a template parameter of the kernel body, so the staging code is
+// straight-line -- with a run-time width every load sat behind a branch and the compiler waited for it (vmcnt(0)) at the join
+template <int U> struct Unit;
+template <> struct Unit<8> { using T = uint4; };
+template <> struct Unit<4> { using T = uint2; };
+template <> struct Unit<2> { using T = uint32_t; };
+template <int U> __device__ __forceinline__ typename Unit<U>::T load_unit(const _Float16* p) { return *reinterpret_cast<const typename Unit<U>::T*>(p); }
+template <int U> __device__ __forceinline__ void store_unit(_Float16* p, typename Unit<U>::T v) { *reinterpret_cast<typename Unit<U>::T*>(p) = v; }
+
+// 8 consecutive k (rows kb .. kb+7 of the LDS image) of column `col` for lane (r, h) of an MFMA operand: two transposed reads.
+// Lane 4q + p of each 16-lane group supplies the address of row q, columns 4p .. 4p+3 of its block; lane i receives column i.
+__device__ __forceinline__ half8 frag_tr(const _Float16* img, int stride, int kb, int colbase, int lane) {
+  const int h = lane >> 5, g1 = (lane >> 4) & 1, q = (lane >> 2) & 3, p = lane & 3;
+  const _Float16* a = img + (size_t)(kb + 8 * h + q) * stride + colbase + 16 * g1 + 4 * p;
+  const fp16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4*)a);
+  const fp16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4*)(a + 4 * (size_t)stride));
+  // (bit copies: __fp16 and _Float16 are the same 16 bits; a value conversion would go through fp32, 16 VALU instructions per fragment)
+  struct Pair { fp16x4 lo, hi; } pr = {lo, hi};
+  return __builtin_bit_cast(half8, pr);
+}
+
+// The body for a block whose waves keep TPW tiles each: branch-free inner loops (a tile slot beyond the block's last column
+// recomputes that last column and is dropped at the end), so that the compiler can issue every LDS read of a k-step ahead of its
+// MFMAs.  Pipeline per stage t: [global loads of t+2 -> registers] [registers of t+1 -> LDS buffer (t+1) & 1] [MFMAs on buffer t & 1]
+// [ONE barrier].
+template <int TPW, int GU, int XU>
+__device__ __forceinline__ void wgrad_body(const Args& A, const Part& P, int split, _Float16* lds) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int st_begin = (int)((long long)split * A.nstage_total / P.splits), st_end = (int)((long long)(split + 1) * A.nstage_total / P.splits);
+  const int buf_halfs = KT * (P.gs + P.xs);
+  // tiles of this wave: the waves form an mt x (8 / mt) grid; a wave keeps ONE row of tiles (its A fragment is shared) and every
+  // (8 / mt)-th tile column
+  const int wm = wave % P.mt, wn = wave / P.mt, ncol = WG_WAVES / P.mt;
+  int ncolbase[TPW];
+#pragma unroll
+  for (int s = 0; s < TPW; ++s) { const int n = wn + s * ncol; ncolbase[s] = 32 * (n < P.nt ? n : P.nt - 1); }
+  f32x16 acc[TPW];
+#pragma unroll
+  for (int s = 0; s < TPW; ++s)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[s][e] = 0.f;
+  const int gupr = P.gcols / GU, xupr = P.xcols / XU;   // load units per row
+  const int gunits = KT * gupr, xunits = KT * xupr;
+  // the (row, unit) of every slot of this thread is the same in every stage: global / LDS offsets once, outside the loop.  A slot
+  // beyond the operand's last unit re-reads unit 0 and stores into a per-thread scrap word behind the two buffers: no branches
+  const int scrap = 2 * buf_halfs + tid * 8;
+  int g_src[MAX_UNITS], g_dst[MAX_UNITS], x_src[MAX_UNITS], x_dst[MAX_UNITS];
+#pragma unroll
+  for (int i = 0; i < MAX_UNITS; ++i) {
+    const int idx = tid + i * WG_THREADS;
+    int row = idx / gupr, c = idx - row * gupr;
+    g_src[i] = idx < gunits ? row * P.ldg + P.g0 + c * GU : P.g0; g_dst[i] = idx < gunits ? row * P.gs + c * GU : scrap - 0;
+    row = idx / xupr; c = idx - row * xupr;
+    x_src[i] = idx < xunits ? row * P.ldx + P.x0 + c * XU : P.x0; x_dst[i] = idx < xunits ? KT * P.gs + row * P.xs + c * XU : scrap;
+  }
+  // two stages of the operand stream live in registers (ring of depth 2) and two in LDS: while stage t is multiplied out of one
+  // LDS buffer, stage t+1 is being written into the other and the loads of stage t+2 are in flight
+  typename Unit<GU>::T gr[2][MAX_UNITS];
+  typename Unit<XU>::T xr[2][MAX_UNITS];
+  auto prefetch = [&](int st, typename Unit<GU>::T (&g4)[MAX_UNITS], typename Unit<XU>::T (&x4)[MAX_UNITS]) {
+    const long long k0 = (long long)st * KT;
+    const _Float16* gb = P.g + k0 * P.ldg;
+    const _Float16* xb = P.x + k0 * P.ldx;
+#pragma unroll
+    for (int i = 0; i < MAX_UNITS; ++i) { g4[i] = load_unit<GU>(gb + g_src[i]); x4[i] = load_unit<XU>(xb + x_src[i]); }
+  };
+  auto stage = [&](_Float16* buf, const typename Unit<GU>::T (&g4)[MAX_UNITS], const typename Unit<XU>::T (&x4)[MAX_UNITS]) {
+    // (buffer 1 lies buf_halfs behind buffer 0; the scrap offsets were computed relative to buffer 0)
+    const int shift = (int)(buf - lds);
+#pragma unroll
+    for (int i = 0; i < MAX_UNITS; ++i) {
+      store_unit<GU>(lds + (g_dst[i] >= 2 * buf_halfs ? g_dst[i] : g_dst[i] + shift), g4[i]);
+      store_unit<XU>(lds + (x_dst[i] >= 2 * buf_halfs ? x_dst[i] : x_dst[i] + shift), x4[i]);
+    }
+  };
+  auto multiply = [&](const _Float16* buf) {
+    const _Float16* G = buf;
+    const _Float16* X = buf + (size_t)KT * P.gs;
+#pragma unroll
+    for (int kk = 0; kk < KT / 16; ++kk) {
+      const half8 a = frag_tr(G, P.gs, kk * 16, 32 * wm, lane);   // every lane takes part (the transposed read needs EXEC = all ones)
+      half8 b[TPW];
+#pragma unroll
+      for (int s = 0; s < TPW; ++s) b[s] = frag_tr(X, P.xs, kk * 16, ncolbase[s], lane);
+#pragma unroll
+      for (int s = 0; s < TPW; ++s) acc[s] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b[s], acc[s], 0, 0, 0);
+    }
+  };
+  _Float16* buf0 = lds;
+  _Float16* buf1 = lds + buf_halfs;
+  if (st_begin < st_end) prefetch(st_begin, gr[0], xr[0]);
+  if (st_begin + 1 < st_end) prefetch(st_begin + 1, gr[1], xr[1]);
+  if (st_begin < st_end) stage(buf0, gr[0], xr[0]);
+  if (st_begin + 2 < st_end) prefetch(st_begin + 2, gr[0], xr[0]);
+  __syncthreads();
+  for (int st = st_begin; st < st_end; st += 2) {   // unrolled by the ring depth: register set and LDS buffer of a stage are compile-time choices
+    if (st + 1 < st_end) stage(buf1, gr[1], xr[1]);
+    if (st + 3 < st_end) prefetch(st + 3, gr[1], xr[1]);
+    multiply(buf0);
+    __syncthreads();
+    if (st + 1 < st_end) {
+      if (st + 2 < st_end) stage(buf0, gr[0], xr[0]);
+      if (st + 4 < st_end) prefetch(st + 4, gr[0], xr[0]);
+      multiply(buf1);
+      __syncthreads();
+    }
+  }
+  // partial block: acc register e of lane l = dW[g0 + 32 wm + (e & 3) + 8 (e >> 2) + 4 (l >> 5)][x0 + 32 n + (l & 31)]
+  float* out = A.partial + P.partial_off + (long long)split * P.gcols * P.xcols;
+#pragma unroll
+  for (int s = 0; s < TPW; ++s) {
+    const int n = wn + s * ncol;
+    if (n >= P.nt) continue;
+    const int ci = 32 * n + (lane & 31);
+    if (ci >= P.xcols) continue;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int ri = 32 * wm + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+      if (ri < P.gcols) out[(size_t)ri * P.xcols + ci] = acc[s][e];
+    }
+  }
+}
+
+__global__ void __launch_bounds__(WG_THREADS) wgrad_kernel(Args A) {
+  extern __shared__ __attribute__((aligned(16))) _Float16 lds[];
+  int pi = 0;
+  for (int i = 1; i < A.nparts; ++i) if ((int)blockIdx.x >= A.part[i].wg_begin) pi = i;   // (scalar: <= 24 entries)
+  const Part& P = A.part[pi];
+  const int split = (int)blockIdx.x - P.wg_begin;
+  const int tpw = (P.nt + WG_WAVES / P.mt - 1) / (WG_WAVES / P.mt);   // tile columns per wave of this block
+  const int variant = (tpw <= 1 ? 0 : 2) * 16 + (P.gu == 8 ? 0 : (P.gu == 4 ? 1 : 2)) * 4 + (P.xu == 8 ? 0 : (P.xu == 4 ? 1 : 2));
+  // every (tiles per wave, dY unit, X unit) combination is its own straight-line instantiation
+#define WG_CASE(T, TI, GUV, GI, XUV, XI) case (TI * 16 + GI * 4 + XI): wgrad_body<T, GUV, XUV>(A, P, split, lds); break;
+#define WG_X(T, TI, GUV, GI) WG_CASE(T, TI, GUV, GI, 8, 0) WG_CASE(T, TI, GUV, GI, 4, 1) WG_CASE(T, TI, GUV, GI, 2, 2)
+#define WG_G(T, TI) WG_X(T, TI, 8, 0) WG_X(T, TI, 4, 1) WG_X(T, TI, 2, 2)
+  switch (variant) { WG_G(1, 0) WG_G(4, 2) default: break; }
+#undef WG_G
+#undef WG_X
+#undef WG_CASE
+}
+
+// the splits of every block, added in fixed order into the layer's gradient: grid = (elements of the largest block / 256, blocks)
+__global__ void wgrad_reduce_kernel(Args A) {
+  const Part& P = A.part[blockIdx.y];
+  const int i = blockIdx.x * blockDim.x + threadIdx.x, n = P.gcols * P.xcols;
+  if (i >= n) return;
+  const int r = i / P.xcols, c = i - r * P.xcols;
+  float* d = P.dst + (size_t)(P.g0 + r) * P.dst_ld + P.x0 + c;
+  const float* p = A.partial + P.partial_off + i;
+  float s = A.accumulate ? *d : 0.f;
+  int k = 0;
+  for (; k + 8 <= P.splits; k += 8) {   // eight loads in flight, added in their fixed order: deterministic
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = p[(long long)(k + u) * n];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += v[u];
+  }
+  for (; k < P.splits; ++k) s += p[(long long)k * n];
+  *d = s;
+}
+
+int lds_stride(int cols) {   // halfs: >= cols rounded up to whole tiles, stride bytes = 64 or 192 (mod 256)
+  int c = (cols + 31) / 32 * 32;
+  return ((c / 32) & 1) ? c : c + 32;
+}
+int load_unit_of(const void* base, int ld, int c0, int cols) {   // 0: rows of an odd number of halfs are not taken
+  for (int u = 8; u > 1; u >>= 1)
+    if (cols % u == 0 && c0 % u == 0 && ld % u == 0 && (reinterpret_cast<uintptr_t>(base) % (2 * u)) == 0) return u;
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+/* The weight gradients of `nlayers` Linear layers in one launch pair: dW_L (+)= dY_L^T X_L with dY_L (rows, out_L) and X_L
+ * (rows, in_L) fp16 row-major, dW_L (out_L, in_L) fp32.  partial_dev: scratch of nsplit * sum(out_L * in_L) floats.
+ * rows must be a multiple of 64.  Returns -3 if the shapes do not fit the kernel (the caller keeps its GEMM path). */
+int bez_ppo_wgrad_mfma(const void* const* dy_f16_dev, const void* const* x_f16_dev, const int32_t* out_features, const int32_t* in_features,
+                       float* const* dw_dev, int32_t nlayers, int64_t rows, int32_t nsplit, float* partial_dev, int32_t accumulate, void* stream_) {
+  if (nlayers < 1 || nlayers > 8 || nsplit < 1 || rows <= 0 || rows % KT != 0) return -3;
+  Args A;
+  std::memset(&A, 0, sizeof(A));
+  int np = 0;
+  size_t lds_bytes = 0;
+  long long weight[MAX_PARTS], total_weight = 0, budget = 0;
+  for (int L = 0; L < nlayers; ++L) {
+    const int O = out_features[L], I = in_features[L];
+    if (O < 1 || I < 1) return -3;
+    budget += (long long)nsplit * O * I;                           // the caller's scratch: nsplit images of every gradient
+    const int mtiles = (O + 31) / 32, ntiles = (I + 31) / 32;
+    const int mt = mtiles >= 4 ? 4 : (mtiles >= 2 ? 2 : 1);       // tile rows per block
+    int ntmax = (WG_WAVES / mt) * MAX_TPW;                         // tile columns a block can keep in registers ...
+    if (ntmax > 8) ntmax = 8;                                      // ... and stage with MAX_UNITS 16-byte slots per thread (256 columns)
+    const int nblocks_n = (ntiles + ntmax - 1) / ntmax;
+    const int nt_even = (ntiles + nblocks_n - 1) / nblocks_n;      // balanced column blocks
+    for (int m0 = 0; m0 < mtiles; m0 += mt) {
+      for (int n0 = 0; n0 < ntiles; n0 += nt_even) {
+        if (np >= MAX_PARTS) return -3;
+        Part& P = A.part[np];
+        P.g = static_cast<const _Float16*>(dy_f16_dev[L]); P.ldg = O; P.g0 = 32 * m0; P.gcols = (O - P.g0 < 32 * mt) ? O - P.g0 : 32 * mt;
+        P.x = static_cast<const _Float16*>(x_f16_dev[L]); P.ldx = I; P.x0 = 32 * n0;
+        const int ntp = (ntiles - n0 < nt_even) ? ntiles - n0 : nt_even;
+        P.xcols = (I - P.x0 < 32 * ntp) ? I - P.x0 : 32 * ntp;
+        P.mt = mt; P.nt = ntp;
+        P.gu = load_unit_of(P.g, P.ldg, P.g0, P.gcols); P.xu = load_unit_of(P.x, P.ldx, P.x0, P.xcols);
+        if (P.gu == 0 || P.xu == 0 || KT * (P.gcols / P.gu) > MAX_UNITS * WG_THREADS || KT * (P.xcols / P.xu) > MAX_UNITS * WG_THREADS) return -3;
+        P.gs = lds_stride(32 * mt); P.xs = lds_stride(32 * ntp);
+        P.dst = dw_dev[L]; P.dst_ld = I;
+        const size_t need = 2 * (size_t)KT * (P.gs + P.xs) * sizeof(_Float16) + WG_THREADS * 16;   // two LDS buffers + a scrap slot per thread
+        if (need > lds_bytes) lds_bytes = need;
+        weight[np] = P.gcols + P.xcols;                            // bytes a workgroup of this block streams per row of the reduction
+        total_weight += weight[np];
+        ++np;
+      }
+    }
+  }
+  if (lds_bytes > 160 * 1024) return -3;
+  // K-splits per block in proportion to its stream, ~250 workgroups in all (one round on 256 CUs), within the caller's scratch
+  const int nstage = (int)(rows / KT);
+  const int target_wgs = 250;
+  long long used = 0;
+  int wg = 0;
+  for (int i = 0; i < np; ++i) {
+    Part& P = A.part[i];
+    long long sp = (weight[i] * target_wgs + total_weight / 2) / total_weight;
+    if (sp < 1) sp = 1;
+    if (sp > nstage) sp = nstage;
+    if (sp > nsplit) sp = nsplit;   // the caller's scratch holds nsplit images of every gradient
+    P.splits = (int)sp; P.wg_begin = wg; P.partial_off = used;
+    wg += P.splits;
+    used += (long long)P.splits * P.gcols * P.xcols;
+  }
+  if (used > budget) return -3;
+  A.nparts = np; A.nstage_total = nstage; A.partial = partial_dev; A.accumulate = accumulate;
+  hipStream_t stream = (hipStream_t)stream_;
+  static bool attr_set = false;
+  if (!attr_set) { (void)hipFuncSetAttribute((const void*)wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
+  hipLaunchKernelGGL(wgrad_kernel, dim3(wg), dim3(WG_THREADS), lds_bytes, stream, A);
+  int max_block = 0;
+  for (int i = 0; i < np; ++i) if (A.part[i].gcols * A.part[i].xcols > max_block) max_block = A.part[i].gcols * A.part[i].xcols;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((max_block + 255) / 256, np), dim3(256), 0, stream, A);
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+}  // extern "C"

@@ -791,6 +791,19 @@ class A2CAgent:
                 self._policy_bwd.refresh()
             self._policy_bwd(gmu, gval, tf["act"], tf["gz"], tf["gmu16"], tf["gv16"], [lin[L].bias.grad for L in range(nh)],
                              lin[nh].bias.grad, lin[nh + 1].bias.grad)
+            if self.cfg.get("fused_wgrad", True):
+                # the weight gradients of the hidden layers and of the mu head: one split-K MFMA launch over the output blocks of all
+                # of them + one fixed-order reduction straight into the fp32 master gradient (csrc/bez_wgrad.hip) instead of a batched
+                # GEMM and a sum per layer.  The value head's dY is a single column (rows of one half: no aligned load unit) and stays a GEMM.
+                dys = [tf["gz"][L] for L in range(nh)] + [tf["gmu16"]]
+                xs = [tf["x0"]] + [tf["act"][L] for L in range(nh - 1)] + [h_last]
+                grads = [lin[L].weight.grad for L in range(nh + 1)]
+                wg = getattr(self, "_wgrad_mfma", None)
+                if wg is None or not wg.matches(dys, xs, grads):
+                    wg = self._wgrad_mfma = F.WgradMfma(dys, xs, grads)
+                if wg.ok and wg(accumulate=True):
+                    wgrad(tf["gv16"], h_last, lin[nh + 1])
+                    return
             wgrad(tf["gmu16"], h_last, lin[nh])
             wgrad(tf["gv16"], h_last, lin[nh + 1])
             for L in range(nh - 1, -1, -1):

@@ -28,6 +28,7 @@ _SIGS = {
     "bez_ppo_gae": [_vp, _vp, _vp, _vp, _vp, _i32, _i64, _f, _f, _vp, _vp, _vp],
     "bez_ppo_head_grads_f16": [_vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp],
     "bez_ppo_wgrad_sum": [_vp, _i32, _i64, _vp, _i32, _vp],
+    "bez_ppo_wgrad_mfma": [_vp, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _vp, _i32, _vp],
     "bez_ppo_colsum_f16": [_vp, _i64, _i32, _vp, _i32, _vp],
     "bez_ppo_elu_bwd_colsum_f16": [_vp, _vp, _vp, _i64, _i32, _vp, _i32, _vp],
     "bez_ppo_adam_step": [_vp, _vp, _vp, _vp, _i64, _vp, _i32, _vp, _f, _f, _f, _f, _f, _vp, _vp, _f, _f, _i32, _vp, _vp, _vp],
@@ -137,6 +138,40 @@ def wgrad_sum(partials, out, accumulate=False):
     s_, n = partials.shape[0], out.numel()
     assert partials.numel() == s_ * n and out.is_contiguous()
     _chk(lib().bez_ppo_wgrad_sum(_p(partials, torch.float16), s_, n, _p(out), 1 if accumulate else 0, _stream(out)), "bez_ppo_wgrad_sum")
+
+
+class WgradMfma:
+    """dW_L (+)= dY_L^T X_L for all Linear layers of the MLP in ONE split-K MFMA launch + one deterministic reduction
+    (csrc/bez_wgrad.hip).  Pointer tables are built once per set of tensors; `ok` is False when the kernel does not take the
+    shapes (the caller then keeps its GEMM path)."""
+    NSPLIT = 32
+
+    def __init__(self, dys, xs, grads):
+        n = len(dys)
+        rows = dys[0].shape[0]
+        assert all(t.dtype == torch.float16 and t.is_contiguous() and t.shape[0] == rows for t in list(dys) + list(xs))
+        assert all(g.dtype == torch.float32 and g.is_contiguous() and g.shape == (dy.shape[1], x.shape[1]) for g, dy, x in zip(grads, dys, xs))
+        self.keep = (list(dys), list(xs), list(grads))
+        self.n, self.rows = n, rows
+        self.dy = (C.c_void_p * n)(*[t.data_ptr() for t in dys]); self.x = (C.c_void_p * n)(*[t.data_ptr() for t in xs])
+        self.dw = (C.c_void_p * n)(*[t.data_ptr() for t in grads])
+        self.of = (C.c_int32 * n)(*[t.shape[1] for t in dys]); self.inf = (C.c_int32 * n)(*[t.shape[1] for t in xs])
+        total = sum(g.numel() for g in grads)
+        self.ok = rows % 64 == 0
+        self.partial = torch.empty(self.NSPLIT * total, device=dys[0].device, dtype=torch.float32) if self.ok else None
+
+    def matches(self, dys, xs, grads):
+        k = self.keep
+        return all(a.data_ptr() == b.data_ptr() for a, b in zip(list(dys) + list(xs) + list(grads), k[0] + k[1] + k[2]))
+
+    def __call__(self, accumulate=True):
+        rc = lib().bez_ppo_wgrad_mfma(self.dy, self.x, self.of, self.inf, self.dw, self.n, self.rows, self.NSPLIT, _p(self.partial),
+                                      1 if accumulate else 0, _stream(self.partial))
+        if rc == -3:
+            self.ok = False
+            return False
+        _chk(rc, "bez_ppo_wgrad_mfma")
+        return True
 
 
 def colsum_f16(y, out, accumulate=False):

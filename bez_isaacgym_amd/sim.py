@@ -72,6 +72,7 @@ EXPORTS = ["bez_sim_default_config", "bez_sim_create", "bez_sim_destroy", "bez_s
            "bez_sim_set_obs_calls", "bez_sim_pre_physics", "bez_sim_simulate", "bez_sim_post_physics", "bez_sim_observe_reward", "bez_sim_step",
            "bez_sim_step_many", "bez_sim_reset_indexed", "bez_sim_set_env_params", "bez_sim_get_env_params", "bez_sim_set_randomization", "bez_sim_add_dr_noise", "bez_sim_seed", "bez_sim_time_steps",
            "bez_sim_calibrate"]
+# (the bez_ppo_* entry points of the same library are bound in ppo/fused.py)
 
 
 class _DevView:

@@ -328,6 +328,14 @@ int bez_ppo_policy_forward_train(const float* obs_dev, int64_t n, int32_t num_ob
  * products ([splits][n] fp16) and the bias gradient = column sums of dY ((rows, cols) fp16).  accumulate != 0 adds to out_dev. */
 int bez_ppo_wgrad_sum(const void* partials_f16_dev, int32_t splits, int64_t n, float* out_dev, int32_t accumulate, void* stream);
 int bez_ppo_colsum_f16(const void* y_f16_dev, int64_t rows, int32_t cols, float* out_dev, int32_t accumulate, void* stream);
+/* The weight gradients of `nlayers` (<= 8) Linear layers in one launch pair (csrc/bez_wgrad.hip): dW_L (+)= dY_L^T X_L with dY_L
+ * (rows, out_L) and X_L (rows, in_L) fp16 row-major, dW_L (out_L, in_L) fp32 (accumulate != 0 adds).  A split-K MFMA kernel over
+ * the output blocks of all layers -- each split along the rows in proportion to the bytes it streams, ~250 workgroups in all --
+ * writes fp32 partial blocks into partial_dev (room for nsplit * sum(out_L * in_L) floats; it uses what the balance needs), a
+ * second kernel adds a block's splits in fixed order (deterministic).  rows % 64 must be 0; -3 = shapes the kernel does not
+ * take (the caller keeps its GEMM path).  Replaces torch.bmm + bez_ppo_wgrad_sum of a2c_common.py's backward [ext]. */
+int bez_ppo_wgrad_mfma(const void* const* dy_f16_dev, const void* const* x_f16_dev, const int32_t* out_features, const int32_t* in_features,
+                       float* const* dw_dev, int32_t nlayers, int64_t rows, int32_t nsplit, float* partial_dev, int32_t accumulate, void* stream);
 /* ELU (alpha 1) backward fused with the bias gradient: gz = gy * elu'(y) from the layer's ELU OUTPUT y, all (rows, cols) fp16;
  * the column sums of gz go to bias_grad_dev (fp32, cols). */
 int bez_ppo_elu_bwd_colsum_f16(const void* gy_f16_dev, const void* y_f16_dev, void* gz_f16_dev, int64_t rows, int32_t cols, float* bias_grad_dev,

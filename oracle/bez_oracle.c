@@ -374,7 +374,7 @@ static void self_collision(const BezSimConfig* c, real mu, const Kin* k, const S
     segment_closest(a0, a1, b0, b1, &ca, &cb);
     V3 dl = v3sub(ca, cb);
     real d2 = v3dot(dl, dl);
-    real rs = (real)BEZ_CAP_R[ia] + (real)BEZ_CAP_R[ib];
+    real rs = (real)BEZ_CAP_R[ia] + (real)BEZ_CAP_R[ib] + ((c->flags & BEZ_FLAG_HARD_CONTACT) ? 2 * (real)c->tune[6] : 0); /* EXPERIMENT: shape rest offsets */
     if (!(d2 < rs * rs) || !(d2 > (real)1e-12)) continue;
     real dist = sqrt(d2), depth = rs - dist;
     V3 n = v3scale(dl, 1 / dist);                                         /* from capsule b towards capsule a */

@@ -28,6 +28,13 @@ def test_exports_match_header(lib):
     assert declared == set(EXPORTS)
     for name in declared:
         assert hasattr(lib, name), name
+    # the PPO glue kernels of the same header / library: every declared entry point is exported and bound (ppo/fused.py)
+    ppo = set(re.findall(r"\b(bez_ppo_[a-z_0-9]+)\s*\(", hdr))
+    assert len(ppo) >= 20
+    from bez_isaacgym_amd.ppo.fused import _SIGS
+    assert ppo == set(_SIGS), ppo ^ set(_SIGS)
+    for name in ppo:
+        assert hasattr(lib, name), name
 
 
 def test_default_config_matches_python(lib):

@@ -510,3 +510,49 @@ print("DP_OK", st[-1]["kl"])
 ''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert "DP_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
+@pytest.mark.parametrize("rows,shapes", [
+    (32768, [(400, 54), (200, 400), (100, 200), (18, 100)]),               # bez_kickPPO.yaml: 54-400-200-100 + the mu head
+    (4096, [(64, 32), (30, 416), (136, 72), (4, 50)]),                      # partial tiles, a block of 8 columns, 2- and 4-half load units
+    (2048, [(416, 416)]),                                                  # the widest layer the policy kernels take
+])
+def test_wgrad_mfma_matches_fp32_reference(rows, shapes):
+    """bez_ppo_wgrad_mfma (csrc/bez_wgrad.hip): dW_L += dY_L^T X_L for all layers in one split-K MFMA launch + one fixed-order
+    reduction, against the fp32 product of the same fp16 operands; asymmetric integer-valued data first (any row / column or
+    k-order mix-up of the transposed LDS reads shows as an exact mismatch), then random data; twice the same bits (deterministic)."""
+    from bez_isaacgym_amd.ppo import fused as F
+    g = torch.Generator(device=DEV); g.manual_seed(3)
+    for mode in ("integer", "random"):
+        dys, xs, grads, refs = [], [], [], []
+        for (o, i) in shapes:
+            if mode == "integer":   # small integers: every partial sum is exact in fp32, the result must match bit for bit
+                dy = torch.randint(-2, 3, (rows, o), device=DEV, generator=g).to(torch.float16)
+                x = (torch.randint(-2, 3, (rows, i), device=DEV, generator=g) + (torch.arange(i, device=DEV) % 3 == 0)).to(torch.float16)
+            else:
+                dy = (torch.randn(rows, o, device=DEV, generator=g) * 1e-2).to(torch.float16)
+                x = torch.randn(rows, i, device=DEV, generator=g).to(torch.float16)
+            base = torch.randn(o, i, device=DEV, generator=g)
+            dys.append(dy); xs.append(x); grads.append(base.clone()); refs.append(base.double() + dy.double().t() @ x.double())
+        wg = F.WgradMfma(dys, xs, grads)
+        assert wg.ok and wg(accumulate=True)
+        torch.cuda.synchronize()
+        for gr, ref, (o, i) in zip(grads, refs, shapes):
+            if mode == "integer":
+                assert torch.equal((gr.double() - ref).abs() < 1e-3 * (1 + ref.abs()), torch.ones_like(ref, dtype=torch.bool)), (o, i, float((gr.double() - ref).abs().max()))
+            else:
+                err = (gr.double() - ref).abs().max()
+                assert float(err) < 2e-3 * float(ref.abs().max() + 1), (o, i, float(err))
+        first = [gr.clone() for gr in grads]
+        for gr, b in zip(grads, refs):
+            gr.zero_()
+        assert wg(accumulate=False)
+        again = [gr.clone() for gr in grads]
+        assert wg(accumulate=False)
+        torch.cuda.synchronize()
+        assert all(torch.equal(a, b) for a, b in zip(again, grads))    # fixed-order reduction: bit-identical run to run
+    # rows of an odd number of halfs have no aligned load unit (the value head's dY is one column): refused, the caller keeps
+    # its GEMM path (bez_ppo_wgrad_mfma returns -3)
+    odd = F.WgradMfma([torch.zeros(2048, 1, device=DEV, dtype=torch.float16)], [torch.zeros(2048, 100, device=DEV, dtype=torch.float16)],
+                      [torch.zeros(1, 100, device=DEV)])
+    assert odd.ok and odd(accumulate=False) is False and not odd.ok
