@@ -193,6 +193,7 @@ def main():
                     "'PPO samples/s' half of BASELINE.json's metric (0 = skip)")
     ap.add_argument("--launch", choices=["python", "c"], default="python",
                     help="python: one bez_sim_step call per step from Python; c: bez_sim_step_many (C loop)")
+    ap.add_argument("--keep-aux", action="store_true", help="keep NET_CONTACT_FORCE / FEET / PREV_LIN_VEL current every step (no BEZ_FLAG_LEAN_STEP)")
     ap.add_argument("--randomize", action="store_true", help="PPO leg with task.randomize=True (BASELINE.json configs[4]: domain-randomised "
                     "friction / gains / limits / gravity + observation and action noise, redrawn on the device at reset time)")
     ap.add_argument("--stub-cpu", action="store_true", help="launcher self-test: gloo on the CPU, the env step replaced by a no-op "
@@ -221,7 +222,12 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     n = args.num_envs
-    sim = BezSim(abi.default_config(n, seed=42, env_id_offset=rank * n), local_rank)
+    cfg = abi.default_config(n, seed=42, env_id_offset=rank * n)
+    if not args.keep_aux:
+        # the rollout reads obs / reward / reset only: BEZ_FLAG_LEAN_STEP skips the Isaac-visible extras nothing on this path reads
+        # (net contact force rows, feet, prev_lin_vel: 308 of the 912 B an env-step writes; the obs' feet flags are unaffected)
+        cfg.flags |= abi.FLAG_LEAN_STEP
+    sim = BezSim(cfg, local_rank)
     gen = torch.Generator(device=dev)
     gen.manual_seed(1000 + rank)
     actions = (torch.rand(ACTION_RING, n * 18, device=dev, generator=gen) * 2 - 1).contiguous()
@@ -296,7 +302,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": "bez_kick num_envs=%d per GPU, random-action rollout only (no PPO), dt=1/60 s x 2 substeps, "
                                    "natural resets included" % n,
-                       "envs_per_gpu": n, "total_envs": total_envs, "launch": args.launch, "parallelism": "env-sharded x%d" % world},
+                       "envs_per_gpu": n, "total_envs": total_envs, "launch": args.launch, "parallelism": "env-sharded x%d" % world,
+                       "lean_step": not args.keep_aux},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "bez::w8::step_kernel_ws8<true,true,false,false> (fused control step, default asset, 8 role waves per 64 envs)", "kernel_ms": kernel_ms,

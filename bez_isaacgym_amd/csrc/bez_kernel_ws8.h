@@ -494,7 +494,7 @@ BEZ_DEV void post_imu_orn(const Params& P, float* lds, int lane, int e, bool act
   float* obs_row = lds + X_STAGE * WS_ENVS + lane * P.nobs;
 #pragma unroll
   for (int i = 0; i < 8; ++i) obs_row[36 + i] = tail[i];
-  if (active) {
+  if (active && !P.lean) {
 #pragma unroll
     for (int i = 0; i < 3; ++i) st[(size_t)(F_PREV + i) * n + e] = prev[i];
   }
@@ -527,7 +527,7 @@ BEZ_DEV void post_feet(const Params& P, float* lds, int lane, int e, bool active
   if (!CL) {  // the no-cleats feet logic filters the two foot rows in place (kick_env.py:987-990)
     xs_store_v3(lds, lane, X_CF + BEZ_LFOOT_BODY * 3, co.lf); xs_store_v3(lds, lane, X_CF + BEZ_RFOOT_BODY * 3, co.rf);
   }
-  if (active) {
+  if (active && !P.lean) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) st[(size_t)(F_FEET + i) * n + e] = feet[i];
   }
@@ -692,6 +692,7 @@ BEZ_DEV void root_role(const Params& P, float* lds, int lane, int e, bool active
   // reward and the reset flag of the next step, beside the other waves' copy-out.
   float goal_x = P.goal[0], goal_y = P.goal[1];
   int64_t timeout = 0;
+  bool new_episode = false;
   if (POST) {
     if (P.task != BEZ_TASK_KICK) { goal_x = ld(F_GOAL); goal_y = ld(F_GOAL + 1); }
     timeout = (progress >= (int64_t)(P.max_len - 1)) ? 1 : 0;  // vec_task.py:331-332
@@ -702,7 +703,7 @@ BEZ_DEV void root_role(const Params& P, float* lds, int lane, int e, bool active
 #pragma unroll
       for (int i = 0; i < 4; ++i) { rq[i] = P.bez_init[3 + i]; bq[i] = P.ball_init[3 + i]; }
       root_lin = root_ang = ball_lin = ball_ang = mk(0, 0, 0);
-      if (active) P.episode[e] = P.episode[e] + 1;
+      new_episode = true;  // the counter itself is bumped behind the last barrier (below)
       if (P.task != BEZ_TASK_KICK) {  // walk_env.py:570-575: every env reset by this call receives the same fresh goal
         goal_x = reset_goal(P, 0); goal_y = reset_goal(P, 1);
         if (active) { st[(size_t)F_GOAL * n + e] = goal_x; st[(size_t)(F_GOAL + 1) * n + e] = goal_y; }
@@ -724,6 +725,10 @@ BEZ_DEV void root_role(const Params& P, float* lds, int lane, int e, bool active
   WS_STAMP(3, 19);
   ws_barrier();  // B5 of the last substep = the last barrier
   WS_STAMP(3, 9 + 8 * (P.substeps - 1));
+  // The chain roles key their reset draw with P.episode[e] / P.reset[e], loaded before B4 and CONSUMED (hence waited for) before
+  // this barrier; ws_barrier() itself does not wait for outstanding global loads (vmcnt), so the two words are only rewritten here,
+  // behind the last barrier -- no reliance on the memory pipeline serving another wave's earlier load before this store.
+  if (POST && active && new_episode) P.episode[e] = P.episode[e] + 1;
   if (POST) {
     const float pn = (((XS(X_PSUM + 2) + XS(X_PSUM + 4)) + XS(X_PSUM + 5)) + XS(X_PSUM + 0)) + XS(X_PSUM + 1);
     OrnOut orn; orn.ux = orn.uy = orn.gn = orn.ang_goal = 0.f;
@@ -773,7 +778,7 @@ __global__ __launch_bounds__(WS_BLOCK) void step_kernel_ws8(Params P) {
   if (role != 3) {
     constexpr int NT = WS_BLOCK - 64;
     const int ctid = tid - (role > 3 ? 64 : 0);
-    {
+    if (!P.lean) {
       // net contact force: SoA rows of 64 consecutive envs each -> coalesced
       float* dst = P.state + (size_t)F_CF * P.n + env0;
       static_assert(NT % WS_ENVS == 0, "a copy-out thread stays on one env lane");

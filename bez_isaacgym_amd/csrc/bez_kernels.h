@@ -47,6 +47,7 @@ struct Params {
   float kp, kd, armature, effort, vel_limit, jfric, mu, clip;
   float bez_init[7], ball_init[7], goal[2];
   float kn, cn, ct, veps, lim_k, lim_d, jf_veps, ball_damp;
+  int lean;        // fused step only: skip the stores of the contact-force rows, the feet flags and prev_lin_vel (BEZ_FLAG_LEAN_STEP)
   float bkn, bcn;  // ball <-> ground / ball <-> robot spring and damper (BezSimConfig.ball_kn / ball_cn, defaulting to kn / cn)
   float self_kn, self_cn;
   float cf_w;  // weight of one substep in the net-contact-force mean (1/substeps, or 1 with BEZ_FLAG_CF_LAST_SUBSTEP)

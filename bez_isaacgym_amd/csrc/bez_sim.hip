@@ -232,6 +232,7 @@ Params make_params(const BezSim* s, const float* actions) {
   std::memset(&P, 0, sizeof(P));
   P.n = s->n; P.substeps = c.substeps; P.max_len = c.max_episode_length;
   P.use_prev = (!(c.flags & BEZ_FLAG_IMU_PREV_ALIAS) || s->obs_calls == 0) ? 1 : 0;
+  P.lean = 0;  // set by launch_step for the fused step only
   P.dt = c.dt; P.h = c.dt / (float)c.substeps;
   {
     float igx = c.goal[0] - c.ball_init[0], igy = c.goal[1] - c.ball_init[1];
@@ -438,6 +439,7 @@ template <bool PRE, bool SIM, bool POST>
 int launch_step(BezSim* s, const float* actions, hipStream_t stream, bool obs_only = false) {
   Params P = make_params(s, actions);
   P.obs_only = obs_only ? 1 : 0;
+  P.lean = (PRE && SIM && POST && !obs_only && (s->cfg.flags & BEZ_FLAG_LEAN_STEP) && (s->cfg.flags & BEZ_FLAG_IMU_PREV_ALIAS) && s->obs_calls > 0) ? 1 : 0;
   if (POST && !obs_only && s->dr_on) launch_dr(s, false, stream);  // reset_idx's apply_randomizations (kick_env.py:781-782), on the device
   if (POST && !obs_only && s->cfg.task != BEZ_TASK_KICK) {  // the reset inside this post_physics_step draws its goal on the device
     goal_draw_kernel<<<1, 1, 0, stream>>>(s->cfg.seed, s->post_calls_dev, s->goal_draw_dev);

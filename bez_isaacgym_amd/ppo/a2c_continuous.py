@@ -348,6 +348,9 @@ class A2CAgent:
         g = c.get("hip_graphs", "auto")
         # an env whose step() syncs with the host or allocates (domain randomisation: vec_task.py:505-725) cannot be captured
         env_graph_safe = bool(getattr(getattr(vec_env, "env", vec_env), "graph_safe", True))
+        # this trainer reads obs / reward / dones only: let the simulator skip the Isaac-visible extras (contact rows, feet, prev_lin_vel)
+        if c.get("lean_env_step", True) and hasattr(getattr(vec_env, "env", vec_env), "set_lean"):
+            getattr(vec_env, "env", vec_env).set_lean(True)
         # world > 1: graphs are captured in SEGMENTS that contain no collective (the RCCL calls run eagerly between replays),
         # which needs the fused path's static flat gradient buffer -> decided below, once `self.fused` is known
         self.use_graphs = bool(on_gpu and env_graph_safe and (g is True or g == "auto"))
@@ -371,6 +374,13 @@ class A2CAgent:
         self._policy_bwd = None
         self._packed = None
         self.fused = bool(on_gpu and c.get("fused_ops", True))
+        if not self.fused and self.mixed_precision and g != True:  # noqa: E712 (an explicit hip_graphs: True is honoured)
+            # The plain torch formulation under AMP (torch's GradScaler + autocast) is run EAGERLY: replayed as HIP graphs it
+            # stops learning after ~500 epochs in 4 of 4 seeds (profiles/r03_learning_plain_full.txt: -0.6 ... -1.5 at 6156 epochs)
+            # while the same path eager reaches 23-32 (r03_learning_plain_eager_1500.txt) and without AMP also under graphs (29.7).
+            # Not root-caused (round 2 only escaped it because its capturing epoch did not execute); the fused path carries its own
+            # device-side loss scaling (bez_ppo_adam_step) and is unaffected (8 of 8 seeds).
+            self.use_graphs = False
         if self.fused:
             from . import fused as F
             self._F = F
@@ -499,7 +509,13 @@ class A2CAgent:
                            mb["rew"][n], self.dones, self.current_rewards, self.current_lengths, self.ep_stats)
             o = obs_dict["obs"]
             if o.dtype == torch.float32 and o.is_contiguous() and o.device == self.obs.device:
-                cur = o  # the env's persistent buffer (vec_task.py _clipped_obs): valid until the next step()
+                # the env's persistent buffer (vec_task.py _clipped_obs): valid until the next step().  Under a HIP graph this
+                # branch is resolved ONCE, at capture: the replays read whatever address was seen then, so the env must hand back
+                # the same buffer on every step (host-side pointer compare, no sync)
+                if n == 0:
+                    self._env_obs_ptr = o.data_ptr()
+                assert o.data_ptr() == self._env_obs_ptr, "the env returned a different observation buffer within one rollout"
+                cur = o
             else:
                 self.obs.copy_(o); cur = self.obs
         if cur is not self.obs:

@@ -160,8 +160,9 @@ class VecTask(Env):
     def _clipped_obs(self):
         """vec_task.py:347: clamp(obs_buf, +-clipObservations).to(rl_device).  With the default clipObservations = inf the clamp
         is the identity: the simulator's own buffer is returned (zero-copy, valid until the next step()) instead of a
-        full-tensor copy per control step."""
-        if np.isinf(self.clip_obs):
+        full-tensor copy per control step.  A consumer that keeps obs_dict["obs"] across step() calls sets
+        env.copyObservations: True in the task config to get the reference's fresh tensor per step."""
+        if np.isinf(self.clip_obs) and not self.cfg["env"].get("copyObservations", False):
             return self.obs_buf.to(self.rl_device)
         return torch.clamp(self.obs_buf, -self.clip_obs, self.clip_obs).to(self.rl_device)
 

@@ -129,6 +129,20 @@ class KickEnv(VecTask):
         if self.randomize:
             self.apply_randomizations(self.randomization_params)
 
+    # ---- lean stepping: a consumer that reads only obs / reward / reset (a PPO rollout) may tell the simulator not to keep the
+    # net-contact-force rows, self.feet and prev_lin_vel current (BEZ_FLAG_LEAN_STEP: 308 of the 912 bytes an env-step writes)
+    def set_lean(self, on):
+        f = int(self.sim.cfg.flags)
+        f = (f | abi.FLAG_LEAN_STEP) if on else (f & ~abi.FLAG_LEAN_STEP)
+        self.sim.cfg.flags = f
+        self.sim.set_flags(f)
+        self._lean = bool(on)
+
+    def _not_lean(self, what):
+        if getattr(self, "_lean", False):
+            raise RuntimeError("%s is not kept current while the env steps lean (BEZ_FLAG_LEAN_STEP): call env.set_lean(False) and "
+                               "step again before reading it" % what)
+
     # ---- Isaac-layout tensors and the reference's views of them (kick_env.py:143-196), refreshed lazily
     def _refresh_all(self):
         if self._stale:
@@ -150,6 +164,7 @@ class KickEnv(VecTask):
 
     @property
     def net_contact_forces(self):
+        self._not_lean("net_contact_forces")
         self._refresh_all(); return self.sim.tensor(abi.TENSOR_NET_CONTACT_FORCE)
 
     dof_pos_bez = property(lambda s: s.dof_state.view(s.num_envs, 18, 2)[..., 0])
@@ -171,8 +186,8 @@ class KickEnv(VecTask):
     def goal(self):
         """(N,2) goal: constant for bez_kick; bez_walk / bez_orient redraw it inside reset_idx (walk_env.py:570-575)."""
         return self._goal_cfg if self.HAS_BALL else self.sim.refresh(abi.TENSOR_GOAL)
-    prev_lin_vel = property(lambda s: s.sim.refresh(abi.TENSOR_PREV_LIN_VEL))
-    feet = property(lambda s: s.sim.refresh(abi.TENSOR_FEET))
+    prev_lin_vel = property(lambda s: (s._not_lean("prev_lin_vel"), s.sim.refresh(abi.TENSOR_PREV_LIN_VEL))[1])
+    feet = property(lambda s: (s._not_lean("feet"), s.sim.refresh(abi.TENSOR_FEET))[1])
 
     # ---- step
     @property

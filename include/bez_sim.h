@@ -62,6 +62,12 @@ extern "C" {
 #define BEZ_FLAG_HARD_CONTACT 64u /* rigid contact: velocity-level impulses with Coulomb stiction and restitution 0 (projected Gauss-Seidel on \
                                      the articulated-body impulse responses) instead of the implicit spring-dampers; knobs in `tune` */
 
+#define BEZ_FLAG_LEAN_STEP 128u /* bez_sim_step / bez_sim_step_many keep only what the rollout reads (state, obs, reward, reset / progress / \
+                                   timeout, DOF targets): the stores of the NET_CONTACT_FORCE rows, FEET and PREV_LIN_VEL -- 308 B of the \
+                                   912 B an env-step writes -- are skipped, and those three tensors then hold the values of the last call \
+                                   without the flag.  The feet flags inside the observation are unaffected (computed from the in-kernel \
+                                   forces).  Needs BEZ_FLAG_IMU_PREV_ALIAS (prev_lin_vel is then never read back). */
+
 /* Tasks sharing the robot, the physics and the tensor API; they differ in the post-physics logic (observation tail,
  * reward, reset conditions, goal sampling) and in the ball actor (bez_kick only). */
 #define BEZ_TASK_KICK 0   /* tasks/kick_env.py    54 obs, ball + goal point                              */

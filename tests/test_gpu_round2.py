@@ -286,19 +286,37 @@ def test_player_loads_reference_policy_fixture():
     assert a.shape == (4, 18) and float(a.abs().max()) <= 1.0
 
 
+_S2S = {}
+
+
+def _reference_policy_rollout():
+    if not _S2S:
+        import sys
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        from sim2sim_gpu import evaluate
+        from bez_isaacgym_amd.utils.player import PpoPlayerContinuous
+        player = PpoPlayerContinuous(os.path.join(ROOT, "tests", "golden", "bez_kick_33_policy.npz"), "cuda:0")
+        _S2S.update(evaluate(player, None, n=4096, steps=900, seed=1))
+        print("reference policy in the HIP sim:", {k: v for k, v in _S2S.items() if k not in ("obs_z", "obs_std_ratio")})
+    return _S2S
+
+
+@pytest.mark.xfail(strict=True, reason="DESIGN.md 6.1: the un-pinned physics does not reproduce PhysX for this policy (1.7 % goals, return -1.0; "
+                   "PhysX 87.55).  The bars below are the ACCEPTANCE level of the round-2 review; strict: reaching them must be noticed")
+def test_reference_policy_reaches_physx_level():
+    """The acceptance test of the physics: the reference's shipped policy, which scores 87.55 under PhysX,
+    played in 4096 HIP envs: goal rate >= 0.5, mean return >= 40, observation statistics within 2 sigma of the checkpoint's."""
+    r = _reference_policy_rollout()
+    assert r["goal_rate"] >= 0.5 and r["mean_return"] >= 40.0 and np.abs(np.asarray(r["obs_z"])[:52]).max() < 2.0
+
+
 def test_reference_policy_in_hip_sim():
     """the reference's shipped policy (Bez_Kick_33, 87.55 mean reward under PhysX) played deterministically
     (utils/players.py:46-66) in 4096 HIP envs for a whole 900-step horizon.  This is the only reference-held evidence that
     can speak about the un-pinned physics.  MEASURED outcome: it kicks the ball (about 1 m/s after 5
-    control steps, as under PhysX) but loses its balance about 50 steps later, before the ball reaches the goal.  The
-    assertions pin what this build actually reaches, so a physics regression (or an improvement) shows up here."""
-    import sys
-    sys.path.insert(0, os.path.join(ROOT, "tools"))
-    from sim2sim_gpu import evaluate
-    from bez_isaacgym_amd.utils.player import PpoPlayerContinuous
-    player = PpoPlayerContinuous(os.path.join(ROOT, "tests", "golden", "bez_kick_33_policy.npz"), "cuda:0")
-    r = evaluate(player, None, n=4096, steps=900, seed=1)
-    print("reference policy in the HIP sim:", {k: v for k, v in r.items() if k not in ("obs_z", "obs_std_ratio")})
+    control steps, as under PhysX) but loses its balance about 50 steps later, before the ball reaches the goal.  These
+    assertions are only a REGRESSION FLOOR of what the build reaches today (the acceptance bars are the xfail test above)."""
+    r = _reference_policy_rollout()
     assert r["episodes"] > 4096
     assert 35.0 < r["mean_length"] < 900.0          # PhysX: ~112 steps to the goal; here ~50 until it falls
     assert r["goal_rate"] >= 0.01                    # PhysX: essentially always

@@ -153,3 +153,32 @@ def test_dr_noise_kernel_statistics_and_schedule():
     c = torch.zeros_like(a)
     g.sim.add_dr_noise(c, 1)
     assert not torch.equal(a, c) and abs(float((a * c).mean())) < 2e-5
+
+
+def test_lean_step_changes_nothing_the_rollout_reads():
+    """BEZ_FLAG_LEAN_STEP: the fused step skips the stores of the contact-force rows, FEET and PREV_LIN_VEL (308 B / env-step).
+    State, observations (incl. the feet flags, computed from the in-kernel forces), reward and bookkeeping stay bit-identical;
+    the three tensors freeze at their last non-lean values."""
+    from bez_isaacgym_amd import abi
+    from tests.sim_adapter import SimAdapter
+    n = 300
+    a = SimAdapter(abi.default_config(n, seed=5))
+    c = abi.default_config(n, seed=5); c.flags |= abi.FLAG_LEAN_STEP
+    b = SimAdapter(c)
+    rng = np.random.default_rng(1)
+    frozen = None
+    for t in range(40):
+        act = rng.uniform(-1, 1, (n, 18)).astype(np.float32)
+        a.step(act); b.step(act)
+        np.testing.assert_array_equal(b.obs, a.obs)
+        np.testing.assert_array_equal(b.rew, a.rew)
+        np.testing.assert_array_equal(b.reset_buf, a.reset_buf); np.testing.assert_array_equal(b.progress_buf, a.progress_buf)
+        np.testing.assert_array_equal(b.root_states, a.root_states); np.testing.assert_array_equal(b.dof_state, a.dof_state)
+        np.testing.assert_array_equal(b.targets, a.targets)
+        if t == 0:
+            np.testing.assert_array_equal(b.contact_forces, a.contact_forces)   # the process's first step is never lean (prev_lin_vel is read back once)
+            frozen = b.contact_forces
+        else:
+            np.testing.assert_array_equal(b.contact_forces, frozen)
+    assert np.abs(a.contact_forces - frozen).max() > 1.0
+    assert a.obs[:, 44:52].max() == 1.0 and a.obs[:, 44:52].min() == -1.0

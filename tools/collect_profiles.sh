@@ -1,8 +1,8 @@
 #!/bin/bash
 # Runs on the GPU box (gpurun): bench line, rocprofv3 kernel stats, and the HBM / SQ counters in their own passes.
-# usage: bash tools/collect_profiles.sh r02      (raw output under gpurun_out/<tag>_*; summarise with tools/summarize_profiles.py)
+# usage: bash tools/collect_profiles.sh r03      (raw output under gpurun_out/<tag>_*; summarise with tools/summarize_profiles.py)
 set -e
-TAG=${1:-r02}
+TAG=${1:-r03}
 export TMPDIR=/tmp
 O=gpurun_out
 B="python3 bench.py --steps 1000 --warmup 100 --no-cpu-baseline --ppo-epochs 0"
@@ -17,6 +17,8 @@ rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/${TAG}_cal_w
 # size sweep (1 / 8 / 64 / 256 workgroups): separates the per-launch fixed part of FETCH_SIZE (the instruction stream, once per XCD L2) from the per-env part
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/${TAG}_sweep_fetch -- python3 tools/pmc_probe.py > $O/${TAG}_sweep_fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/${TAG}_sweep_write -- python3 tools/pmc_probe.py > $O/${TAG}_sweep_write.log 2>&1
+# the PPO leg (BASELINE.json configs[2]): kernel stats of 10 + 4 epochs
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_ppo_stats -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline > $O/${TAG}_ppo_stats.log 2>&1
 # keep only the CSVs the summary needs (the merge back is capped at 64 MiB)
 find $O -name "*agent_info.csv" -delete
 echo collected

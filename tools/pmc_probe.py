@@ -8,7 +8,9 @@ import torch
 from bez_isaacgym_amd import abi
 from bez_isaacgym_amd.sim import BezSim
 for n in (64, 512, 4096, 16384):
-    sim = BezSim(abi.default_config(n, seed=1), 0)
+    cfg = abi.default_config(n, seed=1)
+    cfg.flags |= abi.FLAG_LEAN_STEP  # as bench.py's rollout: only what the rollout reads is stored
+    sim = BezSim(cfg, 0)
     act = (torch.rand(8, n * 18, device="cuda") * 2 - 1).contiguous()
     for t in range(24):  # summarize_profiles.py drops the first 4 launches per size
         sim.step(act[t % 8])

@@ -72,7 +72,7 @@ def size_sweep(directory, counter):
 
 
 def main():
-    tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
     src = os.path.join(ROOT, "gpurun_out")
     out_dir = os.path.join(ROOT, "profiles")
     from bez_isaacgym_amd.build import source_hash
@@ -91,6 +91,14 @@ def main():
             if KERNEL in r[0]:
                 kernel_name, avg_ns = r[0], float(r[3])
                 break
+    fp = _one(os.path.join(src, tag + "_ppo_stats", "**", "*kernel_stats.csv"))
+    if fp:
+        rows = list(csv.reader(open(fp)))
+        with open(os.path.join(out_dir, tag + "_ppo_kernel_stats.csv"), "w", newline="") as g:
+            w = csv.writer(g)
+            for r in rows[:40]:
+                r[0] = r[0][:110]
+                w.writerow(r)
     # 2. PMC
     res = {"kernel": kernel_name, "kernel_avg_ns_rocprofv3": avg_ns, "num_envs": 4096, "git_rev": rev, "source_hash": source_hash(),
            "commands": open(os.path.join(ROOT, "tools", "collect_profiles.sh")).read().splitlines()}
@@ -126,8 +134,8 @@ def main():
                "one_workgroup_launch_raw_bytes": sw_r.get(64) and sw_r[64] * 1024,
                "per_env_read_bytes_raw": per_env_raw, "per_env_read_bytes_corrected": per_env_raw * rf,
                "per_env_write_bytes": sw_w and sw_w[4096] * 1024 * wf / 4096,
-               "kernel_stores_per_env": {"state 62 f32": 248, "dof targets": 72, "prev_lin_vel": 12, "net contact force 22x3": 264, "feet flags 8": 32,
-                                         "obs 54": 216, "reward": 4, "reset/progress/timeout": 24, "sum": 872},
+               "kernel_stores_per_env": {"state 62 f32": 248, "dof targets": 72, "obs 54": 216, "reward": 4, "reset/progress/timeout": 24, "sum": 564,
+                                         "skipped under BEZ_FLAG_LEAN_STEP (bench.py default)": {"prev_lin_vel": 12, "net contact force 22x3": 264, "feet flags 8": 32}},
                "algorithmic_read_per_env": 336, "algorithmic_write_per_env": 492}
         res["attribution"] = att
         if fetch and write and code and abs(fixed_raw - code) < 0.05 * code:
