@@ -200,7 +200,7 @@ __global__ void __launch_bounds__(DR_THREADS) dr_kernel(DrArgs A) {
 }
 
 // vec_task.py:544-618 noise lambdas: x += mean + std * N(0,1); 4 elements per thread from one Philox block (two Box-Muller pairs)
-__global__ void dr_noise_kernel(float* __restrict__ x, long long n, const DrState* __restrict__ st, int which, uint64_t seed, int64_t env_off) {
+__global__ void dr_noise_kernel(const float* x, float* y, long long n, const DrState* __restrict__ st, int which, uint64_t seed, int64_t env_off) {
   const long long i4 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i4 * 4 >= n) return;
   const float mean = st->noise[2 * which], sd = st->noise[2 * which + 1];
@@ -212,7 +212,7 @@ __global__ void dr_noise_kernel(float* __restrict__ x, long long n, const DrStat
   for (int k = 0; k < 4; ++k) u[k] = (float)(c[k] >> 8) * (1.0f / 16777216.0f);
   float r0 = sqrtf(-2.0f * logf(1.0f - u[0])), r1 = sqrtf(-2.0f * logf(1.0f - u[2]));
   float z[4] = {r0 * cosf(6.2831853f * u[1]), r0 * sinf(6.2831853f * u[1]), r1 * cosf(6.2831853f * u[3]), r1 * sinf(6.2831853f * u[3])};
-  for (int k = 0; k < 4; ++k) if (i4 * 4 + k < n) x[i4 * 4 + k] += fmaf(z[k], sd, mean);
+  for (int k = 0; k < 4; ++k) if (i4 * 4 + k < n) y[i4 * 4 + k] = x[i4 * 4 + k] + fmaf(z[k], sd, mean);
 }
 
 void launch_dr(BezSim* s, bool first, hipStream_t stream) {
@@ -762,11 +762,11 @@ int bez_sim_get_env_params(BezSim* s, int param, float* out_dev, void* stream_) 
   return 0;
 }
 
-int bez_sim_add_dr_noise(BezSim* s, float* x_dev, int64_t n, int32_t which, void* stream_) {
-  if (!s || !x_dev || n < 0 || which < 0 || which > 1) return fail(s, -1, "bez_sim_add_dr_noise: bad argument");
+int bez_sim_add_dr_noise(BezSim* s, const float* x_dev, float* y_dev, int64_t n, int32_t which, void* stream_) {
+  if (!s || !x_dev || !y_dev || n < 0 || which < 0 || which > 1) return fail(s, -1, "bez_sim_add_dr_noise: bad argument");
   if (n == 0) return 0;
   const long long quads = (n + 3) / 4;
-  hipLaunchKernelGGL(dr_noise_kernel, dim3((unsigned)((quads + TB - 1) / TB)), dim3(TB), 0, (hipStream_t)stream_, x_dev, (long long)n, s->dr_state, (int)which,
+  hipLaunchKernelGGL(dr_noise_kernel, dim3((unsigned)((quads + TB - 1) / TB)), dim3(TB), 0, (hipStream_t)stream_, x_dev, y_dev, (long long)n, s->dr_state, (int)which,
                      s->cfg.seed, s->cfg.env_id_offset);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(s, -2, "dr_noise_kernel launch", e);

@@ -53,7 +53,7 @@ def load_library():
         "bez_sim_set_env_params": (C.c_int, [vp, C.c_int, fp, vp]),
         "bez_sim_get_env_params": (C.c_int, [vp, C.c_int, fp, vp]),
         "bez_sim_set_randomization": (C.c_int, [vp, C.POINTER(abi.BezDrConfig), vp]),
-        "bez_sim_add_dr_noise": (C.c_int, [vp, fp, i64, i32, vp]),
+        "bez_sim_add_dr_noise": (C.c_int, [vp, fp, fp, i64, i32, vp]),
         "bez_sim_seed": (C.c_int, [vp, u64]),
         "bez_sim_calibrate": (C.c_int, [vp, u64, i32, vp]),
         "bez_sim_time_steps": (C.c_int, [vp, fp, i32, vp, C.POINTER(C.c_float)]),
@@ -234,10 +234,11 @@ class BezSim:
         self._dr_cfg = dr  # keep the struct alive for the call
         self._check(self.lib.bez_sim_set_randomization(self.h, None if dr is None else C.byref(dr), self._stream()))
 
-    def add_dr_noise(self, x, which):
-        """in place: x += mean + std * N(0, 1) with the device-resident noise parameters (which: 0 observations, 1 actions)"""
-        self._check(self.lib.bez_sim_add_dr_noise(self.h, self._ptr(x, torch.float32), x.numel(), int(which), self._stream()))
-        return x
+    def add_dr_noise(self, x, which, out=None):
+        """out = x + mean + std * N(0, 1) with the device-resident noise parameters (which: 0 observations, 1 actions); out=None: in place"""
+        out = x if out is None else out
+        self._check(self.lib.bez_sim_add_dr_noise(self.h, self._ptr(x, torch.float32), self._ptr(out, torch.float32, x.numel()), x.numel(), int(which), self._stream()))
+        return out
 
     def seed(self, seed):
         self._check(self.lib.bez_sim_seed(self.h, int(seed)))

@@ -212,7 +212,12 @@ class VecTask(Env):
         if "observations" in dr_params:
             self.dr_randomizations["observations"] = {"noise_lambda": lambda t: sim.add_dr_noise(t if t.is_contiguous() else t.contiguous(), 0)}
         if "actions" in dr_params:
-            self.dr_randomizations["actions"] = {"noise_lambda": lambda t: sim.add_dr_noise(t.to(self.device, torch.float32).clone(memory_format=torch.contiguous_format), 1)}
+            self._noisy_actions = torch.empty(self.num_envs, self.num_actions, device=self.device, dtype=torch.float32)  # persistent: graph-safe
+
+            def act_noise(t):
+                t = t.to(self.device, torch.float32)
+                return sim.add_dr_noise(t if t.is_contiguous() else t.contiguous(), 1, out=self._noisy_actions.view(t.shape))
+            self.dr_randomizations["actions"] = {"noise_lambda": act_noise}
         # rigid_shape_properties.restitution (bez_kick.yaml:187-192) SCALES the asset's restitution, which is 0 (plane
         # restitution 0, bez_kick.yaml:16; asset default 0 [ext]): 0 * U(0, 0.7) = 0 -- nothing to randomise.
         # rigid_body_properties.mass is setup_only (bez_kick.yaml:175): drawn once, here, at frame 0 -- where its linear schedule

@@ -237,10 +237,10 @@ typedef struct BezDrConfig {
   BezDrRange actions;       /* bez_kick.yaml:158-161 */
 } BezDrConfig;
 int bez_sim_set_randomization(BezSim* sim, const BezDrConfig* dr, void* stream);
-/* The noise lambdas of vec_task.py:544-618 in one launch: x[i] += mean + std * N(0,1) for n floats, mean / std = the current
- * entries of BEZ_TENSOR_DR_NOISE for `which` (0 = observations, 1 = actions), normals from Philox keyed by (seed, frame, which,
- * i / 4) -- one call per control step and kind. */
-int bez_sim_add_dr_noise(BezSim* sim, float* x_dev, int64_t n, int32_t which, void* stream);
+/* The noise lambdas of vec_task.py:544-618 in one launch: y[i] = x[i] + mean + std * N(0,1) for n floats (y_dev may be x_dev: in
+ * place), mean / std = the current entries of BEZ_TENSOR_DR_NOISE for `which` (0 = observations, 1 = actions), normals from
+ * Philox keyed by (seed, frame, which, i / 4) -- one call per control step and kind. */
+int bez_sim_add_dr_noise(BezSim* sim, const float* x_dev, float* y_dev, int64_t n, int32_t which, void* stream);
 
 /* Test hooks (state injection for the parity tests; no reference counterpart). */
 int bez_sim_set_prev_lin_vel_tensor(BezSim* sim, const float* prev_dev, void* stream); /* (N,3) */
