@@ -499,9 +499,15 @@ __global__ __launch_bounds__(PPO_TB) void adam_update_kernel(float* __restrict__
   if (p16) p16[i] = __float2half(w);  // the fp16 working copy of the master weights, refreshed in the same pass
 }
 // step counters (one per parameter tensor, all equal) and the loss-scale schedule (GradScaler.update)
+// ... and, in the same launch, the step's bookkeeping sums (tail: dst[i] += *src[i] * scale[i], e.g. the epoch's KL / loss accumulators)
+// and the reset of work[] for the next step (work is zero on entry of bez_ppo_adam_step and zero again on return: no memset per step)
+struct AdamTail { float* dst[4]; const float* src[4]; float scale[4]; int n; };
 __global__ void adam_commit_kernel(float* __restrict__ steps, int nsteps, float* __restrict__ scale, int32_t* __restrict__ growth_tracker,
-                                   float growth_factor, float backoff_factor, int32_t growth_interval, const float* __restrict__ work) {
+                                   float growth_factor, float backoff_factor, int32_t growth_interval, float* __restrict__ work, AdamTail tail) {
   const bool bad = scale && work[1] > 0.f;
+  __syncthreads();
+  if (threadIdx.x < 2) work[threadIdx.x] = 0.f;
+  if ((int)threadIdx.x < tail.n) *tail.dst[threadIdx.x] += *tail.src[threadIdx.x] * tail.scale[threadIdx.x];
   if (threadIdx.x < nsteps && !bad) steps[threadIdx.x] += 1.0f;
   if (threadIdx.x == 0 && scale) {
     if (bad) { scale[0] *= backoff_factor; growth_tracker[0] = 0; }
@@ -583,7 +589,7 @@ int bez_ppo_loss(const float* mu_dev, const float* logstd_dev, const float* valu
   if (!mu_dev || !logstd_dev || !value_dev || !actions_dev || !old_logp_dev || !adv_dev || !old_value_dev || !returns_dev || !old_mu_dev ||
       !old_sigma_dev || !grad_mu_dev || !grad_value_dev || !grad_logstd_dev || !stats_dev || batch <= 0 || num_actions <= 0 || num_actions > 32) return -1;
   if (!(clip_value & 2)) (void)hipMemsetAsync(grad_logstd_dev, 0, (size_t)num_actions * sizeof(float), (hipStream_t)stream);  // bit 1: accumulate
-  (void)hipMemsetAsync(stats_dev, 0, 5 * sizeof(float), (hipStream_t)stream);
+  if (!(clip_value & 4)) (void)hipMemsetAsync(stats_dev, 0, 5 * sizeof(float), (hipStream_t)stream);                    // bit 2: the caller zeroed stats
 #define BEZ_PPO_LOSS(AA)                                                                                                                             \
   hipLaunchKernelGGL(ppo_loss_kernel<AA>, dim3(nblk(batch)), dim3(PPO_TB), 0, (hipStream_t)stream, mu_dev, logstd_dev, value_dev, actions_dev, old_logp_dev,  \
                      adv_dev, old_value_dev, returns_dev, old_mu_dev, old_sigma_dev, batch, e_clip, critic_coef, entropy_coef, bounds_coef,              \
@@ -680,18 +686,24 @@ int bez_ppo_head_grads_f16(const float* grad_mu_dev, const float* grad_value_dev
 int bez_ppo_adam_step(float* params_dev, const float* grads_dev, float* exp_avg_dev, float* exp_avg_sq_dev, int64_t n, float* steps_dev,
                       int32_t nsteps, const float* lr_dev, float beta1, float beta2, float eps, float weight_decay, float max_norm, float* scale_dev,
                       int32_t* growth_tracker_dev, float growth_factor, float backoff_factor, int32_t growth_interval, float* work_dev,
-                      void* params_f16_dev, void* stream) {
+                      void* params_f16_dev, int32_t ntail, float* const* tail_dst_dev, const float* const* tail_src_dev, const float* tail_scale,
+                      void* stream) {
   if (!params_dev || !grads_dev || !exp_avg_dev || !exp_avg_sq_dev || !steps_dev || !lr_dev || !work_dev || n <= 0 || nsteps <= 0 || nsteps > 64 ||
-      (scale_dev && !growth_tracker_dev)) return -1;
+      (scale_dev && !growth_tracker_dev) || ntail < 0 || ntail > 4 || (ntail > 0 && (!tail_dst_dev || !tail_src_dev || !tail_scale))) return -1;
   hipStream_t st = (hipStream_t)stream;
-  (void)hipMemsetAsync(work_dev, 0, 2 * sizeof(float), st);
+  AdamTail tail;
+  tail.n = ntail;
+  for (int i = 0; i < 4; ++i) {
+    tail.dst[i] = i < ntail ? tail_dst_dev[i] : nullptr; tail.src[i] = i < ntail ? tail_src_dev[i] : nullptr; tail.scale[i] = i < ntail ? tail_scale[i] : 0.f;
+    if (i < ntail && (!tail.dst[i] || !tail.src[i])) return -1;
+  }
   unsigned g = nblk(n);
   if (g > 256) g = 256;
   hipLaunchKernelGGL(adam_norm_kernel, dim3(g), dim3(PPO_TB), 0, st, grads_dev, n, (const float*)scale_dev, work_dev);
   hipLaunchKernelGGL(adam_update_kernel, dim3(nblk(n)), dim3(PPO_TB), 0, st, params_dev, grads_dev, exp_avg_dev, exp_avg_sq_dev, n, (const float*)steps_dev,
                      lr_dev, beta1, beta2, eps, weight_decay, max_norm, (const float*)scale_dev, (const float*)work_dev, (__half*)params_f16_dev);
   hipLaunchKernelGGL(adam_commit_kernel, dim3(1), dim3(64), 0, st, steps_dev, (int)nsteps, scale_dev, growth_tracker_dev, growth_factor, backoff_factor,
-                     growth_interval, (const float*)work_dev);
+                     growth_interval, work_dev, tail);
   return launch_ok();
 }
 

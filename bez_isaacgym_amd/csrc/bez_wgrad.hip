@@ -19,7 +19,6 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
-#include <cstdlib>
 #include <cstring>
 
 #include "../../include/bez_sim.h"
@@ -51,8 +50,9 @@ struct Args {
   Part part[MAX_PARTS];
   int nparts, nstage_total;                 // stages of KT rows in the whole reduction
   float* partial;
-  int accumulate;
+  int wg_total, max_block, lds_bytes, pad;  // launch geometry (read by bez_ppo_wgrad_run on the host copy)
 };
+static_assert(sizeof(Args) <= BEZ_PPO_WGRAD_PLAN_BYTES, "plan buffer of the C ABI too small");
 
 // one load unit of U halfs (16, 8, 4 or 2 bytes): the width is a template parameter of the kernel body, so the staging code is
 // straight-line -- with a run-time width every load sat behind a branch and the compiler waited for it (vmcnt(0)) at the join
@@ -60,8 +60,15 @@ template <int U> struct Unit;
 template <> struct Unit<8> { using T = uint4; };
 template <> struct Unit<4> { using T = uint2; };
 template <> struct Unit<2> { using T = uint32_t; };
-template <int U> __device__ __forceinline__ typename Unit<U>::T load_unit(const _Float16* p) { return *reinterpret_cast<const typename Unit<U>::T*>(p); }
-template <int U> __device__ __forceinline__ void store_unit(_Float16* p, typename Unit<U>::T v) { *reinterpret_cast<typename Unit<U>::T*>(p) = v; }
+template <> struct Unit<1> { using T = uint32_t; };   // a single-column dY (the value head): kept in a full register (16-bit register arrays end up in scratch)
+template <int U> __device__ __forceinline__ typename Unit<U>::T load_unit(const _Float16* p) {
+  if constexpr (U == 1) return (uint32_t)*reinterpret_cast<const uint16_t*>(p);
+  else return *reinterpret_cast<const typename Unit<U>::T*>(p);
+}
+template <int U> __device__ __forceinline__ void store_unit(_Float16* p, typename Unit<U>::T v) {
+  if constexpr (U == 1) *reinterpret_cast<uint16_t*>(p) = (uint16_t)v;
+  else *reinterpret_cast<typename Unit<U>::T*>(p) = v;
+}
 
 // 8 consecutive k (rows kb .. kb+7 of the LDS image) of column `col` for lane (r, h) of an MFMA operand: two transposed reads.
 // Lane 4q + p of each 16-lane group supplies the address of row q, columns 4p .. 4p+3 of its block; lane i receives column i.
@@ -80,7 +87,7 @@ __device__ __forceinline__ half8 frag_tr(const _Float16* img, int stride, int kb
 // MFMAs.  Pipeline per stage t: [global loads of t+2 -> registers] [registers of t+1 -> LDS buffer (t+1) & 1] [MFMAs on buffer t & 1]
 // [ONE barrier].
 template <int TPW, int GU, int XU>
-__device__ __forceinline__ void wgrad_body(const Args& A, const Part& P, int split, _Float16* lds) {
+__device__ __forceinline__ void wgrad_body(const Args& A, const Part& P, int split, _Float16* lds) {  // A, P: the plan in global memory (uniform: scalar loads)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int st_begin = (int)((long long)split * A.nstage_total / P.splits), st_end = (int)((long long)(split + 1) * A.nstage_total / P.splits);
   const int buf_halfs = KT * (P.gs + P.xs);
@@ -177,33 +184,38 @@ __device__ __forceinline__ void wgrad_body(const Args& A, const Part& P, int spl
   }
 }
 
-__global__ void __launch_bounds__(WG_THREADS) wgrad_kernel(Args A) {
+// The plan (output blocks, their K-splits, LDS strides) lives in DEVICE memory, written once when the caller's tensors are known: as a
+// by-value kernel argument the table had to be indexed dynamically, and with more than ~20 instantiated variants the compiler
+// copied all 2.5 KB of it into scratch first.
+__global__ void __launch_bounds__(WG_THREADS) wgrad_kernel(const Args* __restrict__ Ap) {
   extern __shared__ __attribute__((aligned(16))) _Float16 lds[];
+  const Args& A = *Ap;
   int pi = 0;
   for (int i = 1; i < A.nparts; ++i) if ((int)blockIdx.x >= A.part[i].wg_begin) pi = i;   // (scalar: <= 24 entries)
   const Part& P = A.part[pi];
   const int split = (int)blockIdx.x - P.wg_begin;
   const int tpw = (P.nt + WG_WAVES / P.mt - 1) / (WG_WAVES / P.mt);   // tile columns per wave of this block
-  const int variant = (tpw <= 1 ? 0 : 2) * 16 + (P.gu == 8 ? 0 : (P.gu == 4 ? 1 : 2)) * 4 + (P.xu == 8 ? 0 : (P.xu == 4 ? 1 : 2));
+  const int variant = (tpw <= 1 ? 0 : 2) * 16 + (P.gu == 8 ? 0 : (P.gu == 4 ? 1 : (P.gu == 2 ? 2 : 3))) * 4 + (P.xu == 8 ? 0 : (P.xu == 4 ? 1 : 2));
   // every (tiles per wave, dY unit, X unit) combination is its own straight-line instantiation
 #define WG_CASE(T, TI, GUV, GI, XUV, XI) case (TI * 16 + GI * 4 + XI): wgrad_body<T, GUV, XUV>(A, P, split, lds); break;
 #define WG_X(T, TI, GUV, GI) WG_CASE(T, TI, GUV, GI, 8, 0) WG_CASE(T, TI, GUV, GI, 4, 1) WG_CASE(T, TI, GUV, GI, 2, 2)
 #define WG_G(T, TI) WG_X(T, TI, 8, 0) WG_X(T, TI, 4, 1) WG_X(T, TI, 2, 2)
-  switch (variant) { WG_G(1, 0) WG_G(4, 2) default: break; }
+  switch (variant) { WG_G(1, 0) WG_G(4, 2) WG_CASE(1, 0, 1, 3, 8, 0) WG_CASE(1, 0, 1, 3, 4, 1) WG_CASE(1, 0, 1, 3, 2, 2) default: break; }
 #undef WG_G
 #undef WG_X
 #undef WG_CASE
 }
 
 // the splits of every block, added in fixed order into the layer's gradient: grid = (elements of the largest block / 256, blocks)
-__global__ void wgrad_reduce_kernel(Args A) {
+__global__ void wgrad_reduce_kernel(const Args* __restrict__ Ap, int accumulate) {
+  const Args& A = *Ap;
   const Part& P = A.part[blockIdx.y];
   const int i = blockIdx.x * blockDim.x + threadIdx.x, n = P.gcols * P.xcols;
   if (i >= n) return;
   const int r = i / P.xcols, c = i - r * P.xcols;
   float* d = P.dst + (size_t)(P.g0 + r) * P.dst_ld + P.x0 + c;
   const float* p = A.partial + P.partial_off + i;
-  float s = A.accumulate ? *d : 0.f;
+  float s = accumulate ? *d : 0.f;
   int k = 0;
   for (; k + 8 <= P.splits; k += 8) {   // eight loads in flight, added in their fixed order: deterministic
     float v[8];
@@ -220,27 +232,32 @@ int lds_stride(int cols) {   // halfs: >= cols rounded up to whole tiles, stride
   int c = (cols + 31) / 32 * 32;
   return ((c / 32) & 1) ? c : c + 32;
 }
-int load_unit_of(const void* base, int ld, int c0, int cols) {   // 0: rows of an odd number of halfs are not taken
+int load_unit_of(const void* base, int ld, int c0, int cols) {
   for (int u = 8; u > 1; u >>= 1)
     if (cols % u == 0 && c0 % u == 0 && ld % u == 0 && (reinterpret_cast<uintptr_t>(base) % (2 * u)) == 0) return u;
-  return 0;
+  return 1;
 }
 
 }  // namespace
 
 extern "C" {
 
-/* The weight gradients of `nlayers` Linear layers in one launch pair: dW_L (+)= dY_L^T X_L with dY_L (rows, out_L) and X_L
- * (rows, in_L) fp16 row-major, dW_L (out_L, in_L) fp32.  partial_dev: scratch of nsplit * sum(out_L * in_L) floats.
- * rows must be a multiple of 64.  Returns -3 if the shapes do not fit the kernel (the caller keeps its GEMM path). */
-int bez_ppo_wgrad_mfma(const void* const* dy_f16_dev, const void* const* x_f16_dev, const int32_t* out_features, const int32_t* in_features,
-                       float* const* dw_dev, int32_t nlayers, int64_t rows, int32_t nsplit, float* partial_dev, int32_t accumulate, void* stream_) {
-  if (nlayers < 1 || nlayers > 8 || nsplit < 1 || rows <= 0 || rows % KT != 0) return -3;
+/* Plan: the output blocks of `nlayers` weight gradients dW_L (+)= dY_L^T X_L (dY_L (rows, out_L), X_L (rows, in_L) fp16 row-major,
+ * dW_L (out_L, in_L) fp32), their K-splits in proportion to the bytes each streams (~250 workgroups in all, within a scratch of
+ * nsplit * sum(out_L * in_L) floats at partial_dev), LDS strides and load widths -- written into plan_host (BEZ_PPO_WGRAD_PLAN_BYTES
+ * bytes).  The caller copies the plan to device memory ONCE and then calls bez_ppo_wgrad_run per step.  rows % 64 must be 0;
+ * -3 = shapes the kernel does not take (the caller keeps its GEMM path). */
+int bez_ppo_wgrad_plan(const void* const* dy_f16_dev, const void* const* x_f16_dev, const int32_t* out_features, const int32_t* in_features,
+                       float* const* dw_dev, int32_t nlayers, int64_t rows, int32_t nsplit, float* partial_dev, void* plan_host) {
+  if (!plan_host || nlayers < 1 || nlayers > 8 || nsplit < 1 || rows <= 0 || rows % KT != 0) return -3;
   Args A;
   std::memset(&A, 0, sizeof(A));
   int np = 0;
   size_t lds_bytes = 0;
   long long weight[MAX_PARTS], total_weight = 0, budget = 0;
+  // fixed part of a stage (barrier, load latency) in column equivalents: measured, 32768 rows of bez_kickPPO.yaml's five layers:
+  // 0 -> 61 us (the heads' few workgroups run 46 short stages each while the wide blocks finish 13), 64 -> 48, 128 -> 46, 512 -> 46
+  const int stage_cost = 128;
   for (int L = 0; L < nlayers; ++L) {
     const int O = out_features[L], I = in_features[L];
     if (O < 1 || I < 1) return -3;
@@ -261,12 +278,14 @@ int bez_ppo_wgrad_mfma(const void* const* dy_f16_dev, const void* const* x_f16_d
         P.xcols = (I - P.x0 < 32 * ntp) ? I - P.x0 : 32 * ntp;
         P.mt = mt; P.nt = ntp;
         P.gu = load_unit_of(P.g, P.ldg, P.g0, P.gcols); P.xu = load_unit_of(P.x, P.ldx, P.x0, P.xcols);
-        if (P.gu == 0 || P.xu == 0 || KT * (P.gcols / P.gu) > MAX_UNITS * WG_THREADS || KT * (P.xcols / P.xu) > MAX_UNITS * WG_THREADS) return -3;
+        // single-half units: only for dY, and only for a block of one tile row whose waves keep one tile each (the value head)
+        if (P.xu == 1 || (P.gu == 1 && (mt != 1 || (ntp + WG_WAVES - 1) / WG_WAVES > 1))) return -3;
+        if (KT * (P.gcols / P.gu) > MAX_UNITS * WG_THREADS || KT * (P.xcols / P.xu) > MAX_UNITS * WG_THREADS) return -3;
         P.gs = lds_stride(32 * mt); P.xs = lds_stride(32 * ntp);
         P.dst = dw_dev[L]; P.dst_ld = I;
         const size_t need = 2 * (size_t)KT * (P.gs + P.xs) * sizeof(_Float16) + WG_THREADS * 16;   // two LDS buffers + a scrap slot per thread
         if (need > lds_bytes) lds_bytes = need;
-        weight[np] = P.gcols + P.xcols;                            // bytes a workgroup of this block streams per row of the reduction
+        weight[np] = P.gcols + P.xcols + stage_cost;               // time of one stage of this block: columns streamed + a fixed part (barrier, load latency)
         total_weight += weight[np];
         ++np;
       }
@@ -277,7 +296,7 @@ int bez_ppo_wgrad_mfma(const void* const* dy_f16_dev, const void* const* x_f16_d
   const int nstage = (int)(rows / KT);
   const int target_wgs = 250;
   long long used = 0;
-  int wg = 0;
+  int wg = 0, max_block = 0;
   for (int i = 0; i < np; ++i) {
     Part& P = A.part[i];
     long long sp = (weight[i] * target_wgs + total_weight / 2) / total_weight;
@@ -287,16 +306,27 @@ int bez_ppo_wgrad_mfma(const void* const* dy_f16_dev, const void* const* x_f16_d
     P.splits = (int)sp; P.wg_begin = wg; P.partial_off = used;
     wg += P.splits;
     used += (long long)P.splits * P.gcols * P.xcols;
+    if (P.gcols * P.xcols > max_block) max_block = P.gcols * P.xcols;
   }
   if (used > budget) return -3;
-  A.nparts = np; A.nstage_total = nstage; A.partial = partial_dev; A.accumulate = accumulate;
+  A.nparts = np; A.nstage_total = nstage; A.partial = partial_dev;
+  A.wg_total = wg; A.max_block = max_block; A.lds_bytes = (int)lds_bytes;
+  std::memset(plan_host, 0, BEZ_PPO_WGRAD_PLAN_BYTES);
+  std::memcpy(plan_host, &A, sizeof(A));
+  return 0;
+}
+
+/* Run a plan: plan_host = the buffer bez_ppo_wgrad_plan filled (launch geometry), plan_dev = its copy in device memory (read by the
+ * kernels).  accumulate != 0 adds to the gradients.  Two launches: the split-K MFMA kernel and the fixed-order reduction. */
+int bez_ppo_wgrad_run(const void* plan_host, const void* plan_dev, int32_t accumulate, void* stream_) {
+  if (!plan_host || !plan_dev) return -1;
+  const Args* H = static_cast<const Args*>(plan_host);
+  const Args* D = static_cast<const Args*>(plan_dev);
   hipStream_t stream = (hipStream_t)stream_;
   static bool attr_set = false;
   if (!attr_set) { (void)hipFuncSetAttribute((const void*)wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
-  hipLaunchKernelGGL(wgrad_kernel, dim3(wg), dim3(WG_THREADS), lds_bytes, stream, A);
-  int max_block = 0;
-  for (int i = 0; i < np; ++i) if (A.part[i].gcols * A.part[i].xcols > max_block) max_block = A.part[i].gcols * A.part[i].xcols;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((max_block + 255) / 256, np), dim3(256), 0, stream, A);
+  hipLaunchKernelGGL(wgrad_kernel, dim3(H->wg_total), dim3(WG_THREADS), (size_t)H->lds_bytes, stream, D);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((H->max_block + 255) / 256, H->nparts), dim3(256), 0, stream, D, (int)accumulate);
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 

@@ -639,17 +639,20 @@ class A2CAgent:
 
     # ------------------------------------------------------------------ update
     def _bind_flat_grads(self):
-        """Every parameter's .grad becomes a fixed view of ONE static fp32 buffer (124 237 + 1 floats; the extra slot carries
-        the minibatch KL): autograd accumulates in place, the data-parallel all-reduce runs on the buffer itself (no flatten /
-        unflatten copies), and graphs captured separately (forward+backward | optimiser) see the same addresses."""
+        """Every parameter's .grad becomes a fixed view of ONE static fp32 buffer (124 237 + 8 floats; the tail carries the loss kernel's
+        five minibatch sums -- a_loss, c_loss, b_loss, KL, entropy -- so that ONE clear per step zeroes gradients and sums alike and the
+        KL travels with the gradient): autograd accumulates in place, the data-parallel all-reduce runs on the buffer itself (no
+        flatten / unflatten copies), and graphs captured separately (forward+backward | optimiser) see the same addresses."""
         params = list(self.model.parameters())
         n = sum(p.numel() for p in params)
-        self._flat = torch.zeros(n + 1, device=self.device, dtype=torch.float32)
+        self._nparam = n
+        self._flat = torch.zeros(n + 8, device=self.device, dtype=torch.float32)
         off = 0
         for p in params:
             p.grad = self._flat[off:off + p.numel()].view_as(p)
             off += p.numel()
-        self._flat_kl = self._flat[n:n + 1]
+        self._flat_stats = self._flat[n:n + 5]   # SUMS over the minibatch's rows (after the all-reduce + division: the ranks' mean)
+        self._flat_kl = self._flat[n + 3:n + 4]
 
     def _bind_flat_optimizer(self):
         """Parameters and Adam's moments become fixed views of three static fp32 buffers laid out like the flat gradient, so the
@@ -757,12 +760,11 @@ class A2CAgent:
             scale = self.scaler._scale
         self._flat.zero_()
         F.loss(mu32.detach(), net.sigma.detach(), v32.detach(), mb, self.e_clip, self.critic_coef, self.entropy_coef, self.bounds_loss_coef,
-               self.clip_value, scale, fx["gmu"], fx["gval"], net.sigma.grad, fx["stats"], zero_glog=False)
+               self.clip_value, scale, fx["gmu"], fx["gval"], net.sigma.grad, self._flat_stats, zero_glog=False, zero_stats=False)
         if manual:
             self._manual_backward(tf, fx["gmu"], fx["gval"])
         else:
             torch.autograd.backward([mu32, v32], [fx["gmu"], fx["gval"]])
-        torch.mul(fx["stats"][3:4], 1.0 / float(mu32.shape[0]), out=self._flat_kl)
 
     def _train_fwd_ok(self, obs):
         net = self.model.a2c_network
@@ -808,17 +810,17 @@ class A2CAgent:
             self._policy_bwd(gmu, gval, tf["act"], tf["gz"], tf["gmu16"], tf["gv16"], [lin[L].bias.grad for L in range(nh)],
                              lin[nh].bias.grad, lin[nh + 1].bias.grad)
             if self.cfg.get("fused_wgrad", True):
-                # the weight gradients of the hidden layers and of the mu head: one split-K MFMA launch over the output blocks of all
-                # of them + one fixed-order reduction straight into the fp32 master gradient (csrc/bez_wgrad.hip) instead of a batched
-                # GEMM and a sum per layer.  The value head's dY is a single column (rows of one half: no aligned load unit) and stays a GEMM.
-                dys = [tf["gz"][L] for L in range(nh)] + [tf["gmu16"]]
-                xs = [tf["x0"]] + [tf["act"][L] for L in range(nh - 1)] + [h_last]
-                grads = [lin[L].weight.grad for L in range(nh + 1)]
+                # all five weight gradients: one split-K MFMA launch over the output blocks of every layer + one fixed-order reduction
+                # straight into the fp32 master gradient (csrc/bez_wgrad.hip) instead of a batched GEMM and a sum per layer.  The plan
+                # is made (and uploaded, synchronously) in the first eager epoch, never inside a graph capture.
+                dys = [tf["gz"][L] for L in range(nh)] + [tf["gmu16"], tf["gv16"]]
+                xs = [tf["x0"]] + [tf["act"][L] for L in range(nh - 1)] + [h_last, h_last]
+                grads = [lin[L].weight.grad for L in range(nh + 2)]
                 wg = getattr(self, "_wgrad_mfma", None)
                 if wg is None or not wg.matches(dys, xs, grads):
+                    assert not torch.cuda.is_current_stream_capturing(), "the weight-gradient plan must exist before the update is captured"
                     wg = self._wgrad_mfma = F.WgradMfma(dys, xs, grads)
-                if wg.ok and wg(accumulate=True):
-                    wgrad(tf["gv16"], h_last, lin[nh + 1])
+                if wg(accumulate=True):
                     return
             wgrad(tf["gmu16"], h_last, lin[nh])
             wgrad(tf["gv16"], h_last, lin[nh + 1])
@@ -847,10 +849,15 @@ class A2CAgent:
         if self._fused_opt:
             g0 = self.optimizer.param_groups[0]
             amp = self.scaler.is_enabled()
-            self._F.adam_step(self._pflat, self._flat[:-1], self._mflat, self._vflat, self._steps, self.lr_t, g0["betas"], g0["eps"],
+            # (the epoch's KL / loss accumulators ride in the optimiser's last launch: the sums of the loss kernel -> means)
+            rows = float(self.minibatch_size)
+            st = self._flat_stats
+            tail = ((kl_out, st[3:4], 1.0 / (rows * self.num_minibatches)), (loss_out[0:1], st[0:1], 1.0 / rows), (loss_out[1:2], st[1:2], 1.0 / rows))
+            self._F.adam_step(self._pflat, self._flat[:self._nparam], self._mflat, self._vflat, self._steps, self.lr_t, g0["betas"], g0["eps"],
                               g0["weight_decay"], self.grad_norm if self.truncate_grads else 0.0, self.scaler._scale if amp else None,
                               self.scaler._growth_tracker if amp else None, self.scaler.get_growth_factor(), self.scaler.get_backoff_factor(),
-                              self.scaler.get_growth_interval(), self._opt_work, self._hflat)
+                              self.scaler.get_growth_interval(), self._opt_work, self._hflat, tail=tail)
+            return
         else:
             if self.truncate_grads:
                 self.scaler.unscale_(self.optimizer)
@@ -859,8 +866,8 @@ class A2CAgent:
             self.scaler.update()
         with torch.no_grad():
             # (one launch each: add with a scalar multiplier)
-            kl_out.add_(self._flat_kl[0], alpha=1.0 / self.num_minibatches)
-            loss_out.add_(self._fx["stats"][0:2], alpha=1.0 / float(self.minibatch_size))
+            kl_out.add_(self._flat_kl[0], alpha=1.0 / (self.num_minibatches * float(self.minibatch_size)))
+            loss_out.add_(self._flat_stats[0:2], alpha=1.0 / float(self.minibatch_size))
 
     def _calc_gradients_fused(self, mb, kl_out, loss_out):
         """calc_gradients with the HIP glue kernels: running update of the input normaliser from the epoch's precomputed moments, MLP

@@ -28,10 +28,11 @@ _SIGS = {
     "bez_ppo_gae": [_vp, _vp, _vp, _vp, _vp, _i32, _i64, _f, _f, _vp, _vp, _vp],
     "bez_ppo_head_grads_f16": [_vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp],
     "bez_ppo_wgrad_sum": [_vp, _i32, _i64, _vp, _i32, _vp],
-    "bez_ppo_wgrad_mfma": [_vp, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _vp, _i32, _vp],
+    "bez_ppo_wgrad_plan": [_vp, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _vp, _vp],
+    "bez_ppo_wgrad_run": [_vp, _vp, _i32, _vp],
     "bez_ppo_colsum_f16": [_vp, _i64, _i32, _vp, _i32, _vp],
     "bez_ppo_elu_bwd_colsum_f16": [_vp, _vp, _vp, _i64, _i32, _vp, _i32, _vp],
-    "bez_ppo_adam_step": [_vp, _vp, _vp, _vp, _i64, _vp, _i32, _vp, _f, _f, _f, _f, _f, _vp, _vp, _f, _f, _i32, _vp, _vp, _vp],
+    "bez_ppo_adam_step": [_vp, _vp, _vp, _vp, _i64, _vp, _i32, _vp, _f, _f, _f, _f, _f, _vp, _vp, _f, _f, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _vp],
 }
 _lib = None
 
@@ -111,25 +112,33 @@ def rollout_post(rew, dones, timeouts, values, reward_scale, gamma, bootstrap, s
          "bez_ppo_rollout_post")
 
 
-def loss(mu, logstd, value, mb, e_clip, critic_coef, entropy_coef, bounds_coef, clip_value, scale, gmu, gval, glog, stats, zero_glog=True):
-    """stats[5] <- sums of a_loss, c_loss, b_loss, kl, entropy; gmu / gval <- gradient of the mean loss (x loss scale);
-    glog is ACCUMULATED into (zero_glog: cleared first)."""
+def loss(mu, logstd, value, mb, e_clip, critic_coef, entropy_coef, bounds_coef, clip_value, scale, gmu, gval, glog, stats, zero_glog=True,
+         zero_stats=True):
+    """stats[5] <- sums of a_loss, c_loss, b_loss, kl, entropy (zero_stats False: the caller cleared them); gmu / gval <- gradient of the
+    mean loss (x loss scale); glog is ACCUMULATED into (zero_glog: cleared first)."""
     b, a = mu.shape
     _chk(lib().bez_ppo_loss(_p(mu), _p(logstd), _p(value), _p(mb["actions"]), _p(mb["old_logp"]), _p(mb["advantages"]), _p(mb["old_values"]),
                             _p(mb["returns"]), _p(mb["mu"]), _p(mb["sigma"]), b, a, float(e_clip), float(critic_coef), float(entropy_coef),
-                            float(bounds_coef), (1 if clip_value else 0) | (0 if zero_glog else 2), None if scale is None else _p(scale), _p(gmu),
+                            float(bounds_coef), (1 if clip_value else 0) | (0 if zero_glog else 2) | (0 if zero_stats else 4), None if scale is None else _p(scale), _p(gmu),
                             _p(gval), _p(glog), _p(stats), _stream(mu)), "bez_ppo_loss")
 
 
 def adam_step(params, grads, exp_avg, exp_avg_sq, steps, lr, betas, eps, weight_decay, max_norm, scale, growth_tracker, growth_factor,
-              backoff_factor, growth_interval, work, params_f16=None):
+              backoff_factor, growth_interval, work, params_f16=None, tail=()):
     """unscale + clip + Adam + scaler update on the flat buffers (csrc/bez_ppo.hip adam_*_kernel); scale / growth_tracker None = no AMP;
-    params_f16 (flat fp16, same layout) receives the updated parameters in the same pass."""
+    params_f16 (flat fp16, same layout) receives the updated parameters in the same pass.  `work` (2 floats) must be zero on entry and is
+    zero again afterwards.  tail: up to 4 (dst, src, scale) with one-element fp32 tensors: dst += src * scale in the last launch."""
     n = params.numel()
+    nt = len(tail)
+    assert nt <= 4 and all(d.numel() == 1 and x.numel() == 1 for d, x, _ in tail)
+    td = (C.c_void_p * 4)(*[_p(d).value for d, _, _ in tail])
+    ts = (C.c_void_p * 4)(*[_p(x).value for _, x, _ in tail])
+    tsc = (C.c_float * 4)(*[float(a) for _, _, a in tail])
     _chk(lib().bez_ppo_adam_step(_p(params), _p(grads), _p(exp_avg), _p(exp_avg_sq), n, _p(steps), steps.numel(), _p(lr), float(betas[0]),
                                  float(betas[1]), float(eps), float(weight_decay), float(max_norm), None if scale is None else _p(scale),
                                  None if growth_tracker is None else _p(growth_tracker, torch.int32), float(growth_factor), float(backoff_factor),
-                                 int(growth_interval), _p(work), None if params_f16 is None else _p(params_f16, torch.float16), _stream(params)),
+                                 int(growth_interval), _p(work), None if params_f16 is None else _p(params_f16, torch.float16), nt, td, ts, tsc,
+                                 _stream(params)),
          "bez_ppo_adam_step")
 
 
@@ -142,9 +151,10 @@ def wgrad_sum(partials, out, accumulate=False):
 
 class WgradMfma:
     """dW_L (+)= dY_L^T X_L for all Linear layers of the MLP in ONE split-K MFMA launch + one deterministic reduction
-    (csrc/bez_wgrad.hip).  Pointer tables are built once per set of tensors; `ok` is False when the kernel does not take the
-    shapes (the caller then keeps its GEMM path)."""
+    (csrc/bez_wgrad.hip).  The work is laid out once per set of tensors (bez_ppo_wgrad_plan), the plan copied to the device once;
+    `ok` is False when the kernel does not take the shapes (the caller then keeps its GEMM path)."""
     NSPLIT = 32
+    PLAN_BYTES = 3072
 
     def __init__(self, dys, xs, grads):
         n = len(dys)
@@ -152,25 +162,30 @@ class WgradMfma:
         assert all(t.dtype == torch.float16 and t.is_contiguous() and t.shape[0] == rows for t in list(dys) + list(xs))
         assert all(g.dtype == torch.float32 and g.is_contiguous() and g.shape == (dy.shape[1], x.shape[1]) for g, dy, x in zip(grads, dys, xs))
         self.keep = (list(dys), list(xs), list(grads))
-        self.n, self.rows = n, rows
-        self.dy = (C.c_void_p * n)(*[t.data_ptr() for t in dys]); self.x = (C.c_void_p * n)(*[t.data_ptr() for t in xs])
-        self.dw = (C.c_void_p * n)(*[t.data_ptr() for t in grads])
-        self.of = (C.c_int32 * n)(*[t.shape[1] for t in dys]); self.inf = (C.c_int32 * n)(*[t.shape[1] for t in xs])
+        dy = (C.c_void_p * n)(*[t.data_ptr() for t in dys]); x = (C.c_void_p * n)(*[t.data_ptr() for t in xs])
+        dw = (C.c_void_p * n)(*[t.data_ptr() for t in grads])
+        of = (C.c_int32 * n)(*[t.shape[1] for t in dys]); inf = (C.c_int32 * n)(*[t.shape[1] for t in xs])
         total = sum(g.numel() for g in grads)
-        self.ok = rows % 64 == 0
-        self.partial = torch.empty(self.NSPLIT * total, device=dys[0].device, dtype=torch.float32) if self.ok else None
+        dev = dys[0].device
+        self.partial = torch.empty(self.NSPLIT * total, device=dev, dtype=torch.float32)
+        self.plan_host = (C.c_uint8 * self.PLAN_BYTES)()
+        rc = lib().bez_ppo_wgrad_plan(dy, x, of, inf, dw, n, rows, self.NSPLIT, _p(self.partial), self.plan_host) if rows % 64 == 0 else -3
+        self.ok = rc == 0
+        if rc not in (0, -3):
+            _chk(rc, "bez_ppo_wgrad_plan")
+        if self.ok:   # one synchronous upload, outside any graph capture
+            self.plan_dev = torch.frombuffer(bytearray(self.plan_host), dtype=torch.uint8).to(dev)
+        else:
+            self.partial = None
 
     def matches(self, dys, xs, grads):
         k = self.keep
         return all(a.data_ptr() == b.data_ptr() for a, b in zip(list(dys) + list(xs) + list(grads), k[0] + k[1] + k[2]))
 
     def __call__(self, accumulate=True):
-        rc = lib().bez_ppo_wgrad_mfma(self.dy, self.x, self.of, self.inf, self.dw, self.n, self.rows, self.NSPLIT, _p(self.partial),
-                                      1 if accumulate else 0, _stream(self.partial))
-        if rc == -3:
-            self.ok = False
+        if not self.ok:
             return False
-        _chk(rc, "bez_ppo_wgrad_mfma")
+        _chk(lib().bez_ppo_wgrad_run(self.plan_host, C.c_void_p(self.plan_dev.data_ptr()), 1 if accumulate else 0, _stream(self.partial)), "bez_ppo_wgrad_run")
         return True
 
 

@@ -295,7 +295,8 @@ int bez_ppo_rollout_post(const float* rew_dev, const int64_t* dones_dev, const i
 /* PPO minibatch loss (clipped surrogate, clipped value loss, entropy, bounds loss) AND its gradient w.r.t. the network
  * outputs mu (B,A), value (B) and the log-std parameter (A), multiplied by *loss_scale_dev (GradScaler; NULL = 1).
  * stats_dev[5] = sums of a_loss, c_loss, b_loss, KL(current || old), entropy over the minibatch.
- * clip_value: bit 0 = clipped value loss; bit 1 = ACCUMULATE into grad_logstd_dev instead of clearing it first. */
+ * clip_value: bit 0 = clipped value loss; bit 1 = ACCUMULATE into grad_logstd_dev instead of clearing it first; bit 2 = stats_dev was
+ * zeroed by the caller (e.g. as part of the flat gradient buffer's one clear per step). */
 int bez_ppo_loss(const float* mu_dev, const float* logstd_dev, const float* value_dev, const float* actions_dev, const float* old_logp_dev,
                  const float* adv_dev, const float* old_value_dev, const float* returns_dev, const float* old_mu_dev,
                  const float* old_sigma_dev, int64_t batch, int32_t num_actions, float e_clip, float critic_coef, float entropy_coef,
@@ -335,13 +336,17 @@ int bez_ppo_policy_forward_train(const float* obs_dev, int64_t n, int32_t num_ob
 int bez_ppo_wgrad_sum(const void* partials_f16_dev, int32_t splits, int64_t n, float* out_dev, int32_t accumulate, void* stream);
 int bez_ppo_colsum_f16(const void* y_f16_dev, int64_t rows, int32_t cols, float* out_dev, int32_t accumulate, void* stream);
 /* The weight gradients of `nlayers` (<= 8) Linear layers in one launch pair (csrc/bez_wgrad.hip): dW_L (+)= dY_L^T X_L with dY_L
- * (rows, out_L) and X_L (rows, in_L) fp16 row-major, dW_L (out_L, in_L) fp32 (accumulate != 0 adds).  A split-K MFMA kernel over
- * the output blocks of all layers -- each split along the rows in proportion to the bytes it streams, ~250 workgroups in all --
- * writes fp32 partial blocks into partial_dev (room for nsplit * sum(out_L * in_L) floats; it uses what the balance needs), a
- * second kernel adds a block's splits in fixed order (deterministic).  rows % 64 must be 0; -3 = shapes the kernel does not
- * take (the caller keeps its GEMM path).  Replaces torch.bmm + bez_ppo_wgrad_sum of a2c_common.py's backward [ext]. */
-int bez_ppo_wgrad_mfma(const void* const* dy_f16_dev, const void* const* x_f16_dev, const int32_t* out_features, const int32_t* in_features,
-                       float* const* dw_dev, int32_t nlayers, int64_t rows, int32_t nsplit, float* partial_dev, int32_t accumulate, void* stream);
+ * (rows, out_L) and X_L (rows, in_L) fp16 row-major, dW_L (out_L, in_L) fp32.  A split-K MFMA kernel over the output blocks of
+ * all layers -- each split along the rows in proportion to the bytes it streams, ~250 workgroups in all -- writes fp32 partial
+ * blocks into partial_dev (room for nsplit * sum(out_L * in_L) floats; it uses what the balance needs), a second kernel adds a
+ * block's splits in fixed order (deterministic).  Replaces torch.bmm + bez_ppo_wgrad_sum of a2c_common.py's backward [ext].
+ * bez_ppo_wgrad_plan lays the work out ONCE for a set of tensors into plan_host (BEZ_PPO_WGRAD_PLAN_BYTES bytes of host memory;
+ * rows % 64 must be 0; -3 = shapes the kernel does not take, the caller keeps its GEMM path); the caller copies the plan to
+ * device memory and calls bez_ppo_wgrad_run(plan_host, plan_dev, accumulate, stream) per step. */
+#define BEZ_PPO_WGRAD_PLAN_BYTES 3072
+int bez_ppo_wgrad_plan(const void* const* dy_f16_dev, const void* const* x_f16_dev, const int32_t* out_features, const int32_t* in_features,
+                       float* const* dw_dev, int32_t nlayers, int64_t rows, int32_t nsplit, float* partial_dev, void* plan_host);
+int bez_ppo_wgrad_run(const void* plan_host, const void* plan_dev, int32_t accumulate, void* stream);
 /* ELU (alpha 1) backward fused with the bias gradient: gz = gy * elu'(y) from the layer's ELU OUTPUT y, all (rows, cols) fp16;
  * the column sums of gz go to bias_grad_dev (fp32, cols). */
 int bez_ppo_elu_bwd_colsum_f16(const void* gy_f16_dev, const void* y_f16_dev, void* gz_f16_dev, int64_t rows, int32_t cols, float* bias_grad_dev,
@@ -390,12 +395,16 @@ int bez_ppo_head_grads_f16(const float* grad_mu_dev, const float* grad_value_dev
  * clip_grad_norm_ + scaler.step(Adam) + scaler.update, a2c_common.py [ext] via train.py:89-113): the gradient is divided by
  * *scale_dev (NULL = no loss scaling), clipped to max_norm (<= 0: no clipping), applied with torch's Adam formula; a non-finite
  * gradient skips the step and backs the scale off, growth_interval clean steps grow it.  steps_dev[nsteps] are the per-tensor
- * step counters of the optimiser state (all equal).  work_dev[2]: squared norm of the unscaled gradient / non-finite count.
- * params_f16_dev (NULL or n fp16): receives the updated parameters as fp16 in the same pass (the AMP working copy). */
+ * step counters of the optimiser state (all equal).  work_dev[2]: squared norm of the unscaled gradient / non-finite count --
+ * ZERO on entry (allocate it zeroed), zero again on return (the last kernel clears it: no memset per step).
+ * params_f16_dev (NULL or n fp16): receives the updated parameters as fp16 in the same pass (the AMP working copy).
+ * ntail (0..4) bookkeeping sums ride in the last launch: *tail_dst_dev[i] += *tail_src_dev[i] * tail_scale[i] (host arrays of
+ * device pointers / host floats) -- the epoch's KL and loss accumulators of a2c_common.py's train_epoch [ext]. */
 int bez_ppo_adam_step(float* params_dev, const float* grads_dev, float* exp_avg_dev, float* exp_avg_sq_dev, int64_t n, float* steps_dev,
                       int32_t nsteps, const float* lr_dev, float beta1, float beta2, float eps, float weight_decay, float max_norm, float* scale_dev,
                       int32_t* growth_tracker_dev, float growth_factor, float backoff_factor, int32_t growth_interval, float* work_dev,
-                      void* params_f16_dev, void* stream);
+                      void* params_f16_dev, int32_t ntail, float* const* tail_dst_dev, const float* const* tail_src_dev, const float* tail_scale,
+                      void* stream);
 
 #ifdef __cplusplus
 }

@@ -264,6 +264,7 @@ def test_adam_step_kernel_matches_torch_amp_clip_adam():
     hflat = torch.zeros(n, device=DEV, dtype=torch.float16)
     scale, tracker = torch.tensor([1024.0], device=DEV), torch.zeros(1, device=DEV, dtype=torch.int32)
     seen = []
+    acc, src = torch.zeros(3, device=DEV), torch.tensor([1.5, -2.0, 0.25], device=DEV)
     for it in range(7):
         g = [torch.randn(sh, device=DEV) * (3.0 if it % 2 else 0.02) for sh in shapes]  # norms above and below the clip threshold
         if it == 4:
@@ -276,7 +277,10 @@ def test_adam_step_kernel_matches_torch_amp_clip_adam():
         torch.nn.utils.clip_grad_norm_(ref, 1.0)
         scaler.step(opt)
         scaler.update()
-        F.adam_step(pflat, gflat, mflat, vflat, steps, lr, (0.9, 0.999), 1e-8, 0.0, 1.0, scale, tracker, 2.0, 0.5, 3, work, hflat)
+        F.adam_step(pflat, gflat, mflat, vflat, steps, lr, (0.9, 0.999), 1e-8, 0.0, 1.0, scale, tracker, 2.0, 0.5, 3, work, hflat,
+                    tail=((acc[0:1], src[0:1], 2.0), (acc[1:2], src[1:2], 0.5), (acc[2:3], src[2:3], 1.0)))
+        assert work.tolist() == [0.0, 0.0]           # left zero for the next step (no memset per step)
+        assert acc.tolist() == [3.0 * (it + 1), -1.0 * (it + 1), 0.25 * (it + 1)]   # the bookkeeping sums of the last launch, skipped step or not
         if it != 4:
             assert torch.equal(hflat, pflat.half())  # the fp16 working copy written in the same pass
         assert float(scale) == scaler.get_scale(), (it, float(scale), scaler.get_scale())
@@ -513,12 +517,12 @@ print("DP_OK", st[-1]["kl"])
 
 
 @pytest.mark.parametrize("rows,shapes", [
-    (32768, [(400, 54), (200, 400), (100, 200), (18, 100)]),               # bez_kickPPO.yaml: 54-400-200-100 + the mu head
+    (32768, [(400, 54), (200, 400), (100, 200), (18, 100), (1, 100)]),     # bez_kickPPO.yaml: 54-400-200-100 + the mu and value heads
     (4096, [(64, 32), (30, 416), (136, 72), (4, 50)]),                      # partial tiles, a block of 8 columns, 2- and 4-half load units
     (2048, [(416, 416)]),                                                  # the widest layer the policy kernels take
 ])
 def test_wgrad_mfma_matches_fp32_reference(rows, shapes):
-    """bez_ppo_wgrad_mfma (csrc/bez_wgrad.hip): dW_L += dY_L^T X_L for all layers in one split-K MFMA launch + one fixed-order
+    """bez_ppo_wgrad_plan / _run (csrc/bez_wgrad.hip): dW_L += dY_L^T X_L for all layers in one split-K MFMA launch + one fixed-order
     reduction, against the fp32 product of the same fp16 operands; asymmetric integer-valued data first (any row / column or
     k-order mix-up of the transposed LDS reads shows as an exact mismatch), then random data; twice the same bits (deterministic)."""
     from bez_isaacgym_amd.ppo import fused as F
@@ -551,8 +555,9 @@ def test_wgrad_mfma_matches_fp32_reference(rows, shapes):
         assert wg(accumulate=False)
         torch.cuda.synchronize()
         assert all(torch.equal(a, b) for a, b in zip(again, grads))    # fixed-order reduction: bit-identical run to run
-    # rows of an odd number of halfs have no aligned load unit (the value head's dY is one column): refused, the caller keeps
-    # its GEMM path (bez_ppo_wgrad_mfma returns -3)
-    odd = F.WgradMfma([torch.zeros(2048, 1, device=DEV, dtype=torch.float16)], [torch.zeros(2048, 100, device=DEV, dtype=torch.float16)],
-                      [torch.zeros(1, 100, device=DEV)])
-    assert odd.ok and odd(accumulate=False) is False and not odd.ok
+    # what the kernel refuses (bez_ppo_wgrad_plan returns -3, the caller keeps its GEMM path): X rows of an odd number of halfs
+    # (no aligned load unit), and a dY of odd width that needs more than one tile row (single-half loads are for a head's few columns)
+    for (o, i) in ((8, 101), (45, 64)):
+        odd = F.WgradMfma([torch.zeros(2048, o, device=DEV, dtype=torch.float16)], [torch.zeros(2048, i, device=DEV, dtype=torch.float16)],
+                          [torch.zeros(o, i, device=DEV)])
+        assert not odd.ok and odd(accumulate=False) is False

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Time bez_ppo_wgrad_mfma (csrc/bez_wgrad.hip) on the bez_kickPPO.yaml shapes against the round-2 path (32-way batched GEMM + sum).
+"""Time bez_ppo_wgrad_plan / _run (csrc/bez_wgrad.hip) on the bez_kickPPO.yaml shapes against the round-2 path (32-way batched GEMM + sum).
 usage: python tools/wgrad_bench.py [all|L0|L1|L2|heads]"""
 import os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
@@ -7,7 +7,7 @@ import torch
 from bez_isaacgym_amd.ppo import fused as F
 dev = "cuda:0"
 rows = 32768
-ALL = {"L0": [(400, 54)], "L1": [(200, 400)], "L2": [(100, 200)], "heads": [(18, 100)], "all": [(400, 54), (200, 400), (100, 200), (18, 100)]}
+ALL = {"L0": [(400, 54)], "L1": [(200, 400)], "L2": [(100, 200)], "heads": [(18, 100), (1, 100)], "all": [(400, 54), (200, 400), (100, 200), (18, 100), (1, 100)]}
 for which in (sys.argv[1:] or ["all"]):
     shapes = ALL[which]
     dys = [torch.randn(rows, o, device=dev).half() for o, i in shapes]
