@@ -161,47 +161,56 @@ __global__ __launch_bounds__(PPO_TB) void ppo_rollout_post_kernel(const float* _
 // stats (atomically accumulated, caller zeroes): [sum a_loss, sum c_loss, sum b_loss, sum kl, sum entropy]
 // grad_mu / grad_value are d(loss)/d(mu), d(loss)/d(value) times *scale (GradScaler's loss scale, a device scalar; null = 1);
 // grad_logstd (A) is accumulated atomically (caller zeroes).
-// Layout: one sample per thread; the (B,A) row-major operands of a workgroup's 256 consecutive rows are one contiguous block,
+// Layout: one sample per thread; the (B,A) row-major operands of a workgroup's 64 consecutive rows are one contiguous block,
 // moved with coalesced accesses and transposed through LDS ([row][A+1]: conflict-free for the per-thread row walk).  A is a
 // template parameter (register arrays, unrolled loops); the per-column / per-term sums are reduced in the workgroup first, so a
-// launch issues 23 atomics per 256 samples.
+// launch issues A + 5 atomics per 64 samples.
+constexpr int LOSS_TB = 64;   // one wave per 64 samples: 512 workgroups for config 3's minibatch (256-thread blocks filled half the CUs)
 template <int A>
-__global__ __launch_bounds__(PPO_TB) void ppo_loss_kernel(const float* __restrict__ mu, const float* __restrict__ logstd, const float* __restrict__ value,
-                                                          const float* __restrict__ act, const float* __restrict__ old_logp, const float* __restrict__ adv,
-                                                          const float* __restrict__ old_value, const float* __restrict__ ret, const float* __restrict__ old_mu,
-                                                          const float* __restrict__ old_sigma, int64_t B, float e_clip, float critic_coef,
-                                                          float entropy_coef, float bounds_coef, int clip_value, const float* __restrict__ scale,
-                                                          float* __restrict__ grad_mu, float* __restrict__ grad_value, float* __restrict__ grad_logstd,
-                                                          float* __restrict__ stats) {
-  constexpr int LD = A + 1;
-  __shared__ float tile[PPO_TB * LD];
-  __shared__ float red[4][A + 5];
+__global__ __launch_bounds__(LOSS_TB) void ppo_loss_kernel(const float* __restrict__ mu, const float* __restrict__ logstd, const float* __restrict__ value,
+                                                           const float* __restrict__ act, const float* __restrict__ old_logp, const float* __restrict__ adv,
+                                                           const float* __restrict__ old_value, const float* __restrict__ ret, const float* __restrict__ old_mu,
+                                                           const float* __restrict__ old_sigma, int64_t B, float e_clip, float critic_coef,
+                                                           float entropy_coef, float bounds_coef, int clip_value, const float* __restrict__ scale,
+                                                           float* __restrict__ grad_mu, float* __restrict__ grad_value, float* __restrict__ grad_logstd,
+                                                           float* __restrict__ stats) {
+  constexpr int LD = A + 1, TB = LOSS_TB;
+  __shared__ float tile[TB * LD];
   const int tid = threadIdx.x;
-  const int64_t row0 = (int64_t)blockIdx.x * PPO_TB;
+  const int64_t row0 = (int64_t)blockIdx.x * TB;
   const int64_t i = row0 + tid;
-  const int nrow = (int)((B - row0) < (int64_t)PPO_TB ? (B - row0) : (int64_t)PPO_TB);
+  const int nrow = (int)((B - row0) < (int64_t)TB ? (B - row0) : (int64_t)TB);
   const bool on = tid < nrow;
   const float S = scale ? scale[0] : 1.0f, invB = 1.0f / (float)B;
-  // coalesced load of this workgroup's (nrow, A) block of `src` into the LDS tile, then this thread's row into registers
-  auto load_rows = [&](const float* __restrict__ src, float* r) {
+  // the workgroup's (nrow, A) blocks of the four row-major operands: ALL coalesced loads issued first (4 * A in flight per thread),
+  // then each block goes through the LDS tile and this thread reads its row
+  float raw[4][A];
+  {
+    const float* src[4] = {mu + row0 * A, act + row0 * A, old_mu + row0 * A, old_sigma + row0 * A};
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int j = 0; j < A; ++j) { const int k = tid + j * TB; raw[q][j] = k < nrow * A ? src[q][k] : 0.f; }
+  }
+  auto rows_of = [&](const float* rq, float* r) {
     __syncthreads();
-    const float* blk = src + row0 * A;
-    for (int k = tid; k < nrow * A; k += PPO_TB) tile[(k / A) * LD + (k % A)] = blk[k];
+#pragma unroll
+    for (int j = 0; j < A; ++j) { const int k = tid + j * TB; tile[(k / A) * LD + (k % A)] = rq[j]; }
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < A; ++j) r[j] = on ? tile[tid * LD + j] : 0.f;
   };
   float m[A], z[A], sg[A], gls[A];
   float a_l = 0.f, c_l = 0.f, b_l = 0.f, kl = 0.f, ent = 0.f;
-  load_rows(mu, m);
+  rows_of(raw[0], m);
   {
     float x[A];
-    load_rows(act, x);
+    rows_of(raw[1], x);
 #pragma unroll
     for (int j = 0; j < A; ++j) { sg[j] = expf(logstd[j]); z[j] = (x[j] - m[j]) / sg[j]; }
     float om[A];
-    load_rows(old_mu, om);
-    load_rows(old_sigma, x);
+    rows_of(raw[2], om);
+    rows_of(raw[3], x);
     if (on) {
 #pragma unroll
       for (int j = 0; j < A; ++j) {  // policy_kl(current, old)
@@ -262,19 +271,20 @@ __global__ __launch_bounds__(PPO_TB) void ppo_loss_kernel(const float* __restric
   __syncthreads();
   {
     float* blk = grad_mu + row0 * A;
-    for (int k = tid; k < nrow * A; k += PPO_TB) blk[k] = tile[(k / A) * LD + (k % A)];
-  }
-  // workgroup reduction of the A log-std gradient columns and the five statistics, then one atomic each
-  const int w = tid >> 6, l = tid & 63;
 #pragma unroll
-  for (int j = 0; j < A; ++j) { const float g = wave_sum(gls[j]); if (l == 0) red[w][j] = g; }
-  a_l = wave_sum(a_l); c_l = wave_sum(c_l); b_l = wave_sum(b_l); kl = wave_sum(kl); ent = wave_sum(ent);
-  if (l == 0) { red[w][A] = a_l; red[w][A + 1] = c_l; red[w][A + 2] = b_l; red[w][A + 3] = kl; red[w][A + 4] = ent; }
-  __syncthreads();
-  if (tid < A + 5) {
-    const float t = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
-    atomicAdd(tid < A ? &grad_logstd[tid] : &stats[tid - A], t);
+    for (int j = 0; j < A; ++j) { const int k = tid + j * TB; if (k < nrow * A) blk[k] = tile[(k / A) * LD + (k % A)]; }
   }
+  // wave reduction of the A log-std gradient columns and the five statistics, then one atomic each (A + 5 per 64 samples)
+  float mine = 0.f;
+#pragma unroll
+  for (int j = 0; j < A; ++j) { const float g = wave_sum(gls[j]); if (tid == j) mine = g; }
+  a_l = wave_sum(a_l); c_l = wave_sum(c_l); b_l = wave_sum(b_l); kl = wave_sum(kl); ent = wave_sum(ent);
+  if (tid == A) mine = a_l;
+  if (tid == A + 1) mine = c_l;
+  if (tid == A + 2) mine = b_l;
+  if (tid == A + 3) mine = kl;
+  if (tid == A + 4) mine = ent;
+  if (tid < A + 5) atomicAdd(tid < A ? &grad_logstd[tid] : &stats[tid - A], mine);
 }
 
 // ---- gradient reductions of the explicit-fp16 linear layers (a2c_continuous.py _HalfLinearFn), written straight into the fp32
@@ -591,7 +601,7 @@ int bez_ppo_loss(const float* mu_dev, const float* logstd_dev, const float* valu
   if (!(clip_value & 2)) (void)hipMemsetAsync(grad_logstd_dev, 0, (size_t)num_actions * sizeof(float), (hipStream_t)stream);  // bit 1: accumulate
   if (!(clip_value & 4)) (void)hipMemsetAsync(stats_dev, 0, 5 * sizeof(float), (hipStream_t)stream);                    // bit 2: the caller zeroed stats
 #define BEZ_PPO_LOSS(AA)                                                                                                                             \
-  hipLaunchKernelGGL(ppo_loss_kernel<AA>, dim3(nblk(batch)), dim3(PPO_TB), 0, (hipStream_t)stream, mu_dev, logstd_dev, value_dev, actions_dev, old_logp_dev,  \
+  hipLaunchKernelGGL(ppo_loss_kernel<AA>, dim3((unsigned)((batch + LOSS_TB - 1) / LOSS_TB)), dim3(LOSS_TB), 0, (hipStream_t)stream, mu_dev, logstd_dev, value_dev, actions_dev, old_logp_dev,  \
                      adv_dev, old_value_dev, returns_dev, old_mu_dev, old_sigma_dev, batch, e_clip, critic_coef, entropy_coef, bounds_coef,              \
                      (int)(clip_value & 1), loss_scale_dev, grad_mu_dev, grad_value_dev, grad_logstd_dev, stats_dev)
   switch (num_actions) {  // the action width is a compile-time constant of the kernel (register arrays, unrolled loops): bez has 18
