@@ -192,6 +192,15 @@ __global__ __launch_bounds__(LOSS_TB) void ppo_loss_kernel(const float* __restri
 #pragma unroll
       for (int j = 0; j < A; ++j) { const int k = tid + j * TB; raw[q][j] = k < nrow * A ? src[q][k] : 0.f; }
   }
+  if (clip_value & 8) {   // PPODataset.update_mu_sigma [ext]: the policy's current mu / sigma replace the minibatch's old ones (already in registers)
+    float* om = const_cast<float*>(old_mu) + row0 * A;
+    float* os = const_cast<float*>(old_sigma) + row0 * A;
+#pragma unroll
+    for (int j = 0; j < A; ++j) {
+      const int k = tid + j * TB;
+      if (k < nrow * A) { om[k] = raw[0][j]; os[k] = expf(logstd[k % A]); }
+    }
+  }
   auto rows_of = [&](const float* rq, float* r) {
     __syncthreads();
 #pragma unroll
@@ -241,7 +250,7 @@ __global__ __launch_bounds__(LOSS_TB) void ppo_loss_kernel(const float* __restri
     // value loss
     const float v = value[i], ov = old_value[i], rt = ret[i];
     float g_v;
-    if (clip_value) {
+    if (clip_value & 1) {
       const float dv = v - ov, dvc = fminf(fmaxf(dv, -e_clip), e_clip), vc = ov + dvc;
       const float q1 = (v - rt) * (v - rt), q2 = (vc - rt) * (vc - rt);
       c_l = fmaxf(q1, q2);
@@ -511,13 +520,20 @@ __global__ __launch_bounds__(PPO_TB) void adam_update_kernel(float* __restrict__
 // step counters (one per parameter tensor, all equal) and the loss-scale schedule (GradScaler.update)
 // ... and, in the same launch, the step's bookkeeping sums (tail: dst[i] += *src[i] * scale[i], e.g. the epoch's KL / loss accumulators)
 // and the reset of work[] for the next step (work is zero on entry of bez_ppo_adam_step and zero again on return: no memset per step)
-struct AdamTail { float* dst[4]; const float* src[4]; float scale[4]; int n; };
+struct AdamTail { float* dst[4]; const float* src[4]; float scale[4]; int n; float* lr; const float* kl; float kl_thr, min_lr, max_lr; };
 __global__ void adam_commit_kernel(float* __restrict__ steps, int nsteps, float* __restrict__ scale, int32_t* __restrict__ growth_tracker,
                                    float growth_factor, float backoff_factor, int32_t growth_interval, float* __restrict__ work, AdamTail tail) {
   const bool bad = scale && work[1] > 0.f;
   __syncthreads();
   if (threadIdx.x < 2) work[threadIdx.x] = 0.f;
   if ((int)threadIdx.x < tail.n) *tail.dst[threadIdx.x] += *tail.src[threadIdx.x] * tail.scale[threadIdx.x];
+  if (threadIdx.x == 0 && tail.kl) {   // rl_games AdaptiveScheduler.update ('legacy' schedule: after every minibatch step, for the NEXT one)
+    float v = tail.lr[0];
+    const float k = tail.kl[0];
+    if (k > 2.0f * tail.kl_thr) v = fmaxf(v / 1.5f, tail.min_lr);
+    if (k < 0.5f * tail.kl_thr) v = fminf(v * 1.5f, tail.max_lr);
+    tail.lr[0] = v;
+  }
   if (threadIdx.x < nsteps && !bad) steps[threadIdx.x] += 1.0f;
   if (threadIdx.x == 0 && scale) {
     if (bad) { scale[0] *= backoff_factor; growth_tracker[0] = 0; }
@@ -603,7 +619,7 @@ int bez_ppo_loss(const float* mu_dev, const float* logstd_dev, const float* valu
 #define BEZ_PPO_LOSS(AA)                                                                                                                             \
   hipLaunchKernelGGL(ppo_loss_kernel<AA>, dim3((unsigned)((batch + LOSS_TB - 1) / LOSS_TB)), dim3(LOSS_TB), 0, (hipStream_t)stream, mu_dev, logstd_dev, value_dev, actions_dev, old_logp_dev,  \
                      adv_dev, old_value_dev, returns_dev, old_mu_dev, old_sigma_dev, batch, e_clip, critic_coef, entropy_coef, bounds_coef,              \
-                     (int)(clip_value & 1), loss_scale_dev, grad_mu_dev, grad_value_dev, grad_logstd_dev, stats_dev)
+                     (int)(clip_value & 9), loss_scale_dev, grad_mu_dev, grad_value_dev, grad_logstd_dev, stats_dev)
   switch (num_actions) {  // the action width is a compile-time constant of the kernel (register arrays, unrolled loops): bez has 18
     case 1: BEZ_PPO_LOSS(1); break;
     case 2: BEZ_PPO_LOSS(2); break;
@@ -694,15 +710,16 @@ int bez_ppo_head_grads_f16(const float* grad_mu_dev, const float* grad_value_dev
 }
 
 int bez_ppo_adam_step(float* params_dev, const float* grads_dev, float* exp_avg_dev, float* exp_avg_sq_dev, int64_t n, float* steps_dev,
-                      int32_t nsteps, const float* lr_dev, float beta1, float beta2, float eps, float weight_decay, float max_norm, float* scale_dev,
+                      int32_t nsteps, float* lr_dev, float beta1, float beta2, float eps, float weight_decay, float max_norm, float* scale_dev,
                       int32_t* growth_tracker_dev, float growth_factor, float backoff_factor, int32_t growth_interval, float* work_dev,
                       void* params_f16_dev, int32_t ntail, float* const* tail_dst_dev, const float* const* tail_src_dev, const float* tail_scale,
-                      void* stream) {
+                      const float* adapt_kl_dev, float adapt_kl_threshold, float min_lr, float max_lr, void* stream) {
   if (!params_dev || !grads_dev || !exp_avg_dev || !exp_avg_sq_dev || !steps_dev || !lr_dev || !work_dev || n <= 0 || nsteps <= 0 || nsteps > 64 ||
       (scale_dev && !growth_tracker_dev) || ntail < 0 || ntail > 4 || (ntail > 0 && (!tail_dst_dev || !tail_src_dev || !tail_scale))) return -1;
   hipStream_t st = (hipStream_t)stream;
   AdamTail tail;
   tail.n = ntail;
+  tail.lr = lr_dev; tail.kl = adapt_kl_dev; tail.kl_thr = adapt_kl_threshold; tail.min_lr = min_lr; tail.max_lr = max_lr;
   for (int i = 0; i < 4; ++i) {
     tail.dst[i] = i < ntail ? tail_dst_dev[i] : nullptr; tail.src[i] = i < ntail ? tail_src_dev[i] : nullptr; tail.scale[i] = i < ntail ? tail_scale[i] : 0.f;
     if (i < ntail && (!tail.dst[i] || !tail.src[i])) return -1;
@@ -711,7 +728,7 @@ int bez_ppo_adam_step(float* params_dev, const float* grads_dev, float* exp_avg_
   if (g > 256) g = 256;
   hipLaunchKernelGGL(adam_norm_kernel, dim3(g), dim3(PPO_TB), 0, st, grads_dev, n, (const float*)scale_dev, work_dev);
   hipLaunchKernelGGL(adam_update_kernel, dim3(nblk(n)), dim3(PPO_TB), 0, st, params_dev, grads_dev, exp_avg_dev, exp_avg_sq_dev, n, (const float*)steps_dev,
-                     lr_dev, beta1, beta2, eps, weight_decay, max_norm, (const float*)scale_dev, (const float*)work_dev, (__half*)params_f16_dev);
+                     (const float*)lr_dev, beta1, beta2, eps, weight_decay, max_norm, (const float*)scale_dev, (const float*)work_dev, (__half*)params_f16_dev);
   hipLaunchKernelGGL(adam_commit_kernel, dim3(1), dim3(64), 0, st, steps_dev, (int)nsteps, scale_dev, growth_tracker_dev, growth_factor, backoff_factor,
                      growth_interval, work_dev, tail);
   return launch_ok();

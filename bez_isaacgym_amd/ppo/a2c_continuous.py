@@ -236,15 +236,18 @@ class AdaptiveScheduler:
         return lr
 
     @torch.no_grad()
-    def update_(self, lr_t, kl_t):
+    def update_(self, lr_t, kl_t, scale=1.0):
+        """scale: kl_t holds scale x the KL (a sum over rows instead of their mean): the thresholds are scaled instead."""
+        thr = self.kl_threshold * scale
         if isinstance(lr_t, torch.Tensor) and lr_t.is_cuda and lr_t.dtype == torch.float32 and kl_t.dtype == torch.float32 and lr_t.is_contiguous():
             from . import fused as F   # one launch instead of ten elementwise ones
-            return F.adaptive_lr(lr_t, kl_t, self.kl_threshold, self.min_lr, self.max_lr)
+            return F.adaptive_lr(lr_t, kl_t, thr, self.min_lr, self.max_lr)
         cur = lr_t.value if hasattr(lr_t, "value") else lr_t
+        kl_t = kl_t.reshape(())
         down = torch.clamp(cur / 1.5, min=self.min_lr)
-        lr1 = torch.where(kl_t > 2.0 * self.kl_threshold, down, cur)
+        lr1 = torch.where(kl_t > 2.0 * thr, down, cur)
         up = torch.clamp(lr1 * 1.5, max=self.max_lr)
-        lr_t.copy_(torch.where(kl_t < 0.5 * self.kl_threshold, up, lr1))
+        lr_t.copy_(torch.where(kl_t < 0.5 * thr, up, lr1))
 
 
 def discount_values(gamma, tau, fdones, last_values, mb_fdones, mb_values, mb_rewards):
@@ -319,6 +322,12 @@ class A2CAgent:
         self.last_lr = float(c["learning_rate"])
         self.is_adaptive_lr = c.get("lr_schedule") == "adaptive"
         self.scheduler = AdaptiveScheduler(float(c.get("kl_threshold", 0.008)))
+        # rl_games 1.1.3 (setup.py:22) [ext]: config.get('schedule_type', 'legacy') -- 'legacy' moves the learning rate after EVERY
+        # minibatch step on that step's KL, 'standard' once per mini-epoch on the mean; and PPODataset.update_mu_sigma stores the
+        # policy's current mu / sigma over the minibatch's old ones after every step, so from the second mini-epoch on the KL is
+        # measured against the previous pass, not against the rollout policy.  bez_kickPPO.yaml sets neither key.
+        self.schedule_type = str(c.get("schedule_type", "legacy"))
+        self.update_mu_sigma = bool(c.get("update_mu_sigma", True))
         self.name = c.get("full_experiment_name") or c.get("name", "bez_kick")
         self.writer = writer
         net = params["network"]
@@ -760,7 +769,8 @@ class A2CAgent:
             scale = self.scaler._scale
         self._flat.zero_()
         F.loss(mu32.detach(), net.sigma.detach(), v32.detach(), mb, self.e_clip, self.critic_coef, self.entropy_coef, self.bounds_loss_coef,
-               self.clip_value, scale, fx["gmu"], fx["gval"], net.sigma.grad, self._flat_stats, zero_glog=False, zero_stats=False)
+               self.clip_value, scale, fx["gmu"], fx["gval"], net.sigma.grad, self._flat_stats, zero_glog=False, zero_stats=False,
+               update_mu_sigma=self.update_mu_sigma)
         if manual:
             self._manual_backward(tf, fx["gmu"], fx["gval"])
         else:
@@ -853,10 +863,13 @@ class A2CAgent:
             rows = float(self.minibatch_size)
             st = self._flat_stats
             tail = ((kl_out, st[3:4], 1.0 / (rows * self.num_minibatches)), (loss_out[0:1], st[0:1], 1.0 / rows), (loss_out[1:2], st[1:2], 1.0 / rows))
+            # 'legacy' schedule: the lr moves after every step, in the same launch (the step's KL is a SUM over the rows: threshold scaled)
+            sc = self.scheduler
+            adapt = (self._flat_kl, sc.kl_threshold * rows, sc.min_lr, sc.max_lr) if self.is_adaptive_lr and self.schedule_type == "legacy" else None
             self._F.adam_step(self._pflat, self._flat[:self._nparam], self._mflat, self._vflat, self._steps, self.lr_t, g0["betas"], g0["eps"],
                               g0["weight_decay"], self.grad_norm if self.truncate_grads else 0.0, self.scaler._scale if amp else None,
                               self.scaler._growth_tracker if amp else None, self.scaler.get_growth_factor(), self.scaler.get_backoff_factor(),
-                              self.scaler.get_growth_interval(), self._opt_work, self._hflat, tail=tail)
+                              self.scaler.get_growth_interval(), self._opt_work, self._hflat, tail=tail, adapt=adapt)
             return
         else:
             if self.truncate_grads:
@@ -868,6 +881,8 @@ class A2CAgent:
             # (one launch each: add with a scalar multiplier)
             kl_out.add_(self._flat_kl[0], alpha=1.0 / (self.num_minibatches * float(self.minibatch_size)))
             loss_out.add_(self._flat_stats[0:2], alpha=1.0 / float(self.minibatch_size))
+            if self.is_adaptive_lr and self.schedule_type == "legacy":
+                self.scheduler.update_(self.lr_t, self._flat_kl, scale=float(self.minibatch_size))
 
     def _calc_gradients_fused(self, mb, kl_out, loss_out):
         """calc_gradients with the HIP glue kernels: running update of the input normaliser from the epoch's precomputed moments, MLP
@@ -926,6 +941,10 @@ class A2CAgent:
         with torch.no_grad():
             kl_out.add_(kl / self.num_minibatches)
             loss_out[0] += a_l.detach(); loss_out[1] += c_l.detach()
+            if self.update_mu_sigma:   # PPODataset.update_mu_sigma [ext]
+                mb["mu"].copy_(mu.detach()); mb["sigma"].copy_(sigma.detach())
+            if self.is_adaptive_lr and self.schedule_type == "legacy":
+                self.scheduler.update_(self.lr_t, kl.detach().float())
 
     def _minibatch(self, i):
         sl = slice(i * self.minibatch_size, (i + 1) * self.minibatch_size)
@@ -939,7 +958,7 @@ class A2CAgent:
         for ep in range(self.mini_epochs):
             for i in range(self.num_minibatches):
                 self.calc_gradients(self._minibatch(i), self.kl_acc[ep], self.loss_acc)
-            if self.is_adaptive_lr:
+            if self.is_adaptive_lr and self.schedule_type != "legacy":
                 self.scheduler.update_(self.lr_t, self.kl_acc[ep])
 
     def _update_segmented(self):
@@ -968,7 +987,7 @@ class A2CAgent:
                     dist.all_reduce(self._flat)
                 seg["c"].replay()
             self.kl_acc[ep].copy_(seg["kl"])
-            if self.is_adaptive_lr:
+            if self.is_adaptive_lr and self.schedule_type != "legacy":
                 self.scheduler.update_(self.lr_t, self.kl_acc[ep])
 
     def run_update(self):

@@ -32,7 +32,7 @@ _SIGS = {
     "bez_ppo_wgrad_run": [_vp, _vp, _i32, _vp],
     "bez_ppo_colsum_f16": [_vp, _i64, _i32, _vp, _i32, _vp],
     "bez_ppo_elu_bwd_colsum_f16": [_vp, _vp, _vp, _i64, _i32, _vp, _i32, _vp],
-    "bez_ppo_adam_step": [_vp, _vp, _vp, _vp, _i64, _vp, _i32, _vp, _f, _f, _f, _f, _f, _vp, _vp, _f, _f, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _vp],
+    "bez_ppo_adam_step": [_vp, _vp, _vp, _vp, _i64, _vp, _i32, _vp, _f, _f, _f, _f, _f, _vp, _vp, _f, _f, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _f, _f, _f, _vp],
 }
 _lib = None
 
@@ -113,21 +113,23 @@ def rollout_post(rew, dones, timeouts, values, reward_scale, gamma, bootstrap, s
 
 
 def loss(mu, logstd, value, mb, e_clip, critic_coef, entropy_coef, bounds_coef, clip_value, scale, gmu, gval, glog, stats, zero_glog=True,
-         zero_stats=True):
+         zero_stats=True, update_mu_sigma=False):
     """stats[5] <- sums of a_loss, c_loss, b_loss, kl, entropy (zero_stats False: the caller cleared them); gmu / gval <- gradient of the
-    mean loss (x loss scale); glog is ACCUMULATED into (zero_glog: cleared first)."""
+    mean loss (x loss scale); glog is ACCUMULATED into (zero_glog: cleared first); update_mu_sigma: mb["mu"] / mb["sigma"] are
+    overwritten with the current mu / exp(logstd) once the KL against the old ones is taken."""
     b, a = mu.shape
     _chk(lib().bez_ppo_loss(_p(mu), _p(logstd), _p(value), _p(mb["actions"]), _p(mb["old_logp"]), _p(mb["advantages"]), _p(mb["old_values"]),
                             _p(mb["returns"]), _p(mb["mu"]), _p(mb["sigma"]), b, a, float(e_clip), float(critic_coef), float(entropy_coef),
-                            float(bounds_coef), (1 if clip_value else 0) | (0 if zero_glog else 2) | (0 if zero_stats else 4), None if scale is None else _p(scale), _p(gmu),
+                            float(bounds_coef), (1 if clip_value else 0) | (0 if zero_glog else 2) | (0 if zero_stats else 4) | (8 if update_mu_sigma else 0), None if scale is None else _p(scale), _p(gmu),
                             _p(gval), _p(glog), _p(stats), _stream(mu)), "bez_ppo_loss")
 
 
 def adam_step(params, grads, exp_avg, exp_avg_sq, steps, lr, betas, eps, weight_decay, max_norm, scale, growth_tracker, growth_factor,
-              backoff_factor, growth_interval, work, params_f16=None, tail=()):
+              backoff_factor, growth_interval, work, params_f16=None, tail=(), adapt=None):
     """unscale + clip + Adam + scaler update on the flat buffers (csrc/bez_ppo.hip adam_*_kernel); scale / growth_tracker None = no AMP;
     params_f16 (flat fp16, same layout) receives the updated parameters in the same pass.  `work` (2 floats) must be zero on entry and is
-    zero again afterwards.  tail: up to 4 (dst, src, scale) with one-element fp32 tensors: dst += src * scale in the last launch."""
+    zero again afterwards.  tail: up to 4 (dst, src, scale) with one-element fp32 tensors: dst += src * scale in the last launch.
+    adapt = (kl, threshold, min_lr, max_lr): the AdaptiveScheduler rule moves `lr` on that one-element KL after the step."""
     n = params.numel()
     nt = len(tail)
     assert nt <= 4 and all(d.numel() == 1 and x.numel() == 1 for d, x, _ in tail)
@@ -138,7 +140,8 @@ def adam_step(params, grads, exp_avg, exp_avg_sq, steps, lr, betas, eps, weight_
                                  float(betas[1]), float(eps), float(weight_decay), float(max_norm), None if scale is None else _p(scale),
                                  None if growth_tracker is None else _p(growth_tracker, torch.int32), float(growth_factor), float(backoff_factor),
                                  int(growth_interval), _p(work), None if params_f16 is None else _p(params_f16, torch.float16), nt, td, ts, tsc,
-                                 _stream(params)),
+                                 None if adapt is None else _p(adapt[0]), float(adapt[1]) if adapt else 0.0, float(adapt[2]) if adapt else 0.0,
+                                 float(adapt[3]) if adapt else 0.0, _stream(params)),
          "bez_ppo_adam_step")
 
 

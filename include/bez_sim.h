@@ -296,7 +296,9 @@ int bez_ppo_rollout_post(const float* rew_dev, const int64_t* dones_dev, const i
  * outputs mu (B,A), value (B) and the log-std parameter (A), multiplied by *loss_scale_dev (GradScaler; NULL = 1).
  * stats_dev[5] = sums of a_loss, c_loss, b_loss, KL(current || old), entropy over the minibatch.
  * clip_value: bit 0 = clipped value loss; bit 1 = ACCUMULATE into grad_logstd_dev instead of clearing it first; bit 2 = stats_dev was
- * zeroed by the caller (e.g. as part of the flat gradient buffer's one clear per step). */
+ * zeroed by the caller (e.g. as part of the flat gradient buffer's one clear per step); bit 3 = after the KL is taken, WRITE the
+ * current mu and sigma = exp(logstd) over old_mu_dev / old_sigma_dev (rl_games' PPODataset.update_mu_sigma [ext]: from the second
+ * mini-epoch on the KL is measured against the previous pass over the minibatch). */
 int bez_ppo_loss(const float* mu_dev, const float* logstd_dev, const float* value_dev, const float* actions_dev, const float* old_logp_dev,
                  const float* adv_dev, const float* old_value_dev, const float* returns_dev, const float* old_mu_dev,
                  const float* old_sigma_dev, int64_t batch, int32_t num_actions, float e_clip, float critic_coef, float entropy_coef,
@@ -399,12 +401,14 @@ int bez_ppo_head_grads_f16(const float* grad_mu_dev, const float* grad_value_dev
  * ZERO on entry (allocate it zeroed), zero again on return (the last kernel clears it: no memset per step).
  * params_f16_dev (NULL or n fp16): receives the updated parameters as fp16 in the same pass (the AMP working copy).
  * ntail (0..4) bookkeeping sums ride in the last launch: *tail_dst_dev[i] += *tail_src_dev[i] * tail_scale[i] (host arrays of
- * device pointers / host floats) -- the epoch's KL and loss accumulators of a2c_common.py's train_epoch [ext]. */
+ * device pointers / host floats) -- the epoch's KL and loss accumulators of a2c_common.py's train_epoch [ext].
+ * adapt_kl_dev (NULL = off): after the step, *lr_dev moves by rl_games' AdaptiveScheduler rule on *adapt_kl_dev (lr /= 1.5 above
+ * 2 x adapt_kl_threshold, floor min_lr; lr *= 1.5 below half of it, cap max_lr) -- the 'legacy' schedule, once per minibatch step. */
 int bez_ppo_adam_step(float* params_dev, const float* grads_dev, float* exp_avg_dev, float* exp_avg_sq_dev, int64_t n, float* steps_dev,
-                      int32_t nsteps, const float* lr_dev, float beta1, float beta2, float eps, float weight_decay, float max_norm, float* scale_dev,
+                      int32_t nsteps, float* lr_dev, float beta1, float beta2, float eps, float weight_decay, float max_norm, float* scale_dev,
                       int32_t* growth_tracker_dev, float growth_factor, float backoff_factor, int32_t growth_interval, float* work_dev,
                       void* params_f16_dev, int32_t ntail, float* const* tail_dst_dev, const float* const* tail_src_dev, const float* tail_scale,
-                      void* stream);
+                      const float* adapt_kl_dev, float adapt_kl_threshold, float min_lr, float max_lr, void* stream);
 
 #ifdef __cplusplus
 }

@@ -206,6 +206,17 @@ def test_loss_kernel_value_and_gradient(clip_value, entropy_coef, b, a):
     np.testing.assert_allclose(gmu.cpu(), mu.grad.cpu(), atol=2e-5 * scale, rtol=1e-4)
     np.testing.assert_allclose(gval.cpu(), value.grad.cpu(), atol=2e-5 * float(value.grad.abs().max()), rtol=1e-4)
     np.testing.assert_allclose(glog.cpu(), logstd.grad.cpu(), rtol=2e-3, atol=2e-4 * float(logstd.grad.abs().max()))
+    # rl_games' PPODataset.update_mu_sigma folded into the same launch: identical results, and afterwards the minibatch's old mu / sigma
+    # hold the current policy's (a second pass measures its KL against this one: exactly 0 for unchanged weights up to the 1e-5 terms)
+    keep_mu, keep_sigma = old_mu.clone(), old_sigma.clone()
+    g2, s2 = torch.empty_like(gmu), torch.empty(5, device=DEV)
+    F.loss(mu.detach(), logstd.detach(), value.detach(), mb, e, cc, entropy_coef, bc, clip_value, torch.tensor([S], device=DEV), g2, gval, glog, s2,
+           update_mu_sigma=True)
+    assert torch.equal(g2, gmu) and torch.allclose(s2, stats, rtol=1e-5, atol=1e-3)   # (the sums are float atomics: order varies)
+    assert torch.equal(mb["mu"], mu.detach()) and torch.allclose(mb["sigma"], torch.exp(logstd.detach()).expand(b, a), rtol=1e-6, atol=0)
+    assert not torch.equal(keep_mu, mb["mu"]) and not torch.equal(keep_sigma, mb["sigma"])
+    F.loss(mu.detach(), logstd.detach(), value.detach(), mb, e, cc, entropy_coef, bc, clip_value, torch.tensor([S], device=DEV), g2, gval, glog, s2)
+    assert abs(float(s2[3]) / b) < 2e-3   # (c2's 1e-5 makes the self-KL slightly negative: -0.5 * 1e-5 / sigma^2 per action)
 
 
 def test_half_linear_gradient_reductions():
@@ -291,6 +302,14 @@ def test_adam_step_kernel_matches_torch_amp_clip_adam():
     assert seen == [1024.0, 1024.0, 2048.0, 2048.0, 1024.0, 1024.0, 1024.0]  # grown after 3 clean steps, backed off by the inf step
     want_m = torch.cat([opt.state[p]["exp_avg"].reshape(-1) for p in ref])
     np.testing.assert_allclose(mflat.cpu(), want_m.cpu(), rtol=1e-5, atol=1e-8)
+    # the 'legacy' schedule riding in the last launch: the lr moves AFTER the step that used it, by AdaptiveScheduler's rule
+    lr2, klt = torch.tensor([3e-4], device=DEV), torch.zeros(1, device=DEV)
+    for kl, want in ((0.02, 2e-4), (0.02, 2e-4 / 1.5), (0.001, 2e-4), (0.008, 2e-4), (0.0, 3e-4)):
+        klt.fill_(kl)
+        before = pflat.clone()
+        F.adam_step(pflat, gflat, mflat, vflat, steps, lr2, (0.9, 0.999), 1e-8, 0.0, 1.0, None, None, 2.0, 0.5, 3, work, None,
+                    adapt=(klt, 0.008, 1e-6, 1e-2))
+        assert abs(float(lr2) - want) < 1e-9 and not torch.equal(before, pflat)
 
 
 def test_fused_and_plain_optimiser_step_agree():
