@@ -474,7 +474,12 @@ __global__ __launch_bounds__(PPO_TB) void gae_kernel(const float* __restrict__ r
 
 // ---- the optimiser tail of one minibatch step on the flat fp32 buffers: GradScaler.unscale_ + clip_grad_norm_ + Adam (torch
 // semantics, no amsgrad) + GradScaler.update, three launches instead of torch's dozen.
-// work[0] = sum of squares of the UNSCALED gradient, work[1] = number of non-finite elements (caller zeroes both).
+// work[1] = number of non-finite elements (an integer-valued float: exact in any order; zero on entry, re-zeroed by the last kernel);
+// work[2 + b] = block b's sum of squares of the UNSCALED gradient.  The squared norm is the FIXED-ORDER sum of those partials, formed
+// again by every block of the update kernel: float atomics would make the clip coefficient differ in its last bits from run to run
+// and, data parallel, from rank to rank -- the replicas' weights then drift apart (tests: test_two_ranks_on_the_gpu_stay_bit_identical).
+constexpr int ADAM_NORM_BLOCKS = 256;
+static_assert(2 + ADAM_NORM_BLOCKS <= BEZ_PPO_ADAM_WORK_FLOATS, "work buffer of the C ABI too small");
 __global__ __launch_bounds__(PPO_TB) void adam_norm_kernel(const float* __restrict__ g, int64_t n, const float* __restrict__ scale, float* __restrict__ work) {
   __shared__ float red[2][4];
   const float inv = scale ? 1.0f / scale[0] : 1.0f;
@@ -488,7 +493,7 @@ __global__ __launch_bounds__(PPO_TB) void adam_norm_kernel(const float* __restri
   if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s2; red[1][threadIdx.x >> 6] = bad; }
   __syncthreads();
   if (threadIdx.x == 0) {
-    atomicAdd(&work[0], (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]));
+    work[2 + blockIdx.x] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
     const float b = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
     if (b > 0.f) atomicAdd(&work[1], b);
   }
@@ -497,13 +502,23 @@ __global__ __launch_bounds__(PPO_TB) void adam_norm_kernel(const float* __restri
 __global__ __launch_bounds__(PPO_TB) void adam_update_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                                                              int64_t n, const float* __restrict__ steps, const float* __restrict__ lr, float beta1,
                                                              float beta2, float eps, float weight_decay, float max_norm,
-                                                             const float* __restrict__ scale, const float* __restrict__ work, __half* __restrict__ p16) {
+                                                             const float* __restrict__ scale, const float* __restrict__ work, int nparts,
+                                                             __half* __restrict__ p16) {
+  static_assert(PPO_TB == ADAM_NORM_BLOCKS, "one partial per thread");
+  __shared__ float red[4];
+  float coef = 1.0f;
+  if (max_norm > 0.f) {   // clip_grad_norm_: the same fixed-order sum in every block (and on every rank)
+    float part = (int)threadIdx.x < nparts ? work[2 + threadIdx.x] : 0.f;
+    part = wave_sum(part);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = part;
+    __syncthreads();
+    const float norm2 = (red[0] + red[1]) + (red[2] + red[3]);
+    coef = fminf(max_norm / (sqrtf(norm2) + 1e-6f), 1.0f);
+  }
   const int64_t i = (int64_t)blockIdx.x * PPO_TB + threadIdx.x;
   if (i >= n) return;
   if (scale && work[1] > 0.f) return;
   const float inv = scale ? 1.0f / scale[0] : 1.0f;
-  float coef = 1.0f;
-  if (max_norm > 0.f) coef = fminf(max_norm / (sqrtf(work[0]) + 1e-6f), 1.0f);  // clip_grad_norm_
   const float t = steps[0] + 1.0f;
   const float bc1 = 1.0f - powf(beta1, t), bc2 = 1.0f - powf(beta2, t);
   float x = g[i] * inv * coef;
@@ -725,10 +740,10 @@ int bez_ppo_adam_step(float* params_dev, const float* grads_dev, float* exp_avg_
     if (i < ntail && (!tail.dst[i] || !tail.src[i])) return -1;
   }
   unsigned g = nblk(n);
-  if (g > 256) g = 256;
+  if (g > (unsigned)ADAM_NORM_BLOCKS) g = ADAM_NORM_BLOCKS;
   hipLaunchKernelGGL(adam_norm_kernel, dim3(g), dim3(PPO_TB), 0, st, grads_dev, n, (const float*)scale_dev, work_dev);
   hipLaunchKernelGGL(adam_update_kernel, dim3(nblk(n)), dim3(PPO_TB), 0, st, params_dev, grads_dev, exp_avg_dev, exp_avg_sq_dev, n, (const float*)steps_dev,
-                     (const float*)lr_dev, beta1, beta2, eps, weight_decay, max_norm, (const float*)scale_dev, (const float*)work_dev, (__half*)params_f16_dev);
+                     (const float*)lr_dev, beta1, beta2, eps, weight_decay, max_norm, (const float*)scale_dev, (const float*)work_dev, (int)g, (__half*)params_f16_dev);
   hipLaunchKernelGGL(adam_commit_kernel, dim3(1), dim3(64), 0, st, steps_dev, (int)nsteps, scale_dev, growth_tracker_dev, growth_factor, backoff_factor,
                      growth_interval, work_dev, tail);
   return launch_ok();

@@ -675,7 +675,7 @@ class A2CAgent:
         self._mflat = torch.zeros(n, device=dev, dtype=torch.float32)
         self._vflat = torch.zeros(n, device=dev, dtype=torch.float32)
         self._steps = torch.zeros(len(params), device=dev, dtype=torch.float32)
-        self._opt_work = torch.zeros(2, device=dev, dtype=torch.float32)
+        self._opt_work = torch.zeros(self._F.ADAM_WORK_FLOATS, device=dev, dtype=torch.float32)
         off = 0
         with torch.no_grad():
             for k, p in enumerate(params):

@@ -124,6 +124,9 @@ def loss(mu, logstd, value, mb, e_clip, critic_coef, entropy_coef, bounds_coef, 
                             _p(gval), _p(glog), _p(stats), _stream(mu)), "bez_ppo_loss")
 
 
+ADAM_WORK_FLOATS = 258   # BEZ_PPO_ADAM_WORK_FLOATS
+
+
 def adam_step(params, grads, exp_avg, exp_avg_sq, steps, lr, betas, eps, weight_decay, max_norm, scale, growth_tracker, growth_factor,
               backoff_factor, growth_interval, work, params_f16=None, tail=(), adapt=None):
     """unscale + clip + Adam + scaler update on the flat buffers (csrc/bez_ppo.hip adam_*_kernel); scale / growth_tracker None = no AMP;
@@ -131,6 +134,7 @@ def adam_step(params, grads, exp_avg, exp_avg_sq, steps, lr, betas, eps, weight_
     zero again afterwards.  tail: up to 4 (dst, src, scale) with one-element fp32 tensors: dst += src * scale in the last launch.
     adapt = (kl, threshold, min_lr, max_lr): the AdaptiveScheduler rule moves `lr` on that one-element KL after the step."""
     n = params.numel()
+    assert work.numel() >= ADAM_WORK_FLOATS, "work: BEZ_PPO_ADAM_WORK_FLOATS zero-initialised floats"
     nt = len(tail)
     assert nt <= 4 and all(d.numel() == 1 and x.numel() == 1 for d, x, _ in tail)
     td = (C.c_void_p * 4)(*[_p(d).value for d, _, _ in tail])

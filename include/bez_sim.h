@@ -397,13 +397,16 @@ int bez_ppo_head_grads_f16(const float* grad_mu_dev, const float* grad_value_dev
  * clip_grad_norm_ + scaler.step(Adam) + scaler.update, a2c_common.py [ext] via train.py:89-113): the gradient is divided by
  * *scale_dev (NULL = no loss scaling), clipped to max_norm (<= 0: no clipping), applied with torch's Adam formula; a non-finite
  * gradient skips the step and backs the scale off, growth_interval clean steps grow it.  steps_dev[nsteps] are the per-tensor
- * step counters of the optimiser state (all equal).  work_dev[2]: squared norm of the unscaled gradient / non-finite count --
- * ZERO on entry (allocate it zeroed), zero again on return (the last kernel clears it: no memset per step).
+ * step counters of the optimiser state (all equal).  work_dev[BEZ_PPO_ADAM_WORK_FLOATS]: [1] non-finite count, [2..] per-block
+ * partial sums of the squared gradient norm, added in FIXED order (no float atomics: the clip coefficient, and with it every
+ * weight, is bit-identical run to run and rank to rank) -- ZERO on entry (allocate it zeroed), [0..1] zero again on return (the
+ * last kernel clears them: no memset per step).
  * params_f16_dev (NULL or n fp16): receives the updated parameters as fp16 in the same pass (the AMP working copy).
  * ntail (0..4) bookkeeping sums ride in the last launch: *tail_dst_dev[i] += *tail_src_dev[i] * tail_scale[i] (host arrays of
  * device pointers / host floats) -- the epoch's KL and loss accumulators of a2c_common.py's train_epoch [ext].
  * adapt_kl_dev (NULL = off): after the step, *lr_dev moves by rl_games' AdaptiveScheduler rule on *adapt_kl_dev (lr /= 1.5 above
  * 2 x adapt_kl_threshold, floor min_lr; lr *= 1.5 below half of it, cap max_lr) -- the 'legacy' schedule, once per minibatch step. */
+#define BEZ_PPO_ADAM_WORK_FLOATS 258
 int bez_ppo_adam_step(float* params_dev, const float* grads_dev, float* exp_avg_dev, float* exp_avg_sq_dev, int64_t n, float* steps_dev,
                       int32_t nsteps, float* lr_dev, float beta1, float beta2, float eps, float weight_decay, float max_norm, float* scale_dev,
                       int32_t* growth_tracker_dev, float growth_factor, float backoff_factor, int32_t growth_interval, float* work_dev,

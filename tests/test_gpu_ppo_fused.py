@@ -271,7 +271,7 @@ def test_adam_step_kernel_matches_torch_amp_clip_adam():
     scaler._lazy_init_scale_growth_tracker(torch.device(DEV))  # what scaler.scale(loss) would do
     pflat = torch.cat([p.detach().reshape(-1) for p in ref]).clone()
     mflat, vflat = torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
-    steps, work = torch.zeros(len(shapes), device=DEV), torch.zeros(2, device=DEV)
+    steps, work = torch.zeros(len(shapes), device=DEV), torch.zeros(F.ADAM_WORK_FLOATS, device=DEV)
     hflat = torch.zeros(n, device=DEV, dtype=torch.float16)
     scale, tracker = torch.tensor([1024.0], device=DEV), torch.zeros(1, device=DEV, dtype=torch.int32)
     seen = []
@@ -290,7 +290,7 @@ def test_adam_step_kernel_matches_torch_amp_clip_adam():
         scaler.update()
         F.adam_step(pflat, gflat, mflat, vflat, steps, lr, (0.9, 0.999), 1e-8, 0.0, 1.0, scale, tracker, 2.0, 0.5, 3, work, hflat,
                     tail=((acc[0:1], src[0:1], 2.0), (acc[1:2], src[1:2], 0.5), (acc[2:3], src[2:3], 1.0)))
-        assert work.tolist() == [0.0, 0.0]           # left zero for the next step (no memset per step)
+        assert work[:2].tolist() == [0.0, 0.0]       # left zero for the next step (no memset per step)
         assert acc.tolist() == [3.0 * (it + 1), -1.0 * (it + 1), 0.25 * (it + 1)]   # the bookkeeping sums of the last launch, skipped step or not
         if it != 4:
             assert torch.equal(hflat, pflat.half())  # the fp16 working copy written in the same pass
@@ -533,6 +533,92 @@ print("DP_OK", st[-1]["kl"])
 ''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert "DP_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
+def test_two_ranks_on_the_gpu_stay_bit_identical(tmp_path):
+    """World size 2 with the real HIP kernels: two processes share the 1-GPU box's card, each with its own shard of envs (global env
+    ids rank * N + e), segmented HIP graphs, the step's one all-reduce between the replays.  RCCL refuses two ranks on one device, so
+    the transport here is gloo (staged through the host when gloo has no device support); what is under test is everything around
+    the collective: after 2 eager + 1 capturing + 2 replayed epochs both replicas hold bit-identical parameters, Adam moments,
+    learning rate and loss scale, their rollouts differ (different env shards), and an epoch issues steps + 2 collectives."""
+    import os
+    import subprocess
+    import sys
+    code = '''
+import os, sys, hashlib, numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+rank = int(os.environ["RANK"])
+torch.cuda.set_device(0)
+dist.init_process_group("gloo", rank=rank, world_size=2)
+real = dist.all_reduce
+calls = []
+def staged(t, *a, **k):
+    calls.append(int(t.numel()))
+    if t.is_cuda:
+        h = t.detach().cpu()
+        real(h, *a, **k)
+        t.copy_(h)
+        return None
+    return real(t, *a, **k)
+dist.all_reduce = staged
+real_bc = dist.broadcast
+def staged_bc(t, src=0, *a, **k):
+    if t.is_cuda:
+        h = t.detach().cpu()
+        real_bc(h, src, *a, **k)
+        t.copy_(h)
+        return None
+    return real_bc(t, src, *a, **k)
+dist.broadcast = staged_bc
+from bez_isaacgym_amd.ppo.a2c_continuous import A2CAgent
+from bez_isaacgym_amd.utils.config import load_config
+from bez_isaacgym_amd.utils.rlgames_utils import RLGPUEnv, get_rlgames_env_creator
+N = 512
+cfg = load_config(["task=bez_kick", "num_envs=%%d" %% N, "headless=True"])
+cfg["task"]["seed"] = 42
+cfg["task"]["env_id_offset"] = rank * N          # what create_rlgpu_env records for a rank (rlgames_utils.py:71-81 + global env ids)
+venv = RLGPUEnv("rlgpu", N, env_creator=get_rlgames_env_creator(cfg["task"], "bez_kick", "cuda:0", "cuda:0", 0, True))
+params = cfg["train"]["params"]
+params["config"].update(minibatch_size=4096, save_frequency=0, save_best_after=10 ** 9)
+a = A2CAgent(params, venv, "cuda:0", rank=rank, world=2)
+a.obs = a.env_reset()
+st = [a.train_epoch() for _ in range(5)]
+torch.cuda.synchronize()
+assert a._seg is not None and a._g_rollout is not None, "segmented graphs were not captured"
+assert all(np.isfinite([s["kl"], s["a_loss"], s["c_loss"]]).all() for s in st), st
+calls.clear()
+a.train_epoch()
+steps = a.mini_epochs * a.num_minibatches
+assert len(calls) == steps + 2 and calls[2:] == [a._flat.numel()] * steps, calls
+def digest(ts):
+    h = hashlib.sha256()
+    for t in ts:
+        h.update(t.detach().cpu().numpy().tobytes())
+    return h.hexdigest()
+mine = [digest(list(a.model.parameters())), digest([a._mflat, a._vflat, a._steps]), digest([a.lr_t.reshape(1), a.scaler._scale.reshape(1)]),
+        digest([a.running_mean_std.running_mean, a.running_mean_std.running_var, a.value_mean_std.running_mean]),
+        digest([a.mb["obs"]])]
+both = [None, None]
+dist.all_gather_object(both, mine)
+assert both[0][:4] == both[1][:4], ("replicas diverged", both)
+assert both[0][4] != both[1][4], "both ranks rolled out the same envs"
+dist.barrier()
+dist.destroy_process_group()
+print("DP2_OK", rank, st[-1]["kl"])
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29791", WORLD_SIZE="2", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, "-c", code], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+             for r in range(2)]
+    outs = []
+    for p in procs:
+        try:
+            outs.append(p.communicate(timeout=420))
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+    for r, (so, se) in enumerate(outs):
+        assert "DP2_OK %d" % r in so, so[-2000:] + se[-3000:]
 
 
 @pytest.mark.parametrize("rows,shapes", [
