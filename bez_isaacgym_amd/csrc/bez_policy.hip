@@ -313,7 +313,8 @@ struct BackwardArgs {
   _Float16* gmu16; _Float16* gv16;
   float* bgrad[PF_MAXL]; float* bmu_grad; float* bv_grad;
   int packed;  // wt[L] / wht are fragment-major (packed as Linear(out = width[L-1], in = width[L]) and Linear(out = width[last], in = 32))
-  float* partial; int ptotal; int poff[PF_MAXL];  // per-workgroup column sums of gz (ceil(n / 64), ptotal = sum of the widths), layer L at poff[L]
+  float* partial; int ptotal; int poff[PF_MAXL];  // per-workgroup column sums of gz (ceil(n / 64) rows of prow floats; ptotal = sum of the widths, layer L at poff[L])
+  int prow;                                       // = ptotal + 32: the heads' column sums [d/d mu | d/d value] follow the hidden layers' in a row
 };
 
 // one layer of the chain: gz = g * elu'(y) in place in tile A (and out to HBM), its per-workgroup column sums, then d/d h_{L-1} = gz W_L
@@ -364,7 +365,7 @@ __device__ __forceinline__ void backward_stage(const BackwardArgs& a, _Float16 (
     float sx = 0.f, sy = 0.f;
     for (int q = 0; q < nparts; ++q) { sx += red[q * ncp + tid].x; sy += red[q * ncp + tid].y; }
     // (512 workgroups adding to the same 700 addresses cost 20 us of the kernel: per-workgroup partials + one small reduction instead)
-    float* dst = a.partial + (size_t)blockIdx.x * a.ptotal + a.poff[L] + 2 * tid;
+    float* dst = a.partial + (size_t)blockIdx.x * a.prow + a.poff[L] + 2 * tid;
     dst[0] = sx; dst[1] = sy;
   }
   if (L > 0) {
@@ -406,10 +407,10 @@ __global__ __launch_bounds__(PF_WAVES * 64, ((LD0 + LD1) * PF_ROWS * 2 <= 80 * 1
     }
     red[tid] = acc;
     __syncthreads();
-    if (tid <= A) {
+    if (tid <= A) {   // per-workgroup partial, added in fixed order by policy_bias_reduce_kernel (no float atomics: bit-reproducible)
       float sum = 0.f;
       for (int q = 0; q < NT / 32; ++q) sum += red[q * 32 + tid];
-      atomicAdd(tid < A ? &a.bmu_grad[tid] : a.bv_grad, sum);
+      a.partial[(size_t)blockIdx.x * a.prow + a.ptotal + tid] = sum;
     }
     __syncthreads();
   }
@@ -423,26 +424,32 @@ __global__ __launch_bounds__(PF_WAVES * 64, ((LD0 + LD1) * PF_ROWS * 2 <= 80 * 1
   }
 }
 
-// bias gradients of the hidden layers: column c of layer L += sum over the workgroups' partials.  1024 threads = 16 row lanes x 64
-// columns; a row lane sums every 16th partial (eight loads in flight), the lanes meet in LDS in a fixed order (deterministic)
+// bias gradients of the hidden layers and of the two heads: column c += sum over the workgroups' partials.  1024 threads = 16 row lanes
+// x 64 columns; a row lane sums every 16th partial (eight loads in flight), the lanes meet in LDS in a fixed order (deterministic)
 __global__ __launch_bounds__(1024) void policy_bias_reduce_kernel(BackwardArgs a, int nwg) {
   __shared__ float sh[16][64];
   const int l = threadIdx.x & 63, rl = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + l;
+  const int ncol = a.ptotal + a.num_actions + 1;
   float s = 0.f;
-  if (c < a.ptotal) {
+  if (c < ncol) {
 #pragma unroll 8
-    for (int w = rl; w < nwg; w += 16) s += a.partial[(size_t)w * a.ptotal + c];
+    for (int w = rl; w < nwg; w += 16) s += a.partial[(size_t)w * a.prow + c];
   }
   sh[rl][l] = s;
   __syncthreads();
-  if (rl == 0 && c < a.ptotal) {
+  if (rl == 0 && c < ncol) {
     float t = 0.f;
 #pragma unroll
     for (int q = 0; q < 16; ++q) t += sh[q][l];
-    int L = 0;
-    while (L + 1 < a.nhid && c >= a.poff[L + 1]) ++L;
-    a.bgrad[L][c - a.poff[L]] += t;
+    if (c >= a.ptotal) {
+      const int k = c - a.ptotal;
+      if (k < a.num_actions) a.bmu_grad[k] += t; else a.bv_grad[0] += t;
+    } else {
+      int L = 0;
+      while (L + 1 < a.nhid && c >= a.poff[L + 1]) ++L;
+      a.bgrad[L][c - a.poff[L]] += t;
+    }
   }
 }
 
@@ -574,6 +581,7 @@ extern "C" int bez_ppo_policy_backward(const float* grad_mu_dev, const float* gr
   a.partial = partial_dev; a.ptotal = 0; a.packed = weights_packed;
   for (int i = 0; i < PF_MAXL; ++i) a.poff[i] = 0;
   for (int i = 0; i < num_hidden; ++i) { a.poff[i] = a.ptotal; a.ptotal += hidden_width[i]; }
+  a.prow = a.ptotal + 32;
   const unsigned nwg = (unsigned)((n + PF_ROWS - 1) / PF_ROWS);
   int w0 = 32, w1 = 0;  // widest tenant of each tile (see policy_backward_kernel)
   for (int i = 0; i < num_hidden; ++i) { int& w = ((num_hidden - 1 - i) & 1) ? w0 : w1; if (hidden_width[i] > w) w = hidden_width[i]; }
@@ -582,7 +590,7 @@ extern "C" int bez_ppo_policy_backward(const float* grad_mu_dev, const float* gr
   else if (narrow) hipLaunchKernelGGL((policy_backward_kernel<216, PF_LD, false>), dim3(nwg), dim3(PF_WAVES * 64), 0, (hipStream_t)stream, a);
   else if (weights_packed) hipLaunchKernelGGL((policy_backward_kernel<PF_LD, PF_LD, true>), dim3(nwg), dim3(PF_WAVES * 64), 0, (hipStream_t)stream, a);
   else hipLaunchKernelGGL((policy_backward_kernel<PF_LD, PF_LD, false>), dim3(nwg), dim3(PF_WAVES * 64), 0, (hipStream_t)stream, a);
-  hipLaunchKernelGGL(policy_bias_reduce_kernel, dim3((unsigned)((a.ptotal + 63) / 64)), dim3(1024), 0, (hipStream_t)stream, a, (int)nwg);
+  hipLaunchKernelGGL(policy_bias_reduce_kernel, dim3((unsigned)((a.ptotal + num_actions + 1 + 63) / 64)), dim3(1024), 0, (hipStream_t)stream, a, (int)nwg);
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 

@@ -27,7 +27,8 @@ __device__ __forceinline__ double wave_sum(double v) {
 }
 
 // ---- RunningMeanStd (rl_games): per-column sum / sum of squares of x (B,D) in fp64 -> out[0:D], out[D:2D]; out[2D] = B
-__global__ __launch_bounds__(PPO_TB) void rms_moments_kernel(const float* __restrict__ x, int64_t B, int D, double* __restrict__ out) {
+__global__ __launch_bounds__(PPO_TB) void rms_moments_kernel(const float* __restrict__ x, int64_t B, int D, double* __restrict__ out,
+                                                             double* __restrict__ scratch) {
   // 256 threads = 4 row lanes x 64 column lanes (D <= 64)
   const int col = threadIdx.x & 63, rl = threadIdx.x >> 6;
   __shared__ double sh[2][4][64];
@@ -44,10 +45,32 @@ __global__ __launch_bounds__(PPO_TB) void rms_moments_kernel(const float* __rest
   if (rl == 0 && col < D) {
     s1 = sh[0][0][col] + sh[0][1][col] + sh[0][2][col] + sh[0][3][col];
     s2 = sh[1][0][col] + sh[1][1][col] + sh[1][2][col] + sh[1][3][col];
-    atomicAdd(&out[col], s1);
-    atomicAdd(&out[D + col], s2);
+    if (!scratch) {   // fp64 atomics: the sums differ in their last bits from run to run
+      atomicAdd(&out[col], s1);
+      atomicAdd(&out[D + col], s2);
+    } else {
+      scratch[1 + (size_t)blockIdx.x * 2 * D + col] = s1;
+      scratch[1 + (size_t)blockIdx.x * 2 * D + D + col] = s2;
+    }
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) out[2 * D] = (double)B;
+  if (!scratch) return;
+  // bit-reproducible: per-workgroup partials, added in workgroup order by the LAST workgroup to arrive (ticket counter in the first
+  // word of scratch: zero on entry, zero again on exit); agent-scope release / atomic loads make the partials visible across XCDs
+  __shared__ int is_last;
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) is_last = (atomicAdd(reinterpret_cast<unsigned int*>(scratch), 1u) == gridDim.x - 1u) ? 1 : 0;
+  __syncthreads();
+  if (!is_last) return;
+  __threadfence();
+  if ((int)threadIdx.x < 2 * D) {
+    double acc = 0.0;
+    for (unsigned int b = 0; b < gridDim.x; ++b)
+      acc += __hip_atomic_load(&scratch[1 + (size_t)b * 2 * D + threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    out[threadIdx.x] = acc;
+  }
+  if (threadIdx.x == 0) __hip_atomic_store(reinterpret_cast<unsigned int*>(scratch), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // parallel-variance update of (mean, var, count) from the (possibly all-reduced) moments: a2c_continuous.py RunningMeanStd.update
@@ -173,7 +196,7 @@ __global__ __launch_bounds__(LOSS_TB) void ppo_loss_kernel(const float* __restri
                                                            const float* __restrict__ old_sigma, int64_t B, float e_clip, float critic_coef,
                                                            float entropy_coef, float bounds_coef, int clip_value, const float* __restrict__ scale,
                                                            float* __restrict__ grad_mu, float* __restrict__ grad_value, float* __restrict__ grad_logstd,
-                                                           float* __restrict__ stats) {
+                                                           float* __restrict__ stats, float* __restrict__ scratch) {
   constexpr int LD = A + 1, TB = LOSS_TB;
   __shared__ float tile[TB * LD];
   const int tid = threadIdx.x;
@@ -293,7 +316,31 @@ __global__ __launch_bounds__(LOSS_TB) void ppo_loss_kernel(const float* __restri
   if (tid == A + 2) mine = b_l;
   if (tid == A + 3) mine = kl;
   if (tid == A + 4) mine = ent;
-  if (tid < A + 5) atomicAdd(tid < A ? &grad_logstd[tid] : &stats[tid - A], mine);
+  if (!scratch) {   // one float atomic each (A + 5 per 64 samples): the sums then differ in their last bits from run to run
+    if (tid < A + 5) atomicAdd(tid < A ? &grad_logstd[tid] : &stats[tid - A], mine);
+    return;
+  }
+  // bit-reproducible: every workgroup stores its A + 5 partials, the LAST one to arrive (a ticket counter in scratch[0], zero on entry,
+  // zero again on exit) adds all of them in a fixed order -- lane l takes workgroups l, l + 64, ..., then the butterfly -- and is the
+  // only writer of grad_logstd / stats.  Partials are published with an agent-scope release and read back with agent-scope atomic
+  // loads, so they are visible across the 8 XCDs' L2s.
+  constexpr int NV = A + 5;
+  __shared__ int is_last;
+  if (tid < NV) scratch[2 + (size_t)blockIdx.x * NV + tid] = mine;
+  __threadfence();
+  __syncthreads();
+  if (tid == 0) is_last = (atomicAdd(reinterpret_cast<unsigned int*>(scratch), 1u) == gridDim.x - 1u) ? 1 : 0;
+  __syncthreads();
+  if (!is_last) return;
+  __threadfence();
+  for (int c = 0; c < NV; ++c) {
+    float acc = 0.f;
+    for (unsigned int b = tid; b < gridDim.x; b += TB)
+      acc += __hip_atomic_load(&scratch[2 + (size_t)b * NV + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    acc = wave_sum(acc);
+    if (tid == 0) { if (c < A) grad_logstd[c] += acc; else stats[c - A] += acc; }
+  }
+  if (tid == 0) __hip_atomic_store(reinterpret_cast<unsigned int*>(scratch), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // ---- gradient reductions of the explicit-fp16 linear layers (a2c_continuous.py _HalfLinearFn), written straight into the fp32
@@ -567,12 +614,12 @@ unsigned nblk(int64_t n) { return (unsigned)((n + PPO_TB - 1) / PPO_TB); }
 
 extern "C" {
 
-int bez_ppo_rms_moments(const float* x_dev, int64_t rows, int32_t cols, double* moments_dev, void* stream) {
+int bez_ppo_rms_moments(const float* x_dev, int64_t rows, int32_t cols, double* moments_dev, double* scratch_dev, void* stream) {
   if (!x_dev || !moments_dev || rows <= 0 || cols <= 0 || cols > 64) return -1;
-  (void)hipMemsetAsync(moments_dev, 0, (size_t)(2 * cols + 1) * sizeof(double), (hipStream_t)stream);
+  if (!scratch_dev) (void)hipMemsetAsync(moments_dev, 0, (size_t)(2 * cols + 1) * sizeof(double), (hipStream_t)stream);  // (the fixed-order path overwrites)
   unsigned g = (unsigned)((rows + 127) / 128);
   if (g > 1024) g = 1024;
-  hipLaunchKernelGGL(rms_moments_kernel, dim3(g), dim3(PPO_TB), 0, (hipStream_t)stream, x_dev, rows, (int)cols, moments_dev);
+  hipLaunchKernelGGL(rms_moments_kernel, dim3(g), dim3(PPO_TB), 0, (hipStream_t)stream, x_dev, rows, (int)cols, moments_dev, scratch_dev);
   return launch_ok();
 }
 int bez_ppo_rms_apply(const double* moments_dev, int32_t cols, double* mean_dev, double* var_dev, double* count_dev, void* stream) {
@@ -626,7 +673,8 @@ int bez_ppo_rollout_post(const float* rew_dev, const int64_t* dones_dev, const i
 int bez_ppo_loss(const float* mu_dev, const float* logstd_dev, const float* value_dev, const float* actions_dev, const float* old_logp_dev,
                  const float* adv_dev, const float* old_value_dev, const float* returns_dev, const float* old_mu_dev, const float* old_sigma_dev,
                  int64_t batch, int32_t num_actions, float e_clip, float critic_coef, float entropy_coef, float bounds_coef, int32_t clip_value,
-                 const float* loss_scale_dev, float* grad_mu_dev, float* grad_value_dev, float* grad_logstd_dev, float* stats_dev, void* stream) {
+                 const float* loss_scale_dev, float* grad_mu_dev, float* grad_value_dev, float* grad_logstd_dev, float* stats_dev,
+                 float* scratch_dev, void* stream) {
   if (!mu_dev || !logstd_dev || !value_dev || !actions_dev || !old_logp_dev || !adv_dev || !old_value_dev || !returns_dev || !old_mu_dev ||
       !old_sigma_dev || !grad_mu_dev || !grad_value_dev || !grad_logstd_dev || !stats_dev || batch <= 0 || num_actions <= 0 || num_actions > 32) return -1;
   if (!(clip_value & 2)) (void)hipMemsetAsync(grad_logstd_dev, 0, (size_t)num_actions * sizeof(float), (hipStream_t)stream);  // bit 1: accumulate
@@ -634,7 +682,7 @@ int bez_ppo_loss(const float* mu_dev, const float* logstd_dev, const float* valu
 #define BEZ_PPO_LOSS(AA)                                                                                                                             \
   hipLaunchKernelGGL(ppo_loss_kernel<AA>, dim3((unsigned)((batch + LOSS_TB - 1) / LOSS_TB)), dim3(LOSS_TB), 0, (hipStream_t)stream, mu_dev, logstd_dev, value_dev, actions_dev, old_logp_dev,  \
                      adv_dev, old_value_dev, returns_dev, old_mu_dev, old_sigma_dev, batch, e_clip, critic_coef, entropy_coef, bounds_coef,              \
-                     (int)(clip_value & 9), loss_scale_dev, grad_mu_dev, grad_value_dev, grad_logstd_dev, stats_dev)
+                     (int)(clip_value & 9), loss_scale_dev, grad_mu_dev, grad_value_dev, grad_logstd_dev, stats_dev, scratch_dev)
   switch (num_actions) {  // the action width is a compile-time constant of the kernel (register arrays, unrolled loops): bez has 18
     case 1: BEZ_PPO_LOSS(1); break;
     case 2: BEZ_PPO_LOSS(2); break;

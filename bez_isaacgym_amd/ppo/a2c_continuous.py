@@ -483,7 +483,8 @@ class A2CAgent:
             A, D, MB = self.act_dim, self.obs_dim, self.minibatch_size
             self._fx = dict(obs_n=torch.zeros(N, D, device=dev, dtype=hd), env_act=z(N, A), noise=z(H, N, A),
                             mb_obs_n=torch.zeros(MB, D, device=dev, dtype=hd), gmu=z(MB, A), gval=z(MB, 1), glog=z(A), stats=z(5),
-                            last_mu=z(N, A), last_v=z(N, 1), advs=z(H, N, 1), rets=z(H, N, 1), val_n=z(H * N, 1), ret_n=z(H * N, 1))
+                            last_mu=z(N, A), last_v=z(N, 1), advs=z(H, N, 1), rets=z(H, N, 1), val_n=z(H * N, 1), ret_n=z(H * N, 1),
+                            loss_scratch=self._F.loss_scratch(MB, A, dev))   # fixed-order sums in the loss kernel: bit-reproducible steps
 
     @torch.no_grad()
     def _rollout_steps_fused(self):
@@ -770,7 +771,7 @@ class A2CAgent:
         self._flat.zero_()
         F.loss(mu32.detach(), net.sigma.detach(), v32.detach(), mb, self.e_clip, self.critic_coef, self.entropy_coef, self.bounds_loss_coef,
                self.clip_value, scale, fx["gmu"], fx["gval"], net.sigma.grad, self._flat_stats, zero_glog=False, zero_stats=False,
-               update_mu_sigma=self.update_mu_sigma)
+               update_mu_sigma=self.update_mu_sigma, scratch=fx["loss_scratch"])
         if manual:
             self._manual_backward(tf, fx["gmu"], fx["gval"])
         else:

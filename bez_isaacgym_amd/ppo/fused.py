@@ -11,12 +11,12 @@ from ..sim import load_library
 
 _vp, _i32, _i64, _f = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 _SIGS = {
-    "bez_ppo_rms_moments": [_vp, _i64, _i32, _vp, _vp],
+    "bez_ppo_rms_moments": [_vp, _i64, _i32, _vp, _vp, _vp],
     "bez_ppo_rms_apply": [_vp, _i32, _vp, _vp, _vp, _vp],
     "bez_ppo_rms_normalize": [_vp, _i64, _i32, _vp, _vp, _f, _vp, _i32, _vp],
     "bez_ppo_sample": [_vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp],
     "bez_ppo_rollout_post": [_vp, _vp, _vp, _vp, _i64, _f, _f, _i32, _vp, _vp, _vp, _vp, _vp, _vp],
-    "bez_ppo_loss": [_vp] * 10 + [_i64, _i32, _f, _f, _f, _f, _i32] + [_vp] * 6,
+    "bez_ppo_loss": [_vp] * 10 + [_i64, _i32, _f, _f, _f, _f, _i32] + [_vp] * 7,
     "bez_ppo_rollout_pre": [_vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _f, _i64, _i32, _i32] + [_vp] * 9,
     "bez_ppo_policy_forward": [_vp, _i64, _i32, _vp, _vp, _f, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _vp],
     "bez_ppo_policy_rollout_step": [_vp, _i64, _i32, _vp, _vp, _f, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f] + [_vp] * 8 + [_i32, _vp],
@@ -70,6 +70,8 @@ class FusedRunningMeanStd:
         d = rms.running_mean.numel()
         self.d = d
         self.mom = torch.zeros(2 * d + 1, dtype=torch.float64, device=rms.running_mean.device)
+        # per-workgroup partials + ticket counter of the fixed-order (bit-reproducible) column sums: 1 + 1024 * 2 * d doubles, zeroed once
+        self.scratch = torch.zeros(1 + 1024 * 2 * d, dtype=torch.float64, device=rms.running_mean.device)
         self.reduce_fn = reduce_fn  # e.g. dist.all_reduce for data-parallel training
 
     def moments(self, x, out=None):
@@ -77,7 +79,7 @@ class FusedRunningMeanStd:
         rows = x.numel() // self.d
         out = self.mom if out is None else out
         assert out.numel() == 2 * self.d + 1 and out.is_contiguous()
-        _chk(lib().bez_ppo_rms_moments(_p(x), rows, self.d, _p(out, torch.float64), _stream(x)), "bez_ppo_rms_moments")
+        _chk(lib().bez_ppo_rms_moments(_p(x), rows, self.d, _p(out, torch.float64), _p(self.scratch, torch.float64), _stream(x)), "bez_ppo_rms_moments")
 
     def apply(self, mom=None):
         r = self.rms
@@ -113,15 +115,21 @@ def rollout_post(rew, dones, timeouts, values, reward_scale, gamma, bootstrap, s
 
 
 def loss(mu, logstd, value, mb, e_clip, critic_coef, entropy_coef, bounds_coef, clip_value, scale, gmu, gval, glog, stats, zero_glog=True,
-         zero_stats=True, update_mu_sigma=False):
+         zero_stats=True, update_mu_sigma=False, scratch=None):
     """stats[5] <- sums of a_loss, c_loss, b_loss, kl, entropy (zero_stats False: the caller cleared them); gmu / gval <- gradient of the
     mean loss (x loss scale); glog is ACCUMULATED into (zero_glog: cleared first); update_mu_sigma: mb["mu"] / mb["sigma"] are
-    overwritten with the current mu / exp(logstd) once the KL against the old ones is taken."""
+    overwritten with the current mu / exp(logstd) once the KL against the old ones is taken; scratch (loss_scratch(b, a), zeroed once):
+    the sums are added in a fixed order instead of with float atomics (bit-reproducible)."""
     b, a = mu.shape
     _chk(lib().bez_ppo_loss(_p(mu), _p(logstd), _p(value), _p(mb["actions"]), _p(mb["old_logp"]), _p(mb["advantages"]), _p(mb["old_values"]),
                             _p(mb["returns"]), _p(mb["mu"]), _p(mb["sigma"]), b, a, float(e_clip), float(critic_coef), float(entropy_coef),
                             float(bounds_coef), (1 if clip_value else 0) | (0 if zero_glog else 2) | (0 if zero_stats else 4) | (8 if update_mu_sigma else 0), None if scale is None else _p(scale), _p(gmu),
-                            _p(gval), _p(glog), _p(stats), _stream(mu)), "bez_ppo_loss")
+                            _p(gval), _p(glog), _p(stats), None if scratch is None else _p(scratch), _stream(mu)), "bez_ppo_loss")
+
+
+def loss_scratch(b, a, device):
+    """zeroed scratch for loss(..., scratch=): 2 + ceil(b / 64) * (a + 5) floats"""
+    return torch.zeros(2 + ((b + 63) // 64) * (a + 5), device=device, dtype=torch.float32)
 
 
 ADAM_WORK_FLOATS = 258   # BEZ_PPO_ADAM_WORK_FLOATS
@@ -268,7 +276,7 @@ class PolicyBackward:
         t_act = (C.c_void_p * self.nh)(*[a.data_ptr() for a in acts])
         t_gz = (C.c_void_p * self.nh)(*[z.data_ptr() for z in gz])
         t_b = (C.c_void_p * self.nh)(*[b.data_ptr() for b in bias_grads])
-        need = ((n + 63) // 64) * sum(self.widths)
+        need = ((n + 63) // 64) * (sum(self.widths) + 32)
         if getattr(self, "_partial", None) is None or self._partial.numel() < need:
             self._partial = torch.empty(need, device=gmu.device, dtype=torch.float32)
         _chk(lib().bez_ppo_policy_backward(_p(gmu), _p(gval), n, self.nh, C.cast(self.c_widths, C.c_void_p), self.A, C.cast(t_act, C.c_void_p),

@@ -269,8 +269,10 @@ int bez_sim_time_steps(BezSim* sim, const float* actions_dev, int32_t n_steps, v
  * elementwise / reduction launches per minibatch step around it.  All pointers are device memory, fp32 unless noted. */
 
 /* RunningMeanStd (normalize_input / normalize_value, bez_kickPPO.yaml:51-52): moments[0:D] = column sums, [D:2D] = sums of
- * squares, [2D] = rows, in fp64 (the caller may all-reduce them across ranks before applying). */
-int bez_ppo_rms_moments(const float* x_dev, int64_t rows, int32_t cols, double* moments_dev, void* stream);
+ * squares, [2D] = rows, in fp64 (the caller may all-reduce them across ranks before applying).  scratch_dev: NULL = fp64 atomics (the
+ * last bits vary from run to run); otherwise 1 + 1024 * 2 * cols doubles, ZERO on first use (the kernel leaves its ticket counter
+ * zero): per-workgroup partials added in workgroup order by the last workgroup to finish -- bit-reproducible. */
+int bez_ppo_rms_moments(const float* x_dev, int64_t rows, int32_t cols, double* moments_dev, double* scratch_dev, void* stream);
 int bez_ppo_rms_apply(const double* moments_dev, int32_t cols, double* mean_dev, double* var_dev, double* count_dev, void* stream);
 /* y = clamp((x - mean) / sqrt(var + eps), -5, 5); y_dev is fp32 or (out_f16 != 0) fp16 */
 int bez_ppo_rms_normalize(const float* x_dev, int64_t rows, int32_t cols, const double* mean_dev, const double* var_dev, float eps,
@@ -298,12 +300,14 @@ int bez_ppo_rollout_post(const float* rew_dev, const int64_t* dones_dev, const i
  * clip_value: bit 0 = clipped value loss; bit 1 = ACCUMULATE into grad_logstd_dev instead of clearing it first; bit 2 = stats_dev was
  * zeroed by the caller (e.g. as part of the flat gradient buffer's one clear per step); bit 3 = after the KL is taken, WRITE the
  * current mu and sigma = exp(logstd) over old_mu_dev / old_sigma_dev (rl_games' PPODataset.update_mu_sigma [ext]: from the second
- * mini-epoch on the KL is measured against the previous pass over the minibatch). */
+ * mini-epoch on the KL is measured against the previous pass over the minibatch).
+ * scratch_dev: NULL = the A + 5 sums are float atomics (last bits differ from run to run); otherwise 2 + ceil(batch / 64) * (A + 5)
+ * floats, ZERO on first use (the kernel leaves its ticket counter zero): the sums are formed in a fixed order, bit-reproducible. */
 int bez_ppo_loss(const float* mu_dev, const float* logstd_dev, const float* value_dev, const float* actions_dev, const float* old_logp_dev,
                  const float* adv_dev, const float* old_value_dev, const float* returns_dev, const float* old_mu_dev,
                  const float* old_sigma_dev, int64_t batch, int32_t num_actions, float e_clip, float critic_coef, float entropy_coef,
                  float bounds_coef, int32_t clip_value, const float* loss_scale_dev, float* grad_mu_dev, float* grad_value_dev,
-                 float* grad_logstd_dev, float* stats_dev, void* stream);
+                 float* grad_logstd_dev, float* stats_dev, float* scratch_dev, void* stream);
 
 /* The rollout's policy forward pass (rl_games get_action_values [ext] via train.py:89-113) in one launch: observation normaliser
  * (NULL mean = none), num_hidden Linear + ELU layers, the mu head (num_actions <= 31) and the value head, on fp16 weights /
@@ -360,7 +364,8 @@ int bez_ppo_elu_bwd_colsum_f16(const void* gy_f16_dev, const void* y_f16_dev, vo
  * the two loss gradients (operands of the head weight-gradient GEMMs); ADDED by atomics: the bias gradients of every hidden layer and of the
  * two heads.  Weight operands are transposed fp16 copies: wt[i] = W_i^T (hidden_width[i-1], hidden_width[i]) for i >= 1 (wt[0] unused) and
  * heads_t (hidden_width[last], 32) = [Wmu^T | Wvalue^T | 0]; bez_ppo_scatter_f16 refreshes them from a flat fp16 copy through an index map.
- * partial_dev: scratch of ceil(n / 64) * sum(hidden_width) floats (per-workgroup column sums, reduced by a second small launch).
+ * partial_dev: scratch of ceil(n / 64) * (sum(hidden_width) + 32) floats (per-workgroup column sums of the hidden layers and of the
+ * two heads, added in fixed order by a second small launch: every bias gradient is bit-reproducible).
  * Widths even, 32 <= width <= 416. */
 int bez_ppo_policy_backward(const float* grad_mu_dev, const float* grad_value_dev, int64_t n, int32_t num_hidden, const int32_t* hidden_width,
                             int32_t num_actions, const void* const* act_f16_dev, const void* const* wt_f16_dev, const void* heads_t_f16_dev,

@@ -206,6 +206,18 @@ def test_loss_kernel_value_and_gradient(clip_value, entropy_coef, b, a):
     np.testing.assert_allclose(gmu.cpu(), mu.grad.cpu(), atol=2e-5 * scale, rtol=1e-4)
     np.testing.assert_allclose(gval.cpu(), value.grad.cpu(), atol=2e-5 * float(value.grad.abs().max()), rtol=1e-4)
     np.testing.assert_allclose(glog.cpu(), logstd.grad.cpu(), rtol=2e-3, atol=2e-4 * float(logstd.grad.abs().max()))
+    # fixed-order sums (scratch): the same values, and bit-identical from call to call (the atomic path is not)
+    sc = F.loss_scratch(b, a, DEV)
+    outs = []
+    for _ in range(3):
+        gl, st2 = torch.zeros(a, device=DEV), torch.zeros(5, device=DEV)
+        F.loss(mu.detach(), logstd.detach(), value.detach(), mb, e, cc, entropy_coef, bc, clip_value, torch.tensor([S], device=DEV), torch.empty_like(gmu), gval,
+               gl, st2, zero_glog=False, zero_stats=False, scratch=sc)
+        outs.append((gl.clone(), st2.clone()))
+    assert float(sc[0].view(torch.int32)) == 0                      # the ticket counter is left zero
+    assert all(torch.equal(outs[0][0], o[0]) and torch.equal(outs[0][1], o[1]) for o in outs[1:])
+    np.testing.assert_allclose(outs[0][1].cpu(), stats.cpu(), rtol=1e-5, atol=1e-3)
+    np.testing.assert_allclose(outs[0][0].cpu(), glog.cpu(), rtol=1e-4, atol=2e-4 * float(logstd.grad.abs().max()))
     # rl_games' PPODataset.update_mu_sigma folded into the same launch: identical results, and afterwards the minibatch's old mu / sigma
     # hold the current policy's (a second pass measures its KL against this one: exactly 0 for unchanged weights up to the 1e-5 terms)
     keep_mu, keep_sigma = old_mu.clone(), old_sigma.clone()
@@ -538,6 +550,26 @@ print("DP_OK", st[-1]["kl"])
 ''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert "DP_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
+def test_training_is_bit_reproducible():
+    """Same seed, same build, same GPU -> the same weights: two agents trained independently for 2 eager + 1 capturing + 2 replayed
+    epochs end bit-identical (parameters, Adam moments, loss scale, normalisers).  What makes this hold: no float atomic on the path
+    from the rollout to the weights -- loss sums, bias gradients, weight gradients and the gradient norm are fixed-order reductions."""
+    from tests.test_gpu_round2 import _agent
+    snaps = []
+    for _ in range(2):
+        torch.manual_seed(123); torch.cuda.manual_seed_all(123)
+        a = _agent(512, 4096)
+        a.obs = a.env_reset()
+        for _e in range(5):
+            a.train_epoch()
+        torch.cuda.synchronize()
+        assert a._g_update is not None
+        snaps.append([p.detach().clone() for p in a.model.parameters()] + [a._mflat.clone(), a._vflat.clone(), a.scaler._scale.clone(),
+                                                                          a.running_mean_std.running_mean.clone(), a.value_mean_std.running_var.clone()])
+        del a
+    assert all(torch.equal(x, y) for x, y in zip(*snaps)), [i for i, (x, y) in enumerate(zip(*snaps)) if not torch.equal(x, y)]
 
 
 def test_two_ranks_on_the_gpu_stay_bit_identical(tmp_path):
