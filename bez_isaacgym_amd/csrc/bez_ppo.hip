@@ -54,23 +54,26 @@ __global__ __launch_bounds__(PPO_TB) void rms_moments_kernel(const float* __rest
     }
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) out[2 * D] = (double)B;
-  if (!scratch) return;
-  // bit-reproducible: per-workgroup partials, added in workgroup order by the LAST workgroup to arrive (ticket counter in the first
-  // word of scratch: zero on entry, zero again on exit); agent-scope release / atomic loads make the partials visible across XCDs
-  __shared__ int is_last;
-  __threadfence();
-  __syncthreads();
-  if (threadIdx.x == 0) is_last = (atomicAdd(reinterpret_cast<unsigned int*>(scratch), 1u) == gridDim.x - 1u) ? 1 : 0;
-  __syncthreads();
-  if (!is_last) return;
-  __threadfence();
-  if ((int)threadIdx.x < 2 * D) {
-    double acc = 0.0;
-    for (unsigned int b = 0; b < gridDim.x; ++b)
-      acc += __hip_atomic_load(&scratch[1 + (size_t)b * 2 * D + threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    out[threadIdx.x] = acc;
+}
+// second stage of the fixed-order column sums: a block per 64 of the 2D columns, 16 row lanes x 64 columns -- lane r adds workgroups
+// r, r + 16, ... (independent coalesced loads), the lanes meet in LDS in order
+__global__ __launch_bounds__(1024) void rms_reduce_kernel(const double* __restrict__ scratch, int D, unsigned int nblocks, double* __restrict__ out) {
+  __shared__ double lds[16][64];
+  const int W = 2 * D, l = threadIdx.x & 63, r = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + l;
+  double acc = 0.0;
+  if (c < W) {
+#pragma unroll 8
+    for (unsigned int b = r; b < nblocks; b += 16) acc += scratch[1 + (size_t)b * W + c];
   }
-  if (threadIdx.x == 0) __hip_atomic_store(reinterpret_cast<unsigned int*>(scratch), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  lds[r][l] = acc;
+  __syncthreads();
+  if (r == 0 && c < W) {
+    double t = 0.0;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) t += lds[q][l];
+    out[c] = t;
+  }
 }
 
 // parallel-variance update of (mean, var, count) from the (possibly all-reduced) moments: a2c_continuous.py RunningMeanStd.update
@@ -320,27 +323,22 @@ __global__ __launch_bounds__(LOSS_TB) void ppo_loss_kernel(const float* __restri
     if (tid < A + 5) atomicAdd(tid < A ? &grad_logstd[tid] : &stats[tid - A], mine);
     return;
   }
-  // bit-reproducible: every workgroup stores its A + 5 partials, the LAST one to arrive (a ticket counter in scratch[0], zero on entry,
-  // zero again on exit) adds all of them in a fixed order -- lane l takes workgroups l, l + 64, ..., then the butterfly -- and is the
-  // only writer of grad_logstd / stats.  Partials are published with an agent-scope release and read back with agent-scope atomic
-  // loads, so they are visible across the 8 XCDs' L2s.
-  constexpr int NV = A + 5;
-  __shared__ int is_last;
-  if (tid < NV) scratch[2 + (size_t)blockIdx.x * NV + tid] = mine;
-  __threadfence();
-  __syncthreads();
-  if (tid == 0) is_last = (atomicAdd(reinterpret_cast<unsigned int*>(scratch), 1u) == gridDim.x - 1u) ? 1 : 0;
-  __syncthreads();
-  if (!is_last) return;
-  __threadfence();
-  for (int c = 0; c < NV; ++c) {
-    float acc = 0.f;
-    for (unsigned int b = tid; b < gridDim.x; b += TB)
-      acc += __hip_atomic_load(&scratch[2 + (size_t)b * NV + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    acc = wave_sum(acc);
-    if (tid == 0) { if (c < A) grad_logstd[c] += acc; else stats[c - A] += acc; }
-  }
-  if (tid == 0) __hip_atomic_store(reinterpret_cast<unsigned int*>(scratch), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  // bit-reproducible: every workgroup stores its A + 5 partials (column-major: a column's partials are contiguous); a second, one-wave
+  // launch adds them in a fixed order and is the only writer of grad_logstd / stats.  (A last-workgroup-reduces scheme inside this kernel
+  // was measured first: its agent-scope fences -- an L2 write-back + invalidate per workgroup on the 8-XCD part -- cost 65 us per call.)
+  if (tid < A + 5) scratch[2 + (size_t)tid * gridDim.x + blockIdx.x] = mine;
+}
+// second stage of the fixed-order sums: one wave per column (blockIdx.x = column); lane l adds workgroups l, l + 64, ... (independent,
+// coalesced loads), then the butterfly
+__global__ __launch_bounds__(64) void ppo_loss_reduce_kernel(const float* __restrict__ scratch, int A, unsigned int nblocks,
+                                                             float* __restrict__ grad_logstd, float* __restrict__ stats) {
+  const int tid = threadIdx.x, c = blockIdx.x;
+  const float* col = scratch + 2 + (size_t)c * nblocks;
+  float acc = 0.f;
+#pragma unroll 8
+  for (unsigned int b = tid; b < nblocks; b += 64) acc += col[b];
+  acc = wave_sum(acc);
+  if (tid == 0) { if (c < A) grad_logstd[c] += acc; else stats[c - A] += acc; }
 }
 
 // ---- gradient reductions of the explicit-fp16 linear layers (a2c_continuous.py _HalfLinearFn), written straight into the fp32
@@ -620,6 +618,7 @@ int bez_ppo_rms_moments(const float* x_dev, int64_t rows, int32_t cols, double* 
   unsigned g = (unsigned)((rows + 127) / 128);
   if (g > 1024) g = 1024;
   hipLaunchKernelGGL(rms_moments_kernel, dim3(g), dim3(PPO_TB), 0, (hipStream_t)stream, x_dev, rows, (int)cols, moments_dev, scratch_dev);
+  if (scratch_dev) hipLaunchKernelGGL(rms_reduce_kernel, dim3((unsigned)((2 * cols + 63) / 64)), dim3(1024), 0, (hipStream_t)stream, (const double*)scratch_dev, (int)cols, g, moments_dev);
   return launch_ok();
 }
 int bez_ppo_rms_apply(const double* moments_dev, int32_t cols, double* mean_dev, double* var_dev, double* count_dev, void* stream) {
@@ -719,6 +718,9 @@ int bez_ppo_loss(const float* mu_dev, const float* logstd_dev, const float* valu
     default: return -1;
   }
 #undef BEZ_PPO_LOSS
+  if (scratch_dev)
+    hipLaunchKernelGGL(ppo_loss_reduce_kernel, dim3((unsigned)num_actions + 5), dim3(64), 0, (hipStream_t)stream, (const float*)scratch_dev, (int)num_actions,
+                       (unsigned int)((batch + LOSS_TB - 1) / LOSS_TB), grad_logstd_dev, stats_dev);
   return launch_ok();
 }
 

@@ -270,8 +270,8 @@ int bez_sim_time_steps(BezSim* sim, const float* actions_dev, int32_t n_steps, v
 
 /* RunningMeanStd (normalize_input / normalize_value, bez_kickPPO.yaml:51-52): moments[0:D] = column sums, [D:2D] = sums of
  * squares, [2D] = rows, in fp64 (the caller may all-reduce them across ranks before applying).  scratch_dev: NULL = fp64 atomics (the
- * last bits vary from run to run); otherwise 1 + 1024 * 2 * cols doubles, ZERO on first use (the kernel leaves its ticket counter
- * zero): per-workgroup partials added in workgroup order by the last workgroup to finish -- bit-reproducible. */
+ * last bits vary from run to run); otherwise 1 + 1024 * 2 * cols doubles: per-workgroup partials, added in workgroup order by a second
+ * small launch -- bit-reproducible. */
 int bez_ppo_rms_moments(const float* x_dev, int64_t rows, int32_t cols, double* moments_dev, double* scratch_dev, void* stream);
 int bez_ppo_rms_apply(const double* moments_dev, int32_t cols, double* mean_dev, double* var_dev, double* count_dev, void* stream);
 /* y = clamp((x - mean) / sqrt(var + eps), -5, 5); y_dev is fp32 or (out_f16 != 0) fp16 */
@@ -302,7 +302,7 @@ int bez_ppo_rollout_post(const float* rew_dev, const int64_t* dones_dev, const i
  * current mu and sigma = exp(logstd) over old_mu_dev / old_sigma_dev (rl_games' PPODataset.update_mu_sigma [ext]: from the second
  * mini-epoch on the KL is measured against the previous pass over the minibatch).
  * scratch_dev: NULL = the A + 5 sums are float atomics (last bits differ from run to run); otherwise 2 + ceil(batch / 64) * (A + 5)
- * floats, ZERO on first use (the kernel leaves its ticket counter zero): the sums are formed in a fixed order, bit-reproducible. */
+ * floats: every workgroup stores its partials there and a second one-wave launch adds them in a fixed order -- bit-reproducible. */
 int bez_ppo_loss(const float* mu_dev, const float* logstd_dev, const float* value_dev, const float* actions_dev, const float* old_logp_dev,
                  const float* adv_dev, const float* old_value_dev, const float* returns_dev, const float* old_mu_dev,
                  const float* old_sigma_dev, int64_t batch, int32_t num_actions, float e_clip, float critic_coef, float entropy_coef,

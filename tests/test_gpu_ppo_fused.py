@@ -214,7 +214,6 @@ def test_loss_kernel_value_and_gradient(clip_value, entropy_coef, b, a):
         F.loss(mu.detach(), logstd.detach(), value.detach(), mb, e, cc, entropy_coef, bc, clip_value, torch.tensor([S], device=DEV), torch.empty_like(gmu), gval,
                gl, st2, zero_glog=False, zero_stats=False, scratch=sc)
         outs.append((gl.clone(), st2.clone()))
-    assert float(sc[0].view(torch.int32)) == 0                      # the ticket counter is left zero
     assert all(torch.equal(outs[0][0], o[0]) and torch.equal(outs[0][1], o[1]) for o in outs[1:])
     np.testing.assert_allclose(outs[0][1].cpu(), stats.cpu(), rtol=1e-5, atol=1e-3)
     np.testing.assert_allclose(outs[0][0].cpu(), glog.cpu(), rtol=1e-4, atol=2e-4 * float(logstd.grad.abs().max()))
