@@ -612,6 +612,8 @@ unsigned nblk(int64_t n) { return (unsigned)((n + PPO_TB - 1) / PPO_TB); }
 
 extern "C" {
 
+int32_t bez_ppo_abi_version(void) { return BEZ_PPO_ABI_VERSION; }
+
 int bez_ppo_rms_moments(const float* x_dev, int64_t rows, int32_t cols, double* moments_dev, double* scratch_dev, void* stream) {
   if (!x_dev || !moments_dev || rows <= 0 || cols <= 0 || cols > 64) return -1;
   if (!scratch_dev) (void)hipMemsetAsync(moments_dev, 0, (size_t)(2 * cols + 1) * sizeof(double), (hipStream_t)stream);  // (the fixed-order path overwrites)

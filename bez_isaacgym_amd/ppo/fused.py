@@ -35,12 +35,17 @@ _SIGS = {
     "bez_ppo_adam_step": [_vp, _vp, _vp, _vp, _i64, _vp, _i32, _vp, _f, _f, _f, _f, _f, _vp, _vp, _f, _f, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _f, _f, _f, _vp],
 }
 _lib = None
+PPO_ABI_VERSION = 3   # BEZ_PPO_ABI_VERSION (include/bez_sim.h)
 
 
 def lib():
     global _lib
     if _lib is None:
         l = load_library()
+        l.bez_ppo_abi_version.restype, l.bez_ppo_abi_version.argtypes = C.c_int32, []
+        got = int(l.bez_ppo_abi_version())
+        if got != PPO_ABI_VERSION:
+            raise RuntimeError("libbez_sim.so speaks PPO ABI %d, this binding %d: rebuild (python -m bez_isaacgym_amd.build)" % (got, PPO_ABI_VERSION))
         for name, args in _SIGS.items():
             fn = getattr(l, name)
             fn.restype, fn.argtypes = C.c_int, args

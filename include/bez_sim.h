@@ -268,6 +268,11 @@ int bez_sim_time_steps(BezSim* sim, const float* actions_dev, int32_t n_steps, v
  * hyper-parameters cfg/train/bez_kickPPO.yaml); its MLP stays in PyTorch-ROCm, these entry points replace the ~250 tiny
  * elementwise / reduction launches per minibatch step around it.  All pointers are device memory, fp32 unless noted. */
 
+/* The signatures below change between rounds (round 3: scratch buffers of the fixed-order reductions, plan / run split of the weight
+ * gradients, the optimiser tail's bookkeeping): a binding checks this number once after dlopen. */
+#define BEZ_PPO_ABI_VERSION 3
+int32_t bez_ppo_abi_version(void);
+
 /* RunningMeanStd (normalize_input / normalize_value, bez_kickPPO.yaml:51-52): moments[0:D] = column sums, [D:2D] = sums of
  * squares, [2D] = rows, in fp64 (the caller may all-reduce them across ranks before applying).  scratch_dev: NULL = fp64 atomics (the
  * last bits vary from run to run); otherwise 1 + 1024 * 2 * cols doubles: per-workgroup partials, added in workgroup order by a second

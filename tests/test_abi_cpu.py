@@ -32,9 +32,12 @@ def test_exports_match_header(lib):
     ppo = set(re.findall(r"\b(bez_ppo_[a-z_0-9]+)\s*\(", hdr))
     assert len(ppo) >= 20
     from bez_isaacgym_amd.ppo.fused import _SIGS
-    assert ppo == set(_SIGS), ppo ^ set(_SIGS)
+    assert ppo == set(_SIGS) | {"bez_ppo_abi_version"}, ppo ^ set(_SIGS)
     for name in ppo:
         assert hasattr(lib, name), name
+    from bez_isaacgym_amd.ppo.fused import PPO_ABI_VERSION
+    lib.bez_ppo_abi_version.restype = C.c_int32
+    assert lib.bez_ppo_abi_version() == PPO_ABI_VERSION == int(re.search(r"#define BEZ_PPO_ABI_VERSION (\d+)", hdr).group(1))
 
 
 def test_default_config_matches_python(lib):
