@@ -184,13 +184,14 @@ __global__ __launch_bounds__(PPO_TB) void ppo_rollout_post_kernel(const float* _
 
 // ---- the PPO loss of one minibatch and its gradient with respect to the network outputs, in one pass.
 //   loss = mean(a_loss) + 0.5 * critic_coef * mean(c_loss) - entropy_coef * mean(entropy) + bounds_coef * mean(b_loss)
-// stats (atomically accumulated, caller zeroes): [sum a_loss, sum c_loss, sum b_loss, sum kl, sum entropy]
+// stats (accumulated into, caller zeroes): [sum a_loss, sum c_loss, sum b_loss, sum kl, sum entropy]
 // grad_mu / grad_value are d(loss)/d(mu), d(loss)/d(value) times *scale (GradScaler's loss scale, a device scalar; null = 1);
-// grad_logstd (A) is accumulated atomically (caller zeroes).
+// grad_logstd (A) is accumulated into (caller zeroes).  With `scratch` both are fixed-order two-stage sums (per-workgroup partials +
+// ppo_loss_reduce_kernel), without it float atomics.
 // Layout: one sample per thread; the (B,A) row-major operands of a workgroup's 64 consecutive rows are one contiguous block,
 // moved with coalesced accesses and transposed through LDS ([row][A+1]: conflict-free for the per-thread row walk).  A is a
 // template parameter (register arrays, unrolled loops); the per-column / per-term sums are reduced in the workgroup first, so a
-// launch issues A + 5 atomics per 64 samples.
+// launch produces A + 5 partial sums per 64 samples.
 constexpr int LOSS_TB = 64;   // one wave per 64 samples: 512 workgroups for config 3's minibatch (256-thread blocks filled half the CUs)
 template <int A>
 __global__ __launch_bounds__(LOSS_TB) void ppo_loss_kernel(const float* __restrict__ mu, const float* __restrict__ logstd, const float* __restrict__ value,
@@ -309,7 +310,7 @@ __global__ __launch_bounds__(LOSS_TB) void ppo_loss_kernel(const float* __restri
 #pragma unroll
     for (int j = 0; j < A; ++j) { const int k = tid + j * TB; if (k < nrow * A) blk[k] = tile[(k / A) * LD + (k % A)]; }
   }
-  // wave reduction of the A log-std gradient columns and the five statistics, then one atomic each (A + 5 per 64 samples)
+  // wave reduction of the A log-std gradient columns and the five statistics: A + 5 values per 64 samples
   float mine = 0.f;
 #pragma unroll
   for (int j = 0; j < A; ++j) { const float g = wave_sum(gls[j]); if (tid == j) mine = g; }
