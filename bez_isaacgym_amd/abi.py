@@ -23,6 +23,7 @@ FLAG_CLEATS = 16
 FLAG_BOX_ASSET = 32
 FLAG_HARD_CONTACT = 64
 FLAG_LEAN_STEP = 128
+FLAG_OBS_NOISE_IN_STEP = 256
 TASK_KICK, TASK_WALK, TASK_ORIENT = 0, 1, 2
 TASK_IDS = {"bez_kick": TASK_KICK, "bez_walk": TASK_WALK, "bez_orient": TASK_ORIENT}
 

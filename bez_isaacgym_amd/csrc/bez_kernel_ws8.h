@@ -793,8 +793,25 @@ __global__ __launch_bounds__(WS_BLOCK) void step_kernel_ws8(Params P) {
       const float4* rows = reinterpret_cast<const float4*>(lds + X_STAGE * WS_ENVS);
       float4* dst = reinterpret_cast<float4*>(P.obs + (size_t)env0 * P.nobs);  // 64 * nobs * 4 B per workgroup: 16-B aligned for 54 and 52
       const int nvec = (nloc * P.nobs) >> 2;
-      for (int i = ctid; i < nvec; i += NT) dst[i] = rows[i];
-      for (int i = (nvec << 2) + ctid; i < nloc * P.nobs; i += NT) P.obs[(size_t)env0 * P.nobs + i] = lds[X_STAGE * WS_ENVS + i];
+      if (DR && P.obs_noise) {
+        // the observation noise of the domain randomisation rides on the copy-out (one Philox block per 16-byte vector, spread over
+        // the seven copying waves) instead of a launch of its own behind the step: the same bits as bez_sim_add_dr_noise would add
+        const long long q0 = ((long long)env0 * P.nobs) >> 2;   // env0 is a multiple of 64: the workgroup's block starts on a vector
+        const float mean = P.dr_state->noise[0], sd = P.dr_state->noise[1];
+        const unsigned long long frame = P.dr_state->frame;
+        for (int i = ctid; i < nvec; i += NT) {
+          float z[4];
+          dr_noise_quad(P.seed, P.env_off, frame, 0, q0 + i, z);
+          float4 v = rows[i];
+          v.x += fmaf(z[0], sd, mean); v.y += fmaf(z[1], sd, mean); v.z += fmaf(z[2], sd, mean); v.w += fmaf(z[3], sd, mean);
+          dst[i] = v;
+        }
+        for (int i = (nvec << 2) + ctid; i < nloc * P.nobs; i += NT)
+          P.obs[(size_t)env0 * P.nobs + i] = obs_with_noise(P, (long long)env0 * P.nobs + i, lds[X_STAGE * WS_ENVS + i]);
+      } else {
+        for (int i = ctid; i < nvec; i += NT) dst[i] = rows[i];
+        for (int i = (nvec << 2) + ctid; i < nloc * P.nobs; i += NT) P.obs[(size_t)env0 * P.nobs + i] = lds[X_STAGE * WS_ENVS + i];
+      }
     }
   }
   WS_STAMP(role, 23);

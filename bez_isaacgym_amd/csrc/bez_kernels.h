@@ -39,6 +39,10 @@ constexpr int LDS_HIT = LDS_P3 + BEZ_ND * P3_STRIDE;  // ground-point records, 8
 constexpr int HIT_STRIDE = 8;                       // x(3) fn0 kn ct ftx0 fty0
 constexpr int LDS_SLOTS = LDS_HIT + BEZ_NPT * HIT_STRIDE;
 
+// device-resident state of the domain randomisation (bez_sim.hip dr_kernel): frame counter, frame of the last non-env randomisation,
+// noise parameters [obs mean, obs std, action mean, action std]
+struct DrState { unsigned long long frame, last_rand; float noise[4]; };
+
 struct Params {
   int n, substeps, max_len, use_prev, obs_only;
   float dt, h;
@@ -68,6 +72,8 @@ struct Params {
   int64_t* timeout;
   uint32_t* episode;
   const float* actions;
+  const DrState* dr_state;   // != null with obs_noise: frame counter + noise parameters of the device-side domain randomisation
+  int obs_noise;             // the POST part adds the observation noise itself (BEZ_FLAG_OBS_NOISE_IN_STEP)
   const float* dr_friction;  // (N)      or null
   const float* dr_kp;        // (N,18)   or null
   const float* dr_kd;        // (N,18)   or null
@@ -79,6 +85,7 @@ struct Params {
 };
 // the goal an env reset by this launch receives (bez_walk / bez_orient)
 BEZ_DEV float reset_goal(const Params& P, int k) { return P.goal_dev ? P.goal_dev[k] : P.goal_draw[k]; }
+
 
 
 // ---- model variant: CL = the cleats asset (BEZ_FLAG_CLEATS): same tree, heavier feet, 8 cleat bodies, per-cleat ground points
@@ -129,6 +136,25 @@ BEZ_DEV void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
     c[0] = n0; c[1] = lo1; c[2] = n2; c[3] = lo0;
     k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
   }
+}
+
+// vec_task.py:544-618 noise lambdas (gaussian, additive): element i of a flat tensor gets mean + std * z, z = word (i & 3) of the Box-Muller
+// pairs of ONE Philox block keyed by (seed, shard offset * 64 + (i >> 2), frame, which: 0 observations / 1 actions).  Shared by
+// dr_noise_kernel (bez_sim.hip) and by the step kernels' observation copy-out (BEZ_FLAG_OBS_NOISE_IN_STEP): the same bits either way.
+BEZ_DEV void dr_noise_quad(uint64_t seed, int64_t env_off, unsigned long long frame, int which, long long i4, float z[4]) {
+  const unsigned long long key = (unsigned long long)(env_off * 64 + i4);   // distinct per shard: 54 / 18 floats per env < 64 * 4
+  uint32_t c[4] = {(uint32_t)key, (uint32_t)(key >> 32), (uint32_t)frame, 0x4e4f4953u + (uint32_t)which + ((uint32_t)(frame >> 32) << 8)};
+  philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+  float u[4];
+  for (int k = 0; k < 4; ++k) u[k] = (float)(c[k] >> 8) * (1.0f / 16777216.0f);
+  const float r0 = sqrtf(-2.0f * logf(1.0f - u[0])), r1 = sqrtf(-2.0f * logf(1.0f - u[2]));
+  z[0] = r0 * cosf(6.2831853f * u[1]); z[1] = r0 * sinf(6.2831853f * u[1]); z[2] = r1 * cosf(6.2831853f * u[3]); z[3] = r1 * sinf(6.2831853f * u[3]);
+}
+// observation element i (flat index into this shard's obs_buf) with the domain-randomisation noise of this frame
+BEZ_DEV float obs_with_noise(const Params& P, long long i, float v) {
+  float z[4];
+  dr_noise_quad(P.seed, P.env_off, P.dr_state->frame, 0, i >> 2, z);
+  return v + fmaf(z[i & 3], P.dr_state->noise[1], P.dr_state->noise[0]);
 }
 
 // Per-lane working copy of the generalized state
@@ -1062,7 +1088,8 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(Params P) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) st[(size_t)(F_FEET + i) * n + e] = feet[i];
 #pragma unroll
-    for (int i = 0; i < BEZ_NUM_OBS; ++i) if (i < P.nobs) P.obs[(size_t)e * P.nobs + i] = obs[i];
+    for (int i = 0; i < BEZ_NUM_OBS; ++i)
+      if (i < P.nobs) P.obs[(size_t)e * P.nobs + i] = P.obs_noise ? obs_with_noise(P, (long long)e * P.nobs + i, obs[i]) : obs[i];
     P.rew[e] = rew; P.reset[e] = reset; P.progress[e] = progress;
   }
   if (SIM || POST) {

@@ -26,7 +26,7 @@ struct DevBuf {
 
 }  // namespace
 
-struct DrState { unsigned long long frame, last_rand; float noise[4]; };
+// (DrState: bez_kernels.h -- the step kernels read the frame counter and the observation-noise parameters)
 
 struct BezSim {
   BezSimConfig cfg;
@@ -58,9 +58,10 @@ struct BezSim {
   float* dr[BEZ_PARAM_COUNT] = {};
   // device-side domain randomisation (bez_sim_set_randomization)
   bool dr_on = false;
+  bool obs_noise_applied = false;  // the last post-physics launch added the observation noise itself (BEZ_FLAG_OBS_NOISE_IN_STEP)
   BezDrConfig drc = {};
   int64_t* randomize = nullptr;   // (N) randomize_buf, vec_task.py:247
-  struct DrState* dr_state = nullptr;  // device: frame counter, frame of the last non-env randomisation, noise parameters
+  DrState* dr_state = nullptr;  // device: frame counter, frame of the last non-env randomisation, noise parameters
   float* goal_draw_dev = nullptr;            // [2] the goal of the current post-physics reset (bez_walk / bez_orient)
   unsigned long long* post_calls_dev = nullptr;  // device-resident call counter keying that draw (HIP-graph replay safe)
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -205,13 +206,8 @@ __global__ void dr_noise_kernel(const float* x, float* y, long long n, const DrS
   if (i4 * 4 >= n) return;
   const float mean = st->noise[2 * which], sd = st->noise[2 * which + 1];
   const unsigned long long frame = st->frame;
-  const unsigned long long key = (unsigned long long)(env_off * 64 + i4);   // distinct per shard: 54 / 18 floats per env < 64 * 4
-  uint32_t c[4] = {(uint32_t)key, (uint32_t)(key >> 32), (uint32_t)frame, 0x4e4f4953u + (uint32_t)which + ((uint32_t)(frame >> 32) << 8)};
-  bez::philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
-  float u[4];
-  for (int k = 0; k < 4; ++k) u[k] = (float)(c[k] >> 8) * (1.0f / 16777216.0f);
-  float r0 = sqrtf(-2.0f * logf(1.0f - u[0])), r1 = sqrtf(-2.0f * logf(1.0f - u[2]));
-  float z[4] = {r0 * cosf(6.2831853f * u[1]), r0 * sinf(6.2831853f * u[1]), r1 * cosf(6.2831853f * u[3]), r1 * sinf(6.2831853f * u[3])};
+  float z[4];
+  bez::dr_noise_quad(seed, env_off, frame, which, i4, z);   // (shared with the step kernels' observation copy-out: same bits)
   for (int k = 0; k < 4; ++k) if (i4 * 4 + k < n) y[i4 * 4 + k] = x[i4 * 4 + k] + fmaf(z[k], sd, mean);
 }
 
@@ -441,6 +437,12 @@ int launch_step(BezSim* s, const float* actions, hipStream_t stream, bool obs_on
   P.obs_only = obs_only ? 1 : 0;
   P.lean = (PRE && SIM && POST && !obs_only && (s->cfg.flags & BEZ_FLAG_LEAN_STEP) && (s->cfg.flags & BEZ_FLAG_IMU_PREV_ALIAS) && s->obs_calls > 0) ? 1 : 0;
   if (POST && !obs_only && s->dr_on) launch_dr(s, false, stream);  // reset_idx's apply_randomizations (kick_env.py:781-782), on the device
+  // the observation noise of the randomisation inside this launch's copy-out (DR kernel variants only: has_dr is true once a
+  // randomisation is set) -- bez_sim_add_dr_noise on the observation tensor is then a no-op
+  const bool obs_noise = POST && !obs_only && s->dr_on && (s->cfg.flags & BEZ_FLAG_OBS_NOISE_IN_STEP) && s->drc.observations.enabled &&
+                         (has_dr(s) || s->cleats);   // (the kernel variants with per-env parameters carry the noise code)
+  P.dr_state = s->dr_state; P.obs_noise = obs_noise ? 1 : 0;
+  s->obs_noise_applied = obs_noise;
   if (POST && !obs_only && s->cfg.task != BEZ_TASK_KICK) {  // the reset inside this post_physics_step draws its goal on the device
     goal_draw_kernel<<<1, 1, 0, stream>>>(s->cfg.seed, s->post_calls_dev, s->goal_draw_dev);
     P.goal_dev = s->goal_draw_dev;
@@ -765,6 +767,7 @@ int bez_sim_get_env_params(BezSim* s, int param, float* out_dev, void* stream_) 
 int bez_sim_add_dr_noise(BezSim* s, const float* x_dev, float* y_dev, int64_t n, int32_t which, void* stream_) {
   if (!s || !x_dev || !y_dev || n < 0 || which < 0 || which > 1) return fail(s, -1, "bez_sim_add_dr_noise: bad argument");
   if (n == 0) return 0;
+  if (which == 0 && x_dev == s->obs && y_dev == s->obs && s->obs_noise_applied) return 0;   // the step kernel already added it (BEZ_FLAG_OBS_NOISE_IN_STEP)
   const long long quads = (n + 3) / 4;
   hipLaunchKernelGGL(dr_noise_kernel, dim3((unsigned)((quads + TB - 1) / TB)), dim3(TB), 0, (hipStream_t)stream_, x_dev, y_dev, (long long)n, s->dr_state, (int)which,
                      s->cfg.seed, s->cfg.env_id_offset);

@@ -210,6 +210,10 @@ class VecTask(Env):
         # std (BEZ_TENSOR_DR_NOISE, moved by the schedule) are read on the device.  The caller's action tensor is not modified.
         sim = self.sim
         if "observations" in dr_params:
+            # BEZ_FLAG_OBS_NOISE_IN_STEP: the step kernel adds this noise on its way out (one launch less per step); on the simulator's
+            # own observation buffer the call below is then a no-op inside the library, any other tensor still gets a launch
+            sim.set_flags(int(sim.cfg.flags) | abi.FLAG_OBS_NOISE_IN_STEP)
+            sim.cfg.flags = int(sim.cfg.flags) | abi.FLAG_OBS_NOISE_IN_STEP
             self.dr_randomizations["observations"] = {"noise_lambda": lambda t: sim.add_dr_noise(t if t.is_contiguous() else t.contiguous(), 0)}
         if "actions" in dr_params:
             self._noisy_actions = torch.empty(self.num_envs, self.num_actions, device=self.device, dtype=torch.float32)  # persistent: graph-safe

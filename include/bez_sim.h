@@ -68,6 +68,11 @@ extern "C" {
                                    without the flag.  The feet flags inside the observation are unaffected (computed from the in-kernel \
                                    forces).  Needs BEZ_FLAG_IMU_PREV_ALIAS (prev_lin_vel is then never read back). */
 
+#define BEZ_FLAG_OBS_NOISE_IN_STEP 256u /* with a randomisation that has observation noise (bez_sim_set_randomization): the post-physics \
+                                          part of bez_sim_step / bez_sim_post_physics writes the NOISY observations itself (the noise \
+                                          rides on the kernel's copy-out, bit-identical to what bez_sim_add_dr_noise(OBS, OBS, 0) adds), \
+                                          and that call on the observation tensor becomes a no-op: one launch less per control step */
+
 /* Tasks sharing the robot, the physics and the tensor API; they differ in the post-physics logic (observation tail,
  * reward, reset conditions, goal sampling) and in the ball actor (bez_kick only). */
 #define BEZ_TASK_KICK 0   /* tasks/kick_env.py    54 obs, ball + goal point                              */

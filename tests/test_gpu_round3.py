@@ -155,6 +155,42 @@ def test_dr_noise_kernel_statistics_and_schedule():
     assert not torch.equal(a, c) and abs(float((a * c).mean())) < 2e-5
 
 
+@pytest.mark.parametrize("kernel,n", [("ws8", 4096), ("ws8", 200), ("lane", 256)])
+def test_observation_noise_inside_the_step_equals_the_separate_launch(kernel, n, monkeypatch):
+    """BEZ_FLAG_OBS_NOISE_IN_STEP: the post-physics part writes the noisy observations itself (the noise rides on the kernel's
+    copy-out).  Two simulators with the same seed and randomisation, one with the flag, one adding the noise with
+    bez_sim_add_dr_noise after every step: bit-identical observations over 40 steps (resets, a partial last workgroup at n = 200),
+    everything else identical too; the call on the observation tensor is a no-op with the flag, a real launch on any other tensor."""
+    import torch
+    from bez_isaacgym_amd import abi
+    from tests.sim_adapter import SimAdapter
+    monkeypatch.setenv("BEZ_SIM_KERNEL", kernel)
+    cfg_a, cfg_b = abi.default_config(n, seed=9), abi.default_config(n, seed=9)
+    cfg_a.flags |= abi.FLAG_OBS_NOISE_IN_STEP
+    a, b = SimAdapter(cfg_a), SimAdapter(cfg_b)
+    for g in (a, b):
+        g.set_randomization(_dr_cfg(freq=5, sched=0))
+    obs_a, obs_b = a.sim.tensor(abi.TENSOR_OBS), b.sim.tensor(abi.TENSOR_OBS)
+    rng = np.random.default_rng(2)
+    clean_differs = False
+    for t in range(40):
+        act = rng.uniform(-1, 1, (n, 18)).astype(np.float32)
+        a.step(act); b.step(act)
+        clean = obs_b.clone()
+        a.sim.add_dr_noise(obs_a, 0)          # no-op: the kernel has added it
+        b.sim.add_dr_noise(obs_b, 0)          # the separate launch
+        assert torch.equal(obs_a, obs_b), (t, float((obs_a - obs_b).abs().max()))
+        clean_differs |= not torch.equal(clean, obs_b)
+        d = (obs_b - clean).flatten()
+        assert abs(float(d.std()) - 0.002) < 2e-4 and abs(float(d.mean())) < 2e-4
+    assert clean_differs
+    np.testing.assert_array_equal(a.root_states, b.root_states)
+    np.testing.assert_array_equal(a.rew, b.rew); np.testing.assert_array_equal(a.reset_buf, b.reset_buf)
+    x = torch.zeros(n * 54, device=a.dev)
+    a.sim.add_dr_noise(x, 0)
+    assert float(x.std()) > 1e-3              # any other tensor still gets its noise
+
+
 def test_lean_step_changes_nothing_the_rollout_reads():
     """BEZ_FLAG_LEAN_STEP: the fused step skips the stores of the contact-force rows, FEET and PREV_LIN_VEL (308 B / env-step).
     State, observations (incl. the feet flags, computed from the in-kernel forces), reward and bookkeeping stay bit-identical;
