@@ -183,6 +183,9 @@ def config_from_task_cfg(cfg, seed=42, env_id_offset=0, strict_reference_quirks=
     for k in CONTACT_DEFAULTS:
         if k in sim.get("bez", {}):
             setattr(c, k, float(sim["bez"][k]))
+    for k in ("effort", "vel_limit", "joint_friction"):   # kick_env.py:322-329 hard-codes these; sim.bez.<k> overrides them for experiments
+        if k in sim.get("bez", {}):
+            setattr(c, k, float(sim["bez"][k]))
     c.flags = FLAG_IMU_PREV_ALIAS if strict_reference_quirks else 0
     if env.get("asset", {}).get("cleats", False):
         c.flags |= FLAG_CLEATS
