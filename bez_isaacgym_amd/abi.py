@@ -7,7 +7,7 @@ reference).  Loading / calling the library is in `bez_isaacgym_amd.sim`.
 import ctypes as C
 import math
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 NUM_OBS = 54
 NUM_ACTIONS = 18
 NUM_DOFS = 18
@@ -24,6 +24,7 @@ FLAG_BOX_ASSET = 32
 FLAG_HARD_CONTACT = 64
 FLAG_LEAN_STEP = 128
 FLAG_OBS_NOISE_IN_STEP = 256
+FLAG_TGS_SOLVER = 512
 TASK_KICK, TASK_WALK, TASK_ORIENT = 0, 1, 2
 TASK_IDS = {"bez_kick": TASK_KICK, "bez_walk": TASK_WALK, "bez_orient": TASK_ORIENT}
 
@@ -68,7 +69,7 @@ class BezSimConfig(C.Structure):
         ("self_cn", C.c_float),
         ("ball_kn", C.c_float),
         ("ball_cn", C.c_float),
-        ("tune", C.c_float * 8),
+        ("tune", C.c_float * 24),
         ("task", C.c_int32),
         ("goal_angle", C.c_float),
         ("flags", C.c_uint32),

@@ -497,6 +497,16 @@ int bez_sim_default_config(BezSimConfig* c, int32_t num_envs) {
 
 const char* bez_sim_last_error(const BezSim* sim) { return sim ? sim->err.c_str() : g_create_error.c_str(); }
 
+/* Model variants that exist only in the CPU oracle (experiments that did not earn a kernel: DESIGN 3.1 / 6.1).  This library
+ * has no kernel for them and says so instead of silently stepping the compliant model (include/bez_sim.h: BEZ_FLAG_HARD_CONTACT,
+ * BEZ_FLAG_TGS_SOLVER, BezSimConfig.tune). */
+static const char* oracle_only(uint32_t flags, const float* tune) {
+  if (flags & BEZ_FLAG_HARD_CONTACT) return "BEZ_FLAG_HARD_CONTACT: rigid contact exists only in the CPU oracle; libbez_sim.so has no kernel for it";
+  if (flags & BEZ_FLAG_TGS_SOLVER) return "BEZ_FLAG_TGS_SOLVER: the TGS-shaped solver exists only in the CPU oracle; libbez_sim.so has no kernel for it";
+  if (tune) for (int i = 0; i < 24; ++i) if (tune[i] != 0.f) return "BezSimConfig.tune[]: knobs of the oracle-only solver variants; must be 0 for libbez_sim.so";
+  return nullptr;
+}
+
 int bez_sim_destroy(BezSim* s) {
   if (!s) return 0;
   (void)hipSetDevice(s->device);
@@ -516,6 +526,7 @@ int bez_sim_create(const BezSimConfig* cfg, int device_id, BezSim** out) {
   if (cfg->abi_version != BEZ_SIM_ABI_VERSION) return fail(nullptr, -1, "bez_sim_create: BezSimConfig.abi_version mismatch");
   if (cfg->num_envs <= 0) return fail(nullptr, -1, "bez_sim_create: num_envs must be > 0");
   if (cfg->substeps <= 0 || !(cfg->dt > 0.f)) return fail(nullptr, -1, "bez_sim_create: substeps and dt must be > 0");
+  if (const char* why = oracle_only(cfg->flags, cfg->tune)) return fail(nullptr, -5, why);
   int ndev = 0;
   hipError_t e = hipGetDeviceCount(&ndev);
   if (e != hipSuccess || ndev <= 0) return fail(nullptr, -3, "bez_sim_create: no HIP device available (the HIP path has no CPU fallback)", e);
@@ -655,6 +666,7 @@ int bez_sim_set_prev_lin_vel_tensor(BezSim* s, const float* prev_dev, void* stre
 }
 int bez_sim_set_flags(BezSim* s, uint32_t flags) {
   if (!s) return -1;
+  if (const char* why = oracle_only(flags, nullptr)) return fail(s, -5, why);
   const uint32_t asset = BEZ_FLAG_CLEATS | BEZ_FLAG_BOX_ASSET;  // the asset is fixed at creation (buffer shapes, kernel variant)
   s->cfg.flags = (flags & ~asset) | (s->cfg.flags & asset);
   return 0;

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define BEZ_SIM_ABI_VERSION 4
+#define BEZ_SIM_ABI_VERSION 5
 
 #define BEZ_NUM_OBS 54       /* bez_kick; bez_walk / bez_orient: 52 (no ball tail)  walk_env.py:104 */
 #define BEZ_NUM_OBS_WALK 52
@@ -60,7 +60,13 @@ extern "C" {
                                   points, ball <-> torso box); with BEZ_FLAG_CLEATS also that URDF's right ankle joint origin */
 
 #define BEZ_FLAG_HARD_CONTACT 64u /* rigid contact: velocity-level impulses with Coulomb stiction and restitution 0 (projected Gauss-Seidel on \
-                                     the articulated-body impulse responses) instead of the implicit spring-dampers; knobs in `tune` */
+                                     the articulated-body impulse responses) instead of the implicit spring-dampers; knobs in `tune`. \
+                                     ORACLE ONLY (an experiment that did not earn a kernel): bez_sim_create / \
+                                     bez_sim_set_flags of libbez_sim.so refuse it with rc -5 */
+#define BEZ_FLAG_TGS_SOLVER 512u /* TGS-shaped unified substep: drives, joint friction, joint limits, joint speed limit and every contact \
+                                    as clamped impulse rows relaxed together over posIters sub-steps of dt / posIters (+ velIters), the \
+                                    solver shape PhysX is configured with (bez_kick.yaml:128-147); knobs in `tune[8..23]`.  ORACLE ONLY \
+                                    (DESIGN.md 3.2 / 6.1): libbez_sim.so refuses it with rc -5 */
 
 #define BEZ_FLAG_LEAN_STEP 128u /* bez_sim_step / bez_sim_step_many keep only what the rollout reads (state, obs, reward, reset / progress / \
                                    timeout, DOF targets): the stores of the NET_CONTACT_FORCE rows, FEET and PREV_LIN_VEL -- 308 B of the \
@@ -111,7 +117,8 @@ typedef struct BezSimConfig {
   float ball_kn;       /* ball <-> ground / ball <-> robot contact spring [N/m]; 0 = contact_kn */
   float ball_cn;       /* and damper [N*s/m]; 0 = contact_cn.  PhysX restitution is 0 (bez_kick.yaml:16): critical damping of the 0.3 kg
                           ball against contact_kn is 2 sqrt(kn m) = 155 N*s/m */
-  float tune[8];       /* knobs of the rigid-contact model (BEZ_FLAG_HARD_CONTACT; oracle/bez_oracle.c documents the slots); 0 = default */
+  float tune[24];      /* knobs of the oracle-only solver variants (BEZ_FLAG_HARD_CONTACT: [0..7], BEZ_FLAG_TGS_SOLVER: [8..23];
+                          oracle/bez_oracle.c documents the slots); 0 = default.  libbez_sim.so refuses a non-zero entry (rc -5) */
   int32_t task;        /* BEZ_TASK_*: which env logic POST runs (tasks/__init__.py:10-16)                */
   float goal_angle;    /* bez_orient: env.goalState.goal_angle                       orient_env.py:61 */
   uint32_t flags;      /* BEZ_FLAG_* */

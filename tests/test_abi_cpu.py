@@ -57,6 +57,24 @@ def test_create_argument_errors(lib):
     assert lib.bez_sim_create(C.byref(c), 0, C.byref(h)) < 0
 
 
+def test_oracle_only_model_variants_are_refused(lib):
+    """BEZ_FLAG_HARD_CONTACT, BEZ_FLAG_TGS_SOLVER and BezSimConfig.tune[] select solver experiments that exist only in the CPU
+    oracle (include/bez_sim.h): the HIP library must say so (rc -5, before it even looks for a device) instead of stepping
+    the compliant model under a flag it ignores.  bez_sim_set_flags applies the same rule (GPU: tests/test_gpu_round3.py)."""
+    for mutate in (lambda c: setattr(c, "flags", c.flags | abi.FLAG_HARD_CONTACT),
+                   lambda c: setattr(c, "flags", c.flags | abi.FLAG_TGS_SOLVER),
+                   lambda c: c.tune.__setitem__(3, 0.5), lambda c: c.tune.__setitem__(23, 1.0)):
+        h = C.c_void_p()
+        c = abi.default_config(8)
+        mutate(c)
+        assert lib.bez_sim_create(C.byref(c), 0, C.byref(h)) == -5
+        assert not h.value
+        assert b"oracle" in lib.bez_sim_last_error(None)
+    hdr = open(os.path.join(ROOT, "include", "bez_sim.h")).read()
+    assert int(re.search(r"#define BEZ_FLAG_HARD_CONTACT (\d+)u", hdr).group(1)) == abi.FLAG_HARD_CONTACT
+    assert int(re.search(r"#define BEZ_FLAG_TGS_SOLVER (\d+)u", hdr).group(1)) == abi.FLAG_TGS_SOLVER
+
+
 @pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU failure mode")
 def test_product_fails_loudly_without_gpu(lib):
     from bez_isaacgym_amd.sim import BezSim, BezSimError
