@@ -41,7 +41,7 @@ def pmc_traffic(num_envs):
     return None, None
 
 
-def cpu_baseline(num_envs, seconds_target=9.0, seconds_single=3.0):
+def cpu_baseline(num_envs, seconds_target=9.0, seconds_single=3.0, seconds_small=2.0):
     """The oracle (kind 'port': this build's CPU restatement; the reference's own CPU pipeline is the closed
     PhysX binary and cannot run) on the host cores, bounded sample of the same workload: all cores of the box's
     share, then one thread (BASELINE.md 3 asks for both), with mean / p50 / p99 step times."""
@@ -57,7 +57,7 @@ def cpu_baseline(num_envs, seconds_target=9.0, seconds_single=3.0):
     rng = np.random.default_rng(0)
     acts = rng.uniform(-1, 1, (8, num_envs, 18)).astype(np.float32)
 
-    def sample(threads, budget):
+    def sample(threads, budget, orc=orc, acts=acts, num_envs=num_envs):
         gomp.omp_set_num_threads(threads)
         orc.step(acts[0])
         t0 = time.perf_counter()
@@ -77,14 +77,21 @@ def cpu_baseline(num_envs, seconds_target=9.0, seconds_single=3.0):
                 "ms_per_step": {"mean": float(times.mean() * 1e3), "p50": float(np.percentile(times, 50) * 1e3), "p99": float(np.percentile(times, 99) * 1e3)}}
     multi = sample(cores, seconds_target)
     single = sample(1, seconds_single)
+    # BASELINE.md 3 asks for N = 64 as well (BASELINE.json configs[0], the reference's own CPU-runnable size)
+    small_args = dict(orc=Oracle(abi.default_config(64)), acts=rng.uniform(-1, 1, (8, 64, 18)).astype(np.float32), num_envs=64)
+    small = sample(cores, seconds_small, **small_args)
+    small1 = sample(1, seconds_small, **small_args)
     return {"value": multi["value"], "unit": "env-steps/s", "cores": cores, "kind": "port", "spread": multi["spread"],
             "ms_per_step": multi["ms_per_step"],
             "single_thread": {"value": single["value"], "cores": 1, "ms_per_step": single["ms_per_step"],
                               "sample": "%d control steps (%.1f s)" % (single["steps"], single["seconds"])},
+            "num_envs_64": {"value": small["value"], "cores": cores, "ms_per_step": small["ms_per_step"],
+                            "single_thread": {"value": small1["value"], "ms_per_step": small1["ms_per_step"]},
+                            "sample": "64 envs x %d / %d control steps (BASELINE.json configs[0])" % (small["steps"], small1["steps"])},
             "sample": "%d envs x %d control steps in 4 segments, fp64 C oracle, OpenMP over envs (%.1f s)" % (num_envs, multi["steps"], multi["seconds"])}
 
 
-def launch_ranks(n, argv, env=None, python=sys.executable):
+def launch_ranks(n, argv, env=None, python=sys.executable, timeout=1500.0):
     """`python bench.py --gpus N` without a launcher: start N ranks of this script (one per GPU: RANK = LOCAL_RANK = i,
     WORLD_SIZE = N, rendezvous on 127.0.0.1) BEFORE anything in this process touches a GPU, let rank 0's stdout through
     (its ONE JSON line), and return the worst exit code.  The reference picks the device the same way, from the rank
@@ -92,19 +99,56 @@ def launch_ranks(n, argv, env=None, python=sys.executable):
     already set and this function is not reached."""
     import socket
     import subprocess
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
+    # the port is found by binding port 0; SO_REUSEADDR + keeping the probe socket open until the children exist narrows the
+    # window in which another process could take it (the ranks' TCPStore binds with SO_REUSEADDR as well)
+    probe = socket.socket()
+    probe.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+    probe.bind(("127.0.0.1", 0))
+    port = probe.getsockname()[1]
     procs = []
-    for r in range(n):
-        e = dict(os.environ if env is None else env)
-        e.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-        e.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        procs.append(subprocess.Popen([python, os.path.abspath(__file__)] + list(argv), env=e,
-                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    try:
+        for r in range(n):
+            e = dict(os.environ if env is None else env)
+            e.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+            e.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            procs.append(subprocess.Popen([python, os.path.abspath(__file__)] + list(argv), env=e,
+                                          stdout=None if r == 0 else subprocess.DEVNULL))
+    finally:
+        probe.close()
+    return wait_ranks(procs, timeout)
+
+
+def wait_ranks(procs, timeout=1500.0, grace=10.0, poll=0.2):
+    """Polls ALL children: the first non-zero exit (import error, OOM, HIP error in one rank) terminates the siblings -- which
+    would otherwise sit in the rendezvous or a barrier for ever -- after `grace` seconds kills them, and its code is returned;
+    so does the overall `timeout` (code 124).  0 only if every rank exited 0."""
+    deadline = time.monotonic() + timeout
     rc = 0
-    for p in procs:
-        rc = max(rc, abs(p.wait()))
+    live = list(procs)
+    while live and rc == 0:
+        for p in list(live):
+            r = p.poll()
+            if r is None:
+                continue
+            live.remove(p)
+            if r != 0:
+                rc = abs(r) or 1
+                break
+        else:
+            if time.monotonic() > deadline:
+                rc = 124
+            elif live:
+                time.sleep(poll)
+    if live:  # a rank failed or the time ran out: take the others down
+        for p in live:
+            p.terminate()
+        t_end = time.monotonic() + grace
+        for p in live:
+            try:
+                p.wait(max(0.0, t_end - time.monotonic()))
+            except Exception:
+                p.kill()
+                p.wait()
     return rc
 
 
@@ -157,6 +201,8 @@ def stub_main(args, rank, world):
     region, MAX over ranks, one JSON line from rank 0.  Exercised by tests/test_bench_launcher.py."""
     import torch
     import torch.distributed as dist
+    if os.environ.get("BEZ_BENCH_STUB_FAIL_RANK") == str(rank):
+        sys.exit(7)  # launcher self-test: one rank dies before the rendezvous; its siblings must not be left waiting
     if world > 1:
         dist.init_process_group("gloo")
         assert dist.get_world_size() == args.gpus
@@ -174,8 +220,12 @@ def stub_main(args, rank, world):
         dist.all_reduce(ranks)
         assert int(ranks.sum()) == world
     if rank == 0:
-        print(json.dumps({"metric": "stub", "value": args.num_envs * world * args.steps / elapsed, "n_gpus": world, "steps": args.steps,
-                          "warmup": args.warmup, "scaling": "weak", "config": {"parallelism": "env-sharded x%d" % world}}), flush=True)
+        out = {"metric": "stub", "value": args.num_envs * world * args.steps / elapsed, "n_gpus": world, "steps": args.steps,
+               "warmup": args.warmup, "scaling": "weak", "config": {"parallelism": "env-sharded x%d" % world}}
+        if world > 1:
+            out["collective"] = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "rank_sum_check": True}
+            out["cpu_baseline"] = "N=1 only"
+        print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -277,6 +327,33 @@ def main():
     per = sorted(evs[t].elapsed_time(evs[t + 1]) for t in range(400))
     step_ms = {"mean": sum(per) / len(per), "p50": per[200], "p99": per[396], "what": "400 extra steps outside the timed region, HIP event pair per step"}
 
+    # the C ABI's default keeps every Isaac-visible tensor current (no BEZ_FLAG_LEAN_STEP): the same build's full-store step,
+    # timed beside the headline so that the difference is on record
+    other = BezSim(abi.default_config(n, seed=42, env_id_offset=rank * n), local_rank) if not args.keep_aux else None
+    full_store_ms = None
+    if other is not None:
+        for t in range(50):
+            other.step(actions[t % ACTION_RING])
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for t in range(400):
+            other.step(actions[t % ACTION_RING])
+        e1.record()
+        torch.cuda.synchronize()
+        full_store_ms = e0.elapsed_time(e1) / 400
+        other.close()
+
+    collective = None
+    if world > 1:
+        # evidence that the ranks really form one RCCL job: a real all-reduce whose result every rank can check
+        chk = torch.tensor([float(rank + 1), 1.0], device=dev, dtype=torch.float64)
+        dist.all_reduce(chk)
+        ok = int(chk[0].item()) == world * (world + 1) // 2 and int(chk[1].item()) == world
+        collective = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "rank_sum_check": bool(ok),
+                      "rank_sum": chk[0].item(), "data_path_collectives_per_env_step": 0,
+                      "ppo_collectives_per_epoch": "optimiser steps + 2 (DESIGN.md 7)"}
+        assert ok, chk
+
     ppo = None
     if args.ppo_epochs > 0:
         ppo = ppo_leg(args, rank, local_rank, world, n)
@@ -303,7 +380,7 @@ def main():
             "config": {"workload": "bez_kick num_envs=%d per GPU, random-action rollout only (no PPO), dt=1/60 s x 2 substeps, "
                                    "natural resets included" % n,
                        "envs_per_gpu": n, "total_envs": total_envs, "launch": args.launch, "parallelism": "env-sharded x%d" % world,
-                       "lean_step": not args.keep_aux},
+                       "lean_step": not args.keep_aux, "full_store_step_ms": full_store_ms},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "bez::w8::step_kernel_ws8<true,true,false,false> (fused control step, default asset, 8 role waves per 64 envs)", "kernel_ms": kernel_ms,
@@ -317,7 +394,9 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(n)
         elif not args.no_cpu_baseline:
-            out["cpu_baseline"] = None
+            out["cpu_baseline"] = "N=1 only"
+        if collective is not None:
+            out["collective"] = collective
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

@@ -23,6 +23,18 @@ def test_bench_gpus_2_launches_two_ranks():
     assert len(lines) == 1, r.stdout  # only rank 0 prints
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["config"]["parallelism"] == "env-sharded x2" and d["steps"] == 5 and d["warmup"] == 1
+    assert d["collective"] == {"backend": "gloo", "world_size": 2, "rank_sum_check": True} and d["cpu_baseline"] == "N=1 only"
+
+
+def test_a_dying_rank_takes_the_job_down():
+    """the launcher used to wait for its children one after the other -- rank 1 dying left rank 0 in the
+    rendezvous for ever.  Now every child is polled, the survivor is terminated and the failing code is returned."""
+    import time
+    t0 = time.time()
+    r = _run(["--gpus", "2", "--steps", "5", "--warmup", "1", "--stub-cpu"], env={"BEZ_BENCH_STUB_FAIL_RANK": "1"})
+    assert r.returncode == 7, (r.returncode, r.stderr[-500:])
+    assert time.time() - t0 < 120
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
 
 
 def test_bench_single_rank_unchanged():
