@@ -19,6 +19,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <atomic>
 #include <cstring>
 
 #include "../../include/bez_sim.h"
@@ -323,8 +324,15 @@ int bez_ppo_wgrad_run(const void* plan_host, const void* plan_dev, int32_t accum
   const Args* H = static_cast<const Args*>(plan_host);
   const Args* D = static_cast<const Args*>(plan_dev);
   hipStream_t stream = (hipStream_t)stream_;
-  static bool attr_set = false;
-  if (!attr_set) { (void)hipFuncSetAttribute((const void*)wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
+  // the attribute is per device (a process may drive several) and cheap to set: per device once, guarded by an atomic bit mask
+  static std::atomic<uint64_t> attr_devices{0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0) return -2;
+  const uint64_t bit = dev < 64 ? (1ull << dev) : 0;  // beyond 64 devices: set it every time
+  if (!bit || !(attr_devices.load(std::memory_order_acquire) & bit)) {
+    if (hipFuncSetAttribute((const void*)wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return -2;
+    attr_devices.fetch_or(bit, std::memory_order_release);
+  }
   hipLaunchKernelGGL(wgrad_kernel, dim3(H->wg_total), dim3(WG_THREADS), (size_t)H->lds_bytes, stream, D);
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((H->max_block + 255) / 256, H->nparts), dim3(256), 0, stream, D, (int)accumulate);
   return hipGetLastError() == hipSuccess ? 0 : -2;

@@ -358,8 +358,10 @@ class A2CAgent:
         # an env whose step() syncs with the host or allocates (domain randomisation: vec_task.py:505-725) cannot be captured
         env_graph_safe = bool(getattr(getattr(vec_env, "env", vec_env), "graph_safe", True))
         # this trainer reads obs / reward / dones only: let the simulator skip the Isaac-visible extras (contact rows, feet, prev_lin_vel)
-        if c.get("lean_env_step", True) and hasattr(getattr(vec_env, "env", vec_env), "set_lean"):
-            getattr(vec_env, "env", vec_env).set_lean(True)
+        # -- for as long as this agent trains: train() hands the env back with every tensor current (release_env)
+        self._lean_env = getattr(vec_env, "env", vec_env) if c.get("lean_env_step", True) and hasattr(getattr(vec_env, "env", vec_env), "set_lean") else None
+        if self._lean_env is not None:
+            self._lean_env.set_lean(True)
         # world > 1: graphs are captured in SEGMENTS that contain no collective (the RCCL calls run eagerly between replays),
         # which needs the fused path's static flat gradient buffer -> decided below, once `self.fused` is known
         self.use_graphs = bool(on_gpu and env_graph_safe and (g is True or g == "auto"))
@@ -383,6 +385,11 @@ class A2CAgent:
         self._policy_bwd = None
         self._packed = None
         self.fused = bool(on_gpu and c.get("fused_ops", True))
+        if not self.fused and self.mixed_precision and g is True and on_gpu:
+            import warnings
+            warnings.warn("fused_ops: False + mixed_precision + hip_graphs: True replays torch's GradScaler / autocast update as HIP "
+                          "graphs: known to stop learning once agent.save() runs between replays (DESIGN.md 6.1); use hip_graphs: auto",
+                          RuntimeWarning, stacklevel=2)
         if not self.fused and self.mixed_precision and g != True:  # noqa: E712 (an explicit hip_graphs: True is honoured)
             # The plain torch formulation under AMP (torch's GradScaler + autocast) is run EAGERLY: replayed as HIP graphs it
             # stops learning after ~500 epochs in 4 of 4 seeds (profiles/r03_learning_plain_full.txt: -0.6 ... -1.5 at 6156 epochs)
@@ -1036,7 +1043,27 @@ class A2CAgent:
         return dict(play_time=t_play, update_time=t_total - t_play, total_time=t_total, kl=sum(kls) / len(kls),
                     a_loss=a_l, c_loss=c_l, lr=self.last_lr)
 
+    def release_env(self):
+        """Hands the env back to other consumers: lean stepping off, so env.net_contact_forces / feet / prev_lin_vel are
+        current again after its next step (the agent switched them off for its rollouts)."""
+        if getattr(self, "_lean_env", None) is not None:
+            self._lean_env.set_lean(False)
+
+    def __del__(self):
+        try:
+            self.release_env()
+        except Exception:
+            pass
+
     def train(self, max_epochs=None, log=print):
+        if self._lean_env is not None:
+            self._lean_env.set_lean(True)  # a second train() after release_env(): the captured rollout graphs step lean
+        try:
+            return self._train(max_epochs, log)
+        finally:
+            self.release_env()
+
+    def _train(self, max_epochs=None, log=print):
         self.obs = self.env_reset()
         max_epochs = max_epochs or self.max_epochs
         total_time = 0.0

@@ -199,8 +199,11 @@ class WgradMfma:
             self.partial = None
 
     def matches(self, dys, xs, grads):
+        # the plan bakes raw device pointers AND the geometry (rows, widths, strides): all of it must still hold
         k = self.keep
-        return all(a.data_ptr() == b.data_ptr() for a, b in zip(list(dys) + list(xs) + list(grads), k[0] + k[1] + k[2]))
+        new, old = list(dys) + list(xs) + list(grads), k[0] + k[1] + k[2]
+        return len(new) == len(old) and all(a.data_ptr() == b.data_ptr() and a.shape == b.shape and a.stride() == b.stride() and a.dtype == b.dtype
+                                            for a, b in zip(new, old))
 
     def __call__(self, accumulate=True):
         if not self.ok:

@@ -136,7 +136,9 @@ class KickEnv(VecTask):
         f = (f | abi.FLAG_LEAN_STEP) if on else (f & ~abi.FLAG_LEAN_STEP)
         self.sim.cfg.flags = f
         self.sim.set_flags(f)
-        self._lean = bool(on)
+        # the kernels honour the flag only together with BEZ_FLAG_IMU_PREV_ALIAS (prev_lin_vel is then never read back,
+        # include/bez_sim.h); without it every tensor stays current and the accessors below must not refuse
+        self._lean = bool(on) and bool(f & abi.FLAG_IMU_PREV_ALIAS)
 
     def _not_lean(self, what):
         if getattr(self, "_lean", False):
