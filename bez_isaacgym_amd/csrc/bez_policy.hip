@@ -561,7 +561,8 @@ extern "C" int bez_ppo_policy_forward_train(const float* obs_dev, int64_t n, int
 extern "C" int bez_ppo_policy_backward(const float* grad_mu_dev, const float* grad_value_dev, int64_t n, int32_t num_hidden, const int32_t* hidden_width,
                                        int32_t num_actions, const void* const* act_f16_dev, const void* const* wt_f16_dev, const void* heads_t_f16_dev,
                                        void* const* gz_f16_dev, void* grad_mu_f16_dev, void* grad_value_f16_dev, float* const* bias_grad_dev,
-                                       float* mu_bias_grad_dev, float* value_bias_grad_dev, float* partial_dev, int32_t weights_packed, void* stream) {
+                                       float* mu_bias_grad_dev, float* value_bias_grad_dev, float* partial_dev, int32_t weights_packed_flags, void* stream) {
+  const int32_t weights_packed = weights_packed_flags & 1;
   if (!partial_dev) return -1;
   if (!grad_mu_dev || !grad_value_dev || n <= 0 || num_hidden <= 0 || num_hidden > PF_MAXL || !hidden_width || num_actions <= 0 || num_actions > 31 ||
       !act_f16_dev || !wt_f16_dev || !heads_t_f16_dev || !gz_f16_dev || !grad_mu_f16_dev || !grad_value_f16_dev || !bias_grad_dev || !mu_bias_grad_dev ||
@@ -590,7 +591,8 @@ extern "C" int bez_ppo_policy_backward(const float* grad_mu_dev, const float* gr
   else if (narrow) hipLaunchKernelGGL((policy_backward_kernel<216, PF_LD, false>), dim3(nwg), dim3(PF_WAVES * 64), 0, (hipStream_t)stream, a);
   else if (weights_packed) hipLaunchKernelGGL((policy_backward_kernel<PF_LD, PF_LD, true>), dim3(nwg), dim3(PF_WAVES * 64), 0, (hipStream_t)stream, a);
   else hipLaunchKernelGGL((policy_backward_kernel<PF_LD, PF_LD, false>), dim3(nwg), dim3(PF_WAVES * 64), 0, (hipStream_t)stream, a);
-  hipLaunchKernelGGL(policy_bias_reduce_kernel, dim3((unsigned)((a.ptotal + num_actions + 1 + 63) / 64)), dim3(1024), 0, (hipStream_t)stream, a, (int)nwg);
+  if (!(weights_packed_flags & 2))  // bit 1: the per-workgroup column sums only -- bez_ppo_grad_reduce_all adds them with the step's other reductions
+    hipLaunchKernelGGL(policy_bias_reduce_kernel, dim3((unsigned)((a.ptotal + num_actions + 1 + 63) / 64)), dim3(1024), 0, (hipStream_t)stream, a, (int)nwg);
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 

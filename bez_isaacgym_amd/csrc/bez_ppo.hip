@@ -519,88 +519,129 @@ __global__ __launch_bounds__(PPO_TB) void gae_kernel(const float* __restrict__ r
 }
 
 // ---- the optimiser tail of one minibatch step on the flat fp32 buffers: GradScaler.unscale_ + clip_grad_norm_ + Adam (torch
-// semantics, no amsgrad) + GradScaler.update, three launches instead of torch's dozen.
-// work[1] = number of non-finite elements (an integer-valued float: exact in any order; zero on entry, re-zeroed by the last kernel);
-// work[2 + b] = block b's sum of squares of the UNSCALED gradient.  The squared norm is the FIXED-ORDER sum of those partials, formed
-// again by every block of the update kernel: float atomics would make the clip coefficient differ in its last bits from run to run
-// and, data parallel, from rank to rank -- the replicas' weights then drift apart (tests: test_two_ranks_on_the_gpu_stay_bit_identical).
-constexpr int ADAM_NORM_BLOCKS = 256;
-static_assert(2 + ADAM_NORM_BLOCKS <= BEZ_PPO_ADAM_WORK_FLOATS, "work buffer of the C ABI too small");
-__global__ __launch_bounds__(PPO_TB) void adam_norm_kernel(const float* __restrict__ g, int64_t n, const float* __restrict__ scale, float* __restrict__ work) {
-  __shared__ float red[2][4];
-  const float inv = scale ? 1.0f / scale[0] : 1.0f;
+// semantics, no amsgrad) + GradScaler.update + the step's bookkeeping, ONE launch (round 3: three; torch: a dozen).
+//   phase 1  every workgroup forms the squared norm of the WHOLE unscaled gradient and its non-finite count by itself, in the same
+//            fixed order (thread t owns the float4s t, t + 1024, ...; wave butterfly; 16 wave sums added in order): no float atomics,
+//            the clip coefficient -- and with it every weight -- is bit-identical in every workgroup, run to run and rank to rank
+//            (tests: test_training_is_bit_reproducible, test_two_ranks_on_the_gpu_stay_bit_identical).  0.5 MB from L2 per
+//            workgroup, 31 independent 16-byte loads per thread: cheaper than the launch it replaces.
+//   phase 2  every workgroup reads what the commit will overwrite (loss scale, learning rate, step count), waits for those loads
+//            and draws a ticket (ONE agent-scope atomic add per workgroup on work[0]).
+//   phase 3  Adam on the workgroup's own slice; the fp16 working copy and the fragment-major forward / backward copies the MFMA
+//            policy kernels read (maps of bez_ppo_scatter2_f16) are written in the same pass.
+//   phase 4  the workgroup that drew the LAST ticket commits: by then every other workgroup has read the old scale / lr / steps, so the
+//            new ones cannot be seen too early -- step counters, loss-scale schedule, the tail sums (epoch KL / loss accumulators),
+//            rl_games' per-step learning-rate rule; it also resets the ticket counter.  No fence: nothing a workgroup WRITES is read
+//            by another workgroup of this launch.
+//   extra    workgroup 0 applies the NEXT minibatch's observation moments to the input normaliser (rms_apply), which nothing in this
+//            launch reads: one launch less in front of the next forward pass.
+constexpr int ADAM_TB = 1024;
+struct AdamTail { float* dst[4]; const float* src[4]; float scale[4]; int n; float* lr; const float* kl; float kl_thr, min_lr, max_lr; };
+struct AdamExtra {
+  const int32_t* map_a; const int32_t* map_b; __half* packed;          // fragment-major weight copies (NULL: none)
+  const double* rms_mom; int rms_d; double* rms_mean; double* rms_var; double* rms_count;  // next normaliser update (NULL: none)
+};
+__global__ __launch_bounds__(ADAM_TB) void adam_fused_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                                            int64_t n, float* __restrict__ steps, int nsteps, float* __restrict__ lr, float beta1, float beta2,
+                                                            float eps, float weight_decay, float max_norm, float* __restrict__ scale,
+                                                            int32_t* __restrict__ growth_tracker, float growth_factor, float backoff_factor,
+                                                            int32_t growth_interval, unsigned int* __restrict__ ticket, __half* __restrict__ p16,
+                                                            AdamTail tail, AdamExtra ex) {
+  __shared__ float red[2][ADAM_TB / 64];
+  __shared__ unsigned int my_ticket;
+  const int tid = threadIdx.x;
+  // ---- phase 2 first in program order (the loads are in flight while phase 1 streams the gradient)
+  const float scale_v = scale ? scale[0] : 1.0f;
+  const float lr_v = lr[0];
+  const float step_v = steps[0];
+  // ---- phase 1
+  const float inv = 1.0f / scale_v;
   float s2 = 0.f, bad = 0.f;
-  for (int64_t i = (int64_t)blockIdx.x * PPO_TB + threadIdx.x; i < n; i += (int64_t)gridDim.x * PPO_TB) {
-    const float x = g[i] * inv;
-    if (!(fabsf(x) <= 3.4028234e38f)) bad += 1.f;  // inf or nan
-    s2 = fmaf(x, x, s2);
+  const int64_t n4 = n >> 2;
+  const float4* g4 = reinterpret_cast<const float4*>(g);
+  for (int64_t i = tid; i < n4; i += ADAM_TB) {
+    const float4 x = g4[i];
+    const float a = x.x * inv, b = x.y * inv, c = x.z * inv, d = x.w * inv;
+    bad += (fabsf(a) <= 3.4028234e38f ? 0.f : 1.f) + (fabsf(b) <= 3.4028234e38f ? 0.f : 1.f) + (fabsf(c) <= 3.4028234e38f ? 0.f : 1.f) +
+           (fabsf(d) <= 3.4028234e38f ? 0.f : 1.f);
+    s2 = fmaf(a, a, s2); s2 = fmaf(b, b, s2); s2 = fmaf(c, c, s2); s2 = fmaf(d, d, s2);
+  }
+  if (tid < (int)(n & 3)) {  // the last n % 4 elements
+    const float a = g[(n4 << 2) + tid] * inv;
+    bad += fabsf(a) <= 3.4028234e38f ? 0.f : 1.f;
+    s2 = fmaf(a, a, s2);
   }
   s2 = wave_sum(s2); bad = wave_sum(bad);
-  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s2; red[1][threadIdx.x >> 6] = bad; }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    work[2 + blockIdx.x] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
-    const float b = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
-    if (b > 0.f) atomicAdd(&work[1], b);
+  if ((tid & 63) == 0) { red[0][tid >> 6] = s2; red[1][tid >> 6] = bad; }
+  // the ticket: after this workgroup's reads of scale / lr / steps have RETURNED (they were used above / are waited for here)
+  if (tid == 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    float keep = lr_v + step_v;  // (both values are live in registers before the add is issued)
+    asm volatile("" : "+v"(keep));
+    my_ticket = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
-}
-// p, m, v updated in place; skipped altogether when the scaler is on and the gradient is not finite (GradScaler.step)
-__global__ __launch_bounds__(PPO_TB) void adam_update_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
-                                                             int64_t n, const float* __restrict__ steps, const float* __restrict__ lr, float beta1,
-                                                             float beta2, float eps, float weight_decay, float max_norm,
-                                                             const float* __restrict__ scale, const float* __restrict__ work, int nparts,
-                                                             __half* __restrict__ p16) {
-  static_assert(PPO_TB == ADAM_NORM_BLOCKS, "one partial per thread");
-  __shared__ float red[4];
-  float coef = 1.0f;
-  if (max_norm > 0.f) {   // clip_grad_norm_: the same fixed-order sum in every block (and on every rank)
-    float part = (int)threadIdx.x < nparts ? work[2 + threadIdx.x] : 0.f;
-    part = wave_sum(part);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = part;
-    __syncthreads();
-    const float norm2 = (red[0] + red[1]) + (red[2] + red[3]);
-    coef = fminf(max_norm / (sqrtf(norm2) + 1e-6f), 1.0f);
-  }
-  const int64_t i = (int64_t)blockIdx.x * PPO_TB + threadIdx.x;
-  if (i >= n) return;
-  if (scale && work[1] > 0.f) return;
-  const float inv = scale ? 1.0f / scale[0] : 1.0f;
-  const float t = steps[0] + 1.0f;
-  const float bc1 = 1.0f - powf(beta1, t), bc2 = 1.0f - powf(beta2, t);
-  float x = g[i] * inv * coef;
-  float w = p[i];
-  if (weight_decay != 0.f) x = fmaf(weight_decay, w, x);
-  const float mi = fmaf(beta1, m[i], (1.0f - beta1) * x);
-  const float vi = fmaf(beta2, v[i], (1.0f - beta2) * x * x);
-  m[i] = mi; v[i] = vi;
-  const float denom = sqrtf(vi) / sqrtf(bc2) + eps;
-  w -= (lr[0] / bc1) * (mi / denom);
-  p[i] = w;
-  if (p16) p16[i] = __float2half(w);  // the fp16 working copy of the master weights, refreshed in the same pass
-}
-// step counters (one per parameter tensor, all equal) and the loss-scale schedule (GradScaler.update)
-// ... and, in the same launch, the step's bookkeeping sums (tail: dst[i] += *src[i] * scale[i], e.g. the epoch's KL / loss accumulators)
-// and the reset of work[] for the next step (work is zero on entry of bez_ppo_adam_step and zero again on return: no memset per step)
-struct AdamTail { float* dst[4]; const float* src[4]; float scale[4]; int n; float* lr; const float* kl; float kl_thr, min_lr, max_lr; };
-__global__ void adam_commit_kernel(float* __restrict__ steps, int nsteps, float* __restrict__ scale, int32_t* __restrict__ growth_tracker,
-                                   float growth_factor, float backoff_factor, int32_t growth_interval, float* __restrict__ work, AdamTail tail) {
-  const bool bad = scale && work[1] > 0.f;
   __syncthreads();
-  if (threadIdx.x < 2) work[threadIdx.x] = 0.f;
-  if ((int)threadIdx.x < tail.n) *tail.dst[threadIdx.x] += *tail.src[threadIdx.x] * tail.scale[threadIdx.x];
-  if (threadIdx.x == 0 && tail.kl) {   // rl_games AdaptiveScheduler.update ('legacy' schedule: after every minibatch step, for the NEXT one)
-    float v = tail.lr[0];
+  float norm2 = 0.f, nbad = 0.f;
+#pragma unroll
+  for (int w = 0; w < ADAM_TB / 64; ++w) { norm2 += red[0][w]; nbad += red[1][w]; }
+  const bool skip = scale && nbad > 0.f;   // GradScaler.step: a non-finite gradient skips the step
+  // ---- phase 3
+  if (!skip) {
+    const float coef = max_norm > 0.f ? fminf(max_norm / (sqrtf(norm2) + 1e-6f), 1.0f) : 1.0f;
+    const float t = step_v + 1.0f;
+    const float bc1 = 1.0f - powf(beta1, t), bc2 = 1.0f - powf(beta2, t);
+    const float rs2 = 1.0f / sqrtf(bc2), step_size = lr_v / bc1;
+    for (int64_t i = (int64_t)blockIdx.x * ADAM_TB + tid; i < n; i += (int64_t)gridDim.x * ADAM_TB) {
+      float x = g[i] * inv * coef;
+      float w = p[i];
+      if (weight_decay != 0.f) x = fmaf(weight_decay, w, x);
+      const float mi = fmaf(beta1, m[i], (1.0f - beta1) * x);
+      const float vi = fmaf(beta2, v[i], (1.0f - beta2) * x * x);
+      m[i] = mi; v[i] = vi;
+      const float denom = sqrtf(vi) * rs2 + eps;
+      w -= step_size * (mi / denom);
+      p[i] = w;
+      if (p16) {
+        const __half h = __float2half(w);
+        p16[i] = h;
+        if (ex.packed) { const int32_t a = ex.map_a[i], b = ex.map_b[i]; if (a >= 0) ex.packed[a] = h; if (b >= 0) ex.packed[b] = h; }
+      }
+    }
+  }
+  // ---- extra: the next minibatch's moments into the input normaliser (parallel-variance update, as rms_apply_kernel)
+  if (blockIdx.x == 0 && ex.rms_mom) {
+    const int D = ex.rms_d;
+    const double nn = ex.rms_mom[2 * D], cnt = ex.rms_count[0], tot = cnt + nn;
+    if (tid < D) {
+      const double b_mean = ex.rms_mom[tid] / nn;
+      double b_var = ex.rms_mom[D + tid] / nn - b_mean * b_mean;
+      if (b_var < 0.0) b_var = 0.0;
+      b_var *= nn / (nn - 1.0 > 1.0 ? nn - 1.0 : 1.0);
+      const double delta = b_mean - ex.rms_mean[tid];
+      const double m2 = ex.rms_var[tid] * cnt + b_var * nn + delta * delta * cnt * nn / tot;
+      ex.rms_mean[tid] += delta * nn / tot;
+      ex.rms_var[tid] = m2 / tot;
+    }
+    __syncthreads();   // (uniform: the whole workgroup is in this branch) count is read above by every thread before it moves
+    if (tid == 0) ex.rms_count[0] = tot;
+  }
+  // ---- phase 4
+  if (my_ticket != gridDim.x - 1) return;
+  if (tid == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (tid < tail.n) *tail.dst[tid] += *tail.src[tid] * tail.scale[tid];
+  if (tid == 0 && tail.kl) {   // rl_games AdaptiveScheduler.update ('legacy' schedule: after every minibatch step, for the NEXT one)
+    float nv = lr_v;
     const float k = tail.kl[0];
-    if (k > 2.0f * tail.kl_thr) v = fmaxf(v / 1.5f, tail.min_lr);
-    if (k < 0.5f * tail.kl_thr) v = fminf(v * 1.5f, tail.max_lr);
-    tail.lr[0] = v;
+    if (k > 2.0f * tail.kl_thr) nv = fmaxf(nv / 1.5f, tail.min_lr);
+    if (k < 0.5f * tail.kl_thr) nv = fminf(nv * 1.5f, tail.max_lr);
+    lr[0] = nv;
   }
-  if (threadIdx.x < nsteps && !bad) steps[threadIdx.x] += 1.0f;
-  if (threadIdx.x == 0 && scale) {
-    if (bad) { scale[0] *= backoff_factor; growth_tracker[0] = 0; }
+  if (tid < nsteps && !skip) steps[tid] = step_v + 1.0f;
+  if (tid == 0 && scale) {
+    if (skip) { scale[0] = scale_v * backoff_factor; growth_tracker[0] = 0; }
     else {
       const int32_t t = growth_tracker[0] + 1;
-      if (t == growth_interval) { scale[0] *= growth_factor; growth_tracker[0] = 0; }
+      if (t == growth_interval) { scale[0] = scale_v * growth_factor; growth_tracker[0] = 0; }
       else growth_tracker[0] = t;
     }
   }
@@ -679,8 +720,10 @@ int bez_ppo_loss(const float* mu_dev, const float* logstd_dev, const float* valu
                  float* scratch_dev, void* stream) {
   if (!mu_dev || !logstd_dev || !value_dev || !actions_dev || !old_logp_dev || !adv_dev || !old_value_dev || !returns_dev || !old_mu_dev ||
       !old_sigma_dev || !grad_mu_dev || !grad_value_dev || !grad_logstd_dev || !stats_dev || batch <= 0 || num_actions <= 0 || num_actions > 32) return -1;
-  if (!(clip_value & 2)) (void)hipMemsetAsync(grad_logstd_dev, 0, (size_t)num_actions * sizeof(float), (hipStream_t)stream);  // bit 1: accumulate
-  if (!(clip_value & 4)) (void)hipMemsetAsync(stats_dev, 0, 5 * sizeof(float), (hipStream_t)stream);                    // bit 2: the caller zeroed stats
+  const bool defer = (clip_value & 16) != 0;  // bit 4: per-workgroup partials only (needs scratch); bez_ppo_grad_reduce_all writes grad_logstd / stats
+  if (defer && !scratch_dev) return -1;
+  if (!defer && !(clip_value & 2)) (void)hipMemsetAsync(grad_logstd_dev, 0, (size_t)num_actions * sizeof(float), (hipStream_t)stream);  // bit 1: accumulate
+  if (!defer && !(clip_value & 4)) (void)hipMemsetAsync(stats_dev, 0, 5 * sizeof(float), (hipStream_t)stream);                    // bit 2: the caller zeroed stats
 #define BEZ_PPO_LOSS(AA)                                                                                                                             \
   hipLaunchKernelGGL(ppo_loss_kernel<AA>, dim3((unsigned)((batch + LOSS_TB - 1) / LOSS_TB)), dim3(LOSS_TB), 0, (hipStream_t)stream, mu_dev, logstd_dev, value_dev, actions_dev, old_logp_dev,  \
                      adv_dev, old_value_dev, returns_dev, old_mu_dev, old_sigma_dev, batch, e_clip, critic_coef, entropy_coef, bounds_coef,              \
@@ -721,7 +764,7 @@ int bez_ppo_loss(const float* mu_dev, const float* logstd_dev, const float* valu
     default: return -1;
   }
 #undef BEZ_PPO_LOSS
-  if (scratch_dev)
+  if (scratch_dev && !defer)
     hipLaunchKernelGGL(ppo_loss_reduce_kernel, dim3((unsigned)num_actions + 5), dim3(64), 0, (hipStream_t)stream, (const float*)scratch_dev, (int)num_actions,
                        (unsigned int)((batch + LOSS_TB - 1) / LOSS_TB), grad_logstd_dev, stats_dev);
   return launch_ok();
@@ -781,9 +824,10 @@ int bez_ppo_adam_step(float* params_dev, const float* grads_dev, float* exp_avg_
                       int32_t nsteps, float* lr_dev, float beta1, float beta2, float eps, float weight_decay, float max_norm, float* scale_dev,
                       int32_t* growth_tracker_dev, float growth_factor, float backoff_factor, int32_t growth_interval, float* work_dev,
                       void* params_f16_dev, int32_t ntail, float* const* tail_dst_dev, const float* const* tail_src_dev, const float* tail_scale,
-                      const float* adapt_kl_dev, float adapt_kl_threshold, float min_lr, float max_lr, void* stream) {
+                      const float* adapt_kl_dev, float adapt_kl_threshold, float min_lr, float max_lr, const BezPpoAdamExtra* extra, void* stream) {
   if (!params_dev || !grads_dev || !exp_avg_dev || !exp_avg_sq_dev || !steps_dev || !lr_dev || !work_dev || n <= 0 || nsteps <= 0 || nsteps > 64 ||
       (scale_dev && !growth_tracker_dev) || ntail < 0 || ntail > 4 || (ntail > 0 && (!tail_dst_dev || !tail_src_dev || !tail_scale))) return -1;
+  if ((reinterpret_cast<uintptr_t>(grads_dev) & 15) != 0) return -1;  // the norm pass reads the gradient as float4
   hipStream_t st = (hipStream_t)stream;
   AdamTail tail;
   tail.n = ntail;
@@ -792,13 +836,20 @@ int bez_ppo_adam_step(float* params_dev, const float* grads_dev, float* exp_avg_
     tail.dst[i] = i < ntail ? tail_dst_dev[i] : nullptr; tail.src[i] = i < ntail ? tail_src_dev[i] : nullptr; tail.scale[i] = i < ntail ? tail_scale[i] : 0.f;
     if (i < ntail && (!tail.dst[i] || !tail.src[i])) return -1;
   }
-  unsigned g = nblk(n);
-  if (g > (unsigned)ADAM_NORM_BLOCKS) g = ADAM_NORM_BLOCKS;
-  hipLaunchKernelGGL(adam_norm_kernel, dim3(g), dim3(PPO_TB), 0, st, grads_dev, n, (const float*)scale_dev, work_dev);
-  hipLaunchKernelGGL(adam_update_kernel, dim3(nblk(n)), dim3(PPO_TB), 0, st, params_dev, grads_dev, exp_avg_dev, exp_avg_sq_dev, n, (const float*)steps_dev,
-                     (const float*)lr_dev, beta1, beta2, eps, weight_decay, max_norm, (const float*)scale_dev, (const float*)work_dev, (int)g, (__half*)params_f16_dev);
-  hipLaunchKernelGGL(adam_commit_kernel, dim3(1), dim3(64), 0, st, steps_dev, (int)nsteps, scale_dev, growth_tracker_dev, growth_factor, backoff_factor,
-                     growth_interval, work_dev, tail);
+  AdamExtra ex{};
+  if (extra) {
+    if (extra->packed_f16_dev && (!extra->map_a_dev || !extra->map_b_dev || !params_f16_dev)) return -1;
+    if (extra->rms_moments_dev && (!extra->rms_mean_dev || !extra->rms_var_dev || !extra->rms_count_dev || extra->rms_cols <= 0 || extra->rms_cols > ADAM_TB)) return -1;
+    ex.map_a = extra->map_a_dev; ex.map_b = extra->map_b_dev; ex.packed = (__half*)extra->packed_f16_dev;
+    ex.rms_mom = extra->rms_moments_dev; ex.rms_d = extra->rms_cols; ex.rms_mean = extra->rms_mean_dev; ex.rms_var = extra->rms_var_dev; ex.rms_count = extra->rms_count_dev;
+  }
+  // one slice of <= 2 elements per thread keeps the update short; at least 8 workgroups so that every XCD has one
+  unsigned g = (unsigned)((n + 2 * ADAM_TB - 1) / (2 * ADAM_TB));
+  if (g < 8) g = 8;
+  if (g > 256) g = 256;
+  hipLaunchKernelGGL(adam_fused_kernel, dim3(g), dim3(ADAM_TB), 0, st, params_dev, grads_dev, exp_avg_dev, exp_avg_sq_dev, n, steps_dev, (int)nsteps, lr_dev,
+                     beta1, beta2, eps, weight_decay, max_norm, scale_dev, growth_tracker_dev, growth_factor, backoff_factor, growth_interval,
+                     reinterpret_cast<unsigned int*>(work_dev), (__half*)params_f16_dev, tail, ex);
   return launch_ok();
 }
 

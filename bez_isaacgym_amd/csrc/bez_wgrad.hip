@@ -229,6 +229,75 @@ __global__ void wgrad_reduce_kernel(const Args* __restrict__ Ap, int accumulate)
   *d = s;
 }
 
+// ---- every second-stage reduction of a minibatch step's gradient in ONE launch (round 3: three): the split-K partial images of the
+// five weight gradients (wgrad_kernel above), the per-workgroup column sums of the bias gradients (policy_backward_kernel,
+// csrc/bez_policy.hip) and the per-workgroup sums of the loss kernel (d loss / d log-sigma, the five loss / KL / entropy sums:
+// ppo_loss_kernel, csrc/bez_ppo.hip).  All three are fixed-order sums of partials -- no float atomics, bit-reproducible -- and each
+// output element has exactly one writer, so with accumulate == 0 the launch WRITES the whole flat gradient (weights, biases, log-sigma)
+// and the statistics: the caller needs no clear in front of the step.
+constexpr int RA_MAXL = 8;
+struct BiasReduce { const float* partial; int prow, ptotal, nhid, num_actions, nwg; int poff[RA_MAXL]; float* bgrad[RA_MAXL]; float* bmu; float* bv; };
+struct LossReduce { const float* scratch; int A; unsigned int nblocks; float* grad_logstd; float* stats; };
+__global__ __launch_bounds__(256) void grad_reduce_all_kernel(const Args* __restrict__ Ap, int accumulate, int wx, int nwb, BiasReduce B, int nbb, LossReduce Ls) {
+  __shared__ float sh[4][64];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  if (b < nwb) {   // weight gradients: block (b % wx) of part (b / wx)
+    const Args& A = *Ap;
+    const Part& P = A.part[b / wx];
+    const int i = (b % wx) * 256 + tid, n = P.gcols * P.xcols;
+    if (i >= n) return;
+    const int r = i / P.xcols, c = i - r * P.xcols;
+    float* d = P.dst + (size_t)(P.g0 + r) * P.dst_ld + P.x0 + c;
+    const float* p = A.partial + P.partial_off + i;
+    float s = accumulate ? *d : 0.f;
+    int k = 0;
+    for (; k + 8 <= P.splits; k += 8) {   // eight loads in flight, added in their fixed order
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = p[(long long)(k + u) * n];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; k < P.splits; ++k) s += p[(long long)k * n];
+    *d = s;
+  } else if (b < nwb + nbb) {   // bias gradients: 4 row lanes x 64 columns; a row lane sums every 4th workgroup's partial
+    const int l = tid & 63, rl = tid >> 6;
+    const int c = (b - nwb) * 64 + l;
+    const int ncol = B.ptotal + B.num_actions + 1;
+    float s = 0.f;
+    if (c < ncol) {
+#pragma unroll 8
+      for (int w = rl; w < B.nwg; w += 4) s += B.partial[(size_t)w * B.prow + c];
+    }
+    sh[rl][l] = s;
+    __syncthreads();
+    if (rl == 0 && c < ncol) {
+      const float t = (sh[0][l] + sh[1][l]) + (sh[2][l] + sh[3][l]);
+      float* d;
+      if (c >= B.ptotal) { const int k = c - B.ptotal; d = k < B.num_actions ? &B.bmu[k] : &B.bv[0]; }
+      else {
+        int L = 0;
+        while (L + 1 < B.nhid && c >= B.poff[L + 1]) ++L;
+        d = &B.bgrad[L][c - B.poff[L]];
+      }
+      *d = accumulate ? *d + t : t;
+    }
+  } else {   // loss sums: one wave per column; lane l adds workgroups l, l + 64, ..., then the butterfly
+    if (tid >= 64) return;
+    const int c = b - nwb - nbb;
+    const float* col = Ls.scratch + 2 + (size_t)c * Ls.nblocks;
+    float acc = 0.f;
+#pragma unroll 8
+    for (unsigned int q = tid; q < Ls.nblocks; q += 64) acc += col[q];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if (tid == 0) {
+      float* d = c < Ls.A ? &Ls.grad_logstd[c] : &Ls.stats[c - Ls.A];
+      *d = accumulate ? *d + acc : acc;
+    }
+  }
+}
+
 int lds_stride(int cols) {   // halfs: >= cols rounded up to whole tiles, stride bytes = 64 or 192 (mod 256)
   int c = (cols + 31) / 32 * 32;
   return ((c / 32) & 1) ? c : c + 32;
@@ -334,7 +403,27 @@ int bez_ppo_wgrad_run(const void* plan_host, const void* plan_dev, int32_t accum
     attr_devices.fetch_or(bit, std::memory_order_release);
   }
   hipLaunchKernelGGL(wgrad_kernel, dim3(H->wg_total), dim3(WG_THREADS), (size_t)H->lds_bytes, stream, D);
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((H->max_block + 255) / 256, H->nparts), dim3(256), 0, stream, D, (int)accumulate);
+  if (accumulate != 2)  // 2: the partial images only -- bez_ppo_grad_reduce_all adds them together with the step's other reductions
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((H->max_block + 255) / 256, H->nparts), dim3(256), 0, stream, D, (int)accumulate);
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+int bez_ppo_grad_reduce_all(const void* plan_host, const void* plan_dev, const float* bias_partial_dev, int64_t rows, int32_t num_hidden,
+                            const int32_t* hidden_width, int32_t num_actions, float* const* bias_grad_dev, float* mu_bias_grad_dev,
+                            float* value_bias_grad_dev, const float* loss_scratch_dev, int64_t loss_rows, float* grad_logstd_dev, float* stats_dev,
+                            int32_t accumulate, void* stream) {
+  if (!plan_host || !plan_dev || !bias_partial_dev || rows <= 0 || num_hidden <= 0 || num_hidden > RA_MAXL || !hidden_width || num_actions <= 0 ||
+      num_actions > 31 || !bias_grad_dev || !mu_bias_grad_dev || !value_bias_grad_dev || !loss_scratch_dev || loss_rows <= 0 || !grad_logstd_dev || !stats_dev) return -1;
+  const Args* H = static_cast<const Args*>(plan_host);
+  BiasReduce B{};
+  B.partial = bias_partial_dev; B.nhid = num_hidden; B.num_actions = num_actions; B.nwg = (int)((rows + 63) / 64);  // policy_backward_kernel: 64 rows per workgroup
+  int off = 0;
+  for (int i = 0; i < num_hidden; ++i) { if (!bias_grad_dev[i]) return -1; B.poff[i] = off; B.bgrad[i] = bias_grad_dev[i]; off += hidden_width[i]; }
+  B.ptotal = off; B.prow = off + 32; B.bmu = mu_bias_grad_dev; B.bv = value_bias_grad_dev;
+  LossReduce Ls{loss_scratch_dev, (int)num_actions, (unsigned int)((loss_rows + 63) / 64), grad_logstd_dev, stats_dev};  // ppo_loss_kernel: 64 rows per workgroup
+  const int wx = (H->max_block + 255) / 256, nwb = wx * H->nparts, nbb = (B.ptotal + num_actions + 1 + 63) / 64, nlb = num_actions + 5;
+  hipLaunchKernelGGL(grad_reduce_all_kernel, dim3(nwb + nbb + nlb), dim3(256), 0, (hipStream_t)stream, static_cast<const Args*>(plan_dev), (int)(accumulate != 0),
+                     wx, nwb, B, nbb, Ls);
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 

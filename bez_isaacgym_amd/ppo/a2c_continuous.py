@@ -384,6 +384,8 @@ class A2CAgent:
         self._policy_fwd = None
         self._policy_bwd = None
         self._packed = None
+        self._packed_stale = True     # the fragment-major weight copies need a refresh() before their next use (set whenever weights change outside the fused optimiser)
+        self._rms_preapplied = False  # the input normaliser already holds the coming minibatch's moments (folded into the previous optimiser launch)
         self.fused = bool(on_gpu and c.get("fused_ops", True))
         if not self.fused and self.mixed_precision and g is True and on_gpu:
             import warnings
@@ -505,7 +507,8 @@ class A2CAgent:
         cur = self.obs  # step 0 reads the agent's copy; later steps read the env's own observation buffer (no per-step copy)
         vrms = self.value_mean_std if self.normalize_value else None
         if self._packed is not None:
-            self._packed.refresh()  # the last optimiser step changed the weights
+            self._packed.refresh()  # once per epoch, whoever changed the weights last (optimiser, checkpoint restore, parameter broadcast)
+            self._packed_stale = False
         fx["noise"].normal_()  # the whole horizon's action noise in one launch
         for n in range(self.horizon):
             if self._policy_fwd is not None:
@@ -752,18 +755,24 @@ class A2CAgent:
         self.model.train()
         obs = mb["obs"]
         if self.normalize_input:
-            self._f_obs_rms.apply(self._obs_mom[mb["_i"]])
+            if self._rms_preapplied:   # the previous step's optimiser launch already absorbed this minibatch's moments
+                self._rms_preapplied = False
+            else:
+                self._f_obs_rms.apply(self._obs_mom[mb["_i"]])
         if self.half_path and getattr(self, "_hflat", None) is None:
             net.refresh_half()  # (with the fused optimiser the Adam kernel keeps the fp16 copies current)
         manual = self._train_fwd_ok(obs)
+        wg = None
         if manual:
             # forward of the whole MLP as one MFMA kernel that keeps the ELU outputs (csrc/bez_policy.hip, mode 2); the backward pass
             # below is the chain autograd would run through _HalfLinearEluFn / _HalfLinearFn, called directly
             tf = self._train_bufs(obs.shape[0])
-            if self._packed is not None:
-                self._packed.refresh()  # forward and backward copies of this step's weights, one launch
+            if self._packed is not None and (self._packed_stale or not self._fused_opt):
+                self._packed.refresh()  # forward and backward copies of this step's weights (the fused optimiser writes them itself)
+                self._packed_stale = False
             self._policy_fwd.train_forward(obs, tf["x0"], tf["act"], tf["mu"], tf["v"])
             mu32, v32 = tf["mu"], tf["v"]
+            wg = self._wgrad_plan(tf)
         else:
             if self.normalize_input:
                 obs = self._f_obs_rms.normalize(obs, fx["mb_obs_n"])
@@ -775,14 +784,36 @@ class A2CAgent:
             if self.scaler._scale is None:
                 self.scaler._lazy_init_scale_growth_tracker(self.device)
             scale = self.scaler._scale
-        self._flat.zero_()
+        # one launch for every second-stage reduction of the step (weights, biases, log-sigma, statistics), which WRITES the whole flat
+        # gradient: no clear in front of the step (a minibatch step loses the fill and two of its three reduction launches)
+        one_reduce = manual and wg is not None and self._policy_bwd is not None and self.cfg.get("fused_grad_reduce", True)
+        if not one_reduce:
+            self._flat.zero_()
         F.loss(mu32.detach(), net.sigma.detach(), v32.detach(), mb, self.e_clip, self.critic_coef, self.entropy_coef, self.bounds_loss_coef,
                self.clip_value, scale, fx["gmu"], fx["gval"], net.sigma.grad, self._flat_stats, zero_glog=False, zero_stats=False,
-               update_mu_sigma=self.update_mu_sigma, scratch=fx["loss_scratch"])
+               update_mu_sigma=self.update_mu_sigma, scratch=fx["loss_scratch"], defer_reduce=one_reduce)
         if manual:
-            self._manual_backward(tf, fx["gmu"], fx["gval"])
+            self._manual_backward(tf, fx["gmu"], fx["gval"], wg, one_reduce)
         else:
             torch.autograd.backward([mu32, v32], [fx["gmu"], fx["gval"]])
+
+    def _wgrad_plan(self, tf):
+        """The split-K MFMA weight-gradient plan for the training buffers `tf` (None: switched off or shapes not taken).  Made (and
+        uploaded, synchronously) in the first eager epoch, never inside a graph capture."""
+        if self._policy_bwd is None or not self.cfg.get("fused_wgrad", True):
+            return None
+        F, net = self._F, self.model.a2c_network
+        lin = net._lin
+        nh = len(lin) - 2
+        h_last = tf["act"][nh - 1]
+        dys = [tf["gz"][L] for L in range(nh)] + [tf["gmu16"], tf["gv16"]]
+        xs = [tf["x0"]] + [tf["act"][L] for L in range(nh - 1)] + [h_last, h_last]
+        grads = [lin[L].weight.grad for L in range(nh + 2)]
+        wg = getattr(self, "_wgrad_mfma", None)
+        if wg is None or not wg.matches(dys, xs, grads):
+            assert not torch.cuda.is_current_stream_capturing(), "the weight-gradient plan must exist before the update is captured"
+            wg = self._wgrad_mfma = F.WgradMfma(dys, xs, grads)
+        return wg if wg.ok else None
 
     def _train_fwd_ok(self, obs):
         net = self.model.a2c_network
@@ -806,7 +837,7 @@ class A2CAgent:
             self._tf = tf
         return tf
 
-    def _manual_backward(self, tf, gmu, gval):
+    def _manual_backward(self, tf, gmu, gval, wg=None, one_reduce=False):
         """d(loss)/d(parameters) from the loss kernel's d/d(mu), d/d(value): per layer one input-gradient GEMM, the split-K weight
         gradient reduced straight into the fp32 master .grad views, and the fused ELU-derivative / bias-gradient pass -- the same
         launches _HalfLinearFn / _HalfLinearEluFn issue under autograd (tests hold the two against each other)."""
@@ -825,21 +856,19 @@ class A2CAgent:
             # the transposed weight copies (refreshed by one scatter of the fp16 working copy); the weight gradients follow as GEMMs
             if self._packed is None:
                 self._policy_bwd.refresh()
-            self._policy_bwd(gmu, gval, tf["act"], tf["gz"], tf["gmu16"], tf["gv16"], [lin[L].bias.grad for L in range(nh)],
-                             lin[nh].bias.grad, lin[nh + 1].bias.grad)
-            if self.cfg.get("fused_wgrad", True):
-                # all five weight gradients: one split-K MFMA launch over the output blocks of every layer + one fixed-order reduction
-                # straight into the fp32 master gradient (csrc/bez_wgrad.hip) instead of a batched GEMM and a sum per layer.  The plan
-                # is made (and uploaded, synchronously) in the first eager epoch, never inside a graph capture.
-                dys = [tf["gz"][L] for L in range(nh)] + [tf["gmu16"], tf["gv16"]]
-                xs = [tf["x0"]] + [tf["act"][L] for L in range(nh - 1)] + [h_last, h_last]
-                grads = [lin[L].weight.grad for L in range(nh + 2)]
-                wg = getattr(self, "_wgrad_mfma", None)
-                if wg is None or not wg.matches(dys, xs, grads):
-                    assert not torch.cuda.is_current_stream_capturing(), "the weight-gradient plan must exist before the update is captured"
-                    wg = self._wgrad_mfma = F.WgradMfma(dys, xs, grads)
-                if wg(accumulate=True):
-                    return
+            bias_grads = [lin[L].bias.grad for L in range(nh)]
+            self._policy_bwd(gmu, gval, tf["act"], tf["gz"], tf["gmu16"], tf["gv16"], bias_grads, lin[nh].bias.grad, lin[nh + 1].bias.grad,
+                             defer_reduce=one_reduce)
+            # all five weight gradients: one split-K MFMA launch over the output blocks of every layer (csrc/bez_wgrad.hip) instead of a
+            # batched GEMM and a sum per layer ...
+            if one_reduce:
+                # ... and ONE fixed-order reduction launch for its partial images, the bias column sums and the loss kernel's sums
+                wg(reduce=False)
+                F.grad_reduce_all(wg, self._policy_bwd, bias_grads, lin[nh].bias.grad, lin[nh + 1].bias.grad, gmu.shape[0], self._fx["loss_scratch"],
+                                  net.sigma.grad, self._flat_stats, accumulate=False)
+                return
+            if wg is not None and wg(accumulate=True):
+                return
             wgrad(tf["gmu16"], h_last, lin[nh])
             wgrad(tf["gv16"], h_last, lin[nh + 1])
             for L in range(nh - 1, -1, -1):
@@ -861,7 +890,8 @@ class A2CAgent:
                 torch.mm(gz, p16[2 * L], out=g)
             wgrad(gz, x, lin[L])
 
-    def _phase_c(self, kl_out, loss_out):
+    def _phase_c(self, kl_out, loss_out, next_i=None):
+        """next_i: row of the epoch's observation moments the NEXT minibatch step absorbs (None: that step applies them itself)"""
         if _dist_on():
             self._flat.div_(dist.get_world_size())  # mean of the (still scaled) gradients and of the KL
         if self._fused_opt:
@@ -877,7 +907,11 @@ class A2CAgent:
             self._F.adam_step(self._pflat, self._flat[:self._nparam], self._mflat, self._vflat, self._steps, self.lr_t, g0["betas"], g0["eps"],
                               g0["weight_decay"], self.grad_norm if self.truncate_grads else 0.0, self.scaler._scale if amp else None,
                               self.scaler._growth_tracker if amp else None, self.scaler.get_growth_factor(), self.scaler.get_backoff_factor(),
-                              self.scaler.get_growth_interval(), self._opt_work, self._hflat, tail=tail, adapt=adapt)
+                              self.scaler.get_growth_interval(), self._opt_work, self._hflat, tail=tail, adapt=adapt,
+                              packed=self._packed if (self._packed is not None and self._hflat is not None and not self._packed_stale) else None,
+                              next_rms=(self._f_obs_rms, self._obs_mom[next_i]) if (next_i is not None and self.normalize_input) else None)
+            if next_i is not None and self.normalize_input:
+                self._rms_preapplied = True
             return
         else:
             if self.truncate_grads:
@@ -892,7 +926,7 @@ class A2CAgent:
             if self.is_adaptive_lr and self.schedule_type == "legacy":
                 self.scheduler.update_(self.lr_t, self._flat_kl, scale=float(self.minibatch_size))
 
-    def _calc_gradients_fused(self, mb, kl_out, loss_out):
+    def _calc_gradients_fused(self, mb, kl_out, loss_out, next_i=None):
         """calc_gradients with the HIP glue kernels: running update of the input normaliser from the epoch's precomputed moments, MLP
         forward (torch), the whole loss and its gradient w.r.t. mu / value / log-std (1 launch), MLP backward (torch, into the
         static flat gradient), then the all-reduce / unscale / clip / Adam / scaler tail."""
@@ -901,12 +935,13 @@ class A2CAgent:
             # ONE all-reduce of the flat STILL-SCALED gradient + KL (124 238 fp32 = 497 KB, latency-bound on xGMI): an fp16
             # overflow on any rank reaches every rank, so unscale_ records the same found_inf everywhere (as DDP does)
             dist.all_reduce(self._flat)
-        self._phase_c(kl_out, loss_out)
+        self._phase_c(kl_out, loss_out, next_i)
 
-    def calc_gradients(self, mb, kl_out, loss_out):
-        """One optimiser step on minibatch `mb`; device ops only.  KL is written to kl_out (0-dim view), losses added to loss_out."""
+    def calc_gradients(self, mb, kl_out, loss_out, next_i=None):
+        """One optimiser step on minibatch `mb`; device ops only.  KL is written to kl_out (0-dim view), losses added to loss_out.
+        next_i: index of the minibatch the following step will train on (None: this is the update's last step)."""
         if self.fused:
-            return self._calc_gradients_fused(mb, kl_out, loss_out)
+            return self._calc_gradients_fused(mb, kl_out, loss_out, next_i)
         self.model.train()
         if self.normalize_input:
             # rl_games runs the input normaliser in train mode here (every minibatch forward updates it); what it absorbs are this
@@ -963,9 +998,12 @@ class A2CAgent:
     def _update_impl(self):
         """mini_epochs x num_minibatches optimiser steps + the adaptive LR rule, all on the device."""
         self.kl_acc.zero_(); self.loss_acc.zero_()
+        self._rms_preapplied = False
+        last = self.mini_epochs * self.num_minibatches - 1
         for ep in range(self.mini_epochs):
             for i in range(self.num_minibatches):
-                self.calc_gradients(self._minibatch(i), self.kl_acc[ep], self.loss_acc)
+                step = ep * self.num_minibatches + i
+                self.calc_gradients(self._minibatch(i), self.kl_acc[ep], self.loss_acc, None if step == last else (i + 1) % self.num_minibatches)
             if self.is_adaptive_lr and self.schedule_type != "legacy":
                 self.scheduler.update_(self.lr_t, self.kl_acc[ep])
 
@@ -973,6 +1011,7 @@ class A2CAgent:
         """Data-parallel update with HIP graphs: per minibatch a forward/backward graph, one shared optimiser graph; the step's ONE
         RCCL all-reduce (gradient + KL) runs eagerly between the two replays (no collective is ever captured).
         The first call captures the segments (capture records, it does not execute) and then replays them like every later call."""
+        self._rms_preapplied = False
         if self._seg is None:
             torch.cuda.synchronize()
             seg = dict(b=[], c=torch.cuda.CUDAGraph(), kl=torch.zeros((), device=self.device))

@@ -32,10 +32,11 @@ _SIGS = {
     "bez_ppo_wgrad_run": [_vp, _vp, _i32, _vp],
     "bez_ppo_colsum_f16": [_vp, _i64, _i32, _vp, _i32, _vp],
     "bez_ppo_elu_bwd_colsum_f16": [_vp, _vp, _vp, _i64, _i32, _vp, _i32, _vp],
-    "bez_ppo_adam_step": [_vp, _vp, _vp, _vp, _i64, _vp, _i32, _vp, _f, _f, _f, _f, _f, _vp, _vp, _f, _f, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _f, _f, _f, _vp],
+    "bez_ppo_adam_step": [_vp, _vp, _vp, _vp, _i64, _vp, _i32, _vp, _f, _f, _f, _f, _f, _vp, _vp, _f, _f, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _f, _f, _f, _vp, _vp],
+    "bez_ppo_grad_reduce_all": [_vp, _vp, _vp, _i64, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i32, _vp],
 }
 _lib = None
-PPO_ABI_VERSION = 3   # BEZ_PPO_ABI_VERSION (include/bez_sim.h)
+PPO_ABI_VERSION = 4   # BEZ_PPO_ABI_VERSION (include/bez_sim.h)
 
 
 def lib():
@@ -120,15 +121,17 @@ def rollout_post(rew, dones, timeouts, values, reward_scale, gamma, bootstrap, s
 
 
 def loss(mu, logstd, value, mb, e_clip, critic_coef, entropy_coef, bounds_coef, clip_value, scale, gmu, gval, glog, stats, zero_glog=True,
-         zero_stats=True, update_mu_sigma=False, scratch=None):
+         zero_stats=True, update_mu_sigma=False, scratch=None, defer_reduce=False):
     """stats[5] <- sums of a_loss, c_loss, b_loss, kl, entropy (zero_stats False: the caller cleared them); gmu / gval <- gradient of the
     mean loss (x loss scale); glog is ACCUMULATED into (zero_glog: cleared first); update_mu_sigma: mb["mu"] / mb["sigma"] are
     overwritten with the current mu / exp(logstd) once the KL against the old ones is taken; scratch (loss_scratch(b, a), zeroed once):
-    the sums are added in a fixed order instead of with float atomics (bit-reproducible)."""
+    the sums are added in a fixed order instead of with float atomics (bit-reproducible).  defer_reduce: only the per-workgroup partials
+    are written (into scratch); grad_reduce_all() then WRITES glog / stats together with the step's other gradient reductions."""
     b, a = mu.shape
+    assert scratch is not None or not defer_reduce
     _chk(lib().bez_ppo_loss(_p(mu), _p(logstd), _p(value), _p(mb["actions"]), _p(mb["old_logp"]), _p(mb["advantages"]), _p(mb["old_values"]),
                             _p(mb["returns"]), _p(mb["mu"]), _p(mb["sigma"]), b, a, float(e_clip), float(critic_coef), float(entropy_coef),
-                            float(bounds_coef), (1 if clip_value else 0) | (0 if zero_glog else 2) | (0 if zero_stats else 4) | (8 if update_mu_sigma else 0), None if scale is None else _p(scale), _p(gmu),
+                            float(bounds_coef), (1 if clip_value else 0) | (0 if zero_glog else 2) | (0 if zero_stats else 4) | (8 if update_mu_sigma else 0) | (16 if defer_reduce else 0), None if scale is None else _p(scale), _p(gmu),
                             _p(gval), _p(glog), _p(stats), None if scratch is None else _p(scratch), _stream(mu)), "bez_ppo_loss")
 
 
@@ -141,12 +144,26 @@ ADAM_WORK_FLOATS = 258   # BEZ_PPO_ADAM_WORK_FLOATS
 
 
 def adam_step(params, grads, exp_avg, exp_avg_sq, steps, lr, betas, eps, weight_decay, max_norm, scale, growth_tracker, growth_factor,
-              backoff_factor, growth_interval, work, params_f16=None, tail=(), adapt=None):
-    """unscale + clip + Adam + scaler update on the flat buffers (csrc/bez_ppo.hip adam_*_kernel); scale / growth_tracker None = no AMP;
-    params_f16 (flat fp16, same layout) receives the updated parameters in the same pass.  `work` (2 floats) must be zero on entry and is
-    zero again afterwards.  tail: up to 4 (dst, src, scale) with one-element fp32 tensors: dst += src * scale in the last launch.
-    adapt = (kl, threshold, min_lr, max_lr): the AdaptiveScheduler rule moves `lr` on that one-element KL after the step."""
+              backoff_factor, growth_interval, work, params_f16=None, tail=(), adapt=None, packed=None, next_rms=None):
+    """unscale + clip + Adam + scaler update on the flat buffers in ONE launch (csrc/bez_ppo.hip adam_fused_kernel); scale / growth_tracker
+    None = no AMP; params_f16 (flat fp16, same layout) receives the updated parameters in the same pass.  `work` must be zero on entry and
+    is zero again afterwards.  tail: up to 4 (dst, src, scale) with one-element fp32 tensors: dst += src * scale.
+    adapt = (kl, threshold, min_lr, max_lr): the AdaptiveScheduler rule moves `lr` on that one-element KL after the step.
+    packed (PackedWeights): its fragment-major copies are written in the same pass (instead of a refresh() launch before the next forward);
+    next_rms = (FusedRunningMeanStd, moments): the input normaliser absorbs the NEXT minibatch's moments here (instead of an apply() launch)."""
     n = params.numel()
+    extra = None
+    if packed is not None or next_rms is not None:
+        extra = AdamExtra()
+        if packed is not None:
+            assert params_f16 is not None and packed.hflat.data_ptr() == params_f16.data_ptr()
+            extra.map_a_dev, extra.map_b_dev, extra.packed_f16_dev = packed.map_a.data_ptr(), packed.map_b.data_ptr(), packed.flat.data_ptr()
+        if next_rms is not None:
+            f, mom = next_rms
+            r = f.rms
+            assert mom.dtype == torch.float64 and mom.numel() == 2 * f.d + 1 and mom.is_contiguous()
+            extra.rms_moments_dev, extra.rms_cols = mom.data_ptr(), f.d
+            extra.rms_mean_dev, extra.rms_var_dev, extra.rms_count_dev = r.running_mean.data_ptr(), r.running_var.data_ptr(), r.count.data_ptr()
     assert work.numel() >= ADAM_WORK_FLOATS, "work: BEZ_PPO_ADAM_WORK_FLOATS zero-initialised floats"
     nt = len(tail)
     assert nt <= 4 and all(d.numel() == 1 and x.numel() == 1 for d, x, _ in tail)
@@ -158,8 +175,25 @@ def adam_step(params, grads, exp_avg, exp_avg_sq, steps, lr, betas, eps, weight_
                                  None if growth_tracker is None else _p(growth_tracker, torch.int32), float(growth_factor), float(backoff_factor),
                                  int(growth_interval), _p(work), None if params_f16 is None else _p(params_f16, torch.float16), nt, td, ts, tsc,
                                  None if adapt is None else _p(adapt[0]), float(adapt[1]) if adapt else 0.0, float(adapt[2]) if adapt else 0.0,
-                                 float(adapt[3]) if adapt else 0.0, _stream(params)),
+                                 float(adapt[3]) if adapt else 0.0, None if extra is None else C.byref(extra), _stream(params)),
          "bez_ppo_adam_step")
+
+
+class AdamExtra(C.Structure):
+    """BezPpoAdamExtra (include/bez_sim.h)"""
+    _fields_ = [("map_a_dev", C.c_void_p), ("map_b_dev", C.c_void_p), ("packed_f16_dev", C.c_void_p), ("rms_moments_dev", C.c_void_p),
+                ("rms_cols", C.c_int32), ("rms_mean_dev", C.c_void_p), ("rms_var_dev", C.c_void_p), ("rms_count_dev", C.c_void_p)]
+
+
+def grad_reduce_all(wgrad, bwd, bias_grads, mu_bias_grad, value_bias_grad, rows, loss_scratch_buf, glog, stats, accumulate=False):
+    """The step's three second-stage reductions in one launch: the split-K images of `wgrad` (WgradMfma called with reduce=False), the bias
+    column sums of `bwd` (PolicyBackward called with defer_reduce=True) and the loss kernel's per-workgroup sums (loss(defer_reduce=True)).
+    accumulate False: every weight / bias / log-sigma gradient and the five statistics are WRITTEN (no clear needed in front of the step)."""
+    nh = bwd.nh
+    t_b = (C.c_void_p * nh)(*[b.data_ptr() for b in bias_grads])
+    _chk(lib().bez_ppo_grad_reduce_all(wgrad.plan_host, C.c_void_p(wgrad.plan_dev.data_ptr()), _p(bwd._partial), rows, nh, C.cast(bwd.c_widths, C.c_void_p),
+                                       bwd.A, C.cast(t_b, C.c_void_p), _p(mu_bias_grad), _p(value_bias_grad), _p(loss_scratch_buf), rows, _p(glog), _p(stats),
+                                       1 if accumulate else 0, _stream(glog)), "bez_ppo_grad_reduce_all")
 
 
 def wgrad_sum(partials, out, accumulate=False):
@@ -205,10 +239,12 @@ class WgradMfma:
         return len(new) == len(old) and all(a.data_ptr() == b.data_ptr() and a.shape == b.shape and a.stride() == b.stride() and a.dtype == b.dtype
                                             for a, b in zip(new, old))
 
-    def __call__(self, accumulate=True):
+    def __call__(self, accumulate=True, reduce=True):
+        """reduce False: the split-K partial images only; grad_reduce_all() adds them (with the step's other reductions)"""
         if not self.ok:
             return False
-        _chk(lib().bez_ppo_wgrad_run(self.plan_host, C.c_void_p(self.plan_dev.data_ptr()), 1 if accumulate else 0, _stream(self.partial)), "bez_ppo_wgrad_run")
+        _chk(lib().bez_ppo_wgrad_run(self.plan_host, C.c_void_p(self.plan_dev.data_ptr()), (1 if accumulate else 0) if reduce else 2, _stream(self.partial)),
+             "bez_ppo_wgrad_run")
         return True
 
 
@@ -275,7 +311,8 @@ class PolicyBackward:
         _chk(lib().bez_ppo_scatter_f16(_p(self.hflat, torch.float16), C.c_void_p(self.map.data_ptr()), self.hflat.numel(), _p(self.flat_t, torch.float16),
                                        _stream(self.hflat)), "bez_ppo_scatter_f16")
 
-    def __call__(self, gmu, gval, acts, gz, gmu16, gv16, bias_grads, mu_bias_grad, value_bias_grad):
+    def __call__(self, gmu, gval, acts, gz, gmu16, gv16, bias_grads, mu_bias_grad, value_bias_grad, defer_reduce=False):
+        """defer_reduce: the per-workgroup column sums only (self._partial); grad_reduce_all() writes the bias gradients"""
         n = gmu.shape[0]
         assert gmu.shape == (n, self.A) and gval.numel() == n and len(acts) == len(gz) == len(bias_grads) == self.nh
         for a, z, b, w in zip(acts, gz, bias_grads, self.widths):
@@ -289,7 +326,7 @@ class PolicyBackward:
             self._partial = torch.empty(need, device=gmu.device, dtype=torch.float32)
         _chk(lib().bez_ppo_policy_backward(_p(gmu), _p(gval), n, self.nh, C.cast(self.c_widths, C.c_void_p), self.A, C.cast(t_act, C.c_void_p),
                                            C.cast(self.c_wt, C.c_void_p), C.c_void_p(self.wht.data_ptr()), C.cast(t_gz, C.c_void_p), _p(gmu16, torch.float16),
-                                           _p(gv16, torch.float16), C.cast(t_b, C.c_void_p), _p(mu_bias_grad), _p(value_bias_grad), _p(self._partial), self.flag,
+                                           _p(gv16, torch.float16), C.cast(t_b, C.c_void_p), _p(mu_bias_grad), _p(value_bias_grad), _p(self._partial), self.flag | (2 if defer_reduce else 0),
                                            _stream(gmu)),
              "bez_ppo_policy_backward")
 

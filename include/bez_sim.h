@@ -282,7 +282,7 @@ int bez_sim_time_steps(BezSim* sim, const float* actions_dev, int32_t n_steps, v
 
 /* The signatures below change between rounds (round 3: scratch buffers of the fixed-order reductions, plan / run split of the weight
  * gradients, the optimiser tail's bookkeeping): a binding checks this number once after dlopen. */
-#define BEZ_PPO_ABI_VERSION 3
+#define BEZ_PPO_ABI_VERSION 4
 int32_t bez_ppo_abi_version(void);
 
 /* RunningMeanStd (normalize_input / normalize_value, bez_kickPPO.yaml:51-52): moments[0:D] = column sums, [D:2D] = sums of
@@ -370,6 +370,16 @@ int bez_ppo_colsum_f16(const void* y_f16_dev, int64_t rows, int32_t cols, float*
 int bez_ppo_wgrad_plan(const void* const* dy_f16_dev, const void* const* x_f16_dev, const int32_t* out_features, const int32_t* in_features,
                        float* const* dw_dev, int32_t nlayers, int64_t rows, int32_t nsplit, float* partial_dev, void* plan_host);
 int bez_ppo_wgrad_run(const void* plan_host, const void* plan_dev, int32_t accumulate, void* stream);
+/* Every second-stage reduction of a minibatch step's gradient in ONE launch (ABI 4): the split-K images of bez_ppo_wgrad_run called
+ * with accumulate = 2 ("partial images only"), the per-workgroup bias column sums of bez_ppo_policy_backward called with bit 1 of
+ * weights_packed set ("column sums only"; same partial_dev, rows, widths and gradient pointers as there) and the per-workgroup sums of
+ * bez_ppo_loss called with bit 4 of clip_value set ("partials only"; same scratch_dev, batch = loss_rows, grad_logstd_dev, stats_dev).
+ * Fixed-order sums, one writer per output element: with accumulate = 0 the launch WRITES all weight / bias / log-sigma gradients and
+ * the five statistics, so nothing has to be cleared in front of a step. */
+int bez_ppo_grad_reduce_all(const void* plan_host, const void* plan_dev, const float* bias_partial_dev, int64_t rows, int32_t num_hidden,
+                            const int32_t* hidden_width, int32_t num_actions, float* const* bias_grad_dev, float* mu_bias_grad_dev,
+                            float* value_bias_grad_dev, const float* loss_scratch_dev, int64_t loss_rows, float* grad_logstd_dev, float* stats_dev,
+                            int32_t accumulate, void* stream);
 /* ELU (alpha 1) backward fused with the bias gradient: gz = gy * elu'(y) from the layer's ELU OUTPUT y, all (rows, cols) fp16;
  * the column sums of gz go to bias_grad_dev (fp32, cols). */
 int bez_ppo_elu_bwd_colsum_f16(const void* gy_f16_dev, const void* y_f16_dev, void* gz_f16_dev, int64_t rows, int32_t cols, float* bias_grad_dev,
@@ -419,21 +429,31 @@ int bez_ppo_head_grads_f16(const float* grad_mu_dev, const float* grad_value_dev
  * clip_grad_norm_ + scaler.step(Adam) + scaler.update, a2c_common.py [ext] via train.py:89-113): the gradient is divided by
  * *scale_dev (NULL = no loss scaling), clipped to max_norm (<= 0: no clipping), applied with torch's Adam formula; a non-finite
  * gradient skips the step and backs the scale off, growth_interval clean steps grow it.  steps_dev[nsteps] are the per-tensor
- * step counters of the optimiser state (all equal).  work_dev[BEZ_PPO_ADAM_WORK_FLOATS]: [1] non-finite count, [2..] per-block
- * partial sums of the squared gradient norm, added in FIXED order (no float atomics: the clip coefficient, and with it every
- * weight, is bit-identical run to run and rank to rank) -- ZERO on entry (allocate it zeroed), [0..1] zero again on return (the
- * last kernel clears them: no memset per step).
+ * step counters of the optimiser state (all equal).  ONE launch (ABI 4; three before): every workgroup forms the squared norm of
+ * the whole gradient itself, in the same fixed order (no float atomics: the clip coefficient, and with it every weight, is
+ * bit-identical run to run and rank to rank), updates its slice, and the workgroup that draws the last ticket commits the step
+ * counters / loss scale / learning rate after every other workgroup has read the old ones.  work_dev[BEZ_PPO_ADAM_WORK_FLOATS]:
+ * [0] is that ticket counter -- ZERO on entry (allocate it zeroed), zero again on return (no memset per step).  grads_dev must be
+ * 16-byte aligned.
  * params_f16_dev (NULL or n fp16): receives the updated parameters as fp16 in the same pass (the AMP working copy).
  * ntail (0..4) bookkeeping sums ride in the last launch: *tail_dst_dev[i] += *tail_src_dev[i] * tail_scale[i] (host arrays of
  * device pointers / host floats) -- the epoch's KL and loss accumulators of a2c_common.py's train_epoch [ext].
  * adapt_kl_dev (NULL = off): after the step, *lr_dev moves by rl_games' AdaptiveScheduler rule on *adapt_kl_dev (lr /= 1.5 above
- * 2 x adapt_kl_threshold, floor min_lr; lr *= 1.5 below half of it, cap max_lr) -- the 'legacy' schedule, once per minibatch step. */
+ * 2 x adapt_kl_threshold, floor min_lr; lr *= 1.5 below half of it, cap max_lr) -- the 'legacy' schedule, once per minibatch step.
+ * extra (NULL = none): work of neighbouring launches folded into this one -- (a) the fragment-major fp16 weight copies the MFMA
+ * policy kernels read: packed_f16_dev[map_a_dev[i]] = packed_f16_dev[map_b_dev[i]] = fp16(param i) (negative map entry: no copy), what
+ * bez_ppo_scatter2_f16 does from params_f16_dev; (b) the input normaliser's update for the NEXT minibatch, what bez_ppo_rms_apply
+ * does from rms_moments_dev (rms_cols <= 1024). */
+typedef struct BezPpoAdamExtra {
+  const int32_t* map_a_dev; const int32_t* map_b_dev; void* packed_f16_dev;
+  const double* rms_moments_dev; int32_t rms_cols; double* rms_mean_dev; double* rms_var_dev; double* rms_count_dev;
+} BezPpoAdamExtra;
 #define BEZ_PPO_ADAM_WORK_FLOATS 258
 int bez_ppo_adam_step(float* params_dev, const float* grads_dev, float* exp_avg_dev, float* exp_avg_sq_dev, int64_t n, float* steps_dev,
                       int32_t nsteps, float* lr_dev, float beta1, float beta2, float eps, float weight_decay, float max_norm, float* scale_dev,
                       int32_t* growth_tracker_dev, float growth_factor, float backoff_factor, int32_t growth_interval, float* work_dev,
                       void* params_f16_dev, int32_t ntail, float* const* tail_dst_dev, const float* const* tail_src_dev, const float* tail_scale,
-                      const float* adapt_kl_dev, float adapt_kl_threshold, float min_lr, float max_lr, void* stream);
+                      const float* adapt_kl_dev, float adapt_kl_threshold, float min_lr, float max_lr, const BezPpoAdamExtra* extra, void* stream);
 
 #ifdef __cplusplus
 }

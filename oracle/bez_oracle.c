@@ -269,6 +269,7 @@ typedef struct {
   uint32_t episode;
   /* DR */
   real friction, kp_scale[ND], kd_scale[ND], mass_scale[NL], gravity[3], lim_lo[ND], lim_hi[ND];
+  real ftrans[ND]; /* BEZ_FLAG_TGS_SOLVER: size of the spatial force each joint transmitted in the previous substep */
 } Env;
 
 typedef struct {
@@ -1012,7 +1013,10 @@ static void substep_hard(const BezSimConfig* c, Env* e, real h, int first, real 
   for (int b = 0; b < NBMAX; ++b) for (int i = 0; i < 3; ++i) e->contact_force[b][i] = first ? d.contact_force[b][i] * wgt : e->contact_force[b][i] + d.contact_force[b][i] * wgt;
 }
 
+#include "bez_oracle_tgs.inc"
+
 static void substep(const BezSimConfig* c, Env* e, real h, int first, real wgt) {
+  if (c->flags & BEZ_FLAG_TGS_SOLVER) { substep_tgs(c, e, h, first, wgt); return; }
   if (c->flags & BEZ_FLAG_HARD_CONTACT) { substep_hard(c, e, h, first, wgt); return; }
   Dyn d;
   dynamics(c, e, h, 0, NULL, &d);
@@ -1070,6 +1074,7 @@ static void env_reset(const BezSimConfig* c, Env* e, int64_t genv, const float* 
   for (int i = 0; i < 3; ++i) { e->root_pos[i] = c->bez_init[i]; e->ball_pos[i] = c->ball_init[i]; e->root_lin[i] = e->root_ang[i] = e->ball_lin[i] = e->ball_ang[i] = 0; }
   for (int i = 0; i < 4; ++i) { e->root_quat[i] = c->bez_init[3 + i]; e->ball_quat[i] = c->ball_init[3 + i]; }
   memset(e->contact_force, 0, sizeof(e->contact_force));
+  memset(e->ftrans, 0, sizeof(e->ftrans));
   e->progress = 0; /* kick_env.py:849-850 */
   e->reset = 0;
 }

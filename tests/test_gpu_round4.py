@@ -24,3 +24,91 @@ def test_set_flags_refuses_oracle_only_variants():
     c.tune[9] = 1.0
     with pytest.raises(BezSimError, match="oracle"):
         BezSim(c, 0)
+
+
+def _twin_agents(**over_b):
+    """Two agents with the same weights, rollout dataset and normaliser state; `over_b` = config overrides of the second one."""
+    from tests.test_gpu_round2 import _agent
+    a = _agent(512, 4096, hip_graphs=False, **over_b)
+    b = _agent(512, 4096, hip_graphs=False)
+    b.model.load_state_dict(a.model.state_dict())
+    a.obs = a.env_reset()
+    a.play_steps()
+    b._alloc_static()
+    for k in a.dataset:
+        b.dataset[k].copy_(a.dataset[k])
+    b._mom_pack.copy_(a._mom_pack)
+    for ra, rb in ((a.running_mean_std, b.running_mean_std), (a.value_mean_std, b.value_mean_std)):
+        rb.load_state_dict(ra.state_dict())
+    for ag in (a, b):
+        if getattr(ag, "_hflat", None) is not None:
+            ag.model.a2c_network.refresh_half()
+        ag._packed_stale = True
+    return a, b
+
+
+def test_one_launch_gradient_reduction_equals_the_three_launch_path():
+    """Round 4: the step's three second-stage reductions (split-K weight-gradient images, bias column sums, the loss kernel's sums)
+    are ONE launch that WRITES the whole flat gradient.  Against the three-launch path (`fused_grad_reduce: False`: clear, then three
+    accumulating reductions) on the same minibatch: weight gradients bit-equal (same partials, same order), bias / log-sigma
+    gradients and the statistics to rounding (4 row lanes instead of 16) -- and the flat buffer is poisoned with NaN first: a slot
+    the launch did not write would show."""
+    import torch
+    a, b = _twin_agents(fused_grad_reduce=False)   # a: three launches, b: one
+    out = []
+    for ag in (a, b):
+        mb = ag._minibatch(1)
+        ag._f_obs_rms.moments(mb["obs"], out=ag._obs_mom[1])
+        if ag is b:
+            ag._flat.fill_(float("nan"))
+        ag._phase_b(mb)
+        out.append(ag._flat.detach().clone())
+    torch.cuda.synchronize()
+    ga, gb = out
+    n = a._nparam
+    assert torch.isfinite(gb[:n + 5]).all()
+    off, wmask = 0, torch.zeros(n, dtype=torch.bool, device=ga.device)
+    for p in a.model.parameters():
+        if p.dim() == 2:
+            wmask[off:off + p.numel()] = True
+        off += p.numel()
+    assert torch.equal(ga[:n][wmask], gb[:n][wmask])
+    scale = float(ga[:n].abs().max())
+    np.testing.assert_allclose(gb[:n + 5].cpu().numpy(), ga[:n + 5].cpu().numpy(), rtol=2e-5, atol=2e-6 * scale)
+    # and bit-reproducible: the same step again gives the same bits (the KL / entropy sums aside: the first pass wrote the current
+    # mu / sigma back into the minibatch, PPODataset.update_mu_sigma)
+    b._rms_preapplied = True   # (the moments were applied above: do not absorb them twice)
+    b._flat.fill_(float("nan"))
+    b._phase_b(b._minibatch(1))
+    assert torch.equal(b._flat[:n + 3], gb[:n + 3])
+
+
+def test_optimiser_launch_folds_the_weight_scatter_and_the_next_normaliser_update():
+    """Round 4: bez_ppo_adam_step is one launch, and it also (a) writes the fragment-major weight copies the MFMA policy kernels read
+    (what PackedWeights.refresh() = bez_ppo_scatter2_f16 did in front of the next forward) and (b) lets the input normaliser absorb
+    the NEXT minibatch's moments (what bez_ppo_rms_apply did).  Both against the separate launches, bit for bit."""
+    import torch
+    from bez_isaacgym_amd.ppo import fused as F
+    a, b = _twin_agents()
+    for ag in (a, b):
+        assert ag._fused_opt and ag._packed is not None and ag._hflat is not None
+        for i in range(ag.num_minibatches):
+            ag._f_obs_rms.moments(ag._minibatch(i)["obs"], out=ag._obs_mom[i])
+        ag._packed.refresh(); ag._packed_stale = False
+        ag._rms_preapplied = False
+        ag.kl_acc.zero_(); ag.loss_acc.zero_()
+    # a: one optimiser step with the extras folded in; b: the same step without them, then the two separate launches
+    a._phase_b(a._minibatch(0)); a._phase_c(a.kl_acc[0], a.loss_acc, next_i=1)
+    assert a._rms_preapplied
+    b._phase_b(b._minibatch(0))
+    packed, b._packed_stale = b._packed, True          # stale: _phase_c leaves the copies alone
+    b._phase_c(b.kl_acc[0], b.loss_acc, next_i=None)
+    packed.refresh()
+    b._f_obs_rms.apply(b._obs_mom[1])
+    torch.cuda.synchronize()
+    assert torch.equal(a._pflat, b._pflat) and torch.equal(a._hflat, b._hflat)
+    assert torch.equal(a._packed.flat, b._packed.flat)
+    for k in ("running_mean", "running_var", "count"):
+        assert torch.equal(getattr(a.running_mean_std, k), getattr(b.running_mean_std, k)), k
+    assert float(a._opt_work[0]) == 0.0 and float(a.scaler._scale) == float(b.scaler._scale)
+    assert torch.equal(a._steps, b._steps) and float(a._steps[0]) == 1.0
