@@ -538,6 +538,7 @@ __global__ __launch_bounds__(PPO_TB) void gae_kernel(const float* __restrict__ r
 constexpr int ADAM_TB = 1024;
 struct AdamTail { float* dst[4]; const float* src[4]; float scale[4]; int n; float* lr; const float* kl; float kl_thr, min_lr, max_lr; };
 struct AdamExtra {
+  const float* normpart; int nnormpart;                                 // per-block (sum g^2, non-finite count) of the scaled gradient (NULL: phase 1 reads the gradient)
   const int32_t* map_a; const int32_t* map_b; __half* packed;          // fragment-major weight copies (NULL: none)
   const double* rms_mom; int rms_d; double* rms_mean; double* rms_var; double* rms_count;  // next normaliser update (NULL: none)
 };
@@ -557,19 +558,26 @@ __global__ __launch_bounds__(ADAM_TB) void adam_fused_kernel(float* __restrict__
   // ---- phase 1
   const float inv = 1.0f / scale_v;
   float s2 = 0.f, bad = 0.f;
-  const int64_t n4 = n >> 2;
-  const float4* g4 = reinterpret_cast<const float4*>(g);
-  for (int64_t i = tid; i < n4; i += ADAM_TB) {
-    const float4 x = g4[i];
-    const float a = x.x * inv, b = x.y * inv, c = x.z * inv, d = x.w * inv;
-    bad += (fabsf(a) <= 3.4028234e38f ? 0.f : 1.f) + (fabsf(b) <= 3.4028234e38f ? 0.f : 1.f) + (fabsf(c) <= 3.4028234e38f ? 0.f : 1.f) +
-           (fabsf(d) <= 3.4028234e38f ? 0.f : 1.f);
-    s2 = fmaf(a, a, s2); s2 = fmaf(b, b, s2); s2 = fmaf(c, c, s2); s2 = fmaf(d, d, s2);
-  }
-  if (tid < (int)(n & 3)) {  // the last n % 4 elements
-    const float a = g[(n4 << 2) + tid] * inv;
-    bad += fabsf(a) <= 3.4028234e38f ? 0.f : 1.f;
-    s2 = fmaf(a, a, s2);
+  if (ex.normpart) {   // the producer of the gradient (bez_ppo_grad_reduce_all) left per-block shares of sum g^2 (scaled) and of the non-finite count
+    for (int i = tid; i < ex.nnormpart; i += ADAM_TB) { const float2 q = reinterpret_cast<const float2*>(ex.normpart)[i]; s2 += q.x; bad += q.y; }
+    s2 *= inv * inv;
+    if (!(fabsf(s2) <= 3.4028234e38f)) bad += 1.f;   // (a share that overflowed or holds a NaN)
+  } else {
+    const int64_t n4 = n >> 2;
+    const float4* g4 = reinterpret_cast<const float4*>(g);
+#pragma unroll 8
+    for (int64_t i = tid; i < n4; i += ADAM_TB) {
+      const float4 x = g4[i];
+      const float a = x.x * inv, b = x.y * inv, c = x.z * inv, d = x.w * inv;
+      bad += (fabsf(a) <= 3.4028234e38f ? 0.f : 1.f) + (fabsf(b) <= 3.4028234e38f ? 0.f : 1.f) + (fabsf(c) <= 3.4028234e38f ? 0.f : 1.f) +
+             (fabsf(d) <= 3.4028234e38f ? 0.f : 1.f);
+      s2 = fmaf(a, a, s2); s2 = fmaf(b, b, s2); s2 = fmaf(c, c, s2); s2 = fmaf(d, d, s2);
+    }
+    if (tid < (int)(n & 3)) {  // the last n % 4 elements
+      const float a = g[(n4 << 2) + tid] * inv;
+      bad += fabsf(a) <= 3.4028234e38f ? 0.f : 1.f;
+      s2 = fmaf(a, a, s2);
+    }
   }
   s2 = wave_sum(s2); bad = wave_sum(bad);
   if ((tid & 63) == 0) { red[0][tid >> 6] = s2; red[1][tid >> 6] = bad; }
@@ -840,6 +848,8 @@ int bez_ppo_adam_step(float* params_dev, const float* grads_dev, float* exp_avg_
   if (extra) {
     if (extra->packed_f16_dev && (!extra->map_a_dev || !extra->map_b_dev || !params_f16_dev)) return -1;
     if (extra->rms_moments_dev && (!extra->rms_mean_dev || !extra->rms_var_dev || !extra->rms_count_dev || extra->rms_cols <= 0 || extra->rms_cols > ADAM_TB)) return -1;
+    if (extra->norm_parts_dev && (extra->norm_parts <= 0 || (reinterpret_cast<uintptr_t>(extra->norm_parts_dev) & 7) != 0)) return -1;
+    ex.normpart = extra->norm_parts_dev; ex.nnormpart = extra->norm_parts;
     ex.map_a = extra->map_a_dev; ex.map_b = extra->map_b_dev; ex.packed = (__half*)extra->packed_f16_dev;
     ex.rms_mom = extra->rms_moments_dev; ex.rms_d = extra->rms_cols; ex.rms_mean = extra->rms_mean_dev; ex.rms_var = extra->rms_var_dev; ex.rms_count = extra->rms_count_dev;
   }

@@ -238,28 +238,33 @@ __global__ void wgrad_reduce_kernel(const Args* __restrict__ Ap, int accumulate)
 constexpr int RA_MAXL = 8;
 struct BiasReduce { const float* partial; int prow, ptotal, nhid, num_actions, nwg; int poff[RA_MAXL]; float* bgrad[RA_MAXL]; float* bmu; float* bv; };
 struct LossReduce { const float* scratch; int A; unsigned int nblocks; float* grad_logstd; float* stats; };
-__global__ __launch_bounds__(256) void grad_reduce_all_kernel(const Args* __restrict__ Ap, int accumulate, int wx, int nwb, BiasReduce B, int nbb, LossReduce Ls) {
+__global__ __launch_bounds__(256) void grad_reduce_all_kernel(const Args* __restrict__ Ap, int accumulate, int wx, int nwb, BiasReduce B, int nbb, LossReduce Ls,
+                                                              float* __restrict__ normpart) {
   __shared__ float sh[4][64];
+  __shared__ float nrm[2][4];
   const int b = blockIdx.x, tid = threadIdx.x;
+  float mine = 0.f;      // the gradient element this thread wrote (0: none), for the block's share of the squared gradient norm
   if (b < nwb) {   // weight gradients: block (b % wx) of part (b / wx)
     const Args& A = *Ap;
     const Part& P = A.part[b / wx];
     const int i = (b % wx) * 256 + tid, n = P.gcols * P.xcols;
-    if (i >= n) return;
-    const int r = i / P.xcols, c = i - r * P.xcols;
-    float* d = P.dst + (size_t)(P.g0 + r) * P.dst_ld + P.x0 + c;
-    const float* p = A.partial + P.partial_off + i;
-    float s = accumulate ? *d : 0.f;
-    int k = 0;
-    for (; k + 8 <= P.splits; k += 8) {   // eight loads in flight, added in their fixed order
-      float v[8];
+    if (i < n) {
+      const int r = i / P.xcols, c = i - r * P.xcols;
+      float* d = P.dst + (size_t)(P.g0 + r) * P.dst_ld + P.x0 + c;
+      const float* p = A.partial + P.partial_off + i;
+      float s = accumulate ? *d : 0.f;
+      int k = 0;
+      for (; k + 8 <= P.splits; k += 8) {   // eight loads in flight, added in their fixed order
+        float v[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = p[(long long)(k + u) * n];
+        for (int u = 0; u < 8; ++u) v[u] = p[(long long)(k + u) * n];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) s += v[u];
+        for (int u = 0; u < 8; ++u) s += v[u];
+      }
+      for (; k < P.splits; ++k) s += p[(long long)k * n];
+      *d = s;
+      mine = s;
     }
-    for (; k < P.splits; ++k) s += p[(long long)k * n];
-    *d = s;
   } else if (b < nwb + nbb) {   // bias gradients: 4 row lanes x 64 columns; a row lane sums every 4th workgroup's partial
     const int l = tid & 63, rl = tid >> 6;
     const int c = (b - nwb) * 64 + l;
@@ -272,7 +277,7 @@ __global__ __launch_bounds__(256) void grad_reduce_all_kernel(const Args* __rest
     sh[rl][l] = s;
     __syncthreads();
     if (rl == 0 && c < ncol) {
-      const float t = (sh[0][l] + sh[1][l]) + (sh[2][l] + sh[3][l]);
+      float t = (sh[0][l] + sh[1][l]) + (sh[2][l] + sh[3][l]);
       float* d;
       if (c >= B.ptotal) { const int k = c - B.ptotal; d = k < B.num_actions ? &B.bmu[k] : &B.bv[0]; }
       else {
@@ -280,21 +285,38 @@ __global__ __launch_bounds__(256) void grad_reduce_all_kernel(const Args* __rest
         while (L + 1 < B.nhid && c >= B.poff[L + 1]) ++L;
         d = &B.bgrad[L][c - B.poff[L]];
       }
-      *d = accumulate ? *d + t : t;
+      if (accumulate) t += *d;
+      *d = t;
+      mine = t;
     }
   } else {   // loss sums: one wave per column; lane l adds workgroups l, l + 64, ..., then the butterfly
-    if (tid >= 64) return;
     const int c = b - nwb - nbb;
-    const float* col = Ls.scratch + 2 + (size_t)c * Ls.nblocks;
-    float acc = 0.f;
+    if (tid < 64) {
+      const float* col = Ls.scratch + 2 + (size_t)c * Ls.nblocks;
+      float acc = 0.f;
 #pragma unroll 8
-    for (unsigned int q = tid; q < Ls.nblocks; q += 64) acc += col[q];
+      for (unsigned int q = tid; q < Ls.nblocks; q += 64) acc += col[q];
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
-    if (tid == 0) {
-      float* d = c < Ls.A ? &Ls.grad_logstd[c] : &Ls.stats[c - Ls.A];
-      *d = accumulate ? *d + acc : acc;
+      for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+      if (tid == 0) {
+        float* d = c < Ls.A ? &Ls.grad_logstd[c] : &Ls.stats[c - Ls.A];
+        if (accumulate) acc += *d;
+        *d = acc;
+        if (c < Ls.A) mine = acc;   // (the statistics are not part of the gradient)
+      }
     }
+  }
+  if (!normpart) return;
+  // this block's share of sum g^2 and of the non-finite count (of the STILL-SCALED gradient), fixed order: bez_ppo_adam_step adds the
+  // blocks' shares in order instead of reading the whole gradient again
+  float s2 = mine * mine, bad = fabsf(mine) <= 3.4028234e38f ? 0.f : 1.f;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { s2 += __shfl_xor(s2, o, 64); bad += __shfl_xor(bad, o, 64); }
+  if ((tid & 63) == 0) { nrm[0][tid >> 6] = s2; nrm[1][tid >> 6] = bad; }
+  __syncthreads();
+  if (tid == 0) {
+    normpart[2 * b] = (nrm[0][0] + nrm[0][1]) + (nrm[0][2] + nrm[0][3]);
+    normpart[2 * b + 1] = (nrm[1][0] + nrm[1][1]) + (nrm[1][2] + nrm[1][3]);
   }
 }
 
@@ -408,10 +430,23 @@ int bez_ppo_wgrad_run(const void* plan_host, const void* plan_dev, int32_t accum
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
+static int reduce_all_geometry(const Args* H, int32_t num_hidden, const int32_t* hidden_width, int32_t num_actions, int* wx, int* nwb, int* nbb, int* nlb) {
+  if (!H || num_hidden <= 0 || num_hidden > RA_MAXL || !hidden_width || num_actions <= 0 || num_actions > 31) return -1;
+  int tot = 0;
+  for (int i = 0; i < num_hidden; ++i) tot += hidden_width[i];
+  *wx = (H->max_block + 255) / 256; *nwb = *wx * H->nparts; *nbb = (tot + num_actions + 1 + 63) / 64; *nlb = num_actions + 5;
+  return 0;
+}
+/* workgroups of bez_ppo_grad_reduce_all for this plan / network = pairs of floats it writes to norm_parts_dev */
+int bez_ppo_grad_reduce_blocks(const void* plan_host, int32_t num_hidden, const int32_t* hidden_width, int32_t num_actions) {
+  int wx, nwb, nbb, nlb;
+  if (reduce_all_geometry(static_cast<const Args*>(plan_host), num_hidden, hidden_width, num_actions, &wx, &nwb, &nbb, &nlb)) return -1;
+  return nwb + nbb + nlb;
+}
 int bez_ppo_grad_reduce_all(const void* plan_host, const void* plan_dev, const float* bias_partial_dev, int64_t rows, int32_t num_hidden,
                             const int32_t* hidden_width, int32_t num_actions, float* const* bias_grad_dev, float* mu_bias_grad_dev,
                             float* value_bias_grad_dev, const float* loss_scratch_dev, int64_t loss_rows, float* grad_logstd_dev, float* stats_dev,
-                            int32_t accumulate, void* stream) {
+                            int32_t accumulate, float* norm_parts_dev, void* stream) {
   if (!plan_host || !plan_dev || !bias_partial_dev || rows <= 0 || num_hidden <= 0 || num_hidden > RA_MAXL || !hidden_width || num_actions <= 0 ||
       num_actions > 31 || !bias_grad_dev || !mu_bias_grad_dev || !value_bias_grad_dev || !loss_scratch_dev || loss_rows <= 0 || !grad_logstd_dev || !stats_dev) return -1;
   const Args* H = static_cast<const Args*>(plan_host);
@@ -421,9 +456,10 @@ int bez_ppo_grad_reduce_all(const void* plan_host, const void* plan_dev, const f
   for (int i = 0; i < num_hidden; ++i) { if (!bias_grad_dev[i]) return -1; B.poff[i] = off; B.bgrad[i] = bias_grad_dev[i]; off += hidden_width[i]; }
   B.ptotal = off; B.prow = off + 32; B.bmu = mu_bias_grad_dev; B.bv = value_bias_grad_dev;
   LossReduce Ls{loss_scratch_dev, (int)num_actions, (unsigned int)((loss_rows + 63) / 64), grad_logstd_dev, stats_dev};  // ppo_loss_kernel: 64 rows per workgroup
-  const int wx = (H->max_block + 255) / 256, nwb = wx * H->nparts, nbb = (B.ptotal + num_actions + 1 + 63) / 64, nlb = num_actions + 5;
+  int wx, nwb, nbb, nlb;
+  if (reduce_all_geometry(H, num_hidden, hidden_width, num_actions, &wx, &nwb, &nbb, &nlb)) return -1;
   hipLaunchKernelGGL(grad_reduce_all_kernel, dim3(nwb + nbb + nlb), dim3(256), 0, (hipStream_t)stream, static_cast<const Args*>(plan_dev), (int)(accumulate != 0),
-                     wx, nwb, B, nbb, Ls);
+                     wx, nwb, B, nbb, Ls, accumulate ? nullptr : norm_parts_dev);
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 

@@ -864,8 +864,14 @@ class A2CAgent:
             if one_reduce:
                 # ... and ONE fixed-order reduction launch for its partial images, the bias column sums and the loss kernel's sums
                 wg(reduce=False)
+                np_ = getattr(self, "_norm_parts", None)
+                nb = F.grad_reduce_blocks(wg, self._policy_bwd)
+                if np_ is None or np_.shape[0] != nb:
+                    assert not torch.cuda.is_current_stream_capturing()
+                    np_ = self._norm_parts = torch.zeros(nb, 2, device=self.device, dtype=torch.float32)
                 F.grad_reduce_all(wg, self._policy_bwd, bias_grads, lin[nh].bias.grad, lin[nh + 1].bias.grad, gmu.shape[0], self._fx["loss_scratch"],
-                                  net.sigma.grad, self._flat_stats, accumulate=False)
+                                  net.sigma.grad, self._flat_stats, accumulate=False, norm_parts=np_)
+                self._norm_parts_fresh = True   # they describe the gradient in the flat buffer (until a collective changes it)
                 return
             if wg is not None and wg(accumulate=True):
                 return
@@ -892,8 +898,10 @@ class A2CAgent:
 
     def _phase_c(self, kl_out, loss_out, next_i=None):
         """next_i: row of the epoch's observation moments the NEXT minibatch step absorbs (None: that step applies them itself)"""
+        fresh, self._norm_parts_fresh = getattr(self, "_norm_parts_fresh", False), False
         if _dist_on():
             self._flat.div_(dist.get_world_size())  # mean of the (still scaled) gradients and of the KL
+            fresh = False                            # (the all-reduce changed the gradient: the optimiser launch forms the norm itself)
         if self._fused_opt:
             g0 = self.optimizer.param_groups[0]
             amp = self.scaler.is_enabled()
@@ -909,7 +917,8 @@ class A2CAgent:
                               self.scaler._growth_tracker if amp else None, self.scaler.get_growth_factor(), self.scaler.get_backoff_factor(),
                               self.scaler.get_growth_interval(), self._opt_work, self._hflat, tail=tail, adapt=adapt,
                               packed=self._packed if (self._packed is not None and self._hflat is not None and not self._packed_stale) else None,
-                              next_rms=(self._f_obs_rms, self._obs_mom[next_i]) if (next_i is not None and self.normalize_input) else None)
+                              next_rms=(self._f_obs_rms, self._obs_mom[next_i]) if (next_i is not None and self.normalize_input) else None,
+                              norm_parts=self._norm_parts if fresh else None)
             if next_i is not None and self.normalize_input:
                 self._rms_preapplied = True
             return

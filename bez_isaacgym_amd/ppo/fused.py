@@ -33,7 +33,8 @@ _SIGS = {
     "bez_ppo_colsum_f16": [_vp, _i64, _i32, _vp, _i32, _vp],
     "bez_ppo_elu_bwd_colsum_f16": [_vp, _vp, _vp, _i64, _i32, _vp, _i32, _vp],
     "bez_ppo_adam_step": [_vp, _vp, _vp, _vp, _i64, _vp, _i32, _vp, _f, _f, _f, _f, _f, _vp, _vp, _f, _f, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _f, _f, _f, _vp, _vp],
-    "bez_ppo_grad_reduce_all": [_vp, _vp, _vp, _i64, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i32, _vp],
+    "bez_ppo_grad_reduce_all": [_vp, _vp, _vp, _i64, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i32, _vp, _vp],
+    "bez_ppo_grad_reduce_blocks": [_vp, _i32, _vp, _i32],
 }
 _lib = None
 PPO_ABI_VERSION = 4   # BEZ_PPO_ABI_VERSION (include/bez_sim.h)
@@ -144,17 +145,21 @@ ADAM_WORK_FLOATS = 258   # BEZ_PPO_ADAM_WORK_FLOATS
 
 
 def adam_step(params, grads, exp_avg, exp_avg_sq, steps, lr, betas, eps, weight_decay, max_norm, scale, growth_tracker, growth_factor,
-              backoff_factor, growth_interval, work, params_f16=None, tail=(), adapt=None, packed=None, next_rms=None):
+              backoff_factor, growth_interval, work, params_f16=None, tail=(), adapt=None, packed=None, next_rms=None, norm_parts=None):
     """unscale + clip + Adam + scaler update on the flat buffers in ONE launch (csrc/bez_ppo.hip adam_fused_kernel); scale / growth_tracker
     None = no AMP; params_f16 (flat fp16, same layout) receives the updated parameters in the same pass.  `work` must be zero on entry and
     is zero again afterwards.  tail: up to 4 (dst, src, scale) with one-element fp32 tensors: dst += src * scale.
     adapt = (kl, threshold, min_lr, max_lr): the AdaptiveScheduler rule moves `lr` on that one-element KL after the step.
     packed (PackedWeights): its fragment-major copies are written in the same pass (instead of a refresh() launch before the next forward);
-    next_rms = (FusedRunningMeanStd, moments): the input normaliser absorbs the NEXT minibatch's moments here (instead of an apply() launch)."""
+    next_rms = (FusedRunningMeanStd, moments): the input normaliser absorbs the NEXT minibatch's moments here (instead of an apply() launch);
+    norm_parts: the (blocks, 2) tensor grad_reduce_all() filled for THIS gradient (norm and non-finite count are then not re-derived)."""
     n = params.numel()
     extra = None
-    if packed is not None or next_rms is not None:
+    if packed is not None or next_rms is not None or norm_parts is not None:
         extra = AdamExtra()
+        if norm_parts is not None:
+            assert norm_parts.dtype == torch.float32 and norm_parts.is_contiguous() and norm_parts.shape[1] == 2
+            extra.norm_parts_dev, extra.norm_parts = norm_parts.data_ptr(), norm_parts.shape[0]
         if packed is not None:
             assert params_f16 is not None and packed.hflat.data_ptr() == params_f16.data_ptr()
             extra.map_a_dev, extra.map_b_dev, extra.packed_f16_dev = packed.map_a.data_ptr(), packed.map_b.data_ptr(), packed.flat.data_ptr()
@@ -181,19 +186,28 @@ def adam_step(params, grads, exp_avg, exp_avg_sq, steps, lr, betas, eps, weight_
 
 class AdamExtra(C.Structure):
     """BezPpoAdamExtra (include/bez_sim.h)"""
-    _fields_ = [("map_a_dev", C.c_void_p), ("map_b_dev", C.c_void_p), ("packed_f16_dev", C.c_void_p), ("rms_moments_dev", C.c_void_p),
+    _fields_ = [("norm_parts_dev", C.c_void_p), ("norm_parts", C.c_int32), ("map_a_dev", C.c_void_p), ("map_b_dev", C.c_void_p), ("packed_f16_dev", C.c_void_p), ("rms_moments_dev", C.c_void_p),
                 ("rms_cols", C.c_int32), ("rms_mean_dev", C.c_void_p), ("rms_var_dev", C.c_void_p), ("rms_count_dev", C.c_void_p)]
 
 
-def grad_reduce_all(wgrad, bwd, bias_grads, mu_bias_grad, value_bias_grad, rows, loss_scratch_buf, glog, stats, accumulate=False):
+def grad_reduce_blocks(wgrad, bwd):
+    """rows of the (blocks, 2) fp32 tensor grad_reduce_all(..., norm_parts=) fills"""
+    nb = lib().bez_ppo_grad_reduce_blocks(wgrad.plan_host, bwd.nh, C.cast(bwd.c_widths, C.c_void_p), bwd.A)
+    assert nb > 0
+    return nb
+
+
+def grad_reduce_all(wgrad, bwd, bias_grads, mu_bias_grad, value_bias_grad, rows, loss_scratch_buf, glog, stats, accumulate=False, norm_parts=None):
     """The step's three second-stage reductions in one launch: the split-K images of `wgrad` (WgradMfma called with reduce=False), the bias
     column sums of `bwd` (PolicyBackward called with defer_reduce=True) and the loss kernel's per-workgroup sums (loss(defer_reduce=True)).
-    accumulate False: every weight / bias / log-sigma gradient and the five statistics are WRITTEN (no clear needed in front of the step)."""
+    accumulate False: every weight / bias / log-sigma gradient and the five statistics are WRITTEN (no clear needed in front of the step);
+    norm_parts (grad_reduce_blocks(...), 2) then receives each workgroup's share of sum g^2 / non-finite count for adam_step(norm_parts=)."""
+    assert norm_parts is None or (not accumulate and norm_parts.shape == (grad_reduce_blocks(wgrad, bwd), 2) and norm_parts.is_contiguous())
     nh = bwd.nh
     t_b = (C.c_void_p * nh)(*[b.data_ptr() for b in bias_grads])
     _chk(lib().bez_ppo_grad_reduce_all(wgrad.plan_host, C.c_void_p(wgrad.plan_dev.data_ptr()), _p(bwd._partial), rows, nh, C.cast(bwd.c_widths, C.c_void_p),
                                        bwd.A, C.cast(t_b, C.c_void_p), _p(mu_bias_grad), _p(value_bias_grad), _p(loss_scratch_buf), rows, _p(glog), _p(stats),
-                                       1 if accumulate else 0, _stream(glog)), "bez_ppo_grad_reduce_all")
+                                       1 if accumulate else 0, None if norm_parts is None else _p(norm_parts), _stream(glog)), "bez_ppo_grad_reduce_all")
 
 
 def wgrad_sum(partials, out, accumulate=False):

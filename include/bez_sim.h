@@ -379,7 +379,10 @@ int bez_ppo_wgrad_run(const void* plan_host, const void* plan_dev, int32_t accum
 int bez_ppo_grad_reduce_all(const void* plan_host, const void* plan_dev, const float* bias_partial_dev, int64_t rows, int32_t num_hidden,
                             const int32_t* hidden_width, int32_t num_actions, float* const* bias_grad_dev, float* mu_bias_grad_dev,
                             float* value_bias_grad_dev, const float* loss_scratch_dev, int64_t loss_rows, float* grad_logstd_dev, float* stats_dev,
-                            int32_t accumulate, void* stream);
+                            int32_t accumulate, float* norm_parts_dev, void* stream);
+/* norm_parts_dev (NULL = none; used with accumulate = 0 only): receives per workgroup (sum of squares, count of non-finite values) of the
+ * gradient elements that workgroup wrote -- bez_ppo_grad_reduce_blocks(...) pairs of floats -- for bez_ppo_adam_step (BezPpoAdamExtra). */
+int bez_ppo_grad_reduce_blocks(const void* plan_host, int32_t num_hidden, const int32_t* hidden_width, int32_t num_actions);
 /* ELU (alpha 1) backward fused with the bias gradient: gz = gy * elu'(y) from the layer's ELU OUTPUT y, all (rows, cols) fp16;
  * the column sums of gz go to bias_grad_dev (fp32, cols). */
 int bez_ppo_elu_bwd_colsum_f16(const void* gy_f16_dev, const void* y_f16_dev, void* gz_f16_dev, int64_t rows, int32_t cols, float* bias_grad_dev,
@@ -443,8 +446,10 @@ int bez_ppo_head_grads_f16(const float* grad_mu_dev, const float* grad_value_dev
  * extra (NULL = none): work of neighbouring launches folded into this one -- (a) the fragment-major fp16 weight copies the MFMA
  * policy kernels read: packed_f16_dev[map_a_dev[i]] = packed_f16_dev[map_b_dev[i]] = fp16(param i) (negative map entry: no copy), what
  * bez_ppo_scatter2_f16 does from params_f16_dev; (b) the input normaliser's update for the NEXT minibatch, what bez_ppo_rms_apply
- * does from rms_moments_dev (rms_cols <= 1024). */
+ * does from rms_moments_dev (rms_cols <= 1024); (c) the squared norm and non-finite count taken from the per-workgroup shares the
+ * gradient's producer left instead of reading the gradient once more in every workgroup. */
 typedef struct BezPpoAdamExtra {
+  const float* norm_parts_dev; int32_t norm_parts; /* (c) the norm_parts pairs bez_ppo_grad_reduce_all left (the gradient must not have changed since) */
   const int32_t* map_a_dev; const int32_t* map_b_dev; void* packed_f16_dev;
   const double* rms_moments_dev; int32_t rms_cols; double* rms_mean_dev; double* rms_var_dev; double* rms_count_dev;
 } BezPpoAdamExtra;
