@@ -788,6 +788,10 @@ __global__ __launch_bounds__(WS_BLOCK) void step_kernel_ws8(Params P) {
         if (l < nloc) dst[(size_t)k * P.n + l] = zero ? 0.f : lds[(X_CF + k) * WS_ENVS + l];
       }
     }
+    if (DR && POST && P.dr_snap && blockIdx.x == 0 && ctid == 0) {   // the next step's action-noise parameters: a copy (bez_kernels.h DrSnap)
+      const unsigned long long f = P.dr_state->frame;
+      *P.dr_snap = DrSnap{P.dr_state->noise[2], P.dr_state->noise[3], (unsigned int)f, (unsigned int)(f >> 32)};
+    }
     if (POST) {
       // the staged rows are the contiguous (nloc,nobs) image of this workgroup's slice of obs_buf: 16-byte copy-out
       const float4* rows = reinterpret_cast<const float4*>(lds + X_STAGE * WS_ENVS);

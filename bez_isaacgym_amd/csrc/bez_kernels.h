@@ -19,6 +19,7 @@
 #include "../../include/bez_sim.h"
 #include "bez_model_gen.h"
 #include "bez_spatial.h"
+#include "bez_dr_noise.h"
 
 namespace bez {
 
@@ -42,6 +43,7 @@ constexpr int LDS_SLOTS = LDS_HIT + BEZ_NPT * HIT_STRIDE;
 // device-resident state of the domain randomisation (bez_sim.hip dr_kernel): frame counter, frame of the last non-env randomisation,
 // noise parameters [obs mean, obs std, action mean, action std]
 struct DrState { unsigned long long frame, last_rand; float noise[4]; };
+// (DrSnap, the action-noise snapshot the step kernels keep: bez_dr_noise.h)
 
 struct Params {
   int n, substeps, max_len, use_prev, obs_only;
@@ -74,6 +76,7 @@ struct Params {
   const float* actions;
   const DrState* dr_state;   // != null with obs_noise: frame counter + noise parameters of the device-side domain randomisation
   int obs_noise;             // the POST part adds the observation noise itself (BEZ_FLAG_OBS_NOISE_IN_STEP)
+  DrSnap* dr_snap;           // != null: POST leaves the action-noise snapshot for the next step's consumer
   const float* dr_friction;  // (N)      or null
   const float* dr_kp;        // (N,18)   or null
   const float* dr_kd;        // (N,18)   or null
@@ -126,30 +129,7 @@ BEZ_DEV constexpr int link_box(int l) {
   return -1;
 }
 
-// ---- Philox4x32-10, the reset-noise stream (counter = global env id, episode, block)
-BEZ_DEV void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
-#pragma unroll
-  for (int r = 0; r < 10; ++r) {
-    uint32_t hi0 = __umulhi(0xD2511F53u, c[0]), lo0 = 0xD2511F53u * c[0];
-    uint32_t hi1 = __umulhi(0xCD9E8D57u, c[2]), lo1 = 0xCD9E8D57u * c[2];
-    uint32_t n0 = hi1 ^ c[1] ^ k0, n2 = hi0 ^ c[3] ^ k1;
-    c[0] = n0; c[1] = lo1; c[2] = n2; c[3] = lo0;
-    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
-  }
-}
-
-// vec_task.py:544-618 noise lambdas (gaussian, additive): element i of a flat tensor gets mean + std * z, z = word (i & 3) of the Box-Muller
-// pairs of ONE Philox block keyed by (seed, shard offset * 64 + (i >> 2), frame, which: 0 observations / 1 actions).  Shared by
-// dr_noise_kernel (bez_sim.hip) and by the step kernels' observation copy-out (BEZ_FLAG_OBS_NOISE_IN_STEP): the same bits either way.
-BEZ_DEV void dr_noise_quad(uint64_t seed, int64_t env_off, unsigned long long frame, int which, long long i4, float z[4]) {
-  const unsigned long long key = (unsigned long long)(env_off * 64 + i4);   // distinct per shard: 54 / 18 floats per env < 64 * 4
-  uint32_t c[4] = {(uint32_t)key, (uint32_t)(key >> 32), (uint32_t)frame, 0x4e4f4953u + (uint32_t)which + ((uint32_t)(frame >> 32) << 8)};
-  philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
-  float u[4];
-  for (int k = 0; k < 4; ++k) u[k] = (float)(c[k] >> 8) * (1.0f / 16777216.0f);
-  const float r0 = sqrtf(-2.0f * logf(1.0f - u[0])), r1 = sqrtf(-2.0f * logf(1.0f - u[2]));
-  z[0] = r0 * cosf(6.2831853f * u[1]); z[1] = r0 * sinf(6.2831853f * u[1]); z[2] = r1 * cosf(6.2831853f * u[3]); z[3] = r1 * sinf(6.2831853f * u[3]);
-}
+// ---- Philox4x32-10 (reset-noise stream) and the domain-randomisation noise quad: bez_dr_noise.h (included above)
 // observation element i (flat index into this shard's obs_buf) with the domain-randomisation noise of this frame
 BEZ_DEV float obs_with_noise(const Params& P, long long i, float v) {
   float z[4];
@@ -1091,6 +1071,10 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(Params P) {
     for (int i = 0; i < BEZ_NUM_OBS; ++i)
       if (i < P.nobs) P.obs[(size_t)e * P.nobs + i] = P.obs_noise ? obs_with_noise(P, (long long)e * P.nobs + i, obs[i]) : obs[i];
     P.rew[e] = rew; P.reset[e] = reset; P.progress[e] = progress;
+    if (DR && P.dr_snap && e == 0) {
+      const unsigned long long f = P.dr_state->frame;
+      *P.dr_snap = DrSnap{P.dr_state->noise[2], P.dr_state->noise[3], (unsigned int)f, (unsigned int)(f >> 32)};
+    }
   }
   if (SIM || POST) {
     store_state(st, n, e, S);

@@ -21,6 +21,7 @@
 #include <type_traits>
 
 #include "../../include/bez_sim.h"
+#include "bez_dr_noise.h"
 
 namespace {
 
@@ -44,6 +45,10 @@ struct PolicyArgs {
   // rollout step (ROLL): everything between the forward pass and the env step, fused behind it (bez_ppo_rollout_pre's work)
   const float* logstd; const float* noise; const float* dones; const double* vmean; const double* vvar; float veps;
   float* mb_obs; float* mb_dones; float* mb_mu; float* mb_val; float* act; float* act_env; float* neglogp; float* sigma;
+  // ... and, in front of it, the bookkeeping of the PREVIOUS env step (bez_ppo_rollout_post's work; post.rew == null: none)
+  BezPpoRolloutPost post;
+  // ... and, behind it, the env's action-noise lambda of the domain randomisation (vec_task.py:586-592; an.snap_dev == null: none)
+  BezPpoActionNoise an;
   // training forward (mode 2): what the backward pass needs -- the fp16 input of the first Linear and every ELU output, row-major
   _Float16* x0_out; _Float16* act_out[PF_MAXL];
   int packed;  // weights are fragment-major copies (see gemm_col_block_packed): w[L] and w_mu (= the packed [mu; value] block)
@@ -279,7 +284,15 @@ __global__ __launch_bounds__(PF_WAVES * 64) void policy_forward_kernel(PolicyArg
       const float l = a.logstd[j], sg = expf(l), z = a.noise[(row0 + rr) * A + j];
       const float x = fmaf(sg, z, m);
       const int64_t o = (row0 + rr) * A + j;
-      a.mb_mu[o] = m; a.act[o] = x; a.act_env[o] = fminf(fmaxf(x, -1.0f), 1.0f); a.sigma[o] = sg;
+      float xe = fminf(fmaxf(x, -1.0f), 1.0f);   // what rl_games hands to env.step
+      if (a.an.snap_dev) {
+        // the env would add its action noise to that tensor in a launch of its own (bez_sim_add_dr_noise, which = 1): the same bits here
+        const bez::DrSnap sn = *static_cast<const bez::DrSnap*>(a.an.snap_dev);
+        float z4[4];
+        bez::dr_noise_quad(a.an.seed, a.an.env_id_offset, (unsigned long long)sn.frame_hi << 32 | sn.frame_lo, 1, o >> 2, z4);
+        xe = xe + fmaf(z4[o & 3], sn.sd, sn.mean);
+      }
+      a.mb_mu[o] = m; a.act[o] = x; a.act_env[o] = xe; a.sigma[o] = sg;
       const float q = (x - m) / sg;  // as the reference computes it from the stored action
       zz[rr * 32 + j] = q * q;
     }
@@ -291,7 +304,31 @@ __global__ __launch_bounds__(PF_WAVES * 64) void policy_forward_kernel(PolicyArg
       float v = tile[tid * 33 + A];
       if (a.vmean) v = sqrtf((float)a.vvar[0] + a.veps) * fminf(fmaxf(v, -5.0f), 5.0f) + (float)a.vmean[0];
       a.mb_val[row0 + tid] = v;
-      a.mb_dones[row0 + tid] = a.dones[row0 + tid];
+      if (!a.post.rew) a.mb_dones[row0 + tid] = a.dones[row0 + tid];
+    }
+    if (a.post.rew && tid < 64) {
+      // the env step BEFORE this one, as ppo_rollout_post_kernel (csrc/bez_ppo.hip): shaped reward with the time-out bootstrap on the value
+      // THAT step's policy launch stored, done flags as floats (also this step's rollout row), episode return / length, statistics.
+      // The env's reward / reset / time-out buffers still hold that step's results: the next env step runs behind this launch.
+      const BezPpoRolloutPost& q = a.post;
+      const bool ok = tid < nrow;
+      const int64_t i = row0 + (ok ? tid : 0);
+      double c = 0.0, r = 0.0, l = 0.0;
+      if (ok) {
+        const float rw = q.rew[i];
+        float sh = rw * q.reward_scale;
+        if (q.bootstrap) sh += q.gamma * q.prev_values[i] * (float)q.timeouts[i];
+        q.shaped[i] = sh;
+        const float d = (float)q.reset[i];
+        q.dones_f[i] = d;
+        a.mb_dones[i] = d;
+        const float cr = q.cur_rew[i] + rw, cl = q.cur_len[i] + 1.0f;
+        c = d; r = cr * d; l = cl * d;
+        q.cur_rew[i] = cr * (1.0f - d); q.cur_len[i] = cl * (1.0f - d);
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) { c += __shfl_xor(c, o, 64); r += __shfl_xor(r, o, 64); l += __shfl_xor(l, o, 64); }
+      if (tid == 0 && c != 0.0) { atomicAdd(&q.ep_stats[0], c); atomicAdd(&q.ep_stats[1], r); atomicAdd(&q.ep_stats[2], l); }
     }
   }
   PF_STAMP(15);
@@ -489,6 +526,8 @@ static int fill_args(PolicyArgs& a, const float* obs_dev, int64_t n, int32_t num
   a.mu = nullptr; a.value = nullptr;
   a.logstd = a.noise = a.dones = nullptr; a.vmean = a.vvar = nullptr; a.veps = 0.f;
   a.mb_obs = a.mb_dones = a.mb_mu = a.mb_val = a.act = a.act_env = a.neglogp = a.sigma = nullptr;
+  a.post = BezPpoRolloutPost{};
+  a.an = BezPpoActionNoise{};
   a.x0_out = nullptr;
   for (int i = 0; i < PF_MAXL; ++i) a.act_out[i] = nullptr;
   a.packed = 0;
@@ -517,8 +556,10 @@ extern "C" int bez_ppo_policy_rollout_step(const float* obs_dev, int64_t n, int3
                                            const void* value_w_f16_dev, const void* value_b_f16_dev, const float* logstd_dev, const float* noise_dev,
                                            const float* dones_dev, const double* value_mean_dev, const double* value_var_dev, float value_eps, float* mb_obs_dev,
                                            float* mb_dones_dev, float* mb_mu_dev, float* mb_val_dev, float* actions_dev, float* env_actions_dev,
-                                           float* neglogp_dev, float* sigma_dev, int32_t weights_packed, void* stream) {
+                                           float* neglogp_dev, float* sigma_dev, int32_t weights_packed, const BezPpoRolloutPost* prev_post, const BezPpoActionNoise* action_noise, void* stream) {
   PolicyArgs a;
+  if (prev_post && (!prev_post->rew || !prev_post->reset || !prev_post->timeouts || !prev_post->prev_values || !prev_post->shaped || !prev_post->dones_f ||
+                    !prev_post->cur_rew || !prev_post->cur_len || !prev_post->ep_stats)) return -1;
   if (!logstd_dev || !noise_dev || !dones_dev || !mb_obs_dev || !mb_dones_dev || !mb_mu_dev || !mb_val_dev || !actions_dev || !env_actions_dev || !neglogp_dev ||
       !sigma_dev || (value_mean_dev && !value_var_dev) ||
       fill_args(a, obs_dev, n, num_obs, obs_mean_dev, obs_var_dev, obs_eps, num_hidden, hidden_w_f16_dev, hidden_b_f16_dev, hidden_width, mu_w_f16_dev,
@@ -526,6 +567,8 @@ extern "C" int bez_ppo_policy_rollout_step(const float* obs_dev, int64_t n, int3
   a.logstd = logstd_dev; a.noise = noise_dev; a.dones = dones_dev; a.vmean = value_mean_dev; a.vvar = value_var_dev; a.veps = value_eps;
   a.mb_obs = mb_obs_dev; a.mb_dones = mb_dones_dev; a.mb_mu = mb_mu_dev; a.mb_val = mb_val_dev; a.act = actions_dev; a.act_env = env_actions_dev;
   a.neglogp = neglogp_dev; a.sigma = sigma_dev; a.packed = weights_packed;
+  if (prev_post) a.post = *prev_post;
+  if (action_noise && action_noise->snap_dev) a.an = *action_noise;
   if (weights_packed) hipLaunchKernelGGL((policy_forward_kernel<1, PF_LD, PF_LD, true>), dim3((unsigned)((n + PF_ROWS - 1) / PF_ROWS)), dim3(PF_WAVES * 64), 0, (hipStream_t)stream, a);
   else hipLaunchKernelGGL((policy_forward_kernel<1, PF_LD, PF_LD, false>), dim3((unsigned)((n + PF_ROWS - 1) / PF_ROWS)), dim3(PF_WAVES * 64), 0, (hipStream_t)stream, a);
   return hipGetLastError() == hipSuccess ? 0 : -2;

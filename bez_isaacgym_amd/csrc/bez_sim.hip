@@ -62,6 +62,8 @@ struct BezSim {
   BezDrConfig drc = {};
   int64_t* randomize = nullptr;   // (N) randomize_buf, vec_task.py:247
   DrState* dr_state = nullptr;  // device: frame counter, frame of the last non-env randomisation, noise parameters
+  DrSnap* dr_snap = nullptr;    // device: the action-noise parameters / frame the NEXT step's action noise uses (written by the step kernels)
+  bool dr_prelaunched = false;  // bez_sim_dr_prelaunch ran the randomisation kernel of the coming step already
   float* goal_draw_dev = nullptr;            // [2] the goal of the current post-physics reset (bez_walk / bez_orient)
   unsigned long long* post_calls_dev = nullptr;  // device-resident call counter keying that draw (HIP-graph replay safe)
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -126,6 +128,7 @@ struct DrArgs {
   const uint32_t* episode;
   int64_t* randomize;
   DrState* st;
+  DrSnap* snap;
   float *friction, *kp, *kd, *lower, *upper, *gravity_rows;
 };
 __device__ inline float dr_uniform(uint64_t seed, int64_t key, uint32_t key2, uint32_t tag, int k) {
@@ -197,15 +200,20 @@ __global__ void __launch_bounds__(DR_THREADS) dr_kernel(DrArgs A) {
       A.st->last_rand = frame;
     }
     A.st->frame = frame;
+    // the first randomisation (bez_sim_set_randomization) also seeds the action-noise snapshot; afterwards the step kernels keep it
+    if (A.first) *A.snap = DrSnap{A.st->noise[2], A.st->noise[3], (unsigned int)frame, (unsigned int)(frame >> 32)};
   }
 }
 
 // vec_task.py:544-618 noise lambdas: x += mean + std * N(0,1); 4 elements per thread from one Philox block (two Box-Muller pairs)
-__global__ void dr_noise_kernel(const float* x, float* y, long long n, const DrState* __restrict__ st, int which, uint64_t seed, int64_t env_off) {
+__global__ void dr_noise_kernel(const float* x, float* y, long long n, const DrState* __restrict__ st, const DrSnap* __restrict__ snap, int which, uint64_t seed,
+                                int64_t env_off) {
   const long long i4 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i4 * 4 >= n) return;
-  const float mean = st->noise[2 * which], sd = st->noise[2 * which + 1];
-  const unsigned long long frame = st->frame;
+  // observations: the live state (this step's randomisation has run); actions: the snapshot the last step left -- the same numbers as
+  // the live state unless the coming step's randomisation kernel was launched early (bez_sim_dr_prelaunch)
+  const float mean = which ? snap->mean : st->noise[0], sd = which ? snap->sd : st->noise[1];
+  const unsigned long long frame = which ? ((unsigned long long)snap->frame_hi << 32 | snap->frame_lo) : st->frame;
   float z[4];
   bez::dr_noise_quad(seed, env_off, frame, which, i4, z);   // (shared with the step kernels' observation copy-out: same bits)
   for (int k = 0; k < 4; ++k) if (i4 * 4 + k < n) y[i4 * 4 + k] = x[i4 * 4 + k] + fmaf(z[k], sd, mean);
@@ -216,7 +224,7 @@ void launch_dr(BezSim* s, bool first, hipStream_t stream) {
   A.c = s->drc; A.n = s->n; A.first = first ? 1 : 0; A.seed = s->cfg.seed; A.env_off = s->cfg.env_id_offset;
   A.plane_friction = s->cfg.plane_friction;
   for (int k = 0; k < 3; ++k) A.gravity[k] = s->cfg.gravity[k];
-  A.reset = s->reset; A.episode = s->episode; A.randomize = s->randomize; A.st = s->dr_state;
+  A.reset = s->reset; A.episode = s->episode; A.randomize = s->randomize; A.st = s->dr_state; A.snap = s->dr_snap;
   A.friction = s->dr[BEZ_PARAM_FRICTION]; A.kp = s->dr[BEZ_PARAM_KP_SCALE]; A.kd = s->dr[BEZ_PARAM_KD_SCALE];
   A.lower = s->dr[BEZ_PARAM_DOF_LOWER]; A.upper = s->dr[BEZ_PARAM_DOF_UPPER]; A.gravity_rows = s->dr[BEZ_PARAM_GRAVITY];
   dr_kernel<<<1, DR_THREADS, 0, stream>>>(A);
@@ -436,19 +444,25 @@ int launch_step(BezSim* s, const float* actions, hipStream_t stream, bool obs_on
   Params P = make_params(s, actions);
   P.obs_only = obs_only ? 1 : 0;
   P.lean = (PRE && SIM && POST && !obs_only && (s->cfg.flags & BEZ_FLAG_LEAN_STEP) && (s->cfg.flags & BEZ_FLAG_IMU_PREV_ALIAS) && s->obs_calls > 0) ? 1 : 0;
-  if (POST && !obs_only && s->dr_on) launch_dr(s, false, stream);  // reset_idx's apply_randomizations (kick_env.py:781-782), on the device
+  if (POST && !obs_only && s->dr_on) {   // reset_idx's apply_randomizations (kick_env.py:781-782), on the device
+    if (!s->dr_prelaunched) launch_dr(s, false, stream);
+    s->dr_prelaunched = false;           // (bez_sim_dr_prelaunch ran it for this step already, possibly on another stream: the caller joined)
+  }
   // the observation noise of the randomisation inside this launch's copy-out (DR kernel variants only: has_dr is true once a
   // randomisation is set) -- bez_sim_add_dr_noise on the observation tensor is then a no-op
   const bool obs_noise = POST && !obs_only && s->dr_on && (s->cfg.flags & BEZ_FLAG_OBS_NOISE_IN_STEP) && s->drc.observations.enabled &&
-                         (has_dr(s) || s->cleats);   // (the kernel variants with per-env parameters carry the noise code)
+                         true;                       // (an active randomisation always runs the kernel variants that carry the noise code)
   P.dr_state = s->dr_state; P.obs_noise = obs_noise ? 1 : 0;
+  P.dr_snap = (POST && !obs_only && s->dr_on) ? s->dr_snap : nullptr;
   s->obs_noise_applied = obs_noise;
   if (POST && !obs_only && s->cfg.task != BEZ_TASK_KICK) {  // the reset inside this post_physics_step draws its goal on the device
     goal_draw_kernel<<<1, 1, 0, stream>>>(s->cfg.seed, s->post_calls_dev, s->goal_draw_dev);
     P.goal_dev = s->goal_draw_dev;
     s->post_calls++;
   }
-  const bool dr = has_dr(s) || s->cleats;
+  // an active randomisation runs the DR variants even when it owns no per-env array (null pointers = defaults): they carry the
+  // observation noise and keep the action-noise snapshot
+  const bool dr = has_dr(s) || s->cleats || s->dr_on;
   if constexpr (SIM && PRE == POST) {
     if (s->kernel != 2) {
       bez::launch_step_ws8(P, PRE, dr, s->cleats, stream);
@@ -511,7 +525,7 @@ int bez_sim_destroy(BezSim* s) {
   if (!s) return 0;
   (void)hipSetDevice(s->device);
   void* bufs[] = {s->state, s->obs, s->rew, s->reset, s->progress, s->timeout, s->episode, s->root_states, s->dof_state,
-                  s->rigid_body, s->contact, s->targets_aos, s->prev_aos, s->feet_aos, s->goal_aos, s->goal_draw_dev, s->post_calls_dev, s->randomize, s->dr_state};
+                  s->rigid_body, s->contact, s->targets_aos, s->prev_aos, s->feet_aos, s->goal_aos, s->goal_draw_dev, s->post_calls_dev, s->randomize, s->dr_state, s->dr_snap};
   for (void* b : bufs) if (b) (void)hipFree(b);
   for (int i = 0; i < BEZ_PARAM_COUNT; ++i) if (s->dr[i]) (void)hipFree(s->dr[i]);
   if (s->ev0) (void)hipEventDestroy(s->ev0);
@@ -555,7 +569,7 @@ int bez_sim_create(const BezSimConfig* cfg, int device_id, BezSim** out) {
       {(void**)&s->targets_aos, n * BEZ_ND * sizeof(float)}, {(void**)&s->prev_aos, n * 3 * sizeof(float)},
       {(void**)&s->feet_aos, n * 8 * sizeof(float)}, {(void**)&s->goal_aos, n * 2 * sizeof(float)},
       {(void**)&s->goal_draw_dev, 2 * sizeof(float)}, {(void**)&s->post_calls_dev, sizeof(unsigned long long)},
-      {(void**)&s->randomize, n * sizeof(int64_t)}, {(void**)&s->dr_state, sizeof(DrState)}};
+      {(void**)&s->randomize, n * sizeof(int64_t)}, {(void**)&s->dr_state, sizeof(DrState)}, {(void**)&s->dr_snap, sizeof(DrSnap)}};
   for (auto& a : allocs) {
     e = hipMalloc(a.p, a.bytes);
     if (e == hipSuccess) e = hipMemset(*a.p, 0, a.bytes);
@@ -781,11 +795,34 @@ int bez_sim_add_dr_noise(BezSim* s, const float* x_dev, float* y_dev, int64_t n,
   if (n == 0) return 0;
   if (which == 0 && x_dev == s->obs && y_dev == s->obs && s->obs_noise_applied) return 0;   // the step kernel already added it (BEZ_FLAG_OBS_NOISE_IN_STEP)
   const long long quads = (n + 3) / 4;
-  hipLaunchKernelGGL(dr_noise_kernel, dim3((unsigned)((quads + TB - 1) / TB)), dim3(TB), 0, (hipStream_t)stream_, x_dev, y_dev, (long long)n, s->dr_state, (int)which,
+  hipLaunchKernelGGL(dr_noise_kernel, dim3((unsigned)((quads + TB - 1) / TB)), dim3(TB), 0, (hipStream_t)stream_, x_dev, y_dev, (long long)n, s->dr_state, s->dr_snap, (int)which,
                      s->cfg.seed, s->cfg.env_id_offset);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(s, -2, "dr_noise_kernel launch", e);
   return 0;
+}
+
+/* The randomisation kernel of the COMING control step, now, on `stream` (the step then skips its own): the caller may overlap it with
+ * whatever else precedes that step (a policy forward pass), on another stream, as long as that stream is joined before the step.
+ * Needs: the previous step's post-physics has finished on a stream `stream` is ordered behind. */
+int bez_sim_dr_prelaunch(BezSim* s, void* stream_) {
+  if (!s) return -1;
+  if (!s->dr_on) return 0;
+  if (s->dr_prelaunched) return fail(s, -1, "bez_sim_dr_prelaunch: already launched for the coming step");
+  launch_dr(s, false, (hipStream_t)stream_);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(s, -2, "dr_kernel launch", e);
+  s->dr_prelaunched = true;
+  return 0;
+}
+/* Where a consumer that adds the action noise ITSELF (vec_task.py:586-592; e.g. bez_ppo_policy_rollout_step's epilogue) finds its
+ * parameters: a device struct {float mean, std; uint32 frame_lo, frame_hi} kept by the step kernels, and the Philox key parts.  The
+ * noise of element i of the flat (N, 18) action tensor is mean + std * z with z = word (i & 3) of dr-noise quad (i >> 2) for which = 1
+ * -- the same bits bez_sim_add_dr_noise(which = 1) adds.  Returns 1 if an action noise is configured, 0 if not. */
+int bez_sim_action_noise_source(BezSim* s, const void** snap_dev, uint64_t* seed, int64_t* env_id_offset) {
+  if (!s || !snap_dev || !seed || !env_id_offset) return -1;
+  *snap_dev = s->dr_snap; *seed = s->cfg.seed; *env_id_offset = s->cfg.env_id_offset;
+  return (s->dr_on && s->drc.actions.enabled) ? 1 : 0;
 }
 
 int bez_sim_set_randomization(BezSim* s, const BezDrConfig* dr, void* stream_) {

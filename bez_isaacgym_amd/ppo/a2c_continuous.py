@@ -510,11 +510,41 @@ class A2CAgent:
             self._packed.refresh()  # once per epoch, whoever changed the weights last (optimiser, checkpoint restore, parameter broadcast)
             self._packed_stale = False
         fx["noise"].normal_()  # the whole horizon's action noise in one launch
+        boot = self.value_bootstrap
+        pending = None  # rollout_post arguments of the env step whose bookkeeping has not run yet
+        fold = self._policy_fwd is not None and self.cfg.get("fold_rollout_post", True)
+        # a domain-randomised env at full speed (BASELINE config 5): (a) its action-noise lambda is added by the policy launch itself
+        # (the same bits: bez_sim_action_noise_source), (b) the randomisation kernel in front of the NEXT env step is launched right
+        # behind THIS one on a side stream, where it runs beside the next policy launch instead of between it and the env step
+        env = getattr(self.vec_env, "env", self.vec_env)
+        act_noise = None
+        if self._policy_fwd is not None and self.cfg.get("fold_action_noise", True) and hasattr(env, "action_noise_source"):
+            src = env.action_noise_source()
+            act_noise = None if src is None else F.ActionNoise(*src)
+        prelaunch = bool(self.cfg.get("dr_prelaunch", True) and hasattr(env, "dr_prelaunch") and getattr(env, "randomize", False)
+                         and not getattr(env, "first_randomization", True))
+        if prelaunch and getattr(self, "_side_stream", None) is None:
+            assert not torch.cuda.is_current_stream_capturing()
+            self._side_stream = torch.cuda.Stream(device=self.device)
+        main = torch.cuda.current_stream(self.device) if prelaunch else None
+        forked = False
+        if act_noise is not None:
+            env.external_action_noise = True
+        try:
+            self._rollout_loop(cur, net, vrms, mb, F, fx, boot, pending, fold, env, act_noise, prelaunch, main, forked)
+        finally:
+            if act_noise is not None:
+                env.external_action_noise = False
+
+    def _rollout_loop(self, cur, net, vrms, mb, F, fx, boot, pending, fold, env, act_noise, prelaunch, main, forked):
         for n in range(self.horizon):
             if self._policy_fwd is not None:
-                # normaliser + 5 Linear + 3 ELU + sampling + neglogp + clamp + the rollout-buffer rows: one launch
+                # normaliser + 5 Linear + 3 ELU + sampling + neglogp + clamp + the rollout-buffer rows: one launch -- which also does the
+                # PREVIOUS env step's bookkeeping (reward shaping, done flags, episode statistics): a rollout step is two launches
                 self._policy_fwd.rollout_step(cur, net.sigma.detach(), fx["noise"][n], self.dones, vrms, mb["obs"][n], mb["dones"][n], mb["mu"][n],
-                                              mb["val"][n], mb["act"][n], fx["env_act"], mb["neglogp"][n], mb["sigma"][n])
+                                              mb["val"][n], mb["act"][n], fx["env_act"], mb["neglogp"][n], mb["sigma"][n],
+                                              prev_post=None if pending is None else F.RolloutPost.of(*pending), action_noise=act_noise)
+                pending = None
             else:
                 x = self._f_obs_rms.normalize(cur, fx["obs_n"]) if self.normalize_input else cur
                 with torch.autocast("cuda", dtype=torch.float16, enabled=self.mixed_precision and not self.half_path):
@@ -524,9 +554,21 @@ class A2CAgent:
                 # fp32 rows of obs / dones / mu / de-normalised value + sampling + neglogp + clamp: one launch
                 F.rollout_pre(mu.contiguous(), value.contiguous(), net.sigma.detach(), fx["noise"][n], cur, self.dones, vrms, mb["obs"][n], mb["dones"][n],
                               mb["mu"][n], mb["val"][n], mb["act"][n], fx["env_act"], mb["neglogp"][n], mb["sigma"][n])
+            if forked:
+                main.wait_stream(self._side_stream)   # join: the randomisation kernel of this step ran beside the policy launch
+                forked = False
             obs_dict, rew, dones, infos = self.vec_env.step(fx["env_act"])
-            F.rollout_post(rew, dones, infos["time_outs"], mb["val"][n], self.reward_scale, self.gamma, self.value_bootstrap and "time_outs" in infos,
-                           mb["rew"][n], self.dones, self.current_rewards, self.current_lengths, self.ep_stats)
+            if prelaunch and n + 1 < self.horizon:
+                self._side_stream.wait_stream(main)   # fork behind this env step
+                with torch.cuda.stream(self._side_stream):
+                    env.dr_prelaunch()
+                forked = True
+            post = (rew, dones, infos["time_outs"] if "time_outs" in infos else dones, mb["val"][n], self.reward_scale, self.gamma,
+                    boot and "time_outs" in infos, mb["rew"][n], self.dones, self.current_rewards, self.current_lengths, self.ep_stats)
+            if fold and n + 1 < self.horizon and self._env_buffers_persist(rew, dones, infos):
+                pending = post   # rides in the next policy launch (the env's buffers keep this step's results until the next env step)
+            else:
+                F.rollout_post(*post)
             o = obs_dict["obs"]
             if o.dtype == torch.float32 and o.is_contiguous() and o.device == self.obs.device:
                 # the env's persistent buffer (vec_task.py _clipped_obs): valid until the next step().  Under a HIP graph this
@@ -540,6 +582,21 @@ class A2CAgent:
                 self.obs.copy_(o); cur = self.obs
         if cur is not self.obs:
             self.obs.copy_(cur)
+
+    def _env_buffers_persist(self, rew, dones, infos):
+        """The env hands back ITS OWN reward / reset / time-out buffers (fp32 / int64 on this device), the same ones on every step: then
+        a later launch may still read this step's results from them.  Host-side pointer compares, no sync."""
+        ts = (rew, dones) + ((infos["time_outs"],) if "time_outs" in infos else ())
+        if not (rew.dtype == torch.float32 and dones.dtype == torch.int64 and all(t.dtype == torch.int64 for t in ts[2:])
+                and all(t.is_contiguous() and t.device == self.obs.device for t in ts)):
+            return False
+        ptrs = tuple(t.data_ptr() for t in ts)
+        seen = getattr(self, "_env_buf_ptrs", None)
+        if seen is None:
+            self._env_buf_ptrs = (ptrs, 1)
+            return False   # first sight: nothing to compare with yet
+        self._env_buf_ptrs = (ptrs, seen[1] + 1)
+        return seen[0] == ptrs
 
     @torch.no_grad()
     def _rollout_impl(self, steps_done=False):

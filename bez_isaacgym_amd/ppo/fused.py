@@ -19,7 +19,7 @@ _SIGS = {
     "bez_ppo_loss": [_vp] * 10 + [_i64, _i32, _f, _f, _f, _f, _i32] + [_vp] * 7,
     "bez_ppo_rollout_pre": [_vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _f, _i64, _i32, _i32] + [_vp] * 9,
     "bez_ppo_policy_forward": [_vp, _i64, _i32, _vp, _vp, _f, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _vp],
-    "bez_ppo_policy_rollout_step": [_vp, _i64, _i32, _vp, _vp, _f, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f] + [_vp] * 8 + [_i32, _vp],
+    "bez_ppo_policy_rollout_step": [_vp, _i64, _i32, _vp, _vp, _f, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f] + [_vp] * 8 + [_i32, _vp, _vp, _vp],
     "bez_ppo_policy_forward_train": [_vp, _i64, _i32, _vp, _vp, _f, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp],
     "bez_ppo_policy_backward": [_vp, _vp, _i64, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp],
     "bez_ppo_scatter_f16": [_vp, _vp, _i64, _vp, _vp],
@@ -112,6 +112,25 @@ class FusedRunningMeanStd:
 def sample(mu, logstd, noise, actions, env_actions, neglogp, sigma):
     n, a = mu.shape
     _chk(lib().bez_ppo_sample(_p(mu), _p(logstd), _p(noise), n, a, _p(actions), _p(env_actions), _p(neglogp), _p(sigma), _stream(mu)), "bez_ppo_sample")
+
+
+class ActionNoise(C.Structure):
+    """BezPpoActionNoise (include/bez_sim.h): env.action_noise_source() for the launch that adds the env's action noise itself"""
+    _fields_ = [("snap_dev", C.c_void_p), ("seed", C.c_uint64), ("env_id_offset", C.c_int64)]
+
+
+class RolloutPost(C.Structure):
+    """BezPpoRolloutPost (include/bez_sim.h): the arguments of rollout_post() for the launch that carries them (PolicyForward.rollout_step)"""
+    _fields_ = [("rew", C.c_void_p), ("reset", C.c_void_p), ("timeouts", C.c_void_p), ("prev_values", C.c_void_p), ("reward_scale", C.c_float),
+                ("gamma", C.c_float), ("bootstrap", C.c_int32), ("shaped", C.c_void_p), ("dones_f", C.c_void_p), ("cur_rew", C.c_void_p),
+                ("cur_len", C.c_void_p), ("ep_stats", C.c_void_p)]
+
+    @classmethod
+    def of(cls, rew, dones, timeouts, values, reward_scale, gamma, bootstrap, shaped, dones_f, cur_rew, cur_len, ep_stats):
+        n = rew.numel()
+        assert dones.numel() == timeouts.numel() == values.numel() == shaped.numel() == dones_f.numel() == cur_rew.numel() == cur_len.numel() == n
+        return cls(_p(rew).value, _p(dones, torch.int64).value, _p(timeouts, torch.int64).value, _p(values).value, float(reward_scale), float(gamma),
+                   1 if bootstrap else 0, _p(shaped).value, _p(dones_f).value, _p(cur_rew).value, _p(cur_len).value, _p(ep_stats, torch.float64).value)
 
 
 def rollout_post(rew, dones, timeouts, values, reward_scale, gamma, bootstrap, shaped, dones_f, cur_rew, cur_len, ep_stats):
@@ -470,9 +489,10 @@ class PolicyForward:
             C.c_void_p(self.mu_w.data_ptr()), _p(mu_wb[1], torch.float16), self.num_actions, _p(value_wb[0], torch.float16), _p(value_wb[1], torch.float16),
             _p(x0, torch.float16), C.cast(tab, C.c_void_p), _p(mu_out), _p(value_out), self.flag, _stream(obs)), "bez_ppo_policy_forward_train")
 
-    def rollout_step(self, obs, logstd, noise, dones, value_rms, mb_obs, mb_dones, mb_mu, mb_val, actions, env_actions, neglogp, sigma):
+    def rollout_step(self, obs, logstd, noise, dones, value_rms, mb_obs, mb_dones, mb_mu, mb_val, actions, env_actions, neglogp, sigma, prev_post=None, action_noise=None):
         """Forward + everything up to the env step in the same launch (bez_ppo_policy_rollout_step): same outputs as
-        `self(obs, mu, v); rollout_pre(mu, v, ...)`."""
+        `self(obs, mu, v); rollout_pre(mu, v, ...)`.  prev_post (RolloutPost): rollout_post() of the PREVIOUS env step in the same launch;
+        action_noise (ActionNoise): env_actions also receives the env's domain-randomisation action noise (the env must not add it again)."""
         hidden, mu_wb, value_wb, rms = self.keep
         n, A = obs.shape[0], self.num_actions
         assert obs.shape[1] == self.d_in and noise.shape == (n, A) and logstd.numel() == A and dones.numel() == n
@@ -484,4 +504,6 @@ class PolicyForward:
             C.c_void_p(self.mu_w.data_ptr()), _p(mu_wb[1], torch.float16), A, _p(value_wb[0], torch.float16), _p(value_wb[1], torch.float16), _p(logstd), _p(noise),
             _p(dones), None if value_rms is None else _p(value_rms.running_mean, torch.float64),
             None if value_rms is None else _p(value_rms.running_var, torch.float64), 0.0 if value_rms is None else float(value_rms.epsilon), _p(mb_obs),
-            _p(mb_dones), _p(mb_mu), _p(mb_val), _p(actions), _p(env_actions), _p(neglogp), _p(sigma), self.flag, _stream(obs)), "bez_ppo_policy_rollout_step")
+            _p(mb_dones), _p(mb_mu), _p(mb_val), _p(actions), _p(env_actions), _p(neglogp), _p(sigma), self.flag,
+            None if prev_post is None else C.byref(prev_post), None if action_noise is None else C.byref(action_noise), _stream(obs)),
+            "bez_ppo_policy_rollout_step")

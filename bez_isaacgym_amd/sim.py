@@ -70,7 +70,7 @@ EXPORTS = ["bez_sim_default_config", "bez_sim_create", "bez_sim_destroy", "bez_s
            "bez_sim_set_dof_position_target_tensor", "bez_sim_set_dof_position_target_tensor_indexed",
            "bez_sim_set_net_contact_force_tensor", "bez_sim_set_prev_lin_vel_tensor", "bez_sim_set_goal_tensor", "bez_sim_set_flags",
            "bez_sim_set_obs_calls", "bez_sim_pre_physics", "bez_sim_simulate", "bez_sim_post_physics", "bez_sim_observe_reward", "bez_sim_step",
-           "bez_sim_step_many", "bez_sim_reset_indexed", "bez_sim_set_env_params", "bez_sim_get_env_params", "bez_sim_set_randomization", "bez_sim_add_dr_noise", "bez_sim_seed", "bez_sim_time_steps",
+           "bez_sim_step_many", "bez_sim_reset_indexed", "bez_sim_set_env_params", "bez_sim_get_env_params", "bez_sim_set_randomization", "bez_sim_dr_prelaunch", "bez_sim_action_noise_source", "bez_sim_add_dr_noise", "bez_sim_seed", "bez_sim_time_steps",
            "bez_sim_calibrate"]
 # (the bez_ppo_* entry points of the same library are bound in ppo/fused.py)
 
@@ -239,6 +239,19 @@ class BezSim:
         out = x if out is None else out
         self._check(self.lib.bez_sim_add_dr_noise(self.h, self._ptr(x, torch.float32), self._ptr(out, torch.float32, x.numel()), x.numel(), int(which), self._stream()))
         return out
+
+    def dr_prelaunch(self):
+        """The coming step's randomisation kernel now, on torch's current stream (bez_sim_dr_prelaunch): the step then skips its own."""
+        self._check(self.lib.bez_sim_dr_prelaunch(self.h, self._stream()))
+
+    def action_noise_source(self):
+        """(device pointer of the action-noise snapshot, seed, env id offset) for a consumer that adds the action noise itself, or None
+        when the randomisation has no action noise (bez_sim_action_noise_source)"""
+        p, seed, off = C.c_void_p(), C.c_uint64(), C.c_int64()
+        rc = self.lib.bez_sim_action_noise_source(self.h, C.byref(p), C.byref(seed), C.byref(off))
+        if rc < 0:
+            self._check(rc)
+        return (p.value, seed.value, off.value) if rc == 1 else None
 
     def seed(self, seed):
         self._check(self.lib.bez_sim_seed(self.h, int(seed)))

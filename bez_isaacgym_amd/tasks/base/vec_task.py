@@ -143,7 +143,7 @@ class VecTask(Env):
     def step(self, actions: torch.Tensor):
         """vec_task.py:303-349.  With no Python-side hooks active this is ONE kernel launch
         (bez_sim_step: clamp, PD targets, physics, bookkeeping, reset, obs, reward)."""
-        if self.dr_randomizations.get('actions', None):
+        if self.dr_randomizations.get('actions', None) and not self.external_action_noise:
             actions = self.dr_randomizations['actions']['noise_lambda'](actions)
         actions = actions.to(self.device, torch.float32).contiguous()
         self._fused_step(actions)
@@ -194,6 +194,19 @@ class VecTask(Env):
         return self.num_agents
 
     # ---- domain randomisation (vec_task.py:505-725), device-side: bez_sim_set_randomization
+    # ---- hooks for a trainer that drives the randomised env at full speed (ppo/a2c_continuous.py): both default to "the env does it"
+    external_action_noise = False   # True: the caller adds the action noise itself (action_noise_source), step() must not add it again
+
+    def action_noise_source(self):
+        """(snapshot pointer, seed, env id offset) of the action-noise lambda for a consumer that adds it in its own launch, or None"""
+        return self.sim.action_noise_source() if self.dr_randomizations.get('actions', None) else None
+
+    def dr_prelaunch(self):
+        """The coming step's randomisation kernel now, on the current stream (overlappable with the policy's forward pass); no-op
+        without a device-side randomisation."""
+        if not self.first_randomization and self.randomize:
+            self.sim.dr_prelaunch()
+
     def apply_randomizations(self, dr_params):
         """The reference calls this from reset_idx on every step in which some env resets (kick_env.py:781-782); what it does
         there -- per-env redraws at reset time once `frequency` steps have passed, gravity and the noise parameters on the same

@@ -249,6 +249,18 @@ typedef struct BezDrConfig {
   BezDrRange actions;       /* bez_kick.yaml:158-161 */
 } BezDrConfig;
 int bez_sim_set_randomization(BezSim* sim, const BezDrConfig* dr, void* stream);
+/* The randomisation kernel of the COMING control step (what the next call containing the post-physics would launch first), now, on
+ * `stream`; that call then skips its own.  Lets a caller overlap it with whatever else precedes the step (a policy forward pass) on
+ * another stream -- which must be joined before the step.  The previous step must be complete on a stream `stream` is ordered behind.
+ * The action noise (bez_sim_add_dr_noise(which = 1), BezActionNoiseSource) reads a SNAPSHOT the previous step left, not the state this
+ * kernel updates, so it may run concurrently with it. */
+int bez_sim_dr_prelaunch(BezSim* sim, void* stream);
+/* For a consumer that adds the action noise of vec_task.py:586-592 itself (e.g. bez_ppo_policy_rollout_step): *snap_dev -> device struct
+ * {float mean, std; uint32_t frame_lo, frame_hi} kept current by the step kernels; noise of element i of the flat (N, 18) action tensor =
+ * mean + std * z, z = word (i & 3) of the Philox4x32-10 block with counter (key lo, key hi, frame lo, 0x4e4f4953 + 1 + (frame hi << 8)),
+ * key = env_id_offset * 64 + (i >> 2), Philox key = seed, Box-Muller pairs (words 0,1 -> z0 = r cos, z1 = r sin; words 2,3 -> z2, z3) --
+ * bit for bit what bez_sim_add_dr_noise(which = 1) adds.  Returns 1 if an action noise is configured, 0 if not, < 0 on error. */
+int bez_sim_action_noise_source(BezSim* sim, const void** snap_dev, uint64_t* seed, int64_t* env_id_offset);
 /* The noise lambdas of vec_task.py:544-618 in one launch: y[i] = x[i] + mean + std * N(0,1) for n floats (y_dev may be x_dev: in
  * place), mean / std = the current entries of BEZ_TENSOR_DR_NOISE for `which` (0 = observations, 1 = actions), normals from
  * Philox keyed by (seed, frame, which, i / 4) -- one call per control step and kind. */
@@ -337,14 +349,26 @@ int bez_ppo_policy_forward(const float* obs_dev, int64_t n, int32_t num_obs, con
 
 /* The fused rollout step: bez_ppo_policy_forward followed, inside the same launch, by bez_ppo_rollout_pre's work (rollout-buffer
  * rows of obs / dones / mu / de-normalised value, a = mu + exp(logstd) * noise, neglogp, the clamped env action).  mu / value
- * never visit HBM in fp16; replaces a2c_common.py:1105-1135's per-step get_action_values + buffer updates. */
+ * never visit HBM in fp16; replaces a2c_common.py:1105-1135's per-step get_action_values + buffer updates.
+ * prev_post (NULL = none; ABI 4): the bookkeeping of the env step BEFORE this one rides in the same launch -- exactly
+ * bez_ppo_rollout_post(rew, reset, timeouts, prev_values, ...) on the env's still-unchanged reward / reset / time-out buffers, with
+ * dones_f also written to this step's mb_dones row (dones_dev is then not read): a rollout step is two launches (policy, env). */
+typedef struct BezPpoRolloutPost {
+  const float* rew; const int64_t* reset; const int64_t* timeouts; const float* prev_values;
+  float reward_scale, gamma; int32_t bootstrap;
+  float* shaped; float* dones_f; float* cur_rew; float* cur_len; double* ep_stats;
+} BezPpoRolloutPost;
+/* action_noise (NULL = none; ABI 4): the env's action-noise lambda of the domain randomisation inside this launch -- env_actions_dev receives
+ * clamp(a, -1, 1) + noise, bit for bit what bez_sim_add_dr_noise(which = 1) would add to the clamped actions (the three fields are what
+ * bez_sim_action_noise_source returns; the env must then not add it again). */
+typedef struct BezPpoActionNoise { const void* snap_dev; uint64_t seed; int64_t env_id_offset; } BezPpoActionNoise;
 int bez_ppo_policy_rollout_step(const float* obs_dev, int64_t n, int32_t num_obs, const double* obs_mean_dev, const double* obs_var_dev, float obs_eps,
                                 int32_t num_hidden, const void* const* hidden_w_f16_dev, const void* const* hidden_b_f16_dev, const int32_t* hidden_width,
                                 const void* mu_w_f16_dev, const void* mu_b_f16_dev, int32_t num_actions, const void* value_w_f16_dev,
                                 const void* value_b_f16_dev, const float* logstd_dev, const float* noise_dev, const float* dones_dev,
                                 const double* value_mean_dev, const double* value_var_dev, float value_eps, float* mb_obs_dev, float* mb_dones_dev,
                                 float* mb_mu_dev, float* mb_val_dev, float* actions_dev, float* env_actions_dev, float* neglogp_dev, float* sigma_dev,
-                                int32_t weights_packed, void* stream);
+                                int32_t weights_packed, const BezPpoRolloutPost* prev_post, const BezPpoActionNoise* action_noise, void* stream);
 
 /* The forward half of a PPO minibatch step (a2c_common.py calc_gradients: model(batch) under autocast): bez_ppo_policy_forward
  * that also keeps what the backward pass needs -- x0 (n, num_obs) fp16 = the normalised, clamped input of the first Linear, and

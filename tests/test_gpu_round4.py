@@ -112,3 +112,70 @@ def test_optimiser_launch_folds_the_weight_scatter_and_the_next_normaliser_updat
         assert torch.equal(getattr(a.running_mean_std, k), getattr(b.running_mean_std, k)), k
     assert float(a._opt_work[0]) == 0.0 and float(a.scaler._scale) == float(b.scaler._scale)
     assert torch.equal(a._steps, b._steps) and float(a._steps[0]) == 1.0
+
+
+def test_rollout_bookkeeping_inside_the_policy_launch_changes_nothing():
+    """Round 4: the reward shaping / done flags / episode statistics of env step n ride in the policy launch of step n + 1
+    (BezPpoRolloutPost), so a rollout step is two launches.  Two agents, same seed, one with the separate bez_ppo_rollout_post launch:
+    every rollout row, the dataset, the running episode sums and the statistics are bit-identical over two rollouts (the second
+    one starts from the state the first one's LAST, separately launched, bookkeeping left)."""
+    import torch
+    from tests.test_gpu_round2 import _agent
+    a = _agent(512, 4096, hip_graphs=False, fold_rollout_post=False)
+    b = _agent(512, 4096, hip_graphs=False)
+    b.model.load_state_dict(a.model.state_dict())
+    for ag in (a, b):
+        torch.manual_seed(11)
+        ag.obs = ag.env_reset()
+        ag.play_steps(); ag.play_steps()
+    torch.cuda.synchronize()
+    assert b._env_buf_ptrs[1] >= 2 * (b.horizon - 1)   # the fold was live (the env's buffers are persistent)
+    for k in a.mb:
+        assert torch.equal(a.mb[k], b.mb[k]), k
+    for k in a.dataset:
+        assert torch.equal(a.dataset[k], b.dataset[k]), k
+    assert torch.equal(a.dones, b.dones) and torch.equal(a.current_rewards, b.current_rewards) and torch.equal(a.current_lengths, b.current_lengths)
+    np.testing.assert_allclose(a.ep_stats.cpu().numpy(), b.ep_stats.cpu().numpy(), rtol=1e-12)   # fp64 atomics: order-dependent in the last bits
+    assert float(a.ep_stats[0]) > 0   # episodes did end (random initial policy falls within the horizon)
+
+
+def test_randomised_rollout_at_full_speed_changes_nothing():
+    """Round 4, BASELINE config 5 at speed: with task.randomize=True the agent (a) lets the policy launch add the env's action noise
+    (BezPpoActionNoise: the same Philox bits as the env's own lambda) and (b) launches the randomisation kernel of the next env step
+    right behind the current one on a side stream (bez_sim_dr_prelaunch), beside the next policy launch.  Against an agent that
+    leaves both to the env (two more launches per step, in series), same seeds, redraws every 5 steps: every rollout row, the
+    simulator's state, the per-env randomised parameters and the randomisation clocks are bit-identical."""
+    import torch
+    from bez_isaacgym_amd import abi
+    from bez_isaacgym_amd.ppo.a2c_continuous import A2CAgent
+    from bez_isaacgym_amd.utils.config import load_config
+    from bez_isaacgym_amd.utils.rlgames_utils import RLGPUEnv, get_rlgames_env_creator
+
+    def make(**over):
+        cfg = load_config(["task=bez_kick", "num_envs=512", "headless=True", "task.task.randomize=True"])
+        cfg["task"]["seed"] = 42
+        cfg["task"]["task"]["randomization_params"]["frequency"] = 5
+        venv = RLGPUEnv("rlgpu", 512, env_creator=get_rlgames_env_creator(cfg["task"], "bez_kick", "cuda:0", "cuda:0", 0, True))
+        params = cfg["train"]["params"]
+        params["config"].update(minibatch_size=4096, save_frequency=0, save_best_after=10 ** 9, hip_graphs=False, **over)
+        return A2CAgent(params, venv, "cuda:0")
+    a = make(fold_action_noise=False, dr_prelaunch=False)
+    b = make()
+    b.model.load_state_dict(a.model.state_dict())
+    for ag in (a, b):
+        torch.manual_seed(3)
+        ag.obs = ag.env_reset()
+        ag.play_steps(); ag.play_steps()
+    torch.cuda.synchronize()
+    ea, eb = a.vec_env.env, b.vec_env.env
+    assert eb.action_noise_source() is not None and b._side_stream is not None and not eb.external_action_noise
+    for k in a.mb:
+        assert torch.equal(a.mb[k], b.mb[k]), k
+    for t in (abi.TENSOR_ROOT_STATE, abi.TENSOR_DOF_STATE, abi.TENSOR_RANDOMIZE_BUF, abi.TENSOR_DR_NOISE, abi.TENSOR_OBS, abi.TENSOR_RESET):
+        assert torch.equal(ea.sim.refresh(t) if t < abi.TENSOR_OBS else ea.sim.tensor(t), eb.sim.refresh(t) if t < abi.TENSOR_OBS else eb.sim.tensor(t)), t
+    for p in (abi.PARAM_FRICTION, abi.PARAM_KP_SCALE, abi.PARAM_KD_SCALE, abi.PARAM_DOF_LOWER, abi.PARAM_GRAVITY):
+        assert torch.equal(ea.sim.get_env_params(p), eb.sim.get_env_params(p)), p
+    fr = ea.sim.get_env_params(abi.PARAM_FRICTION)
+    assert float(fr.std()) > 0   # redraws did happen
+    # the noise really is in the actions the env stepped with: a noise-free twin differs
+    assert float(ea.sim.tensor(abi.TENSOR_DR_NOISE)[3]) > 0
