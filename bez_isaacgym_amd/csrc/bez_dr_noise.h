@@ -37,8 +37,14 @@ BEZ_DEV void dr_noise_quad(uint64_t seed, int64_t env_off, unsigned long long fr
   philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
   float u[4];
   for (int k = 0; k < 4; ++k) u[k] = (float)(c[k] >> 8) * (1.0f / 16777216.0f);
-  const float r0 = sqrtf(-2.0f * logf(1.0f - u[0])), r1 = sqrtf(-2.0f * logf(1.0f - u[2]));
-  z[0] = r0 * cosf(6.2831853f * u[1]); z[1] = r0 * sinf(6.2831853f * u[1]); z[2] = r1 * cosf(6.2831853f * u[3]); z[3] = r1 * sinf(6.2831853f * u[3]);
+  // Box-Muller on the hardware transcendentals (v_log_f32 = log2, v_sqrt_f32, v_sin_f32 / v_cos_f32 take REVOLUTIONS, so u is their
+  // argument as it is): a quad costs ~120 instructions instead of ~700 with libm's logf / sinf / cosf, which put +5.7 us on a policy
+  // launch that adds the action noise.  The samples are noise: 1-ulp transcendentals change no statistic (tests: moments of 10^6 draws);
+  // what matters is that every kernel that adds this noise uses THIS function, i.e. the same bits.
+  const float r0 = __builtin_amdgcn_sqrtf(-1.38629436f * __builtin_amdgcn_logf(1.0f - u[0]));   // sqrt(-2 ln x) = sqrt(-2 ln2 log2 x)
+  const float r1 = __builtin_amdgcn_sqrtf(-1.38629436f * __builtin_amdgcn_logf(1.0f - u[2]));
+  z[0] = r0 * __builtin_amdgcn_cosf(u[1]); z[1] = r0 * __builtin_amdgcn_sinf(u[1]);
+  z[2] = r1 * __builtin_amdgcn_cosf(u[3]); z[3] = r1 * __builtin_amdgcn_sinf(u[3]);
 }
 
 }  // namespace bez

@@ -230,6 +230,25 @@ __global__ __launch_bounds__(PF_WAVES * 64) void policy_forward_kernel(PolicyArg
   const int64_t row0 = (int64_t)blockIdx.x * PF_ROWS;
   const int nrow = (int)((a.n - row0) < (int64_t)PF_ROWS ? (a.n - row0) : (int64_t)PF_ROWS);
   PF_STAMP(0);
+  // ROLL with the env's action noise (BezPpoActionNoise): the samples do not depend on the forward pass, so they are drawn HERE, in
+  // the shadow of the observation loads, and kept in registers until the epilogue (element idx = tid + k * 512 of this workgroup's
+  // (nrow, A) block; the quad of an element is recomputed by its <= 4 threads: cheaper than a trip through LDS, which is full until then)
+  float nzr[4] = {0.f, 0.f, 0.f, 0.f};
+  if (ROLL && a.an.snap_dev) {
+    const bez::DrSnap sn = *static_cast<const bez::DrSnap*>(a.an.snap_dev);
+    const unsigned long long frame = (unsigned long long)sn.frame_hi << 32 | sn.frame_lo;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int idx = tid + k * PF_WAVES * 64;
+      if (idx < nrow * a.num_actions) {
+        const int64_t o = row0 * a.num_actions + idx;
+        float z4[4];
+        bez::dr_noise_quad(a.an.seed, a.an.env_id_offset, frame, 1, o >> 2, z4);
+        const int w = (int)(o & 3);
+        nzr[k] = fmaf(w == 0 ? z4[0] : w == 1 ? z4[1] : w == 2 ? z4[2] : z4[3], sn.sd, sn.mean);
+      }
+    }
+  }
   // stage the (normalised) observations as fp16, zero-padded to a multiple of 16 columns
   const int kpad0 = (a.d_in + 15) & ~15;
   for (int idx = tid; idx < PF_ROWS * kpad0; idx += PF_WAVES * 64) {
@@ -278,20 +297,18 @@ __global__ __launch_bounds__(PF_WAVES * 64) void policy_forward_kernel(PolicyArg
     __syncthreads();
     const int A = a.num_actions;
     float* zz = tile + PF_ROWS * 33;  // (64, 32) squared standardised actions
-    for (int idx = tid; idx < nrow * A; idx += PF_WAVES * 64) {
+    static_assert(4 * PF_WAVES * 64 >= PF_ROWS * 31, "nzr holds every element a thread owns");
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int idx = tid + it * PF_WAVES * 64;
+      if (idx >= nrow * A) break;
       const int rr = idx / A, j = idx - rr * A;
       const float m = tile[rr * 33 + j];
       const float l = a.logstd[j], sg = expf(l), z = a.noise[(row0 + rr) * A + j];
       const float x = fmaf(sg, z, m);
       const int64_t o = (row0 + rr) * A + j;
       float xe = fminf(fmaxf(x, -1.0f), 1.0f);   // what rl_games hands to env.step
-      if (a.an.snap_dev) {
-        // the env would add its action noise to that tensor in a launch of its own (bez_sim_add_dr_noise, which = 1): the same bits here
-        const bez::DrSnap sn = *static_cast<const bez::DrSnap*>(a.an.snap_dev);
-        float z4[4];
-        bez::dr_noise_quad(a.an.seed, a.an.env_id_offset, (unsigned long long)sn.frame_hi << 32 | sn.frame_lo, 1, o >> 2, z4);
-        xe = xe + fmaf(z4[o & 3], sn.sd, sn.mean);
-      }
+      if (a.an.snap_dev) xe = xe + nzr[it];
       a.mb_mu[o] = m; a.act[o] = x; a.act_env[o] = xe; a.sigma[o] = sg;
       const float q = (x - m) / sg;  // as the reference computes it from the stored action
       zz[rr * 32 + j] = q * q;

@@ -514,14 +514,15 @@ class A2CAgent:
         pending = None  # rollout_post arguments of the env step whose bookkeeping has not run yet
         fold = self._policy_fwd is not None and self.cfg.get("fold_rollout_post", True)
         # a domain-randomised env at full speed (BASELINE config 5): (a) its action-noise lambda is added by the policy launch itself
-        # (the same bits: bez_sim_action_noise_source), (b) the randomisation kernel in front of the NEXT env step is launched right
-        # behind THIS one on a side stream, where it runs beside the next policy launch instead of between it and the env step
+        # (the same bits: bez_sim_action_noise_source); (b) `dr_prelaunch: True` launches the randomisation kernel in front of the NEXT
+        # env step right behind THIS one on a side stream, beside the next policy launch.  (b) is OFF by default: measured in the
+        # replayed HIP graph each fork / join pair costs more (~14 us) than the 6 us kernel it hides (6.12 vs 5.68 ms per epoch)
         env = getattr(self.vec_env, "env", self.vec_env)
         act_noise = None
         if self._policy_fwd is not None and self.cfg.get("fold_action_noise", True) and hasattr(env, "action_noise_source"):
             src = env.action_noise_source()
             act_noise = None if src is None else F.ActionNoise(*src)
-        prelaunch = bool(self.cfg.get("dr_prelaunch", True) and hasattr(env, "dr_prelaunch") and getattr(env, "randomize", False)
+        prelaunch = bool(self.cfg.get("dr_prelaunch", False) and hasattr(env, "dr_prelaunch") and getattr(env, "randomize", False)
                          and not getattr(env, "first_randomization", True))
         if prelaunch and getattr(self, "_side_stream", None) is None:
             assert not torch.cuda.is_current_stream_capturing()

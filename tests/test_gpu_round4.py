@@ -160,7 +160,7 @@ def test_randomised_rollout_at_full_speed_changes_nothing():
         params["config"].update(minibatch_size=4096, save_frequency=0, save_best_after=10 ** 9, hip_graphs=False, **over)
         return A2CAgent(params, venv, "cuda:0")
     a = make(fold_action_noise=False, dr_prelaunch=False)
-    b = make()
+    b = make(dr_prelaunch=True)
     b.model.load_state_dict(a.model.state_dict())
     for ag in (a, b):
         torch.manual_seed(3)
