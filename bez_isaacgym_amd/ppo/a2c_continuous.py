@@ -48,8 +48,11 @@ class RunningMeanStd(nn.Module):
         """[column sums | column sums of squares | rows] in fp64: what an update needs to know about a batch.  Additive over
         ranks, so a data-parallel job all-reduces THESE (for all minibatches of an epoch at once) and not the statistics."""
         x = x.reshape(-1, *self.running_mean.shape).double()
-        n = torch.full((1,), float(x.shape[0]), dtype=torch.float64, device=x.device)  # fill kernel: graph-capturable
-        return torch.cat([x.sum(0).reshape(-1), (x * x).sum(0).reshape(-1), n])
+        k = self.running_mean.numel()
+        # NO torch.cat / torch.stack in anything a HIP graph may capture (see clip_grad_norm_capturable below): slice writes instead
+        out = torch.empty(2 * k + 1, dtype=torch.float64, device=x.device)
+        out[:k].copy_(x.sum(0).reshape(-1)); out[k:2 * k].copy_((x * x).sum(0).reshape(-1)); out[2 * k:].fill_(float(x.shape[0]))
+        return out
 
     @torch.no_grad()
     def update_from_moments(self, flat):
@@ -222,6 +225,25 @@ def policy_kl(p0_mu, p0_sigma, p1_mu, p1_sigma):
     return (c1 + c2 - 0.5).sum(-1).mean()
 
 
+@torch.no_grad()
+def clip_grad_norm_capturable(parameters, max_norm):
+    """torch.nn.utils.clip_grad_norm_ (2-norm) without torch.stack: the squared norms are added with plain kernels instead of being
+    concatenated first (11 tiny launches instead of a cat + a norm; on ROCm cat stages its input pointers through a pinned host buffer,
+    one more thing a captured graph would have to keep alive).  NOT the cause of round 3's graph + AMP + save defect -- that was the HIP
+    runtime's graph packet capture (bez_isaacgym_amd/__init__.py); both clips behave the same in profiles/r04_plain_graph_probe.txt."""
+    grads = [p.grad for p in parameters if p.grad is not None]
+    if not grads:
+        return torch.zeros(())
+    norms = torch._foreach_norm(grads, 2.0)
+    total_sq = norms[0] * norms[0]
+    for nrm in norms[1:]:
+        total_sq = torch.addcmul(total_sq, nrm, nrm)
+    total = total_sq.sqrt()
+    coef = torch.clamp(float(max_norm) / (total + 1e-6), max=1.0)
+    torch._foreach_mul_(grads, coef)
+    return total
+
+
 class AdaptiveScheduler:
     """rl_games AdaptiveScheduler; `update_` is the same rule on a device-resident lr tensor (no host sync)."""
 
@@ -387,18 +409,18 @@ class A2CAgent:
         self._packed_stale = True     # the fragment-major weight copies need a refresh() before their next use (set whenever weights change outside the fused optimiser)
         self._rms_preapplied = False  # the input normaliser already holds the coming minibatch's moments (folded into the previous optimiser launch)
         self.fused = bool(on_gpu and c.get("fused_ops", True))
-        if not self.fused and self.mixed_precision and g is True and on_gpu:
+        # Replaying ANY graph is only safe with the HIP runtime's graph packet capture off (bez_isaacgym_amd/__init__.py: root cause of
+        # round 3's "plain AMP path stops learning once agent.save() runs between replays", profiles/r04_plain_graph_probe.txt).  The
+        # package switches it off at import; if the process had initialised HIP before, or the user switched it back on, say so -- and
+        # keep the plain torch path (thousands of nodes, clobbered after ~8 KB of eager kernel arguments) eager unless forced.
+        from .. import GRAPH_REPLAY_SAFE
+        if self.use_graphs and not GRAPH_REPLAY_SAFE:
             import warnings
-            warnings.warn("fused_ops: False + mixed_precision + hip_graphs: True replays torch's GradScaler / autocast update as HIP "
-                          "graphs: known to stop learning once agent.save() runs between replays (DESIGN.md 6.1); use hip_graphs: auto",
-                          RuntimeWarning, stacklevel=2)
-        if not self.fused and self.mixed_precision and g != True:  # noqa: E712 (an explicit hip_graphs: True is honoured)
-            # The plain torch formulation under AMP (torch's GradScaler + autocast) is run EAGERLY: replayed as HIP graphs it
-            # stops learning after ~500 epochs in 4 of 4 seeds (profiles/r03_learning_plain_full.txt: -0.6 ... -1.5 at 6156 epochs)
-            # while the same path eager reaches 23-32 (r03_learning_plain_eager_1500.txt) and without AMP also under graphs (29.7).
-            # Not root-caused (round 2 only escaped it because its capturing epoch did not execute); the fused path carries its own
-            # device-side loss scaling (bez_ppo_adam_step) and is unaffected (8 of 8 seeds).
-            self.use_graphs = False
+            warnings.warn("HIP graphs are replayed with the runtime's graph packet capture ON (DEBUG_CLR_GRAPH_PACKET_CAPTURE != 0, or HIP was "
+                          "initialised before bez_isaacgym_amd was imported): enough eager kernel launches between replays corrupt the replayed "
+                          "kernels' arguments (DESIGN.md 6.2)", RuntimeWarning, stacklevel=2)
+            if not self.fused and g is not True:
+                self.use_graphs = False
         if self.fused:
             from . import fused as F
             self._F = F
@@ -983,7 +1005,7 @@ class A2CAgent:
         else:
             if self.truncate_grads:
                 self.scaler.unscale_(self.optimizer)
-                nn.utils.clip_grad_norm_(self.model.parameters(), self.grad_norm)
+                clip_grad_norm_capturable(self.model.parameters(), self.grad_norm)
             self.scaler.step(self.optimizer)
             self.scaler.update()
         with torch.no_grad():
@@ -1045,7 +1067,7 @@ class A2CAgent:
             kl = self._allreduce_grads(kl)
         if self.truncate_grads:
             self.scaler.unscale_(self.optimizer)
-            nn.utils.clip_grad_norm_(self.model.parameters(), self.grad_norm)
+            clip_grad_norm_capturable(self.model.parameters(), self.grad_norm)
         self.scaler.step(self.optimizer)
         self.scaler.update()
         with torch.no_grad():

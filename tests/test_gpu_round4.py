@@ -179,3 +179,44 @@ def test_randomised_rollout_at_full_speed_changes_nothing():
     assert float(fr.std()) > 0   # redraws did happen
     # the noise really is in the actions the env stepped with: a noise-free twin differs
     assert float(ea.sim.tensor(abi.TENSOR_DR_NOISE)[3]) > 0
+
+
+@pytest.mark.parametrize("fused", [False, True])
+def test_eager_work_and_checkpoint_saves_between_graph_replays_change_nothing(fused, tmp_path):
+    """VERDICT round 3, item 4 / ADVICE (medium): the plain AMP path replayed as HIP graphs 'stopped learning once agent.save() ran
+    between replays'.  Root cause (tools/plain_graph_probe.py, profiles/r04_plain_graph_probe.txt): with the HIP runtime's graph packet
+    capture on, kernel arguments launched EAGERLY between two replays (>= ~8 KB for the plain path's graph, a few hundred KB for the
+    fused one) clobber the replayed kernels' arguments.  The package switches the feature off (bez_isaacgym_amd/__init__.py).  Here: two
+    agents per path, same seed; one of them runs 1024 eager reductions (~800 KB of kernel arguments) and a full checkpoint save
+    between every two replayed epochs.  Weights, Adam moments and the loss scale must stay bit-identical to the undisturbed twin."""
+    import io
+    import os
+    import torch
+    import bez_isaacgym_amd
+    from tests.test_gpu_round2 import _agent
+    assert os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE") == "0" and bez_isaacgym_amd.GRAPH_REPLAY_SAFE
+    x = torch.ones(100, device="cuda")
+    out = []
+    for disturbed in (False, True):
+        torch.manual_seed(7)
+        ag = _agent(512, 4096, fused_ops=fused, hip_graphs=True)
+        assert ag.use_graphs   # (the plain AMP path is replayed again: round 3 had to run it eagerly)
+        ag.obs = ag.env_reset()
+        for ep in range(14):
+            ag.train_epoch()
+            if disturbed and ag._g_update is not None:
+                for _ in range(1024):
+                    junk = x.sum()
+                del junk
+                torch.save(ag.get_full_state_weights(), io.BytesIO())
+                ag.save(str(tmp_path / "ck.pth"))
+        torch.cuda.synchronize()
+        assert ag._g_update is not None
+        out.append(([p.detach().clone() for p in ag.model.parameters()], float(ag.scaler.get_scale()),
+                    [ag.optimizer.state[p]["exp_avg"].clone() for p in ag.model.parameters()]))
+        del ag
+    (pa, sa, ma), (pb, sb, mb) = out
+    assert sa == sb and sa >= 1024.0
+    assert all(torch.isfinite(p).all() for p in pb)
+    for u, v in zip(pa + ma, pb + mb):
+        assert torch.equal(u, v)
