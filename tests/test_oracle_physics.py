@@ -291,3 +291,66 @@ def test_hard_contact_ball_robot_impact_is_inelastic(model):
     np.testing.assert_allclose(dp_robot, -dp_ball, atol=2e-3)         # what the ball lost (0.27 N s) the robot gained
     assert out[False][0] > 0.0, out                                   # compliant contact: the ball comes back
     np.testing.assert_allclose(out[False][2], -out[False][3], atol=2e-3)
+
+
+# ------------------------------------------------------------------ TGS-shaped unified substep (BEZ_FLAG_TGS_SOLVER, oracle/bez_oracle_tgs.inc)
+def _tgs_cfg(n, tune=None, **over):
+    c = abi.default_config(n)
+    c.flags |= abi.FLAG_TGS_SOLVER
+    for k, v in (tune or {}).items():
+        c.tune[k] = v
+    for k, v in over.items():
+        setattr(c, k, v)
+    return c
+
+
+@pytest.mark.parametrize("tune", [{}, {18: 1.0}, {11: 4.0, 18: 1.0}, {12: 1.0, 8: 8.0}])
+def test_tgs_solver_stands_and_carries_the_weight(tune):
+    """The unified solver (drives, joint friction, limits, speed limit and contacts as clamped rows over posIters sub-steps): the ready
+    pose stands 300 control steps without a reset, the feet carry exactly the robot's weight, the ball rests on the plane, nothing
+    blows up -- for the defaults, the compliant leg<->leg contact, the load-proportional joint friction and 8 iterations + speed rows."""
+    o = Oracle(_tgs_cfg(2, tune))
+    act = np.zeros((2, 18), np.float32)
+    cf = np.zeros((2, 22, 3))
+    for t in range(300):
+        o.step(act)
+        assert (o.reset_buf == 0).all(), t
+        if t >= 240:
+            cf += o.contact_forces.reshape(2, 22, 3) / 60.0   # mean over the last second (joint stick-slip leaves a small vertical ripple)
+    rs = o.root_states.reshape(2, 2, 13)
+    assert np.isfinite(rs).all() and np.all(np.abs(rs[:, 0, 2] - 0.325) < 0.01)
+    # ALL rows (robot + ball): leg <-> leg and ball <-> leg contacts are rigid rows with equal and opposite forces on two bodies, so only
+    # the sum over everything is the ground reaction = the weight of robot and ball (the default variant creeps forward by ~6 mm/s --
+    # its friction anchors do not persist across substeps -- and ends up leaning on the ball)
+    np.testing.assert_allclose(cf[:, :, 2].sum(1), (2.827994 + 0.3) * 9.81, rtol=2e-2)
+    np.testing.assert_allclose(rs[:, 1, 2], 0.08, atol=1e-3)
+    ds = o.dof_state.reshape(2, 18, 2)
+    assert np.abs(ds[:, :, 0] - o.targets).max() < 0.05   # the drives hold the pose (knee / thigh sag ~0.02 rad under the weight)
+
+
+def test_tgs_drive_is_the_first_order_response_of_the_yaml_gains():
+    """An unloaded joint under the TGS drive row follows the same law as the implicit PD of the compliant model: rate = Kp / Kd x error
+    (13.3 1/s at the yaml's 100 / 7.5) -- the head joint, target stepped by 0.2 rad, covers 1 - exp(-dt Kp / Kd) of the way per step."""
+    c = _tgs_cfg(1, {18: 1.0})
+    o = Oracle(c)
+    act = np.zeros((1, 18), np.float32)
+    for _ in range(60):
+        o.step(act)
+    q0 = o.dof_state.reshape(18, 2)[2, 0]          # left arm joint 0 (the head's targets are forced to 0 by pre_physics_step)
+    act[0, 2] = 0.2
+    errs = []
+    for _ in range(6):
+        o.step(act)
+        errs.append(o.targets[0, 2] - o.dof_state.reshape(18, 2)[2, 0])
+    assert abs(o.targets[0, 2] - (q0 + 0.2)) < 0.02
+    ratio = np.array(errs[1:]) / np.array(errs[:-1])
+    np.testing.assert_allclose(ratio, np.exp(-float(c.dt) * 100.0 / 7.5), atol=0.06)
+
+
+def test_tgs_flag_is_oracle_only():
+    """(the HIP library refuses it: tests/test_abi_cpu.py) -- here: the oracle's TGS and compliant models really are different models"""
+    a, b = Oracle(_tgs_cfg(1)), Oracle(abi.default_config(1))
+    act = np.full((1, 18), 0.3, np.float32)
+    for _ in range(20):
+        a.step(act); b.step(act)
+    assert np.abs(a.root_states - b.root_states).max() > 1e-4
