@@ -554,57 +554,54 @@ class A2CAgent:
         if act_noise is not None:
             env.external_action_noise = True
         try:
-            self._rollout_loop(cur, net, vrms, mb, F, fx, boot, pending, fold, env, act_noise, prelaunch, main, forked)
+            for n in range(self.horizon):
+                if self._policy_fwd is not None:
+                    # normaliser + 5 Linear + 3 ELU + sampling + neglogp + clamp + the rollout-buffer rows: one launch -- which also does the
+                    # PREVIOUS env step's bookkeeping (reward shaping, done flags, episode statistics): a rollout step is two launches
+                    self._policy_fwd.rollout_step(cur, net.sigma.detach(), fx["noise"][n], self.dones, vrms, mb["obs"][n], mb["dones"][n], mb["mu"][n],
+                                                  mb["val"][n], mb["act"][n], fx["env_act"], mb["neglogp"][n], mb["sigma"][n],
+                                                  prev_post=None if pending is None else F.RolloutPost.of(*pending), action_noise=act_noise)
+                    pending = None
+                else:
+                    x = self._f_obs_rms.normalize(cur, fx["obs_n"]) if self.normalize_input else cur
+                    with torch.autocast("cuda", dtype=torch.float16, enabled=self.mixed_precision and not self.half_path):
+                        mu, _logstd, value = net(x)
+                    if mu.dtype not in (torch.float16, torch.float32):
+                        mu, value = mu.float(), value.float()
+                    # fp32 rows of obs / dones / mu / de-normalised value + sampling + neglogp + clamp: one launch
+                    F.rollout_pre(mu.contiguous(), value.contiguous(), net.sigma.detach(), fx["noise"][n], cur, self.dones, vrms, mb["obs"][n], mb["dones"][n],
+                                  mb["mu"][n], mb["val"][n], mb["act"][n], fx["env_act"], mb["neglogp"][n], mb["sigma"][n])
+                if forked:
+                    main.wait_stream(self._side_stream)   # join: the randomisation kernel of this step ran beside the policy launch
+                    forked = False
+                obs_dict, rew, dones, infos = self.vec_env.step(fx["env_act"])
+                if prelaunch and n + 1 < self.horizon:
+                    self._side_stream.wait_stream(main)   # fork behind this env step
+                    with torch.cuda.stream(self._side_stream):
+                        env.dr_prelaunch()
+                    forked = True
+                post = (rew, dones, infos["time_outs"] if "time_outs" in infos else dones, mb["val"][n], self.reward_scale, self.gamma,
+                        boot and "time_outs" in infos, mb["rew"][n], self.dones, self.current_rewards, self.current_lengths, self.ep_stats)
+                if fold and n + 1 < self.horizon and self._env_buffers_persist(rew, dones, infos):
+                    pending = post   # rides in the next policy launch (the env's buffers keep this step's results until the next env step)
+                else:
+                    F.rollout_post(*post)
+                o = obs_dict["obs"]
+                if o.dtype == torch.float32 and o.is_contiguous() and o.device == self.obs.device:
+                    # the env's persistent buffer (vec_task.py _clipped_obs): valid until the next step().  Under a HIP graph this
+                    # branch is resolved ONCE, at capture: the replays read whatever address was seen then, so the env must hand back
+                    # the same buffer on every step (host-side pointer compare, no sync)
+                    if n == 0:
+                        self._env_obs_ptr = o.data_ptr()
+                    assert o.data_ptr() == self._env_obs_ptr, "the env returned a different observation buffer within one rollout"
+                    cur = o
+                else:
+                    self.obs.copy_(o); cur = self.obs
+            if cur is not self.obs:
+                self.obs.copy_(cur)
         finally:
             if act_noise is not None:
                 env.external_action_noise = False
-
-    def _rollout_loop(self, cur, net, vrms, mb, F, fx, boot, pending, fold, env, act_noise, prelaunch, main, forked):
-        for n in range(self.horizon):
-            if self._policy_fwd is not None:
-                # normaliser + 5 Linear + 3 ELU + sampling + neglogp + clamp + the rollout-buffer rows: one launch -- which also does the
-                # PREVIOUS env step's bookkeeping (reward shaping, done flags, episode statistics): a rollout step is two launches
-                self._policy_fwd.rollout_step(cur, net.sigma.detach(), fx["noise"][n], self.dones, vrms, mb["obs"][n], mb["dones"][n], mb["mu"][n],
-                                              mb["val"][n], mb["act"][n], fx["env_act"], mb["neglogp"][n], mb["sigma"][n],
-                                              prev_post=None if pending is None else F.RolloutPost.of(*pending), action_noise=act_noise)
-                pending = None
-            else:
-                x = self._f_obs_rms.normalize(cur, fx["obs_n"]) if self.normalize_input else cur
-                with torch.autocast("cuda", dtype=torch.float16, enabled=self.mixed_precision and not self.half_path):
-                    mu, _logstd, value = net(x)
-                if mu.dtype not in (torch.float16, torch.float32):
-                    mu, value = mu.float(), value.float()
-                # fp32 rows of obs / dones / mu / de-normalised value + sampling + neglogp + clamp: one launch
-                F.rollout_pre(mu.contiguous(), value.contiguous(), net.sigma.detach(), fx["noise"][n], cur, self.dones, vrms, mb["obs"][n], mb["dones"][n],
-                              mb["mu"][n], mb["val"][n], mb["act"][n], fx["env_act"], mb["neglogp"][n], mb["sigma"][n])
-            if forked:
-                main.wait_stream(self._side_stream)   # join: the randomisation kernel of this step ran beside the policy launch
-                forked = False
-            obs_dict, rew, dones, infos = self.vec_env.step(fx["env_act"])
-            if prelaunch and n + 1 < self.horizon:
-                self._side_stream.wait_stream(main)   # fork behind this env step
-                with torch.cuda.stream(self._side_stream):
-                    env.dr_prelaunch()
-                forked = True
-            post = (rew, dones, infos["time_outs"] if "time_outs" in infos else dones, mb["val"][n], self.reward_scale, self.gamma,
-                    boot and "time_outs" in infos, mb["rew"][n], self.dones, self.current_rewards, self.current_lengths, self.ep_stats)
-            if fold and n + 1 < self.horizon and self._env_buffers_persist(rew, dones, infos):
-                pending = post   # rides in the next policy launch (the env's buffers keep this step's results until the next env step)
-            else:
-                F.rollout_post(*post)
-            o = obs_dict["obs"]
-            if o.dtype == torch.float32 and o.is_contiguous() and o.device == self.obs.device:
-                # the env's persistent buffer (vec_task.py _clipped_obs): valid until the next step().  Under a HIP graph this
-                # branch is resolved ONCE, at capture: the replays read whatever address was seen then, so the env must hand back
-                # the same buffer on every step (host-side pointer compare, no sync)
-                if n == 0:
-                    self._env_obs_ptr = o.data_ptr()
-                assert o.data_ptr() == self._env_obs_ptr, "the env returned a different observation buffer within one rollout"
-                cur = o
-            else:
-                self.obs.copy_(o); cur = self.obs
-        if cur is not self.obs:
-            self.obs.copy_(cur)
 
     def _env_buffers_persist(self, rew, dones, infos):
         """The env hands back ITS OWN reward / reset / time-out buffers (fp32 / int64 on this device), the same ones on every step: then
