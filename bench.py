@@ -242,7 +242,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--num-envs", type=int, default=4096, help="envs per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--ppo-epochs", type=int, default=10, help="extra leg after the timed rollout: PPO epochs timed for the "
+    ap.add_argument("--ppo-epochs", type=int, default=30, help="extra leg after the timed rollout: PPO epochs timed for the "
                     "'PPO samples/s' half of BASELINE.json's metric (0 = skip)")
     ap.add_argument("--launch", choices=["python", "c"], default="python",
                     help="python: one bez_sim_step call per step from Python; c: bez_sim_step_many (C loop)")
