@@ -568,10 +568,23 @@ __global__ __launch_bounds__(ADAM_TB) void adam_fused_kernel(float* __restrict__
   __shared__ float red[2][ADAM_TB / 64];
   __shared__ unsigned int my_ticket;
   const int tid = threadIdx.x;
-  // ---- phase 2 first in program order (the loads are in flight while phase 1 streams the gradient)
+  // ---- phase 2 first in program order (the loads are in flight while phase 1 runs)
   const float scale_v = scale ? scale[0] : 1.0f;
   const float lr_v = lr[0];
   const float step_v = steps[0];
+  // ... and this thread's slice of the update (at most ADAM_PER elements: gradient, parameter, moments, packed-copy slots): nothing of
+  // it depends on the norm, so the loads are issued before the reduction and overlap it
+  constexpr int ADAM_PER = 2;
+  float gq[ADAM_PER], pq[ADAM_PER], mq[ADAM_PER], vq[ADAM_PER];
+  int32_t ia[ADAM_PER], ib[ADAM_PER];
+  const int64_t stride = (int64_t)gridDim.x * ADAM_TB, first = (int64_t)blockIdx.x * ADAM_TB + tid;
+#pragma unroll
+  for (int k = 0; k < ADAM_PER; ++k) {
+    const int64_t i = first + k * stride;
+    const bool in = i < n;
+    gq[k] = in ? g[i] : 0.f; pq[k] = in ? p[i] : 0.f; mq[k] = in ? m[i] : 0.f; vq[k] = in ? v[i] : 0.f;
+    ia[k] = (in && ex.packed) ? ex.map_a[i] : -1; ib[k] = (in && ex.packed) ? ex.map_b[i] : -1;
+  }
   // ---- phase 1
   const float inv = 1.0f / scale_v;
   float s2 = 0.f, bad = 0.f;
@@ -598,13 +611,9 @@ __global__ __launch_bounds__(ADAM_TB) void adam_fused_kernel(float* __restrict__
   }
   s2 = wave_sum(s2); bad = wave_sum(bad);
   if ((tid & 63) == 0) { red[0][tid >> 6] = s2; red[1][tid >> 6] = bad; }
-  // the ticket: after this workgroup's reads of scale / lr / steps have RETURNED (they were used above / are waited for here)
-  if (tid == 0) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    float keep = lr_v + step_v;  // (both values are live in registers before the add is issued)
-    asm volatile("" : "+v"(keep));
-    my_ticket = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
+  // every wave holds scale / lr / step count in registers BEFORE this barrier (the asm makes them operands here), so when wave 0 draws
+  // the workgroup's ticket below, no wave of this workgroup still has one of those loads outstanding
+  asm volatile("" :: "v"(scale_v), "v"(lr_v), "v"(step_v));
   __syncthreads();
   float norm2 = 0.f, nbad = 0.f;
 #pragma unroll
@@ -616,7 +625,28 @@ __global__ __launch_bounds__(ADAM_TB) void adam_fused_kernel(float* __restrict__
     const float t = step_v + 1.0f;
     const float bc1 = 1.0f - powf(beta1, t), bc2 = 1.0f - powf(beta2, t);
     const float rs2 = 1.0f / sqrtf(bc2), step_size = lr_v / bc1;
-    for (int64_t i = (int64_t)blockIdx.x * ADAM_TB + tid; i < n; i += (int64_t)gridDim.x * ADAM_TB) {
+#pragma unroll
+    for (int k = 0; k < ADAM_PER; ++k) {
+      const int64_t i = first + k * stride;
+      if (i < n) {
+        float x = gq[k] * inv * coef;
+        float w = pq[k];
+        if (weight_decay != 0.f) x = fmaf(weight_decay, w, x);
+        const float mi = fmaf(beta1, mq[k], (1.0f - beta1) * x);
+        const float vi = fmaf(beta2, vq[k], (1.0f - beta2) * x * x);
+        m[i] = mi; v[i] = vi;
+        const float denom = sqrtf(vi) * rs2 + eps;
+        w -= step_size * (mi / denom);
+        p[i] = w;
+        if (p16) {
+          const __half h = __float2half(w);
+          p16[i] = h;
+          if (ia[k] >= 0) ex.packed[ia[k]] = h;
+          if (ib[k] >= 0) ex.packed[ib[k]] = h;
+        }
+      }
+    }
+    for (int64_t i = first + ADAM_PER * stride; i < n; i += stride) {   // (only when the grid was capped: n > 256 x 1024 x ADAM_PER)
       float x = g[i] * inv * coef;
       float w = p[i];
       if (weight_decay != 0.f) x = fmaf(weight_decay, w, x);
@@ -632,6 +662,12 @@ __global__ __launch_bounds__(ADAM_TB) void adam_fused_kernel(float* __restrict__
         if (ex.packed) { const int32_t a = ex.map_a[i], b = ex.map_b[i]; if (a >= 0) ex.packed[a] = h; if (b >= 0) ex.packed[b] = h; }
       }
     }
+  }
+  // the ticket: drawn at the END of the workgroup's work -- all that matters is that its reads of scale / lr / steps have returned
+  // (they were consumed above); the add's round trip then delays nobody but the committing workgroup
+  if (tid == 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    my_ticket = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   // ---- extra: the next minibatch's moments into the input normaliser (parallel-variance update, as rms_apply_kernel)
   if (blockIdx.x == 0 && ex.rms_mom) {
@@ -651,6 +687,7 @@ __global__ __launch_bounds__(ADAM_TB) void adam_fused_kernel(float* __restrict__
     if (tid == 0) ex.rms_count[0] = tot;
   }
   // ---- phase 4
+  __syncthreads();
   if (my_ticket != gridDim.x - 1) return;
   if (tid == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (tid < tail.n) *tail.dst[tid] += *tail.src[tid] * tail.scale[tid];
