@@ -174,7 +174,10 @@ BEZ_DEV ChainDyn load_chain_dyn(const Params& P, int e) {
   ChainDyn D; D.mu = P.mu; D.g = mk(P.g[0], P.g[1], P.g[2]);
   if (DR) {
     if (P.dr_friction) D.mu = P.dr_friction[e];
-    if (P.dr_gravity) D.g = mk(P.dr_gravity[(size_t)e * 3], P.dr_gravity[(size_t)e * 3 + 1], P.dr_gravity[(size_t)e * 3 + 2]);
+    if (P.dr_gravity) {
+      if (P.dr_gravity_uniform) D.g = mk(P.dr_gravity[0], P.dr_gravity[1], P.dr_gravity[2]);   // uniform address: scalar loads, no VGPR per lane
+      else D.g = mk(P.dr_gravity[(size_t)e * 3], P.dr_gravity[(size_t)e * 3 + 1], P.dr_gravity[(size_t)e * 3 + 2]);
+    }
   }
   return D;
 }
@@ -194,11 +197,16 @@ BEZ_DEV void load_joints(const Params& P, int e, float* q, float* qd, float* kps
     q[i] = st[(size_t)(F_Q + d0 + i) * n + e]; qd[i] = st[(size_t)(F_QD + d0 + i) * n + e];
     kps[i] = 1.f; kds[i] = 1.f; ms[i] = 1.f; lo[i] = (float)BEZ_DOF_LOWER[d0 + i]; hi[i] = (float)BEZ_DOF_UPPER[d0 + i];
     if (DR) {
-      if (P.dr_kp) kps[i] = P.dr_kp[(size_t)e * BEZ_ND + d0 + i];
-      if (P.dr_kd) kds[i] = P.dr_kd[(size_t)e * BEZ_ND + d0 + i];
+      if (P.dr_pack) {   // one 16-byte load per joint instead of four 4-byte ones (the same numbers: bez_sim.hip keeps the pack current)
+        const float4 v = P.dr_pack[(size_t)e * BEZ_ND + d0 + i];
+        kps[i] = v.x; kds[i] = v.y; lo[i] = v.z; hi[i] = v.w;
+      } else {
+        if (P.dr_kp) kps[i] = P.dr_kp[(size_t)e * BEZ_ND + d0 + i];
+        if (P.dr_kd) kds[i] = P.dr_kd[(size_t)e * BEZ_ND + d0 + i];
+        if (P.dr_lower) lo[i] = P.dr_lower[(size_t)e * BEZ_ND + d0 + i];
+        if (P.dr_upper) hi[i] = P.dr_upper[(size_t)e * BEZ_ND + d0 + i];
+      }
       if (P.dr_mass) ms[i] = P.dr_mass[(size_t)e * BEZ_NL + FIRST + i];
-      if (P.dr_lower) lo[i] = P.dr_lower[(size_t)e * BEZ_ND + d0 + i];
-      if (P.dr_upper) hi[i] = P.dr_upper[(size_t)e * BEZ_ND + d0 + i];
     }
   }
 }
@@ -212,11 +220,16 @@ BEZ_DEV void load_joint_params(const Params& P, int e, float* kps, float* kds, f
     constexpr int d0 = FIRST - 1;
     kps[i] = 1.f; kds[i] = 1.f; ms[i] = 1.f; lo[i] = (float)BEZ_DOF_LOWER[d0 + i]; hi[i] = (float)BEZ_DOF_UPPER[d0 + i];
     if (DR) {
-      if (P.dr_kp) kps[i] = P.dr_kp[(size_t)e * BEZ_ND + d0 + i];
-      if (P.dr_kd) kds[i] = P.dr_kd[(size_t)e * BEZ_ND + d0 + i];
+      if (P.dr_pack) {   // one 16-byte load per joint instead of four 4-byte ones (the same numbers: bez_sim.hip keeps the pack current)
+        const float4 v = P.dr_pack[(size_t)e * BEZ_ND + d0 + i];
+        kps[i] = v.x; kds[i] = v.y; lo[i] = v.z; hi[i] = v.w;
+      } else {
+        if (P.dr_kp) kps[i] = P.dr_kp[(size_t)e * BEZ_ND + d0 + i];
+        if (P.dr_kd) kds[i] = P.dr_kd[(size_t)e * BEZ_ND + d0 + i];
+        if (P.dr_lower) lo[i] = P.dr_lower[(size_t)e * BEZ_ND + d0 + i];
+        if (P.dr_upper) hi[i] = P.dr_upper[(size_t)e * BEZ_ND + d0 + i];
+      }
       if (P.dr_mass) ms[i] = P.dr_mass[(size_t)e * BEZ_NL + FIRST + i];
-      if (P.dr_lower) lo[i] = P.dr_lower[(size_t)e * BEZ_ND + d0 + i];
-      if (P.dr_upper) hi[i] = P.dr_upper[(size_t)e * BEZ_ND + d0 + i];
     }
   }
 }

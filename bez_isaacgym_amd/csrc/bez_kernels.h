@@ -82,6 +82,8 @@ struct Params {
   const float* dr_kd;        // (N,18)   or null
   const float* dr_mass;      // (N,19)   or null
   const float* dr_gravity;   // (N,3)    or null
+  int dr_gravity_uniform;    // every row of dr_gravity is the same (the randomisation's one draw per sim, vec_task.py:620-632): read row 0 as a scalar
+  const float4* dr_pack;     // (N,18) {kp scale, kd scale, lower, upper} = dr_kp / dr_kd / dr_lower / dr_upper in one 16-byte load per joint, or null
   const float* dr_lower;     // (N,18)   or null: physical joint limits (targets keep the model's, kick_env.py:393-400)
   const float* dr_upper;     // (N,18)   or null
   unsigned long long* stamps; // diagnostic builds only (-DBEZ_WS_STAMPS): s_memtime per role / phase of workgroup 0

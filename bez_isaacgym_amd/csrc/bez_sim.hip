@@ -63,6 +63,8 @@ struct BezSim {
   int64_t* randomize = nullptr;   // (N) randomize_buf, vec_task.py:247
   DrState* dr_state = nullptr;  // device: frame counter, frame of the last non-env randomisation, noise parameters
   DrSnap* dr_snap = nullptr;    // device: the action-noise parameters / frame the NEXT step's action noise uses (written by the step kernels)
+  float4* dr_pack = nullptr;    // device (N,18): {kp scale, kd scale, lower, upper} per joint, kept equal to the four dr[] arrays (null while none of them exists)
+  bool gravity_uniform = false; // every row of dr[GRAVITY] holds the same vector (written by the randomisation kernel, not by the user)
   bool dr_prelaunched = false;  // bez_sim_dr_prelaunch ran the randomisation kernel of the coming step already
   float* goal_draw_dev = nullptr;            // [2] the goal of the current post-physics reset (bez_walk / bez_orient)
   unsigned long long* post_calls_dev = nullptr;  // device-resident call counter keying that draw (HIP-graph replay safe)
@@ -130,6 +132,7 @@ struct DrArgs {
   DrState* st;
   DrSnap* snap;
   float *friction, *kp, *kd, *lower, *upper, *gravity_rows;
+  float4* pack;
 };
 __device__ inline float dr_uniform(uint64_t seed, int64_t key, uint32_t key2, uint32_t tag, int k) {
   uint32_t c[4] = {(uint32_t)key, (uint32_t)((uint64_t)key >> 32), key2, tag + (uint32_t)(k >> 2)};
@@ -149,10 +152,46 @@ __device__ inline float dr_normal(float u1, float u2) { return sqrtf(-2.0f * log
 constexpr uint32_t DR_TAG_ENV = 0x44520000u, DR_TAG_GRAVITY = 0x47520000u;
 constexpr int DR_THREADS = 1024;
 
+// the per-env redraw of ONE joint (or, j < 0, of the env's friction): the words of the env's Philox stream it needs, as the oracle draws them
+__device__ inline void dr_redraw(const DrArgs& A, int e, int j, unsigned long long frame) {
+  const int64_t genv = A.env_off + e;
+  const uint32_t ep = A.episode[e];
+  if (j < 0) {
+    if (A.c.friction.enabled) {
+      float u = dr_uniform(A.seed, genv, ep, DR_TAG_ENV, 0);
+      if (A.c.friction_buckets > 1) u = rintf(u * (float)(A.c.friction_buckets - 1)) / (float)(A.c.friction_buckets - 1);
+      A.friction[e] = A.plane_friction * dr_scaling(A.c.friction, dr_sched(A.c.friction, frame), u);
+    }
+    return;
+  }
+  const size_t o = (size_t)e * BEZ_ND + j;
+  float kp = A.kp ? A.kp[o] : 1.f, kd = A.kd ? A.kd[o] : 1.f, lo = A.lower ? A.lower[o] : (float)BEZ_DOF_LOWER[j], hi = A.upper ? A.upper[o] : (float)BEZ_DOF_UPPER[j];
+  if (A.c.stiffness.enabled) A.kp[o] = kp = dr_scaling(A.c.stiffness, dr_sched(A.c.stiffness, frame), dr_uniform(A.seed, genv, ep, DR_TAG_ENV, 1 + j));
+  if (A.c.damping.enabled) A.kd[o] = kd = dr_scaling(A.c.damping, dr_sched(A.c.damping, frame), dr_uniform(A.seed, genv, ep, DR_TAG_ENV, 19 + j));
+  if (A.c.lower.enabled) {
+    float sc = dr_sched(A.c.lower, frame), z = dr_normal(dr_uniform(A.seed, genv, ep, DR_TAG_ENV, 37 + 2 * j), dr_uniform(A.seed, genv, ep, DR_TAG_ENV, 38 + 2 * j));
+    A.lower[o] = lo = (float)BEZ_DOF_LOWER[j] + fmaf(z, A.c.lower.b * sc, A.c.lower.a * sc);
+  }
+  if (A.c.upper.enabled) {
+    float sc = dr_sched(A.c.upper, frame), z = dr_normal(dr_uniform(A.seed, genv, ep, DR_TAG_ENV, 73 + 2 * j), dr_uniform(A.seed, genv, ep, DR_TAG_ENV, 74 + 2 * j));
+    A.upper[o] = hi = (float)BEZ_DOF_UPPER[j] + fmaf(z, A.c.upper.b * sc, A.c.upper.a * sc);
+  }
+  if (A.pack) A.pack[o] = make_float4(kp, kd, lo, hi);   // the step kernel's one-load-per-joint copy of the four values
+}
+
+constexpr int DR_LIST = 8192;   // envs whose redraw the workgroup shares out (more than that in one step: their own thread does it)
 __global__ void __launch_bounds__(DR_THREADS) dr_kernel(DrArgs A) {
+  __shared__ int list[DR_LIST];
+  __shared__ int nlist;
   const unsigned long long frame = A.first ? 0ull : A.st->frame + 1;   // gym.get_frame_count: this step's simulate has run
   const unsigned long long last_rand = A.st->last_rand;
+  if (threadIdx.x == 0) nlist = 0;
+  __syncthreads();
   int any = 0;
+  // pass 1: the clocks of every env (thread t looks after envs t, t + 1024, ...); an env that redraws goes on the list.  A redraw is
+  // 109 words of the env's Philox stream -- ~7 000 instructions if its own thread does it, and with 4096 envs some thread has one in
+  // nearly every step once `frequency` frames have passed (the kernel then takes 20 us instead of 6) -- so pass 2 hands every (env, joint)
+  // of the list to a thread of its own.  The draws are keyed by (seed, global env id, episode, word): who computes them changes nothing.
   for (int e = threadIdx.x; e < A.n; e += DR_THREADS) {
     long long rb = A.first ? 0 : A.randomize[e] + 1;   // kick_env.py:430
     bool draw = A.first != 0;
@@ -162,26 +201,13 @@ __global__ void __launch_bounds__(DR_THREADS) dr_kernel(DrArgs A) {
     }
     A.randomize[e] = rb;
     if (!draw) continue;
-    const int64_t genv = A.env_off + e;
-    const uint32_t ep = A.episode[e];
-    if (A.c.friction.enabled) {
-      float u = dr_uniform(A.seed, genv, ep, DR_TAG_ENV, 0);
-      if (A.c.friction_buckets > 1) u = rintf(u * (float)(A.c.friction_buckets - 1)) / (float)(A.c.friction_buckets - 1);
-      A.friction[e] = A.plane_friction * dr_scaling(A.c.friction, dr_sched(A.c.friction, frame), u);
-    }
-    for (int j = 0; j < BEZ_ND; ++j) {
-      if (A.c.stiffness.enabled) A.kp[(size_t)e * BEZ_ND + j] = dr_scaling(A.c.stiffness, dr_sched(A.c.stiffness, frame), dr_uniform(A.seed, genv, ep, DR_TAG_ENV, 1 + j));
-      if (A.c.damping.enabled) A.kd[(size_t)e * BEZ_ND + j] = dr_scaling(A.c.damping, dr_sched(A.c.damping, frame), dr_uniform(A.seed, genv, ep, DR_TAG_ENV, 19 + j));
-      if (A.c.lower.enabled) {
-        float sc = dr_sched(A.c.lower, frame), z = dr_normal(dr_uniform(A.seed, genv, ep, DR_TAG_ENV, 37 + 2 * j), dr_uniform(A.seed, genv, ep, DR_TAG_ENV, 38 + 2 * j));
-        A.lower[(size_t)e * BEZ_ND + j] = (float)BEZ_DOF_LOWER[j] + fmaf(z, A.c.lower.b * sc, A.c.lower.a * sc);
-      }
-      if (A.c.upper.enabled) {
-        float sc = dr_sched(A.c.upper, frame), z = dr_normal(dr_uniform(A.seed, genv, ep, DR_TAG_ENV, 73 + 2 * j), dr_uniform(A.seed, genv, ep, DR_TAG_ENV, 74 + 2 * j));
-        A.upper[(size_t)e * BEZ_ND + j] = (float)BEZ_DOF_UPPER[j] + fmaf(z, A.c.upper.b * sc, A.c.upper.a * sc);
-      }
-    }
+    const int slot = atomicAdd(&nlist, 1);
+    if (slot < DR_LIST) list[slot] = e;
+    else for (int j = -1; j < BEZ_ND; ++j) dr_redraw(A, e, j, frame);
   }
+  __syncthreads();
+  const int nl = nlist < DR_LIST ? nlist : DR_LIST;
+  for (int idx = threadIdx.x; idx < nl * (BEZ_ND + 1); idx += DR_THREADS) dr_redraw(A, list[idx / (BEZ_ND + 1)], idx % (BEZ_ND + 1) - 1, frame);
   any = __syncthreads_or(any);   // also orders every thread's read of A.st before thread 0's update below
   const bool nonenv = A.first || (any && frame - last_rand >= (unsigned long long)A.c.frequency);   // vec_task.py:524,532-533
   if (nonenv && A.c.gravity.enabled) {   // one draw for the whole sim (sim_params, vec_task.py:620-632), keyed by the frame
@@ -219,6 +245,26 @@ __global__ void dr_noise_kernel(const float* x, float* y, long long n, const DrS
   for (int k = 0; k < 4; ++k) if (i4 * 4 + k < n) y[i4 * 4 + k] = x[i4 * 4 + k] + fmaf(z[k], sd, mean);
 }
 
+__global__ void dr_repack_kernel(float4* pack, const float* kp, const float* kd, const float* lower, const float* upper, size_t total) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int j = (int)(i % BEZ_ND);
+  pack[i] = make_float4(kp ? kp[i] : 1.f, kd ? kd[i] : 1.f, lower ? lower[i] : (float)BEZ_DOF_LOWER[j], upper ? upper[i] : (float)BEZ_DOF_UPPER[j]);
+}
+// (re)builds the packed copy from the four per-env arrays; called whenever one of them was written from outside the randomisation kernel
+int repack_dr(BezSim* s, hipStream_t stream) {
+  const bool any = s->dr[BEZ_PARAM_KP_SCALE] || s->dr[BEZ_PARAM_KD_SCALE] || s->dr[BEZ_PARAM_DOF_LOWER] || s->dr[BEZ_PARAM_DOF_UPPER];
+  if (!any) {
+    if (s->dr_pack) { if (hipStreamSynchronize(stream) != hipSuccess) return -2; (void)hipFree(s->dr_pack); s->dr_pack = nullptr; }
+    return 0;
+  }
+  const size_t total = (size_t)s->n * BEZ_ND;
+  if (!s->dr_pack && hipMalloc((void**)&s->dr_pack, total * sizeof(float4)) != hipSuccess) return -4;
+  hipLaunchKernelGGL(dr_repack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, s->dr_pack, s->dr[BEZ_PARAM_KP_SCALE], s->dr[BEZ_PARAM_KD_SCALE],
+                     s->dr[BEZ_PARAM_DOF_LOWER], s->dr[BEZ_PARAM_DOF_UPPER], total);
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
 void launch_dr(BezSim* s, bool first, hipStream_t stream) {
   DrArgs A;
   A.c = s->drc; A.n = s->n; A.first = first ? 1 : 0; A.seed = s->cfg.seed; A.env_off = s->cfg.env_id_offset;
@@ -227,6 +273,7 @@ void launch_dr(BezSim* s, bool first, hipStream_t stream) {
   A.reset = s->reset; A.episode = s->episode; A.randomize = s->randomize; A.st = s->dr_state; A.snap = s->dr_snap;
   A.friction = s->dr[BEZ_PARAM_FRICTION]; A.kp = s->dr[BEZ_PARAM_KP_SCALE]; A.kd = s->dr[BEZ_PARAM_KD_SCALE];
   A.lower = s->dr[BEZ_PARAM_DOF_LOWER]; A.upper = s->dr[BEZ_PARAM_DOF_UPPER]; A.gravity_rows = s->dr[BEZ_PARAM_GRAVITY];
+  A.pack = s->dr_pack;
   dr_kernel<<<1, DR_THREADS, 0, stream>>>(A);
 }
 
@@ -261,6 +308,7 @@ Params make_params(const BezSim* s, const float* actions) {
   P.dr_friction = s->dr[BEZ_PARAM_FRICTION]; P.dr_kp = s->dr[BEZ_PARAM_KP_SCALE]; P.dr_kd = s->dr[BEZ_PARAM_KD_SCALE];
   P.dr_mass = s->dr[BEZ_PARAM_MASS_SCALE]; P.dr_gravity = s->dr[BEZ_PARAM_GRAVITY];
   P.dr_lower = s->dr[BEZ_PARAM_DOF_LOWER]; P.dr_upper = s->dr[BEZ_PARAM_DOF_UPPER];
+  P.dr_pack = s->dr_pack; P.dr_gravity_uniform = (s->dr[BEZ_PARAM_GRAVITY] && s->gravity_uniform) ? 1 : 0;
   P.stamps = s->stamps;
   return P;
 }
@@ -525,7 +573,7 @@ int bez_sim_destroy(BezSim* s) {
   if (!s) return 0;
   (void)hipSetDevice(s->device);
   void* bufs[] = {s->state, s->obs, s->rew, s->reset, s->progress, s->timeout, s->episode, s->root_states, s->dof_state,
-                  s->rigid_body, s->contact, s->targets_aos, s->prev_aos, s->feet_aos, s->goal_aos, s->goal_draw_dev, s->post_calls_dev, s->randomize, s->dr_state, s->dr_snap};
+                  s->rigid_body, s->contact, s->targets_aos, s->prev_aos, s->feet_aos, s->goal_aos, s->goal_draw_dev, s->post_calls_dev, s->randomize, s->dr_state, s->dr_snap, s->dr_pack};
   for (void* b : bufs) if (b) (void)hipFree(b);
   for (int i = 0; i < BEZ_PARAM_COUNT; ++i) if (s->dr[i]) (void)hipFree(s->dr[i]);
   if (s->ev0) (void)hipEventDestroy(s->ev0);
@@ -750,13 +798,17 @@ int bez_sim_reset_indexed(BezSim* s, const int32_t* env_ids_dev, int32_t count, 
 int bez_sim_set_env_params(BezSim* s, int param, const float* values_dev, void* stream) {
   if (!s || param < 0 || param >= BEZ_PARAM_COUNT) return fail(s, -1, "bez_sim_set_env_params: bad argument");
   static const int width[BEZ_PARAM_COUNT] = {1, BEZ_ND, BEZ_ND, BEZ_NL, 3, BEZ_ND, BEZ_ND};
+  const bool packed = param == BEZ_PARAM_KP_SCALE || param == BEZ_PARAM_KD_SCALE || param == BEZ_PARAM_DOF_LOWER || param == BEZ_PARAM_DOF_UPPER;
+  if (param == BEZ_PARAM_GRAVITY) s->gravity_uniform = false;   // rows written from outside may differ from env to env
   if (!values_dev) {
     if (s->dr[param]) { HIP_TRY(s, hipStreamSynchronize((hipStream_t)stream)); (void)hipFree(s->dr[param]); s->dr[param] = nullptr; }
+    if (packed && repack_dr(s, (hipStream_t)stream)) return fail(s, -2, "bez_sim_set_env_params: repack");
     return 0;
   }
   size_t bytes = (size_t)s->n * width[param] * sizeof(float);
   if (!s->dr[param]) HIP_TRY(s, hipMalloc((void**)&s->dr[param], bytes));
   HIP_TRY(s, hipMemcpyAsync(s->dr[param], values_dev, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  if (packed && repack_dr(s, (hipStream_t)stream)) return fail(s, -2, "bez_sim_set_env_params: repack");
   return 0;
 }
 
@@ -846,7 +898,12 @@ int bez_sim_set_randomization(BezSim* s, const BezDrConfig* dr, void* stream_) {
   }
   HIP_TRY(s, hipMemsetAsync(s->dr_state, 0, sizeof(DrState), stream));
   s->dr_on = true;
+  if (repack_dr(s, stream)) return fail(s, -2, "bez_sim_set_randomization: repack");   // (the randomisation kernel keeps it current from here on)
+  // gravity rows: from now on written by the randomisation kernel only, one vector for the whole sim.  (Rows that were set per env
+  // BEFORE stay as they are until the first gravity redraw: only then are they known to be uniform -- the kernel says when.)
+  s->gravity_uniform = false;
   launch_dr(s, true, stream);   // first_randomization (vec_task.py:521-523): every env, frame 0
+  if (dr->gravity.enabled) s->gravity_uniform = true;   // the first randomisation redraws gravity for every env (A.first => nonenv)
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(s, -2, "dr_kernel launch", e);
   return 0;
