@@ -10,6 +10,10 @@
 
 namespace bez {
 
+// device-resident state of the domain randomisation (bez_sim.hip dr_kernel): frame counter, frame of the last non-env randomisation,
+// noise parameters [obs mean, obs std, action mean, action std]
+struct DrState { unsigned long long frame, last_rand; float noise[4]; };
+
 // What the action-noise lambda of the NEXT control step needs (vec_task.py:586-592: applied to the actions before that step): the
 // action-noise parameters and the frame as the randomisation in front of THIS step left them.  Written by the step kernel's POST, read
 // by the consumer that adds the noise (bez_sim_add_dr_noise(which = 1) or a policy launch: BezActionNoiseSource) -- a copy, so that

@@ -40,9 +40,7 @@ constexpr int LDS_HIT = LDS_P3 + BEZ_ND * P3_STRIDE;  // ground-point records, 8
 constexpr int HIT_STRIDE = 8;                       // x(3) fn0 kn ct ftx0 fty0
 constexpr int LDS_SLOTS = LDS_HIT + BEZ_NPT * HIT_STRIDE;
 
-// device-resident state of the domain randomisation (bez_sim.hip dr_kernel): frame counter, frame of the last non-env randomisation,
-// noise parameters [obs mean, obs std, action mean, action std]
-struct DrState { unsigned long long frame, last_rand; float noise[4]; };
+// (DrState, the device-resident state of the domain randomisation: bez_dr_noise.h)
 // (DrSnap, the action-noise snapshot the step kernels keep: bez_dr_noise.h)
 
 struct Params {

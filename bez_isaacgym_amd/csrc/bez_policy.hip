@@ -17,11 +17,13 @@
 #include <hip/hip_fp16.h>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <cstring>
 
 #include <type_traits>
 
 #include "../../include/bez_sim.h"
 #include "bez_dr_noise.h"
+#include "bez_dr_step.h"
 
 namespace {
 
@@ -49,6 +51,8 @@ struct PolicyArgs {
   BezPpoRolloutPost post;
   // ... and, behind it, the env's action-noise lambda of the domain randomisation (vec_task.py:586-592; an.snap_dev == null: none)
   BezPpoActionNoise an;
+  // ... and, as ONE EXTRA workgroup of the launch, the randomisation of the coming env step (bez_sim_dr_step_args; dr_on == 0: none)
+  int dr_on; bez::dr::DrArgs dr;
   // training forward (mode 2): what the backward pass needs -- the fp16 input of the first Linear and every ELU output, row-major
   _Float16* x0_out; _Float16* act_out[PF_MAXL];
   int packed;  // weights are fragment-major copies (see gemm_col_block_packed): w[L] and w_mu (= the packed [mu; value] block)
@@ -227,6 +231,15 @@ __global__ __launch_bounds__(PF_WAVES * 64) void policy_forward_kernel(PolicyArg
   __shared__ __attribute__((aligned(16))) _Float16 t0[PF_ROWS][LD0];
   __shared__ __attribute__((aligned(16))) _Float16 t1[PF_ROWS][LD1];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (ROLL && a.dr_on && blockIdx.x == gridDim.x - 1) {
+    // the extra workgroup: the coming env step's domain randomisation (bez_dr_step.h), beside the forward pass of the others.  It reads the
+    // envs' reset flags / episode counters and writes the randomisation's own state and the per-env parameter rows -- nothing the other
+    // workgroups touch (their action noise comes from the snapshot the last step kernel left, not from the state updated here).
+    int* scratch = reinterpret_cast<int*>(&t0[0][0]);
+    constexpr int cap = (int)(sizeof(t0) / sizeof(int)) - 1;
+    bez::dr::dr_step(a.dr, scratch + 1, cap, scratch);
+    return;
+  }
   const int64_t row0 = (int64_t)blockIdx.x * PF_ROWS;
   const int nrow = (int)((a.n - row0) < (int64_t)PF_ROWS ? (a.n - row0) : (int64_t)PF_ROWS);
   PF_STAMP(0);
@@ -545,6 +558,7 @@ static int fill_args(PolicyArgs& a, const float* obs_dev, int64_t n, int32_t num
   a.mb_obs = a.mb_dones = a.mb_mu = a.mb_val = a.act = a.act_env = a.neglogp = a.sigma = nullptr;
   a.post = BezPpoRolloutPost{};
   a.an = BezPpoActionNoise{};
+  a.dr_on = 0;
   a.x0_out = nullptr;
   for (int i = 0; i < PF_MAXL; ++i) a.act_out[i] = nullptr;
   a.packed = 0;
@@ -573,7 +587,8 @@ extern "C" int bez_ppo_policy_rollout_step(const float* obs_dev, int64_t n, int3
                                            const void* value_w_f16_dev, const void* value_b_f16_dev, const float* logstd_dev, const float* noise_dev,
                                            const float* dones_dev, const double* value_mean_dev, const double* value_var_dev, float value_eps, float* mb_obs_dev,
                                            float* mb_dones_dev, float* mb_mu_dev, float* mb_val_dev, float* actions_dev, float* env_actions_dev,
-                                           float* neglogp_dev, float* sigma_dev, int32_t weights_packed, const BezPpoRolloutPost* prev_post, const BezPpoActionNoise* action_noise, void* stream) {
+                                           float* neglogp_dev, float* sigma_dev, int32_t weights_packed, const BezPpoRolloutPost* prev_post, const BezPpoActionNoise* action_noise,
+                                           const void* dr_step, void* stream) {
   PolicyArgs a;
   if (prev_post && (!prev_post->rew || !prev_post->reset || !prev_post->timeouts || !prev_post->prev_values || !prev_post->shaped || !prev_post->dones_f ||
                     !prev_post->cur_rew || !prev_post->cur_len || !prev_post->ep_stats)) return -1;
@@ -586,8 +601,11 @@ extern "C" int bez_ppo_policy_rollout_step(const float* obs_dev, int64_t n, int3
   a.neglogp = neglogp_dev; a.sigma = sigma_dev; a.packed = weights_packed;
   if (prev_post) a.post = *prev_post;
   if (action_noise && action_noise->snap_dev) a.an = *action_noise;
-  if (weights_packed) hipLaunchKernelGGL((policy_forward_kernel<1, PF_LD, PF_LD, true>), dim3((unsigned)((n + PF_ROWS - 1) / PF_ROWS)), dim3(PF_WAVES * 64), 0, (hipStream_t)stream, a);
-  else hipLaunchKernelGGL((policy_forward_kernel<1, PF_LD, PF_LD, false>), dim3((unsigned)((n + PF_ROWS - 1) / PF_ROWS)), dim3(PF_WAVES * 64), 0, (hipStream_t)stream, a);
+  static_assert(sizeof(bez::dr::DrArgs) <= BEZ_DR_STEP_BYTES, "BezPpoDrStep blob of the C ABI too small");
+  if (dr_step) { std::memcpy(&a.dr, dr_step, sizeof(a.dr)); a.dr_on = 1; if (a.dr.n <= 0 || !a.dr.st || a.dr.first) return -1; }
+  const unsigned grid = (unsigned)((n + PF_ROWS - 1) / PF_ROWS) + (dr_step ? 1u : 0u);   // + the randomisation workgroup
+  if (weights_packed) hipLaunchKernelGGL((policy_forward_kernel<1, PF_LD, PF_LD, true>), dim3(grid), dim3(PF_WAVES * 64), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL((policy_forward_kernel<1, PF_LD, PF_LD, false>), dim3(grid), dim3(PF_WAVES * 64), 0, (hipStream_t)stream, a);
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 

@@ -536,14 +536,17 @@ class A2CAgent:
         pending = None  # rollout_post arguments of the env step whose bookkeeping has not run yet
         fold = self._policy_fwd is not None and self.cfg.get("fold_rollout_post", True)
         # a domain-randomised env at full speed (BASELINE config 5): (a) its action-noise lambda is added by the policy launch itself
-        # (the same bits: bez_sim_action_noise_source); (b) `dr_prelaunch: True` launches the randomisation kernel in front of the NEXT
-        # env step right behind THIS one on a side stream, beside the next policy launch.  (b) is OFF by default: measured in the
-        # replayed HIP graph each fork / join pair costs more (~14 us) than the 6 us kernel it hides (6.12 vs 5.68 ms per epoch)
+        # (the same bits: bez_sim_action_noise_source); (b) the randomisation of the coming env step runs as ONE EXTRA WORKGROUP of the
+        # policy launch (bez_sim_dr_step_args: it touches nothing the forward pass reads) instead of a 6-7 us launch of its own in front of
+        # the step; (c) `dr_prelaunch: True` would instead launch that kernel early on a side stream -- kept as an option, OFF: in the
+        # replayed HIP graph each fork / join pair costs more (~14 us) than the kernel it hides (6.12 vs 5.68 ms per epoch)
         env = getattr(self.vec_env, "env", self.vec_env)
         act_noise = None
         if self._policy_fwd is not None and self.cfg.get("fold_action_noise", True) and hasattr(env, "action_noise_source"):
             src = env.action_noise_source()
             act_noise = None if src is None else F.ActionNoise(*src)
+        fold_dr = bool(self._policy_fwd is not None and self.cfg.get("fold_dr_step", True) and hasattr(env, "dr_step_args") and getattr(env, "randomize", False)
+                       and not self.cfg.get("dr_prelaunch", False))
         prelaunch = bool(self.cfg.get("dr_prelaunch", False) and hasattr(env, "dr_prelaunch") and getattr(env, "randomize", False)
                          and not getattr(env, "first_randomization", True))
         if prelaunch and getattr(self, "_side_stream", None) is None:
@@ -560,7 +563,8 @@ class A2CAgent:
                     # PREVIOUS env step's bookkeeping (reward shaping, done flags, episode statistics): a rollout step is two launches
                     self._policy_fwd.rollout_step(cur, net.sigma.detach(), fx["noise"][n], self.dones, vrms, mb["obs"][n], mb["dones"][n], mb["mu"][n],
                                                   mb["val"][n], mb["act"][n], fx["env_act"], mb["neglogp"][n], mb["sigma"][n],
-                                                  prev_post=None if pending is None else F.RolloutPost.of(*pending), action_noise=act_noise)
+                                                  prev_post=None if pending is None else F.RolloutPost.of(*pending), action_noise=act_noise,
+                                                  dr_step=env.dr_step_args() if fold_dr else None)
                     pending = None
                 else:
                     x = self._f_obs_rms.normalize(cur, fx["obs_n"]) if self.normalize_input else cur

@@ -19,7 +19,7 @@ _SIGS = {
     "bez_ppo_loss": [_vp] * 10 + [_i64, _i32, _f, _f, _f, _f, _i32] + [_vp] * 7,
     "bez_ppo_rollout_pre": [_vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _f, _i64, _i32, _i32] + [_vp] * 9,
     "bez_ppo_policy_forward": [_vp, _i64, _i32, _vp, _vp, _f, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _vp],
-    "bez_ppo_policy_rollout_step": [_vp, _i64, _i32, _vp, _vp, _f, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f] + [_vp] * 8 + [_i32, _vp, _vp, _vp],
+    "bez_ppo_policy_rollout_step": [_vp, _i64, _i32, _vp, _vp, _f, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f] + [_vp] * 8 + [_i32, _vp, _vp, _vp, _vp],
     "bez_ppo_policy_forward_train": [_vp, _i64, _i32, _vp, _vp, _f, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp],
     "bez_ppo_policy_backward": [_vp, _vp, _i64, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp],
     "bez_ppo_scatter_f16": [_vp, _vp, _i64, _vp, _vp],
@@ -489,10 +489,11 @@ class PolicyForward:
             C.c_void_p(self.mu_w.data_ptr()), _p(mu_wb[1], torch.float16), self.num_actions, _p(value_wb[0], torch.float16), _p(value_wb[1], torch.float16),
             _p(x0, torch.float16), C.cast(tab, C.c_void_p), _p(mu_out), _p(value_out), self.flag, _stream(obs)), "bez_ppo_policy_forward_train")
 
-    def rollout_step(self, obs, logstd, noise, dones, value_rms, mb_obs, mb_dones, mb_mu, mb_val, actions, env_actions, neglogp, sigma, prev_post=None, action_noise=None):
+    def rollout_step(self, obs, logstd, noise, dones, value_rms, mb_obs, mb_dones, mb_mu, mb_val, actions, env_actions, neglogp, sigma, prev_post=None, action_noise=None, dr_step=None):
         """Forward + everything up to the env step in the same launch (bez_ppo_policy_rollout_step): same outputs as
         `self(obs, mu, v); rollout_pre(mu, v, ...)`.  prev_post (RolloutPost): rollout_post() of the PREVIOUS env step in the same launch;
-        action_noise (ActionNoise): env_actions also receives the env's domain-randomisation action noise (the env must not add it again)."""
+        action_noise (ActionNoise): env_actions also receives the env's domain-randomisation action noise (the env must not add it again);
+        dr_step (env.dr_step_args()): the coming env step's randomisation runs as one extra workgroup of this launch."""
         hidden, mu_wb, value_wb, rms = self.keep
         n, A = obs.shape[0], self.num_actions
         assert obs.shape[1] == self.d_in and noise.shape == (n, A) and logstd.numel() == A and dones.numel() == n
@@ -505,5 +506,6 @@ class PolicyForward:
             _p(dones), None if value_rms is None else _p(value_rms.running_mean, torch.float64),
             None if value_rms is None else _p(value_rms.running_var, torch.float64), 0.0 if value_rms is None else float(value_rms.epsilon), _p(mb_obs),
             _p(mb_dones), _p(mb_mu), _p(mb_val), _p(actions), _p(env_actions), _p(neglogp), _p(sigma), self.flag,
-            None if prev_post is None else C.byref(prev_post), None if action_noise is None else C.byref(action_noise), _stream(obs)),
+            None if prev_post is None else C.byref(prev_post), None if action_noise is None else C.byref(action_noise),
+            None if dr_step is None else C.cast(dr_step, C.c_void_p), _stream(obs)),
             "bez_ppo_policy_rollout_step")

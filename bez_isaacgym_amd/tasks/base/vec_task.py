@@ -207,6 +207,10 @@ class VecTask(Env):
         if not self.first_randomization and self.randomize:
             self.sim.dr_prelaunch()
 
+    def dr_step_args(self):
+        """The coming step's randomisation as an argument block for a launch that carries it (sim.dr_step_args); None without one."""
+        return self.sim.dr_step_args() if (not self.first_randomization and self.randomize) else None
+
     def apply_randomizations(self, dr_params):
         """The reference calls this from reset_idx on every step in which some env resets (kick_env.py:781-782); what it does
         there -- per-env redraws at reset time once `frequency` steps have passed, gravity and the noise parameters on the same

@@ -255,6 +255,12 @@ int bez_sim_set_randomization(BezSim* sim, const BezDrConfig* dr, void* stream);
  * The action noise (bez_sim_add_dr_noise(which = 1), BezActionNoiseSource) reads a SNAPSHOT the previous step left, not the state this
  * kernel updates, so it may run concurrently with it. */
 int bez_sim_dr_prelaunch(BezSim* sim, void* stream);
+/* The same work as an opaque argument block for a launch of the caller's that executes it ITSELF, as one extra workgroup beside its own
+ * (bez_ppo_policy_rollout_step's dr_step argument): fills blob[BEZ_DR_STEP_BYTES] for the COMING control step, which then skips its own
+ * randomisation kernel -- the caller must run that launch before the step, on the step's stream.  Nothing in the block changes from step
+ * to step (all clocks live in device memory), so a captured graph replays it.  Returns the bytes used, 0 without a randomisation. */
+#define BEZ_DR_STEP_BYTES 512
+int bez_sim_dr_step_args(BezSim* sim, void* blob, int32_t blob_bytes);
 /* For a consumer that adds the action noise of vec_task.py:586-592 itself (e.g. bez_ppo_policy_rollout_step): *snap_dev -> device struct
  * {float mean, std; uint32_t frame_lo, frame_hi} kept current by the step kernels; noise of element i of the flat (N, 18) action tensor =
  * mean + std * z, z = word (i & 3) of the Philox4x32-10 block with counter (key lo, key hi, frame lo, 0x4e4f4953 + 1 + (frame hi << 8)),
@@ -362,13 +368,17 @@ typedef struct BezPpoRolloutPost {
  * clamp(a, -1, 1) + noise, bit for bit what bez_sim_add_dr_noise(which = 1) would add to the clamped actions (the three fields are what
  * bez_sim_action_noise_source returns; the env must then not add it again). */
 typedef struct BezPpoActionNoise { const void* snap_dev; uint64_t seed; int64_t env_id_offset; } BezPpoActionNoise;
+/* dr_step (NULL = none; ABI 4): the block bez_sim_dr_step_args filled -- the coming env step's randomisation runs as ONE EXTRA workgroup of this
+ * launch (it touches nothing the forward pass reads: the action noise comes from the snapshot), instead of a launch of its own in front of
+ * the step. */
 int bez_ppo_policy_rollout_step(const float* obs_dev, int64_t n, int32_t num_obs, const double* obs_mean_dev, const double* obs_var_dev, float obs_eps,
                                 int32_t num_hidden, const void* const* hidden_w_f16_dev, const void* const* hidden_b_f16_dev, const int32_t* hidden_width,
                                 const void* mu_w_f16_dev, const void* mu_b_f16_dev, int32_t num_actions, const void* value_w_f16_dev,
                                 const void* value_b_f16_dev, const float* logstd_dev, const float* noise_dev, const float* dones_dev,
                                 const double* value_mean_dev, const double* value_var_dev, float value_eps, float* mb_obs_dev, float* mb_dones_dev,
                                 float* mb_mu_dev, float* mb_val_dev, float* actions_dev, float* env_actions_dev, float* neglogp_dev, float* sigma_dev,
-                                int32_t weights_packed, const BezPpoRolloutPost* prev_post, const BezPpoActionNoise* action_noise, void* stream);
+                                int32_t weights_packed, const BezPpoRolloutPost* prev_post, const BezPpoActionNoise* action_noise,
+                                const void* dr_step, void* stream);
 
 /* The forward half of a PPO minibatch step (a2c_common.py calc_gradients: model(batch) under autocast): bez_ppo_policy_forward
  * that also keeps what the backward pass needs -- x0 (n, num_obs) fp16 = the normalised, clamped input of the first Linear, and

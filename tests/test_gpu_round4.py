@@ -139,12 +139,14 @@ def test_rollout_bookkeeping_inside_the_policy_launch_changes_nothing():
     assert float(a.ep_stats[0]) > 0   # episodes did end (random initial policy falls within the horizon)
 
 
-def test_randomised_rollout_at_full_speed_changes_nothing():
+@pytest.mark.parametrize("fast", [{}, {"dr_prelaunch": True}])
+def test_randomised_rollout_at_full_speed_changes_nothing(fast):
     """Round 4, BASELINE config 5 at speed: with task.randomize=True the agent (a) lets the policy launch add the env's action noise
-    (BezPpoActionNoise: the same Philox bits as the env's own lambda) and (b) launches the randomisation kernel of the next env step
-    right behind the current one on a side stream (bez_sim_dr_prelaunch), beside the next policy launch.  Against an agent that
-    leaves both to the env (two more launches per step, in series), same seeds, redraws every 5 steps: every rollout row, the
-    simulator's state, the per-env randomised parameters and the randomisation clocks are bit-identical."""
+    (BezPpoActionNoise: the same Philox bits as the env's own lambda) and (b) runs the randomisation of the coming env step as one
+    extra workgroup of that launch (bez_sim_dr_step_args; default) -- or, `dr_prelaunch`, launches the randomisation kernel early on a
+    side stream (bez_sim_dr_prelaunch).  Against an agent that leaves both to the env (two more launches per step, in series),
+    same seeds, redraws every 5 steps: every rollout row, the simulator's state, the per-env randomised parameters and the
+    randomisation clocks are bit-identical."""
     import torch
     from bez_isaacgym_amd import abi
     from bez_isaacgym_amd.ppo.a2c_continuous import A2CAgent
@@ -159,8 +161,8 @@ def test_randomised_rollout_at_full_speed_changes_nothing():
         params = cfg["train"]["params"]
         params["config"].update(minibatch_size=4096, save_frequency=0, save_best_after=10 ** 9, hip_graphs=False, **over)
         return A2CAgent(params, venv, "cuda:0")
-    a = make(fold_action_noise=False, dr_prelaunch=False)
-    b = make(dr_prelaunch=True)
+    a = make(fold_action_noise=False, dr_prelaunch=False, fold_dr_step=False)
+    b = make(**fast)
     b.model.load_state_dict(a.model.state_dict())
     for ag in (a, b):
         torch.manual_seed(3)
@@ -168,7 +170,8 @@ def test_randomised_rollout_at_full_speed_changes_nothing():
         ag.play_steps(); ag.play_steps()
     torch.cuda.synchronize()
     ea, eb = a.vec_env.env, b.vec_env.env
-    assert eb.action_noise_source() is not None and b._side_stream is not None and not eb.external_action_noise
+    assert eb.action_noise_source() is not None and not eb.external_action_noise
+    assert (getattr(b, "_side_stream", None) is not None) == bool(fast.get("dr_prelaunch"))
     for k in a.mb:
         assert torch.equal(a.mb[k], b.mb[k]), k
     for t in (abi.TENSOR_ROOT_STATE, abi.TENSOR_DOF_STATE, abi.TENSOR_RANDOMIZE_BUF, abi.TENSOR_DR_NOISE, abi.TENSOR_OBS, abi.TENSOR_RESET):
