@@ -369,7 +369,15 @@ class A2CAgent:
         self.value_mean_std = RunningMeanStd((1,)).to(self.device) if self.normalize_value else None
         on_gpu = self.device.type == "cuda"
         # lr lives on the device so that the adaptive-KL rule needs no host sync and the update can be graph-captured
-        self.lr_t = torch.tensor(self.last_lr, device=self.device, dtype=torch.float32)
+        # One 512-byte device buffer holds everything the host reads back per epoch -- episode statistics (3 fp64), learning rate, loss and KL
+        # accumulators (fp32 views) -- so an epoch ends with ONE device-to-host copy instead of four reads with a host round trip each
+        # (~30 us of idle GPU apiece between the replayed graphs)
+        self._report = torch.zeros(64, device=self.device, dtype=torch.float64) if on_gpu else None
+        if on_gpu:
+            self.lr_t = self._report.view(torch.float32)[8]
+            self.lr_t.fill_(self.last_lr)
+        else:
+            self.lr_t = torch.tensor(self.last_lr, device=self.device, dtype=torch.float32)
         # fused + capturable Adam: takes GradScaler's found_inf / scale as tensors (no .item()), so scaler.step() is graph-safe
         self.optimizer = torch.optim.Adam(self.model.parameters(), lr=self.lr_t if on_gpu else self.last_lr, eps=1e-8,
                                           capturable=on_gpu, fused=on_gpu)
@@ -498,9 +506,13 @@ class A2CAgent:
         self.dataset = dict(old_values=z(B, 1), old_logp=z(B), advantages=z(B), returns=z(B, 1), actions=z(B, self.act_dim),
                             obs=z(B, self.obs_dim), mu=z(B, self.act_dim), sigma=z(B, self.act_dim))
         # episode statistics accumulated on the device (no .nonzero()/.tolist() inside the rollout)
-        self.ep_stats = torch.zeros(3, device=dev, dtype=torch.float64)  # [finished episodes, sum of returns, sum of lengths]
-        self.kl_acc = torch.zeros(self.mini_epochs, device=dev)
-        self.loss_acc = torch.zeros(2, device=dev)
+        if self._report is not None and 12 + self.mini_epochs <= 2 * self._report.numel():   # views of the epoch report (see __init__)
+            f32 = self._report.view(torch.float32)
+            self.ep_stats, self.loss_acc, self.kl_acc = self._report[0:3], f32[10:12], f32[12:12 + self.mini_epochs]
+        else:
+            self.ep_stats = torch.zeros(3, device=dev, dtype=torch.float64)  # [finished episodes, sum of returns, sum of lengths]
+            self.kl_acc = torch.zeros(self.mini_epochs, device=dev)
+            self.loss_acc = torch.zeros(2, device=dev)
         # the epoch's data-only moments in ONE fp64 buffer = one all-reduce per epoch when data parallel: the
         # observation moments of every minibatch (rl_games updates the input normaliser at every minibatch forward, and what
         # it adds depends on the dataset alone, not on the weights), then the moments of the values and of the returns
@@ -1141,9 +1153,10 @@ class A2CAgent:
         else:
             self._g_update.replay()
 
-    def _drain_episode_stats(self):
-        """One device->host read per epoch: finished-episode count / return / length sums of this epoch's rollout."""
-        cnt, rsum, lsum = self.ep_stats.tolist()
+    def _drain_episode_stats(self, host=None):
+        """Finished-episode count / return / length sums of this epoch's rollout (host = the values already read back with the epoch
+        report; None: one device->host read of its own)."""
+        cnt, rsum, lsum = self.ep_stats.tolist() if host is None else host
         self.ep_stats.zero_()
         if cnt > 0:
             self._ep_hist.append((cnt, rsum, lsum))
@@ -1156,16 +1169,36 @@ class A2CAgent:
 
     def train_epoch(self):
         t0 = time.perf_counter()
-        self.play_steps()
-        if self.device.type == "cuda":
-            torch.cuda.synchronize()
-        t_play = time.perf_counter() - t0
-        self.run_update()
-        self.last_lr = float(self.lr_t.item())  # the epoch's only other host sync
-        kls = self.kl_acc.tolist()
-        a_l, c_l = (self.loss_acc / (self.mini_epochs * self.num_minibatches)).tolist()
-        self._drain_episode_stats()
-        t_total = time.perf_counter() - t0
+        packed = self._report is not None and self.mb is not None and self.ep_stats.data_ptr() == self._report.data_ptr()
+        if packed:
+            # no host synchronisation between the rollout and the update: their shares of the epoch come from HIP events, resolved at
+            # the epoch's ONE device-to-host copy
+            ev = self._epoch_events = getattr(self, "_epoch_events", None) or [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+            ev[0].record()
+            self.play_steps()
+            ev[1].record()
+            self.run_update()
+            ev[2].record()
+            rep = self._report.cpu()     # the epoch's host sync
+            f32 = rep.view(torch.float32)
+            self.last_lr = float(f32[8])
+            kls = f32[12:12 + self.mini_epochs].tolist()
+            a_l, c_l = (f32[10:12] / (self.mini_epochs * self.num_minibatches)).tolist()
+            self._drain_episode_stats(rep[0:3].tolist())
+            t_total = time.perf_counter() - t0
+            dev_play, dev_upd = ev[0].elapsed_time(ev[1]) * 1e-3, ev[1].elapsed_time(ev[2]) * 1e-3
+            t_play = t_total * dev_play / max(dev_play + dev_upd, 1e-9)   # the wall time split as the device time was
+        else:
+            self.play_steps()
+            if self.device.type == "cuda":
+                torch.cuda.synchronize()
+            t_play = time.perf_counter() - t0
+            self.run_update()
+            self.last_lr = float(self.lr_t.item())  # the epoch's only other host sync
+            kls = self.kl_acc.tolist()
+            a_l, c_l = (self.loss_acc / (self.mini_epochs * self.num_minibatches)).tolist()
+            self._drain_episode_stats()
+            t_total = time.perf_counter() - t0
         self._eager_epochs += 1
         self.epoch_num += 1
         self.frame += self.batch_size * self.world
