@@ -53,6 +53,8 @@ struct PolicyArgs {
   BezPpoActionNoise an;
   // ... and, as ONE EXTRA workgroup of the launch, the randomisation of the coming env step (bez_sim_dr_step_args; dr_on == 0: none)
   int dr_on; bez::dr::DrArgs dr;
+  // row strides (floats) of the rollout rows this launch writes: mb_obs; mb_mu / act / sigma; neglogp (BezPpoRolloutLayout; contiguous: d_in, A, 1)
+  int64_t ld_obs, ld_act, ld_one;
   // training forward (mode 2): what the backward pass needs -- the fp16 input of the first Linear and every ELU output, row-major
   _Float16* x0_out; _Float16* act_out[PF_MAXL];
   int packed;  // weights are fragment-major copies (see gemm_col_block_packed): w[L] and w_mu (= the packed [mu; value] block)
@@ -269,7 +271,7 @@ __global__ __launch_bounds__(PF_WAVES * 64) void policy_forward_kernel(PolicyArg
     float v = 0.f;
     if (rr < nrow && k < a.d_in) {
       v = a.obs[(row0 + rr) * a.d_in + k];
-      if (ROLL) a.mb_obs[(row0 + rr) * a.d_in + k] = v;  // the rollout buffer keeps the raw observation
+      if (ROLL) a.mb_obs[(row0 + rr) * a.ld_obs + k] = v;  // the rollout buffer keeps the raw observation
       if (a.mean) {
         v = (v - (float)a.mean[k]) / sqrtf((float)a.var[k] + a.eps);
         v = fminf(fmaxf(v, -5.0f), 5.0f);
@@ -322,7 +324,8 @@ __global__ __launch_bounds__(PF_WAVES * 64) void policy_forward_kernel(PolicyArg
       const int64_t o = (row0 + rr) * A + j;
       float xe = fminf(fmaxf(x, -1.0f), 1.0f);   // what rl_games hands to env.step
       if (a.an.snap_dev) xe = xe + nzr[it];
-      a.mb_mu[o] = m; a.act[o] = x; a.act_env[o] = xe; a.sigma[o] = sg;
+      const int64_t om = (row0 + rr) * a.ld_act + j;   // (the rollout rows may be strided: written straight into the env-major dataset)
+      a.mb_mu[om] = m; a.act[om] = x; a.act_env[o] = xe; a.sigma[om] = sg;
       const float q = (x - m) / sg;  // as the reference computes it from the stored action
       zz[rr * 32 + j] = q * q;
     }
@@ -330,7 +333,7 @@ __global__ __launch_bounds__(PF_WAVES * 64) void policy_forward_kernel(PolicyArg
     if (tid < nrow) {
       float acc = 0.f, ls = 0.f;
       for (int j = 0; j < A; ++j) { acc += zz[tid * 32 + j]; ls += a.logstd[j]; }
-      a.neglogp[row0 + tid] = 0.5f * acc + 0.5f * 1.8378770664093453f * (float)A + ls;
+      a.neglogp[(row0 + tid) * a.ld_one] = 0.5f * acc + 0.5f * 1.8378770664093453f * (float)A + ls;
       float v = tile[tid * 33 + A];
       if (a.vmean) v = sqrtf((float)a.vvar[0] + a.veps) * fminf(fmaxf(v, -5.0f), 5.0f) + (float)a.vmean[0];
       a.mb_val[row0 + tid] = v;
@@ -559,6 +562,7 @@ static int fill_args(PolicyArgs& a, const float* obs_dev, int64_t n, int32_t num
   a.post = BezPpoRolloutPost{};
   a.an = BezPpoActionNoise{};
   a.dr_on = 0;
+  a.ld_obs = num_obs; a.ld_act = num_actions; a.ld_one = 1;
   a.x0_out = nullptr;
   for (int i = 0; i < PF_MAXL; ++i) a.act_out[i] = nullptr;
   a.packed = 0;
@@ -588,7 +592,7 @@ extern "C" int bez_ppo_policy_rollout_step(const float* obs_dev, int64_t n, int3
                                            const float* dones_dev, const double* value_mean_dev, const double* value_var_dev, float value_eps, float* mb_obs_dev,
                                            float* mb_dones_dev, float* mb_mu_dev, float* mb_val_dev, float* actions_dev, float* env_actions_dev,
                                            float* neglogp_dev, float* sigma_dev, int32_t weights_packed, const BezPpoRolloutPost* prev_post, const BezPpoActionNoise* action_noise,
-                                           const void* dr_step, void* stream) {
+                                           const void* dr_step, const BezPpoRolloutLayout* layout, void* stream) {
   PolicyArgs a;
   if (prev_post && (!prev_post->rew || !prev_post->reset || !prev_post->timeouts || !prev_post->prev_values || !prev_post->shaped || !prev_post->dones_f ||
                     !prev_post->cur_rew || !prev_post->cur_len || !prev_post->ep_stats)) return -1;
@@ -601,6 +605,10 @@ extern "C" int bez_ppo_policy_rollout_step(const float* obs_dev, int64_t n, int3
   a.neglogp = neglogp_dev; a.sigma = sigma_dev; a.packed = weights_packed;
   if (prev_post) a.post = *prev_post;
   if (action_noise && action_noise->snap_dev) a.an = *action_noise;
+  if (layout) {
+    if (layout->obs_row_stride < num_obs || layout->act_row_stride < num_actions || layout->scalar_stride < 1) return -1;
+    a.ld_obs = layout->obs_row_stride; a.ld_act = layout->act_row_stride; a.ld_one = layout->scalar_stride;
+  }
   static_assert(sizeof(bez::dr::DrArgs) <= BEZ_DR_STEP_BYTES, "BezPpoDrStep blob of the C ABI too small");
   if (dr_step) { std::memcpy(&a.dr, dr_step, sizeof(a.dr)); a.dr_on = 1; if (a.dr.n <= 0 || !a.dr.st || a.dr.first) return -1; }
   const unsigned grid = (unsigned)((n + PF_ROWS - 1) / PF_ROWS) + (dr_step ? 1u : 0u);   // + the randomisation workgroup

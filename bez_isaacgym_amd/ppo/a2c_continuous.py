@@ -505,6 +505,15 @@ class A2CAgent:
         B = self.batch_size
         self.dataset = dict(old_values=z(B, 1), old_logp=z(B), advantages=z(B), returns=z(B, 1), actions=z(B, self.act_dim),
                             obs=z(B, self.obs_dim), mu=z(B, self.act_dim), sigma=z(B, self.act_dim))
+        if self.fused and self._policy_fwd is not None and self.cfg.get("rollout_into_dataset", True):
+            # the rollout rows of obs / actions / mu / sigma / neglogp ARE the dataset's rows: rl_games flattens env-major (row of env e at
+            # step n = e * H + n), so the (H, N, ...) rollout tensors become strided views of the (N * H, ...) dataset tensors and the
+            # policy launch writes through them (BezPpoRolloutLayout) -- five transposing copies per epoch (28 MB for the observations)
+            # and their temporaries are gone
+            ds = self.dataset
+            for k_mb, k_ds in (("obs", "obs"), ("act", "actions"), ("mu", "mu"), ("sigma", "sigma")):
+                self.mb[k_mb] = ds[k_ds].view(N, H, -1).transpose(0, 1)
+            self.mb["neglogp"] = ds["old_logp"].view(N, H).transpose(0, 1)
         # episode statistics accumulated on the device (no .nonzero()/.tolist() inside the rollout)
         if self._report is not None and 12 + self.mini_epochs <= 2 * self._report.numel():   # views of the epoch report (see __init__)
             f32 = self._report.view(torch.float32)
@@ -675,7 +684,9 @@ class A2CAgent:
         # ---- prepare_dataset (rl_games a2c_continuous.prepare_dataset)
         ds = self.dataset
         values, returns = swap_and_flatten01(mb["val"]), swap_and_flatten01(returns)
-        ds["obs"].copy_(swap_and_flatten01(mb["obs"]))
+        aliased = mb["obs"].data_ptr() == ds["obs"].data_ptr()   # the rollout wrote the dataset's rows itself (_alloc_static)
+        if not aliased:
+            ds["obs"].copy_(swap_and_flatten01(mb["obs"]))
         fused_v = self.normalize_value and self.fused and getattr(self, "_f_val_rms", None) is not None
         # epoch collective 1 of 2: every moment that depends on the data alone, for the whole epoch
         if self.normalize_input:
@@ -716,9 +727,10 @@ class A2CAgent:
             else:
                 adv = (adv - adv.mean()) / (adv.std() + 1e-8)
         ds["old_values"].copy_(values); ds["returns"].copy_(returns); ds["advantages"].copy_(adv)
-        ds["old_logp"].copy_(swap_and_flatten01(mb["neglogp"])); ds["actions"].copy_(swap_and_flatten01(mb["act"]))
-        ds["mu"].copy_(swap_and_flatten01(mb["mu"]))
-        ds["sigma"].copy_(swap_and_flatten01(mb["sigma"]))
+        if not aliased:
+            ds["old_logp"].copy_(swap_and_flatten01(mb["neglogp"])); ds["actions"].copy_(swap_and_flatten01(mb["act"]))
+            ds["mu"].copy_(swap_and_flatten01(mb["mu"]))
+            ds["sigma"].copy_(swap_and_flatten01(mb["sigma"]))
 
     def play_steps(self):
         """Rollout + dataset.  With HIP graphs enabled the first call after warm-up captures, later calls replay."""

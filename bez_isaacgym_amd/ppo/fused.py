@@ -19,7 +19,7 @@ _SIGS = {
     "bez_ppo_loss": [_vp] * 10 + [_i64, _i32, _f, _f, _f, _f, _i32] + [_vp] * 7,
     "bez_ppo_rollout_pre": [_vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _f, _i64, _i32, _i32] + [_vp] * 9,
     "bez_ppo_policy_forward": [_vp, _i64, _i32, _vp, _vp, _f, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _vp],
-    "bez_ppo_policy_rollout_step": [_vp, _i64, _i32, _vp, _vp, _f, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f] + [_vp] * 8 + [_i32, _vp, _vp, _vp, _vp],
+    "bez_ppo_policy_rollout_step": [_vp, _i64, _i32, _vp, _vp, _f, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f] + [_vp] * 8 + [_i32, _vp, _vp, _vp, _vp, _vp],
     "bez_ppo_policy_forward_train": [_vp, _i64, _i32, _vp, _vp, _f, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp],
     "bez_ppo_policy_backward": [_vp, _vp, _i64, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp],
     "bez_ppo_scatter_f16": [_vp, _vp, _i64, _vp, _vp],
@@ -57,6 +57,12 @@ def lib():
 
 def _p(t, dtype=torch.float32):
     assert t.is_cuda and t.dtype == dtype and t.is_contiguous(), (t.dtype, t.is_contiguous())
+    return C.c_void_p(t.data_ptr())
+
+
+def _pv(t, dtype=torch.float32):
+    """device pointer of a tensor that may be a strided view (the callee is told the strides)"""
+    assert t.is_cuda and t.dtype == dtype, t.dtype
     return C.c_void_p(t.data_ptr())
 
 
@@ -112,6 +118,11 @@ class FusedRunningMeanStd:
 def sample(mu, logstd, noise, actions, env_actions, neglogp, sigma):
     n, a = mu.shape
     _chk(lib().bez_ppo_sample(_p(mu), _p(logstd), _p(noise), n, a, _p(actions), _p(env_actions), _p(neglogp), _p(sigma), _stream(mu)), "bez_ppo_sample")
+
+
+class RolloutLayout(C.Structure):
+    """BezPpoRolloutLayout (include/bez_sim.h): row strides (floats) of the rollout rows PolicyForward.rollout_step writes"""
+    _fields_ = [("obs_row_stride", C.c_int64), ("act_row_stride", C.c_int64), ("scalar_stride", C.c_int64)]
 
 
 class ActionNoise(C.Structure):
@@ -499,13 +510,20 @@ class PolicyForward:
         assert obs.shape[1] == self.d_in and noise.shape == (n, A) and logstd.numel() == A and dones.numel() == n
         assert mb_obs.shape == obs.shape and mb_mu.shape == (n, A) and actions.shape == (n, A) and env_actions.shape == (n, A) and sigma.shape == (n, A)
         assert mb_dones.numel() == n and mb_val.numel() == n and neglogp.numel() == n
+        # the rows of mb_obs / (mb_mu, actions, sigma) / neglogp may be strided views (rows of the env-major dataset): unit stride inside a
+        # row, one common row stride per group
+        layout = None
+        so, sa, s1 = mb_obs.stride(0), mb_mu.stride(0), (neglogp.stride(0) if neglogp.dim() else 1)
+        assert mb_obs.stride(1) == 1 and mb_mu.stride(1) == 1 and actions.stride() == mb_mu.stride() and sigma.stride() == mb_mu.stride()
+        if (so, sa, s1) != (self.d_in, A, 1):
+            layout = RolloutLayout(so, sa, s1)
         _chk(lib().bez_ppo_policy_rollout_step(
             _p(obs), n, self.d_in, None if rms is None else _p(rms.running_mean, torch.float64), None if rms is None else _p(rms.running_var, torch.float64),
             0.0 if rms is None else float(rms.epsilon), self.k, C.cast(self.hw, C.c_void_p), C.cast(self.hb, C.c_void_p), C.cast(self.widths, C.c_void_p),
             C.c_void_p(self.mu_w.data_ptr()), _p(mu_wb[1], torch.float16), A, _p(value_wb[0], torch.float16), _p(value_wb[1], torch.float16), _p(logstd), _p(noise),
             _p(dones), None if value_rms is None else _p(value_rms.running_mean, torch.float64),
-            None if value_rms is None else _p(value_rms.running_var, torch.float64), 0.0 if value_rms is None else float(value_rms.epsilon), _p(mb_obs),
-            _p(mb_dones), _p(mb_mu), _p(mb_val), _p(actions), _p(env_actions), _p(neglogp), _p(sigma), self.flag,
+            None if value_rms is None else _p(value_rms.running_var, torch.float64), 0.0 if value_rms is None else float(value_rms.epsilon), _pv(mb_obs),
+            _p(mb_dones), _pv(mb_mu), _p(mb_val), _pv(actions), _p(env_actions), _pv(neglogp), _pv(sigma), self.flag,
             None if prev_post is None else C.byref(prev_post), None if action_noise is None else C.byref(action_noise),
-            None if dr_step is None else C.cast(dr_step, C.c_void_p), _stream(obs)),
+            None if dr_step is None else C.cast(dr_step, C.c_void_p), None if layout is None else C.byref(layout), _stream(obs)),
             "bez_ppo_policy_rollout_step")

@@ -368,6 +368,10 @@ typedef struct BezPpoRolloutPost {
  * clamp(a, -1, 1) + noise, bit for bit what bez_sim_add_dr_noise(which = 1) would add to the clamped actions (the three fields are what
  * bez_sim_action_noise_source returns; the env must then not add it again). */
 typedef struct BezPpoActionNoise { const void* snap_dev; uint64_t seed; int64_t env_id_offset; } BezPpoActionNoise;
+/* layout (NULL = contiguous rows; ABI 4): row strides, in floats, of the rollout rows this launch writes -- mb_obs (>= num_obs); mb_mu / actions /
+ * sigma (>= num_actions); neglogp (>= 1).  Lets the caller point them INTO its env-major dataset tensors (row of env e at step n = e * H + n:
+ * strides H * width), so that the dataset needs no transposing copies after the rollout. */
+typedef struct BezPpoRolloutLayout { int64_t obs_row_stride, act_row_stride, scalar_stride; } BezPpoRolloutLayout;
 /* dr_step (NULL = none; ABI 4): the block bez_sim_dr_step_args filled -- the coming env step's randomisation runs as ONE EXTRA workgroup of this
  * launch (it touches nothing the forward pass reads: the action noise comes from the snapshot), instead of a launch of its own in front of
  * the step. */
@@ -378,7 +382,7 @@ int bez_ppo_policy_rollout_step(const float* obs_dev, int64_t n, int32_t num_obs
                                 const double* value_mean_dev, const double* value_var_dev, float value_eps, float* mb_obs_dev, float* mb_dones_dev,
                                 float* mb_mu_dev, float* mb_val_dev, float* actions_dev, float* env_actions_dev, float* neglogp_dev, float* sigma_dev,
                                 int32_t weights_packed, const BezPpoRolloutPost* prev_post, const BezPpoActionNoise* action_noise,
-                                const void* dr_step, void* stream);
+                                const void* dr_step, const BezPpoRolloutLayout* layout, void* stream);
 
 /* The forward half of a PPO minibatch step (a2c_common.py calc_gradients: model(batch) under autocast): bez_ppo_policy_forward
  * that also keeps what the backward pass needs -- x0 (n, num_obs) fp16 = the normalised, clamped input of the first Linear, and
