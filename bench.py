@@ -247,6 +247,8 @@ def main():
     ap.add_argument("--launch", choices=["python", "c"], default="python",
                     help="python: one bez_sim_step call per step from Python; c: bez_sim_step_many (C loop)")
     ap.add_argument("--keep-aux", action="store_true", help="keep NET_CONTACT_FORCE / FEET / PREV_LIN_VEL current every step (no BEZ_FLAG_LEAN_STEP)")
+    ap.add_argument("--no-full-store", action="store_true", help="skip the side measurement of the full-store (non-lean) step: profiler passes "
+                    "that average a counter over every dispatch of the step kernel want the headline configuration only")
     ap.add_argument("--randomize", action="store_true", help="PPO leg with task.randomize=True (BASELINE.json configs[4]: domain-randomised "
                     "friction / gains / limits / gravity + observation and action noise, redrawn on the device at reset time)")
     ap.add_argument("--stub-cpu", action="store_true", help="launcher self-test: gloo on the CPU, the env step replaced by a no-op "
@@ -332,7 +334,7 @@ def main():
 
     # the C ABI's default keeps every Isaac-visible tensor current (no BEZ_FLAG_LEAN_STEP): the same build's full-store step,
     # timed beside the headline so that the difference is on record
-    other = BezSim(abi.default_config(n, seed=42, env_id_offset=rank * n), local_rank) if not args.keep_aux else None
+    other = BezSim(abi.default_config(n, seed=42, env_id_offset=rank * n), local_rank) if not (args.keep_aux or args.no_full_store) else None
     full_store_ms = None
     if other is not None:
         for t in range(50):

@@ -5,8 +5,8 @@ set -e
 TAG=${1:-r03}
 export TMPDIR=/tmp
 O=gpurun_out
-B="python3 bench.py --steps 1000 --warmup 100 --no-cpu-baseline --ppo-epochs 0"
-S="python3 bench.py --steps 200 --warmup 20 --no-cpu-baseline --ppo-epochs 0"
+B="python3 bench.py --steps 1000 --warmup 100 --no-cpu-baseline --ppo-epochs 0 --no-full-store"
+S="python3 bench.py --steps 200 --warmup 20 --no-cpu-baseline --ppo-epochs 0 --no-full-store"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_stats -- $B > $O/${TAG}_stats.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/${TAG}_pmc_fetch -- $S > $O/${TAG}_pmc_fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/${TAG}_pmc_write -- $S > $O/${TAG}_pmc_write.log 2>&1
