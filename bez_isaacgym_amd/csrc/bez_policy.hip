@@ -169,12 +169,56 @@ __device__ __forceinline__ void gemm_col_block_packed(const _Float16 (*src)[LD],
   while (ks + 1 <= ksteps) group(std::integral_constant<int, 1>{});
 }
 
+// One 32-row half of a column block (fragment-major weights).  A layer with <= 4 column blocks (the 100-wide one: 4; the heads: 1) left half
+// or more of the eight waves idle while the others ran two MFMA chains each (the heads alone: 7.9 k of the forward kernel's 35.8 k cycles,
+// tools/policy_stamp_probe.py): with (column block, row half) as the unit of work every wave gets one chain.
+template <int LD>
+__device__ __forceinline__ void gemm_col_block_packed_half(const _Float16 (*src)[LD], const _Float16* wblk, int ksteps, int r, int h, int half, f32x16& acc) {
+  const _Float16* p = wblk + (h * 32 + r) * 8;
+  int ks = 0;
+  auto group = [&](auto G) {
+    constexpr int g = decltype(G)::value;
+    half8 bf[g];
+#pragma unroll
+    for (int u = 0; u < g; ++u) bf[u] = *reinterpret_cast<const half8*>(p + (size_t)(ks + u) * 512);
+#pragma unroll
+    for (int u = 0; u < g; ++u) {
+      const int k0 = (ks + u) * 16 + 8 * h;
+      const half8 a0 = *reinterpret_cast<const half8*>(&src[32 * half + r][k0]);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, bf[u], acc, 0, 0, 0);
+    }
+    ks += g;
+  };
+  while (ks + 12 <= ksteps) group(std::integral_constant<int, 12>{});
+  while (ks + 4 <= ksteps) group(std::integral_constant<int, 4>{});
+  while (ks + 1 <= ksteps) group(std::integral_constant<int, 1>{});
+}
 // dst[:, 0:Npad] = act(src[:, 0:K] W^T + b) for the 64 rows of the workgroup; this wave takes column blocks wave, wave + PF_WAVES, ...
 template <bool ELU, bool PK, int LDS, int LDD>
 __device__ __forceinline__ void layer(const _Float16 (*src)[LDS], _Float16 (*dst)[LDD], const _Float16* W, const _Float16* B, int in, int out, int wave,
                                       int lane) {
   const int r = lane & 31, h = lane >> 5;
   const int nblk = (out + 31) >> 5, npad = (out + 15) & ~15;  // (a narrow tile only covers the width padded to 16 columns)
+  if constexpr (PK) {
+    if (nblk * 2 <= PF_WAVES) {   // few column blocks: (block, 32-row half) per wave -- the same numbers, half the chain per wave
+      if (wave < 2 * nblk) {
+        const int nb = wave % nblk, half = wave / nblk, n = nb * 32 + r, ksteps = (in + 15) >> 4;
+        f32x16 acc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+        gemm_col_block_packed_half(src, W + (size_t)nb * ksteps * 512, ksteps, r, h, half, acc);
+        const float bias = (B && n < out) ? (float)B[n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int row = 32 * half + (i & 3) + 8 * (i >> 2) + 4 * h;
+          float v = (float)(_Float16)(acc[i] + bias);
+          if (ELU) v = v > 0.f ? v : __expf(v) - 1.f;
+          if (LDD >= PF_LD || n < npad) dst[row][n] = (_Float16)v;
+        }
+      }
+      return;
+    }
+  }
   for (int nb = wave; nb < nblk; nb += PF_WAVES) {
     const int n = nb * 32 + r;
     const _Float16* wrow = W + (size_t)(n < out ? n : 0) * in;
@@ -219,6 +263,26 @@ __device__ __forceinline__ void heads(const PolicyArgs& a, const _Float16 (*src)
     } else {
       if (row < nrow) { if (r < A) a.mu[(row0 + row) * A + r] = v0; else if (r == A) a.value[row0 + row] = v0; }
       if (32 + row < nrow) { if (r < A) a.mu[(row0 + 32 + row) * A + r] = v1; else if (r == A) a.value[row0 + 32 + row] = v1; }
+    }
+  }
+}
+
+template <bool ROLL, int LD>
+__device__ __forceinline__ void heads_half(const PolicyArgs& a, const _Float16 (*src)[LD], int in, float* tile, int64_t row0, int nrow, int lane, int half) {
+  const int r = lane & 31, h = lane >> 5, A = a.num_actions;
+  f32x16 acc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  gemm_col_block_packed_half(src, a.w_mu, (in + 15) >> 4, r, h, half, acc);
+  const float bias = r < A ? (float)a.b_mu[r] : (r == A ? (float)a.b_val[0] : 0.f);
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int row = 32 * half + (i & 3) + 8 * (i >> 2) + 4 * h;
+    const float v = (float)(_Float16)(acc[i] + bias);
+    if (ROLL) {
+      if (r <= A) tile[row * 33 + r] = v;
+    } else if (row < nrow) {
+      if (r < A) a.mu[(row0 + row) * A + r] = v; else if (r == A) a.value[row0 + row] = v;
     }
   }
 }
@@ -302,7 +366,12 @@ __global__ __launch_bounds__(PF_WAVES * 64) void policy_forward_kernel(PolicyArg
   }
   const bool in_t1 = (a.nhid & 1) != 0;  // where the last hidden activations are; the other tile is free
   float* tile = in_t1 ? reinterpret_cast<float*>(&t0[0][0]) : reinterpret_cast<float*>(&t1[0][0]);
-  if (wave == 0) {
+  if constexpr (PK) {
+    if (wave < 2) {   // two waves, one 32-row half each
+      if (in_t1) heads_half<ROLL>(a, t1, in, tile, row0, nrow, lane, wave);
+      else heads_half<ROLL>(a, t0, in, tile, row0, nrow, lane, wave);
+    }
+  } else if (wave == 0) {
     if (in_t1) heads<ROLL, PK>(a, t1, in, tile, row0, nrow, lane);
     else heads<ROLL, PK>(a, t0, in, tile, row0, nrow, lane);
   }
