@@ -29,6 +29,9 @@ namespace {
 
 using half8 = __attribute__((ext_vector_type(8))) _Float16;
 using f32x16 = __attribute__((ext_vector_type(16))) float;
+using f32x2 = __attribute__((ext_vector_type(2))) float;
+using half2v = __attribute__((ext_vector_type(2))) _Float16;
+using half4v = __attribute__((ext_vector_type(4))) _Float16;
 
 constexpr int PF_ROWS = 64;         // envs per workgroup
 constexpr int PF_MAXW = 416;        // widest layer the LDS buffers hold (13 blocks of 32 columns)
@@ -64,18 +67,32 @@ struct PolicyArgs {
 };
 #ifdef BEZ_PF_STAMPS
 #define PF_STAMP(k) do { if (a.stamps && blockIdx.x == 0 && threadIdx.x == 0) a.stamps[k] = __builtin_amdgcn_s_memtime(); } while (0)
+__device__ unsigned long long* g_pf_wave_stamps = nullptr;   // (layer tag, wave, phase) stamps of workgroup 0: entries [tag * 32 + wave * 4 + phase]
+#define PF_WSTAMP(tag, wave, ph) do { if (g_pf_wave_stamps && blockIdx.x == 0 && (threadIdx.x & 63) == 0) g_pf_wave_stamps[(tag) * 32 + (wave) * 4 + (ph)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define PF_STAMP(k) do { } while (0)
+#define PF_WSTAMP(tag, wave, ph) do { } while (0)
 #endif
 
 // rows [0, nrow) x columns [0, cols) of an LDS activation tile -> global (row-major, `cols` halfs per row, cols even): half2 per
 // lane, consecutive lanes on consecutive columns (256 B per wave instruction)
 template <int LD>
 __device__ __forceinline__ void store_tile(const _Float16 (*src)[LD], _Float16* dst, int64_t row0, int nrow, int cols, int tid) {
-  const int c2 = cols >> 1;
-  for (int idx = tid; idx < nrow * c2; idx += PF_WAVES * 64) {
-    const int rr = idx / c2, c = idx - rr * c2;
-    *reinterpret_cast<uint32_t*>(dst + (row0 + rr) * cols + 2 * c) = *reinterpret_cast<const uint32_t*>(&src[rr][2 * c]);
+  // waves over rows, lanes over columns: no index division (a flat index over (row, column pair) costs an integer division by a run-time
+  // width per element -- ~1.9 k of the training forward's 3.4 k vector instructions per wave were that); 8 bytes per lane where the width allows
+  const int lane = tid & 63, wave = tid >> 6;
+  if ((cols & 3) == 0) {
+    const int c4 = cols >> 2;
+    for (int rr = wave; rr < nrow; rr += PF_WAVES) {
+      _Float16* drow = dst + (row0 + rr) * cols;
+      for (int c = lane; c < c4; c += 64) *reinterpret_cast<uint2*>(drow + 4 * c) = *reinterpret_cast<const uint2*>(&src[rr][4 * c]);
+    }
+  } else {
+    const int c2 = cols >> 1;
+    for (int rr = wave; rr < nrow; rr += PF_WAVES) {
+      _Float16* drow = dst + (row0 + rr) * cols;
+      for (int c = lane; c < c2; c += 64) *reinterpret_cast<uint32_t*>(drow + 2 * c) = *reinterpret_cast<const uint32_t*>(&src[rr][2 * c]);
+    }
   }
 }
 
@@ -145,79 +162,179 @@ __device__ __forceinline__ void gemm_col_block(const _Float16 (*src)[LD], const 
 // Read from the row-major matrix the same fragment touches 64 different cache lines per wave instruction (a row per lane), eight waves
 // thrash the 16 KB L1 and every prefetch group costs ~2 k cycles of L2 round trips: the packed copy (kept current by one scatter of the
 // flat fp16 working copy per optimiser step) is what makes the weight stream cheap.
-template <int LD>
-__device__ __forceinline__ void gemm_col_block_packed(const _Float16 (*src)[LD], const _Float16* wblk, int ksteps, int r, int h, f32x16& acc0, f32x16& acc1) {
-  const _Float16* p = wblk + (h * 32 + r) * 8;
-  int ks = 0;
-  auto group = [&](auto G) {
-    constexpr int g = decltype(G)::value;
-    half8 bf[g];
+// Software pipeline of the fragment-major weight stream.  Left to itself the compiler sinks every weight load next to the MFMA that uses
+// it (two loads in flight, `s_waitcnt vmcnt(0..1)` before each pair of MFMAs): a k-step then costs one L2 round trip, ~200 cycles against 64
+// of matrix work.  Here the fragments of the NEXT PF_G k-steps are requested before the MFMAs of the current PF_G, with scheduling barriers
+// that keep the requests where they are written; the two fragment sets alternate (no register copies).
+// T: the TRANSPOSED product (weights as the A operand, activations as B): the same fragments and the same sums, but a lane then holds 16
+// output COLUMNS (4 groups of 4 consecutive ones) of its row r instead of 16 rows of its column -- see layer().
+// NACC = 2: both 32-row halves of the tile (acc[0], acc[1]); NACC = 1: the half `half` only (acc[0]).
+constexpr int PF_G = 4;
+// RP = ksteps mod 2 PF_G as a compile-time constant (the callers switch on it): pairs of full groups in a branch-free loop, then RP k-steps
+// of straight-line code -- no accumulator ever meets a branch (each guarded MFMA is a phi the register allocator answers with copies of the
+// 16-register accumulators and out-of-place MFMAs).
+template <int LD, bool T, int NACC, int RP>
+__device__ __forceinline__ void gemm_packed(const _Float16 (*src)[LD], const _Float16* wblk, int ksteps, int r, int h, int half, f32x16* acc) {
+  const _Float16* p = wblk + (h * 32 + r) * 8;   // this lane's 16 bytes of chunk 0; chunk k is 512 halfs further
+  auto fetch = [&](half8* f, int g) {             // group g: k-steps g PF_G ..; past the end: harmless repeats of the last chunk, never multiplied
 #pragma unroll
-    for (int u = 0; u < g; ++u) bf[u] = *reinterpret_cast<const half8*>(p + (size_t)(ks + u) * 512);
-#pragma unroll
-    for (int u = 0; u < g; ++u) {
-      const int k0 = (ks + u) * 16 + 8 * h;
+    for (int u = 0; u < PF_G; ++u) {
+      const int k = g * PF_G + u < ksteps ? g * PF_G + u : ksteps - 1;
+      f[u] = *reinterpret_cast<const half8*>(p + (size_t)k * 512);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto mma = [&](const half8& w, int ks) {
+    const int k0 = ks * 16 + 8 * h;
+    if (NACC == 2) {
       const half8 a0 = *reinterpret_cast<const half8*>(&src[r][k0]);
       const half8 a1 = *reinterpret_cast<const half8*>(&src[32 + r][k0]);
-      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, bf[u], acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, bf[u], acc1, 0, 0, 0);
+      acc[0] = T ? __builtin_amdgcn_mfma_f32_32x32x16_f16(w, a0, acc[0], 0, 0, 0) : __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, w, acc[0], 0, 0, 0);
+      acc[NACC - 1] = T ? __builtin_amdgcn_mfma_f32_32x32x16_f16(w, a1, acc[NACC - 1], 0, 0, 0) : __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, w, acc[NACC - 1], 0, 0, 0);
+    } else {
+      const half8 a0 = *reinterpret_cast<const half8*>(&src[32 * half + r][k0]);
+      acc[0] = T ? __builtin_amdgcn_mfma_f32_32x32x16_f16(w, a0, acc[0], 0, 0, 0) : __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, w, acc[0], 0, 0, 0);
     }
-    ks += g;
   };
-  while (ks + 12 <= ksteps) group(std::integral_constant<int, 12>{});
-  while (ks + 4 <= ksteps) group(std::integral_constant<int, 4>{});
-  while (ks + 1 <= ksteps) group(std::integral_constant<int, 1>{});
+  auto stage = [&](const half8* f, int ks, auto CNT) {   // CNT k-steps, straight-line
+#pragma unroll
+    for (int u = 0; u < decltype(CNT)::value; ++u) mma(f[u], ks + u);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  using Full = std::integral_constant<int, PF_G>;
+  const int npair = ksteps / (2 * PF_G);
+  half8 fa[PF_G], fb[PF_G];
+  __builtin_amdgcn_sched_barrier(0);
+  fetch(fa, 0);
+  for (int i = 0; i < npair; ++i) {   // branch-free body: the wait counters stay exact (the next group's four requests outstanding)
+    fetch(fb, 2 * i + 1);
+    stage(fa, 2 * i * PF_G, Full{});
+    fetch(fa, 2 * i + 2);
+    stage(fb, (2 * i + 1) * PF_G, Full{});
+  }
+  if constexpr (RP > PF_G) fetch(fb, 2 * npair + 1);
+  if constexpr (RP > 0) stage(fa, 2 * npair * PF_G, std::integral_constant<int, (RP < PF_G ? RP : PF_G)>{});
+  if constexpr (RP > PF_G) stage(fb, (2 * npair + 1) * PF_G, std::integral_constant<int, RP - PF_G>{});
+}
+// run(RP) with RP = ksteps mod 2 PF_G as a compile-time constant
+template <class F>
+__device__ __forceinline__ void dispatch_ksteps(int ksteps, F&& run) {
+  static_assert(PF_G == 4, "eight remainders");
+  switch (ksteps & 7) {
+    case 0: run(std::integral_constant<int, 0>{}); break;
+    case 1: run(std::integral_constant<int, 1>{}); break;
+    case 2: run(std::integral_constant<int, 2>{}); break;
+    case 3: run(std::integral_constant<int, 3>{}); break;
+    case 4: run(std::integral_constant<int, 4>{}); break;
+    case 5: run(std::integral_constant<int, 5>{}); break;
+    case 6: run(std::integral_constant<int, 6>{}); break;
+    default: run(std::integral_constant<int, 7>{}); break;
+  }
+}
+// Epilogue of the transposed product (fragment-major weights): this lane's 16 results are the output columns cb + 8 j + 0..3 (j = 0..3,
+// cb = 32 nb + 4 h) of ONE row.  Bias, the fp16 rounding of the Linear and ELU run two outputs per packed instruction and every group of four
+// leaves as one 8-byte LDS store (the direct product's lane holds 16 rows of one column: 16 two-byte stores and scalar math per 16 results --
+// that epilogue, not the MFMAs, was what a column block cost: ~2 k cycles against 0.4-1.6 k of matrix work, tools/policy_stamp_probe.py).
+struct alignas(4) BiasQuad { half2v lo, hi; };
+struct Bias16 { BiasQuad q[4]; };
+// the 16 bias values of a lane's output columns as four groups of four consecutive ones: unconditional loads, issued BEFORE the product so
+// that they ride behind its weight stream (a guarded load per element compiles to 16 branches, each waiting for its own load).  `out` a
+// multiple of 4 and B 4-byte aligned (every Linear of the flat fp16 working copy): a group is either complete or absent, one request each.
+__device__ __forceinline__ Bias16 load_bias16(const _Float16* B, int cb, int out) {
+  Bias16 b;
+  const half2v z = half2v{(_Float16)0.f, (_Float16)0.f};
+  if (!B) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { b.q[j].lo = z; b.q[j].hi = z; }
+  } else if (((out & 3) | (int)(reinterpret_cast<uintptr_t>(B) & 3)) == 0) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int c = cb + 8 * j;
+      b.q[j] = *reinterpret_cast<const BiasQuad*>(B + (c < out ? c : 0));   // (columns >= out: zeroed in the epilogue)
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int c = cb + 8 * j;
+      b.q[j].lo = half2v{B[c < out ? c : 0], B[c + 1 < out ? c + 1 : 0]};
+      b.q[j].hi = half2v{B[c + 2 < out ? c + 2 : 0], B[c + 3 < out ? c + 3 : 0]};
+    }
+  }
+  return b;
+}
+// (Columns >= out of the last block get the bias of column 0: finite values in the K padding of the next layer, where the fragment-major
+// weights are zero -- as harmless as the elu(0) they used to hold, and two guards per pair cheaper.)
+template <bool ELU, int LDD>
+__device__ __forceinline__ void store_row_groups(const f32x16& acc, const Bias16& b, _Float16 (*dst)[LDD], int row, int cb, int npad) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int c0 = cb + 8 * j;
+    uint32_t o[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int i = 4 * j + 2 * q;
+      const f32x2 s = f32x2{acc[i], acc[i + 1]} + __builtin_convertvector(q ? b.q[j].hi : b.q[j].lo, f32x2);
+      const half2v hq = __builtin_convertvector(s, half2v);  // the fp16 output of the Linear
+      if (ELU) {
+        // elu on the fp16 value, computed in fp32 as torch does: h > 0 ? h : exp(h) - 1.  The select works on the sign bits of the packed pair
+        // (h = +0 and exp(+0) - 1 are the same number, NaN stays NaN either way): one shift and one bit-field insert per pair
+        const f32x2 e = f32x2{__builtin_amdgcn_exp2f(__builtin_fmaf((float)hq.x, 1.4426950408889634f, 0.f)),
+                              __builtin_amdgcn_exp2f(__builtin_fmaf((float)hq.y, 1.4426950408889634f, 0.f))} - f32x2{1.f, 1.f};   // (v_fma_mix_f32: the conversion rides in the multiply)
+        const half2v eh = __builtin_convertvector(e, half2v);
+        const uint32_t hb = __builtin_bit_cast(uint32_t, hq), eb = __builtin_bit_cast(uint32_t, eh);
+        const uint32_t neg = ((hb >> 15) & 0x00010001u) * 0xffffu;   // 0xffff in every half whose sign bit is set
+        o[q] = (eb & neg) | (hb & ~neg);
+      } else {
+        o[q] = __builtin_bit_cast(uint32_t, hq);
+      }
+    }
+    if (LDD >= PF_LD || c0 < npad) *reinterpret_cast<uint2*>(&dst[row][c0]) = make_uint2(o[0], o[1]);
+  }
 }
 
-// One 32-row half of a column block (fragment-major weights).  A layer with <= 4 column blocks (the 100-wide one: 4; the heads: 1) left half
-// or more of the eight waves idle while the others ran two MFMA chains each (the heads alone: 7.9 k of the forward kernel's 35.8 k cycles,
-// tools/policy_stamp_probe.py): with (column block, row half) as the unit of work every wave gets one chain.
-template <int LD>
-__device__ __forceinline__ void gemm_col_block_packed_half(const _Float16 (*src)[LD], const _Float16* wblk, int ksteps, int r, int h, int half, f32x16& acc) {
-  const _Float16* p = wblk + (h * 32 + r) * 8;
-  int ks = 0;
-  auto group = [&](auto G) {
-    constexpr int g = decltype(G)::value;
-    half8 bf[g];
-#pragma unroll
-    for (int u = 0; u < g; ++u) bf[u] = *reinterpret_cast<const half8*>(p + (size_t)(ks + u) * 512);
-#pragma unroll
-    for (int u = 0; u < g; ++u) {
-      const int k0 = (ks + u) * 16 + 8 * h;
-      const half8 a0 = *reinterpret_cast<const half8*>(&src[32 * half + r][k0]);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, bf[u], acc, 0, 0, 0);
-    }
-    ks += g;
-  };
-  while (ks + 12 <= ksteps) group(std::integral_constant<int, 12>{});
-  while (ks + 4 <= ksteps) group(std::integral_constant<int, 4>{});
-  while (ks + 1 <= ksteps) group(std::integral_constant<int, 1>{});
-}
 // dst[:, 0:Npad] = act(src[:, 0:K] W^T + b) for the 64 rows of the workgroup; this wave takes column blocks wave, wave + PF_WAVES, ...
 template <bool ELU, bool PK, int LDS, int LDD>
 __device__ __forceinline__ void layer(const _Float16 (*src)[LDS], _Float16 (*dst)[LDD], const _Float16* W, const _Float16* B, int in, int out, int wave,
-                                      int lane) {
+                                      int lane, int tag = 0) {
   const int r = lane & 31, h = lane >> 5;
   const int nblk = (out + 31) >> 5, npad = (out + 15) & ~15;  // (a narrow tile only covers the width padded to 16 columns)
   if constexpr (PK) {
-    if (nblk * 2 <= PF_WAVES) {   // few column blocks: (block, 32-row half) per wave -- the same numbers, half the chain per wave
+    const int ksteps = (in + 15) >> 4;
+    // One 32-row half of a column block per wave where a layer has <= 4 column blocks (the 100-wide one: 4): half or more of the eight waves
+    // sat idle while the others ran two MFMA chains each; with (column block, row half) as the unit of work every wave gets one chain.
+    if (nblk * 2 <= PF_WAVES) {
       if (wave < 2 * nblk) {
-        const int nb = wave % nblk, half = wave / nblk, n = nb * 32 + r, ksteps = (in + 15) >> 4;
-        f32x16 acc;
+        const int nb = wave % nblk, half = wave / nblk, cb = nb * 32 + 4 * h;
+        dispatch_ksteps(ksteps, [&](auto RP) {
+          const Bias16 bias = load_bias16(B, cb, out);
+          f32x16 acc;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-        gemm_col_block_packed_half(src, W + (size_t)nb * ksteps * 512, ksteps, r, h, half, acc);
-        const float bias = (B && n < out) ? (float)B[n] : 0.f;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const int row = 32 * half + (i & 3) + 8 * (i >> 2) + 4 * h;
-          float v = (float)(_Float16)(acc[i] + bias);
-          if (ELU) v = v > 0.f ? v : __expf(v) - 1.f;
-          if (LDD >= PF_LD || n < npad) dst[row][n] = (_Float16)v;
-        }
+          for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+          PF_WSTAMP(tag, wave, 0);
+          gemm_packed<LDS, true, 1, decltype(RP)::value>(src, W + (size_t)nb * ksteps * 512, ksteps, r, h, half, &acc);
+          PF_WSTAMP(tag, wave, 1);
+          store_row_groups<ELU>(acc, bias, dst, 32 * half + r, cb, npad);
+          PF_WSTAMP(tag, wave, 2);
+        });
       }
       return;
     }
+    dispatch_ksteps(ksteps, [&](auto RP) {
+      for (int nb = wave; nb < nblk; nb += PF_WAVES) {
+        const int cb = nb * 32 + 4 * h;
+        const Bias16 bias = load_bias16(B, cb, out);
+        f32x16 acc[2];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { acc[0][i] = 0.f; acc[1][i] = 0.f; }
+        if (nb == wave) PF_WSTAMP(tag, wave, 0);
+        gemm_packed<LDS, true, 2, decltype(RP)::value>(src, W + (size_t)nb * ksteps * 512, ksteps, r, h, 0, acc);
+        if (nb == wave) PF_WSTAMP(tag, wave, 1);
+        store_row_groups<ELU>(acc[0], bias, dst, r, cb, npad);
+        store_row_groups<ELU>(acc[1], bias, dst, 32 + r, cb, npad);
+        if (nb == wave) PF_WSTAMP(tag, wave, 2); else PF_WSTAMP(tag, wave, 3);
+      }
+    });
+    return;
   }
   for (int nb = wave; nb < nblk; nb += PF_WAVES) {
     const int n = nb * 32 + r;
@@ -225,8 +342,7 @@ __device__ __forceinline__ void layer(const _Float16 (*src)[LDS], _Float16 (*dst
     f32x16 acc0, acc1;
 #pragma unroll
     for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
-    if constexpr (PK) { const int ksteps = (in + 15) >> 4; gemm_col_block_packed(src, W + (size_t)nb * ksteps * 512, ksteps, r, h, acc0, acc1); }
-    else gemm_col_block(src, wrow, n < out, in, r, h, acc0, acc1);
+    gemm_col_block(src, wrow, n < out, in, r, h, acc0, acc1);
     const float bias = (B && n < out) ? (float)B[n] : 0.f;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
@@ -251,8 +367,8 @@ __device__ __forceinline__ void heads(const PolicyArgs& a, const _Float16 (*src)
   f32x16 acc0, acc1;
 #pragma unroll
   for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
-  if constexpr (PK) gemm_col_block_packed(src, a.w_mu, (in + 15) >> 4, r, h, acc0, acc1);
-  else gemm_col_block(src, wrow, live, in, r, h, acc0, acc1);
+  static_assert(!PK, "the fragment-major instantiations use heads_half");
+  gemm_col_block(src, wrow, live, in, r, h, acc0, acc1);
   const float bias = r < A ? (float)a.b_mu[r] : (r == A ? (float)a.b_val[0] : 0.f);
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
@@ -269,22 +385,24 @@ __device__ __forceinline__ void heads(const PolicyArgs& a, const _Float16 (*src)
 
 template <bool ROLL, int LD>
 __device__ __forceinline__ void heads_half(const PolicyArgs& a, const _Float16 (*src)[LD], int in, float* tile, int64_t row0, int nrow, int lane, int half) {
-  const int r = lane & 31, h = lane >> 5, A = a.num_actions;
-  f32x16 acc;
+  const int r = lane & 31, h = lane >> 5, A = a.num_actions, ksteps = (in + 15) >> 4;
+  dispatch_ksteps(ksteps, [&](auto RP) {
+    f32x16 acc;
 #pragma unroll
-  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-  gemm_col_block_packed_half(src, a.w_mu, (in + 15) >> 4, r, h, half, acc);
-  const float bias = r < A ? (float)a.b_mu[r] : (r == A ? (float)a.b_val[0] : 0.f);
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    gemm_packed<LD, false, 1, decltype(RP)::value>(src, a.w_mu, ksteps, r, h, half, &acc);
+    const float bias = r < A ? (float)a.b_mu[r] : (r == A ? (float)a.b_val[0] : 0.f);
 #pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    const int row = 32 * half + (i & 3) + 8 * (i >> 2) + 4 * h;
-    const float v = (float)(_Float16)(acc[i] + bias);
-    if (ROLL) {
-      if (r <= A) tile[row * 33 + r] = v;
-    } else if (row < nrow) {
-      if (r < A) a.mu[(row0 + row) * A + r] = v; else if (r == A) a.value[row0 + row] = v;
+    for (int i = 0; i < 16; ++i) {
+      const int row = 32 * half + (i & 3) + 8 * (i >> 2) + 4 * h;
+      const float v = (float)(_Float16)(acc[i] + bias);
+      if (ROLL) {
+        if (r <= A) tile[row * 33 + r] = v;
+      } else if (row < nrow) {
+        if (r < A) a.mu[(row0 + row) * A + r] = v; else if (r == A) a.value[row0 + row] = v;
+      }
     }
-  }
+  });
 }
 
 // MODE 0: forward only; 1: rollout step (ROLL); 2: training forward (activations kept for the backward pass).  LD0 / LD1: row strides
@@ -292,7 +410,8 @@ __device__ __forceinline__ void heads_half(const PolicyArgs& a, const _Float16 (
 // 0, 2, 4.  (424, 424) fits every supported width; (216, 424) is 80 KB, so that two workgroups share a CU (training forward of
 // 54-400-200-100: 512 workgroups, each one's MFMAs cover the other's weight-fetch latency).
 template <int MODE, int LD0, int LD1, bool PK>
-__global__ __launch_bounds__(PF_WAVES * 64) void policy_forward_kernel(PolicyArgs a) {
+// (two workgroups per CU -- 4 waves per SIMD, <= 128 VGPRs -- where the two tiles fit twice into the CU's LDS)
+__global__ __launch_bounds__(PF_WAVES * 64, ((LD0 + LD1) * PF_ROWS * 2 <= 80 * 1024) ? 4 : 2) void policy_forward_kernel(PolicyArgs a) {
   constexpr bool ROLL = MODE == 1, TRAIN = MODE == 2;
   __shared__ __attribute__((aligned(16))) _Float16 t0[PF_ROWS][LD0];
   __shared__ __attribute__((aligned(16))) _Float16 t1[PF_ROWS][LD1];
@@ -328,27 +447,33 @@ __global__ __launch_bounds__(PF_WAVES * 64) void policy_forward_kernel(PolicyArg
       }
     }
   }
-  // stage the (normalised) observations as fp16, zero-padded to a multiple of 16 columns
+  // stage the (normalised) observations as fp16, zero-padded to a multiple of 16 columns: lanes over columns (the column's mean and
+  // standard deviation once per lane), waves over rows -- no index division, no fp64 in the row loop
   const int kpad0 = (a.d_in + 15) & ~15;
-  for (int idx = tid; idx < PF_ROWS * kpad0; idx += PF_WAVES * 64) {
-    const int rr = idx / kpad0, k = idx - rr * kpad0;
-    float v = 0.f;
-    if (rr < nrow && k < a.d_in) {
-      v = a.obs[(row0 + rr) * a.d_in + k];
-      if (ROLL) a.mb_obs[(row0 + rr) * a.ld_obs + k] = v;  // the rollout buffer keeps the raw observation
-      if (a.mean) {
-        v = (v - (float)a.mean[k]) / sqrtf((float)a.var[k] + a.eps);
-        v = fminf(fmaxf(v, -5.0f), 5.0f);
+  for (int k = lane; k < kpad0; k += 64) {
+    const bool kin = k < a.d_in;
+    float mk = 0.f, sk = 1.f;
+    if (a.mean && kin) { mk = (float)a.mean[k]; sk = sqrtf((float)a.var[k] + a.eps); }
+#pragma unroll 4
+    for (int rr = wave; rr < PF_ROWS; rr += PF_WAVES) {
+      float v = 0.f;
+      if (rr < nrow && kin) {
+        v = a.obs[(row0 + rr) * a.d_in + k];
+        if (ROLL) a.mb_obs[(row0 + rr) * a.ld_obs + k] = v;  // the rollout buffer keeps the raw observation
+        if (a.mean) {
+          v = (v - mk) / sk;
+          v = fminf(fmaxf(v, -5.0f), 5.0f);
+        }
       }
+      t0[rr][k] = (_Float16)v;
     }
-    t0[rr][k] = (_Float16)v;
   }
   __syncthreads();
   PF_STAMP(1);
   if (TRAIN) store_tile(t0, a.x0_out, row0, nrow, a.d_in, tid);
   int in = a.d_in;
   for (int L = 0; L < a.nhid; L += 2) {
-    layer<true, PK>(t0, t1, a.w[L], a.b[L], in, a.width[L], wave, lane);
+    layer<true, PK>(t0, t1, a.w[L], a.b[L], in, a.width[L], wave, lane, L);
     PF_STAMP(2 + 2 * L);
     // the next layer reads K padded to 16: columns width..pad16(width) were written as elu(0 + 0) = 0 by the padded column block
     __syncthreads();
@@ -356,7 +481,7 @@ __global__ __launch_bounds__(PF_WAVES * 64) void policy_forward_kernel(PolicyArg
     in = a.width[L];
     if (TRAIN) store_tile(t1, a.act_out[L], row0, nrow, in, tid);  // (the stores drain behind the next layer's MFMAs)
     if (L + 1 < a.nhid) {
-      layer<true, PK>(t1, t0, a.w[L + 1], a.b[L + 1], in, a.width[L + 1], wave, lane);
+      layer<true, PK>(t1, t0, a.w[L + 1], a.b[L + 1], in, a.width[L + 1], wave, lane, L + 1);
       PF_STAMP(4 + 2 * L);
       __syncthreads();
       PF_STAMP(5 + 2 * L);
@@ -458,54 +583,122 @@ struct BackwardArgs {
 
 // one layer of the chain: gz = g * elu'(y) in place in tile A (and out to HBM), its per-workgroup column sums, then d/d h_{L-1} = gz W_L
 // into tile B.  The reduction scratch lives in tile B, which is free until the GEMM writes it.
+// gz = g * elu'(y) of a full 64-row tile whose width is a multiple of 4, in place in tile A and out to HBM, and its per-workgroup column
+// sums.  Waves over rows, lanes over groups of four columns (8-byte accesses; a narrow layer puts 64 / P rows side by side in a wave,
+// P = the power of two >= W / 4): every address is a row base plus a lane offset, all of a thread's loads are in flight before its first
+// store, and the arithmetic runs on mixed-precision FMAs -- elu'(y) = min(y, 0) + 1 exactly as fp32 of the fp16 ELU output, the product
+// with g in fp32, one rounding to fp16 (what torch's elu_backward does under autocast), the column sums over the rounded values.
+template <int LA, int LB>
+__device__ __forceinline__ void backward_elementwise_x4(const BackwardArgs& a, _Float16 (*A)[LA], _Float16 (*B)[LB], int L, int64_t row0, int tid, int wave,
+                                                        int lane) {
+  const int W = a.width[L], g = W >> 2;
+  int P = 64, sh = 6;
+  while (P > 1 && (P >> 1) >= g) { P >>= 1; --sh; }
+  const int rp = 64 >> sh, lp = lane & (P - 1), sub = lane >> sh;   // rp rows side by side in a wave
+  const int npass = (g + 63) >> 6;                                  // column-group passes (2 only where g > 64: then P = 64, rp = 1)
+  float* red = reinterpret_cast<float*>(&B[0][0]);                  // [8 rp][W] partial column sums (tile B is free until the GEMM writes it)
+  static_assert(sizeof(_Float16) * PF_ROWS * LB >= sizeof(float) * 8 * PF_MAXW, "the free tile holds the column-sum partials");
+  const _Float16* act = a.act[L] + row0 * W;
+  _Float16* gz = a.gz[L] + row0 * W;
+  const int r0 = wave * rp + sub, rstep = PF_WAVES * rp, niter = PF_ROWS / rstep;   // (uniform: 8, 4, 2 or 1 rows per thread)
+  for (int j = 0; j < npass; ++j) {
+    const int cg = lp + 64 * j;
+    f32x2 s01 = {0.f, 0.f}, s23 = {0.f, 0.f};
+    if (cg < g) {
+      constexpr int NB = 8;   // rows per batch (64 / rstep <= 8 iterations in all)
+      uint2 yy[NB], gg[NB];
+#pragma unroll
+      for (int i = 0; i < NB; ++i) {
+        const int rr = r0 + i * rstep;
+        if (i < niter) {
+          yy[i] = *reinterpret_cast<const uint2*>(act + (size_t)rr * W + 4 * cg);
+          gg[i] = *reinterpret_cast<const uint2*>(&A[rr][4 * cg]);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < NB; ++i) {
+        const int rr = r0 + i * rstep;
+        if (i < niter) {
+          uint32_t zz[2];
+#pragma unroll
+          for (int q = 0; q < 2; ++q) {
+            const half2v y = __builtin_bit_cast(half2v, q ? yy[i].y : yy[i].x), gq = __builtin_bit_cast(half2v, q ? gg[i].y : gg[i].x);
+            const half2v yn = __builtin_elementwise_min(y, half2v{(_Float16)0.f, (_Float16)0.f});
+            const float d0 = __builtin_fmaf((float)yn.x, 1.f, 1.f), d1 = __builtin_fmaf((float)yn.y, 1.f, 1.f);
+            const half2v z = __builtin_convertvector(f32x2{__builtin_fmaf((float)gq.x, d0, 0.f), __builtin_fmaf((float)gq.y, d1, 0.f)}, half2v);
+            zz[q] = __builtin_bit_cast(uint32_t, z);
+            f32x2& sacc = q ? s23 : s01;   // the bias gradient sums what the GEMMs see
+            sacc = f32x2{__builtin_fmaf((float)z.x, 1.f, sacc.x), __builtin_fmaf((float)z.y, 1.f, sacc.y)};
+          }
+          *reinterpret_cast<uint2*>(&A[rr][4 * cg]) = make_uint2(zz[0], zz[1]);
+          *reinterpret_cast<uint2*>(gz + (size_t)rr * W + 4 * cg) = make_uint2(zz[0], zz[1]);
+        }
+      }
+      *reinterpret_cast<float4*>(red + (size_t)r0 * W + 4 * cg) = make_float4(s01.x, s01.y, s23.x, s23.y);
+    }
+  }
+  __syncthreads();
+  if (tid < W) {
+    float sum = 0.f;
+    const int parts = PF_WAVES * rp;
+    for (int q = 0; q < parts; ++q) sum += red[q * W + tid];
+    // (512 workgroups adding to the same 700 addresses cost 20 us of the kernel: per-workgroup partials + one small reduction instead)
+    a.partial[(size_t)blockIdx.x * a.prow + a.poff[L] + tid] = sum;
+  }
+}
+
+// one layer of the chain: gz = g * elu'(y) in place in tile A (and out to HBM), its per-workgroup column sums, then d/d h_{L-1} = gz W_L
+// into tile B.  The reduction scratch lives in tile B, which is free until the GEMM writes it.
 template <bool PK, int LA, int LB>
 __device__ __forceinline__ void backward_stage(const BackwardArgs& a, _Float16 (*A)[LA], _Float16 (*B)[LB], int L, int64_t row0, int nrow, int tid,
                                                int wave, int lane) {
   constexpr int NT = PF_WAVES * 64;
-  float2* red = reinterpret_cast<float2*>(&B[0][0]);
-  static_assert(sizeof(_Float16) * PF_ROWS * LB >= sizeof(float2) * NT, "the free tile holds the reduction scratch");
-  const int W = a.width[L], ncp = W >> 1, nparts = NT / ncp;
-  const int part = tid / ncp, cp = tid - part * ncp;
-  float2 acc = make_float2(0.f, 0.f);
-  if (part < nparts) {  // consecutive threads on consecutive column pairs of a row
-    // eight rows per batch: all loads of the batch (ELU outputs from HBM, gradients from the tile) before its first store -- the
-    // stores may alias the loads as far as the compiler knows, so a plain loop would serialise one HBM latency per row
-    for (int rb = part; rb < nrow; rb += 8 * nparts) {
-      uint32_t yy[8], gy[8];
+  const int W = a.width[L];
+  if ((W & 3) == 0 && nrow == PF_ROWS) {
+    backward_elementwise_x4(a, A, B, L, row0, tid, wave, lane);
+  } else {   // a ragged last tile, or a width that is only even: column pairs, guarded rows
+    float2* red = reinterpret_cast<float2*>(&B[0][0]);
+    static_assert(sizeof(_Float16) * PF_ROWS * LB >= sizeof(float2) * NT, "the free tile holds the reduction scratch");
+    const int ncp = W >> 1, nparts = NT / ncp;
+    const int part = tid / ncp, cp = tid - part * ncp;
+    float2 acc = make_float2(0.f, 0.f);
+    if (part < nparts) {  // consecutive threads on consecutive column pairs of a row
+      for (int rb = part; rb < nrow; rb += 8 * nparts) {
+        uint32_t yy[8], gy[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int rr = rb + u * nparts;
-        yy[u] = 0u; gy[u] = 0u;
-        if (rr < nrow) {
-          yy[u] = *reinterpret_cast<const uint32_t*>(a.act[L] + (row0 + rr) * W + 2 * cp);
-          gy[u] = *reinterpret_cast<const uint32_t*>(&A[rr][2 * cp]);
+        for (int u = 0; u < 8; ++u) {
+          const int rr = rb + u * nparts;
+          yy[u] = 0u; gy[u] = 0u;
+          if (rr < nrow) {
+            yy[u] = *reinterpret_cast<const uint32_t*>(a.act[L] + (row0 + rr) * W + 2 * cp);
+            gy[u] = *reinterpret_cast<const uint32_t*>(&A[rr][2 * cp]);
+          }
         }
-      }
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int rr = rb + u * nparts;
-        if (rr < nrow) {
-          const _Float16 g0 = reinterpret_cast<const _Float16*>(&gy[u])[0], g1 = reinterpret_cast<const _Float16*>(&gy[u])[1];
-          const float y0 = (float)reinterpret_cast<const _Float16*>(&yy[u])[0], y1 = (float)reinterpret_cast<const _Float16*>(&yy[u])[1];
-          _Float16 z[2];
-          z[0] = (_Float16)((float)g0 * (y0 > 0.f ? 1.f : y0 + 1.f));
-          z[1] = (_Float16)((float)g1 * (y1 > 0.f ? 1.f : y1 + 1.f));
-          const uint32_t zz = *reinterpret_cast<const uint32_t*>(z);
-          *reinterpret_cast<uint32_t*>(&A[rr][2 * cp]) = zz;
-          *reinterpret_cast<uint32_t*>(a.gz[L] + (row0 + rr) * W + 2 * cp) = zz;
-          acc.x += (float)z[0]; acc.y += (float)z[1];  // the bias gradient sums what the GEMMs see
+        for (int u = 0; u < 8; ++u) {
+          const int rr = rb + u * nparts;
+          if (rr < nrow) {
+            const _Float16 g0 = reinterpret_cast<const _Float16*>(&gy[u])[0], g1 = reinterpret_cast<const _Float16*>(&gy[u])[1];
+            const float y0 = (float)reinterpret_cast<const _Float16*>(&yy[u])[0], y1 = (float)reinterpret_cast<const _Float16*>(&yy[u])[1];
+            _Float16 z[2];
+            z[0] = (_Float16)((float)g0 * (y0 > 0.f ? 1.f : y0 + 1.f));
+            z[1] = (_Float16)((float)g1 * (y1 > 0.f ? 1.f : y1 + 1.f));
+            const uint32_t zz = *reinterpret_cast<const uint32_t*>(z);
+            *reinterpret_cast<uint32_t*>(&A[rr][2 * cp]) = zz;
+            *reinterpret_cast<uint32_t*>(a.gz[L] + (row0 + rr) * W + 2 * cp) = zz;
+            acc.x += (float)z[0]; acc.y += (float)z[1];  // the bias gradient sums what the GEMMs see
+          }
         }
       }
     }
-  }
-  red[tid] = acc;
-  __syncthreads();
-  if (tid < ncp) {
-    float sx = 0.f, sy = 0.f;
-    for (int q = 0; q < nparts; ++q) { sx += red[q * ncp + tid].x; sy += red[q * ncp + tid].y; }
-    // (512 workgroups adding to the same 700 addresses cost 20 us of the kernel: per-workgroup partials + one small reduction instead)
-    float* dst = a.partial + (size_t)blockIdx.x * a.prow + a.poff[L] + 2 * tid;
-    dst[0] = sx; dst[1] = sy;
+    red[tid] = acc;
+    __syncthreads();
+    if (tid < ncp) {
+      float sx = 0.f, sy = 0.f;
+      for (int q = 0; q < nparts; ++q) { sx += red[q * ncp + tid].x; sy += red[q * ncp + tid].y; }
+      float* dst = a.partial + (size_t)blockIdx.x * a.prow + a.poff[L] + 2 * tid;
+      dst[0] = sx; dst[1] = sy;
+    }
   }
   if (L > 0) {
     __syncthreads();  // the scratch has been read: tile B may be overwritten
@@ -609,7 +802,11 @@ __global__ void scatter_f16_kernel(const _Float16* __restrict__ src, const int32
 
 #ifdef BEZ_PF_STAMPS
 static unsigned long long* g_pf_stamps = nullptr;  // diagnostic build: device buffer of 16 stamps (tools/policy_stamp_probe.py)
-extern "C" void bez_ppo_policy_debug_stamps(unsigned long long* dev) { g_pf_stamps = dev; }
+extern "C" void bez_ppo_policy_debug_stamps(unsigned long long* dev) {   // 16 phase stamps, then (layer, wave, phase) stamps: 16 + 32 * PF_MAXL entries
+  g_pf_stamps = dev;
+  unsigned long long* w = dev ? dev + 16 : nullptr;
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(g_pf_wave_stamps), &w, sizeof(w));
+}
 #endif
 static int fill_args(PolicyArgs& a, const float* obs_dev, int64_t n, int32_t num_obs, const double* obs_mean_dev, const double* obs_var_dev, float obs_eps,
                      int32_t num_hidden, const void* const* hidden_w_f16_dev, const void* const* hidden_b_f16_dev, const int32_t* hidden_width,

@@ -5,10 +5,11 @@ import ctypes as C, os, subprocess, sys
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 sys.path.insert(0, ROOT)
 import torch
+SRC = os.environ.get("PF_SRC", os.path.join(ROOT, "bez_isaacgym_amd", "csrc", "bez_policy.hip"))   # (another tree's copy for an A/B)
 so = os.path.join(ROOT, "gpurun_out", "libbez_policy_stamps.so")
 os.makedirs(os.path.dirname(so), exist_ok=True)
 subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fno-slp-vectorize", "-DBEZ_PF_STAMPS", "-o", so,
-                os.path.join(ROOT, "bez_isaacgym_amd", "csrc", "bez_policy.hip")], check=True)
+                SRC], check=True)
 lib = C.CDLL(so)
 dev = "cuda:0"
 torch.manual_seed(0)
@@ -19,7 +20,7 @@ mu_w, mu_b = (torch.randn(a, 100, device=dev) / 10).half().contiguous(), torch.z
 v_w, v_b = (torch.randn(1, 100, device=dev) / 10).half().contiguous(), torch.zeros(1, device=dev).half()
 obs = torch.randn(n, d, device=dev)
 mu, val = torch.empty(n, a, device=dev), torch.empty(n, 1, device=dev)
-stamps = torch.zeros(16, dtype=torch.int64, device=dev)
+stamps = torch.zeros(16 + 32 * 6, dtype=torch.int64, device=dev)
 lib.bez_ppo_policy_debug_stamps(C.c_void_p(stamps.data_ptr()))
 hw = (C.c_void_p * 3)(*[w.data_ptr() for w, _ in hid]); hb = (C.c_void_p * 3)(*[b.data_ptr() for _, b in hid]); wd = (C.c_int32 * 3)(*units)
 vp = C.c_void_p
@@ -56,3 +57,9 @@ names = {0: "entry", 1: "obs staged + sync", 2: "layer 0 done (wave 0)", 3: "aft
 for k in sorted(names):
     if s[k]:
         print("%-24s %8d" % (names[k], s[k] - s[0]))
+print("per wave (relative to entry): layer, wave: product start / product done / epilogue done [/ second block done]")
+for L in range(3):
+    for w in range(8):
+        v = s[16 + L * 32 + w * 4: 16 + L * 32 + w * 4 + 4]
+        if v[0]:
+            print("  L%d w%d  %s" % (L, w, "  ".join("%7d" % (x - s[0]) if x else "      -" for x in v)))

@@ -1,0 +1,24 @@
+#!/bin/bash
+# Per-kernel durations of the PPO leg for library builds (tools/ab_build.sh) on the SAME box, from rocprofv3 kernel stats.
+# usage: bash tools/ppo_kernel_ab.sh a b ...
+set -e
+export TMPDIR=/tmp
+L=bez_isaacgym_amd/lib/libbez_sim.so
+cp $L /tmp/libbez_sim.keep
+for n in "$@"; do
+  cp build_ab/$n.so $L
+  rm -rf gpurun_out/kab_$n
+  rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/kab_$n -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --ppo-epochs 10 > gpurun_out/kab_$n.log 2>&1
+  echo "== $n"
+  python3 - "$n" <<'PY'
+import csv, glob, sys
+f = glob.glob("gpurun_out/kab_%s/**/*kernel_stats.csv" % sys.argv[1], recursive=True)[0]
+rows = list(csv.DictReader(open(f)))
+for r in rows:
+    name = r["Name"]
+    if any(k in name for k in ("policy_forward", "policy_backward", "wgrad", "ppo_loss", "adam_fused", "grad_reduce", "step_kernel")):
+        print("%-90s calls %6s avg %9.2f us" % (name[:90], r["Calls"], float(r["AverageNs"]) / 1e3))
+PY
+done
+cp /tmp/libbez_sim.keep $L
+find gpurun_out -name "*agent_info.csv" -delete; find gpurun_out -name "*kernel_trace.csv" -path "*kab_*" -delete
