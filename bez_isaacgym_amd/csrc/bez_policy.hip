@@ -169,12 +169,42 @@ __device__ __forceinline__ void gemm_col_block(const _Float16 (*src)[LD], const 
 // T: the TRANSPOSED product (weights as the A operand, activations as B): the same fragments and the same sums, but a lane then holds 16
 // output COLUMNS (4 groups of 4 consecutive ones) of its row r instead of 16 rows of its column -- see layer().
 // NACC = 2: both 32-row halves of the tile (acc[0], acc[1]); NACC = 1: the half `half` only (acc[0]).
+struct alignas(4) BiasQuad { half2v lo, hi; };
+struct Bias16 { BiasQuad q[4]; };
+// the 16 bias values of a lane's output columns as four groups of four consecutive ones: unconditional loads, issued BEFORE the product so
+// that they ride behind its weight stream (a guarded load per element compiles to 16 branches, each waiting for its own load).  `out` a
+// multiple of 4 and B 4-byte aligned (every Linear of the flat fp16 working copy): a group is either complete or absent, one request each.
+__device__ __forceinline__ Bias16 load_bias16(const _Float16* B, int cb, int out) {
+  Bias16 b;
+  const half2v z = half2v{(_Float16)0.f, (_Float16)0.f};
+  if (!B) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { b.q[j].lo = z; b.q[j].hi = z; }
+  } else if (((out & 3) | (int)(reinterpret_cast<uintptr_t>(B) & 3)) == 0) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int c = cb + 8 * j;
+      b.q[j] = *reinterpret_cast<const BiasQuad*>(B + (c < out ? c : 0));   // (columns >= out: zeroed in the epilogue)
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int c = cb + 8 * j;
+      b.q[j].lo = half2v{B[c < out ? c : 0], B[c + 1 < out ? c + 1 : 0]};
+      b.q[j].hi = half2v{B[c + 2 < out ? c + 2 : 0], B[c + 3 < out ? c + 3 : 0]};
+    }
+  }
+  return b;
+}
 constexpr int PF_G = 4;
 // RP = ksteps mod 2 PF_G as a compile-time constant (the callers switch on it): pairs of full groups in a branch-free loop, then RP k-steps
 // of straight-line code -- no accumulator ever meets a branch (each guarded MFMA is a phi the register allocator answers with copies of the
 // 16-register accumulators and out-of-place MFMAs).
+// The accumulators start at `bias` (T only: the lane's 16 output columns; null = 0) -- set AFTER the first group's requests are out, so the
+// bias loads ride behind them and the epilogue has no bias add.
 template <int LD, bool T, int NACC, int RP>
-__device__ __forceinline__ void gemm_packed(const _Float16 (*src)[LD], const _Float16* wblk, int ksteps, int r, int h, int half, f32x16* acc) {
+__device__ __forceinline__ void gemm_packed(const _Float16 (*src)[LD], const _Float16* wblk, int ksteps, int r, int h, int half, f32x16* acc,
+                                            const Bias16* bias = nullptr) {
   const _Float16* p = wblk + (h * 32 + r) * 8;   // this lane's 16 bytes of chunk 0; chunk k is 512 halfs further
   auto fetch = [&](half8* f, int g) {             // group g: k-steps g PF_G ..; past the end: harmless repeats of the last chunk, never multiplied
 #pragma unroll
@@ -206,6 +236,14 @@ __device__ __forceinline__ void gemm_packed(const _Float16 (*src)[LD], const _Fl
   half8 fa[PF_G], fb[PF_G];
   __builtin_amdgcn_sched_barrier(0);
   fetch(fa, 0);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    f32x2 lo = {0.f, 0.f}, hi = {0.f, 0.f};
+    if (T && bias) { lo = __builtin_convertvector(bias->q[j].lo, f32x2); hi = __builtin_convertvector(bias->q[j].hi, f32x2); }
+#pragma unroll
+    for (int c = 0; c < NACC; ++c) { acc[c][4 * j] = lo.x; acc[c][4 * j + 1] = lo.y; acc[c][4 * j + 2] = hi.x; acc[c][4 * j + 3] = hi.y; }
+  }
+  __builtin_amdgcn_sched_barrier(0);
   for (int i = 0; i < npair; ++i) {   // branch-free body: the wait counters stay exact (the next group's four requests outstanding)
     fetch(fb, 2 * i + 1);
     stage(fa, 2 * i * PF_G, Full{});
@@ -235,37 +273,10 @@ __device__ __forceinline__ void dispatch_ksteps(int ksteps, F&& run) {
 // cb = 32 nb + 4 h) of ONE row.  Bias, the fp16 rounding of the Linear and ELU run two outputs per packed instruction and every group of four
 // leaves as one 8-byte LDS store (the direct product's lane holds 16 rows of one column: 16 two-byte stores and scalar math per 16 results --
 // that epilogue, not the MFMAs, was what a column block cost: ~2 k cycles against 0.4-1.6 k of matrix work, tools/policy_stamp_probe.py).
-struct alignas(4) BiasQuad { half2v lo, hi; };
-struct Bias16 { BiasQuad q[4]; };
-// the 16 bias values of a lane's output columns as four groups of four consecutive ones: unconditional loads, issued BEFORE the product so
-// that they ride behind its weight stream (a guarded load per element compiles to 16 branches, each waiting for its own load).  `out` a
-// multiple of 4 and B 4-byte aligned (every Linear of the flat fp16 working copy): a group is either complete or absent, one request each.
-__device__ __forceinline__ Bias16 load_bias16(const _Float16* B, int cb, int out) {
-  Bias16 b;
-  const half2v z = half2v{(_Float16)0.f, (_Float16)0.f};
-  if (!B) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) { b.q[j].lo = z; b.q[j].hi = z; }
-  } else if (((out & 3) | (int)(reinterpret_cast<uintptr_t>(B) & 3)) == 0) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int c = cb + 8 * j;
-      b.q[j] = *reinterpret_cast<const BiasQuad*>(B + (c < out ? c : 0));   // (columns >= out: zeroed in the epilogue)
-    }
-  } else {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int c = cb + 8 * j;
-      b.q[j].lo = half2v{B[c < out ? c : 0], B[c + 1 < out ? c + 1 : 0]};
-      b.q[j].hi = half2v{B[c + 2 < out ? c + 2 : 0], B[c + 3 < out ? c + 3 : 0]};
-    }
-  }
-  return b;
-}
 // (Columns >= out of the last block get the bias of column 0: finite values in the K padding of the next layer, where the fragment-major
 // weights are zero -- as harmless as the elu(0) they used to hold, and two guards per pair cheaper.)
 template <bool ELU, int LDD>
-__device__ __forceinline__ void store_row_groups(const f32x16& acc, const Bias16& b, _Float16 (*dst)[LDD], int row, int cb, int npad) {
+__device__ __forceinline__ void store_row_groups(const f32x16& acc, _Float16 (*dst)[LDD], int row, int cb, int npad) {
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int c0 = cb + 8 * j;
@@ -273,16 +284,16 @@ __device__ __forceinline__ void store_row_groups(const f32x16& acc, const Bias16
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
       const int i = 4 * j + 2 * q;
-      const f32x2 s = f32x2{acc[i], acc[i + 1]} + __builtin_convertvector(q ? b.q[j].hi : b.q[j].lo, f32x2);
-      const half2v hq = __builtin_convertvector(s, half2v);  // the fp16 output of the Linear
+      const half2v hq = __builtin_convertvector(f32x2{acc[i], acc[i + 1]}, half2v);  // the fp16 output of the Linear (the bias is in the accumulator)
       if (ELU) {
         // elu on the fp16 value, computed in fp32 as torch does: h > 0 ? h : exp(h) - 1.  The select works on the sign bits of the packed pair
-        // (h = +0 and exp(+0) - 1 are the same number, NaN stays NaN either way): one shift and one bit-field insert per pair
+        // (h = +0 and exp(+0) - 1 are the same number, NaN stays NaN either way): one packed shift and one bit-field insert per pair
         const f32x2 e = f32x2{__builtin_amdgcn_exp2f(__builtin_fmaf((float)hq.x, 1.4426950408889634f, 0.f)),
                               __builtin_amdgcn_exp2f(__builtin_fmaf((float)hq.y, 1.4426950408889634f, 0.f))} - f32x2{1.f, 1.f};   // (v_fma_mix_f32: the conversion rides in the multiply)
         const half2v eh = __builtin_convertvector(e, half2v);
         const uint32_t hb = __builtin_bit_cast(uint32_t, hq), eb = __builtin_bit_cast(uint32_t, eh);
-        const uint32_t neg = ((hb >> 15) & 0x00010001u) * 0xffffu;   // 0xffff in every half whose sign bit is set
+        uint32_t neg;   // 0xffff in every half whose sign bit is set (the compiler turns the C form of this into two compares and selects)
+        asm("v_pk_ashrrev_i16 %0, %1, %2" : "=v"(neg) : "v"(0x000f000fu), "v"(hb));   // (an inline 15 would only reach the low half)
         o[q] = (eb & neg) | (hb & ~neg);
       } else {
         o[q] = __builtin_bit_cast(uint32_t, hq);
@@ -308,12 +319,10 @@ __device__ __forceinline__ void layer(const _Float16 (*src)[LDS], _Float16 (*dst
         dispatch_ksteps(ksteps, [&](auto RP) {
           const Bias16 bias = load_bias16(B, cb, out);
           f32x16 acc;
-#pragma unroll
-          for (int i = 0; i < 16; ++i) acc[i] = 0.f;
           PF_WSTAMP(tag, wave, 0);
-          gemm_packed<LDS, true, 1, decltype(RP)::value>(src, W + (size_t)nb * ksteps * 512, ksteps, r, h, half, &acc);
+          gemm_packed<LDS, true, 1, decltype(RP)::value>(src, W + (size_t)nb * ksteps * 512, ksteps, r, h, half, &acc, &bias);
           PF_WSTAMP(tag, wave, 1);
-          store_row_groups<ELU>(acc, bias, dst, 32 * half + r, cb, npad);
+          store_row_groups<ELU>(acc, dst, 32 * half + r, cb, npad);
           PF_WSTAMP(tag, wave, 2);
         });
       }
@@ -324,13 +333,11 @@ __device__ __forceinline__ void layer(const _Float16 (*src)[LDS], _Float16 (*dst
         const int cb = nb * 32 + 4 * h;
         const Bias16 bias = load_bias16(B, cb, out);
         f32x16 acc[2];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) { acc[0][i] = 0.f; acc[1][i] = 0.f; }
         if (nb == wave) PF_WSTAMP(tag, wave, 0);
-        gemm_packed<LDS, true, 2, decltype(RP)::value>(src, W + (size_t)nb * ksteps * 512, ksteps, r, h, 0, acc);
+        gemm_packed<LDS, true, 2, decltype(RP)::value>(src, W + (size_t)nb * ksteps * 512, ksteps, r, h, 0, acc, &bias);
         if (nb == wave) PF_WSTAMP(tag, wave, 1);
-        store_row_groups<ELU>(acc[0], bias, dst, r, cb, npad);
-        store_row_groups<ELU>(acc[1], bias, dst, 32 + r, cb, npad);
+        store_row_groups<ELU>(acc[0], dst, r, cb, npad);
+        store_row_groups<ELU>(acc[1], dst, 32 + r, cb, npad);
         if (nb == wave) PF_WSTAMP(tag, wave, 2); else PF_WSTAMP(tag, wave, 3);
       }
     });
@@ -339,15 +346,15 @@ __device__ __forceinline__ void layer(const _Float16 (*src)[LDS], _Float16 (*dst
   for (int nb = wave; nb < nblk; nb += PF_WAVES) {
     const int n = nb * 32 + r;
     const _Float16* wrow = W + (size_t)(n < out ? n : 0) * in;
-    f32x16 acc0, acc1;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
-    gemm_col_block(src, wrow, n < out, in, r, h, acc0, acc1);
     const float bias = (B && n < out) ? (float)B[n] : 0.f;
+    f32x16 acc0, acc1;   // (the accumulators start at the bias, as in the fragment-major path: the two stay bit-identical)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { acc0[i] = bias; acc1[i] = bias; }
+    gemm_col_block(src, wrow, n < out, in, r, h, acc0, acc1);
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const int row = (i & 3) + 8 * (i >> 2) + 4 * h;
-      float v0 = (float)(_Float16)(acc0[i] + bias), v1 = (float)(_Float16)(acc1[i] + bias);  // the fp16 output of the Linear
+      float v0 = (float)(_Float16)acc0[i], v1 = (float)(_Float16)acc1[i];  // the fp16 output of the Linear
       if (ELU) { v0 = v0 > 0.f ? v0 : __expf(v0) - 1.f; v1 = v1 > 0.f ? v1 : __expf(v1) - 1.f; }  // (v_exp_f32: the result is rounded to fp16 anyway)
       if (LDD >= PF_LD || n < npad) {
         dst[row][n] = (_Float16)v0;
@@ -388,8 +395,6 @@ __device__ __forceinline__ void heads_half(const PolicyArgs& a, const _Float16 (
   const int r = lane & 31, h = lane >> 5, A = a.num_actions, ksteps = (in + 15) >> 4;
   dispatch_ksteps(ksteps, [&](auto RP) {
     f32x16 acc;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
     gemm_packed<LD, false, 1, decltype(RP)::value>(src, a.w_mu, ksteps, r, h, half, &acc);
     const float bias = r < A ? (float)a.b_mu[r] : (r == A ? (float)a.b_val[0] : 0.f);
 #pragma unroll
@@ -624,8 +629,9 @@ __device__ __forceinline__ void backward_elementwise_x4(const BackwardArgs& a, _
           for (int q = 0; q < 2; ++q) {
             const half2v y = __builtin_bit_cast(half2v, q ? yy[i].y : yy[i].x), gq = __builtin_bit_cast(half2v, q ? gg[i].y : gg[i].x);
             const half2v yn = __builtin_elementwise_min(y, half2v{(_Float16)0.f, (_Float16)0.f});
-            const float d0 = __builtin_fmaf((float)yn.x, 1.f, 1.f), d1 = __builtin_fmaf((float)yn.y, 1.f, 1.f);
-            const half2v z = __builtin_convertvector(f32x2{__builtin_fmaf((float)gq.x, d0, 0.f), __builtin_fmaf((float)gq.y, d1, 0.f)}, half2v);
+            // g (min(y, 0) + 1) = g min(y, 0) + g: one fused multiply-add on fp16 operands, exact before its single fp32 rounding -- the same
+            // number as the fp32 product of g with the (exact) fp32 sum
+            const half2v z = __builtin_convertvector(f32x2{__builtin_fmaf((float)gq.x, (float)yn.x, (float)gq.x), __builtin_fmaf((float)gq.y, (float)yn.y, (float)gq.y)}, half2v);
             zz[q] = __builtin_bit_cast(uint32_t, z);
             f32x2& sacc = q ? s23 : s01;   // the bias gradient sums what the GEMMs see
             sacc = f32x2{__builtin_fmaf((float)z.x, 1.f, sacc.x), __builtin_fmaf((float)z.y, 1.f, sacc.y)};
