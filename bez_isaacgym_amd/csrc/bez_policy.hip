@@ -77,19 +77,19 @@ __device__ unsigned long long* g_pf_wave_stamps = nullptr;   // (layer tag, wave
 // rows [0, nrow) x columns [0, cols) of an LDS activation tile -> global (row-major, `cols` halfs per row, cols even): half2 per
 // lane, consecutive lanes on consecutive columns (256 B per wave instruction)
 template <int LD>
-__device__ __forceinline__ void store_tile(const _Float16 (*src)[LD], _Float16* dst, int64_t row0, int nrow, int cols, int tid) {
+__device__ __forceinline__ void store_tile(const _Float16 (*src)[LD], _Float16* dst, int64_t row0, int nrow, int cols, int tid, int nw = PF_WAVES) {
   // waves over rows, lanes over columns: no index division (a flat index over (row, column pair) costs an integer division by a run-time
   // width per element -- ~1.9 k of the training forward's 3.4 k vector instructions per wave were that); 8 bytes per lane where the width allows
   const int lane = tid & 63, wave = tid >> 6;
   if ((cols & 3) == 0) {
     const int c4 = cols >> 2;
-    for (int rr = wave; rr < nrow; rr += PF_WAVES) {
+    for (int rr = wave; rr < nrow; rr += nw) {
       _Float16* drow = dst + (row0 + rr) * cols;
       for (int c = lane; c < c4; c += 64) *reinterpret_cast<uint2*>(drow + 4 * c) = *reinterpret_cast<const uint2*>(&src[rr][4 * c]);
     }
   } else {
     const int c2 = cols >> 1;
-    for (int rr = wave; rr < nrow; rr += PF_WAVES) {
+    for (int rr = wave; rr < nrow; rr += nw) {
       _Float16* drow = dst + (row0 + rr) * cols;
       for (int c = lane; c < c2; c += 64) *reinterpret_cast<uint32_t*>(drow + 2 * c) = *reinterpret_cast<const uint32_t*>(&src[rr][2 * c]);
     }
@@ -306,14 +306,14 @@ __device__ __forceinline__ void store_row_groups(const f32x16& acc, _Float16 (*d
 // dst[:, 0:Npad] = act(src[:, 0:K] W^T + b) for the 64 rows of the workgroup; this wave takes column blocks wave, wave + PF_WAVES, ...
 template <bool ELU, bool PK, int LDS, int LDD>
 __device__ __forceinline__ void layer(const _Float16 (*src)[LDS], _Float16 (*dst)[LDD], const _Float16* W, const _Float16* B, int in, int out, int wave,
-                                      int lane, int tag = 0) {
+                                      int lane, int tag = 0, int nw = PF_WAVES) {   // nw: waves of the workgroup (8, or 16 in the 4096-row forward kernels)
   const int r = lane & 31, h = lane >> 5;
   const int nblk = (out + 31) >> 5, npad = (out + 15) & ~15;  // (a narrow tile only covers the width padded to 16 columns)
   if constexpr (PK) {
     const int ksteps = (in + 15) >> 4;
     // One 32-row half of a column block per wave where a layer has <= 4 column blocks (the 100-wide one: 4): half or more of the eight waves
     // sat idle while the others ran two MFMA chains each; with (column block, row half) as the unit of work every wave gets one chain.
-    if (nblk * 2 <= PF_WAVES) {
+    if (nblk * 2 <= nw) {
       if (wave < 2 * nblk) {
         const int nb = wave % nblk, half = wave / nblk, cb = nb * 32 + 4 * h;
         dispatch_ksteps(ksteps, [&](auto RP) {
@@ -329,7 +329,7 @@ __device__ __forceinline__ void layer(const _Float16 (*src)[LDS], _Float16 (*dst
       return;
     }
     dispatch_ksteps(ksteps, [&](auto RP) {
-      for (int nb = wave; nb < nblk; nb += PF_WAVES) {
+      for (int nb = wave; nb < nblk; nb += nw) {
         const int cb = nb * 32 + 4 * h;
         const Bias16 bias = load_bias16(B, cb, out);
         f32x16 acc[2];
@@ -343,7 +343,7 @@ __device__ __forceinline__ void layer(const _Float16 (*src)[LDS], _Float16 (*dst
     });
     return;
   }
-  for (int nb = wave; nb < nblk; nb += PF_WAVES) {
+  for (int nb = wave; nb < nblk; nb += nw) {
     const int n = nb * 32 + r;
     const _Float16* wrow = W + (size_t)(n < out ? n : 0) * in;
     const float bias = (B && n < out) ? (float)B[n] : 0.f;
@@ -414,13 +414,18 @@ __device__ __forceinline__ void heads_half(const PolicyArgs& a, const _Float16 (
 // (halfs) of the two LDS activation tiles -- tile 0 holds the staged input and the outputs of layers 1, 3, 5, tile 1 those of layers
 // 0, 2, 4.  (424, 424) fits every supported width; (216, 424) is 80 KB, so that two workgroups share a CU (training forward of
 // 54-400-200-100: 512 workgroups, each one's MFMAs cover the other's weight-fetch latency).
+// Waves per workgroup.  Training forward (MODE 2): 8, and two workgroups per CU (4 waves per SIMD, <= 128 VGPRs) where the
+// two tiles fit twice into the CU's LDS.  Forward-only / rollout (4096 rows = 64 workgroups on 256 CUs, one per CU): 16 waves -- every
+// layer of 54-400-200-100 is then ONE round of units (13 column blocks; 14, 8 and 2 (block, row half) units) instead of two rounds of
+// double work on 8 waves; the kernel is a chain of per-layer latencies, and this halves the two longest links.
+constexpr int PF_FWD_WAVES = 16;
 template <int MODE, int LD0, int LD1, bool PK>
-// (two workgroups per CU -- 4 waves per SIMD, <= 128 VGPRs -- where the two tiles fit twice into the CU's LDS)
-__global__ __launch_bounds__(PF_WAVES * 64, ((LD0 + LD1) * PF_ROWS * 2 <= 80 * 1024) ? 4 : 2) void policy_forward_kernel(PolicyArgs a) {
+__global__ __launch_bounds__(MODE == 2 ? PF_WAVES * 64 : PF_FWD_WAVES * 64, (MODE != 2 || (LD0 + LD1) * PF_ROWS * 2 <= 80 * 1024) ? 4 : 2) void policy_forward_kernel(PolicyArgs a) {
   constexpr bool ROLL = MODE == 1, TRAIN = MODE == 2;
   __shared__ __attribute__((aligned(16))) _Float16 t0[PF_ROWS][LD0];
   __shared__ __attribute__((aligned(16))) _Float16 t1[PF_ROWS][LD1];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  constexpr int nw = MODE == 2 ? PF_WAVES : PF_FWD_WAVES, nt = nw * 64;   // (= blockDim.x: the launches below)
   if (ROLL && a.dr_on && blockIdx.x == gridDim.x - 1) {
     // the extra workgroup: the coming env step's domain randomisation (bez_dr_step.h), beside the forward pass of the others.  It reads the
     // envs' reset flags / episode counters and writes the randomisation's own state and the per-env parameter rows -- nothing the other
@@ -442,7 +447,7 @@ __global__ __launch_bounds__(PF_WAVES * 64, ((LD0 + LD1) * PF_ROWS * 2 <= 80 * 1
     const unsigned long long frame = (unsigned long long)sn.frame_hi << 32 | sn.frame_lo;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      const int idx = tid + k * PF_WAVES * 64;
+      const int idx = tid + k * nt;
       if (idx < nrow * a.num_actions) {
         const int64_t o = row0 * a.num_actions + idx;
         float z4[4];
@@ -460,7 +465,7 @@ __global__ __launch_bounds__(PF_WAVES * 64, ((LD0 + LD1) * PF_ROWS * 2 <= 80 * 1
     float mk = 0.f, sk = 1.f;
     if (a.mean && kin) { mk = (float)a.mean[k]; sk = sqrtf((float)a.var[k] + a.eps); }
 #pragma unroll 4
-    for (int rr = wave; rr < PF_ROWS; rr += PF_WAVES) {
+    for (int rr = wave; rr < PF_ROWS; rr += nw) {
       float v = 0.f;
       if (rr < nrow && kin) {
         v = a.obs[(row0 + rr) * a.d_in + k];
@@ -475,23 +480,23 @@ __global__ __launch_bounds__(PF_WAVES * 64, ((LD0 + LD1) * PF_ROWS * 2 <= 80 * 1
   }
   __syncthreads();
   PF_STAMP(1);
-  if (TRAIN) store_tile(t0, a.x0_out, row0, nrow, a.d_in, tid);
+  if (TRAIN) store_tile(t0, a.x0_out, row0, nrow, a.d_in, tid, nw);
   int in = a.d_in;
   for (int L = 0; L < a.nhid; L += 2) {
-    layer<true, PK>(t0, t1, a.w[L], a.b[L], in, a.width[L], wave, lane, L);
+    layer<true, PK>(t0, t1, a.w[L], a.b[L], in, a.width[L], wave, lane, L, nw);
     PF_STAMP(2 + 2 * L);
     // the next layer reads K padded to 16: columns width..pad16(width) were written as elu(0 + 0) = 0 by the padded column block
     __syncthreads();
     PF_STAMP(3 + 2 * L);
     in = a.width[L];
-    if (TRAIN) store_tile(t1, a.act_out[L], row0, nrow, in, tid);  // (the stores drain behind the next layer's MFMAs)
+    if (TRAIN) store_tile(t1, a.act_out[L], row0, nrow, in, tid, nw);  // (the stores drain behind the next layer's MFMAs)
     if (L + 1 < a.nhid) {
-      layer<true, PK>(t1, t0, a.w[L + 1], a.b[L + 1], in, a.width[L + 1], wave, lane, L + 1);
+      layer<true, PK>(t1, t0, a.w[L + 1], a.b[L + 1], in, a.width[L + 1], wave, lane, L + 1, nw);
       PF_STAMP(4 + 2 * L);
       __syncthreads();
       PF_STAMP(5 + 2 * L);
       in = a.width[L + 1];
-      if (TRAIN) store_tile(t0, a.act_out[L + 1], row0, nrow, in, tid);
+      if (TRAIN) store_tile(t0, a.act_out[L + 1], row0, nrow, in, tid, nw);
     }
   }
   const bool in_t1 = (a.nhid & 1) != 0;  // where the last hidden activations are; the other tile is free
@@ -511,10 +516,10 @@ __global__ __launch_bounds__(PF_WAVES * 64, ((LD0 + LD1) * PF_ROWS * 2 <= 80 * 1
     __syncthreads();
     const int A = a.num_actions;
     float* zz = tile + PF_ROWS * 33;  // (64, 32) squared standardised actions
-    static_assert(4 * PF_WAVES * 64 >= PF_ROWS * 31, "nzr holds every element a thread owns");
+    static_assert(4 * PF_WAVES * 64 >= PF_ROWS * 31, "nzr holds every element a thread owns (at the smallest workgroup)");
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
-      const int idx = tid + it * PF_WAVES * 64;
+      const int idx = tid + it * nt;
       if (idx >= nrow * A) break;
       const int rr = idx / A, j = idx - rr * A;
       const float m = tile[rr * 33 + j];
@@ -586,8 +591,6 @@ struct BackwardArgs {
   int prow;                                       // = ptotal + 32: the heads' column sums [d/d mu | d/d value] follow the hidden layers' in a row
 };
 
-// one layer of the chain: gz = g * elu'(y) in place in tile A (and out to HBM), its per-workgroup column sums, then d/d h_{L-1} = gz W_L
-// into tile B.  The reduction scratch lives in tile B, which is free until the GEMM writes it.
 // gz = g * elu'(y) of a full 64-row tile whose width is a multiple of 4, in place in tile A and out to HBM, and its per-workgroup column
 // sums.  Waves over rows, lanes over groups of four columns (8-byte accesses; a narrow layer puts 64 / P rows side by side in a wave,
 // P = the power of two >= W / 4): every address is a row base plus a lane offset, all of a thread's loads are in flight before its first
@@ -852,8 +855,8 @@ extern "C" int bez_ppo_policy_forward(const float* obs_dev, int64_t n, int32_t n
   if (!mu_dev || !value_dev || fill_args(a, obs_dev, n, num_obs, obs_mean_dev, obs_var_dev, obs_eps, num_hidden, hidden_w_f16_dev, hidden_b_f16_dev, hidden_width,
                                          mu_w_f16_dev, mu_b_f16_dev, num_actions, value_w_f16_dev, value_b_f16_dev)) return -1;
   a.mu = mu_dev; a.value = value_dev; a.packed = weights_packed;
-  if (weights_packed) hipLaunchKernelGGL((policy_forward_kernel<0, PF_LD, PF_LD, true>), dim3((unsigned)((n + PF_ROWS - 1) / PF_ROWS)), dim3(PF_WAVES * 64), 0, (hipStream_t)stream, a);
-  else hipLaunchKernelGGL((policy_forward_kernel<0, PF_LD, PF_LD, false>), dim3((unsigned)((n + PF_ROWS - 1) / PF_ROWS)), dim3(PF_WAVES * 64), 0, (hipStream_t)stream, a);
+  if (weights_packed) hipLaunchKernelGGL((policy_forward_kernel<0, PF_LD, PF_LD, true>), dim3((unsigned)((n + PF_ROWS - 1) / PF_ROWS)), dim3(PF_FWD_WAVES * 64), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL((policy_forward_kernel<0, PF_LD, PF_LD, false>), dim3((unsigned)((n + PF_ROWS - 1) / PF_ROWS)), dim3(PF_FWD_WAVES * 64), 0, (hipStream_t)stream, a);
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
@@ -884,8 +887,8 @@ extern "C" int bez_ppo_policy_rollout_step(const float* obs_dev, int64_t n, int3
   static_assert(sizeof(bez::dr::DrArgs) <= BEZ_DR_STEP_BYTES, "BezPpoDrStep blob of the C ABI too small");
   if (dr_step) { std::memcpy(&a.dr, dr_step, sizeof(a.dr)); a.dr_on = 1; if (a.dr.n <= 0 || !a.dr.st || a.dr.first) return -1; }
   const unsigned grid = (unsigned)((n + PF_ROWS - 1) / PF_ROWS) + (dr_step ? 1u : 0u);   // + the randomisation workgroup
-  if (weights_packed) hipLaunchKernelGGL((policy_forward_kernel<1, PF_LD, PF_LD, true>), dim3(grid), dim3(PF_WAVES * 64), 0, (hipStream_t)stream, a);
-  else hipLaunchKernelGGL((policy_forward_kernel<1, PF_LD, PF_LD, false>), dim3(grid), dim3(PF_WAVES * 64), 0, (hipStream_t)stream, a);
+  if (weights_packed) hipLaunchKernelGGL((policy_forward_kernel<1, PF_LD, PF_LD, true>), dim3(grid), dim3(PF_FWD_WAVES * 64), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL((policy_forward_kernel<1, PF_LD, PF_LD, false>), dim3(grid), dim3(PF_FWD_WAVES * 64), 0, (hipStream_t)stream, a);
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
