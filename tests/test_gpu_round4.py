@@ -223,3 +223,59 @@ def test_eager_work_and_checkpoint_saves_between_graph_replays_change_nothing(fu
     assert all(torch.isfinite(p).all() for p in pb)
     for u, v in zip(pa + ma, pb + mb):
         assert torch.equal(u, v)
+
+
+@pytest.mark.parametrize("packed", [False, True])
+@pytest.mark.parametrize("n,d,units,a", [(64 * 3 + 21, 34, (96, 50), 7), (64 * 4, 54, (400, 200, 100), 18)])
+def test_backward_chain_matches_a_plain_torch_restatement(n, d, units, a, packed):
+    """bez_ppo_policy_backward against the chain written out in torch (fp16 tensors, fp32 arithmetic, one rounding per autocast
+    node): gz_L = fp16(g_L * elu'(y_L)), bias gradient = sum of the rounded gz_L, g_(L-1) = fp16(gz_L W_L).  Shapes: full 64-row tiles
+    with widths that are multiples of 4 (the 8-byte fast path of the elementwise pass), a ragged last tile and a width that is only
+    even (the guarded column-pair path), fragment-major and row-major weights."""
+    import torch
+    from bez_isaacgym_amd.ppo import fused as F
+    from bez_isaacgym_amd.ppo.a2c_continuous import RunningMeanStd
+    DEV = "cuda:0"
+    torch.manual_seed(23)
+    nl = len(units)
+    dims = [d] + list(units)
+    shapes = [(dims[i + 1], dims[i]) for i in range(nl)] + [(a, dims[-1]), (1, dims[-1])]
+    hflat = (torch.randn(sum(o * k + o for o, k in shapes), device=DEV) * 0.1).half()
+    views, layout, off = [], [], 0
+    for o, k in shapes:
+        w = hflat[off:off + o * k].view(o, k); layout.append((off, o, k)); off += o * k
+        b = hflat[off:off + o]; off += o
+        views.append((w, b))
+    rms = RunningMeanStd((d,)).to(DEV)
+    pk = F.PackedWeights(hflat, layout, a) if packed else None
+    pf = F.PolicyForward(views[:nl], views[nl], views[nl + 1], rms, pk)
+    obs = torch.randn(n, d, device=DEV)
+    x0 = torch.zeros(n, d, device=DEV, dtype=torch.float16)
+    acts = [torch.zeros(n, w, device=DEV, dtype=torch.float16) for w in units]
+    mu, v = torch.zeros(n, a, device=DEV), torch.zeros(n, 1, device=DEV)
+    pf.train_forward(obs, x0, acts, mu, v)
+    # the forward the kernel kept, against torch on the same fp16 weights
+    h = x0
+    for (w, b), y in zip(views[:nl], acts):
+        h = torch.nn.functional.elu((h.float() @ w.float().t() + b.float()).half().float()).half()
+        torch.testing.assert_close(y.float(), h.float(), rtol=4e-3, atol=2e-3)
+    pb = F.PolicyBackward(hflat, layout, a, pk)
+    pb.refresh()
+    gmu, gval = torch.randn(n, a, device=DEV) * 1e-2, torch.randn(n, 1, device=DEV) * 1e-2
+    gz = [torch.zeros(n, w, device=DEV, dtype=torch.float16) for w in units]
+    g16, v16 = torch.zeros(n, a, device=DEV, dtype=torch.float16), torch.zeros(n, 1, device=DEV, dtype=torch.float16)
+    bg = [torch.zeros(w, device=DEV) for w in units]
+    bm, bv = torch.zeros(a, device=DEV), torch.zeros(1, device=DEV)
+    pb(gmu, gval, acts, gz, g16, v16, bg, bm, bv)
+    assert torch.equal(g16, gmu.half()) and torch.equal(v16, gval.half())
+    torch.testing.assert_close(bm, g16.float().sum(0), rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(bv, v16.float().sum(0), rtol=1e-4, atol=1e-5)
+    g = (g16.float() @ views[nl][0].float() + v16.float() @ views[nl + 1][0].float()).half()
+    for L in range(nl - 1, -1, -1):
+        y = acts[L].float()
+        ref = (g.float() * torch.where(y > 0, torch.ones_like(y), y + 1.0)).half()
+        # (g itself is a rounded MFMA sum whose order differs from torch's: one fp16 ulp of g moves gz by one ulp)
+        torch.testing.assert_close(gz[L].float(), ref.float(), rtol=4e-3, atol=2e-5)
+        torch.testing.assert_close(bg[L], gz[L].float().sum(0), rtol=1e-4, atol=1e-5)   # the bias gradient sums what the kernel stored
+        if L > 0:
+            g = (gz[L].float() @ views[L][0].float()).half()
