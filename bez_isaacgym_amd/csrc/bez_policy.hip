@@ -313,9 +313,11 @@ __device__ __forceinline__ void layer(const _Float16 (*src)[LDS], _Float16 (*dst
     const int ksteps = (in + 15) >> 4;
     // One 32-row half of a column block per wave where a layer has <= 4 column blocks (the 100-wide one: 4): half or more of the eight waves
     // sat idle while the others ran two MFMA chains each; with (column block, row half) as the unit of work every wave gets one chain.
-    if (nblk * 2 <= nw) {
+    // (<= 4 blocks whatever the wave count: each unit streams its block's weights, and two half units stream them twice -- the 200-wide layer
+    // as 14 half units on 16 waves pulled 350 KB through the CU's 64 B/clk L1 port, 5.5 k cycles, where 7 full units take 2.7 k)
+    if (nblk * 2 <= PF_WAVES) {
       if (wave < 2 * nblk) {
-        const int nb = wave % nblk, half = wave / nblk, cb = nb * 32 + 4 * h;
+        const int nb = wave < nblk ? wave : wave - nblk, half = wave < nblk ? 0 : 1, cb = nb * 32 + 4 * h;   // (no integer division)
         dispatch_ksteps(ksteps, [&](auto RP) {
           const Bias16 bias = load_bias16(B, cb, out);
           f32x16 acc;
