@@ -535,6 +535,153 @@ __global__ __launch_bounds__(PPO_TB) void gae_kernel(const float* __restrict__ r
   }
 }
 
+// ---- the epoch's dataset preparation between GAE and the first minibatch (rl_games a2c_continuous.prepare_dataset + the per-minibatch
+// input-normaliser moments) in FOUR launches instead of ~30 small ones (6 x moments + 6 x reduce, 2 x apply, 2 x normalise, two
+// transposes, difference, mean, Welford, three elementwise, three copies: ~150 us of launch latencies per epoch):
+//   1  column sums / sums of squares of every minibatch's observation rows AND of the values / returns (seen as 64 virtual columns),
+//      per-workgroup partials in fp64 (grid.y = task);
+//   2  their fixed-order second stage -> the (2 D + 1) moments of each task;
+//   3  values / returns through the value normaliser as RunningMeanStd.forward does in train mode -- update with the values' moments,
+//      normalise the values, update with the returns' moments, normalise the returns (every workgroup forms the two updates itself from
+//      the moments and the OLD statistics; nobody writes them here) --, transposed from the rollout's (H, N) into the dataset's env-major
+//      rows, advantage = return - value, per-workgroup partial sums of the advantage (fp64);
+//   4  every workgroup adds those partials in the same fixed order, (adv - mean) / (std + 1e-8) with torch's unbiased std in place; workgroup 0
+//      commits the value normaliser's new statistics.
+struct PrepTask { const float* x; long long rows; int cols; double* out; };
+constexpr int PREP_MAXT = 10;
+struct PrepTasks { PrepTask t[PREP_MAXT]; int n; };
+__global__ __launch_bounds__(PPO_TB) void prep_moments_kernel(PrepTasks T, double* __restrict__ scratch) {
+  const PrepTask& t = T.t[blockIdx.y];
+  const int D = t.cols, col = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  __shared__ double sh[2][4][64];
+  double s1 = 0.0, s2 = 0.0;
+  if (col < D) {
+#pragma unroll 8
+    for (long long r = (long long)blockIdx.x * 4 + rl; r < t.rows; r += (long long)gridDim.x * 4) {
+      const double v = (double)t.x[r * D + col];
+      s1 += v; s2 += v * v;
+    }
+  }
+  sh[0][rl][col] = s1; sh[1][rl][col] = s2;
+  __syncthreads();
+  if (rl == 0) {
+    double* dst = scratch + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 128;
+    dst[col] = col < D ? sh[0][0][col] + sh[0][1][col] + sh[0][2][col] + sh[0][3][col] : 0.0;
+    dst[64 + col] = col < D ? sh[1][0][col] + sh[1][1][col] + sh[1][2][col] + sh[1][3][col] : 0.0;
+  }
+}
+// one workgroup per task: 16 row lanes x 64 columns add the partials of workgroups r, r + 16, ... (fixed order); a task with `fold` set is a
+// scalar seen as 64 virtual columns, whose column sums are then added in lane order
+__global__ __launch_bounds__(1024) void prep_reduce_kernel(PrepTasks T, const double* __restrict__ scratch, int nblocks, int fold_from) {
+  __shared__ double lds[2][16][64];
+  const PrepTask& t = T.t[blockIdx.x];
+  const int l = threadIdx.x & 63, r = threadIdx.x >> 6;
+  double a1 = 0.0, a2 = 0.0;
+  for (int b = r; b < nblocks; b += 16) {
+    const double* src = scratch + ((size_t)blockIdx.x * nblocks + b) * 128;
+    a1 += src[l]; a2 += src[64 + l];
+  }
+  lds[0][r][l] = a1; lds[1][r][l] = a2;
+  __syncthreads();
+  if (r == 0) {
+    double t1 = 0.0, t2 = 0.0;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) { t1 += lds[0][q][l]; t2 += lds[1][q][l]; }
+    lds[0][0][l] = t1; lds[1][0][l] = t2;
+  }
+  __syncthreads();
+  if ((int)blockIdx.x >= fold_from) {   // scalar task
+    if (threadIdx.x == 0) {
+      double t1 = 0.0, t2 = 0.0;
+      for (int q = 0; q < 64; ++q) { t1 += lds[0][0][q]; t2 += lds[1][0][q]; }
+      t.out[0] = t1; t.out[1] = t2; t.out[2] = (double)(t.rows * t.cols);
+    }
+  } else if (r == 0) {
+    if (l < t.cols) { t.out[l] = lds[0][0][l]; t.out[t.cols + l] = lds[1][0][l]; }
+    if (l == 0) t.out[2 * t.cols] = (double)t.rows;
+  }
+}
+// RunningMeanStd.update_from_moments on scalars (rms_apply_kernel's arithmetic)
+struct Rms1 { double mean, var, count; };
+__device__ __forceinline__ Rms1 rms1_apply(Rms1 s, const double* mom) {
+  const double n = mom[2], tot = s.count + n;
+  const double b_mean = mom[0] / n;
+  double b_var = mom[1] / n - b_mean * b_mean;
+  if (b_var < 0.0) b_var = 0.0;
+  b_var *= n / (n - 1.0 > 1.0 ? n - 1.0 : 1.0);
+  const double delta = b_mean - s.mean;
+  const double m2 = s.var * s.count + b_var * n + delta * delta * s.count * n / tot;
+  Rms1 o;
+  o.mean = s.mean + delta * n / tot; o.var = m2 / tot; o.count = tot;
+  return o;
+}
+__global__ __launch_bounds__(PPO_TB) void prep_values_kernel(const float* __restrict__ values, const float* __restrict__ returns, int H, long long N,
+                                                             const double* __restrict__ vmean, const double* __restrict__ vvar, const double* __restrict__ vcount,
+                                                             float eps, const double* __restrict__ val_mom, const double* __restrict__ ret_mom,
+                                                             float* __restrict__ old_values, float* __restrict__ ds_returns, float* __restrict__ adv,
+                                                             double* __restrict__ partial) {
+  float m1 = 0.f, d1 = 1.f, m2 = 0.f, d2 = 1.f;
+  const bool norm = vmean != nullptr;
+  if (norm) {
+    Rms1 s{vmean[0], vvar[0], vcount[0]};
+    s = rms1_apply(s, val_mom); m1 = (float)s.mean; d1 = sqrtf((float)s.var + eps);
+    s = rms1_apply(s, ret_mom); m2 = (float)s.mean; d2 = sqrtf((float)s.var + eps);
+  }
+  const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x, total = (long long)H * N;
+  double a1 = 0.0, a2 = 0.0;
+  if (j < total) {
+    const long long e = j / H;
+    const int t = (int)(j - e * H);
+    float v = values[(long long)t * N + e], r = returns[(long long)t * N + e];
+    if (norm) {
+      v = fminf(fmaxf((v - m1) / d1, -5.0f), 5.0f);
+      r = fminf(fmaxf((r - m2) / d2, -5.0f), 5.0f);
+    }
+    old_values[j] = v; ds_returns[j] = r;
+    const float a = r - v;
+    adv[j] = a;
+    a1 = (double)a; a2 = (double)a * (double)a;
+  }
+  __shared__ double sh[2][PPO_TB / 64];
+  a1 = wave_sum(a1); a2 = wave_sum(a2);
+  if ((threadIdx.x & 63) == 0) { sh[0][threadIdx.x >> 6] = a1; sh[1][threadIdx.x >> 6] = a2; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t1 = 0.0, t2 = 0.0;
+    for (int q = 0; q < PPO_TB / 64; ++q) { t1 += sh[0][q]; t2 += sh[1][q]; }
+    partial[2 * blockIdx.x] = t1; partial[2 * blockIdx.x + 1] = t2;
+  }
+}
+__global__ __launch_bounds__(PPO_TB) void prep_advantage_kernel(float* __restrict__ adv, long long total, const double* __restrict__ partial, int nparts, int normalize,
+                                                                double* __restrict__ vmean, double* __restrict__ vvar, double* __restrict__ vcount,
+                                                                const double* __restrict__ val_mom, const double* __restrict__ ret_mom) {
+  __shared__ double sh[2][PPO_TB];
+  __shared__ float ms[2];
+  if (normalize) {
+    double a1 = 0.0, a2 = 0.0;
+    for (int q = threadIdx.x; q < nparts; q += PPO_TB) { a1 += partial[2 * q]; a2 += partial[2 * q + 1]; }
+    sh[0][threadIdx.x] = a1; sh[1][threadIdx.x] = a2;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double t1 = 0.0, t2 = 0.0;
+      for (int q = 0; q < PPO_TB; ++q) { t1 += sh[0][q]; t2 += sh[1][q]; }
+      const double n = (double)total, mean = t1 / n;
+      double var = (t2 - t1 * mean) / (n - 1.0 > 1.0 ? n - 1.0 : 1.0);   // unbiased, as torch.std
+      if (var < 0.0) var = 0.0;
+      ms[0] = (float)mean; ms[1] = (float)sqrt(var);
+    }
+    __syncthreads();
+    const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < total) adv[j] = (adv[j] - ms[0]) / (ms[1] + 1e-8f);
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0 && vmean) {   // the value normaliser's statistics after both updates
+    Rms1 s{vmean[0], vvar[0], vcount[0]};
+    s = rms1_apply(s, val_mom);
+    s = rms1_apply(s, ret_mom);
+    vmean[0] = s.mean; vvar[0] = s.var; vcount[0] = s.count;
+  }
+}
+
 // ---- the optimiser tail of one minibatch step on the flat fp32 buffers: GradScaler.unscale_ + clip_grad_norm_ + Adam (torch
 // semantics, no amsgrad) + GradScaler.update + the step's bookkeeping, ONE launch (round 3: three; torch: a dozen).
 //   phase 1  every workgroup forms the squared norm of the WHOLE unscaled gradient and its non-finite count by itself, in the same
@@ -869,6 +1016,40 @@ int bez_ppo_gae(const float* rewards_dev, const float* values_dev, const float* 
   if (!rewards_dev || !values_dev || !mb_dones_dev || !dones_dev || !last_values_dev || !advantages_dev || horizon <= 0 || num_envs <= 0) return -1;
   hipLaunchKernelGGL(gae_kernel, dim3(nblk(num_envs)), dim3(PPO_TB), 0, (hipStream_t)stream, rewards_dev, values_dev, mb_dones_dev, dones_dev, last_values_dev,
                      (int)horizon, num_envs, gamma, tau, advantages_dev, returns_dev);
+  return launch_ok();
+}
+
+int bez_ppo_dataset_prep(const float* obs_dev, int64_t minibatch_rows, int32_t num_minibatches, int32_t num_obs, double* obs_moments_dev,
+                         const float* values_dev, const float* returns_dev, int32_t horizon, int64_t num_envs, double* value_mean_dev, double* value_var_dev,
+                         double* value_count_dev, float value_eps, double* value_moments_dev, double* return_moments_dev, float* old_values_dev,
+                         float* ds_returns_dev, float* advantages_dev, int32_t normalize_advantage, double* scratch_dev, int64_t scratch_doubles, void* stream) {
+  const int64_t total = (int64_t)horizon * num_envs;
+  if (!values_dev || !returns_dev || horizon <= 0 || num_envs <= 0 || !value_moments_dev || !return_moments_dev || !old_values_dev || !ds_returns_dev ||
+      !advantages_dev || !scratch_dev || (value_mean_dev && (!value_var_dev || !value_count_dev)) || num_minibatches < 0 || num_minibatches > PREP_MAXT - 2 ||
+      (num_minibatches > 0 && (!obs_dev || !obs_moments_dev || minibatch_rows <= 0 || num_obs <= 0 || num_obs > 64))) return -1;
+  if (total % 64 != 0) return -3;   // the scalar tasks are read as (total / 64, 64): the caller keeps its separate launches
+  hipStream_t st = (hipStream_t)stream;
+  PrepTasks T;
+  T.n = num_minibatches + 2;
+  for (int i = 0; i < num_minibatches; ++i)
+    T.t[i] = PrepTask{obs_dev + (size_t)i * minibatch_rows * num_obs, (long long)minibatch_rows, (int)num_obs, obs_moments_dev + (size_t)i * (2 * num_obs + 1)};
+  T.t[num_minibatches] = PrepTask{values_dev, (long long)(total / 64), 64, value_moments_dev};
+  T.t[num_minibatches + 1] = PrepTask{returns_dev, (long long)(total / 64), 64, return_moments_dev};
+  for (int i = T.n; i < PREP_MAXT; ++i) T.t[i] = PrepTask{nullptr, 0, 0, nullptr};
+  int64_t maxrows = total / 64;
+  if (num_minibatches > 0 && minibatch_rows > maxrows) maxrows = minibatch_rows;
+  unsigned g = (unsigned)((maxrows + 127) / 128);
+  if (g > 256) g = 256;
+  const unsigned nvb = nblk(total);
+  if ((int64_t)T.n * g * 128 + 2 * (int64_t)nvb > scratch_doubles) return -1;
+  double* partial = scratch_dev + (size_t)T.n * g * 128;
+  hipLaunchKernelGGL(prep_moments_kernel, dim3(g, (unsigned)T.n), dim3(PPO_TB), 0, st, T, scratch_dev);
+  hipLaunchKernelGGL(prep_reduce_kernel, dim3((unsigned)T.n), dim3(1024), 0, st, T, (const double*)scratch_dev, (int)g, (int)num_minibatches);
+  hipLaunchKernelGGL(prep_values_kernel, dim3(nvb), dim3(PPO_TB), 0, st, values_dev, returns_dev, (int)horizon, (long long)num_envs, (const double*)value_mean_dev,
+                     (const double*)value_var_dev, (const double*)value_count_dev, value_eps, (const double*)value_moments_dev, (const double*)return_moments_dev,
+                     old_values_dev, ds_returns_dev, advantages_dev, partial);
+  hipLaunchKernelGGL(prep_advantage_kernel, dim3(nvb), dim3(PPO_TB), 0, st, advantages_dev, (long long)total, (const double*)partial, (int)nvb,
+                     (int)(normalize_advantage != 0), value_mean_dev, value_var_dev, value_count_dev, (const double*)value_moments_dev, (const double*)return_moments_dev);
   return launch_ok();
 }
 

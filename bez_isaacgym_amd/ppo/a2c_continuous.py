@@ -683,11 +683,28 @@ class A2CAgent:
             returns = advs + mb["val"]
         # ---- prepare_dataset (rl_games a2c_continuous.prepare_dataset)
         ds = self.dataset
-        values, returns = swap_and_flatten01(mb["val"]), swap_and_flatten01(returns)
         aliased = mb["obs"].data_ptr() == ds["obs"].data_ptr()   # the rollout wrote the dataset's rows itself (_alloc_static)
         if not aliased:
             ds["obs"].copy_(swap_and_flatten01(mb["obs"]))
         fused_v = self.normalize_value and self.fused and getattr(self, "_f_val_rms", None) is not None
+        if (self.fused and self._policy_fwd is not None and not _dist_on() and self.normalize_input and (fused_v or not self.normalize_value)
+                and self.cfg.get("fused_dataset_prep", True)):
+            # one rank: everything from here to the dataset's old_values / returns / advantages -- the per-minibatch observation moments, the
+            # value / return moments, both value-normaliser updates, the two normalisations, the advantage and its normalisation, the
+            # transposes into env-major rows -- in FOUR launches (csrc/bez_ppo.hip, bez_ppo_dataset_prep) instead of ~30
+            sc = getattr(self, "_prep_scratch", None)
+            if sc is None:
+                assert not torch.cuda.is_current_stream_capturing()
+                sc = self._prep_scratch = self._F.dataset_prep_scratch(self.num_minibatches, self.horizon, self.num_actors, dev)
+            if self._F.dataset_prep(ds["obs"], self.minibatch_size, self.num_minibatches, self._obs_mom, mb["val"], fx["rets"],
+                                    self.value_mean_std if fused_v else None, self._val_mom, self._ret_mom, ds["old_values"], ds["returns"],
+                                    ds["advantages"], self.normalize_advantage, sc):
+                if not aliased:
+                    ds["old_logp"].copy_(swap_and_flatten01(mb["neglogp"])); ds["actions"].copy_(swap_and_flatten01(mb["act"]))
+                    ds["mu"].copy_(swap_and_flatten01(mb["mu"]))
+                    ds["sigma"].copy_(swap_and_flatten01(mb["sigma"]))
+                return
+        values, returns = swap_and_flatten01(mb["val"]), swap_and_flatten01(returns)
         # epoch collective 1 of 2: every moment that depends on the data alone, for the whole epoch
         if self.normalize_input:
             for i in range(self.num_minibatches):

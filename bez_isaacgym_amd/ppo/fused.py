@@ -27,6 +27,7 @@ _SIGS = {
     "bez_ppo_adaptive_lr": [_vp, _vp, _f, _f, _f, _vp],
     "bez_ppo_gae": [_vp, _vp, _vp, _vp, _vp, _i32, _i64, _f, _f, _vp, _vp, _vp],
     "bez_ppo_head_grads_f16": [_vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp],
+    "bez_ppo_dataset_prep": [_vp, _i64, _i32, _i32, _vp, _vp, _vp, _i32, _i64, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _i64, _vp],
     "bez_ppo_wgrad_sum": [_vp, _i32, _i64, _vp, _i32, _vp],
     "bez_ppo_wgrad_plan": [_vp, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _vp, _vp],
     "bez_ppo_wgrad_run": [_vp, _vp, _i32, _vp],
@@ -37,7 +38,7 @@ _SIGS = {
     "bez_ppo_grad_reduce_blocks": [_vp, _i32, _vp, _i32],
 }
 _lib = None
-PPO_ABI_VERSION = 4   # BEZ_PPO_ABI_VERSION (include/bez_sim.h)
+PPO_ABI_VERSION = 5   # BEZ_PPO_ABI_VERSION (include/bez_sim.h)
 
 
 def lib():
@@ -388,6 +389,38 @@ def gae(rewards, values, mb_dones, dones, last_values, gamma, tau, advs, returns
     assert values.numel() == h * n and mb_dones.numel() == h * n and dones.numel() == n and last_values.numel() == n and advs.numel() == h * n
     _chk(lib().bez_ppo_gae(_p(rewards), _p(values), _p(mb_dones), _p(dones), _p(last_values), h, n, float(gamma), float(tau), _p(advs),
                            None if returns is None else _p(returns), _stream(rewards)), "bez_ppo_gae")
+
+
+def dataset_prep_scratch(num_minibatches, horizon, num_envs, device):
+    return torch.zeros((num_minibatches + 2) * 256 * 128 + 2 * ((horizon * num_envs + 255) // 256), device=device, dtype=torch.float64)
+
+
+def dataset_prep(obs, minibatch_rows, num_minibatches, obs_moments, values, returns, value_rms, value_moments, return_moments, old_values, ds_returns,
+                 advantages, normalize_advantage, scratch):
+    """prepare_dataset + the per-minibatch observation moments in four launches (bez_ppo_dataset_prep).  obs: the dataset's (rows, D) fp32
+    observations (None: no observation moments); values / returns (H, N[, 1]) fp32 in the rollout's layout; value_rms: the RunningMeanStd of
+    the values (None: values / returns are used as they are); outputs env-major (N * H[, 1]).  False: shapes the kernel does not take."""
+    h = values.shape[0]
+    n = values.numel() // h
+    assert returns.numel() == h * n and old_values.numel() == h * n and ds_returns.numel() == h * n and advantages.numel() == h * n
+    assert values.is_contiguous() and returns.is_contiguous() and old_values.is_contiguous() and ds_returns.is_contiguous() and advantages.is_contiguous()
+    d = 0
+    if obs is not None and num_minibatches > 0:
+        d = obs.shape[1]
+        assert obs.is_contiguous() and obs.shape[0] >= num_minibatches * minibatch_rows and obs_moments.is_contiguous() and obs_moments.numel() == num_minibatches * (2 * d + 1)
+    else:
+        num_minibatches = 0
+    r = value_rms
+    rc = lib().bez_ppo_dataset_prep(None if not num_minibatches else _p(obs), minibatch_rows, num_minibatches, d,
+                                    None if not num_minibatches else _p(obs_moments, torch.float64), _p(values), _p(returns), h, n,
+                                    None if r is None else _p(r.running_mean, torch.float64), None if r is None else _p(r.running_var, torch.float64),
+                                    None if r is None else _p(r.count.view(1), torch.float64), 0.0 if r is None else float(r.epsilon),
+                                    _p(value_moments, torch.float64), _p(return_moments, torch.float64), _p(old_values), _p(ds_returns), _p(advantages),
+                                    1 if normalize_advantage else 0, _p(scratch, torch.float64), scratch.numel(), _stream(values))
+    if rc == -3:
+        return False
+    _chk(rc, "bez_ppo_dataset_prep")
+    return True
 
 
 def head_grads_f16(gmu, gval, gmu16, gv16, mu_bias_grad, value_bias_grad):

@@ -300,7 +300,7 @@ int bez_sim_time_steps(BezSim* sim, const float* actions_dev, int32_t n_steps, v
 
 /* The signatures below change between rounds (round 3: scratch buffers of the fixed-order reductions, plan / run split of the weight
  * gradients, the optimiser tail's bookkeeping): a binding checks this number once after dlopen. */
-#define BEZ_PPO_ABI_VERSION 4
+#define BEZ_PPO_ABI_VERSION 5
 int32_t bez_ppo_abi_version(void);
 
 /* RunningMeanStd (normalize_input / normalize_value, bez_kickPPO.yaml:51-52): moments[0:D] = column sums, [D:2D] = sums of
@@ -459,6 +459,24 @@ int bez_ppo_adaptive_lr(float* lr_dev, const float* kl_dev, float kl_threshold, 
  * values.  One thread per env, the reference's operation order. */
 int bez_ppo_gae(const float* rewards_dev, const float* values_dev, const float* mb_dones_dev, const float* dones_dev, const float* last_values_dev,
                 int32_t horizon, int64_t num_envs, float gamma, float tau, float* advantages_dev, float* returns_dev, void* stream);
+
+/* The epoch's dataset preparation between GAE and the first minibatch (rl_games a2c_continuous.py prepare_dataset [ext], called from
+ * train_epoch via train.py:89-113, + the per-minibatch moments RunningMeanStd absorbs at every training forward) in four launches:
+ *   - obs_moments_dev[i] (2 num_obs + 1 doubles: column sums, sums of squares, rows) of minibatch i's rows of obs_dev
+ *     ((num_minibatches * minibatch_rows, num_obs) fp32), and value_moments_dev / return_moments_dev (3 doubles) of values_dev / returns_dev
+ *     ((horizon, num_envs) fp32, the rollout's layout);
+ *   - with value_mean_dev != NULL, RunningMeanStd.forward in train mode on the values, then on the returns: update with the values' moments,
+ *     normalise the values (clamp +-5), update with the returns' moments, normalise the returns; the statistics (mean / var / count
+ *     doubles) are updated in place;
+ *   - old_values_dev, ds_returns_dev, advantages_dev (horizon * num_envs fp32, ENV-major: row e * horizon + t, swap_and_flatten01's order):
+ *     the normalised values / returns and advantage = return - value, normalised as (adv - mean) / (std + 1e-8) (torch's unbiased std)
+ *     when normalize_advantage != 0.
+ * Every sum is a fixed-order two-stage fp64 sum (bit-reproducible).  scratch_dev: (num_minibatches + 2) * 256 * 128 + 2 * ceil(horizon *
+ * num_envs / 256) doubles at most.  -3: horizon * num_envs is not a multiple of 64 (the caller keeps its separate launches). */
+int bez_ppo_dataset_prep(const float* obs_dev, int64_t minibatch_rows, int32_t num_minibatches, int32_t num_obs, double* obs_moments_dev,
+                         const float* values_dev, const float* returns_dev, int32_t horizon, int64_t num_envs, double* value_mean_dev, double* value_var_dev,
+                         double* value_count_dev, float value_eps, double* value_moments_dev, double* return_moments_dev, float* old_values_dev,
+                         float* ds_returns_dev, float* advantages_dev, int32_t normalize_advantage, double* scratch_dev, int64_t scratch_doubles, void* stream);
 
 /* The backward inputs of the two heads in one pass over the loss gradients (torch.autocast's cast nodes + the bias-gradient sums of
  * nn.Linear's backward): fp16 copies of d loss / d mu (rows, num_actions) and d loss / d value (rows, 1), and the column sums of those

@@ -279,3 +279,31 @@ def test_backward_chain_matches_a_plain_torch_restatement(n, d, units, a, packed
         torch.testing.assert_close(bg[L], gz[L].float().sum(0), rtol=1e-4, atol=1e-5)   # the bias gradient sums what the kernel stored
         if L > 0:
             g = (gz[L].float() @ views[L][0].float()).half()
+
+
+def test_dataset_prep_in_four_launches_equals_the_separate_launches():
+    """bez_ppo_dataset_prep against the path it replaces (per-minibatch moments, value / return moments, two RunningMeanStd updates, two
+    normalisations, advantage + its normalisation, env-major transposes): same dataset and the same normaliser statistics after a rollout."""
+    import torch
+    from tests.test_gpu_round2 import _agent
+    out = []
+    for fused_prep in (False, True):
+        torch.manual_seed(11)
+        ag = _agent(512, 4096, fused_ops=True, hip_graphs=False, fused_dataset_prep=fused_prep)
+        ag.obs = ag.env_reset()
+        for _ in range(2):
+            ag.play_steps()
+        torch.cuda.synchronize()
+        assert (getattr(ag, "_prep_scratch", None) is not None) == fused_prep
+        ds = ag.dataset
+        out.append(dict(old_values=ds["old_values"].clone(), returns=ds["returns"].clone(), advantages=ds["advantages"].clone(),
+                        obs_mom=ag._obs_mom.clone(), val_mom=ag._val_mom.clone(), ret_mom=ag._ret_mom.clone(),
+                        vmean=ag.value_mean_std.running_mean.clone(), vvar=ag.value_mean_std.running_var.clone(), vcount=ag.value_mean_std.count.clone()))
+        del ag
+    a, b = out
+    assert float(a["advantages"].abs().max()) > 0 and float(a["old_values"].abs().max()) > 0
+    for k in ("obs_mom", "val_mom", "ret_mom", "vmean", "vvar", "vcount"):
+        torch.testing.assert_close(b[k], a[k], rtol=1e-12, atol=1e-9)    # fp64 sums, a different fixed order
+    for k in ("old_values", "returns"):
+        torch.testing.assert_close(b[k].reshape(-1), a[k].reshape(-1), rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(b["advantages"].reshape(-1), a["advantages"].reshape(-1), rtol=2e-5, atol=2e-5)   # torch's fp32 mean / std against fp64 sums
