@@ -365,6 +365,8 @@ class A2CAgent:
         seed = params.get("seed", 42)
         torch.manual_seed(int(seed if seed not in ("", None) else 42))
         self.model = ModelA2CContinuousLogStd(obs_dim, act_dim, units).to(self.device)
+        # (anything that loads weights into the model marks the derived fp16 / fragment-major copies stale: _refresh_weight_copies_if_dirty)
+        self.model.register_load_state_dict_post_hook(lambda module, incompatible_keys: self._mark_weights_dirty())
         self.running_mean_std = RunningMeanStd((obs_dim,)).to(self.device) if self.normalize_input else None
         self.value_mean_std = RunningMeanStd((1,)).to(self.device) if self.normalize_value else None
         on_gpu = self.device.type == "cuda"
@@ -415,6 +417,7 @@ class A2CAgent:
         self._policy_bwd = None
         self._packed = None
         self._packed_stale = True     # the fragment-major weight copies need a refresh() before their next use (set whenever weights change outside the fused optimiser)
+        self._weights_dirty = True    # weights were written from outside the optimiser since the derived copies were last refreshed
         self._rms_preapplied = False  # the input normaliser already holds the coming minibatch's moments (folded into the previous optimiser launch)
         self.fused = bool(on_gpu and c.get("fused_ops", True))
         # Replaying ANY graph is only safe with the HIP runtime's graph packet capture off (bez_isaacgym_amd/__init__.py: root cause of
@@ -545,13 +548,17 @@ class A2CAgent:
         mb, F, fx = self.mb, self._F, self._fx
         net = self.model.a2c_network
         self.model.eval()
-        if self.half_path:
-            net.refresh_half()
+        if not self._copies_kept_current():
+            # (with the fused optimiser the Adam launch writes the fp16 working copy and the fragment-major copies at every step, and weights
+            # changed from outside -- checkpoint restore, load_state_dict, the parameter broadcast -- are caught eagerly in play_steps: the
+            # 26 us multi-tensor copy and the scatter at the head of every rollout were refreshing what was already current)
+            if self.half_path:
+                net.refresh_half()
+            if self._packed is not None:
+                self._packed.refresh()  # once per epoch, whoever changed the weights last
+                self._packed_stale = False
         cur = self.obs  # step 0 reads the agent's copy; later steps read the env's own observation buffer (no per-step copy)
         vrms = self.value_mean_std if self.normalize_value else None
-        if self._packed is not None:
-            self._packed.refresh()  # once per epoch, whoever changed the weights last (optimiser, checkpoint restore, parameter broadcast)
-            self._packed_stale = False
         fx["noise"].normal_()  # the whole horizon's action noise in one launch
         boot = self.value_bootstrap
         pending = None  # rollout_post arguments of the env step whose bookkeeping has not run yet
@@ -749,10 +756,31 @@ class A2CAgent:
             ds["mu"].copy_(swap_and_flatten01(mb["mu"]))
             ds["sigma"].copy_(swap_and_flatten01(mb["sigma"]))
 
+    def _mark_weights_dirty(self):
+        self._weights_dirty = True
+        self._packed_stale = True
+
+    def _copies_kept_current(self):
+        """True where the fused optimiser launch maintains every derived weight copy (fp16 working copy, fragment-major forward / backward
+        copies): the rollout then needs no refresh of its own."""
+        return bool(self._fused_opt and self.half_path and getattr(self, "_hflat", None) is not None)
+
+    def _refresh_weight_copies_if_dirty(self):
+        """Weights written from outside the optimiser (load_state_dict on the model -- a post-hook marks it --, set_full_state_weights, the
+        initial parameter broadcast): bring the derived copies up to date, eagerly, never inside a captured graph."""
+        if self._weights_dirty and self._copies_kept_current():
+            net = self.model.a2c_network
+            net.refresh_half()
+            if self._packed is not None:
+                self._packed.refresh()
+                self._packed_stale = False
+        self._weights_dirty = False
+
     def play_steps(self):
         """Rollout + dataset.  With HIP graphs enabled the first call after warm-up captures, later calls replay."""
         if self.mb is None:
             self._alloc_static()
+        self._refresh_weight_copies_if_dirty()
         if self.use_graphs and self.world > 1 and self._eager_epochs >= self.graph_warmup_epochs:
             # data parallel: the horizon loop has no collective and is replayed; GAE + dataset (two all-reduces) stay eager
             if self._g_rollout is None:
@@ -883,6 +911,8 @@ class A2CAgent:
                 self._f_obs_rms.apply(self._obs_mom[mb["_i"]])
         if self.half_path and getattr(self, "_hflat", None) is None:
             net.refresh_half()  # (with the fused optimiser the Adam kernel keeps the fp16 copies current)
+        elif self._weights_dirty and not torch.cuda.is_current_stream_capturing():
+            self._refresh_weight_copies_if_dirty()   # an update without a rollout in front of it (tests, tools) after weights were loaded
         manual = self._train_fwd_ok(obs)
         wg = None
         if manual:
