@@ -24,6 +24,7 @@
 #include "../../include/bez_sim.h"
 #include "bez_dr_noise.h"
 #include "bez_dr_step.h"
+#include "bez_ppo_loss.h"
 
 namespace {
 
@@ -591,6 +592,7 @@ struct BackwardArgs {
   int packed;  // wt[L] / wht are fragment-major (packed as Linear(out = width[L-1], in = width[L]) and Linear(out = width[last], in = 32))
   float* partial; int ptotal; int poff[PF_MAXL];  // per-workgroup column sums of gz (ceil(n / 64) rows of prow floats; ptotal = sum of the widths, layer L at poff[L])
   int prow;                                       // = ptotal + 32: the heads' column sums [d/d mu | d/d value] follow the hidden layers' in a row
+  bez_loss::LossArgs loss;                        // the fused-loss instantiations (LA > 0): the minibatch's loss operands; gmu / gval are then not read
 };
 
 // gz = g * elu'(y) of a full 64-row tile whose width is a multiple of 4, in place in tile A and out to HBM, and its per-workgroup column
@@ -720,7 +722,10 @@ __device__ __forceinline__ void backward_stage(const BackwardArgs& a, _Float16 (
 
 // LD0 / LD1: row strides of the two LDS tiles.  Tile 0 holds the (64, 32) head-gradient tile and d/d h_L for L = nhid-2, nhid-4, ...;
 // tile 1 holds d/d h_L for L = nhid-1, nhid-3, ...  (216, 424) = 80 KB: two workgroups per CU for 54-400-200-100.
-template <int LD0, int LD1, bool PK>
+// LA > 0: the PPO loss of the tile (bez_ppo_loss.h, action width LA as its compile-time constant) runs IN FRONT of the head stage, in tile 1:
+// d loss / d mu and d loss / d value go from LDS straight into the fp16 head-gradient tile -- one launch (11 us of latencies) and their
+// round trip through HBM less per minibatch step.  Same arithmetic, same bits as bez_ppo_loss + bez_ppo_policy_backward.
+template <int LD0, int LD1, bool PK, int LA = 0>
 // 4 waves per SIMD = two workgroups per CU (<= 128 VGPRs) only where the two tiles fit twice into the CU's LDS: the (424, 424)
 // fallback for wider networks holds 106 KB and runs one workgroup per CU, so it does not ask for an occupancy it cannot have
 __global__ __launch_bounds__(PF_WAVES * 64, ((LD0 + LD1) * PF_ROWS * 2 <= 80 * 1024) ? 4 : 2) void policy_backward_kernel(BackwardArgs a) {
@@ -731,16 +736,25 @@ __global__ __launch_bounds__(PF_WAVES * 64, ((LD0 + LD1) * PF_ROWS * 2 <= 80 * 1
   const int64_t row0 = (int64_t)blockIdx.x * PF_ROWS;
   const int nrow = (int)((a.n - row0) < (int64_t)PF_ROWS ? (a.n - row0) : (int64_t)PF_ROWS);
   const int A = a.num_actions;
+  constexpr int LOSS_FLOATS = LA > 0 ? bez_loss::loss_lds_floats(LA > 0 ? LA : 1) : 0;
+  static_assert(sizeof(float) * (LOSS_FLOATS + NT) <= sizeof(_Float16) * PF_ROWS * LD1, "tile 1 holds the loss tile and the head stage's scratch");
+  static_assert(bez_loss::LOSS_TB == PF_ROWS, "the loss tile is the backward tile");
+  float* ltile = reinterpret_cast<float*>(&t1[0][0]);   // (tile 1 is free until the first GEMM)
+  if constexpr (LA > 0) bez_loss::ppo_loss_tile<LA, true>(a.loss, ltile, tid);   // ends behind a barrier: ltile[row * (LA + 1) + k], gvalue[row]
   {  // heads: the (64, 32) tile [d/d mu | d/d value | 0] as fp16 (= the cast nodes of autocast), its copies for the head weight-gradient
      // GEMMs, and its column sums = the head bias gradients.  Thread -> column tid & 31, rows tid >> 5, + 16, ...
-    float* red = reinterpret_cast<float*>(&t1[0][0]);  // (tile 1 is free until the first GEMM)
+    float* red = ltile + LOSS_FLOATS;
+    const float* lgv = ltile + 4 * PF_ROWS * (LA + 1) + 3 * bez_loss::LOSS_CW * PF_ROWS;
     const int k = tid & 31, rsub = tid >> 5;
     float acc = 0.f;
 #pragma unroll
     for (int j = 0; j < PF_ROWS / (NT / 32); ++j) {
       const int rr = rsub + j * (NT / 32);
       float v = 0.f;
-      if (rr < nrow) v = k < A ? a.gmu[(row0 + rr) * A + k] : (k == A ? a.gval[row0 + rr] : 0.f);
+      if (rr < nrow) {
+        if constexpr (LA > 0) v = k < A ? ltile[rr * (LA + 1) + k] : (k == A ? lgv[rr] : 0.f);
+        else v = k < A ? a.gmu[(row0 + rr) * A + k] : (k == A ? a.gval[row0 + rr] : 0.f);
+      }
       const _Float16 hv = (_Float16)v;
       t0[rr][k] = hv;
       if (rr < nrow) {
@@ -921,13 +935,14 @@ extern "C" int bez_ppo_policy_forward_train(const float* obs_dev, int64_t n, int
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
-extern "C" int bez_ppo_policy_backward(const float* grad_mu_dev, const float* grad_value_dev, int64_t n, int32_t num_hidden, const int32_t* hidden_width,
-                                       int32_t num_actions, const void* const* act_f16_dev, const void* const* wt_f16_dev, const void* heads_t_f16_dev,
-                                       void* const* gz_f16_dev, void* grad_mu_f16_dev, void* grad_value_f16_dev, float* const* bias_grad_dev,
-                                       float* mu_bias_grad_dev, float* value_bias_grad_dev, float* partial_dev, int32_t weights_packed_flags, void* stream) {
+constexpr int PF_FUSED_LOSS_ACTIONS = 18;   // the action width the fused-loss backward kernel is instantiated for (bez: 18 joints)
+static int policy_backward_impl(const BezPpoLossOperands* loss, const float* grad_mu_dev, const float* grad_value_dev, int64_t n, int32_t num_hidden, const int32_t* hidden_width,
+                                int32_t num_actions, const void* const* act_f16_dev, const void* const* wt_f16_dev, const void* heads_t_f16_dev,
+                                void* const* gz_f16_dev, void* grad_mu_f16_dev, void* grad_value_f16_dev, float* const* bias_grad_dev,
+                                float* mu_bias_grad_dev, float* value_bias_grad_dev, float* partial_dev, int32_t weights_packed_flags, void* stream) {
   const int32_t weights_packed = weights_packed_flags & 1;
   if (!partial_dev) return -1;
-  if (!grad_mu_dev || !grad_value_dev || n <= 0 || num_hidden <= 0 || num_hidden > PF_MAXL || !hidden_width || num_actions <= 0 || num_actions > 31 ||
+  if ((!loss && (!grad_mu_dev || !grad_value_dev)) || n <= 0 || num_hidden <= 0 || num_hidden > PF_MAXL || !hidden_width || num_actions <= 0 || num_actions > 31 ||
       !act_f16_dev || !wt_f16_dev || !heads_t_f16_dev || !gz_f16_dev || !grad_mu_f16_dev || !grad_value_f16_dev || !bias_grad_dev || !mu_bias_grad_dev ||
       !value_bias_grad_dev) return -1;
   BackwardArgs a;
@@ -950,6 +965,19 @@ extern "C" int bez_ppo_policy_backward(const float* grad_mu_dev, const float* gr
   int w0 = 32, w1 = 0;  // widest tenant of each tile (see policy_backward_kernel)
   for (int i = 0; i < num_hidden; ++i) { int& w = ((num_hidden - 1 - i) & 1) ? w0 : w1; if (hidden_width[i] > w) w = hidden_width[i]; }
   const bool narrow = ((w0 + 15) & ~15) + 8 <= 216;
+  if (loss) {
+    // the fused-loss kernel exists for the production shape only: bez's action width, fragment-major weights, the two-workgroups-per-CU
+    // tiles, deferred (fixed-order) reductions.  -3: the caller keeps bez_ppo_loss + bez_ppo_policy_backward.
+    if (num_actions != PF_FUSED_LOSS_ACTIONS || !narrow || !weights_packed || !(weights_packed_flags & 2) || !loss->scratch_dev) return -3;
+    if (!loss->mu_dev || !loss->logstd_dev || !loss->value_dev || !loss->actions_dev || !loss->old_logp_dev || !loss->adv_dev || !loss->old_value_dev ||
+        !loss->returns_dev || !loss->old_mu_dev || !loss->old_sigma_dev) return -1;
+    a.loss = bez_loss::LossArgs{loss->mu_dev, loss->logstd_dev, loss->value_dev, loss->actions_dev, loss->old_logp_dev, loss->adv_dev, loss->old_value_dev,
+                                loss->returns_dev, loss->old_mu_dev, loss->old_sigma_dev, n, loss->e_clip, loss->critic_coef, loss->entropy_coef,
+                                loss->bounds_coef, (int)(loss->clip_value & 9), loss->loss_scale_dev, nullptr, nullptr, nullptr, nullptr, loss->scratch_dev};
+    hipLaunchKernelGGL((policy_backward_kernel<216, PF_LD, true, PF_FUSED_LOSS_ACTIONS>), dim3(nwg), dim3(PF_WAVES * 64), 0, (hipStream_t)stream, a);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+  }
+  a.loss = bez_loss::LossArgs{};
   if (narrow && weights_packed) hipLaunchKernelGGL((policy_backward_kernel<216, PF_LD, true>), dim3(nwg), dim3(PF_WAVES * 64), 0, (hipStream_t)stream, a);
   else if (narrow) hipLaunchKernelGGL((policy_backward_kernel<216, PF_LD, false>), dim3(nwg), dim3(PF_WAVES * 64), 0, (hipStream_t)stream, a);
   else if (weights_packed) hipLaunchKernelGGL((policy_backward_kernel<PF_LD, PF_LD, true>), dim3(nwg), dim3(PF_WAVES * 64), 0, (hipStream_t)stream, a);
@@ -957,6 +985,23 @@ extern "C" int bez_ppo_policy_backward(const float* grad_mu_dev, const float* gr
   if (!(weights_packed_flags & 2))  // bit 1: the per-workgroup column sums only -- bez_ppo_grad_reduce_all adds them with the step's other reductions
     hipLaunchKernelGGL(policy_bias_reduce_kernel, dim3((unsigned)((a.ptotal + num_actions + 1 + 63) / 64)), dim3(1024), 0, (hipStream_t)stream, a, (int)nwg);
   return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+extern "C" int bez_ppo_policy_backward(const float* grad_mu_dev, const float* grad_value_dev, int64_t n, int32_t num_hidden, const int32_t* hidden_width,
+                                       int32_t num_actions, const void* const* act_f16_dev, const void* const* wt_f16_dev, const void* heads_t_f16_dev,
+                                       void* const* gz_f16_dev, void* grad_mu_f16_dev, void* grad_value_f16_dev, float* const* bias_grad_dev,
+                                       float* mu_bias_grad_dev, float* value_bias_grad_dev, float* partial_dev, int32_t weights_packed_flags, void* stream) {
+  return policy_backward_impl(nullptr, grad_mu_dev, grad_value_dev, n, num_hidden, hidden_width, num_actions, act_f16_dev, wt_f16_dev, heads_t_f16_dev, gz_f16_dev,
+                              grad_mu_f16_dev, grad_value_f16_dev, bias_grad_dev, mu_bias_grad_dev, value_bias_grad_dev, partial_dev, weights_packed_flags, stream);
+}
+
+extern "C" int bez_ppo_policy_backward_with_loss(const BezPpoLossOperands* loss, int64_t n, int32_t num_hidden, const int32_t* hidden_width, int32_t num_actions,
+                                                 const void* const* act_f16_dev, const void* const* wt_f16_dev, const void* heads_t_f16_dev,
+                                                 void* const* gz_f16_dev, void* grad_mu_f16_dev, void* grad_value_f16_dev, float* const* bias_grad_dev,
+                                                 float* mu_bias_grad_dev, float* value_bias_grad_dev, float* partial_dev, int32_t weights_packed_flags, void* stream) {
+  if (!loss) return -1;
+  return policy_backward_impl(loss, nullptr, nullptr, n, num_hidden, hidden_width, num_actions, act_f16_dev, wt_f16_dev, heads_t_f16_dev, gz_f16_dev,
+                              grad_mu_f16_dev, grad_value_f16_dev, bias_grad_dev, mu_bias_grad_dev, value_bias_grad_dev, partial_dev, weights_packed_flags, stream);
 }
 
 extern "C" int bez_ppo_scatter2_f16(const void* src_f16_dev, const int32_t* map_a_dev, const int32_t* map_b_dev, int64_t n, void* dst_f16_dev, void* stream) {

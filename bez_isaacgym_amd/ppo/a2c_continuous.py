@@ -941,11 +941,22 @@ class A2CAgent:
         one_reduce = manual and wg is not None and self._policy_bwd is not None and self.cfg.get("fused_grad_reduce", True)
         if not one_reduce:
             self._flat.zero_()
-        F.loss(mu32.detach(), net.sigma.detach(), v32.detach(), mb, self.e_clip, self.critic_coef, self.entropy_coef, self.bounds_loss_coef,
-               self.clip_value, scale, fx["gmu"], fx["gval"], net.sigma.grad, self._flat_stats, zero_glog=False, zero_stats=False,
-               update_mu_sigma=self.update_mu_sigma, scratch=fx["loss_scratch"], defer_reduce=one_reduce)
+        fused_loss = None
+        if one_reduce and self.cfg.get("fused_loss_backward", True):
+            # the loss rides in front of the backward chain (one launch; d loss / d mu, d loss / d value stay on the chip)
+            fused_loss = F.LossOperands.of(mu32, net.sigma.detach(), v32, mb, self.e_clip, self.critic_coef, self.entropy_coef, self.bounds_loss_coef,
+                                           self.clip_value, scale, self.update_mu_sigma, fx["loss_scratch"])
+            lin = net._lin
+            nh = len(lin) - 2
+            if not self._policy_bwd.with_loss(fused_loss, tf["act"], tf["gz"], tf["gmu16"], tf["gv16"], [lin[L].bias.grad for L in range(nh)],
+                                              lin[nh].bias.grad, lin[nh + 1].bias.grad):
+                fused_loss = None
+        if fused_loss is None:
+            F.loss(mu32.detach(), net.sigma.detach(), v32.detach(), mb, self.e_clip, self.critic_coef, self.entropy_coef, self.bounds_loss_coef,
+                   self.clip_value, scale, fx["gmu"], fx["gval"], net.sigma.grad, self._flat_stats, zero_glog=False, zero_stats=False,
+                   update_mu_sigma=self.update_mu_sigma, scratch=fx["loss_scratch"], defer_reduce=one_reduce)
         if manual:
-            self._manual_backward(tf, fx["gmu"], fx["gval"], wg, one_reduce)
+            self._manual_backward(tf, fx["gmu"], fx["gval"], wg, one_reduce, chain_done=fused_loss is not None)
         else:
             torch.autograd.backward([mu32, v32], [fx["gmu"], fx["gval"]])
 
@@ -989,7 +1000,7 @@ class A2CAgent:
             self._tf = tf
         return tf
 
-    def _manual_backward(self, tf, gmu, gval, wg=None, one_reduce=False):
+    def _manual_backward(self, tf, gmu, gval, wg=None, one_reduce=False, chain_done=False):
         """d(loss)/d(parameters) from the loss kernel's d/d(mu), d/d(value): per layer one input-gradient GEMM, the split-K weight
         gradient reduced straight into the fp32 master .grad views, and the fused ELU-derivative / bias-gradient pass -- the same
         launches _HalfLinearFn / _HalfLinearEluFn issue under autograd (tests hold the two against each other)."""
@@ -1009,8 +1020,9 @@ class A2CAgent:
             if self._packed is None:
                 self._policy_bwd.refresh()
             bias_grads = [lin[L].bias.grad for L in range(nh)]
-            self._policy_bwd(gmu, gval, tf["act"], tf["gz"], tf["gmu16"], tf["gv16"], bias_grads, lin[nh].bias.grad, lin[nh + 1].bias.grad,
-                             defer_reduce=one_reduce)
+            if not chain_done:   # (chain_done: PolicyBackward.with_loss already ran it, behind the loss)
+                self._policy_bwd(gmu, gval, tf["act"], tf["gz"], tf["gmu16"], tf["gv16"], bias_grads, lin[nh].bias.grad, lin[nh + 1].bias.grad,
+                                 defer_reduce=one_reduce)
             # all five weight gradients: one split-K MFMA launch over the output blocks of every layer (csrc/bez_wgrad.hip) instead of a
             # batched GEMM and a sum per layer ...
             if one_reduce:

@@ -27,6 +27,7 @@ _SIGS = {
     "bez_ppo_adaptive_lr": [_vp, _vp, _f, _f, _f, _vp],
     "bez_ppo_gae": [_vp, _vp, _vp, _vp, _vp, _i32, _i64, _f, _f, _vp, _vp, _vp],
     "bez_ppo_head_grads_f16": [_vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp],
+    "bez_ppo_policy_backward_with_loss": [_vp, _i64, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp],
     "bez_ppo_dataset_prep": [_vp, _i64, _i32, _i32, _vp, _vp, _vp, _i32, _i64, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _i64, _vp],
     "bez_ppo_wgrad_sum": [_vp, _i32, _i64, _vp, _i32, _vp],
     "bez_ppo_wgrad_plan": [_vp, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _vp, _vp],
@@ -165,6 +166,26 @@ def loss(mu, logstd, value, mb, e_clip, critic_coef, entropy_coef, bounds_coef, 
                             _p(mb["returns"]), _p(mb["mu"]), _p(mb["sigma"]), b, a, float(e_clip), float(critic_coef), float(entropy_coef),
                             float(bounds_coef), (1 if clip_value else 0) | (0 if zero_glog else 2) | (0 if zero_stats else 4) | (8 if update_mu_sigma else 0) | (16 if defer_reduce else 0), None if scale is None else _p(scale), _p(gmu),
                             _p(gval), _p(glog), _p(stats), None if scratch is None else _p(scratch), _stream(mu)), "bez_ppo_loss")
+
+
+class LossOperands(C.Structure):
+    """BezPpoLossOperands (include/bez_sim.h): the operands of loss() for PolicyBackward.with_loss()"""
+    _fields_ = [(k, C.c_void_p) for k in ("mu_dev", "logstd_dev", "value_dev", "actions_dev", "old_logp_dev", "adv_dev", "old_value_dev", "returns_dev",
+                                           "old_mu_dev", "old_sigma_dev")] + \
+               [("e_clip", C.c_float), ("critic_coef", C.c_float), ("entropy_coef", C.c_float), ("bounds_coef", C.c_float), ("clip_value", C.c_int32),
+                ("loss_scale_dev", C.c_void_p), ("scratch_dev", C.c_void_p)]
+
+    @classmethod
+    def of(cls, mu, logstd, value, mb, e_clip, critic_coef, entropy_coef, bounds_coef, clip_value, scale, update_mu_sigma, scratch):
+        o = cls()
+        for k, t in (("mu_dev", mu), ("logstd_dev", logstd), ("value_dev", value), ("actions_dev", mb["actions"]), ("old_logp_dev", mb["old_logp"]),
+                     ("adv_dev", mb["advantages"]), ("old_value_dev", mb["old_values"]), ("returns_dev", mb["returns"]), ("old_mu_dev", mb["mu"]),
+                     ("old_sigma_dev", mb["sigma"]), ("scratch_dev", scratch)):
+            setattr(o, k, _p(t).value)
+        o.loss_scale_dev = None if scale is None else _p(scale).value
+        o.e_clip, o.critic_coef, o.entropy_coef, o.bounds_coef = float(e_clip), float(critic_coef), float(entropy_coef), float(bounds_coef)
+        o.clip_value = (1 if clip_value else 0) | (8 if update_mu_sigma else 0)
+        return o
 
 
 def loss_scratch(b, a, device):
@@ -374,6 +395,30 @@ class PolicyBackward:
                                            _p(gv16, torch.float16), C.cast(t_b, C.c_void_p), _p(mu_bias_grad), _p(value_bias_grad), _p(self._partial), self.flag | (2 if defer_reduce else 0),
                                            _stream(gmu)),
              "bez_ppo_policy_backward")
+
+
+def _policy_backward_with_loss(self, loss_ops, acts, gz, gmu16, gv16, bias_grads, mu_bias_grad, value_bias_grad):
+    """loss() + __call__(defer_reduce=True) as ONE launch (bez_ppo_policy_backward_with_loss): the tile's loss terms and d loss / d mu, d loss / d value
+    are formed in front of the backward chain and never leave the chip.  False: a shape the fused kernel does not take (the caller runs the two)."""
+    n = gmu16.shape[0]
+    assert len(acts) == len(gz) == len(bias_grads) == self.nh and gmu16.shape == (n, self.A) and gv16.numel() == n
+    t_act = (C.c_void_p * self.nh)(*[a.data_ptr() for a in acts])
+    t_gz = (C.c_void_p * self.nh)(*[z.data_ptr() for z in gz])
+    t_b = (C.c_void_p * self.nh)(*[b.data_ptr() for b in bias_grads])
+    need = ((n + 63) // 64) * (sum(self.widths) + 32)
+    if getattr(self, "_partial", None) is None or self._partial.numel() < need:
+        self._partial = torch.empty(need, device=gmu16.device, dtype=torch.float32)
+    rc = lib().bez_ppo_policy_backward_with_loss(C.byref(loss_ops), n, self.nh, C.cast(self.c_widths, C.c_void_p), self.A, C.cast(t_act, C.c_void_p),
+                                                 C.cast(self.c_wt, C.c_void_p), C.c_void_p(self.wht.data_ptr()), C.cast(t_gz, C.c_void_p),
+                                                 _p(gmu16, torch.float16), _p(gv16, torch.float16), C.cast(t_b, C.c_void_p), _p(mu_bias_grad),
+                                                 _p(value_bias_grad), _p(self._partial), self.flag | 2, _stream(gmu16))
+    if rc == -3:
+        return False
+    _chk(rc, "bez_ppo_policy_backward_with_loss")
+    return True
+
+
+PolicyBackward.with_loss = _policy_backward_with_loss
 
 
 def adaptive_lr(lr, kl, kl_threshold, min_lr, max_lr):

@@ -460,6 +460,25 @@ int bez_ppo_adaptive_lr(float* lr_dev, const float* kl_dev, float kl_threshold, 
 int bez_ppo_gae(const float* rewards_dev, const float* values_dev, const float* mb_dones_dev, const float* dones_dev, const float* last_values_dev,
                 int32_t horizon, int64_t num_envs, float gamma, float tau, float* advantages_dev, float* returns_dev, void* stream);
 
+/* bez_ppo_loss + bez_ppo_policy_backward of one minibatch as ONE launch: every 64-row tile forms its loss terms and d loss / d mu,
+ * d loss / d value in front of the backward chain (the same code, the same bits), which reads them from on-chip memory.  The loss's per-
+ * workgroup partial sums go to loss->scratch_dev (bez_ppo_loss's scratch, bit 4 semantics: bez_ppo_grad_reduce_all writes d loss / d
+ * log-sigma and the statistics); weights_packed_flags must carry bits 0 and 1 (fragment-major weights, column sums only).  clip_value: bits 0
+ * and 3 of bez_ppo_loss.  -3: a shape the fused kernel is not instantiated for (it exists for num_actions == 18 and hidden layers that fit
+ * the two-workgroups-per-CU tiles) -- the caller keeps the two separate calls. */
+typedef struct BezPpoLossOperands {
+  const float* mu_dev; const float* logstd_dev; const float* value_dev; const float* actions_dev; const float* old_logp_dev; const float* adv_dev;
+  const float* old_value_dev; const float* returns_dev; const float* old_mu_dev; const float* old_sigma_dev;
+  float e_clip, critic_coef, entropy_coef, bounds_coef;
+  int32_t clip_value;
+  const float* loss_scale_dev;
+  float* scratch_dev;
+} BezPpoLossOperands;
+int bez_ppo_policy_backward_with_loss(const BezPpoLossOperands* loss, int64_t n, int32_t num_hidden, const int32_t* hidden_width, int32_t num_actions,
+                                      const void* const* act_f16_dev, const void* const* wt_f16_dev, const void* heads_t_f16_dev, void* const* gz_f16_dev,
+                                      void* grad_mu_f16_dev, void* grad_value_f16_dev, float* const* bias_grad_dev, float* mu_bias_grad_dev,
+                                      float* value_bias_grad_dev, float* partial_dev, int32_t weights_packed_flags, void* stream);
+
 /* The epoch's dataset preparation between GAE and the first minibatch (rl_games a2c_continuous.py prepare_dataset [ext], called from
  * train_epoch via train.py:89-113, + the per-minibatch moments RunningMeanStd absorbs at every training forward) in four launches:
  *   - obs_moments_dev[i] (2 num_obs + 1 doubles: column sums, sums of squares, rows) of minibatch i's rows of obs_dev

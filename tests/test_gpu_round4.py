@@ -307,3 +307,37 @@ def test_dataset_prep_in_four_launches_equals_the_separate_launches():
     for k in ("old_values", "returns"):
         torch.testing.assert_close(b[k].reshape(-1), a[k].reshape(-1), rtol=1e-6, atol=1e-6)
     torch.testing.assert_close(b["advantages"].reshape(-1), a["advantages"].reshape(-1), rtol=2e-5, atol=2e-5)   # torch's fp32 mean / std against fp64 sums
+
+
+def test_loss_in_front_of_the_backward_chain_changes_nothing():
+    """bez_ppo_policy_backward_with_loss (the tile's loss terms and d loss / d mu, d loss / d value formed in the backward launch, read from
+    LDS) against bez_ppo_loss + bez_ppo_policy_backward: the same code on the same numbers -- weights, Adam moments, loss scale and the
+    dataset's updated mu / sigma are bit-identical after four epochs (80 optimiser steps, update_mu_sigma and adaptive lr included)."""
+    import torch
+    from tests.test_gpu_round2 import _agent
+    out = []
+    for fused in (False, True):
+        torch.manual_seed(5)
+        ag = _agent(512, 4096, hip_graphs=False, fused_loss_backward=fused)
+        torch.manual_seed(5)
+        ag.model.load_state_dict({k: v.clone() for k, v in ag.model.state_dict().items()})
+        seen = []
+        if fused:   # the fused entry point is what runs (it would fall back silently on an unsupported shape)
+            orig = ag._policy_bwd.with_loss
+            def spy(*a, **k):
+                r = orig(*a, **k)
+                seen.append(r)
+                return r
+            ag._policy_bwd.with_loss = spy
+        ag.obs = ag.env_reset()
+        stats = [ag.train_epoch() for _ in range(4)]
+        torch.cuda.synchronize()
+        if fused:
+            assert len(seen) == 4 * ag.mini_epochs * ag.num_minibatches and all(seen)
+        out.append(([p.detach().clone() for p in ag.model.parameters()], [ag.optimizer.state[p]["exp_avg_sq"].clone() for p in ag.model.parameters()],
+                    float(ag.scaler.get_scale()), ag.dataset["mu"].clone(), ag.dataset["sigma"].clone(), [s["kl"] for s in stats]))
+        del ag
+    (pa, va, sa, mua, sga, kla), (pb, vb, sb, mub, sgb, klb) = out
+    assert sa == sb and kla == klb
+    for u, v in zip(pa + va + [mua, sga], pb + vb + [mub, sgb]):
+        assert torch.equal(u, v)
