@@ -365,18 +365,36 @@ __global__ void adaptive_lr_kernel(float* __restrict__ lr, const float* __restri
 // same fp32 operations, in the same order, as the 8 elementwise launches per step of the torch formulation
 __global__ __launch_bounds__(PPO_TB) void gae_kernel(const float* __restrict__ rew, const float* __restrict__ val, const float* __restrict__ mb_dones,
                                                      const float* __restrict__ dones, const float* __restrict__ last_values, int H, int64_t N,
-                                                     float gamma, float tau, float* __restrict__ advs, float* __restrict__ returns) {
+                                                     float gamma, float tau, float* __restrict__ advs, float* __restrict__ returns,
+                                                     const double* __restrict__ vmean, const double* __restrict__ vvar, float veps) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N) return;
   float last = 0.f;
   float nnt = 1.0f - dones[i], nv = last_values[i];
-  for (int t = H - 1; t >= 0; --t) {
-    const float v = val[(int64_t)t * N + i];
-    const float delta = rew[(int64_t)t * N + i] + gamma * nv * nnt - v;
-    last = delta + gamma * tau * nnt * last;
-    advs[(int64_t)t * N + i] = last;
-    if (returns) returns[(int64_t)t * N + i] = last + v;
-    nnt = 1.0f - mb_dones[(int64_t)t * N + i]; nv = v;  // for step t-1: "next" = step t
+  if (vmean) {   // the bootstrap values come straight from the network: RunningMeanStd(unnorm=True) here instead of five elementwise launches
+    const float sd = sqrtf((float)vvar[0] + veps), y = fminf(fmaxf(nv, -5.0f), 5.0f);
+    nv = __fadd_rn(__fmul_rn(sd, y), (float)vmean[0]);   // (product, then sum: torch's two roundings)
+  }
+  // eight steps of loads in flight per thread, then their scan: the chain itself is 32 dependent fused multiply-adds, the loads are not part of it
+  constexpr int CH = 8;
+  for (int t1 = H; t1 > 0; t1 -= CH) {
+    float v[CH], r[CH], d[CH];
+#pragma unroll
+    for (int u = 0; u < CH; ++u) {
+      const int t = t1 - 1 - u;
+      if (t >= 0) { v[u] = val[(int64_t)t * N + i]; r[u] = rew[(int64_t)t * N + i]; d[u] = mb_dones[(int64_t)t * N + i]; }
+    }
+#pragma unroll
+    for (int u = 0; u < CH; ++u) {
+      const int t = t1 - 1 - u;
+      if (t >= 0) {
+        const float delta = r[u] + gamma * nv * nnt - v[u];
+        last = delta + gamma * tau * nnt * last;
+        advs[(int64_t)t * N + i] = last;
+        if (returns) returns[(int64_t)t * N + i] = last + v[u];
+        nnt = 1.0f - d[u]; nv = v[u];  // for step t-1: "next" = step t
+      }
+    }
   }
 }
 
@@ -856,10 +874,12 @@ int bez_ppo_adaptive_lr(float* lr_dev, const float* kl_dev, float kl_threshold, 
 }
 
 int bez_ppo_gae(const float* rewards_dev, const float* values_dev, const float* mb_dones_dev, const float* dones_dev, const float* last_values_dev,
-                int32_t horizon, int64_t num_envs, float gamma, float tau, float* advantages_dev, float* returns_dev, void* stream) {
-  if (!rewards_dev || !values_dev || !mb_dones_dev || !dones_dev || !last_values_dev || !advantages_dev || horizon <= 0 || num_envs <= 0) return -1;
+                int32_t horizon, int64_t num_envs, float gamma, float tau, float* advantages_dev, float* returns_dev, const double* value_mean_dev,
+                const double* value_var_dev, float value_eps, void* stream) {
+  if (!rewards_dev || !values_dev || !mb_dones_dev || !dones_dev || !last_values_dev || !advantages_dev || horizon <= 0 || num_envs <= 0 ||
+      (value_mean_dev && !value_var_dev)) return -1;
   hipLaunchKernelGGL(gae_kernel, dim3(nblk(num_envs)), dim3(PPO_TB), 0, (hipStream_t)stream, rewards_dev, values_dev, mb_dones_dev, dones_dev, last_values_dev,
-                     (int)horizon, num_envs, gamma, tau, advantages_dev, returns_dev);
+                     (int)horizon, num_envs, gamma, tau, advantages_dev, returns_dev, value_mean_dev, value_var_dev, value_eps);
   return launch_ok();
 }
 

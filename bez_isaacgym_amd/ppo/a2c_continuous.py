@@ -681,9 +681,9 @@ class A2CAgent:
             # bootstrap values: the one-launch forward; GAE: one thread per env instead of eight elementwise launches per step
             fx = self._fx
             self._policy_fwd(self.obs, fx["last_mu"], fx["last_v"])
-            last_values = self.value_mean_std(fx["last_v"], unnorm=True) if self.normalize_value else fx["last_v"]
             advs, returns = fx["advs"], fx["rets"]
-            self._F.gae(mb["rew"], mb["val"], mb["dones"], self.dones, last_values.contiguous(), self.gamma, self.tau, advs, returns)
+            self._F.gae(mb["rew"], mb["val"], mb["dones"], self.dones, fx["last_v"], self.gamma, self.tau, advs, returns,
+                        unnorm=self.value_mean_std if self.normalize_value else None)   # (the bootstrap values are de-normalised inside the launch)
         else:
             last_values = self.get_values(self.obs)
             advs = discount_values(self.gamma, self.tau, self.dones, last_values, mb["dones"], mb["val"], mb["rew"])

@@ -25,7 +25,7 @@ _SIGS = {
     "bez_ppo_scatter_f16": [_vp, _vp, _i64, _vp, _vp],
     "bez_ppo_scatter2_f16": [_vp, _vp, _vp, _i64, _vp, _vp],
     "bez_ppo_adaptive_lr": [_vp, _vp, _f, _f, _f, _vp],
-    "bez_ppo_gae": [_vp, _vp, _vp, _vp, _vp, _i32, _i64, _f, _f, _vp, _vp, _vp],
+    "bez_ppo_gae": [_vp, _vp, _vp, _vp, _vp, _i32, _i64, _f, _f, _vp, _vp, _vp, _vp, _f, _vp],
     "bez_ppo_head_grads_f16": [_vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp],
     "bez_ppo_policy_backward_with_loss": [_vp, _i64, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp],
     "bez_ppo_dataset_prep": [_vp, _i64, _i32, _i32, _vp, _vp, _vp, _i32, _i64, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _i64, _vp],
@@ -427,13 +427,16 @@ def adaptive_lr(lr, kl, kl_threshold, min_lr, max_lr):
     _chk(lib().bez_ppo_adaptive_lr(_p(lr), _p(kl), float(kl_threshold), float(min_lr), float(max_lr), _stream(lr)), "bez_ppo_adaptive_lr")
 
 
-def gae(rewards, values, mb_dones, dones, last_values, gamma, tau, advs, returns=None):
-    """GAE backward scan: rewards / values / mb_dones (H,N[,1]) fp32, dones / last_values (N[,1]); writes advs (and returns = advs + values)."""
+def gae(rewards, values, mb_dones, dones, last_values, gamma, tau, advs, returns=None, unnorm=None):
+    """GAE backward scan: rewards / values / mb_dones (H,N[,1]) fp32, dones / last_values (N[,1]); writes advs (and returns = advs + values).
+    unnorm (a RunningMeanStd): last_values are the network's normalised outputs, de-normalised inside the launch."""
     h = rewards.shape[0]
     n = rewards.numel() // h
     assert values.numel() == h * n and mb_dones.numel() == h * n and dones.numel() == n and last_values.numel() == n and advs.numel() == h * n
     _chk(lib().bez_ppo_gae(_p(rewards), _p(values), _p(mb_dones), _p(dones), _p(last_values), h, n, float(gamma), float(tau), _p(advs),
-                           None if returns is None else _p(returns), _stream(rewards)), "bez_ppo_gae")
+                           None if returns is None else _p(returns), None if unnorm is None else _p(unnorm.running_mean, torch.float64),
+                           None if unnorm is None else _p(unnorm.running_var, torch.float64), 0.0 if unnorm is None else float(unnorm.epsilon),
+                           _stream(rewards)), "bez_ppo_gae")
 
 
 def dataset_prep_scratch(num_minibatches, horizon, num_envs, device):

@@ -456,9 +456,11 @@ int bez_ppo_adaptive_lr(float* lr_dev, const float* kl_dev, float kl_threshold, 
 
 /* GAE (rl_games a2c_common.py discount_values, called from play_steps): advantages (H,N) from rewards / values (H,N), the done
  * flags recorded BEFORE each step (H,N), the current done flags (N) and the bootstrap values (N); returns_dev (optional) = advantages +
- * values.  One thread per env, the reference's operation order. */
+ * values.  One thread per env, the reference's operation order.  value_mean_dev != NULL: last_values_dev holds the network's NORMALISED
+ * value outputs and the kernel de-normalises them first (RunningMeanStd(unnorm=True): clamp +-5, * sqrt(var + eps), + mean). */
 int bez_ppo_gae(const float* rewards_dev, const float* values_dev, const float* mb_dones_dev, const float* dones_dev, const float* last_values_dev,
-                int32_t horizon, int64_t num_envs, float gamma, float tau, float* advantages_dev, float* returns_dev, void* stream);
+                int32_t horizon, int64_t num_envs, float gamma, float tau, float* advantages_dev, float* returns_dev, const double* value_mean_dev,
+                const double* value_var_dev, float value_eps, void* stream);
 
 /* bez_ppo_loss + bez_ppo_policy_backward of one minibatch as ONE launch: every 64-row tile forms its loss terms and d loss / d mu,
  * d loss / d value in front of the backward chain (the same code, the same bits), which reads them from on-chip memory.  The loss's per-

@@ -429,6 +429,15 @@ def test_gae_kernel_matches_discount_values():
         F.gae(rew, val, mbd, d, last, 0.99, 0.95, advs, rets)
         np.testing.assert_allclose(advs.cpu(), want.cpu(), rtol=1e-5, atol=1e-5)   # same operations; the compiler contracts a*b+c (1.4e-6 over 32 steps)
         np.testing.assert_allclose(rets.cpu(), (want + val).cpu(), rtol=1e-5, atol=1e-5)
+        # the bootstrap values as the network's normalised outputs, de-normalised inside the launch (RunningMeanStd(unnorm=True))
+        from bez_isaacgym_amd.ppo.a2c_continuous import RunningMeanStd
+        rms = RunningMeanStd((1,)).to(DEV)
+        rms.running_mean.fill_(0.37); rms.running_var.fill_(2.5)
+        raw = torch.randn(n, 1, device=DEV) * 3.0     # (some beyond the +-5 clamp)
+        want2 = discount_values(0.99, 0.95, d, rms(raw, unnorm=True), mbd, val, rew)
+        advs2 = torch.full((h, n, 1), 7.0, device=DEV)
+        F.gae(rew, val, mbd, d, raw, 0.99, 0.95, advs2, None, unnorm=rms)
+        np.testing.assert_allclose(advs2.cpu(), want2.cpu(), rtol=1e-5, atol=1e-5)
 
 
 def test_head_grads_kernel():
