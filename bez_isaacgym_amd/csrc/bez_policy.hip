@@ -441,23 +441,20 @@ __global__ __launch_bounds__(MODE == 2 ? PF_WAVES * 64 : PF_FWD_WAVES * 64, (MOD
   const int64_t row0 = (int64_t)blockIdx.x * PF_ROWS;
   const int nrow = (int)((a.n - row0) < (int64_t)PF_ROWS ? (a.n - row0) : (int64_t)PF_ROWS);
   PF_STAMP(0);
-  // ROLL with the env's action noise (BezPpoActionNoise): the samples do not depend on the forward pass, so they are drawn HERE, in
-  // the shadow of the observation loads, and kept in registers until the epilogue (element idx = tid + k * 512 of this workgroup's
-  // (nrow, A) block; the quad of an element is recomputed by its <= 4 threads: cheaper than a trip through LDS, which is full until then)
-  float nzr[4] = {0.f, 0.f, 0.f, 0.f};
+  // ROLL with the env's action noise (BezPpoActionNoise): the samples do not depend on the forward pass, so they are drawn HERE, in the
+  // shadow of the observation loads: one Philox block + Box-Muller pair = four samples per thread (the block's 64 x A / 4 quads on its first
+  // threads), parked in LDS until the epilogue (this mode's tiles leave 54 KB free).  Every element used to recompute its whole quad:
+  // 4 x the generator work, +1.3 us on the launch.  (row0 * A is a multiple of 4: a workgroup's block starts on a quad.)
+  __shared__ float nzs[ROLL ? PF_ROWS * 32 : 1];
   if (ROLL && a.an.snap_dev) {
     const bez::DrSnap sn = *static_cast<const bez::DrSnap*>(a.an.snap_dev);
     const unsigned long long frame = (unsigned long long)sn.frame_hi << 32 | sn.frame_lo;
+    const int nel = nrow * a.num_actions;
+    for (int q = tid; 4 * q < nel; q += nt) {
+      float z4[4];
+      bez::dr_noise_quad(a.an.seed, a.an.env_id_offset, frame, 1, ((row0 * a.num_actions) >> 2) + q, z4);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int idx = tid + k * nt;
-      if (idx < nrow * a.num_actions) {
-        const int64_t o = row0 * a.num_actions + idx;
-        float z4[4];
-        bez::dr_noise_quad(a.an.seed, a.an.env_id_offset, frame, 1, o >> 2, z4);
-        const int w = (int)(o & 3);
-        nzr[k] = fmaf(w == 0 ? z4[0] : w == 1 ? z4[1] : w == 2 ? z4[2] : z4[3], sn.sd, sn.mean);
-      }
+      for (int c = 0; c < 4; ++c) nzs[4 * q + c] = fmaf(z4[c], sn.sd, sn.mean);
     }
   }
   // stage the (normalised) observations as fp16, zero-padded to a multiple of 16 columns: lanes over columns (the column's mean and
@@ -519,7 +516,7 @@ __global__ __launch_bounds__(MODE == 2 ? PF_WAVES * 64 : PF_FWD_WAVES * 64, (MOD
     __syncthreads();
     const int A = a.num_actions;
     float* zz = tile + PF_ROWS * 33;  // (64, 32) squared standardised actions
-    static_assert(4 * PF_WAVES * 64 >= PF_ROWS * 31, "nzr holds every element a thread owns (at the smallest workgroup)");
+    static_assert(4 * PF_WAVES * 64 >= PF_ROWS * 31, "four elements per thread cover the block (at the smallest workgroup)");
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
       const int idx = tid + it * nt;
@@ -530,7 +527,7 @@ __global__ __launch_bounds__(MODE == 2 ? PF_WAVES * 64 : PF_FWD_WAVES * 64, (MOD
       const float x = fmaf(sg, z, m);
       const int64_t o = (row0 + rr) * A + j;
       float xe = fminf(fmaxf(x, -1.0f), 1.0f);   // what rl_games hands to env.step
-      if (a.an.snap_dev) xe = xe + nzr[it];
+      if (a.an.snap_dev) xe = xe + nzs[idx];
       const int64_t om = (row0 + rr) * a.ld_act + j;   // (the rollout rows may be strided: written straight into the env-major dataset)
       a.mb_mu[om] = m; a.act[om] = x; a.act_env[o] = xe; a.sigma[om] = sg;
       const float q = (x - m) / sg;  // as the reference computes it from the stored action
