@@ -341,3 +341,55 @@ def test_loss_in_front_of_the_backward_chain_changes_nothing():
     assert sa == sb and kla == klb
     for u, v in zip(pa + va + [mua, sga], pb + vb + [mub, sgb]):
         assert torch.equal(u, v)
+
+
+@pytest.mark.parametrize("h,n,nmb,with_rms,norm_adv", [(32, 4096, 4, True, True), (16, 256, 2, False, True), (8, 64, 0, True, False), (5, 333, 1, True, True)])
+def test_dataset_prep_kernels_against_a_torch_restatement(h, n, nmb, with_rms, norm_adv):
+    """bez_ppo_dataset_prep called directly, against prepare_dataset written out in torch (fp64 moments, RunningMeanStd's parallel-variance
+    update twice, fp32 normalisation with the clamp, advantage and its unbiased-std normalisation, env-major transposes): with and without
+    the value normaliser, with and without advantage normalisation, without observations, and a size the kernel declines (H * N not a
+    multiple of 64 -> False, nothing written)."""
+    import torch
+    from bez_isaacgym_amd.ppo import fused as F
+    from bez_isaacgym_amd.ppo.a2c_continuous import RunningMeanStd
+    DEV = "cuda:0"
+    torch.manual_seed(3)
+    d = 54
+    values, returns = torch.randn(h, n, 1, device=DEV) * 2 + 0.5, torch.randn(h, n, 1, device=DEV) * 3 - 1.0
+    rows = h * n // max(nmb, 1)
+    obs = torch.randn(max(nmb, 1) * rows, d, device=DEV) * 1.7 + 0.3
+    rms = RunningMeanStd((1,)).to(DEV) if with_rms else None
+    if rms is not None:
+        rms.running_mean.fill_(0.2); rms.running_var.fill_(1.5); rms.count.fill_(1000.0)
+        ref = RunningMeanStd((1,)).to(DEV)
+        ref.load_state_dict(rms.state_dict())
+    obs_mom = torch.zeros(max(nmb, 1), 2 * d + 1, device=DEV, dtype=torch.float64)
+    vm, rm = torch.zeros(3, device=DEV, dtype=torch.float64), torch.zeros(3, device=DEV, dtype=torch.float64)
+    ov, rt, adv = (torch.full((h * n, 1), 7.0, device=DEV), torch.full((h * n, 1), 7.0, device=DEV), torch.full((h * n,), 7.0, device=DEV))
+    sc = F.dataset_prep_scratch(nmb, h, n, DEV)
+    ok = F.dataset_prep(obs if nmb else None, rows, nmb, obs_mom[:max(nmb, 1)].reshape(-1)[:nmb * (2 * d + 1)] if nmb else None, values, returns, rms, vm, rm, ov, rt, adv, norm_adv, sc)
+    if (h * n) % 64:
+        assert ok is False and float(ov.min()) == 7.0 and float(adv.min()) == 7.0
+        return
+    assert ok is True
+    flat = lambda t: t.transpose(0, 1).reshape(h * n, 1)
+    v, r = flat(values), flat(returns)
+    for i in range(nmb):
+        x = obs[i * rows:(i + 1) * rows].double()
+        want = torch.cat([x.sum(0), (x * x).sum(0), torch.tensor([float(rows)], device=DEV, dtype=torch.float64)])
+        torch.testing.assert_close(obs_mom[i], want, rtol=1e-12, atol=1e-9)
+    for mom, t in ((vm, v), (rm, r)):
+        want = torch.stack([t.double().sum(), (t.double() ** 2).sum(), torch.tensor(float(h * n), device=DEV, dtype=torch.float64)])
+        torch.testing.assert_close(mom, want, rtol=1e-12, atol=1e-9)
+    if rms is not None:
+        ref.eval()
+        ref.update_from_moments(vm); v = ref(v)
+        ref.update_from_moments(rm); r = ref(r)
+        for k in ("running_mean", "running_var", "count"):
+            torch.testing.assert_close(getattr(rms, k), getattr(ref, k), rtol=1e-12, atol=1e-12)
+    torch.testing.assert_close(ov, v, rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(rt, r, rtol=1e-6, atol=1e-6)
+    a = (r - v).sum(dim=1)
+    if norm_adv:
+        a = (a - a.mean()) / (a.std() + 1e-8)
+    torch.testing.assert_close(adv, a, rtol=2e-5, atol=2e-5)
