@@ -1,0 +1,166 @@
+// lanegroup_probe.hip -- a measurement for the NEXT redesign of the step kernel, not product code (tools/lanegroup_probe.py builds and runs it).
+//
+// The fused control step is bound by the instruction stream of one leg role: the articulated-body recursion of a six-joint
+// chain (pass 2) is ~13 k of a substep's ~27 k cycles, one env per lane, every 6x6 operation spelled out in that lane.  SURVEY.md 7 names the
+// alternative -- "lane-group mapping": an env's 6x6 rows spread over a group of lanes, cross-lane sums through DPP -- and this probe prices it on
+// the recursion itself, with the same arithmetic in both mappings:
+//     per joint i = 5..0:   IA += LI_i;  pA += pAl_i;  U = IA S_i;  D = S_i.U + arm;  u = tau_i - S_i.pA;
+//                           IA -= U U^T / D;  pA += IA cb_i + U u / D
+//   A  one lane per env, IA as a symmetric 6x6 (21 floats), as the product kernel holds it (csrc/bez_spatial.h);
+//   B  eight lanes per env: lane r < 6 holds row r of IA and pA[r]; the two dot products are 3-step DPP sums (row_half_mirror + two
+//      quad_perms), U is shared through six ds_swizzle broadcasts.
+// Output per env: pA (6) and the sum of IA -- compared between the mappings by the driver; s_memtime per wave around the chain.
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+constexpr int NJ = 6;
+
+// ---- inputs: [joint][env][...] row-major blocks: LI (36, full symmetric matrix), pAl (6), S (6), cb (6), tau (1)
+struct Inputs { const float* LI; const float* pAl; const float* S; const float* cb; const float* tau; int n; float arm; };
+
+// ------------------------------------------------------------------------------------------------ mapping A
+struct Sym6 { float a[21]; };   // upper triangle, row-major: (0,0) (0,1) .. (0,5) (1,1) ..
+__device__ __forceinline__ constexpr int tri(int r, int c) { return r <= c ? r * 6 - r * (r - 1) / 2 + (c - r) : c * 6 - c * (c - 1) / 2 + (r - c); }
+
+constexpr int NE = 36 + 6 + 6 + 6 + 1;   // floats per (joint, env): LI, pAl, S, cb, tau
+__global__ __launch_bounds__(64) void chain_one_lane(Inputs in, float* __restrict__ out, unsigned long long* __restrict__ cycles, int reps) {
+  __shared__ float sh[NJ][NE][64];   // the chain's inputs, lane-contiguous (the product kernel holds them in registers / LDS slots; staging is not timed)
+  const int lane = threadIdx.x, e = blockIdx.x * 64 + lane, ee = e < in.n ? e : 0;
+  for (int j = 0; j < NJ; ++j) {
+    const size_t b = (size_t)j * in.n + ee;
+    for (int k = 0; k < 36; ++k) sh[j][k][lane] = in.LI[b * 36 + k];
+    for (int k = 0; k < 6; ++k) { sh[j][36 + k][lane] = in.pAl[b * 6 + k]; sh[j][42 + k][lane] = in.S[b * 6 + k]; sh[j][48 + k][lane] = in.cb[b * 6 + k]; }
+    sh[j][54][lane] = in.tau[b];
+  }
+  __syncthreads();
+  Sym6 IA;
+  float pA[6];
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  for (int rep = 0; rep < reps; ++rep) {
+#pragma unroll
+    for (int k = 0; k < 21; ++k) IA.a[k] = 0.f;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) pA[k] = 0.f;
+#pragma unroll
+    for (int j = NJ - 1; j >= 0; --j) {
+      float S[6], cb[6];
+#pragma unroll
+      for (int r = 0; r < 6; ++r) {
+        S[r] = sh[j][42 + r][lane]; cb[r] = sh[j][48 + r][lane]; pA[r] += sh[j][36 + r][lane];
+#pragma unroll
+        for (int c = r; c < 6; ++c) IA.a[tri(r, c)] += sh[j][r * 6 + c][lane];
+      }
+      float U[6];
+#pragma unroll
+      for (int r = 0; r < 6; ++r) {
+        float s = 0.f;
+#pragma unroll
+        for (int c = 0; c < 6; ++c) s = fmaf(IA.a[tri(r, c)], S[c], s);
+        U[r] = s;
+      }
+      float D = in.arm, sp = 0.f;
+#pragma unroll
+      for (int r = 0; r < 6; ++r) { D = fmaf(S[r], U[r], D); sp = fmaf(S[r], pA[r], sp); }
+      const float Dinv = __builtin_amdgcn_rcpf(D), uD = (sh[j][54][lane] - sp) * Dinv;
+#pragma unroll
+      for (int r = 0; r < 6; ++r)
+#pragma unroll
+        for (int c = r; c < 6; ++c) IA.a[tri(r, c)] = fmaf(-U[r] * Dinv, U[c], IA.a[tri(r, c)]);
+#pragma unroll
+      for (int r = 0; r < 6; ++r) {
+        float s = U[r] * uD;
+#pragma unroll
+        for (int c = 0; c < 6; ++c) s = fmaf(IA.a[tri(r, c)], cb[c], s);
+        pA[r] += s;
+      }
+    }
+    asm volatile("" : "+v"(pA[0]));   // (one chain per repetition: nothing is hoisted across repetitions)
+  }
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  if (e >= in.n) return;
+  float tot = 0.f;
+#pragma unroll
+  for (int r = 0; r < 6; ++r)
+#pragma unroll
+    for (int c = 0; c < 6; ++c) tot += IA.a[tri(r, c)];
+#pragma unroll
+  for (int r = 0; r < 6; ++r) out[(size_t)e * 7 + r] = pA[r];
+  out[(size_t)e * 7 + 6] = tot;
+  if (threadIdx.x == 0) cycles[blockIdx.x] = t1 - t0;
+}
+
+// ------------------------------------------------------------------------------------------------ mapping B
+__device__ __forceinline__ float group8_sum(float v) {   // every lane of an aligned group of 8 ends with the group's sum
+  int x = __builtin_bit_cast(int, v);
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, x, 0x141 /* row_half_mirror */, 0xF, 0xF, true));
+  x = __builtin_bit_cast(int, v);
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, x, 0xB1 /* quad_perm [1,0,3,2] */, 0xF, 0xF, true));
+  x = __builtin_bit_cast(int, v);
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, x, 0x4E /* quad_perm [2,3,0,1] */, 0xF, 0xF, true));
+  return v;
+}
+template <int C>
+__device__ __forceinline__ float group8_bcast(float v) {   // lane C of every aligned group of 8 (ds_swizzle, bit mode: and 0x18, or C)
+  return __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), (C << 5) | 0x18));
+}
+
+__global__ __launch_bounds__(64) void chain_lane_group(Inputs in, float* __restrict__ out, unsigned long long* __restrict__ cycles, int reps) {
+  __shared__ float sh[NJ][8][NE + 1];   // (env-major rows, padded)
+  const int lane = threadIdx.x, r = lane & 7, g = lane >> 3;
+  const int e = blockIdx.x * 8 + g;      // eight envs per wave
+  const bool live = r < 6 && e < in.n;
+  const int ee = e < in.n ? e : 0, rr = r < 6 ? r : 0;
+  for (int j = 0; j < NJ; ++j) {
+    const size_t b = (size_t)j * in.n + ee;
+    for (int k = r; k < 36; k += 8) sh[j][g][k] = in.LI[b * 36 + k];
+    if (r < 6) { sh[j][g][36 + r] = in.pAl[b * 6 + r]; sh[j][g][42 + r] = in.S[b * 6 + r]; sh[j][g][48 + r] = in.cb[b * 6 + r]; }
+    if (r == 6) sh[j][g][54] = in.tau[b];
+  }
+  __syncthreads();
+  float a[6], pA = 0.f;
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  for (int rep = 0; rep < reps; ++rep) {
+#pragma unroll
+    for (int c = 0; c < 6; ++c) a[c] = 0.f;
+    pA = 0.f;
+#pragma unroll
+    for (int j = NJ - 1; j >= 0; --j) {
+      const float* row = sh[j][g];
+      float S[6], cb[6];
+#pragma unroll
+      for (int c = 0; c < 6; ++c) { S[c] = row[42 + c]; cb[c] = row[48 + c]; a[c] += live ? row[rr * 6 + c] : 0.f; }
+      pA += live ? row[36 + rr] : 0.f;
+      const float Sr = live ? row[42 + rr] : 0.f;
+      float U = 0.f;
+#pragma unroll
+      for (int c = 0; c < 6; ++c) U = fmaf(a[c], S[c], U);
+      const float D = group8_sum(Sr * U) + in.arm, sp = group8_sum(Sr * pA);
+      const float Dinv = __builtin_amdgcn_rcpf(D), uD = (row[54] - sp) * Dinv;
+      const float Ud = -U * Dinv;
+      float Uc[6];
+      Uc[0] = group8_bcast<0>(U); Uc[1] = group8_bcast<1>(U); Uc[2] = group8_bcast<2>(U);
+      Uc[3] = group8_bcast<3>(U); Uc[4] = group8_bcast<4>(U); Uc[5] = group8_bcast<5>(U);
+      float s = U * uD;
+#pragma unroll
+      for (int c = 0; c < 6; ++c) { a[c] = fmaf(Ud, Uc[c], a[c]); s = fmaf(a[c], cb[c], s); }
+      pA += s;
+    }
+    asm volatile("" : "+v"(pA));
+  }
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  float rowsum = 0.f;
+#pragma unroll
+  for (int c = 0; c < 6; ++c) rowsum += a[c];
+  const float tot = group8_sum(live ? rowsum : 0.f);
+  if (live) out[(size_t)e * 7 + r] = pA;
+  if (r == 6 && e < in.n) out[(size_t)e * 7 + 6] = tot;
+  if (threadIdx.x == 0) cycles[blockIdx.x] = t1 - t0;
+}
+
+extern "C" int probe_run(int mapping, const float* LI, const float* pAl, const float* S, const float* cb, const float* tau, int n, float arm, float* out,
+                         unsigned long long* cycles, int reps, void* stream) {
+  Inputs in{LI, pAl, S, cb, tau, n, arm};
+  if (mapping == 0) hipLaunchKernelGGL(chain_one_lane, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, in, out, cycles, reps);
+  else hipLaunchKernelGGL(chain_lane_group, dim3((n + 7) / 8), dim3(64), 0, (hipStream_t)stream, in, out, cycles, reps);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
