@@ -89,6 +89,93 @@ __global__ __launch_bounds__(64) void chain_one_lane(Inputs in, float* __restric
   if (threadIdx.x == 0) cycles[blockIdx.x] = t1 - t0;
 }
 
+// ------------------------------------------------------------------------------------------------ mapping A2
+// one lane per env, the FULL 6x6 as 18 register pairs and every 6-vector as three pairs: packed fp32 math (v_pk_fma_f32 / v_pk_mul_f32 /
+// v_pk_add_f32).  A lone wave issues a v_pk_fma_f32 in the time of a v_fma_f32 (tools/pk_issue_probe.py: 4.95 vs 5.72 cycles), so where the
+// product kernel's leg role is bound by the instruction count of its stream, two FMAs per instruction are worth up to a factor two -- IF the
+// data sits in aligned pairs without shuffles.  (Symmetry is given up: 36 elements instead of 21.)
+using f32x2 = __attribute__((ext_vector_type(2))) float;
+__global__ __launch_bounds__(64) void chain_one_lane_packed(Inputs in, float* __restrict__ out, unsigned long long* __restrict__ cycles, int reps) {
+  __shared__ float sh[NJ][NE][64];
+  const int lane = threadIdx.x, e = blockIdx.x * 64 + lane, ee = e < in.n ? e : 0;
+  for (int j = 0; j < NJ; ++j) {
+    const size_t b = (size_t)j * in.n + ee;
+    for (int k = 0; k < 36; ++k) sh[j][k][lane] = in.LI[b * 36 + k];
+    for (int k = 0; k < 6; ++k) { sh[j][36 + k][lane] = in.pAl[b * 6 + k]; sh[j][42 + k][lane] = in.S[b * 6 + k]; sh[j][48 + k][lane] = in.cb[b * 6 + k]; }
+    sh[j][54][lane] = in.tau[b];
+  }
+  __syncthreads();
+  f32x2 IA[6][3], pA[3];
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  for (int rep = 0; rep < reps; ++rep) {
+#pragma unroll
+    for (int r = 0; r < 6; ++r)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) IA[r][p] = f32x2{0.f, 0.f};
+#pragma unroll
+    for (int p = 0; p < 3; ++p) pA[p] = f32x2{0.f, 0.f};
+#pragma unroll
+    for (int j = NJ - 1; j >= 0; --j) {
+      f32x2 S[3], cb[3];
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {
+        S[p] = f32x2{sh[j][42 + 2 * p][lane], sh[j][43 + 2 * p][lane]};
+        cb[p] = f32x2{sh[j][48 + 2 * p][lane], sh[j][49 + 2 * p][lane]};
+        pA[p] += f32x2{sh[j][36 + 2 * p][lane], sh[j][37 + 2 * p][lane]};
+      }
+#pragma unroll
+      for (int r = 0; r < 6; ++r)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) IA[r][p] += f32x2{sh[j][r * 6 + 2 * p][lane], sh[j][r * 6 + 2 * p + 1][lane]};
+      // U = IA S: per row three packed products, then the two halves
+      float U[6];
+#pragma unroll
+      for (int r = 0; r < 6; ++r) {
+        f32x2 t = IA[r][0] * S[0];
+        t = __builtin_elementwise_fma(IA[r][1], S[1], t);
+        t = __builtin_elementwise_fma(IA[r][2], S[2], t);
+        U[r] = t.x + t.y;
+      }
+      const f32x2 U2[3] = {f32x2{U[0], U[1]}, f32x2{U[2], U[3]}, f32x2{U[4], U[5]}};
+      f32x2 d2 = S[0] * U2[0], s2 = S[0] * pA[0];
+      d2 = __builtin_elementwise_fma(S[1], U2[1], d2); s2 = __builtin_elementwise_fma(S[1], pA[1], s2);
+      d2 = __builtin_elementwise_fma(S[2], U2[2], d2); s2 = __builtin_elementwise_fma(S[2], pA[2], s2);
+      const float D = d2.x + d2.y + in.arm, sp = s2.x + s2.y;
+      const float Dinv = __builtin_amdgcn_rcpf(D), uD = (sh[j][54][lane] - sp) * Dinv;
+#pragma unroll
+      for (int r = 0; r < 6; ++r) {
+        const float k = -U[r] * Dinv;
+        const f32x2 kk = {k, k};
+#pragma unroll
+        for (int p = 0; p < 3; ++p) IA[r][p] = __builtin_elementwise_fma(kk, U2[p], IA[r][p]);
+      }
+      float add[6];
+#pragma unroll
+      for (int r = 0; r < 6; ++r) {
+        f32x2 t = IA[r][0] * cb[0];
+        t = __builtin_elementwise_fma(IA[r][1], cb[1], t);
+        t = __builtin_elementwise_fma(IA[r][2], cb[2], t);
+        add[r] = t.x + t.y;
+      }
+      const f32x2 uu = {uD, uD};
+#pragma unroll
+      for (int p = 0; p < 3; ++p) pA[p] += __builtin_elementwise_fma(U2[p], uu, f32x2{add[2 * p], add[2 * p + 1]});
+    }
+    asm volatile("" : "+v"(pA[0]));
+  }
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  if (e >= in.n) return;
+  float tot = 0.f;
+#pragma unroll
+  for (int r = 0; r < 6; ++r)
+#pragma unroll
+    for (int p = 0; p < 3; ++p) tot += IA[r][p].x + IA[r][p].y;
+#pragma unroll
+  for (int p = 0; p < 3; ++p) { out[(size_t)e * 7 + 2 * p] = pA[p].x; out[(size_t)e * 7 + 2 * p + 1] = pA[p].y; }
+  out[(size_t)e * 7 + 6] = tot;
+  if (threadIdx.x == 0) cycles[blockIdx.x] = t1 - t0;
+}
+
 // ------------------------------------------------------------------------------------------------ mapping B
 __device__ __forceinline__ float group8_sum(float v) {   // every lane of an aligned group of 8 ends with the group's sum
   int x = __builtin_bit_cast(int, v);
@@ -160,7 +247,8 @@ __global__ __launch_bounds__(64) void chain_lane_group(Inputs in, float* __restr
 extern "C" int probe_run(int mapping, const float* LI, const float* pAl, const float* S, const float* cb, const float* tau, int n, float arm, float* out,
                          unsigned long long* cycles, int reps, void* stream) {
   Inputs in{LI, pAl, S, cb, tau, n, arm};
-  if (mapping == 0) hipLaunchKernelGGL(chain_one_lane, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, in, out, cycles, reps);
+  if (mapping == 2) hipLaunchKernelGGL(chain_one_lane_packed, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, in, out, cycles, reps);
+  else if (mapping == 0) hipLaunchKernelGGL(chain_one_lane, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, in, out, cycles, reps);
   else hipLaunchKernelGGL(chain_lane_group, dim3((n + 7) / 8), dim3(64), 0, (hipStream_t)stream, in, out, cycles, reps);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }

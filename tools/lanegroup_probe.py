@@ -16,8 +16,8 @@ import torch
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 so = os.path.join(ROOT, "gpurun_out", "liblanegroup_probe.so")
 os.makedirs(os.path.dirname(so), exist_ok=True)
-subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", so,
-                os.path.join(ROOT, "tools", "lanegroup_probe.hip")], check=True)
+subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared"] + os.environ.get("PROBE_FLAGS", "").split() + ["-o", so,
+                os.path.join(ROOT, "tools", "lanegroup_probe.hip")], check=True)   # PROBE_FLAGS=-fno-slp-vectorize: the product's build (no compiler packing)
 lib = C.CDLL(so)
 vp = C.c_void_p
 lib.probe_run.argtypes = [C.c_int, vp, vp, vp, vp, vp, C.c_int, C.c_float, vp, vp, C.c_int, vp]
@@ -36,7 +36,7 @@ arm = 1e-3
 
 def run(mapping, reps):
     out = torch.zeros(n, 7, device=dev)
-    nwg = (n + 63) // 64 if mapping == 0 else (n + 7) // 8
+    nwg = (n + 7) // 8 if mapping == 1 else (n + 63) // 64
     cyc = torch.zeros(nwg, dtype=torch.int64, device=dev)
     args = (mapping, vp(LI.data_ptr()), vp(pAl.data_ptr()), vp(S.data_ptr()), vp(cb.data_ptr()), vp(tau.data_ptr()), n, arm, vp(out.data_ptr()), vp(cyc.data_ptr()), reps, None)
     for _ in range(3):
@@ -63,9 +63,10 @@ for j in range(nj - 1, -1, -1):
 want = torch.cat([pA, IA.sum((-1, -2)).unsqueeze(-1)], -1)
 
 REPS = 64
-print("articulated-body recursion of one six-joint chain, %d envs, %d chains per wave-launch timed" % (n, REPS))
+print("articulated-body recursion of one six-joint chain, %d envs, %d chains per wave-launch timed; extra compiler flags: %s" % (n, REPS, os.environ.get("PROBE_FLAGS", "(none: SLP vectoriser on)")))
 res = {}
-for mapping, name in ((0, "A  one lane per env (symmetric 6x6 in 21 registers)"), (1, "B  eight lanes per env (row per lane, DPP sums, ds_swizzle broadcasts)")):
+for mapping, name in ((0, "A  one lane per env (symmetric 6x6 in 21 registers)"), (1, "B  eight lanes per env (row per lane, DPP sums, ds_swizzle broadcasts)"),
+                      (2, "A2 one lane per env, packed fp32 (full 6x6 as 18 register pairs, v_pk_fma_f32)")):
     out, cyc, us = run(mapping, REPS)
     err = float((out.double() - want).abs().max() / want.abs().max())
     res[mapping] = (cyc, us)
@@ -75,3 +76,5 @@ for mapping, name in ((0, "A  one lane per env (symmetric 6x6 in 21 registers)")
 a, b = np.median(res[0][0]), np.median(res[1][0])
 print("latency of one chain: %.0f -> %.0f cycles = x%.2f; waves needed for 64 envs: 1 -> 8 (the idle three quarters of the chip at 4096 envs)" % (a, b, a / b))
 print("chip-level throughput of the recursion alone at %d envs: %.1f -> %.1f us per %d chains" % (n, res[0][1], res[1][1], REPS))
+c = np.median(res[2][0])
+print("packed fp32 in the one-lane mapping: %.0f -> %.0f cycles per chain = x%.2f, same waves, same registers' worth of state" % (a, c, a / c))
