@@ -176,6 +176,88 @@ __global__ __launch_bounds__(64) void chain_one_lane_packed(Inputs in, float* __
   if (threadIdx.x == 0) cycles[blockIdx.x] = t1 - t0;
 }
 
+// ------------------------------------------------------------------------------------------------ mapping A3
+// one lane per env, the full 6x6 as COLUMN pairs P[c][rp] = (M[2 rp][c], M[2 rp + 1][c]): y = M x is 18 v_pk_fma_f32 whose x operand is one
+// half of a register pair broadcast by op_sel (no moves, no horizontal adds -- the result pairs ARE (y[2 rp], y[2 rp + 1])); the rank-1 update
+// is 18 more with the scalar k u[c] broadcast the same way.
+#define PK_FMA_BLO(d, a, b) asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(d) : "v"(a), "v"(b))                 /* d += a * b.lo */
+#define PK_FMA_BHI(d, a, b) asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(d) : "v"(a), "v"(b))  /* d += a * b.hi */
+__global__ __launch_bounds__(64) void chain_one_lane_colpairs(Inputs in, float* __restrict__ out, unsigned long long* __restrict__ cycles, int reps) {
+  __shared__ float sh[NJ][NE][64];
+  const int lane = threadIdx.x, e = blockIdx.x * 64 + lane, ee = e < in.n ? e : 0;
+  for (int j = 0; j < NJ; ++j) {
+    const size_t b = (size_t)j * in.n + ee;
+    for (int k = 0; k < 36; ++k) sh[j][k][lane] = in.LI[b * 36 + k];
+    for (int k = 0; k < 6; ++k) { sh[j][36 + k][lane] = in.pAl[b * 6 + k]; sh[j][42 + k][lane] = in.S[b * 6 + k]; sh[j][48 + k][lane] = in.cb[b * 6 + k]; }
+    sh[j][54][lane] = in.tau[b];
+  }
+  __syncthreads();
+  f32x2 P[6][3], pA[3];
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  for (int rep = 0; rep < reps; ++rep) {
+#pragma unroll
+    for (int c = 0; c < 6; ++c)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) P[c][p] = f32x2{0.f, 0.f};
+#pragma unroll
+    for (int p = 0; p < 3; ++p) pA[p] = f32x2{0.f, 0.f};
+#pragma unroll
+    for (int j = NJ - 1; j >= 0; --j) {
+      f32x2 S[3], cb[3];
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {
+        S[p] = f32x2{sh[j][42 + 2 * p][lane], sh[j][43 + 2 * p][lane]};
+        cb[p] = f32x2{sh[j][48 + 2 * p][lane], sh[j][49 + 2 * p][lane]};
+        pA[p] += f32x2{sh[j][36 + 2 * p][lane], sh[j][37 + 2 * p][lane]};
+      }
+#pragma unroll
+      for (int c = 0; c < 6; ++c)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) P[c][p] += f32x2{sh[j][(2 * p) * 6 + c][lane], sh[j][(2 * p + 1) * 6 + c][lane]};
+      // U = M S
+      f32x2 U[3] = {f32x2{0.f, 0.f}, f32x2{0.f, 0.f}, f32x2{0.f, 0.f}};
+#pragma unroll
+      for (int c = 0; c < 6; ++c)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) { if (c & 1) PK_FMA_BHI(U[p], P[c][p], S[c >> 1]); else PK_FMA_BLO(U[p], P[c][p], S[c >> 1]); }
+      f32x2 d2 = S[0] * U[0], s2 = S[0] * pA[0];
+      d2 = __builtin_elementwise_fma(S[1], U[1], d2); s2 = __builtin_elementwise_fma(S[1], pA[1], s2);
+      d2 = __builtin_elementwise_fma(S[2], U[2], d2); s2 = __builtin_elementwise_fma(S[2], pA[2], s2);
+      const float D = d2.x + d2.y + in.arm, sp = s2.x + s2.y;
+      const float Dinv = __builtin_amdgcn_rcpf(D), uD = (sh[j][54][lane] - sp) * Dinv;
+      // M -= U U^T / D: column c gets (-u_c / D) U
+      f32x2 kU[3];
+      const f32x2 nd = {-Dinv, -Dinv};
+#pragma unroll
+      for (int p = 0; p < 3; ++p) kU[p] = U[p] * nd;
+#pragma unroll
+      for (int c = 0; c < 6; ++c)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) { if (c & 1) PK_FMA_BHI(P[c][p], U[p], kU[c >> 1]); else PK_FMA_BLO(P[c][p], U[p], kU[c >> 1]); }
+      // pA += M cb + U uD
+      const f32x2 uu = {uD, uD};
+#pragma unroll
+      for (int p = 0; p < 3; ++p) pA[p] = __builtin_elementwise_fma(U[p], uu, pA[p]);
+#pragma unroll
+      for (int c = 0; c < 6; ++c)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) { if (c & 1) PK_FMA_BHI(pA[p], P[c][p], cb[c >> 1]); else PK_FMA_BLO(pA[p], P[c][p], cb[c >> 1]); }
+    }
+    asm volatile("" : "+v"(pA[0]));
+  }
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  if (e >= in.n) return;
+  float tot = 0.f;
+#pragma unroll
+  for (int c = 0; c < 6; ++c)
+#pragma unroll
+    for (int p = 0; p < 3; ++p) tot += P[c][p].x + P[c][p].y;
+#pragma unroll
+  for (int p = 0; p < 3; ++p) { out[(size_t)e * 7 + 2 * p] = pA[p].x; out[(size_t)e * 7 + 2 * p + 1] = pA[p].y; }
+  out[(size_t)e * 7 + 6] = tot;
+  if (threadIdx.x == 0) cycles[blockIdx.x] = t1 - t0;
+}
+
 // ------------------------------------------------------------------------------------------------ mapping B
 __device__ __forceinline__ float group8_sum(float v) {   // every lane of an aligned group of 8 ends with the group's sum
   int x = __builtin_bit_cast(int, v);
@@ -247,7 +329,8 @@ __global__ __launch_bounds__(64) void chain_lane_group(Inputs in, float* __restr
 extern "C" int probe_run(int mapping, const float* LI, const float* pAl, const float* S, const float* cb, const float* tau, int n, float arm, float* out,
                          unsigned long long* cycles, int reps, void* stream) {
   Inputs in{LI, pAl, S, cb, tau, n, arm};
-  if (mapping == 2) hipLaunchKernelGGL(chain_one_lane_packed, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, in, out, cycles, reps);
+  if (mapping == 3) hipLaunchKernelGGL(chain_one_lane_colpairs, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, in, out, cycles, reps);
+  else if (mapping == 2) hipLaunchKernelGGL(chain_one_lane_packed, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, in, out, cycles, reps);
   else if (mapping == 0) hipLaunchKernelGGL(chain_one_lane, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, in, out, cycles, reps);
   else hipLaunchKernelGGL(chain_lane_group, dim3((n + 7) / 8), dim3(64), 0, (hipStream_t)stream, in, out, cycles, reps);
   return hipGetLastError() == hipSuccess ? 0 : -1;

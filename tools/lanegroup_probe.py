@@ -66,7 +66,8 @@ REPS = 64
 print("articulated-body recursion of one six-joint chain, %d envs, %d chains per wave-launch timed; extra compiler flags: %s" % (n, REPS, os.environ.get("PROBE_FLAGS", "(none: SLP vectoriser on)")))
 res = {}
 for mapping, name in ((0, "A  one lane per env (symmetric 6x6 in 21 registers)"), (1, "B  eight lanes per env (row per lane, DPP sums, ds_swizzle broadcasts)"),
-                      (2, "A2 one lane per env, packed fp32 (full 6x6 as 18 register pairs, v_pk_fma_f32)")):
+                      (2, "A2 one lane per env, packed fp32 (full 6x6 as 18 register pairs, v_pk_fma_f32)"),
+                      (3, "A3 one lane per env, column pairs + op_sel broadcasts (no moves, no horizontal adds)")):
     out, cyc, us = run(mapping, REPS)
     err = float((out.double() - want).abs().max() / want.abs().max())
     res[mapping] = (cyc, us)
@@ -78,3 +79,5 @@ print("latency of one chain: %.0f -> %.0f cycles = x%.2f; waves needed for 64 en
 print("chip-level throughput of the recursion alone at %d envs: %.1f -> %.1f us per %d chains" % (n, res[0][1], res[1][1], REPS))
 c = np.median(res[2][0])
 print("packed fp32 in the one-lane mapping: %.0f -> %.0f cycles per chain = x%.2f, same waves, same registers' worth of state" % (a, c, a / c))
+c3 = np.median(res[3][0])
+print("column pairs with op_sel broadcasts: %.0f -> %.0f cycles per chain = x%.2f (36 matrix registers instead of 21)" % (a, c3, a / c3))
