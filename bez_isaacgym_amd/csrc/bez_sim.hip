@@ -468,6 +468,8 @@ const char* bez_sim_last_error(const BezSim* sim) { return sim ? sim->err.c_str(
 static const char* oracle_only(uint32_t flags, const float* tune) {
   if (flags & BEZ_FLAG_HARD_CONTACT) return "BEZ_FLAG_HARD_CONTACT: rigid contact exists only in the CPU oracle; libbez_sim.so has no kernel for it";
   if (flags & BEZ_FLAG_TGS_SOLVER) return "BEZ_FLAG_TGS_SOLVER: the TGS-shaped solver exists only in the CPU oracle; libbez_sim.so has no kernel for it";
+  if (flags & BEZ_FLAG_ANKLE_STOP) return "BEZ_FLAG_ANKLE_STOP: the calf <-> foot-plate contact exists only in the CPU oracle; libbez_sim.so has no kernel for it";
+  if (flags & BEZ_FLAG_ALL_GROUND_SHAPES) return "BEZ_FLAG_ALL_GROUND_SHAPES: ground contact at every shape's corners exists only in the CPU oracle; libbez_sim.so has no kernel for it";
   if (tune) for (int i = 0; i < 24; ++i) if (tune[i] != 0.f) return "BezSimConfig.tune[]: knobs of the oracle-only solver variants; must be 0 for libbez_sim.so";
   return nullptr;
 }

@@ -68,6 +68,20 @@ extern "C" {
                                     solver shape PhysX is configured with (bez_kick.yaml:128-147); knobs in `tune[8..23]`.  ORACLE ONLY \
                                     (DESIGN.md 3.2 / 6.1): libbez_sim.so refuses it with rc -5 */
 
+#define BEZ_FLAG_ANKLE_STOP 1024u /* same-leg calf <-> foot-plate contact.  `create_actor(..., collision_filter 0)` (kick_env.py:365-366) makes \
+                                     PhysX collide every non-adjacent pair of the robot's shapes, and one such pair limits the robot's motion \
+                                     all the time: the bottom corners of the calf box (soccerbot_stl.urdf:232-236) meet the top face of the \
+                                     3 mm foot plate (:272-276) once the flexed ankle also rolls by 0.3-0.45 rad -- well inside the roll \
+                                     joint's own +-0.785 rad.  The gap is a function of the two ankle angles alone, so the contact is a \
+                                     coupled limit of those two joints: an implicit spring-damper along the gap's gradient.  ORACLE ONLY \
+                                     (the reference policy's sim-to-sim does not move with it): libbez_sim.so refuses it, rc -5 */
+
+#define BEZ_FLAG_ALL_GROUND_SHAPES 2048u /* ground contact at the corners of EVERY collision shape of soccerbot_stl.urdf (hip, thigh, calf, ankle, \
+                                            forearm, neck, head boxes / mesh bounds), not only the foot corners and the upper-body guard points. \
+                                            ORACLE ONLY (the get-up scenarios of tools/getup_probe.py need knees and elbows on the ground; \
+                                            nothing on the bez_kick path touches the ground with them before its fall reset): libbez_sim.so \
+                                            refuses it with rc -5 */
+
 #define BEZ_FLAG_LEAN_STEP 128u /* bez_sim_step / bez_sim_step_many keep only what the rollout reads (state, obs, reward, reset / progress / \
                                    timeout, DOF targets): the stores of the NET_CONTACT_FORCE rows, FEET and PREV_LIN_VEL -- 308 B of the \
                                    912 B an env-step writes -- are skipped, and those three tensors then hold the values of the last call \

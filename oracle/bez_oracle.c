@@ -35,6 +35,7 @@
 
 #include "../bez_isaacgym_amd/csrc/bez_model_gen.h"
 #include "../include/bez_sim.h"
+#include "bez_oracle_shapes.inc"
 
 #ifndef BEZ_REAL
 #define BEZ_REAL double
@@ -398,6 +399,40 @@ static void self_collision(const BezSimConfig* c, real mu, const Kin* k, const S
   }
 }
 
+/* ---- same-leg calf <-> foot-plate contact (BEZ_FLAG_ANKLE_STOP; kick_env.py:365-366: collision_filter 0 collides every non-adjacent
+ * shape pair, soccerbot_stl.urdf:232-236 calf box, :272-276 foot plate).  Each bottom corner of the calf box is tested against the plane of
+ * the plate's top face; gap g = n . (corner - foot origin) - z_top with n the foot's z axis.  The two bodies are joined by the ankle-pitch and
+ * foot-roll joints only, so the contact force pair does work through those two joint rates alone:  g' = J_a qd_a + J_f qd_f  with
+ * J_d = -n . (S_d at the corner), and the contact is the joint-space force tau_d = J_d lambda,  lambda = -k (g + h g') - c g' - (h^2 k + h c) sum_e J_e qdd_e
+ * (the implicit spring-damper of the joint limits; the own-joint term goes into the joint's D, the cross term is dropped). */
+typedef struct { int n; int la[8], lf[8]; real Ja[8], Jf[8], lam0[8]; V3 nrm[8]; } AnkleStop;
+static real m_stop_kn(const BezSimConfig* c) { return c->tune[0] != 0 ? (real)c->tune[0] : (real)2e5; }
+static real m_stop_cn(const BezSimConfig* c) { return c->tune[1] != 0 ? (real)c->tune[1] : (real)1e3; }
+static void ankle_stop(const BezSimConfig* c, const Env* e, real h, const Kin* k, const SV* S, AnkleStop* A) {
+  A->n = 0;
+  const real kn = m_stop_kn(c), cn = m_stop_cn(c);
+  for (int side = 0; side < 2; ++side) {
+    const int bc = 2 + 5 * side, bf = 4 + 5 * side;              /* calf box, foot box */
+    const int lc = BEZ_BOX_LINK[bc], lf = BEZ_BOX_LINK[bf], la = lf - 1;
+    const real ztop = (real)(BEZ_BOX_CENTER[bf][2] + BEZ_BOX_HALF[bf][2]);
+    V3 n = v3(k->E[lf].m[0][2], k->E[lf].m[1][2], k->E[lf].m[2][2]);
+    for (int cx = -1; cx <= 1; cx += 2) for (int cy = -1; cy <= 1; cy += 2) {
+      V3 pl = v3((real)(BEZ_BOX_CENTER[bc][0] + cx * BEZ_BOX_HALF[bc][0]), (real)(BEZ_BOX_CENTER[bc][1] + cy * BEZ_BOX_HALF[bc][1]),
+                 (real)(BEZ_BOX_CENTER[bc][2] - BEZ_BOX_HALF[bc][2]));
+      V3 x = v3add(k->r[lc], m3mulv(&k->E[lc], pl));
+      real g = v3dot(n, v3sub(x, k->r[lf])) - ztop;
+      if (!(g < 0)) continue;
+      real Ja = -v3dot(n, v3add(sv_lin(S[la]), v3cross(sv_ang(S[la]), x)));
+      real Jf = -v3dot(n, v3add(sv_lin(S[lf]), v3cross(sv_ang(S[lf]), x)));
+      real gd = Ja * e->qd[la - 1] + Jf * e->qd[lf - 1];
+      real lam0 = -kn * (g + h * gd) - cn * gd;
+      if (!(lam0 > 0)) continue;
+      int i = A->n++;
+      A->la[i] = la; A->lf[i] = lf; A->Ja[i] = Ja; A->Jf[i] = Jf; A->lam0[i] = lam0; A->nrm[i] = n;
+    }
+  }
+}
+
 /* pass 1 of the ABA: kinematics, link velocities, bias accelerations, rigid-body inertias and bias forces (gravity included) */
 typedef struct { Kin k; SV V[NL], S[NL], cb[NL], pA[NL]; M6 IA[NL]; } Pass1;
 static void aba_pass1(const BezSimConfig* c, const Env* e, Pass1* P) {
@@ -450,7 +485,7 @@ static void dynamics(const BezSimConfig* c, const Env* e, real h, int mode, cons
   memset(out->contact_force, 0, sizeof(out->contact_force));
 
   /* contacts (implicit spring-dampers folded into IA / pA) */
-  GroundHit hits[BEZ_NPT];
+  GroundHit hits[BEZ_NPT + BEZ_NXPT];
   int nhit = 0;
   real mu = e->friction;
   /* ball as a free body about its own centre, classical accelerations */
@@ -466,6 +501,14 @@ static void dynamics(const BezSimConfig* c, const Env* e, real h, int mode, cons
       V3 x = v3add(k.r[l], m3mulv(&k.E[l], pl));
       real z = e->root_pos[2] + x.v[2];
       if (ground_contact(c, (real)c->contact_kn, (real)c->contact_cn, mu, h, x, z, V[l], &IA[l], &pA[l], &hits[nhit])) { hits[nhit].link = l; hits[nhit].body = m_pt_body(c, i); ++nhit; }
+    }
+    if ((c->flags & BEZ_FLAG_ALL_GROUND_SHAPES) && !m_cl(c) && !m_box(c)) { /* EXPERIMENT (get-up scenarios): the corners of every other collision shape */
+      for (int i = 0; i < BEZ_NXPT; ++i) {
+        int l = BEZ_XPT_LINK[i];
+        V3 x = v3add(k.r[l], m3mulv(&k.E[l], v3((real)BEZ_XPT_POS[i][0], (real)BEZ_XPT_POS[i][1], (real)BEZ_XPT_POS[i][2])));
+        real z = e->root_pos[2] + x.v[2];
+        if (ground_contact(c, (real)c->contact_kn, (real)c->contact_cn, mu, h, x, z, V[l], &IA[l], &pA[l], &hits[nhit])) { hits[nhit].link = l; hits[nhit].body = BEZ_XPT_BODY[i]; ++nhit; }
+      }
     }
     if (!(c->flags & BEZ_FLAG_NO_SELF_COLLISION)) {
       self_collision(c, mu, &k, V, pS, out->contact_force, (c->flags & BEZ_FLAG_CF_WITH_FRICTION) != 0);
@@ -559,6 +602,18 @@ static void dynamics(const BezSimConfig* c, const Env* e, real h, int mode, cons
     }
   }
 
+  /* same-leg calf <-> foot-plate contact as a coupled limit of the two ankle joints */
+  AnkleStop AS; AS.n = 0;
+  real stop_tau[NL], stop_k[NL];
+  memset(stop_tau, 0, sizeof(stop_tau)); memset(stop_k, 0, sizeof(stop_k));
+  if (mode == 0 && (c->flags & BEZ_FLAG_ANKLE_STOP)) {
+    ankle_stop(c, e, h, &k, S, &AS);
+    const real kimp = h * h * m_stop_kn(c) + h * m_stop_cn(c);
+    for (int i = 0; i < AS.n; ++i) {
+      stop_tau[AS.la[i]] += AS.Ja[i] * AS.lam0[i]; stop_k[AS.la[i]] += kimp * AS.Ja[i] * AS.Ja[i];
+      stop_tau[AS.lf[i]] += AS.Jf[i] * AS.lam0[i]; stop_k[AS.lf[i]] += kimp * AS.Jf[i] * AS.Jf[i];
+    }
+  }
   /* pass 2: articulated inertias, leaves -> root */
   SV U[NL]; real Dinv[NL], u[NL];
   for (int l = NL - 1; l >= 1; --l) {
@@ -577,6 +632,7 @@ static void dynamics(const BezSimConfig* c, const Env* e, real h, int mode, cons
       real lo = e->lim_lo[d], hi = e->lim_hi[d]; /* DR may jitter the PHYSICAL limits (bez_kick.yaml:206-219); targets keep the originals */
       if (e->q[d] < lo) { tau_l0 = (real)c->limit_k * (lo - e->q[d] - h * e->qd[d]) - (real)c->limit_d * e->qd[d]; k_l = h * h * (real)c->limit_k + h * (real)c->limit_d; }
       else if (e->q[d] > hi) { tau_l0 = (real)c->limit_k * (hi - e->q[d] - h * e->qd[d]) - (real)c->limit_d * e->qd[d]; k_l = h * h * (real)c->limit_k + h * (real)c->limit_d; }
+      tau_l0 += stop_tau[l]; k_l += stop_k[l];
       /* effort-limit predictor: joint acceleration with the parent held (a_parent = 0) */
       real bias = sv_dot(S[l], pA[l]) + sv_dot(U[l], cb[l]);
       real qdd_est = (tau_pd0 + tau_f0 + tau_l0 - bias) / (J + k_pd + k_f + k_l);
@@ -631,6 +687,13 @@ static void dynamics(const BezSimConfig* c, const Env* e, real h, int mode, cons
         out->contact_force[body][1] += hh->fty0 - h * hh->ct * ap.v[1];
       }
       out->contact_force[body][2] += hh->fn0 - hh->kn * ap.v[2];
+    }
+    for (int i = 0; i < AS.n; ++i) { /* calf <-> foot plate: +lambda n on the calf, -lambda n on the foot */
+      const real kimp = h * h * m_stop_kn(c) + h * m_stop_cn(c);
+      real lam = AS.lam0[i] - kimp * (AS.Ja[i] * out->qdd[AS.la[i] - 1] + AS.Jf[i] * out->qdd[AS.lf[i] - 1]);
+      if (!(lam > 0)) continue;
+      int bcalf = m_link_body(c, AS.la[i] - 1), bfoot = m_link_body(c, AS.lf[i]);
+      for (int j = 0; j < 3; ++j) { out->contact_force[bcalf][j] += lam * AS.nrm[i].v[j]; out->contact_force[bfoot][j] -= lam * AS.nrm[i].v[j]; }
     }
     V3 fl = v3(0, 0, 0); /* force on the link from the ball */
     if (bl_link >= 0) {

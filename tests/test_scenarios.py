@@ -1,0 +1,80 @@
+"""Scripted scenarios on the CPU oracle (missing 3): the reference's get-up tables from lying starts and
+the per-DOF limit sweep of `bez_isaacgym/test/test_kick_env.py:142-186`.  The same scenarios run on the HIP simulator in
+tests/test_gpu_round5.py.  What the get-ups reach is MEASURED here, not assumed: nothing under /root/reference records that these
+open-loop tables (written for the soccerbot's PyBullet model) succeed under Isaac Gym either."""
+import numpy as np
+import pytest
+
+from bez_isaacgym_amd import abi
+from tests.scenarios import dof_sweep, lay_down, make_backend, play
+
+
+def _getup(name, n=8, flags=None):
+    import json, os
+    from tests.scenarios import ROOT
+    model = json.load(open(os.path.join(ROOT, "bez_isaacgym_amd", "model", "bez_model.json")))
+    cfg = abi.default_config(n, seed=7)
+    if flags is not None:
+        cfg.flags = flags
+    sim = make_backend("oracle", cfg)
+    sim.step(np.zeros((n, 18), np.float32))
+    lay_down(sim, n, name, np.random.default_rng(3))
+    return play(sim, n, name, model)
+
+
+def test_getup_front_reaches_the_squat_oracle():
+    """`simulation_getupfront` from lying face down (the yaml's own "flat" quaternion, bez_kick.yaml:20): the arms push the torso up and
+    the legs fold under it -- the robot reaches the squat on its feet (torso 0.22 m high, 33 degrees forward) in every env.  Regression floor."""
+    r = _getup("getupfront")
+    assert r["finite"] == 1.0 and r["max_z"] > 0.20 and r["max_up"] > 0.75, r
+
+
+def test_getup_side_rolls_onto_the_front_oracle():
+    """`simulation_getupside` only swings the arms back (-pi/2): from its side the robot ends lying on its front, where getupfront starts."""
+    r = _getup("getupside")
+    assert r["finite"] == 1.0 and r["final_z"] < 0.12 and abs(r["final_up"]) < 0.4, r
+
+
+@pytest.mark.xfail(strict=True, reason="measured: 0 of 8 envs stand at the end of simulation_getupfront (squat reached, max z 0.219 / up 0.80; in the "
+                                       "last key frame the torso pitches forward over the toes, final z 0.077); identical at damping 2 and effort 5 N*m -- "
+                                       "profiles/r05_getup.txt")
+def test_getup_front_ends_standing_oracle():
+    assert _getup("getupfront")["standing"] >= 0.9
+
+
+@pytest.mark.xfail(strict=True, reason="measured: with the baked contact set (feet + 14 upper-body guard points) the robot never rolls off its back "
+                                       "(max z 0.092); with ground contact at every collision shape's corners (BEZ_FLAG_ALL_GROUND_SHAPES, oracle only) "
+                                       "it rolls over and reaches the same squat as getupfront, then tips forward the same way -- profiles/r05_getup.txt")
+def test_getup_back_ends_standing_oracle():
+    assert _getup("getupback")["standing"] >= 0.9
+
+
+def test_all_ground_shapes_let_the_back_getup_roll_over_oracle():
+    """Oracle-only variant: knees, hips and forearm boxes touch the ground as well.  The back get-up then rolls the robot over and reaches
+    the squat (without them it stays on its back): what the get-ups need is contact geometry, not drive authority."""
+    a = _getup("getupback", n=4)
+    b = _getup("getupback", n=4, flags=abi.FLAG_IMU_PREV_ALIAS | abi.FLAG_ALL_GROUND_SHAPES)
+    assert a["max_z"] < 0.12 and b["max_z"] > 0.20 and b["max_up"] > 0.75, (a, b)
+
+
+def check_dof_sweep(rows):
+    """Every actuated DOF reaches both limits and returns (zero gravity, floating base) -- except where the model says it cannot:
+    the head joints never receive an action (kick_env.py:414) and a hip rolling INWARD meets the other leg (collision_filter 0,
+    kick_env.py:365-366) 0.34 rad short of its -0.785 rad limit."""
+    for r in rows:
+        assert r["finite"], r
+        if r["dof"] < 2:
+            assert r["miss_default"] < 1e-3 and r["miss_lower"] > 1.5, r       # did not move
+        elif r["name"].endswith("leg_motor_1"):
+            assert 0.2 < r["miss_lower"] < 0.5 and r["miss_upper"] < 0.05 and r["miss_default"] < 0.05, r
+        else:
+            assert r["miss_lower"] < 0.05 and r["miss_upper"] < 0.05 and r["miss_default"] < 0.05, r
+
+
+def test_dof_sweep_oracle(model):
+    n = 2
+    cfg = abi.default_config(n, seed=3)
+    cfg.gravity[:] = [0.0, 0.0, 0.0]
+    sim = make_backend("oracle", cfg)
+    sim.step(np.zeros((n, 18), np.float32))
+    check_dof_sweep(dof_sweep(sim, n, model))
