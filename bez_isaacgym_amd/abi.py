@@ -164,9 +164,36 @@ def default_config(num_envs=4096, seed=42, env_id_offset=0):
     return c
 
 
+def refuse_unmodelled(cfg):
+    """Config keys the reference forwards to Isaac Gym that this build's rigid-body step does not model: a non-default value raises
+    instead of being read and ignored (the defaults of bez_kick.yaml are what the kernels implement).
+    kick_env.py:250-256 (plane), :283-294 (asset options)."""
+    env = cfg["env"]
+    ua, plane = env.get("urdfAsset", {}), env.get("plane", {})
+
+    def no(cond, key, value, why):
+        if cond:
+            raise ValueError("task config: %s = %r is not modelled by the HIP simulator (%s); only the value of the reference's "
+                             "yaml is implemented" % (key, value, why))
+    no(bool(ua.get("fixBaseLink", False)), "env.urdfAsset.fixBaseLink", ua.get("fixBaseLink"), "the robot is always a floating-base tree")
+    no(bool(ua.get("disable_gravity", False)), "env.urdfAsset.disable_gravity", ua.get("disable_gravity"),
+       "gravity acts on every body; set sim.gravity to zero instead")
+    for k in ("angular_damping", "linear_damping"):
+        no(float(ua.get(k, 0.0)) != 0.0, "env.urdfAsset." + k, ua.get(k), "per-body velocity damping is not part of the step")
+    no(float(plane.get("restitution", 0.0)) != 0.0, "env.plane.restitution", plane.get("restitution"), "contacts are inelastic")
+    if "staticFriction" in plane and "dynamicFriction" in plane:
+        no(float(plane["staticFriction"]) != float(plane["dynamicFriction"]), "env.plane.staticFriction", plane["staticFriction"],
+           "one Coulomb coefficient (dynamicFriction) serves for both")
+    # vec_task.py:90 reads env.controlFrequencyInv (the yaml's env.control.controlFrequencyInv is never read by the reference):
+    # k simulate calls per env step, taken by KickEnv._fused_step through the split entry points
+    cfi = int(env.get("controlFrequencyInv", 1))
+    no(cfi < 1, "env.controlFrequencyInv", cfi, "must be >= 1")
+
+
 def config_from_task_cfg(cfg, seed=42, env_id_offset=0, strict_reference_quirks=True, task="bez_kick"):
     """Build a BezSimConfig from the task config dict (the structure of cfg/task/bez_{kick,walk,orient}.yaml)."""
     env, sim = cfg["env"], cfg["sim"]
+    refuse_unmodelled(cfg)
     c = default_config(int(env["numEnvs"]), seed=seed, env_id_offset=env_id_offset)
     c.task = TASK_IDS[task]
     c.goal_angle = float(env["goalState"].get("goal_angle", 0.0))

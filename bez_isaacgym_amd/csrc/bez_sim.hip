@@ -782,6 +782,11 @@ int bez_sim_dr_step_args(BezSim* s, void* blob, int32_t blob_bytes) {
   s->dr_prelaunched = true;
   return (int)sizeof(DrArgs);
 }
+int bez_sim_dr_cancel(BezSim* s) {
+  if (!s) return -1;
+  s->dr_prelaunched = false;
+  return 0;
+}
 /* Where a consumer that adds the action noise ITSELF (vec_task.py:586-592; e.g. bez_ppo_policy_rollout_step's epilogue) finds its
  * parameters: a device struct {float mean, std; uint32 frame_lo, frame_hi} kept by the step kernels, and the Philox key parts.  The
  * noise of element i of the flat (N, 18) action tensor is mean + std * z with z = word (i & 3) of dr-noise quad (i >> 2) for which = 1
@@ -795,6 +800,7 @@ int bez_sim_action_noise_source(BezSim* s, const void** snap_dev, uint64_t* seed
 int bez_sim_set_randomization(BezSim* s, const BezDrConfig* dr, void* stream_) {
   if (!s) return -1;
   hipStream_t stream = (hipStream_t)stream_;
+  s->dr_prelaunched = false;   // a hand-out made under the previous configuration is void
   if (!dr) { s->dr_on = false; return 0; }
   if (dr->frequency < 1) return fail(s, -1, "bez_sim_set_randomization: frequency must be >= 1");
   s->drc = *dr;
@@ -846,6 +852,6 @@ int bez_sim_calibrate(void* buf_dev, uint64_t n_floats, int32_t write, void* str
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
-int bez_sim_seed(BezSim* s, uint64_t seed) { if (!s) return -1; s->cfg.seed = seed; return 0; }
+int bez_sim_seed(BezSim* s, uint64_t seed) { if (!s) return -1; s->cfg.seed = seed; s->dr_prelaunched = false; return 0; }
 
 }  // extern "C"

@@ -426,11 +426,18 @@ class A2CAgent:
         # keep the plain torch path (thousands of nodes, clobbered after ~8 KB of eager kernel arguments) eager unless forced.
         from .. import GRAPH_REPLAY_SAFE
         if self.use_graphs and not GRAPH_REPLAY_SAFE:
+            # a hard condition for EVERY path (round-4 advisor finding: the fused path only warned and kept replaying): without the
+            # guarantee `hip_graphs: auto` means eager; only an explicit `hip_graphs: True` replays, at the caller's risk and with a warning
             import warnings
-            warnings.warn("HIP graphs are replayed with the runtime's graph packet capture ON (DEBUG_CLR_GRAPH_PACKET_CAPTURE != 0, or HIP was "
-                          "initialised before bez_isaacgym_amd was imported): enough eager kernel launches between replays corrupt the replayed "
-                          "kernels' arguments (DESIGN.md 6.2)", RuntimeWarning, stacklevel=2)
-            if not self.fused and g is not True:
+            if g is True:
+                warnings.warn("HIP graphs are replayed with the runtime's graph packet capture ON (DEBUG_CLR_GRAPH_PACKET_CAPTURE != 0, or HIP "
+                              "was initialised before bez_isaacgym_amd was imported): enough eager kernel launches between replays corrupt the "
+                              "replayed kernels' arguments (DESIGN.md 6.2)", RuntimeWarning, stacklevel=2)
+            else:
+                warnings.warn("HIP graphs are OFF for this agent: the runtime's graph packet capture could not be switched off (HIP was initialised "
+                              "before bez_isaacgym_amd was imported, or DEBUG_CLR_GRAPH_PACKET_CAPTURE is set to non-zero), and replaying graphs "
+                              "in that state corrupts kernel arguments (DESIGN.md 6.2).  Import bez_isaacgym_amd before the first CUDA call to "
+                              "get the replayed (faster) epochs", RuntimeWarning, stacklevel=2)
                 self.use_graphs = False
         if self.fused:
             from . import fused as F
@@ -589,10 +596,18 @@ class A2CAgent:
                 if self._policy_fwd is not None:
                     # normaliser + 5 Linear + 3 ELU + sampling + neglogp + clamp + the rollout-buffer rows: one launch -- which also does the
                     # PREVIOUS env step's bookkeeping (reward shaping, done flags, episode statistics): a rollout step is two launches
-                    self._policy_fwd.rollout_step(cur, net.sigma.detach(), fx["noise"][n], self.dones, vrms, mb["obs"][n], mb["dones"][n], mb["mu"][n],
-                                                  mb["val"][n], mb["act"][n], fx["env_act"], mb["neglogp"][n], mb["sigma"][n],
-                                                  prev_post=None if pending is None else F.RolloutPost.of(*pending), action_noise=act_noise,
-                                                  dr_step=env.dr_step_args() if fold_dr else None)
+                    dr_blob = env.dr_step_args() if fold_dr else None
+                    try:
+                        self._policy_fwd.rollout_step(cur, net.sigma.detach(), fx["noise"][n], self.dones, vrms, mb["obs"][n], mb["dones"][n], mb["mu"][n],
+                                                      mb["val"][n], mb["act"][n], fx["env_act"], mb["neglogp"][n], mb["sigma"][n],
+                                                      prev_post=None if pending is None else F.RolloutPost.of(*pending), action_noise=act_noise,
+                                                      dr_step=dr_blob)
+                    except BaseException:
+                        # the launch that was to carry the coming step's randomisation did not run: hand it back, or the next env step
+                        # would silently skip its randomisation pass (round-4 advisor finding)
+                        if dr_blob is not None:
+                            env.sim.dr_cancel()
+                        raise
                     pending = None
                 else:
                     x = self._f_obs_rms.normalize(cur, fx["obs_n"]) if self.normalize_input else cur
@@ -760,6 +775,23 @@ class A2CAgent:
         self._weights_dirty = True
         self._packed_stale = True
 
+    def mark_weights_dirty(self):
+        """Public: call after writing the fp32 master weights by any route this agent cannot see (a raw-pointer kernel, `param.data` writes).
+        `load_state_dict` and in-place tensor writes are noticed without it (post-hook / `_weights_signature`)."""
+        self._mark_weights_dirty()
+
+    def _weights_signature(self):
+        """Host-only fingerprint of the master weights' identity: in-place writes bump a tensor's `_version`, re-pointing `param.data`
+        changes its storage.  (The fused optimiser writes through raw pointers and changes neither: what it writes, it also mirrors.)"""
+        return tuple((p._version, p.data_ptr()) for p in self.model.parameters())
+
+    def _notice_external_weight_writes(self):
+        sig = self._weights_signature()
+        if sig != getattr(self, "_weights_sig", None):
+            if getattr(self, "_weights_sig", None) is not None:
+                self._mark_weights_dirty()
+            self._weights_sig = sig
+
     def _copies_kept_current(self):
         """True where the fused optimiser launch maintains every derived weight copy (fp16 working copy, fragment-major forward / backward
         copies): the rollout then needs no refresh of its own."""
@@ -780,7 +812,10 @@ class A2CAgent:
         """Rollout + dataset.  With HIP graphs enabled the first call after warm-up captures, later calls replay."""
         if self.mb is None:
             self._alloc_static()
+        self._notice_external_weight_writes()   # round-4 advisor finding: p.copy_(), EMA / perturbation tools, a late broadcast
         self._refresh_weight_copies_if_dirty()
+        if self._g_rollout is not None and self._lean_env is not None and not getattr(self._lean_env, "_lean", True):
+            self._lean_env.set_lean(True)       # the captured rollout steps lean whatever release_env() set in between
         if self.use_graphs and self.world > 1 and self._eager_epochs >= self.graph_warmup_epochs:
             # data parallel: the horizon loop has no collective and is replayed; GAE + dataset (two all-reduces) stay eager
             if self._g_rollout is None:
@@ -1273,6 +1308,7 @@ class A2CAgent:
         self._eager_epochs += 1
         self.epoch_num += 1
         self.frame += self.batch_size * self.world
+        self._weights_sig = self._weights_signature()   # whatever this epoch's own optimiser steps did to the versions is not "external"
         return dict(play_time=t_play, update_time=t_total - t_play, total_time=t_total, kl=sum(kls) / len(kls),
                     a_loss=a_l, c_loss=c_l, lr=self.last_lr)
 

@@ -70,7 +70,7 @@ EXPORTS = ["bez_sim_default_config", "bez_sim_create", "bez_sim_destroy", "bez_s
            "bez_sim_set_dof_position_target_tensor", "bez_sim_set_dof_position_target_tensor_indexed",
            "bez_sim_set_net_contact_force_tensor", "bez_sim_set_prev_lin_vel_tensor", "bez_sim_set_goal_tensor", "bez_sim_set_flags",
            "bez_sim_set_obs_calls", "bez_sim_pre_physics", "bez_sim_simulate", "bez_sim_post_physics", "bez_sim_observe_reward", "bez_sim_step",
-           "bez_sim_step_many", "bez_sim_reset_indexed", "bez_sim_set_env_params", "bez_sim_get_env_params", "bez_sim_set_randomization", "bez_sim_dr_prelaunch", "bez_sim_dr_step_args", "bez_sim_action_noise_source", "bez_sim_add_dr_noise", "bez_sim_seed", "bez_sim_time_steps",
+           "bez_sim_step_many", "bez_sim_reset_indexed", "bez_sim_set_env_params", "bez_sim_get_env_params", "bez_sim_set_randomization", "bez_sim_dr_prelaunch", "bez_sim_dr_step_args", "bez_sim_dr_cancel", "bez_sim_action_noise_source", "bez_sim_add_dr_noise", "bez_sim_seed", "bez_sim_time_steps",
            "bez_sim_calibrate"]
 # (the bez_ppo_* entry points of the same library are bound in ppo/fused.py)
 
@@ -252,6 +252,10 @@ class BezSim:
         if rc < 0:
             self._check(rc)
         return blob if rc > 0 else None
+
+    def dr_cancel(self):
+        """The consumer of dr_prelaunch() / dr_step_args() did not run: the coming step launches its own randomisation kernel again."""
+        self._check(self.lib.bez_sim_dr_cancel(self.h))
 
     def action_noise_source(self):
         """(device pointer of the action-noise snapshot, seed, env id offset) for a consumer that adds the action noise itself, or None

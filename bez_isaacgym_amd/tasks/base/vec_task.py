@@ -91,6 +91,9 @@ class Env(abc.ABC):
         return self.num_observations
 
 
+MASS_DRAW_TAG = 0x4D415353  # "MASS": Philox counter word of the setup-only mass scale draw
+
+
 class VecTask(Env):
     """Subclasses create `self.sim` (a bez_isaacgym_amd.sim.BezSim) in create_sim()."""
 
@@ -245,8 +248,11 @@ class VecTask(Env):
         # still interpolates to "no randomisation" (scale 1); without a schedule it is a real one-time draw.
         rbp = (((dr_params.get("actor_params") or {}).get("bez") or {}).get("rigid_body_properties") or {})
         if "mass" in rbp and rbp["mass"].get("schedule") != "linear":
-            lo, hi = rbp["mass"]["range"]
-            g = torch.Generator(device=self.device)
-            g.manual_seed(int(self.cfg.get("seed", 42)) + 7919 * int(self.cfg.get("env_id_offset", 0)))
-            self.sim.set_env_params(abi.PARAM_MASS_SCALE, (torch.rand(self.num_envs, 19, device=self.device, generator=g) * (hi - lo) + lo).contiguous())
+            # one draw per (GLOBAL env id, link) from the simulator's own counter-based generator: the same env gets the same
+            # masses whatever the number of ranks (every other per-env draw is keyed that way, include/bez_sim.h)
+            from ...utils.utils import per_env_uniform
+            lo, hi = (float(v) for v in rbp["mass"]["range"])
+            off = int(self.cfg.get("env_id_offset", 0))
+            u = per_env_uniform(int(self.cfg.get("seed", 42)), range(off, off + self.num_envs), MASS_DRAW_TAG, 19)
+            self.sim.set_env_params(abi.PARAM_MASS_SCALE, torch.from_numpy(u * (hi - lo) + lo).to(self.device).contiguous())
         self.first_randomization = False

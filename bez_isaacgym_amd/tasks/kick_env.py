@@ -214,6 +214,10 @@ class KickEnv(VecTask):
         return True
 
     def _fused_step(self, actions):
+        if self.control_freq_inv != 1:
+            # vec_task.py:322-324 loops gym.simulate controlFrequencyInv times per env step: the fused kernel is one simulate per
+            # step, so any other value takes the split entry points (pre_physics, simulate x k, post_physics)
+            return VecTask._fused_step(self, actions)
         self._raw_actions = actions  # borrowed until the next step (see `actions`)
         self.sim.step(actions)  # with randomize: True the kernel in front of the step counts randomize_buf and redraws at reset time
         self._stale = True

@@ -275,6 +275,10 @@ int bez_sim_dr_prelaunch(BezSim* sim, void* stream);
  * to step (all clocks live in device memory), so a captured graph replays it.  Returns the bytes used, 0 without a randomisation. */
 #define BEZ_DR_STEP_BYTES 512
 int bez_sim_dr_step_args(BezSim* sim, void* blob, int32_t blob_bytes);
+/* Takes back a hand-out of bez_sim_dr_prelaunch / bez_sim_dr_step_args whose consumer did NOT run (its launch failed or was skipped): the
+ * coming control step launches its own randomisation kernel again.  Also implied by bez_sim_set_randomization and bez_sim_seed.  Only for
+ * the not-run case: after a consumer that did run, the step would randomise twice. */
+int bez_sim_dr_cancel(BezSim* sim);
 /* For a consumer that adds the action noise of vec_task.py:586-592 itself (e.g. bez_ppo_policy_rollout_step): *snap_dev -> device struct
  * {float mean, std; uint32_t frame_lo, frame_hi} kept current by the step kernels; noise of element i of the flat (N, 18) action tensor =
  * mean + std * z, z = word (i & 3) of the Philox4x32-10 block with counter (key lo, key hi, frame lo, 0x4e4f4953 + 1 + (frame hi << 8)),

@@ -1,6 +1,7 @@
 """CPU: the C-ABI library loads without a GPU and exports every symbol include/bez_sim.h declares;
 the ctypes mirror of BezSimConfig matches the C struct; the product refuses to run without a GPU."""
 import ctypes as C
+import numpy as np
 import os
 import re
 
@@ -98,3 +99,38 @@ def test_product_does_not_import_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 txt = open(os.path.join(dp, f)).read()
                 assert "bez_oracle" not in txt and "import oracle" not in txt and "from oracle" not in txt, os.path.join(dp, f)
+
+
+@pytest.mark.parametrize("path,value", [(("env", "urdfAsset", "fixBaseLink"), True), (("env", "urdfAsset", "disable_gravity"), True),
+                                        (("env", "urdfAsset", "angular_damping"), 0.05), (("env", "urdfAsset", "linear_damping"), 0.1),
+                                        (("env", "plane", "restitution"), 0.3), (("env", "plane", "staticFriction"), 0.5),
+                                        (("env", "controlFrequencyInv"), 0)])
+def test_unmodelled_config_values_are_refused(path, value):
+    """kick_env.py:250-256,283-294 forward these keys to Isaac Gym; the HIP step models only the reference yaml's values, so anything
+    else raises in abi.config_from_task_cfg instead of being read and ignored (missing 5)."""
+    from bez_isaacgym_amd.utils.config import load_config
+    cfg = load_config(["task=bez_kick", "num_envs=8", "headless=True"])["task"]
+    abi.config_from_task_cfg(cfg)           # the reference's own yaml passes
+    node = cfg
+    for k in path[:-1]:
+        node = node[k]
+    node[path[-1]] = value
+    with pytest.raises(ValueError, match=path[-1]):
+        abi.config_from_task_cfg(cfg)
+
+
+def test_per_env_uniform_is_the_oracles_philox_and_shard_invariant():
+    """The setup-only mass scale draw (bez_kick.yaml:175, vec_task.py: rigid_body_properties.mass without a schedule) uses
+    utils.per_env_uniform: word k of Philox4x32-10 keyed by (seed, GLOBAL env id, tag) -- the oracle's generator word for word,
+    and a shard [off, off + n) of the envs draws exactly the rows of the whole range."""
+    from bez_isaacgym_amd.utils.utils import per_env_uniform
+    from oracle.bez_oracle import Oracle
+    o = Oracle(num_envs=2)
+    seed, tag = (42 << 32) | 7, 0x4D415353
+    whole = per_env_uniform(seed, range(0, 300), tag, 19)
+    for g in (0, 5, 299):
+        for k in (0, 3, 4, 18):
+            w = o.philox_word(seed, g, tag, k)      # counter = (env lo, env hi, third word, k >> 2), word k & 3
+            assert whole[g, k] == np.float32(w >> 8) * np.float32(1.0 / 16777216.0)
+    assert np.array_equal(per_env_uniform(seed, range(100, 228), tag, 19), whole[100:228])
+    assert 0.0 <= whole.min() and whole.max() < 1.0 and abs(whole.mean() - 0.5) < 0.02

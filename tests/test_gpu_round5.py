@@ -49,3 +49,139 @@ def test_dof_sweep_hip(model):
     sim = make_backend("hip", cfg)
     sim.step(np.zeros((n, 18), np.float32))
     check_dof_sweep(dof_sweep(sim, n, model))
+
+
+def _kick_env(n, overrides=(), seed=42, env_id_offset=0, mutate=None):
+    from bez_isaacgym_amd.tasks import isaacgym_task_map
+    from bez_isaacgym_amd.utils.config import load_config
+    cfg = load_config(["task=bez_kick", "num_envs=%d" % n, "headless=True"] + list(overrides))["task"]
+    cfg["rl_device"] = "cuda:0"
+    cfg["seed"] = seed
+    cfg["env_id_offset"] = env_id_offset
+    if mutate:
+        mutate(cfg)
+    return isaacgym_task_map["bez_kick"](cfg=cfg, sim_device="cuda:0", graphics_device_id=0, headless=True)
+
+
+def test_control_frequency_inv_loops_the_simulate_call():
+    """vec_task.py:322-324: `for i in range(self.control_freq_inv): self.gym.simulate(self.sim)` (the key is env.controlFrequencyInv,
+    vec_task.py:90).  KickEnv.step with controlFrequencyInv = 2 must equal pre_physics + two simulate calls + post_physics driven by
+    hand on a twin, and differ from the one-simulate fused step."""
+    import torch
+    n = 128
+    two = _kick_env(n, mutate=lambda c: c["env"].__setitem__("controlFrequencyInv", 2))
+    twin = _kick_env(n)
+    one = _kick_env(n)
+    assert two.control_freq_inv == 2 and one.control_freq_inv == 1
+    g = torch.Generator(device="cpu").manual_seed(3)
+    for t in range(12):
+        a = (torch.rand(n, 18, generator=g) * 2 - 1).to("cuda:0")
+        o2, r2, d2, _ = two.step(a)
+        twin.pre_physics_step(torch.clamp(a, -twin.clip_actions, twin.clip_actions))
+        twin.sim.simulate(); twin.sim.simulate()
+        twin.post_physics_step()
+        one.step(a)
+        assert torch.equal(o2["obs"], twin.obs_buf) and torch.equal(r2, twin.rew_buf) and torch.equal(d2, twin.reset_buf)
+    assert not torch.equal(two.obs_buf, one.obs_buf)
+    assert torch.equal(two.progress_buf, one.progress_buf) or (two.reset_buf != one.reset_buf).any()  # progress counts env steps, not simulate calls
+
+
+def test_setup_only_mass_randomisation_is_shard_invariant():
+    """rigid_body_properties.mass without a linear schedule is a real one-time draw (vec_task.py:505-725, `setup_only`): keyed by the
+    GLOBAL env id like every other per-env draw, so two shards of 64 envs hold the rows of one env of 128 (round 4 drew it from a torch
+    generator seeded with the shard offset)."""
+    import torch
+    from bez_isaacgym_amd import abi
+
+    def no_schedule(c):
+        m = c["task"]["randomization_params"]["actor_params"]["bez"]["rigid_body_properties"]["mass"]
+        m.pop("schedule", None); m.pop("schedule_steps", None)
+    whole = _kick_env(128, ["task.task.randomize=True"], mutate=no_schedule)
+    parts = [_kick_env(64, ["task.task.randomize=True"], env_id_offset=64 * k, mutate=no_schedule) for k in range(2)]
+    mw = whole.sim.get_env_params(abi.PARAM_MASS_SCALE)
+    mp = torch.cat([p.sim.get_env_params(abi.PARAM_MASS_SCALE) for p in parts])
+    assert torch.equal(mw, mp)
+    lo, hi = whole.cfg["task"]["randomization_params"]["actor_params"]["bez"]["rigid_body_properties"]["mass"]["range"]
+    assert float(mw.min()) >= lo and float(mw.max()) <= hi and float(mw.std()) > 0.05 * (hi - lo)
+
+
+def test_agent_runs_eager_when_graph_replay_is_not_safe():
+    """Round-4 advisor finding (medium): `torch.cuda.init()` before `import bez_isaacgym_amd` leaves the HIP runtime's graph packet
+    capture on -- replayed kernels then run with clobbered arguments once enough eager launches happen in between.
+    The agent must not replay graphs in that state (hip_graphs: auto -> eager, with a warning), on the fused path too."""
+    import os, subprocess, sys
+    code = r'''
+import os, sys, warnings
+os.environ.pop("DEBUG_CLR_GRAPH_PACKET_CAPTURE", None)
+import torch
+torch.cuda.init(); torch.zeros(1, device="cuda:0")
+sys.path.insert(0, %r)
+import bez_isaacgym_amd
+assert not bez_isaacgym_amd.GRAPH_REPLAY_SAFE
+from tests.test_gpu_round2 import _agent
+with warnings.catch_warnings(record=True) as w:
+    warnings.simplefilter("always")
+    a = _agent(256, 2048)
+assert a.fused and not a.use_graphs, (a.fused, a.use_graphs)
+assert any("HIP graphs are OFF" in str(x.message) for x in w), [str(x.message)[:60] for x in w]
+a.obs = a.env_reset()
+for _ in range(4):
+    s = a.train_epoch()
+assert a._g_rollout is None and a._g_update is None
+import numpy as np
+assert np.isfinite([s["kl"], s["a_loss"], s["c_loss"]]).all()
+print("EAGER-OK")
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k != "DEBUG_CLR_GRAPH_PACKET_CAPTURE"}
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and "EAGER-OK" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
+
+
+def test_external_weight_writes_reach_the_mfma_kernels():
+    """Round-4 advisor finding: with the fused optimiser the fp16 working copy and the fragment-major copies are refreshed only when the
+    model's load_state_dict hook fires.  An in-place write to the fp32 master weights between epochs (p.mul_, an EMA tool, a late
+    broadcast) must reach the rollout's MFMA forward too: play_steps() notices it from the parameters' version counters (host only)."""
+    import torch
+    from tests.test_gpu_round2 import _agent
+    a = _agent(256, 2048, hip_graphs=False)
+    a.obs = a.env_reset()
+    a.train_epoch()
+    net = a.model.a2c_network
+    half_before = a._hflat.clone() if getattr(a, "_hflat", None) is not None else None
+    assert half_before is not None and a._copies_kept_current()
+    with torch.no_grad():
+        for p in a.model.parameters():
+            p.mul_(0.5)
+    a.play_steps()
+    assert not torch.equal(a._hflat, half_before)
+    for p16, p32 in zip(net._p16, net._p32):          # the fp16 working copy is the rounded master copy again
+        assert torch.equal(p16, p32.detach().half())
+
+
+def test_dr_hand_out_can_be_taken_back():
+    """bez_sim_dr_step_args / bez_sim_dr_prelaunch mark the coming step's randomisation as "done by the caller".  If the caller's launch
+    never runs, bez_sim_dr_cancel (also implied by set_randomization / seed) gives it back: the step after a cancelled hand-out equals the
+    step of a twin that never handed anything out, and a second hand-out is accepted again (round-4 advisor finding)."""
+    import torch
+    from bez_isaacgym_amd import abi
+    from bez_isaacgym_amd.sim import BezSim, BezSimError
+    from tests.test_gpu_round3 import _dr_cfg
+    n = 256
+    a, b = BezSim(abi.default_config(n, seed=9), 0), BezSim(abi.default_config(n, seed=9), 0)
+    for s in (a, b):
+        s.set_randomization(_dr_cfg(freq=1, sched=0))
+    act = torch.rand(n * 18, device=a.device) * 2 - 1
+    for t in range(6):
+        blob = a.dr_step_args()
+        assert blob is not None
+        with pytest.raises(BezSimError, match="already"):
+            a.dr_step_args()
+        a.dr_cancel()                      # ... the launch that should have carried `blob` failed
+        a.step(act); b.step(act)
+        torch.cuda.synchronize()
+        for p in (abi.PARAM_FRICTION, abi.PARAM_KP_SCALE, abi.PARAM_DOF_LOWER):
+            assert torch.equal(a.get_env_params(p), b.get_env_params(p)), (t, p)
+        assert torch.equal(a.tensor(abi.TENSOR_OBS), b.tensor(abi.TENSOR_OBS))
+        assert torch.equal(a.tensor(abi.TENSOR_RANDOMIZE_BUF), b.tensor(abi.TENSOR_RANDOMIZE_BUF))
+    a.dr_step_args(); a.seed(9)            # seeding voids a hand-out too
+    assert a.dr_step_args() is not None
