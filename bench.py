@@ -152,6 +152,56 @@ def wait_ranks(procs, timeout=1500.0, grace=10.0, poll=0.2):
     return rc
 
 
+MFMA_PEAK_TFLOPS = 2500.0      # MI355X_MICROARCH.md: dense fp16 / bf16 MFMA peak (the sparsity figure is twice that and never used)
+VALU_PEAK_GINST_S = 256 * 2 * 2.4  # wave64 vector instructions per second at peak: 256 CUs x 128 fp32 lanes = 2 per CU and clock, 2.4 GHz (= 157 TFLOP/s of FMAs)
+
+
+def profile_tag_for_this_build(num_envs):
+    """Tag ("r05") of the committed profile set whose PMC summary records THIS build's source hash and size, or None."""
+    import glob
+    from bez_isaacgym_amd.build import source_hash
+    cur = source_hash()
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")), reverse=True):
+        try:
+            d = json.load(open(path))
+            if d.get("source_hash") == cur and int(d["num_envs"]) == int(num_envs):
+                return os.path.basename(path)[:-len("_pmc_traffic.json")], d
+        except Exception:
+            continue
+    return None, None
+
+
+def ppo_roofline(agent, samples_per_s, num_envs):
+    """MFMA roofline of the PPO half of the metric.  Algorithmic flops per sample = 2 x MACs of the MLP x (1 rollout forward +
+    mini_epochs x (forward + input-gradient/weight-gradient backward = 3 passes)) -- SURVEY.md 8(d): 2 x 123 500 x 16 = 3.95 Mflop.
+    Per-kernel rows come from the committed rocprofv3 kernel stats of the SAME build (source hash recorded beside them), else None."""
+    import csv
+    net = agent.model.a2c_network
+    macs = sum(int(w.shape[0]) * int(w.shape[1]) for w in (p for n_, p in net.named_parameters() if p.dim() == 2))
+    bwd_macs = macs - int(next(p for n_, p in net.named_parameters() if p.dim() == 2).numel())   # no input gradient for the first layer
+    passes = 1 + 3 * agent.mini_epochs
+    fps = 2.0 * macs * passes
+    achieved = fps * samples_per_s / 1e12
+    out = {"bound": "mfma", "flops_per_sample": fps, "macs_per_forward": macs, "passes_per_sample": passes, "achieved": achieved,
+           "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_PEAK_TFLOPS, "kernels": None}
+    tag, _ = profile_tag_for_this_build(num_envs)
+    path = os.path.join(ROOT, "profiles", "%s_ppo_kernel_stats.csv" % tag) if tag else None
+    if path and os.path.exists(path):
+        mb = float(agent.minibatch_size)
+        flops = {"policy_forward_kernel<2": ("training forward", 2.0 * macs * mb), "policy_backward_kernel": ("loss + input-gradient chain", 2.0 * bwd_macs * mb),
+                 "wgrad_kernel": ("weight gradients (split-K)", 2.0 * macs * mb), "policy_forward_kernel<1": ("rollout forward", 2.0 * macs * float(agent.num_actors))}
+        rows = []
+        for r in csv.DictReader(open(path)):
+            for key, (what, fl) in flops.items():
+                if key in r["Name"]:
+                    us = float(r["AverageNs"]) * 1e-3
+                    rows.append({"kernel": what, "avg_us": us, "gflop_per_launch": fl / 1e9, "tflops": fl / (us * 1e-6) / 1e12,
+                                 "frac": fl / (us * 1e-6) / 1e12 / MFMA_PEAK_TFLOPS, "calls": int(r["Calls"])})
+        out["kernels"] = rows
+        out["kernels_source"] = "profiles/%s_ppo_kernel_stats.csv (rocprofv3 --kernel-trace --stats of this build: source hash matches profiles/%s_pmc_traffic.json)" % (tag, tag)
+    return out
+
+
 def ppo_leg(args, rank, local_rank, world, n):
     """bez_kick PPO training (BASELINE.json configs[2]: rl_games default MLP, horizon 32, minibatch 32768, 5 mini-epochs,
     AMP): samples/s = horizon * envs * GPUs / epoch wall time (rollout + update), max over ranks."""
@@ -192,11 +242,35 @@ def ppo_leg(args, rank, local_rank, world, n):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt, play = float(t[0]), float(t[1])
     samples = agent.batch_size * world * args.ppo_epochs
-    return {"metric": "PPO samples/s (rollout + update)", "value": samples / dt, "unit": "samples/s", "epochs": args.ppo_epochs,
-            "samples_per_epoch": agent.batch_size * world, "epoch_ms": dt / args.ppo_epochs * 1e3,
-            "rollout_share": play / dt, "dtype": "fp16 autocast (AMP, as bez_kickPPO.yaml mixed_precision) + f32 sim",
-            "randomize": bool(args.randomize), "hip_graphs": bool(agent.use_graphs),
-            "minibatch": agent.minibatch_size, "mini_epochs": agent.mini_epochs}
+    out = {"metric": "PPO samples/s (rollout + update)", "value": samples / dt, "unit": "samples/s", "epochs": args.ppo_epochs,
+           "samples_per_epoch": agent.batch_size * world, "epoch_ms": dt / args.ppo_epochs * 1e3,
+           "rollout_share": play / dt, "dtype": "fp16 autocast (AMP, as bez_kickPPO.yaml mixed_precision) + f32 sim",
+           "randomize": bool(args.randomize), "hip_graphs": bool(agent.use_graphs), "data_parallel_path": bool(agent._segmented),
+           "minibatch": agent.minibatch_size, "mini_epochs": agent.mini_epochs}
+    if rank == 0:
+        out["roofline"] = ppo_roofline(agent, samples / dt, n)
+    agent.release_env()
+    return out
+
+
+def dp_path_leg(args, local_rank, n):
+    """The data-parallel PPO code path on ONE GPU: a 1-rank RCCL process group + BEZ_PPO_FORCE_DIST=1, so the
+    epoch runs as every rank of an N-GPU job runs it -- rollout graph, dataset preparation around its two all-reduces, per optimiser step a
+    forward/backward graph, ONE real RCCL all-reduce of the flat gradient, the optimiser graph -- minus the wire time.  What it costs a rank
+    over the single-GPU path is `dp_path_epoch_ms - epoch_ms`."""
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", str(29500 + os.getpid() % 2000))
+    os.environ["BEZ_PPO_FORCE_DIST"] = "1"
+    import torch
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
+    try:
+        r = ppo_leg(args, 0, local_rank, 1, n)
+    finally:
+        dist.destroy_process_group()
+        os.environ.pop("BEZ_PPO_FORCE_DIST", None)
+    return {"dp_path_epoch_ms": r["epoch_ms"], "dp_path_samples_per_s": r["value"], "dp_path_rollout_share": r["rollout_share"],
+            "dp_path_what": "1-rank RCCL group, BEZ_PPO_FORCE_DIST=1: segmented graphs + %d real all-reduce calls per epoch, no wire time" % (r["mini_epochs"] * (131072 // r["minibatch"] if r["minibatch"] else 0) + 2)}
 
 
 def stub_main(args, rank, world):
@@ -249,6 +323,8 @@ def main():
     ap.add_argument("--keep-aux", action="store_true", help="keep NET_CONTACT_FORCE / FEET / PREV_LIN_VEL current every step (no BEZ_FLAG_LEAN_STEP)")
     ap.add_argument("--no-full-store", action="store_true", help="skip the side measurement of the full-store (non-lean) step: profiler passes "
                     "that average a counter over every dispatch of the step kernel want the headline configuration only")
+    ap.add_argument("--dp-path", action="store_true", help="N = 1 only: time the PPO leg a second time on the data-parallel code path (1-rank RCCL group, "
+                    "BEZ_PPO_FORCE_DIST=1) and report ppo.dp_path_epoch_ms beside ppo.epoch_ms")
     ap.add_argument("--randomize", action="store_true", help="PPO leg with task.randomize=True (BASELINE.json configs[4]: domain-randomised "
                     "friction / gains / limits / gravity + observation and action noise, redrawn on the device at reset time)")
     ap.add_argument("--stub-cpu", action="store_true", help="launcher self-test: gloo on the CPU, the env step replaced by a no-op "
@@ -334,18 +410,27 @@ def main():
 
     # the C ABI's default keeps every Isaac-visible tensor current (no BEZ_FLAG_LEAN_STEP): the same build's full-store step,
     # timed beside the headline so that the difference is on record
-    other = BezSim(abi.default_config(n, seed=42, env_id_offset=rank * n), local_rank) if not (args.keep_aux or args.no_full_store) else None
-    full_store_ms = None
-    if other is not None:
+    other = None
+    full_store_ms = lean_event_ms = None
+    if not (args.keep_aux or args.no_full_store):
+        ocfg = abi.default_config(n, seed=42, env_id_offset=rank * n)
+        ocfg.flags = int(cfg.flags) & ~abi.FLAG_LEAN_STEP      # the headline sim's configuration, minus the lean flag
+        other = BezSim(ocfg, local_rank)
         for t in range(50):
             other.step(actions[t % ACTION_RING])
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for t in range(400):
-            other.step(actions[t % ACTION_RING])
-        e1.record()
-        torch.cuda.synchronize()
-        full_store_ms = e0.elapsed_time(e1) / 400
+        # both sims timed the SAME way in the same region (round-4 advisor finding: an event-timed figure beside a wall-clock one says
+        # nothing): event pairs over 100-step blocks, lean / full interleaved, four blocks each
+        acc = {"lean": 0.0, "full": 0.0}
+        for blk in range(4):
+            for name, s_ in (("lean", sim), ("full", other)):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for t in range(100):
+                    s_.step(actions[(blk * 100 + t) % ACTION_RING])
+                e1.record()
+                torch.cuda.synchronize()
+                acc[name] += e0.elapsed_time(e1)
+        lean_event_ms, full_store_ms = acc["lean"] / 400, acc["full"] / 400
         other.close()
 
     collective = None
@@ -362,12 +447,25 @@ def main():
     ppo = None
     if args.ppo_epochs > 0:
         ppo = ppo_leg(args, rank, local_rank, world, n)
+        if args.dp_path and world == 1:
+            ppo.update(dp_path_leg(args, local_rank, n))
+            ppo["dp_path_overhead"] = ppo["dp_path_epoch_ms"] / ppo["epoch_ms"] - 1.0
 
     if rank == 0:
         total_envs = n * world
         kernel_ms = dev_ms / args.steps  # avg device time per fused-step launch over the timed region (HIP events)
         traffic, traffic_src = pmc_traffic(n)
         achieved = ALGO_BYTES_PER_ENV_STEP * n / (kernel_ms * 1e-3) / 1e9
+        # "also report FP32 VALU fraction" -- wave-level vector instructions per launch (SQ_INSTS_VALU of the hash-matched
+        # PMC profile) over this run's kernel time, against the chip's vector issue peak
+        valu = None
+        _tag, _pmc = profile_tag_for_this_build(n)
+        if _pmc is not None and "sq_counters_per_launch" in _pmc:
+            vi = float(_pmc["sq_counters_per_launch"]["SQ_INSTS_VALU"])
+            ginst = vi / (kernel_ms * 1e-3) / 1e9
+            valu = {"insts_per_launch": vi, "achieved": ginst, "peak": VALU_PEAK_GINST_S, "unit": "G wave-instructions/s", "frac": ginst / VALU_PEAK_GINST_S,
+                    "waves": _pmc["sq_counters_per_launch"].get("SQ_WAVES"), "wait_share": float(_pmc["sq_counters_per_launch"]["SQ_WAIT_ANY"]) / float(_pmc["sq_counters_per_launch"]["SQ_WAVE_CYCLES"]),
+                    "source": "profiles/%s_pmc_traffic.json" % _tag}
         out = {
             "metric": "env-steps/s at num_envs=4096 (random-action rollout, bez_kick)",
             "value": total_envs * args.steps / elapsed,
@@ -385,9 +483,10 @@ def main():
             "config": {"workload": "bez_kick num_envs=%d per GPU, random-action rollout only (no PPO), dt=1/60 s x 2 substeps, "
                                    "natural resets included" % n,
                        "envs_per_gpu": n, "total_envs": total_envs, "launch": args.launch, "parallelism": "env-sharded x%d" % world,
-                       "lean_step": not args.keep_aux, "full_store_step_ms": full_store_ms},
+                       "lean_step": not args.keep_aux, "full_store_step_ms": full_store_ms, "lean_event_ms": lean_event_ms,
+                       "lean_vs_full_what": "HIP event pairs over 4 x 100-step blocks each, interleaved, after the timed region (device time; the headline ms_per_step is wall clock)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "valu_frac": None if valu is None else valu["frac"], "valu": valu,
                          "kernel": "bez::w8::step_kernel_ws8<true,true,false,false> (fused control step, default asset, 8 role waves per 64 envs)", "kernel_ms": kernel_ms,
                          "algorithmic_bytes_per_launch": ALGO_BYTES_PER_ENV_STEP * n,
                          "traffic_unit": "bytes per launch (rocprofv3 FETCH_SIZE: instruction stream x1 + data x2, + WRITE_SIZE; source: profiles/%s)" % traffic_src

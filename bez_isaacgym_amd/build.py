@@ -35,7 +35,9 @@ def source_hash():
 
 
 def lib_path():
-    return OUT
+    """The in-tree library -- or, for same-box A/B measurements of library variants (tools/ppo_ab.sh, tools/ab_bench.py), the file BEZ_SIM_LIB
+    names: the tree is never overwritten by an experiment (round-4 advisor finding)."""
+    return os.environ.get("BEZ_SIM_LIB") or OUT
 
 
 def needs_build():
@@ -52,6 +54,8 @@ def build(force=False, verbose=False):
     import fcntl
     import shutil
     import tempfile
+    if os.environ.get("BEZ_SIM_LIB"):
+        return os.environ["BEZ_SIM_LIB"]   # an explicitly named variant is used as it is
     if not force and not needs_build():
         return OUT
     os.makedirs(os.path.dirname(OUT), exist_ok=True)

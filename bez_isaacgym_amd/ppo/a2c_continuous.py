@@ -317,6 +317,9 @@ class A2CAgent:
         self.cfg, self.params = c, params
         self.vec_env, self.device = vec_env, torch.device(device)
         self.rank, self.world = rank, world
+        # data parallel (more than one rank, or BEZ_PPO_FORCE_DIST=1 on a 1-rank group: the same code path with real RCCL calls on a
+        # 1-GPU box -- tests, `bench.py --dp-path`): HIP graphs are captured in segments with the collectives between the replays
+        self._segmented = bool(world > 1 or _dist_on())
         self.num_actors = int(c["num_actors"])
         self.horizon = int(c["horizon_length"])
         self.gamma, self.tau = float(c["gamma"]), float(c["tau"])
@@ -468,7 +471,7 @@ class A2CAgent:
                     # ... and the input-gradient chain of the minibatch backward pass as one kernel on transposed copies
                     if (hflat is not None and c.get("fused_policy_backward", True) and all(32 <= w.shape[0] <= 416 and w.shape[0] % 2 == 0 for w, _ in wb[:nh])):
                         self._policy_bwd = F.PolicyBackward(hflat, layout, act_dim, self._packed)
-        if world > 1 and not self.fused:
+        if self._segmented and not self.fused:
             self.use_graphs = False  # the plain torch path has collectives in the middle of autograd-heavy code: eager only
         self._seg = None  # segmented graphs of the data-parallel update
         if _dist_on():  # identical replicas (hvd.broadcast_parameters equivalent)
@@ -816,7 +819,7 @@ class A2CAgent:
         self._refresh_weight_copies_if_dirty()
         if self._g_rollout is not None and self._lean_env is not None and not getattr(self._lean_env, "_lean", True):
             self._lean_env.set_lean(True)       # the captured rollout steps lean whatever release_env() set in between
-        if self.use_graphs and self.world > 1 and self._eager_epochs >= self.graph_warmup_epochs:
+        if self.use_graphs and self._segmented and self._eager_epochs >= self.graph_warmup_epochs:
             # data parallel: the horizon loop has no collective and is replayed; GAE + dataset (two all-reduces) stay eager
             if self._g_rollout is None:
                 torch.cuda.synchronize()
@@ -1246,7 +1249,7 @@ class A2CAgent:
                 self.scheduler.update_(self.lr_t, self.kl_acc[ep])
 
     def run_update(self):
-        if self.use_graphs and self.world > 1 and self._eager_epochs >= self.graph_warmup_epochs:
+        if self.use_graphs and self._segmented and self._eager_epochs >= self.graph_warmup_epochs:
             return self._update_segmented()
         if not self.use_graphs or self._eager_epochs < self.graph_warmup_epochs:
             self._update_impl()

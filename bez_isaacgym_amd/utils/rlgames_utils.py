@@ -73,6 +73,8 @@ class RLGPUAlgoObserver:
         mean = row.get("mean_reward")
         out = dict(row)
         if mean is not None and mean == mean:
-            out.update({"scores/mean": mean, "scores/iter": mean, "scores/time": mean})
+            # rlgames_utils.py:150-153: add_scalar('scores/mean', m, frame), ('scores/iter', m, epoch_num), ('scores/time', m, total_time) --
+            # one value under three tags that differ by their STEP axis; a line-oriented log keeps (value, step) per tag
+            out["scalars"] = {"scores/mean": [mean, row.get("frame")], "scores/iter": [mean, row.get("epoch")], "scores/time": [mean, row.get("time")]}
         self.f.write(json.dumps(out) + "\n")
         self.f.flush()

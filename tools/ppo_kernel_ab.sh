@@ -3,12 +3,10 @@
 # usage: bash tools/ppo_kernel_ab.sh a b ...
 set -e
 export TMPDIR=/tmp
-L=bez_isaacgym_amd/lib/libbez_sim.so
-cp $L /tmp/libbez_sim.keep
 for n in "$@"; do
-  cp build_ab/$n.so $L
+  export BEZ_SIM_LIB=$PWD/build_ab/$n.so   # (selected by environment: the in-tree library is never overwritten)
   rm -rf gpurun_out/kab_$n
-  rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/kab_$n -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --ppo-epochs 10 > gpurun_out/kab_$n.log 2>&1
+  rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/kab_$n -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --ppo-epochs ${PPO_AB_EPOCHS:-10} > gpurun_out/kab_$n.log 2>&1
   echo "== $n"
   python3 - "$n" <<'PY'
 import csv, glob, sys
@@ -20,5 +18,4 @@ for r in rows:
         print("%-90s calls %6s avg %9.2f us" % (name[:90], r["Calls"], float(r["AverageNs"]) / 1e3))
 PY
 done
-cp /tmp/libbez_sim.keep $L
 find gpurun_out -name "*agent_info.csv" -delete; find gpurun_out -name "*kernel_trace.csv" -path "*kab_*" -delete

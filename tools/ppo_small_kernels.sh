@@ -4,11 +4,13 @@ set -e
 export TMPDIR=/tmp
 rm -rf gpurun_out/small
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/small -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --ppo-epochs 10 > gpurun_out/small.log 2>&1
+export SMALL_EPOCHS=$(python3 -c "import json; d=json.loads(open('gpurun_out/small.log').read().strip().splitlines()[-1]); print(d['ppo']['epochs'] + 4)")
 python3 - <<'PY'
 import csv, glob
 f = glob.glob("gpurun_out/small/**/*kernel_stats.csv", recursive=True)[0]
 rows = list(csv.DictReader(open(f)))
-ep = 14.0   # 10 timed + 4 warm-up / capture epochs
+import os
+ep = float(os.environ.get('SMALL_EPOCHS', 14))   # timed epochs (from the bench line) + 4 warm-up / capture epochs
 tot = 0
 for r in sorted(rows, key=lambda r: -float(r["TotalDurationNs"])):
     n = r["Name"]
