@@ -515,20 +515,36 @@ __global__ __launch_bounds__(PPO_TB) void prep_values_kernel(const float* __rest
     partial[2 * blockIdx.x] = t1; partial[2 * blockIdx.x + 1] = t2;
   }
 }
+// data parallel: the rank's (sum adv, sum adv^2, count) from the per-workgroup partials, in the order prep_advantage_kernel adds them
+__global__ __launch_bounds__(PPO_TB) void prep_adv_sums_kernel(const double* __restrict__ partial, int nparts, long long total, double* __restrict__ out) {
+  __shared__ double sh[2][PPO_TB];
+  double a1 = 0.0, a2 = 0.0;
+  for (int q = threadIdx.x; q < nparts; q += PPO_TB) { a1 += partial[2 * q]; a2 += partial[2 * q + 1]; }
+  sh[0][threadIdx.x] = a1; sh[1][threadIdx.x] = a2;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t1 = 0.0, t2 = 0.0;
+    for (int q = 0; q < PPO_TB; ++q) { t1 += sh[0][q]; t2 += sh[1][q]; }
+    out[0] = t1; out[1] = t2; out[2] = (double)total;
+  }
+}
+// `global` (data parallel): (sum adv, sum adv^2, count) of the WHOLE job's batch, all-reduced; NULL: this launch adds the partials itself
 __global__ __launch_bounds__(PPO_TB) void prep_advantage_kernel(float* __restrict__ adv, long long total, const double* __restrict__ partial, int nparts, int normalize,
                                                                 double* __restrict__ vmean, double* __restrict__ vvar, double* __restrict__ vcount,
-                                                                const double* __restrict__ val_mom, const double* __restrict__ ret_mom) {
+                                                                const double* __restrict__ val_mom, const double* __restrict__ ret_mom,
+                                                                const double* __restrict__ global) {
   __shared__ double sh[2][PPO_TB];
   __shared__ float ms[2];
   if (normalize) {
     double a1 = 0.0, a2 = 0.0;
-    for (int q = threadIdx.x; q < nparts; q += PPO_TB) { a1 += partial[2 * q]; a2 += partial[2 * q + 1]; }
+    if (!global) for (int q = threadIdx.x; q < nparts; q += PPO_TB) { a1 += partial[2 * q]; a2 += partial[2 * q + 1]; }
     sh[0][threadIdx.x] = a1; sh[1][threadIdx.x] = a2;
     __syncthreads();
     if (threadIdx.x == 0) {
       double t1 = 0.0, t2 = 0.0;
-      for (int q = 0; q < PPO_TB; ++q) { t1 += sh[0][q]; t2 += sh[1][q]; }
-      const double n = (double)total, mean = t1 / n;
+      if (global) { t1 = global[0]; t2 = global[1]; }
+      else for (int q = 0; q < PPO_TB; ++q) { t1 += sh[0][q]; t2 += sh[1][q]; }
+      const double n = global ? global[2] : (double)total, mean = t1 / n;
       double var = (t2 - t1 * mean) / (n - 1.0 > 1.0 ? n - 1.0 : 1.0);   // unbiased, as torch.std
       if (var < 0.0) var = 0.0;
       ms[0] = (float)mean; ms[1] = (float)sqrt(var);
@@ -564,7 +580,36 @@ __global__ __launch_bounds__(PPO_TB) void prep_advantage_kernel(float* __restric
 //            launch reads: one launch less in front of the next forward pass.
 constexpr int ADAM_TB = 1024;
 struct AdamTail { float* dst[4]; const float* src[4]; float scale[4]; int n; float* lr; const float* kl; float kl_thr, min_lr, max_lr; };
+// data parallel: per-workgroup (sum g^2, non-finite count) of the all-reduced, still scaled gradient -- the shares bez_ppo_grad_reduce_all leaves
+// on one rank.  Workgroup b owns the float4s b * 1024 + t (+ a tail workgroup for n % 4); wave butterfly, 16 wave sums added in order.
+__global__ __launch_bounds__(1024) void grad_norm_parts_kernel(const float* __restrict__ g, int64_t n, float* __restrict__ parts) {
+  __shared__ float red[2][16];
+  const int tid = threadIdx.x;
+  const int64_t n4 = n >> 2, i = (int64_t)blockIdx.x * 1024 + tid;
+  float s2 = 0.f, bad = 0.f;
+  if (i < n4) {
+    const float4 x = reinterpret_cast<const float4*>(g)[i];
+    bad = (fabsf(x.x) <= 3.4028234e38f ? 0.f : 1.f) + (fabsf(x.y) <= 3.4028234e38f ? 0.f : 1.f) + (fabsf(x.z) <= 3.4028234e38f ? 0.f : 1.f) +
+          (fabsf(x.w) <= 3.4028234e38f ? 0.f : 1.f);
+    s2 = fmaf(x.x, x.x, s2); s2 = fmaf(x.y, x.y, s2); s2 = fmaf(x.z, x.z, s2); s2 = fmaf(x.w, x.w, s2);
+  } else if (i - n4 < (n & 3)) {      // the last n % 4 elements, one thread each
+    const float a = g[(n4 << 2) + (i - n4)];
+    bad = fabsf(a) <= 3.4028234e38f ? 0.f : 1.f;
+    s2 = a * a;
+  }
+  s2 = wave_sum(s2); bad = wave_sum(bad);
+  if ((tid & 63) == 0) { red[0][tid >> 6] = s2; red[1][tid >> 6] = bad; }
+  __syncthreads();
+  if (tid == 0) {
+    float a = 0.f, b = 0.f;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) { a += red[0][w]; b += red[1][w]; }
+    parts[2 * blockIdx.x] = a; parts[2 * blockIdx.x + 1] = b;
+  }
+}
+
 struct AdamExtra {
+  float grad_div;                                                       // the buffer holds the sum over this many ranks (0 / 1: it is the gradient)
   const float* normpart; int nnormpart;                                 // per-block (sum g^2, non-finite count) of the scaled gradient (NULL: phase 1 reads the gradient)
   const int32_t* map_a; const int32_t* map_b; __half* packed;          // fragment-major weight copies (NULL: none)
   const double* rms_mom; int rms_d; double* rms_mean; double* rms_var; double* rms_count;  // next normaliser update (NULL: none)
@@ -596,7 +641,7 @@ __global__ __launch_bounds__(ADAM_TB) void adam_fused_kernel(float* __restrict__
     ia[k] = (in && ex.packed) ? ex.map_a[i] : -1; ib[k] = (in && ex.packed) ? ex.map_b[i] : -1;
   }
   // ---- phase 1
-  const float inv = 1.0f / scale_v;
+  const float inv = 1.0f / (ex.grad_div > 1.0f ? scale_v * ex.grad_div : scale_v);
   float s2 = 0.f, bad = 0.f;
   if (ex.normpart) {   // the producer of the gradient (bez_ppo_grad_reduce_all) left per-block shares of sum g^2 (scaled) and of the non-finite count
     for (int i = tid; i < ex.nnormpart; i += ADAM_TB) { const float2 q = reinterpret_cast<const float2*>(ex.normpart)[i]; s2 += q.x; bad += q.y; }
@@ -883,14 +928,16 @@ int bez_ppo_gae(const float* rewards_dev, const float* values_dev, const float* 
   return launch_ok();
 }
 
-int bez_ppo_dataset_prep(const float* obs_dev, int64_t minibatch_rows, int32_t num_minibatches, int32_t num_obs, double* obs_moments_dev,
-                         const float* values_dev, const float* returns_dev, int32_t horizon, int64_t num_envs, double* value_mean_dev, double* value_var_dev,
-                         double* value_count_dev, float value_eps, double* value_moments_dev, double* return_moments_dev, float* old_values_dev,
-                         float* ds_returns_dev, float* advantages_dev, int32_t normalize_advantage, double* scratch_dev, int64_t scratch_doubles, void* stream) {
+int bez_ppo_dataset_prep_staged(int32_t stages, const float* obs_dev, int64_t minibatch_rows, int32_t num_minibatches, int32_t num_obs,
+                                double* obs_moments_dev, const float* values_dev, const float* returns_dev, int32_t horizon, int64_t num_envs,
+                                double* value_mean_dev, double* value_var_dev, double* value_count_dev, float value_eps, double* value_moments_dev,
+                                double* return_moments_dev, float* old_values_dev, float* ds_returns_dev, float* advantages_dev,
+                                int32_t normalize_advantage, double* adv_sums_dev, double* scratch_dev, int64_t scratch_doubles, void* stream) {
   const int64_t total = (int64_t)horizon * num_envs;
   if (!values_dev || !returns_dev || horizon <= 0 || num_envs <= 0 || !value_moments_dev || !return_moments_dev || !old_values_dev || !ds_returns_dev ||
       !advantages_dev || !scratch_dev || (value_mean_dev && (!value_var_dev || !value_count_dev)) || num_minibatches < 0 || num_minibatches > PREP_MAXT - 2 ||
       (num_minibatches > 0 && (!obs_dev || !obs_moments_dev || minibatch_rows <= 0 || num_obs <= 0 || num_obs > 64))) return -1;
+  if (stages <= 0 || stages > 7 || (stages != 7 && !adv_sums_dev)) return -1;   // a split needs the buffer the second collective reduces
   if (total % 64 != 0) return -3;   // the scalar tasks are read as (total / 64, 64): the caller keeps its separate launches
   hipStream_t st = (hipStream_t)stream;
   PrepTasks T;
@@ -907,14 +954,30 @@ int bez_ppo_dataset_prep(const float* obs_dev, int64_t minibatch_rows, int32_t n
   const unsigned nvb = nblk(total);
   if ((int64_t)T.n * g * 128 + 2 * (int64_t)nvb > scratch_doubles) return -1;
   double* partial = scratch_dev + (size_t)T.n * g * 128;
-  hipLaunchKernelGGL(prep_moments_kernel, dim3(g, (unsigned)T.n), dim3(PPO_TB), 0, st, T, scratch_dev);
-  hipLaunchKernelGGL(prep_reduce_kernel, dim3((unsigned)T.n), dim3(1024), 0, st, T, (const double*)scratch_dev, (int)g, (int)num_minibatches);
-  hipLaunchKernelGGL(prep_values_kernel, dim3(nvb), dim3(PPO_TB), 0, st, values_dev, returns_dev, (int)horizon, (long long)num_envs, (const double*)value_mean_dev,
-                     (const double*)value_var_dev, (const double*)value_count_dev, value_eps, (const double*)value_moments_dev, (const double*)return_moments_dev,
-                     old_values_dev, ds_returns_dev, advantages_dev, partial);
-  hipLaunchKernelGGL(prep_advantage_kernel, dim3(nvb), dim3(PPO_TB), 0, st, advantages_dev, (long long)total, (const double*)partial, (int)nvb,
-                     (int)(normalize_advantage != 0), value_mean_dev, value_var_dev, value_count_dev, (const double*)value_moments_dev, (const double*)return_moments_dev);
+  if (stages & 1) {
+    hipLaunchKernelGGL(prep_moments_kernel, dim3(g, (unsigned)T.n), dim3(PPO_TB), 0, st, T, scratch_dev);
+    hipLaunchKernelGGL(prep_reduce_kernel, dim3((unsigned)T.n), dim3(1024), 0, st, T, (const double*)scratch_dev, (int)g, (int)num_minibatches);
+  }
+  if (stages & 2) {
+    hipLaunchKernelGGL(prep_values_kernel, dim3(nvb), dim3(PPO_TB), 0, st, values_dev, returns_dev, (int)horizon, (long long)num_envs, (const double*)value_mean_dev,
+                       (const double*)value_var_dev, (const double*)value_count_dev, value_eps, (const double*)value_moments_dev, (const double*)return_moments_dev,
+                       old_values_dev, ds_returns_dev, advantages_dev, partial);
+    if (adv_sums_dev) hipLaunchKernelGGL(prep_adv_sums_kernel, dim3(1), dim3(PPO_TB), 0, st, (const double*)partial, (int)nvb, (long long)total, adv_sums_dev);
+  }
+  if (stages & 4)
+    hipLaunchKernelGGL(prep_advantage_kernel, dim3(nvb), dim3(PPO_TB), 0, st, advantages_dev, (long long)total, (const double*)partial, (int)nvb,
+                       (int)(normalize_advantage != 0), value_mean_dev, value_var_dev, value_count_dev, (const double*)value_moments_dev, (const double*)return_moments_dev,
+                       (const double*)adv_sums_dev);
   return launch_ok();
+}
+
+int bez_ppo_dataset_prep(const float* obs_dev, int64_t minibatch_rows, int32_t num_minibatches, int32_t num_obs, double* obs_moments_dev,
+                         const float* values_dev, const float* returns_dev, int32_t horizon, int64_t num_envs, double* value_mean_dev, double* value_var_dev,
+                         double* value_count_dev, float value_eps, double* value_moments_dev, double* return_moments_dev, float* old_values_dev,
+                         float* ds_returns_dev, float* advantages_dev, int32_t normalize_advantage, double* scratch_dev, int64_t scratch_doubles, void* stream) {
+  return bez_ppo_dataset_prep_staged(7, obs_dev, minibatch_rows, num_minibatches, num_obs, obs_moments_dev, values_dev, returns_dev, horizon, num_envs, value_mean_dev,
+                                     value_var_dev, value_count_dev, value_eps, value_moments_dev, return_moments_dev, old_values_dev, ds_returns_dev, advantages_dev,
+                                     normalize_advantage, nullptr, scratch_dev, scratch_doubles, stream);
 }
 
 int bez_ppo_head_grads_f16(const float* grad_mu_dev, const float* grad_value_dev, int64_t rows, int32_t num_actions, void* grad_mu_f16_dev,
@@ -925,6 +988,16 @@ int bez_ppo_head_grads_f16(const float* grad_mu_dev, const float* grad_value_dev
   hipLaunchKernelGGL(head_grads_kernel, dim3((unsigned)((rows + rpb - 1) / rpb)), dim3(PPO_TB), 0, (hipStream_t)stream, grad_mu_dev, grad_value_dev, rows,
                      (int)num_actions, (__half*)grad_mu_f16_dev, (__half*)grad_value_f16_dev, mu_bias_grad_dev, value_bias_grad_dev, rpb);
   return launch_ok();
+}
+
+int bez_ppo_grad_norm_parts(const float* grads_dev, int64_t n, float* parts_dev, int32_t parts, void* stream) {
+  if (!grads_dev || !parts_dev || n <= 0 || (reinterpret_cast<uintptr_t>(grads_dev) & 15) != 0) return -1;
+  const int64_t units = (n >> 2) + (n & 3);
+  const int64_t g = (units + 1023) / 1024;
+  if (g > parts) return -1;
+  hipLaunchKernelGGL(grad_norm_parts_kernel, dim3((unsigned)g), dim3(1024), 0, (hipStream_t)stream, grads_dev, n, parts_dev);
+  const int rc = launch_ok();
+  return rc ? rc : (int)g;
 }
 
 int bez_ppo_adam_step(float* params_dev, const float* grads_dev, float* exp_avg_dev, float* exp_avg_sq_dev, int64_t n, float* steps_dev,
@@ -948,7 +1021,7 @@ int bez_ppo_adam_step(float* params_dev, const float* grads_dev, float* exp_avg_
     if (extra->packed_f16_dev && (!extra->map_a_dev || !extra->map_b_dev || !params_f16_dev)) return -1;
     if (extra->rms_moments_dev && (!extra->rms_mean_dev || !extra->rms_var_dev || !extra->rms_count_dev || extra->rms_cols <= 0 || extra->rms_cols > ADAM_TB)) return -1;
     if (extra->norm_parts_dev && (extra->norm_parts <= 0 || (reinterpret_cast<uintptr_t>(extra->norm_parts_dev) & 7) != 0)) return -1;
-    ex.normpart = extra->norm_parts_dev; ex.nnormpart = extra->norm_parts;
+    ex.normpart = extra->norm_parts_dev; ex.nnormpart = extra->norm_parts; ex.grad_div = extra->grad_div;
     ex.map_a = extra->map_a_dev; ex.map_b = extra->map_b_dev; ex.packed = (__half*)extra->packed_f16_dev;
     ex.rms_mom = extra->rms_moments_dev; ex.rms_d = extra->rms_cols; ex.rms_mean = extra->rms_mean_dev; ex.rms_var = extra->rms_var_dev; ex.rms_count = extra->rms_count_dev;
   }

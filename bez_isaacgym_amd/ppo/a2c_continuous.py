@@ -712,7 +712,7 @@ class A2CAgent:
         if not aliased:
             ds["obs"].copy_(swap_and_flatten01(mb["obs"]))
         fused_v = self.normalize_value and self.fused and getattr(self, "_f_val_rms", None) is not None
-        if (self.fused and self._policy_fwd is not None and not _dist_on() and self.normalize_input and (fused_v or not self.normalize_value)
+        if (self.fused and self._policy_fwd is not None and self.normalize_input and (fused_v or not self.normalize_value)
                 and self.cfg.get("fused_dataset_prep", True)):
             # one rank: everything from here to the dataset's old_values / returns / advantages -- the per-minibatch observation moments, the
             # value / return moments, both value-normaliser updates, the two normalisations, the advantage and its normalisation, the
@@ -721,9 +721,24 @@ class A2CAgent:
             if sc is None:
                 assert not torch.cuda.is_current_stream_capturing()
                 sc = self._prep_scratch = self._F.dataset_prep_scratch(self.num_minibatches, self.horizon, self.num_actors, dev)
-            if self._F.dataset_prep(ds["obs"], self.minibatch_size, self.num_minibatches, self._obs_mom, mb["val"], fx["rets"],
-                                    self.value_mean_std if fused_v else None, self._val_mom, self._ret_mom, ds["old_values"], ds["returns"],
-                                    ds["advantages"], self.normalize_advantage, sc):
+            prep = lambda stages, sums=None: self._F.dataset_prep(ds["obs"], self.minibatch_size, self.num_minibatches, self._obs_mom, mb["val"], fx["rets"],
+                                                                  self.value_mean_std if fused_v else None, self._val_mom, self._ret_mom, ds["old_values"],
+                                                                  ds["returns"], ds["advantages"], self.normalize_advantage, sc, stages=stages, adv_sums=sums)
+            if not _dist_on():
+                done = prep(7)
+            else:
+                # data parallel: the same launches with the epoch's two collectives between them (the moments are plain sums, so the
+                # all-reduced buffers hold the global batch's); the episode statistics ride in the second one
+                st = self._adv_pack
+                done = prep(1)
+                if done:
+                    dist.all_reduce(self._mom_pack)
+                    prep(2, st)
+                    st[3:6] = self.ep_stats
+                    dist.all_reduce(st)
+                    self.ep_stats.copy_(st[3:6])
+                    prep(4, st)
+            if done:
                 if not aliased:
                     ds["old_logp"].copy_(swap_and_flatten01(mb["neglogp"])); ds["actions"].copy_(swap_and_flatten01(mb["act"]))
                     ds["mu"].copy_(swap_and_flatten01(mb["mu"]))
@@ -1101,26 +1116,40 @@ class A2CAgent:
     def _phase_c(self, kl_out, loss_out, next_i=None):
         """next_i: row of the epoch's observation moments the NEXT minibatch step absorbs (None: that step applies them itself)"""
         fresh, self._norm_parts_fresh = getattr(self, "_norm_parts_fresh", False), False
+        wdiv = 1.0
         if _dist_on():
-            self._flat.div_(dist.get_world_size())  # mean of the (still scaled) gradients and of the KL
-            fresh = False                            # (the all-reduce changed the gradient: the optimiser launch forms the norm itself)
+            wdiv = float(dist.get_world_size())
+            fresh = False                            # (the all-reduce changed the gradient its producer left the norm shares for)
+            if not self._fused_opt:
+                self._flat.div_(wdiv)                # mean of the (still scaled) gradients and of the KL
         if self._fused_opt:
             g0 = self.optimizer.param_groups[0]
             amp = self.scaler.is_enabled()
             # (the epoch's KL / loss accumulators ride in the optimiser's last launch: the sums of the loss kernel -> means)
-            rows = float(self.minibatch_size)
+            # data parallel: the flat buffer holds the SUM over the ranks (gradient and statistics alike); the mean is never formed by a
+            # pass of its own -- the division rides in the optimiser launch's unscale factor, in the tail scales and in the KL threshold
+            rows = float(self.minibatch_size) * wdiv
             st = self._flat_stats
             tail = ((kl_out, st[3:4], 1.0 / (rows * self.num_minibatches)), (loss_out[0:1], st[0:1], 1.0 / rows), (loss_out[1:2], st[1:2], 1.0 / rows))
             # 'legacy' schedule: the lr moves after every step, in the same launch (the step's KL is a SUM over the rows: threshold scaled)
             sc = self.scheduler
             adapt = (self._flat_kl, sc.kl_threshold * rows, sc.min_lr, sc.max_lr) if self.is_adaptive_lr and self.schedule_type == "legacy" else None
+            parts = self._norm_parts if fresh else None
+            if wdiv != 1.0 or _dist_on():
+                # ... and the norm shares are re-formed from the all-reduced buffer by one small launch (every workgroup of the optimiser
+                # launch reading the whole gradient instead costs it 18 us against 9)
+                npd = getattr(self, "_norm_parts_dp", None)
+                if npd is None:
+                    assert not torch.cuda.is_current_stream_capturing()
+                    npd = self._norm_parts_dp = torch.zeros((self._nparam // 4 + 3 + 1023) // 1024 + 1, 2, device=self.device, dtype=torch.float32)
+                parts = self._F.grad_norm_parts(self._flat[:self._nparam], npd)
             self._F.adam_step(self._pflat, self._flat[:self._nparam], self._mflat, self._vflat, self._steps, self.lr_t, g0["betas"], g0["eps"],
                               g0["weight_decay"], self.grad_norm if self.truncate_grads else 0.0, self.scaler._scale if amp else None,
                               self.scaler._growth_tracker if amp else None, self.scaler.get_growth_factor(), self.scaler.get_backoff_factor(),
                               self.scaler.get_growth_interval(), self._opt_work, self._hflat, tail=tail, adapt=adapt,
                               packed=self._packed if (self._packed is not None and self._hflat is not None and not self._packed_stale) else None,
                               next_rms=(self._f_obs_rms, self._obs_mom[next_i]) if (next_i is not None and self.normalize_input) else None,
-                              norm_parts=self._norm_parts if fresh else None)
+                              norm_parts=parts, grad_div=wdiv)
             if next_i is not None and self.normalize_input:
                 self._rms_preapplied = True
             return
@@ -1219,34 +1248,49 @@ class A2CAgent:
                 self.scheduler.update_(self.lr_t, self.kl_acc[ep])
 
     def _update_segmented(self):
-        """Data-parallel update with HIP graphs: per minibatch a forward/backward graph, one shared optimiser graph; the step's ONE
-        RCCL all-reduce (gradient + KL) runs eagerly between the two replays (no collective is ever captured).
-        The first call captures the segments (capture records, it does not execute) and then replays them like every later call."""
+        """Data-parallel update with HIP graphs; the step's ONE RCCL all-reduce (gradient + KL) runs eagerly between replays (no collective is
+        ever captured).  Segments: the forward/backward half of a step ("B", per minibatch) and the optimiser half ("C") -- and because the C
+        of step s and the B of step s + 1 have no collective between them, they are ONE graph: an update of S steps is S + 1 replays
+        (B0 | CB ... CB | C) instead of 2 S, and the C inside a CB graph absorbs the next minibatch's observation moments as the one-rank
+        path's does.  The first call captures the segments (capture records, it does not execute) and then replays them like every later call."""
         self._rms_preapplied = False
+        nm = self.num_minibatches
         if self._seg is None:
             torch.cuda.synchronize()
-            seg = dict(b=[], c=torch.cuda.CUDAGraph(), kl=torch.zeros((), device=self.device))
-            for i in range(self.num_minibatches):
-                mb = self._minibatch(i)
+            seg = dict(b0=torch.cuda.CUDAGraph(), cb=[], c=torch.cuda.CUDAGraph(), kl=torch.zeros((), device=self.device))
+            with torch.cuda.graph(seg["b0"], pool=self._graph_pool()):
+                self._phase_b(self._minibatch(0))
+            for i in range(nm):
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g, pool=self._graph_pool()):
-                    self._phase_b(mb)
-                seg["b"].append(g)
+                    self._phase_c(seg["kl"], self.loss_acc, i)
+                    self._phase_b(self._minibatch(i))
+                seg["cb"].append(g)
             with torch.cuda.graph(seg["c"], pool=self._graph_pool()):
                 self._phase_c(seg["kl"], self.loss_acc)
+            self._rms_preapplied = False
             self._seg = seg
         seg = self._seg
         self.kl_acc.zero_(); self.loss_acc.zero_()
-        for ep in range(self.mini_epochs):
-            seg["kl"].zero_()
-            for i in range(self.num_minibatches):
-                seg["b"][i].replay()
-                if _dist_on():
-                    dist.all_reduce(self._flat)
-                seg["c"].replay()
+        seg["kl"].zero_()
+        steps = self.mini_epochs * nm
+
+        def close_mini_epoch(ep):   # the C that completed mini-epoch `ep` has just been replayed
             self.kl_acc[ep].copy_(seg["kl"])
+            seg["kl"].zero_()
             if self.is_adaptive_lr and self.schedule_type != "legacy":
                 self.scheduler.update_(self.lr_t, self.kl_acc[ep])
+        for s_ in range(steps):
+            if s_ == 0:
+                seg["b0"].replay()
+            else:
+                seg["cb"][s_ % nm].replay()
+                if s_ % nm == 0:
+                    close_mini_epoch(s_ // nm - 1)
+            if _dist_on():
+                dist.all_reduce(self._flat)
+        seg["c"].replay()
+        close_mini_epoch(self.mini_epochs - 1)
 
     def run_update(self):
         if self.use_graphs and self._segmented and self._eager_epochs >= self.graph_warmup_epochs:

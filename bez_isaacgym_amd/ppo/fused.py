@@ -29,6 +29,7 @@ _SIGS = {
     "bez_ppo_head_grads_f16": [_vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp],
     "bez_ppo_policy_backward_with_loss": [_vp, _i64, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp],
     "bez_ppo_dataset_prep": [_vp, _i64, _i32, _i32, _vp, _vp, _vp, _i32, _i64, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _i64, _vp],
+    "bez_ppo_dataset_prep_staged": [_i32, _vp, _i64, _i32, _i32, _vp, _vp, _vp, _i32, _i64, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _i64, _vp],
     "bez_ppo_wgrad_sum": [_vp, _i32, _i64, _vp, _i32, _vp],
     "bez_ppo_wgrad_plan": [_vp, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _vp, _vp],
     "bez_ppo_wgrad_run": [_vp, _vp, _i32, _vp],
@@ -37,9 +38,10 @@ _SIGS = {
     "bez_ppo_adam_step": [_vp, _vp, _vp, _vp, _i64, _vp, _i32, _vp, _f, _f, _f, _f, _f, _vp, _vp, _f, _f, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _f, _f, _f, _vp, _vp],
     "bez_ppo_grad_reduce_all": [_vp, _vp, _vp, _i64, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i32, _vp, _vp],
     "bez_ppo_grad_reduce_blocks": [_vp, _i32, _vp, _i32],
+    "bez_ppo_grad_norm_parts": [_vp, _i64, _vp, _i32, _vp],
 }
 _lib = None
-PPO_ABI_VERSION = 5   # BEZ_PPO_ABI_VERSION (include/bez_sim.h)
+PPO_ABI_VERSION = 6   # BEZ_PPO_ABI_VERSION (include/bez_sim.h)
 
 
 def lib():
@@ -197,18 +199,20 @@ ADAM_WORK_FLOATS = 258   # BEZ_PPO_ADAM_WORK_FLOATS
 
 
 def adam_step(params, grads, exp_avg, exp_avg_sq, steps, lr, betas, eps, weight_decay, max_norm, scale, growth_tracker, growth_factor,
-              backoff_factor, growth_interval, work, params_f16=None, tail=(), adapt=None, packed=None, next_rms=None, norm_parts=None):
+              backoff_factor, growth_interval, work, params_f16=None, tail=(), adapt=None, packed=None, next_rms=None, norm_parts=None, grad_div=1.0):
     """unscale + clip + Adam + scaler update on the flat buffers in ONE launch (csrc/bez_ppo.hip adam_fused_kernel); scale / growth_tracker
     None = no AMP; params_f16 (flat fp16, same layout) receives the updated parameters in the same pass.  `work` must be zero on entry and
     is zero again afterwards.  tail: up to 4 (dst, src, scale) with one-element fp32 tensors: dst += src * scale.
     adapt = (kl, threshold, min_lr, max_lr): the AdaptiveScheduler rule moves `lr` on that one-element KL after the step.
     packed (PackedWeights): its fragment-major copies are written in the same pass (instead of a refresh() launch before the next forward);
     next_rms = (FusedRunningMeanStd, moments): the input normaliser absorbs the NEXT minibatch's moments here (instead of an apply() launch);
-    norm_parts: the (blocks, 2) tensor grad_reduce_all() filled for THIS gradient (norm and non-finite count are then not re-derived)."""
+    norm_parts: the (blocks, 2) tensor grad_reduce_all() / grad_norm_parts() filled for THIS gradient (norm and non-finite count are then not
+    re-derived); grad_div: the buffer holds the all-reduced SUM over that many ranks (the division rides in the unscale factor)."""
     n = params.numel()
     extra = None
-    if packed is not None or next_rms is not None or norm_parts is not None:
+    if packed is not None or next_rms is not None or norm_parts is not None or grad_div != 1.0:
         extra = AdamExtra()
+        extra.grad_div = float(grad_div)
         if norm_parts is not None:
             assert norm_parts.dtype == torch.float32 and norm_parts.is_contiguous() and norm_parts.shape[1] == 2
             extra.norm_parts_dev, extra.norm_parts = norm_parts.data_ptr(), norm_parts.shape[0]
@@ -236,9 +240,19 @@ def adam_step(params, grads, exp_avg, exp_avg_sq, steps, lr, betas, eps, weight_
          "bez_ppo_adam_step")
 
 
+def grad_norm_parts(grads, parts):
+    """Per-workgroup (sum g^2, non-finite count) of the flat gradient `grads` into `parts` ((>= blocks, 2) fp32): what grad_reduce_all(norm_parts=)
+    leaves, re-formed after an all-reduce replaced the gradient.  Returns the view of the rows written (adam_step(norm_parts=))."""
+    assert parts.dtype == torch.float32 and parts.is_contiguous() and parts.dim() == 2 and parts.shape[1] == 2
+    rc = lib().bez_ppo_grad_norm_parts(_p(grads), grads.numel(), _p(parts), parts.shape[0], _stream(grads))
+    if rc <= 0:
+        raise RuntimeError("bez_ppo_grad_norm_parts failed (%d)" % rc)
+    return parts[:rc]
+
+
 class AdamExtra(C.Structure):
     """BezPpoAdamExtra (include/bez_sim.h)"""
-    _fields_ = [("norm_parts_dev", C.c_void_p), ("norm_parts", C.c_int32), ("map_a_dev", C.c_void_p), ("map_b_dev", C.c_void_p), ("packed_f16_dev", C.c_void_p), ("rms_moments_dev", C.c_void_p),
+    _fields_ = [("norm_parts_dev", C.c_void_p), ("norm_parts", C.c_int32), ("grad_div", C.c_float), ("map_a_dev", C.c_void_p), ("map_b_dev", C.c_void_p), ("packed_f16_dev", C.c_void_p), ("rms_moments_dev", C.c_void_p),
                 ("rms_cols", C.c_int32), ("rms_mean_dev", C.c_void_p), ("rms_var_dev", C.c_void_p), ("rms_count_dev", C.c_void_p)]
 
 
@@ -444,10 +458,12 @@ def dataset_prep_scratch(num_minibatches, horizon, num_envs, device):
 
 
 def dataset_prep(obs, minibatch_rows, num_minibatches, obs_moments, values, returns, value_rms, value_moments, return_moments, old_values, ds_returns,
-                 advantages, normalize_advantage, scratch):
+                 advantages, normalize_advantage, scratch, stages=7, adv_sums=None):
     """prepare_dataset + the per-minibatch observation moments in four launches (bez_ppo_dataset_prep).  obs: the dataset's (rows, D) fp32
     observations (None: no observation moments); values / returns (H, N[, 1]) fp32 in the rollout's layout; value_rms: the RunningMeanStd of
-    the values (None: values / returns are used as they are); outputs env-major (N * H[, 1]).  False: shapes the kernel does not take."""
+    the values (None: values / returns are used as they are); outputs env-major (N * H[, 1]).  False: shapes the kernel does not take.
+    stages / adv_sums (data parallel, bez_ppo_dataset_prep_staged): 1 = local moments, 2 = values / returns / advantages + adv_sums (3 fp64:
+    sum, sum of squares, count of this rank's advantages), 4 = advantage normalisation from adv_sums; the caller all-reduces between them."""
     h = values.shape[0]
     n = values.numel() // h
     assert returns.numel() == h * n and old_values.numel() == h * n and ds_returns.numel() == h * n and advantages.numel() == h * n
@@ -459,12 +475,14 @@ def dataset_prep(obs, minibatch_rows, num_minibatches, obs_moments, values, retu
     else:
         num_minibatches = 0
     r = value_rms
-    rc = lib().bez_ppo_dataset_prep(None if not num_minibatches else _p(obs), minibatch_rows, num_minibatches, d,
-                                    None if not num_minibatches else _p(obs_moments, torch.float64), _p(values), _p(returns), h, n,
-                                    None if r is None else _p(r.running_mean, torch.float64), None if r is None else _p(r.running_var, torch.float64),
-                                    None if r is None else _p(r.count.view(1), torch.float64), 0.0 if r is None else float(r.epsilon),
-                                    _p(value_moments, torch.float64), _p(return_moments, torch.float64), _p(old_values), _p(ds_returns), _p(advantages),
-                                    1 if normalize_advantage else 0, _p(scratch, torch.float64), scratch.numel(), _stream(values))
+    assert adv_sums is None or (adv_sums.is_contiguous() and adv_sums.numel() >= 3)
+    rc = lib().bez_ppo_dataset_prep_staged(int(stages), None if not num_minibatches else _p(obs), minibatch_rows, num_minibatches, d,
+                                           None if not num_minibatches else _p(obs_moments, torch.float64), _p(values), _p(returns), h, n,
+                                           None if r is None else _p(r.running_mean, torch.float64), None if r is None else _p(r.running_var, torch.float64),
+                                           None if r is None else _p(r.count.view(1), torch.float64), 0.0 if r is None else float(r.epsilon),
+                                           _p(value_moments, torch.float64), _p(return_moments, torch.float64), _p(old_values), _p(ds_returns), _p(advantages),
+                                           1 if normalize_advantage else 0, None if adv_sums is None else _p(adv_sums, torch.float64),
+                                           _p(scratch, torch.float64), scratch.numel(), _stream(values))
     if rc == -3:
         return False
     _chk(rc, "bez_ppo_dataset_prep")

@@ -318,7 +318,7 @@ int bez_sim_time_steps(BezSim* sim, const float* actions_dev, int32_t n_steps, v
 
 /* The signatures below change between rounds (round 3: scratch buffers of the fixed-order reductions, plan / run split of the weight
  * gradients, the optimiser tail's bookkeeping): a binding checks this number once after dlopen. */
-#define BEZ_PPO_ABI_VERSION 5
+#define BEZ_PPO_ABI_VERSION 6
 int32_t bez_ppo_abi_version(void);
 
 /* RunningMeanStd (normalize_input / normalize_value, bez_kickPPO.yaml:51-52): moments[0:D] = column sums, [D:2D] = sums of
@@ -517,6 +517,19 @@ int bez_ppo_dataset_prep(const float* obs_dev, int64_t minibatch_rows, int32_t n
                          double* value_count_dev, float value_eps, double* value_moments_dev, double* return_moments_dev, float* old_values_dev,
                          float* ds_returns_dev, float* advantages_dev, int32_t normalize_advantage, double* scratch_dev, int64_t scratch_doubles, void* stream);
 
+/* The same work in STAGES, for the data-parallel loop, whose two per-epoch collectives sit between them -- every moment above is
+ * a plain sum (sum x, sum x^2, count), so an all-reduce of the local moments yields the global batch's:
+ *   stage 1  the observation / value / return moments of THIS rank's rows                 (2 launches)   -> all-reduce of the moment buffers
+ *   stage 2  value-normaliser statistics from the (now global) moments, normalised values / returns, advantages, and adv_sums_dev[0..2] =
+ *            (sum adv, sum adv^2, count) of this rank's rows                              (2 launches)   -> all-reduce of adv_sums_dev
+ *   stage 4  advantage normalisation with the (now global) adv_sums_dev; commits the value normaliser's statistics       (1 launch)
+ * `stages` is a bit mask; 1 | 2 | 4 with adv_sums_dev == NULL is bez_ppo_dataset_prep.  The paths differ by the collectives only. */
+int bez_ppo_dataset_prep_staged(int32_t stages, const float* obs_dev, int64_t minibatch_rows, int32_t num_minibatches, int32_t num_obs,
+                                double* obs_moments_dev, const float* values_dev, const float* returns_dev, int32_t horizon, int64_t num_envs,
+                                double* value_mean_dev, double* value_var_dev, double* value_count_dev, float value_eps, double* value_moments_dev,
+                                double* return_moments_dev, float* old_values_dev, float* ds_returns_dev, float* advantages_dev,
+                                int32_t normalize_advantage, double* adv_sums_dev, double* scratch_dev, int64_t scratch_doubles, void* stream);
+
 /* The backward inputs of the two heads in one pass over the loss gradients (torch.autocast's cast nodes + the bias-gradient sums of
  * nn.Linear's backward): fp16 copies of d loss / d mu (rows, num_actions) and d loss / d value (rows, 1), and the column sums of those
  * fp16 values ADDED to the fp32 bias gradients of the mu and value heads. */
@@ -544,10 +557,16 @@ int bez_ppo_head_grads_f16(const float* grad_mu_dev, const float* grad_value_dev
  * does from rms_moments_dev (rms_cols <= 1024); (c) the squared norm and non-finite count taken from the per-workgroup shares the
  * gradient's producer left instead of reading the gradient once more in every workgroup. */
 typedef struct BezPpoAdamExtra {
-  const float* norm_parts_dev; int32_t norm_parts; /* (c) the norm_parts pairs bez_ppo_grad_reduce_all left (the gradient must not have changed since) */
+  const float* norm_parts_dev; int32_t norm_parts; /* (c) the norm_parts pairs bez_ppo_grad_reduce_all (or bez_ppo_grad_norm_parts) left for THIS gradient */
+  float grad_div;                                  /* data parallel: the gradient buffer holds the SUM over this many ranks (an all-reduce); 0 = 1.
+                                                      Folded into the unscale factor: no separate division pass over the buffer */
   const int32_t* map_a_dev; const int32_t* map_b_dev; void* packed_f16_dev;
   const double* rms_moments_dev; int32_t rms_cols; double* rms_mean_dev; double* rms_var_dev; double* rms_count_dev;
 } BezPpoAdamExtra;
+/* Data parallel: an all-reduce has replaced the gradient bez_ppo_grad_reduce_all left its norm shares for.  One small launch re-forms them
+ * (workgroup b: sum g^2 and non-finite count of its slice of the n-element buffer, fixed order) so that the optimiser launch reads `parts`
+ * pairs instead of the whole gradient in every workgroup.  parts_dev: 2 * parts floats; returns the number of pairs written (<= parts). */
+int bez_ppo_grad_norm_parts(const float* grads_dev, int64_t n, float* parts_dev, int32_t parts, void* stream);
 #define BEZ_PPO_ADAM_WORK_FLOATS 258
 int bez_ppo_adam_step(float* params_dev, const float* grads_dev, float* exp_avg_dev, float* exp_avg_sq_dev, int64_t n, float* steps_dev,
                       int32_t nsteps, float* lr_dev, float beta1, float beta2, float eps, float weight_decay, float max_norm, float* scale_dev,

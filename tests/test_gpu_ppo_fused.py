@@ -557,7 +557,7 @@ def test_segmented_graphs_equal_the_monolithic_update():
     mono.run_update()                    # captures the whole update, then replays it: one real update
     segm.run_update()                    # captures the segments, then replays them: one real update
     torch.cuda.synchronize()
-    assert segm._seg is not None and len(segm._seg["b"]) == segm.num_minibatches and mono._g_update is not None
+    assert segm._seg is not None and len(segm._seg["cb"]) == segm.num_minibatches and mono._g_update is not None
     # 20 optimiser steps on: the first mini-epoch's KL agrees to rounding, the later ones to the drift 20 Adam steps make of last-bit
     # differences in the atomically summed sigma / head-bias gradients (measured: <= 0.5 %)
     np.testing.assert_allclose(segm.kl_acc.cpu()[:1], mono.kl_acc.cpu()[:1], rtol=2e-3, atol=1e-6)

@@ -185,3 +185,92 @@ def test_dr_hand_out_can_be_taken_back():
         assert torch.equal(a.tensor(abi.TENSOR_RANDOMIZE_BUF), b.tensor(abi.TENSOR_RANDOMIZE_BUF))
     a.dr_step_args(); a.seed(9)            # seeding voids a hand-out too
     assert a.dr_step_args() is not None
+
+
+def test_staged_dataset_prep_equals_the_one_call_form():
+    """bez_ppo_dataset_prep_staged: the data-parallel loop runs the SAME launches with its two collectives between the stages (stage 1 |
+    all-reduce of the moments | stage 2 | all-reduce of the advantage sums | stage 4).  On one rank -- the all-reduces are the identity --
+    the staged form must reproduce the one-call form bit for bit, normaliser statistics included; and with the moment / advantage-sum
+    buffers DOUBLED between the stages (what a second rank holding the same rows would contribute) the normalisations must be those of the
+    doubled batch: same mean, the unbiased variance of 2n samples."""
+    import torch
+    from bez_isaacgym_amd.ppo import fused as F
+    from bez_isaacgym_amd.ppo.a2c_continuous import RunningMeanStd
+    DEV = "cuda:0"
+    torch.manual_seed(4)
+    h, n, nmb, d = 32, 512, 4, 54
+    values, returns = torch.randn(h, n, 1, device=DEV) * 2 + 0.5, torch.randn(h, n, 1, device=DEV) * 3 - 1.0
+    rows = h * n // nmb
+    obs = torch.randn(nmb * rows, d, device=DEV) * 1.7 + 0.3
+
+    def run(staged, double=False):
+        rms = RunningMeanStd((1,)).to(DEV)
+        rms.running_mean.fill_(0.2); rms.running_var.fill_(1.5); rms.count.fill_(1000.0)
+        mom = torch.zeros(nmb * (2 * d + 1) + 6, device=DEV, dtype=torch.float64)      # one buffer, as the agent's _mom_pack
+        om, vm, rm = mom[:nmb * (2 * d + 1)], mom[-6:-3], mom[-3:]
+        ov, rt, adv = torch.zeros(h * n, 1, device=DEV), torch.zeros(h * n, 1, device=DEV), torch.zeros(h * n, device=DEV)
+        sc = F.dataset_prep_scratch(nmb, h, n, DEV)
+        sums = torch.zeros(6, device=DEV, dtype=torch.float64)
+        call = lambda st, s=None: F.dataset_prep(obs, rows, nmb, om, values, returns, rms, vm, rm, ov, rt, adv, True, sc, stages=st, adv_sums=s)
+        if not staged:
+            assert call(7)
+        else:
+            assert call(1)
+            if double:
+                mom.mul_(2.0)
+            assert call(2, sums)
+            if double:
+                sums[:3].mul_(2.0)
+            assert call(4, sums)
+        torch.cuda.synchronize()
+        return dict(ov=ov, rt=rt, adv=adv, mom=mom.clone(), mean=rms.running_mean.clone(), var=rms.running_var.clone(), count=rms.count.clone(), sums=sums)
+    one, st = run(False), run(True)
+    for k in ("ov", "rt", "adv", "mom", "mean", "var", "count"):
+        assert torch.equal(one[k], st[k]), k
+    a = (one["rt"] - one["ov"]).reshape(-1).double()   # un-normalised advantages of the one-call run: recompute what stage 2 summed
+    dbl = run(True, double=True)
+    assert float(dbl["count"]) == 1000.0 + 4 * h * n   # two updates (values, returns) of 2 x h x n samples each
+    a2 = (dbl["rt"] - dbl["ov"]).reshape(-1).double()
+    m2, n2 = a2.mean(), 2.0 * a2.numel()
+    std2 = torch.sqrt(((a2 * a2).sum() * 2 - n2 * m2 * m2) / (n2 - 1))
+    torch.testing.assert_close(dbl["adv"].double(), (a2 - m2) / (std2 + 1e-8), rtol=2e-5, atol=2e-5)
+    assert not torch.equal(dbl["adv"], one["adv"]) and a.numel() == a2.numel()
+
+
+def test_norm_shares_after_an_all_reduce_and_the_folded_rank_division():
+    """Data-parallel optimiser step: bez_ppo_grad_norm_parts re-forms the per-workgroup (sum g^2, non-finite count) shares from the
+    all-reduced buffer, and BezPpoAdamExtra.grad_div folds the division by the number of ranks into the unscale factor.  (a) with the shares
+    the step equals the step in which every workgroup reads the whole gradient (clip coefficient to rounding: a different fixed order);
+    (b) the SUM of two identical rank gradients with grad_div = 2 equals the plain step on one of them; (c) a non-finite element anywhere
+    -- the n % 4 tail included -- skips the step and halves the loss scale."""
+    import torch
+    from bez_isaacgym_amd.ppo import fused as F
+    DEV = "cuda:0"
+    torch.manual_seed(8)
+    n = 124237                                        # bez_kickPPO.yaml's parameter count: n % 4 = 1
+    g = torch.randn(n + 3, device=DEV)[:n] * 3.0      # (a slice: 16-byte aligned start, odd length)
+    p0 = torch.randn(n, device=DEV)
+
+    def step(grad, parts=None, div=1.0, scale0=1024.0):
+        p, m, v = p0.clone(), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+        steps, lr = torch.zeros(1, device=DEV), torch.tensor([3e-4], device=DEV)
+        scale, gt = torch.tensor([scale0], device=DEV), torch.zeros(1, device=DEV, dtype=torch.int32)
+        work = torch.zeros(F.ADAM_WORK_FLOATS, device=DEV)
+        buf = torch.zeros(64, 2, device=DEV)
+        np_ = F.grad_norm_parts(grad, buf) if parts else None
+        F.adam_step(p, grad, m, v, steps, lr, (0.9, 0.999), 1e-8, 0.0, 1.0, scale, gt, 2.0, 0.5, 2000, work, norm_parts=np_, grad_div=div)
+        torch.cuda.synchronize()
+        assert float(work.abs().max()) == 0.0
+        return p, m, float(scale), (np_.clone() if np_ is not None else None)
+    gs = (g * 1024.0).contiguous()                    # "still scaled" gradient
+    p_ref, m_ref, sc_ref, _ = step(gs)
+    p_a, m_a, sc_a, parts = step(gs, parts=True)
+    assert parts.shape[0] == (n // 4 + n % 4 + 1023) // 1024 and sc_a == sc_ref == 1024.0
+    torch.testing.assert_close(parts[:, 0].double().sum(), (gs.double() ** 2).sum(), rtol=1e-5, atol=0)
+    torch.testing.assert_close(p_a, p_ref, rtol=0, atol=2e-9); torch.testing.assert_close(m_a, m_ref, rtol=1e-6, atol=1e-9)
+    p_b, m_b, _, _ = step((gs * 2.0).contiguous(), parts=True, div=2.0)
+    torch.testing.assert_close(p_b, p_ref, rtol=0, atol=2e-9); torch.testing.assert_close(m_b, m_ref, rtol=1e-6, atol=1e-9)
+    for bad_at in (5, n - 1):
+        gb = gs.clone(); gb[bad_at] = float("inf")
+        p_c, _, sc_c, parts_c = step(gb, parts=True)
+        assert torch.equal(p_c, p0) and sc_c == 512.0 and float(parts_c[:, 1].sum()) == 1.0
