@@ -937,7 +937,7 @@ int bez_ppo_dataset_prep_staged(int32_t stages, const float* obs_dev, int64_t mi
   if (!values_dev || !returns_dev || horizon <= 0 || num_envs <= 0 || !value_moments_dev || !return_moments_dev || !old_values_dev || !ds_returns_dev ||
       !advantages_dev || !scratch_dev || (value_mean_dev && (!value_var_dev || !value_count_dev)) || num_minibatches < 0 || num_minibatches > PREP_MAXT - 2 ||
       (num_minibatches > 0 && (!obs_dev || !obs_moments_dev || minibatch_rows <= 0 || num_obs <= 0 || num_obs > 64))) return -1;
-  if (stages <= 0 || stages > 7 || (stages != 7 && !adv_sums_dev)) return -1;   // a split needs the buffer the second collective reduces
+  if (stages <= 0 || stages > 7 || ((((stages & 2) != 0) != ((stages & 4) != 0)) && !adv_sums_dev)) return -1;   // stages 2 and 4 apart: via the buffer the second collective reduces
   if (total % 64 != 0) return -3;   // the scalar tasks are read as (total / 64, 64): the caller keeps its separate launches
   hipStream_t st = (hipStream_t)stream;
   PrepTasks T;

@@ -326,10 +326,229 @@ __global__ __launch_bounds__(64) void chain_lane_group(Inputs in, float* __restr
   if (threadIdx.x == 0) cycles[blockIdx.x] = t1 - t0;
 }
 
+// ------------------------------------------------------------------------------------------------ mapping C (round 5; north_star: "MFMA only if
+// the batched 6x6 spatial-inertia products prove worth it in rocprof")
+// FOUR lanes per env, sixteen envs per wave, the matrix padded to 8 x 8 as 2 x 2 blocks of 4 x 4: lane q of an env's group holds COLUMNS q and 4 + q
+// (= rows, the matrix is symmetric) in four float4 accumulators acc[R][C] -- exactly the C / D layout of v_mfma_f32_4x4x1_16B_f32 (16 independent
+// 4 x 4 blocks per instruction: one per env).  Then
+//   * U = IA S and IA cb are LOCAL dot products of a lane's two columns with the (group-uniform) vectors: no cross-lane traffic;
+//   * the rank-1 update IA -= U U^T / D is FOUR MFMAs whose A / B operands -- U[4 R + q] and -U[4 C + q] / D -- already sit in lane q: the matrix
+//     core does the outer product across the four lanes that mapping B needed six ds_swizzle broadcasts for;
+//   * only the two scalars S.U and S.pA cross lanes (two quad_perm DPP steps each).
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+__device__ __forceinline__ float quad_sum(float v) {
+  int x = __builtin_bit_cast(int, v);
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, x, 0xB1 /* quad_perm [1,0,3,2] */, 0xF, 0xF, true));
+  x = __builtin_bit_cast(int, v);
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, x, 0x4E /* quad_perm [2,3,0,1] */, 0xF, 0xF, true));
+  return v;
+}
+__global__ __launch_bounds__(64) void chain_mfma4(Inputs in, float* __restrict__ out, unsigned long long* __restrict__ cycles, int reps) {
+  // per (joint, env): LI as 8 x 8 (zero padded), then pAl[8], S[8], cb[8], tau: rows of 16-byte aligned floats
+  constexpr int ROW = 64 + 8 + 8 + 8 + 4;
+  __shared__ __attribute__((aligned(16))) float sh[NJ][16][ROW + 4];
+  const int lane = threadIdx.x, q = lane & 3, g = lane >> 2;
+  const int e = blockIdx.x * 16 + g;     // sixteen envs per wave
+  const int ee = e < in.n ? e : 0;
+  for (int j = 0; j < NJ; ++j) {
+    const size_t b = (size_t)j * in.n + ee;
+    for (int k = q; k < 64; k += 4) { const int r = k >> 3, c = k & 7; sh[j][g][k] = (r < 6 && c < 6) ? in.LI[b * 36 + r * 6 + c] : 0.f; }
+    for (int k = q; k < 8; k += 4) {
+      sh[j][g][64 + k] = k < 6 ? in.pAl[b * 6 + k] : 0.f; sh[j][g][72 + k] = k < 6 ? in.S[b * 6 + k] : 0.f; sh[j][g][80 + k] = k < 6 ? in.cb[b * 6 + k] : 0.f;
+    }
+    if (q == 0) sh[j][g][88] = in.tau[b];
+  }
+  __syncthreads();
+  f32x4 acc[2][2];
+  float pA[2];
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  for (int rep = 0; rep < reps; ++rep) {
+#pragma unroll
+    for (int R = 0; R < 2; ++R)
+#pragma unroll
+      for (int C = 0; C < 2; ++C) acc[R][C] = f32x4{0.f, 0.f, 0.f, 0.f};
+    pA[0] = pA[1] = 0.f;
+#pragma unroll
+    for (int j = NJ - 1; j >= 0; --j) {
+      const float* row = sh[j][g];
+      float S[8], cb[8];
+#pragma unroll
+      for (int k = 0; k < 8; k += 4) {
+        const f32x4 s4 = *reinterpret_cast<const f32x4*>(row + 72 + k), c4 = *reinterpret_cast<const f32x4*>(row + 80 + k);
+        S[k] = s4.x; S[k + 1] = s4.y; S[k + 2] = s4.z; S[k + 3] = s4.w; cb[k] = c4.x; cb[k + 1] = c4.y; cb[k + 2] = c4.z; cb[k + 3] = c4.w;
+      }
+      // IA += LI: this lane's two columns (rows 4 R + i of column 4 C + q)
+#pragma unroll
+      for (int R = 0; R < 2; ++R)
+#pragma unroll
+        for (int C = 0; C < 2; ++C)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) acc[R][C][i] += row[(4 * R + i) * 8 + 4 * C + q];
+      pA[0] += row[64 + q]; pA[1] += row[68 + q];
+      // U[4 C + q] = column (4 C + q) . S      (symmetric matrix: column = row)
+      float U[2];
+#pragma unroll
+      for (int C = 0; C < 2; ++C) {
+        float u = 0.f;
+#pragma unroll
+        for (int R = 0; R < 2; ++R)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) u = fmaf(acc[R][C][i], S[4 * R + i], u);
+        U[C] = u;
+      }
+      const float Sq0 = row[72 + q], Sq1 = row[76 + q];
+      const float D = quad_sum(fmaf(Sq0, U[0], Sq1 * U[1])) + in.arm, sp = quad_sum(fmaf(Sq0, pA[0], Sq1 * pA[1]));
+      const float Dinv = __builtin_amdgcn_rcpf(D), uD = (row[88] - sp) * Dinv;
+      const float kU0 = -U[0] * Dinv, kU1 = -U[1] * Dinv;
+      // rank-1 update on the matrix cores: block (R, C) += U[4 R + .] (x) kU[4 C + .]
+      acc[0][0] = __builtin_amdgcn_mfma_f32_4x4x1f32(U[0], kU0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_4x4x1f32(U[0], kU1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_4x4x1f32(U[1], kU0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_4x4x1f32(U[1], kU1, acc[1][1], 0, 0, 0);
+      // pA[4 C + q] += column (4 C + q) . cb + U uD
+#pragma unroll
+      for (int C = 0; C < 2; ++C) {
+        float s = U[C] * uD;
+#pragma unroll
+        for (int R = 0; R < 2; ++R)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) s = fmaf(acc[R][C][i], cb[4 * R + i], s);
+        pA[C] += s;
+      }
+    }
+    asm volatile("" : "+v"(pA[0]));
+  }
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  float colsum = 0.f;
+#pragma unroll
+  for (int R = 0; R < 2; ++R)
+#pragma unroll
+    for (int C = 0; C < 2; ++C)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) colsum += acc[R][C][i];
+  const float tot = quad_sum(colsum);
+  if (e < in.n) {
+    out[(size_t)e * 7 + q] = pA[0];
+    if (q < 2) out[(size_t)e * 7 + 4 + q] = pA[1];
+    if (q == 3) out[(size_t)e * 7 + 6] = tot;
+  }
+  if (threadIdx.x == 0) cycles[blockIdx.x] = t1 - t0;
+}
+
+// ------------------------------------------------------------------------------------------------ the OTHER per-joint work (round 5)
+// Pass 2 of the product kernel spends ~370 vector instructions per joint, of which the recursion above is ~140.  The rest is per-(env, joint)
+// work with no dependence BETWEEN joints: the link's spatial inertia about the common reference point from its mass / COM / rotated inertia, the
+// velocity-product bias and gravity wrench, the drive / friction / limit terms with the saturation predictor's operands.  Written here with the
+// product's own helpers (csrc/bez_spatial.h) on synthetic link states: mode 0 = one lane per env, the six joints one after the other (the
+// product's mapping); mode 1 = one lane per (env, joint), eight lanes per env.  Outputs go to LDS as the packages the recursion consumes.
+namespace bsp {
+#include "../bez_isaacgym_amd/csrc/bez_spatial.h"
+}
+struct JointOut { float v[34]; };
+__device__ __forceinline__ void joint_package(const float* __restrict__ src, float h, JointOut& o) {
+  using namespace bsp;
+  using bsp::Sym6;
+  // src: quaternion (4), link origin r (3), joint axis code folded into a unit vector (3), V (6), q, qd, target, mass, com (3), inertia diag (3)
+  const M3 E = quat_to_mat(src[0], src[1], src[2], src[3]);
+  const V3 r = mk(src[4], src[5], src[6]), ax = mul(E, mk(src[7], src[8], src[9]));
+  const SV V = mksv(mk(src[10], src[11], src[12]), mk(src[13], src[14], src[15]));
+  const float q = src[16], qd = src[17], tgt = src[18], m = src[19];
+  const V3 cw = r + mul(E, mk(src[20], src[21], src[22]));
+  Sym6 I;
+  I.A = rotate_inertia_diag(E, src[23], src[24], src[25]);
+  // + m [c]x [c]x^T ; B = m [c]x ; C = m 1
+  I.A.xx += m * (cw.y * cw.y + cw.z * cw.z); I.A.yy += m * (cw.x * cw.x + cw.z * cw.z); I.A.zz += m * (cw.x * cw.x + cw.y * cw.y);
+  I.A.xy -= m * cw.x * cw.y; I.A.xz -= m * cw.x * cw.z; I.A.yz -= m * cw.y * cw.z;
+  I.B = m3zero(); I.B.m01 = -m * cw.z; I.B.m02 = m * cw.y; I.B.m10 = m * cw.z; I.B.m12 = -m * cw.x; I.B.m20 = -m * cw.y; I.B.m21 = m * cw.x;
+  I.C = sym3zero(); I.C.xx = I.C.yy = I.C.zz = m;
+  const SV S = mksv(ax, cross(r, ax));
+  const SV vj = S * qd, cbias = crm(V, vj);
+  SV p = crf(V, mul(I, V)) - wrench_at(cw, mk(0.f, 0.f, -9.81f * m));
+  // drive: implicit PD, regularised friction, limit spring (the product's terms), and the saturation predictor's operands
+  const float kp = 100.f, kd = 7.5f;
+  const float tau_pd0 = kp * (tgt - q - h * qd) - kd * qd, k_pd = h * h * kp + h * kd;
+  const float cf = 0.1f * frcp(fmaxf(fabsf(qd), 0.1f)), k_f = h * cf, tau_f0 = -cf * qd;
+  float k_l = 0.f, tau_l0 = 0.f;
+  if (q < -0.78f) { tau_l0 = 200.f * (-0.78f - q - h * qd) - 2.f * qd; k_l = h * h * 200.f + h * 2.f; }
+  else if (q > 1.57f) { tau_l0 = 200.f * (1.57f - q - h * qd) - 2.f * qd; k_l = h * h * 200.f + h * 2.f; }
+  const SV U = mul(I, S);
+  const float J = dot(S, U) + 1e-3f, bias = dot(S, p) + dot(U, cbias);
+  const float qdd_est = (tau_pd0 + tau_f0 + tau_l0 - bias) * frcp(J + k_pd + k_f + k_l);
+  const float tau_drive = tau_pd0 - k_pd * qdd_est;
+  const bool sat = fabsf(tau_drive) > 2.5f;
+  const float tau = sat ? copysignf(2.5f, tau_drive) + tau_f0 + tau_l0 : tau_pd0 + tau_f0 + tau_l0;
+  const float kdiag = sat ? k_f + k_l : k_pd + k_f + k_l;
+  float* v = o.v;
+  v[0] = I.A.xx; v[1] = I.A.yy; v[2] = I.A.zz; v[3] = I.A.xy; v[4] = I.A.xz; v[5] = I.A.yz;
+  v[6] = I.B.m00; v[7] = I.B.m01; v[8] = I.B.m02; v[9] = I.B.m10; v[10] = I.B.m11; v[11] = I.B.m12; v[12] = I.B.m20; v[13] = I.B.m21; v[14] = I.B.m22;
+  v[15] = m; v[16] = p.a.x; v[17] = p.a.y; v[18] = p.a.z; v[19] = p.l.x; v[20] = p.l.y; v[21] = p.l.z;
+  v[22] = S.a.x; v[23] = S.a.y; v[24] = S.a.z; v[25] = S.l.x; v[26] = S.l.y; v[27] = S.l.z;
+  v[28] = cbias.a.x + cbias.l.x; v[29] = cbias.a.y + cbias.l.y; v[30] = cbias.a.z + cbias.l.z; v[31] = tau; v[32] = kdiag; v[33] = J;
+}
+template <int MODE>
+__global__ __launch_bounds__(64) void joint_work(const float* __restrict__ links, int n, float* __restrict__ out, unsigned long long* __restrict__ cycles, int reps) {
+  __shared__ float sh[NJ][26][64];         // mode 0: [joint][field][env lane]
+  __shared__ float pk[NJ * 64][35];        // packages (padded)
+  const int lane = threadIdx.x;
+  const int epw = MODE == 0 ? 64 : 8;
+  const int e0 = blockIdx.x * epw;
+  for (int j = 0; j < NJ; ++j)
+    for (int l = lane; l < epw * 26; l += 64) { const int el = l / 26, f = l - el * 26; const int e = e0 + el < n ? e0 + el : 0; sh[j][f][el] = links[((size_t)j * n + e) * 26 + f]; }
+  __syncthreads();
+  float keep = 0.f;
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  for (int rep = 0; rep < reps; ++rep) {
+    if (MODE == 0) {
+#pragma unroll 1
+      for (int j = 0; j < NJ; ++j) {
+        float src[26];
+#pragma unroll
+        for (int f = 0; f < 26; ++f) src[f] = sh[j][f][lane];
+        JointOut o;
+        joint_package(src, 1.f / 120.f + 1e-9f * rep, o);
+#pragma unroll
+        for (int k = 0; k < 34; ++k) pk[j * 64 + lane][k] = o.v[k];
+        keep += o.v[31];
+      }
+    } else {
+      const int j = lane & 7, el = lane >> 3;
+      if (j < NJ) {
+        float src[26];
+#pragma unroll
+        for (int f = 0; f < 26; ++f) src[f] = sh[j][f][el];
+        JointOut o;
+        joint_package(src, 1.f / 120.f + 1e-9f * rep, o);
+#pragma unroll
+        for (int k = 0; k < 34; ++k) pk[j * 64 + el][k] = o.v[k];
+        keep += o.v[31];
+      }
+    }
+    asm volatile("" : "+v"(keep));
+  }
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  __syncthreads();
+  // checksum per env: sum over joints and fields of the packages
+  if (MODE == 0) {
+    const int e = e0 + lane;
+    if (e < n) { float s = 0.f; for (int j = 0; j < NJ; ++j) for (int k = 0; k < 34; ++k) s += pk[j * 64 + lane][k]; out[e] = s; }
+  } else {
+    const int el = lane >> 3, e = e0 + el;
+    if ((lane & 7) == 0 && e < n) { float s = 0.f; for (int j = 0; j < NJ; ++j) for (int k = 0; k < 34; ++k) s += pk[j * 64 + el][k]; out[e] = s; }
+  }
+  if (threadIdx.x == 0) cycles[blockIdx.x] = t1 - t0;
+  if (keep == 123.456f) out[0] = keep;
+}
+extern "C" int probe_joint_work(int mode, const float* links, int n, float* out, unsigned long long* cycles, int reps, void* stream) {
+  if (mode == 0) hipLaunchKernelGGL(joint_work<0>, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, links, n, out, cycles, reps);
+  else hipLaunchKernelGGL(joint_work<1>, dim3((n + 7) / 8), dim3(64), 0, (hipStream_t)stream, links, n, out, cycles, reps);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
 extern "C" int probe_run(int mapping, const float* LI, const float* pAl, const float* S, const float* cb, const float* tau, int n, float arm, float* out,
                          unsigned long long* cycles, int reps, void* stream) {
   Inputs in{LI, pAl, S, cb, tau, n, arm};
-  if (mapping == 3) hipLaunchKernelGGL(chain_one_lane_colpairs, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, in, out, cycles, reps);
+  if (mapping == 4) hipLaunchKernelGGL(chain_mfma4, dim3((n + 15) / 16), dim3(64), 0, (hipStream_t)stream, in, out, cycles, reps);
+  else if (mapping == 3) hipLaunchKernelGGL(chain_one_lane_colpairs, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, in, out, cycles, reps);
   else if (mapping == 2) hipLaunchKernelGGL(chain_one_lane_packed, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, in, out, cycles, reps);
   else if (mapping == 0) hipLaunchKernelGGL(chain_one_lane, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, in, out, cycles, reps);
   else hipLaunchKernelGGL(chain_lane_group, dim3((n + 7) / 8), dim3(64), 0, (hipStream_t)stream, in, out, cycles, reps);
