@@ -30,12 +30,19 @@ using half8 = __attribute__((ext_vector_type(8))) _Float16;
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 typedef __fp16 fp16x4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
 
-constexpr int WG_THREADS = 512;   // 8 waves
-constexpr int WG_WAVES = 8;
+#ifndef BEZ_WGRAD_WAVES
+#define BEZ_WGRAD_WAVES 8
+#endif
+constexpr int WG_WAVES = BEZ_WGRAD_WAVES;   // 8: output blocks of <= 4 x 8 tiles (216 VGPRs); 16: <= 8 x 8 tiles, each operand column read by fewer blocks (<= 128 VGPRs)
+constexpr int WG_THREADS = 64 * WG_WAVES;
+#ifndef BEZ_WGRAD_TPW
+#define BEZ_WGRAD_TPW 4
+#endif
+constexpr int MAX_TPW = BEZ_WGRAD_TPW;      // output tiles a wave keeps in registers (16 accumulator registers each): 4, or 8 (blocks of <= 8 x 8 tiles on 8 waves)
+constexpr int MAX_MT = WG_WAVES * MAX_TPW / 8;   // tile rows of a block: 4 (8 waves x 4 tiles), 8 (16 waves x 4 tiles, or 8 waves x 8 tiles)
 constexpr int KT = 64;            // rows of the reduction staged per step
 constexpr int MAX_PARTS = 24;
-constexpr int MAX_TPW = 4;        // output tiles a wave keeps in registers
-constexpr int MAX_UNITS = 4;      // 16-byte slots a thread prefetches per operand and stage
+constexpr int MAX_UNITS = 2048 / WG_THREADS;   // 16-byte slots a thread prefetches per operand and stage: 64 rows x 256 columns per operand at most
 
 struct Part {
   const _Float16* g; int ldg, g0, gcols;   // dY (K, ldg): columns [g0, g0 + gcols) = output rows of this block
@@ -119,8 +126,9 @@ __device__ __forceinline__ void wgrad_body(const Args& A, const Part& P, int spl
   }
   // two stages of the operand stream live in registers (ring of depth 2) and two in LDS: while stage t is multiplied out of one
   // LDS buffer, stage t+1 is being written into the other and the loads of stage t+2 are in flight
-  typename Unit<GU>::T gr[2][MAX_UNITS];
-  typename Unit<XU>::T xr[2][MAX_UNITS];
+  constexpr int RING = TPW > 4 ? 1 : 2;
+  typename Unit<GU>::T gr[RING][MAX_UNITS];
+  typename Unit<XU>::T xr[RING][MAX_UNITS];
   auto prefetch = [&](int st, typename Unit<GU>::T (&g4)[MAX_UNITS], typename Unit<XU>::T (&x4)[MAX_UNITS]) {
     const long long k0 = (long long)st * KT;
     const _Float16* gb = P.g + k0 * P.ldg;
@@ -143,15 +151,43 @@ __device__ __forceinline__ void wgrad_body(const Args& A, const Part& P, int spl
 #pragma unroll
     for (int kk = 0; kk < KT / 16; ++kk) {
       const half8 a = frag_tr(G, P.gs, kk * 16, 32 * wm, lane);   // every lane takes part (the transposed read needs EXEC = all ones)
-      half8 b[TPW];
+      if constexpr (TPW <= 4) {
+        half8 b[TPW];
 #pragma unroll
-      for (int s = 0; s < TPW; ++s) b[s] = frag_tr(X, P.xs, kk * 16, ncolbase[s], lane);
+        for (int s = 0; s < TPW; ++s) b[s] = frag_tr(X, P.xs, kk * 16, ncolbase[s], lane);
 #pragma unroll
-      for (int s = 0; s < TPW; ++s) acc[s] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b[s], acc[s], 0, 0, 0);
+        for (int s = 0; s < TPW; ++s) acc[s] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b[s], acc[s], 0, 0, 0);
+      } else {
+        // eight tiles per wave (128 accumulator registers): the B fragments in groups of four, and no LDS read of the next k-step above
+        // this one's MFMAs -- hoisted, four k-steps' fragments cost 144 registers the accumulators have left no room for
+#pragma unroll
+        for (int h = 0; h < TPW; h += 4) {
+          half8 b[4];
+#pragma unroll
+          for (int s = 0; s < 4; ++s) b[s] = frag_tr(X, P.xs, kk * 16, ncolbase[h + s], lane);
+#pragma unroll
+          for (int s = 0; s < 4; ++s) acc[h + s] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b[s], acc[h + s], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
     }
   };
   _Float16* buf0 = lds;
   _Float16* buf1 = lds + buf_halfs;
+  if constexpr (TPW > 4) {
+    // eight tiles per wave: the 128 accumulator registers leave room for ONE stage of the operand stream in registers -- its loads are
+    // issued before the MFMAs of the stage in LDS and land behind them (64 rows x <= 512 columns in flight per CU)
+    if (st_begin < st_end) { prefetch(st_begin, gr[0], xr[0]); stage(buf0, gr[0], xr[0]); }
+    __syncthreads();
+    for (int st = st_begin; st < st_end; ++st) {
+      _Float16* cur = ((st - st_begin) & 1) ? buf1 : buf0;
+      _Float16* nxt = ((st - st_begin) & 1) ? buf0 : buf1;
+      if (st + 1 < st_end) prefetch(st + 1, gr[0], xr[0]);
+      multiply(cur);
+      if (st + 1 < st_end) stage(nxt, gr[0], xr[0]);
+      __syncthreads();
+    }
+  } else {
   if (st_begin < st_end) prefetch(st_begin, gr[0], xr[0]);
   if (st_begin + 1 < st_end) prefetch(st_begin + 1, gr[1], xr[1]);
   if (st_begin < st_end) stage(buf0, gr[0], xr[0]);
@@ -168,6 +204,7 @@ __device__ __forceinline__ void wgrad_body(const Args& A, const Part& P, int spl
       multiply(buf1);
       __syncthreads();
     }
+  }
   }
   // partial block: acc register e of lane l = dW[g0 + 32 wm + (e & 3) + 8 (e >> 2) + 4 (l >> 5)][x0 + 32 n + (l & 31)]
   float* out = A.partial + P.partial_off + (long long)split * P.gcols * P.xcols;
@@ -196,12 +233,16 @@ __global__ void __launch_bounds__(WG_THREADS) wgrad_kernel(const Args* __restric
   const Part& P = A.part[pi];
   const int split = (int)blockIdx.x - P.wg_begin;
   const int tpw = (P.nt + WG_WAVES / P.mt - 1) / (WG_WAVES / P.mt);   // tile columns per wave of this block
-  const int variant = (tpw <= 1 ? 0 : 2) * 16 + (P.gu == 8 ? 0 : (P.gu == 4 ? 1 : (P.gu == 2 ? 2 : 3))) * 4 + (P.xu == 8 ? 0 : (P.xu == 4 ? 1 : 2));
+  const int variant = (tpw <= 1 ? 0 : (tpw <= 4 ? 2 : 3)) * 16 + (P.gu == 8 ? 0 : (P.gu == 4 ? 1 : (P.gu == 2 ? 2 : 3))) * 4 + (P.xu == 8 ? 0 : (P.xu == 4 ? 1 : 2));
   // every (tiles per wave, dY unit, X unit) combination is its own straight-line instantiation
 #define WG_CASE(T, TI, GUV, GI, XUV, XI) case (TI * 16 + GI * 4 + XI): wgrad_body<T, GUV, XUV>(A, P, split, lds); break;
 #define WG_X(T, TI, GUV, GI) WG_CASE(T, TI, GUV, GI, 8, 0) WG_CASE(T, TI, GUV, GI, 4, 1) WG_CASE(T, TI, GUV, GI, 2, 2)
 #define WG_G(T, TI) WG_X(T, TI, 8, 0) WG_X(T, TI, 4, 1) WG_X(T, TI, 2, 2)
+#if BEZ_WGRAD_TPW > 4
+  switch (variant) { WG_G(1, 0) WG_G(4, 2) WG_G(8, 3) WG_CASE(1, 0, 1, 3, 8, 0) WG_CASE(1, 0, 1, 3, 4, 1) WG_CASE(1, 0, 1, 3, 2, 2) default: break; }
+#else
   switch (variant) { WG_G(1, 0) WG_G(4, 2) WG_CASE(1, 0, 1, 3, 8, 0) WG_CASE(1, 0, 1, 3, 4, 1) WG_CASE(1, 0, 1, 3, 2, 2) default: break; }
+#endif
 #undef WG_G
 #undef WG_X
 #undef WG_CASE
@@ -355,7 +396,7 @@ int bez_ppo_wgrad_plan(const void* const* dy_f16_dev, const void* const* x_f16_d
     if (O < 1 || I < 1) return -3;
     budget += (long long)nsplit * O * I;                           // the caller's scratch: nsplit images of every gradient
     const int mtiles = (O + 31) / 32, ntiles = (I + 31) / 32;
-    const int mt = mtiles >= 4 ? 4 : (mtiles >= 2 ? 2 : 1);       // tile rows per block
+    const int mt = (mtiles > 4 && MAX_MT >= 8) ? 8 : (mtiles >= 4 ? 4 : (mtiles >= 2 ? 2 : 1));       // tile rows per block
     int ntmax = (WG_WAVES / mt) * MAX_TPW;                         // tile columns a block can keep in registers ...
     if (ntmax > 8) ntmax = 8;                                      // ... and stage with MAX_UNITS 16-byte slots per thread (256 columns)
     const int nblocks_n = (ntiles + ntmax - 1) / ntmax;
