@@ -19,6 +19,8 @@ rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/${TAG}_sweep
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/${TAG}_sweep_write -- python3 tools/pmc_probe.py > $O/${TAG}_sweep_write.log 2>&1
 # the PPO leg (BASELINE.json configs[2]): kernel stats of 10 + 4 epochs
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_ppo_stats -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline > $O/${TAG}_ppo_stats.log 2>&1
+# the same leg on the data-parallel code path (1-rank RCCL group, BEZ_PPO_FORCE_DIST=1): which kernels a rank of an N-GPU job runs per epoch
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_ppo_dp_stats -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --dp-path > $O/${TAG}_ppo_dp_stats.log 2>&1
 # keep only the CSVs the summary needs (the merge back is capped at 64 MiB)
 find $O -name "*agent_info.csv" -delete
 echo collected

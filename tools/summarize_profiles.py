@@ -99,6 +99,14 @@ def main():
             for r in rows[:40]:
                 r[0] = r[0][:110]
                 w.writerow(r)
+    fp = _one(os.path.join(src, tag + "_ppo_dp_stats", "**", "*kernel_stats.csv"))
+    if fp:   # the PPO leg twice: single-GPU path, then the data-parallel path (bench.py --dp-path); the kernels only the latter runs show up here
+        rows = list(csv.reader(open(fp)))
+        with open(os.path.join(out_dir, tag + "_ppo_dp_kernel_stats.csv"), "w", newline="") as g:
+            w = csv.writer(g)
+            for r in rows[:40]:
+                r[0] = r[0][:110]
+                w.writerow(r)
     # 2. PMC
     res = {"kernel": kernel_name, "kernel_avg_ns_rocprofv3": avg_ns, "num_envs": 4096, "git_rev": rev, "source_hash": source_hash(),
            "commands": open(os.path.join(ROOT, "tools", "collect_profiles.sh")).read().splitlines()}
