@@ -273,6 +273,25 @@ def dp_path_leg(args, local_rank, n):
             "dp_path_what": "1-rank RCCL group, BEZ_PPO_FORCE_DIST=1: segmented graphs + %d real all-reduce calls per epoch, no wire time" % (r["mini_epochs"] * (131072 // r["minibatch"] if r["minibatch"] else 0) + 2)}
 
 
+def dp_path_in_child(args, n, limit_s=240):
+    """dp_path_leg in a child process with a time limit: the extra leg brings up a process group, and neither an RCCL failure nor a hang there
+    may take the headline line down with it.  Returns the leg's dict, or {"dp_path_error": ...}."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--dp-path-child", "--gpus", "1", "--num-envs", str(n), "--ppo-epochs", str(args.ppo_epochs)] + \
+          (["--randomize"] if args.randomize else [])
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29500 + os.getpid() % 2000), RANK="0", LOCAL_RANK=os.environ.get("LOCAL_RANK", "0"), WORLD_SIZE="1")
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=limit_s, env=env)
+        lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
+        if r.returncode == 0 and lines:
+            return json.loads(lines[-1])
+        return {"dp_path_error": "child rc %d: %s" % (r.returncode, (r.stderr or r.stdout)[-300:])}
+    except subprocess.TimeoutExpired:
+        return {"dp_path_error": "child exceeded %d s" % limit_s}
+    except Exception as e:   # noqa: BLE001 -- an optional leg
+        return {"dp_path_error": repr(e)[:300]}
+
+
 def stub_main(args, rank, world):
     """The multi-rank skeleton of main() on the CPU (gloo), the env step replaced by a no-op: rendezvous, barrier-bracketed timed
     region, MAX over ranks, one JSON line from rank 0.  Exercised by tests/test_bench_launcher.py."""
@@ -323,8 +342,12 @@ def main():
     ap.add_argument("--keep-aux", action="store_true", help="keep NET_CONTACT_FORCE / FEET / PREV_LIN_VEL current every step (no BEZ_FLAG_LEAN_STEP)")
     ap.add_argument("--no-full-store", action="store_true", help="skip the side measurement of the full-store (non-lean) step: profiler passes "
                     "that average a counter over every dispatch of the step kernel want the headline configuration only")
-    ap.add_argument("--dp-path", action="store_true", help="N = 1 only: time the PPO leg a second time on the data-parallel code path (1-rank RCCL group, "
-                    "BEZ_PPO_FORCE_DIST=1) and report ppo.dp_path_epoch_ms beside ppo.epoch_ms")
+    ap.add_argument("--dp-path", dest="dp_path", action="store_true", default=True,
+                    help="N = 1 (default on): time the PPO leg a second time on the data-parallel code path (1-rank RCCL group, BEZ_PPO_FORCE_DIST=1) and "
+                         "report ppo.dp_path_epoch_ms beside ppo.epoch_ms.  Runs in a child process under a time limit: a failure or a hang of that "
+                         "extra leg is reported in the line (ppo.dp_path_error), it never costs the headline")
+    ap.add_argument("--no-dp-path", dest="dp_path", action="store_false")
+    ap.add_argument("--dp-path-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--randomize", action="store_true", help="PPO leg with task.randomize=True (BASELINE.json configs[4]: domain-randomised "
                     "friction / gains / limits / gravity + observation and action noise, redrawn on the device at reset time)")
     ap.add_argument("--stub-cpu", action="store_true", help="launcher self-test: gloo on the CPU, the env step replaced by a no-op "
@@ -340,6 +363,9 @@ def main():
         sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d: launch one rank per GPU (python bench.py --gpus N does)" % (args.gpus, world))
     if args.stub_cpu:
         return stub_main(args, rank, world)
+    if args.dp_path_child:   # the extra leg of --dp-path, in its own process: one JSON dict on stdout
+        print(json.dumps(dp_path_leg(args, local_rank, args.num_envs)), flush=True)
+        return 0
 
     import torch
     import torch.distributed as dist
@@ -448,8 +474,9 @@ def main():
     if args.ppo_epochs > 0:
         ppo = ppo_leg(args, rank, local_rank, world, n)
         if args.dp_path and world == 1:
-            ppo.update(dp_path_leg(args, local_rank, n))
-            ppo["dp_path_overhead"] = ppo["dp_path_epoch_ms"] / ppo["epoch_ms"] - 1.0
+            ppo.update(dp_path_in_child(args, n))
+            if "dp_path_epoch_ms" in ppo:
+                ppo["dp_path_overhead"] = ppo["dp_path_epoch_ms"] / ppo["epoch_ms"] - 1.0
 
     if rank == 0:
         total_envs = n * world

@@ -18,9 +18,10 @@ rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/${TAG}_cal_w
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/${TAG}_sweep_fetch -- python3 tools/pmc_probe.py > $O/${TAG}_sweep_fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/${TAG}_sweep_write -- python3 tools/pmc_probe.py > $O/${TAG}_sweep_write.log 2>&1
 # the PPO leg (BASELINE.json configs[2]): kernel stats of 10 + 4 epochs
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_ppo_stats -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline > $O/${TAG}_ppo_stats.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_ppo_stats -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-dp-path > $O/${TAG}_ppo_stats.log 2>&1
 # the same leg on the data-parallel code path (1-rank RCCL group, BEZ_PPO_FORCE_DIST=1): which kernels a rank of an N-GPU job runs per epoch
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_ppo_dp_stats -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --dp-path > $O/${TAG}_ppo_dp_stats.log 2>&1
+# (r05's committed table was taken with both legs in one process; bench.py has since moved the extra leg into a child process, profiled here directly)
+MASTER_ADDR=127.0.0.1 MASTER_PORT=29611 RANK=0 LOCAL_RANK=0 WORLD_SIZE=1 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_ppo_dp_stats -- python3 bench.py --dp-path-child --ppo-epochs 30 > $O/${TAG}_ppo_dp_stats.log 2>&1
 # keep only the CSVs the summary needs (the merge back is capped at 64 MiB)
 find $O -name "*agent_info.csv" -delete
 echo collected
