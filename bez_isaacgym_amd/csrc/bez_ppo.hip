@@ -610,6 +610,7 @@ __global__ __launch_bounds__(1024) void grad_norm_parts_kernel(const float* __re
 
 struct AdamExtra {
   float grad_div;                                                       // the buffer holds the sum over this many ranks (0 / 1: it is the gradient)
+  float* gridnorm;                                                      // data parallel: 2 * 256 share slots + the arrival counter of the in-launch norm (NULL: off)
   const float* normpart; int nnormpart;                                 // per-block (sum g^2, non-finite count) of the scaled gradient (NULL: phase 1 reads the gradient)
   const int32_t* map_a; const int32_t* map_b; __half* packed;          // fragment-major weight copies (NULL: none)
   const double* rms_mom; int rms_d; double* rms_mean; double* rms_var; double* rms_count;  // next normaliser update (NULL: none)
@@ -647,6 +648,37 @@ __global__ __launch_bounds__(ADAM_TB) void adam_fused_kernel(float* __restrict__
     for (int i = tid; i < ex.nnormpart; i += ADAM_TB) { const float2 q = reinterpret_cast<const float2*>(ex.normpart)[i]; s2 += q.x; bad += q.y; }
     s2 *= inv * inv;
     if (!(fabsf(s2) <= 3.4028234e38f)) bad += 1.f;   // (a share that overflowed or holds a NaN)
+  } else if (ex.gridnorm) {
+    // data parallel, no shares from the gradient's producer (an all-reduce has replaced the gradient): every workgroup sums ITS OWN slice --
+    // the elements it is about to update, already in registers --, publishes the pair, and all workgroups meet at a counter before each adds
+    // the pairs in the same fixed order.  The grid is <= 256 workgroups of 1024 threads: co-resident on 256 CUs, so the wait cannot
+    // starve a workgroup that has not started.  Slots and counter are exchanged with agent-scope atomics only (no cache-wide fence).
+    float q2 = 0.f, qb = 0.f;
+#pragma unroll
+    for (int k = 0; k < ADAM_PER; ++k) {
+      const int64_t i = first + k * stride;
+      if (i < n) { const float a = gq[k] * inv; qb += fabsf(a) <= 3.4028234e38f ? 0.f : 1.f; q2 = fmaf(a, a, q2); }
+    }
+    for (int64_t i = first + ADAM_PER * stride; i < n; i += stride) { const float a = g[i] * inv; qb += fabsf(a) <= 3.4028234e38f ? 0.f : 1.f; q2 = fmaf(a, a, q2); }
+    q2 = wave_sum(q2); qb = wave_sum(qb);
+    if ((tid & 63) == 0) { red[0][tid >> 6] = q2; red[1][tid >> 6] = qb; }
+    __syncthreads();
+    unsigned int* arrive = reinterpret_cast<unsigned int*>(ex.gridnorm + 512);
+    if (tid == 0) {
+      float a2 = 0.f, ab = 0.f;
+#pragma unroll
+      for (int w = 0; w < ADAM_TB / 64; ++w) { a2 += red[0][w]; ab += red[1][w]; }
+      __hip_atomic_store(ex.gridnorm + 2 * blockIdx.x, a2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(ex.gridnorm + 2 * blockIdx.x + 1, ab, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_fetch_add(arrive, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      while (__hip_atomic_load(arrive, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x) __builtin_amdgcn_s_sleep(2);
+    }
+    __syncthreads();   // (also: red[] is free again)
+    for (int i = tid; i < (int)gridDim.x; i += ADAM_TB) {
+      s2 += __hip_atomic_load(ex.gridnorm + 2 * i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      bad += __hip_atomic_load(ex.gridnorm + 2 * i + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (!(fabsf(s2) <= 3.4028234e38f)) bad += 1.f;
   } else {
     const int64_t n4 = n >> 2;
     const float4* g4 = reinterpret_cast<const float4*>(g);
@@ -745,6 +777,8 @@ __global__ __launch_bounds__(ADAM_TB) void adam_fused_kernel(float* __restrict__
   __syncthreads();
   if (my_ticket != gridDim.x - 1) return;
   if (tid == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  // (every workgroup drew its ticket behind the norm's meeting point: nobody is still waiting on the arrival counter)
+  if (tid == 0 && ex.gridnorm) __hip_atomic_store(reinterpret_cast<unsigned int*>(ex.gridnorm + 512), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (tid < tail.n) *tail.dst[tid] += *tail.src[tid] * tail.scale[tid];
   if (tid == 0 && tail.kl) {   // rl_games AdaptiveScheduler.update ('legacy' schedule: after every minibatch step, for the NEXT one)
     float nv = lr_v;
@@ -1022,6 +1056,8 @@ int bez_ppo_adam_step(float* params_dev, const float* grads_dev, float* exp_avg_
     if (extra->rms_moments_dev && (!extra->rms_mean_dev || !extra->rms_var_dev || !extra->rms_count_dev || extra->rms_cols <= 0 || extra->rms_cols > ADAM_TB)) return -1;
     if (extra->norm_parts_dev && (extra->norm_parts <= 0 || (reinterpret_cast<uintptr_t>(extra->norm_parts_dev) & 7) != 0)) return -1;
     ex.normpart = extra->norm_parts_dev; ex.nnormpart = extra->norm_parts; ex.grad_div = extra->grad_div;
+    if (extra->grid_norm_dev && (extra->norm_parts_dev || (reinterpret_cast<uintptr_t>(extra->grid_norm_dev) & 3) != 0)) return -1;
+    ex.gridnorm = extra->grid_norm_dev;
     ex.map_a = extra->map_a_dev; ex.map_b = extra->map_b_dev; ex.packed = (__half*)extra->packed_f16_dev;
     ex.rms_mom = extra->rms_moments_dev; ex.rms_d = extra->rms_cols; ex.rms_mean = extra->rms_mean_dev; ex.rms_var = extra->rms_var_dev; ex.rms_count = extra->rms_count_dev;
   }

@@ -1134,22 +1134,29 @@ class A2CAgent:
             # 'legacy' schedule: the lr moves after every step, in the same launch (the step's KL is a SUM over the rows: threshold scaled)
             sc = self.scheduler
             adapt = (self._flat_kl, sc.kl_threshold * rows, sc.min_lr, sc.max_lr) if self.is_adaptive_lr and self.schedule_type == "legacy" else None
-            parts = self._norm_parts if fresh else None
+            parts, gridn = (self._norm_parts if fresh else None), None
             if wdiv != 1.0 or _dist_on():
-                # ... and the norm shares are re-formed from the all-reduced buffer by one small launch (every workgroup of the optimiser
-                # launch reading the whole gradient instead costs it 18 us against 9)
-                npd = getattr(self, "_norm_parts_dp", None)
-                if npd is None:
-                    assert not torch.cuda.is_current_stream_capturing()
-                    npd = self._norm_parts_dp = torch.zeros((self._nparam // 4 + 3 + 1023) // 1024 + 1, 2, device=self.device, dtype=torch.float32)
-                parts = self._F.grad_norm_parts(self._flat[:self._nparam], npd)
+                # ... and the norm of the all-reduced buffer is formed INSIDE the optimiser launch: every workgroup sums its own slice, the
+                # workgroups meet at a counter (`dp_grid_norm`, default).  Off: one small launch re-forms the shares (bez_ppo_grad_norm_parts).
+                # (Every workgroup reading the whole gradient instead costs the launch 18 us against 9.)
+                if self.cfg.get("dp_grid_norm", True):
+                    gridn = getattr(self, "_grid_norm", None)
+                    if gridn is None:
+                        assert not torch.cuda.is_current_stream_capturing()
+                        gridn = self._grid_norm = torch.zeros(self._F.ADAM_GRIDNORM_FLOATS, device=self.device, dtype=torch.float32)
+                else:
+                    npd = getattr(self, "_norm_parts_dp", None)
+                    if npd is None:
+                        assert not torch.cuda.is_current_stream_capturing()
+                        npd = self._norm_parts_dp = torch.zeros((self._nparam // 4 + 3 + 1023) // 1024 + 1, 2, device=self.device, dtype=torch.float32)
+                    parts = self._F.grad_norm_parts(self._flat[:self._nparam], npd)
             self._F.adam_step(self._pflat, self._flat[:self._nparam], self._mflat, self._vflat, self._steps, self.lr_t, g0["betas"], g0["eps"],
                               g0["weight_decay"], self.grad_norm if self.truncate_grads else 0.0, self.scaler._scale if amp else None,
                               self.scaler._growth_tracker if amp else None, self.scaler.get_growth_factor(), self.scaler.get_backoff_factor(),
                               self.scaler.get_growth_interval(), self._opt_work, self._hflat, tail=tail, adapt=adapt,
                               packed=self._packed if (self._packed is not None and self._hflat is not None and not self._packed_stale) else None,
                               next_rms=(self._f_obs_rms, self._obs_mom[next_i]) if (next_i is not None and self.normalize_input) else None,
-                              norm_parts=parts, grad_div=wdiv)
+                              norm_parts=parts, grad_div=wdiv, grid_norm=gridn)
             if next_i is not None and self.normalize_input:
                 self._rms_preapplied = True
             return

@@ -41,7 +41,7 @@ _SIGS = {
     "bez_ppo_grad_norm_parts": [_vp, _i64, _vp, _i32, _vp],
 }
 _lib = None
-PPO_ABI_VERSION = 6   # BEZ_PPO_ABI_VERSION (include/bez_sim.h)
+PPO_ABI_VERSION = 7   # BEZ_PPO_ABI_VERSION (include/bez_sim.h)
 
 
 def lib():
@@ -196,10 +196,12 @@ def loss_scratch(b, a, device):
 
 
 ADAM_WORK_FLOATS = 258   # BEZ_PPO_ADAM_WORK_FLOATS
+ADAM_GRIDNORM_FLOATS = 516   # BEZ_PPO_ADAM_GRIDNORM_FLOATS
 
 
 def adam_step(params, grads, exp_avg, exp_avg_sq, steps, lr, betas, eps, weight_decay, max_norm, scale, growth_tracker, growth_factor,
-              backoff_factor, growth_interval, work, params_f16=None, tail=(), adapt=None, packed=None, next_rms=None, norm_parts=None, grad_div=1.0):
+              backoff_factor, growth_interval, work, params_f16=None, tail=(), adapt=None, packed=None, next_rms=None, norm_parts=None, grad_div=1.0,
+              grid_norm=None):
     """unscale + clip + Adam + scaler update on the flat buffers in ONE launch (csrc/bez_ppo.hip adam_fused_kernel); scale / growth_tracker
     None = no AMP; params_f16 (flat fp16, same layout) receives the updated parameters in the same pass.  `work` must be zero on entry and
     is zero again afterwards.  tail: up to 4 (dst, src, scale) with one-element fp32 tensors: dst += src * scale.
@@ -210,9 +212,12 @@ def adam_step(params, grads, exp_avg, exp_avg_sq, steps, lr, betas, eps, weight_
     re-derived); grad_div: the buffer holds the all-reduced SUM over that many ranks (the division rides in the unscale factor)."""
     n = params.numel()
     extra = None
-    if packed is not None or next_rms is not None or norm_parts is not None or grad_div != 1.0:
+    if packed is not None or next_rms is not None or norm_parts is not None or grad_div != 1.0 or grid_norm is not None:
         extra = AdamExtra()
         extra.grad_div = float(grad_div)
+        if grid_norm is not None:   # (ADAM_GRIDNORM_FLOATS zero-initialised floats: the launch forms the norm itself, workgroups meeting at a counter)
+            assert norm_parts is None and grid_norm.dtype == torch.float32 and grid_norm.is_contiguous() and grid_norm.numel() >= ADAM_GRIDNORM_FLOATS
+            extra.grid_norm_dev = grid_norm.data_ptr()
         if norm_parts is not None:
             assert norm_parts.dtype == torch.float32 and norm_parts.is_contiguous() and norm_parts.shape[1] == 2
             extra.norm_parts_dev, extra.norm_parts = norm_parts.data_ptr(), norm_parts.shape[0]
@@ -252,7 +257,7 @@ def grad_norm_parts(grads, parts):
 
 class AdamExtra(C.Structure):
     """BezPpoAdamExtra (include/bez_sim.h)"""
-    _fields_ = [("norm_parts_dev", C.c_void_p), ("norm_parts", C.c_int32), ("grad_div", C.c_float), ("map_a_dev", C.c_void_p), ("map_b_dev", C.c_void_p), ("packed_f16_dev", C.c_void_p), ("rms_moments_dev", C.c_void_p),
+    _fields_ = [("norm_parts_dev", C.c_void_p), ("norm_parts", C.c_int32), ("grad_div", C.c_float), ("grid_norm_dev", C.c_void_p), ("map_a_dev", C.c_void_p), ("map_b_dev", C.c_void_p), ("packed_f16_dev", C.c_void_p), ("rms_moments_dev", C.c_void_p),
                 ("rms_cols", C.c_int32), ("rms_mean_dev", C.c_void_p), ("rms_var_dev", C.c_void_p), ("rms_count_dev", C.c_void_p)]
 
 

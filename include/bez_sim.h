@@ -318,7 +318,7 @@ int bez_sim_time_steps(BezSim* sim, const float* actions_dev, int32_t n_steps, v
 
 /* The signatures below change between rounds (round 3: scratch buffers of the fixed-order reductions, plan / run split of the weight
  * gradients, the optimiser tail's bookkeeping): a binding checks this number once after dlopen. */
-#define BEZ_PPO_ABI_VERSION 6
+#define BEZ_PPO_ABI_VERSION 7
 int32_t bez_ppo_abi_version(void);
 
 /* RunningMeanStd (normalize_input / normalize_value, bez_kickPPO.yaml:51-52): moments[0:D] = column sums, [D:2D] = sums of
@@ -560,6 +560,10 @@ typedef struct BezPpoAdamExtra {
   const float* norm_parts_dev; int32_t norm_parts; /* (c) the norm_parts pairs bez_ppo_grad_reduce_all (or bez_ppo_grad_norm_parts) left for THIS gradient */
   float grad_div;                                  /* data parallel: the gradient buffer holds the SUM over this many ranks (an all-reduce); 0 = 1.
                                                       Folded into the unscale factor: no separate division pass over the buffer */
+  float* grid_norm_dev;                            /* data parallel, instead of norm_parts_dev: BEZ_PPO_ADAM_GRIDNORM_FLOATS zero-initialised floats; the launch
+                                                      forms the norm itself -- every workgroup sums its own slice, the workgroups meet at a counter in this
+                                                      buffer (all of them are co-resident: <= 256 workgroups), each adds the shares in the same fixed order --
+                                                      and leaves the counter at zero.  No extra launch, no workgroup reads the whole gradient */
   const int32_t* map_a_dev; const int32_t* map_b_dev; void* packed_f16_dev;
   const double* rms_moments_dev; int32_t rms_cols; double* rms_mean_dev; double* rms_var_dev; double* rms_count_dev;
 } BezPpoAdamExtra;
@@ -568,6 +572,7 @@ typedef struct BezPpoAdamExtra {
  * pairs instead of the whole gradient in every workgroup.  parts_dev: 2 * parts floats; returns the number of pairs written (<= parts). */
 int bez_ppo_grad_norm_parts(const float* grads_dev, int64_t n, float* parts_dev, int32_t parts, void* stream);
 #define BEZ_PPO_ADAM_WORK_FLOATS 258
+#define BEZ_PPO_ADAM_GRIDNORM_FLOATS 516
 int bez_ppo_adam_step(float* params_dev, const float* grads_dev, float* exp_avg_dev, float* exp_avg_sq_dev, int64_t n, float* steps_dev,
                       int32_t nsteps, float* lr_dev, float beta1, float beta2, float eps, float weight_decay, float max_norm, float* scale_dev,
                       int32_t* growth_tracker_dev, float growth_factor, float backoff_factor, int32_t growth_interval, float* work_dev,

@@ -251,16 +251,21 @@ def test_norm_shares_after_an_all_reduce_and_the_folded_rank_division():
     g = torch.randn(n + 3, device=DEV)[:n] * 3.0      # (a slice: 16-byte aligned start, odd length)
     p0 = torch.randn(n, device=DEV)
 
-    def step(grad, parts=None, div=1.0, scale0=1024.0):
+    grid_buf = torch.zeros(F.ADAM_GRIDNORM_FLOATS, device=DEV)
+
+    def step(grad, parts=None, div=1.0, scale0=1024.0, grid=False):
         p, m, v = p0.clone(), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
         steps, lr = torch.zeros(1, device=DEV), torch.tensor([3e-4], device=DEV)
         scale, gt = torch.tensor([scale0], device=DEV), torch.zeros(1, device=DEV, dtype=torch.int32)
         work = torch.zeros(F.ADAM_WORK_FLOATS, device=DEV)
         buf = torch.zeros(64, 2, device=DEV)
         np_ = F.grad_norm_parts(grad, buf) if parts else None
-        F.adam_step(p, grad, m, v, steps, lr, (0.9, 0.999), 1e-8, 0.0, 1.0, scale, gt, 2.0, 0.5, 2000, work, norm_parts=np_, grad_div=div)
+        F.adam_step(p, grad, m, v, steps, lr, (0.9, 0.999), 1e-8, 0.0, 1.0, scale, gt, 2.0, 0.5, 2000, work, norm_parts=np_, grad_div=div,
+                    grid_norm=grid_buf if grid else None)
         torch.cuda.synchronize()
         assert float(work.abs().max()) == 0.0
+        if grid:   # the arrival counter is back at zero: the buffer serves the next launch as it is
+            assert int(grid_buf[512:513].view(torch.int32)) == 0
         return p, m, float(scale), (np_.clone() if np_ is not None else None)
     gs = (g * 1024.0).contiguous()                    # "still scaled" gradient
     p_ref, m_ref, sc_ref, _ = step(gs)
@@ -274,3 +279,16 @@ def test_norm_shares_after_an_all_reduce_and_the_folded_rank_division():
         gb = gs.clone(); gb[bad_at] = float("inf")
         p_c, _, sc_c, parts_c = step(gb, parts=True)
         assert torch.equal(p_c, p0) and sc_c == 512.0 and float(parts_c[:, 1].sum()) == 1.0
+    # (d) the norm formed inside the optimiser launch (BezPpoAdamExtra.grid_norm_dev: own-slice sums, the workgroups meet at a counter): the
+    # same step again, three launches in a row on the same buffer, with the rank division, and a non-finite element skips the step
+    for _ in range(3):
+        p_d, m_d, sc_d, _ = step(gs, grid=True)
+        torch.testing.assert_close(p_d, p_ref, rtol=0, atol=2e-9); torch.testing.assert_close(m_d, m_ref, rtol=1e-6, atol=1e-9)
+    first = step(gs, grid=True)[0]
+    assert torch.equal(first, p_d)                      # fixed order: bit-identical from launch to launch
+    p_e, m_e, _, _ = step((gs * 2.0).contiguous(), div=2.0, grid=True)
+    torch.testing.assert_close(p_e, p_ref, rtol=0, atol=2e-9)
+    for bad_at in (5, n - 1):
+        gb = gs.clone(); gb[bad_at] = float("nan")
+        p_f, _, sc_f, _ = step(gb, grid=True)
+        assert torch.equal(p_f, p0) and sc_f == 512.0
