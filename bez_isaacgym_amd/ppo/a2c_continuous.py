@@ -28,6 +28,11 @@ import torch.distributed as dist
 import torch.nn as nn
 
 
+# measurement only: BEZ_PPO_MEASURE_NO_COLLECTIVE=1 leaves the per-step all-reduce call out of the segmented update, to separate what
+# the graph boundaries cost from what the collective call costs on the 1-GPU box.  Never set it in a real data-parallel run.
+_MEASURE_NO_COLLECTIVE = os.environ.get("BEZ_PPO_MEASURE_NO_COLLECTIVE") == "1"
+
+
 def _dist_on():
     # BEZ_PPO_FORCE_DIST=1 (tests): treat a 1-rank process group as data parallel, so the real RCCL calls run on a 1-GPU box
     return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or os.environ.get("BEZ_PPO_FORCE_DIST") == "1")
@@ -1294,7 +1299,7 @@ class A2CAgent:
                 seg["cb"][s_ % nm].replay()
                 if s_ % nm == 0:
                     close_mini_epoch(s_ // nm - 1)
-            if _dist_on():
+            if _dist_on() and not _MEASURE_NO_COLLECTIVE:
                 dist.all_reduce(self._flat)
         seg["c"].replay()
         close_mini_epoch(self.mini_epochs - 1)
