@@ -324,7 +324,10 @@ class A2CAgent:
         self.rank, self.world = rank, world
         # data parallel (more than one rank, or BEZ_PPO_FORCE_DIST=1 on a 1-rank group: the same code path with real RCCL calls on a
         # 1-GPU box -- tests, `bench.py --dp-path`): HIP graphs are captured in segments with the collectives between the replays
-        self._segmented = bool(world > 1 or _dist_on())
+        # `dp_capture_collectives: True` (opt-in, EXPERIMENTAL): capture the RCCL calls into the same graphs as everything else -- the single-GPU
+        # path's two replays per epoch, collectives included.  torch.distributed supports capturing NCCL / RCCL work; exercised here on a
+        # 1-rank group only (a 1-GPU box cannot hold two RCCL ranks), hence off by default
+        self._segmented = bool((world > 1 or _dist_on()) and not c.get("dp_capture_collectives", False))
         self.num_actors = int(c["num_actors"])
         self.horizon = int(c["horizon_length"])
         self.gamma, self.tau = float(c["gamma"]), float(c["tau"])

@@ -578,6 +578,7 @@ def test_data_parallel_path_with_real_rccl_calls_on_one_rank(tmp_path):
     code = '''
 import os, sys, numpy as np, torch, torch.distributed as dist
 sys.path.insert(0, %r)
+import bez_isaacgym_amd   # before anything initialises HIP: graph replay is only safe with the runtime's packet capture off (DESIGN.md 6.2)
 os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29777", RANK="0", WORLD_SIZE="1", BEZ_PPO_FORCE_DIST="1")
 torch.cuda.set_device(0)
 dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
@@ -634,6 +635,7 @@ def test_two_ranks_on_the_gpu_stay_bit_identical(tmp_path):
     code = '''
 import os, sys, hashlib, numpy as np, torch, torch.distributed as dist
 sys.path.insert(0, %r)
+import bez_isaacgym_amd   # before anything initialises HIP (DESIGN.md 6.2)
 rank = int(os.environ["RANK"])
 torch.cuda.set_device(0)
 dist.init_process_group("gloo", rank=rank, world_size=2)

@@ -292,3 +292,37 @@ def test_norm_shares_after_an_all_reduce_and_the_folded_rank_division():
         gb = gs.clone(); gb[bad_at] = float("nan")
         p_f, _, sc_f, _ = step(gb, grid=True)
         assert torch.equal(p_f, p0) and sc_f == 512.0
+
+
+def test_captured_collectives_equal_the_segmented_update_on_one_rank():
+    """`dp_capture_collectives: True` (opt-in, experimental): the RCCL calls are captured into the same graphs as everything else, so the
+    data-parallel epoch is the single-GPU path's two replays again (bench: 4.17 against 4.52 ms segmented, 4.16 single-GPU).  On a 1-rank RCCL
+    group -- all a 1-GPU box can hold -- it must train to the SAME bits as the segmented update: same kernels, same order, only the launch
+    mechanism differs."""
+    import os, subprocess, sys
+    code = r'''
+import os, sys, numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+import bez_isaacgym_amd   # before anything initialises HIP: graph replay is only safe with the runtime's packet capture off (DESIGN.md 6.2)
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29779", RANK="0", WORLD_SIZE="1", BEZ_PPO_FORCE_DIST="1")
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+from tests.test_gpu_round2 import _agent
+snaps = []
+for capture in (False, True):
+    torch.manual_seed(77); torch.cuda.manual_seed_all(77)
+    a = _agent(512, 4096, dp_capture_collectives=capture)
+    assert a._segmented == (not capture)
+    a.obs = a.env_reset()
+    st = [a.train_epoch() for _ in range(6)]
+    torch.cuda.synchronize()
+    assert (a._seg is None) == capture and (a._g_update is not None) == capture and a._g_rollout is not None, (capture, a.use_graphs, a._seg is None, a._g_update is None, a._g_rollout is None)
+    assert all(np.isfinite([s["kl"], s["a_loss"], s["c_loss"]]).all() for s in st), st
+    snaps.append([p.detach().clone() for p in a.model.parameters()] + [a._mflat.clone(), a.scaler._scale.clone(), a.running_mean_std.running_mean.clone()])
+    a.release_env(); del a
+assert all(torch.equal(x, y) for x, y in zip(*snaps)), [float((x.float() - y.float()).abs().max()) for x, y in zip(*snaps)]
+dist.destroy_process_group()
+print("CAPTURE_OK")
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert "CAPTURE_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
