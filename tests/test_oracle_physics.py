@@ -354,3 +354,45 @@ def test_tgs_flag_is_oracle_only():
     for _ in range(20):
         a.step(act); b.step(act)
     assert np.abs(a.root_states - b.root_states).max() > 1e-4
+
+
+def test_ankle_stop_is_the_calf_foot_plate_contact(model):
+    """BEZ_FLAG_ANKLE_STOP (oracle only; kick_env.py:365-366 collision_filter 0, soccerbot_stl.urdf:232-236 / 272-276): the gap between the calf
+    box's bottom corners and the foot plate's top face is a function of ankle pitch and foot roll alone.  tools/arm_posture.ankle_gap derives it
+    in Python from the baked model (axes, origins, boxes); the oracle's contact must be active exactly where that gap is negative, act on the
+    calf and foot rows with equal and opposite forces along the foot's z axis, and push the two ankle joints back out of the contact."""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    from arm_posture import ankle_gap
+    cfg = abi.default_config(1)
+    cfg.flags |= abi.FLAG_ANKLE_STOP
+    cfg.gravity[:] = [0.0, 0.0, 0.0]
+    o = Oracle(cfg)
+    plain = Oracle(abi.default_config(1))
+    dflt = np.asarray(model["dof_default"], float)
+    calf_l, foot_l, calf_r, foot_r = 10, 12, 18, 20           # Isaac body rows (bez_model.json body_names)
+    cases = [(0.613, 0.0), (0.79, 0.23), (0.79, 0.45), (1.2, 0.6), (0.3, -0.75), (1.3, -0.5), (0.0, 0.78)]
+    seen_active = seen_free = 0
+    for side, (ip, ir, calf, foot) in (("left", (8, 9, calf_l, foot_l)), ("right", (16, 17, calf_r, foot_r))):
+        for pitch, roll in cases:
+            q = dflt.copy(); q[ip], q[ir] = pitch, roll
+            for orc in (o, plain):
+                _inject(orc, [0.0, 0.0, 1.0], [0, 0, 0, 1], np.zeros(6), q, np.zeros(18))   # in the air, at rest: no ground, no drive error but the pose's
+                orc.set_targets(q[None].astype(np.float32))
+            gap = ankle_gap(model, side, pitch, roll)
+            _, qdd, _, cf = o.forward_dynamics(0, mode=0)
+            _, qdd0, _, cf0 = plain.forward_dynamics(0, mode=0)
+            f_calf, f_foot = cf[calf], cf[foot]
+            if gap < -2e-4:
+                seen_active += 1
+                assert np.linalg.norm(f_foot) > 1.0, (side, pitch, roll, gap, f_foot)
+                np.testing.assert_allclose(f_calf, -f_foot, rtol=1e-9, atol=1e-9)        # an internal force pair
+                # along the foot's z axis (foot frame = calf frame rotated by the two ankle joints; the torso is upright and the hip joints are at 0)
+                assert abs(np.linalg.norm(f_foot)) == pytest.approx(2e5 * -gap, rel=0.35), (gap, f_foot)   # k * depth of the deepest corner (others may add)
+                # the stop opens the contact: it drives the roll joint back towards a smaller |roll|
+                assert (qdd[ir] - qdd0[ir]) * np.sign(roll) < 0, (side, pitch, roll, qdd[ir], qdd0[ir])
+            elif gap > 2e-4:
+                seen_free += 1
+                np.testing.assert_array_equal(cf, cf0)
+                np.testing.assert_allclose(qdd, qdd0, rtol=0, atol=1e-12)
+    assert seen_active >= 6 and seen_free >= 4

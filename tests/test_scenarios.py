@@ -78,3 +78,30 @@ def test_dof_sweep_oracle(model):
     sim = make_backend("oracle", cfg)
     sim.step(np.zeros((n, 18), np.float32))
     check_dof_sweep(dof_sweep(sim, n, model))
+
+
+def test_separating_axis_test_of_the_pair_log():
+    """tools/pair_penetration.obb_separation on configurations with known answers: face-to-face gap and overlap, a rotated box whose corner
+    dips into a face, an edge-edge case only a cross-product axis separates, and the degenerate parallel-axes case."""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    from pair_penetration import obb_separation, quat_to_mat
+    I = np.eye(3)[None]
+    h = np.array([0.5, 0.5, 0.5])
+    sep = lambda ca, Ra, ha, cb, Rb, hb: float(obb_separation(np.array([ca], float), Ra, np.asarray(ha, float), np.array([cb], float), Rb, np.asarray(hb, float))[0])
+    assert sep([0, 0, 0], I, h, [1.3, 0, 0], I, h) == pytest.approx(0.3)          # face to face, 0.3 apart (parallel axes: cross products degenerate)
+    assert sep([0, 0, 0], I, h, [0.9, 0.2, 0.1], I, h) == pytest.approx(-0.1)     # overlapping by 0.1 along x (the least-penetration axis)
+    # box B rotated 45 deg about z: its corner points at A's +x face; corner reach = 0.5 * sqrt(2)
+    q = np.array([[0.0, 0.0, np.sin(np.pi / 8), np.cos(np.pi / 8)]])
+    R45 = quat_to_mat(q)
+    reach = 0.5 * np.sqrt(2.0)
+    assert sep([0, 0, 0], I, h, [0.5 + reach + 0.05, 0, 0], R45, h) == pytest.approx(0.05, abs=1e-9)
+    assert sep([0, 0, 0], I, h, [0.5 + reach - 0.02, 0, 0], R45, h) == pytest.approx(-0.02, abs=1e-9)
+    # two long thin rods crossing at right angles, offset along z: only z separates them
+    assert sep([0, 0, 0], I, [2.0, 0.05, 0.05], [0, 0, 0.3], I, [0.05, 2.0, 0.05]) == pytest.approx(0.2)
+    # a rod along x and a rod along (y + z) / sqrt 2 whose centre sits 0.4 above: the lines are 0.4 / sqrt 2 apart along n = (0, -1, 1) / sqrt 2,
+    # which is B's own thin axis; A's square cross-section reaches 0.05 sqrt 2 along n, B's 0.05
+    qx = np.array([[np.sin(np.pi / 8), 0.0, 0.0, np.cos(np.pi / 8)]])      # 45 deg about x
+    Rx = quat_to_mat(qx)
+    d = sep([0, 0, 0], I, [1.0, 0.05, 0.05], [0, 0.0, 0.4], Rx, [0.05, 1.0, 0.05])
+    assert d == pytest.approx(0.4 / np.sqrt(2.0) - 0.05 * np.sqrt(2.0) - 0.05, abs=1e-9)
