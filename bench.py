@@ -279,7 +279,11 @@ def dp_path_in_child(args, n, limit_s=240):
     import subprocess
     cmd = [sys.executable, os.path.abspath(__file__), "--dp-path-child", "--gpus", "1", "--num-envs", str(n), "--ppo-epochs", str(args.ppo_epochs)] + \
           (["--randomize"] if args.randomize else [])
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29500 + os.getpid() % 2000), RANK="0", LOCAL_RANK=os.environ.get("LOCAL_RANK", "0"), WORLD_SIZE="1")
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as so:   # a port that is free right now (a fixed number may be taken on a shared box)
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", LOCAL_RANK=os.environ.get("LOCAL_RANK", "0"), WORLD_SIZE="1")
     try:
         r = subprocess.run(cmd, capture_output=True, text=True, timeout=limit_s, env=env)
         lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]

@@ -24,3 +24,11 @@ def golden():
 def model():
     import json
     return json.load(open(os.path.join(ROOT, "bez_isaacgym_amd", "model", "bez_model.json")))
+
+
+def free_port():
+    """A TCP port that is free on 127.0.0.1 right now (rendezvous of the subprocess tests: a fixed number may be taken on a shared box)."""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]

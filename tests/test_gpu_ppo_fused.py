@@ -579,7 +579,7 @@ def test_data_parallel_path_with_real_rccl_calls_on_one_rank(tmp_path):
 import os, sys, numpy as np, torch, torch.distributed as dist
 sys.path.insert(0, %r)
 import bez_isaacgym_amd   # before anything initialises HIP: graph replay is only safe with the runtime's packet capture off (DESIGN.md 6.2)
-os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29777", RANK="0", WORLD_SIZE="1", BEZ_PPO_FORCE_DIST="1")
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="%d", RANK="0", WORLD_SIZE="1", BEZ_PPO_FORCE_DIST="1")
 torch.cuda.set_device(0)
 dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
 from tests.test_gpu_round2 import _agent
@@ -598,7 +598,7 @@ steps = a.mini_epochs * a.num_minibatches
 assert len(calls) == steps + 2 and calls[2:] == [a._flat.numel()] * steps, calls   # SURVEY.md 5.8: ONE collective per optimiser step (+ 2 per epoch)
 dist.destroy_process_group()
 print("DP_OK", st[-1]["kl"])
-''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+''' % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), __import__("tests.conftest", fromlist=["free_port"]).free_port())
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert "DP_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
 
@@ -695,7 +695,7 @@ dist.barrier()
 dist.destroy_process_group()
 print("DP2_OK", rank, st[-1]["kl"])
 ''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29791", WORLD_SIZE="2", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(__import__("tests.conftest", fromlist=["free_port"]).free_port()), WORLD_SIZE="2", HSA_ENABLE_IPC_MODE_LEGACY="0")
     procs = [subprocess.Popen([sys.executable, "-c", code], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
              for r in range(2)]
     outs = []

@@ -304,7 +304,7 @@ def test_captured_collectives_equal_the_segmented_update_on_one_rank():
 import os, sys, numpy as np, torch, torch.distributed as dist
 sys.path.insert(0, %r)
 import bez_isaacgym_amd   # before anything initialises HIP: graph replay is only safe with the runtime's packet capture off (DESIGN.md 6.2)
-os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29779", RANK="0", WORLD_SIZE="1", BEZ_PPO_FORCE_DIST="1")
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="%d", RANK="0", WORLD_SIZE="1", BEZ_PPO_FORCE_DIST="1")
 torch.cuda.set_device(0)
 dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
 from tests.test_gpu_round2 import _agent
@@ -323,6 +323,6 @@ for capture in (False, True):
 assert all(torch.equal(x, y) for x, y in zip(*snaps)), [float((x.float() - y.float()).abs().max()) for x, y in zip(*snaps)]
 dist.destroy_process_group()
 print("CAPTURE_OK")
-''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+''' % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), __import__("tests.conftest", fromlist=["free_port"]).free_port())
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
     assert "CAPTURE_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
