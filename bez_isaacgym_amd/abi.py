@@ -27,6 +27,7 @@ FLAG_OBS_NOISE_IN_STEP = 256
 FLAG_TGS_SOLVER = 512
 FLAG_ANKLE_STOP = 1024          # oracle only (this round's experiment; include/bez_sim.h)
 FLAG_ALL_GROUND_SHAPES = 2048   # oracle only
+FLAG_FIX_BASE = 4096            # urdfAsset.fixBaseLink: the torso welded to the world
 TASK_KICK, TASK_WALK, TASK_ORIENT = 0, 1, 2
 TASK_IDS = {"bez_kick": TASK_KICK, "bez_walk": TASK_WALK, "bez_orient": TASK_ORIENT}
 
@@ -166,7 +167,7 @@ def default_config(num_envs=4096, seed=42, env_id_offset=0):
 
 def refuse_unmodelled(cfg):
     """Config keys the reference forwards to Isaac Gym that this build's rigid-body step does not model: a non-default value raises
-    instead of being read and ignored (the defaults of bez_kick.yaml are what the kernels implement).
+    instead of being read and ignored (the defaults of bez_kick.yaml are what the kernels implement; fixBaseLink IS modelled: BEZ_FLAG_FIX_BASE).
     kick_env.py:250-256 (plane), :283-294 (asset options)."""
     env = cfg["env"]
     ua, plane = env.get("urdfAsset", {}), env.get("plane", {})
@@ -175,7 +176,6 @@ def refuse_unmodelled(cfg):
         if cond:
             raise ValueError("task config: %s = %r is not modelled by the HIP simulator (%s); only the value of the reference's "
                              "yaml is implemented" % (key, value, why))
-    no(bool(ua.get("fixBaseLink", False)), "env.urdfAsset.fixBaseLink", ua.get("fixBaseLink"), "the robot is always a floating-base tree")
     no(bool(ua.get("disable_gravity", False)), "env.urdfAsset.disable_gravity", ua.get("disable_gravity"),
        "gravity acts on every body; set sim.gravity to zero instead")
     for k in ("angular_damping", "linear_damping"):
@@ -221,4 +221,6 @@ def config_from_task_cfg(cfg, seed=42, env_id_offset=0, strict_reference_quirks=
         c.flags |= FLAG_CLEATS
     if not env.get("asset", {}).get("stl", True):  # kick_env.py:266-276: soccerbot_box*.urdf
         c.flags |= FLAG_BOX_ASSET
+    if env.get("urdfAsset", {}).get("fixBaseLink", False):  # kick_env.py:287
+        c.flags |= FLAG_FIX_BASE
     return c

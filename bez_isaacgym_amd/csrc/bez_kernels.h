@@ -721,8 +721,9 @@ BEZ_DEV void substep(const Params& P, const EnvDyn& D, EnvState& S, const float*
   chain_up<5, 6, CL>(P, D, S, target, E0, V0, ball, bc, sel, selfw, IA0, pA0, lds, lane, keep);    // left leg
   chain_up<11, 2, CL>(P, D, S, target, E0, V0, ball, bc, sel, selfw, IA0, pA0, lds, lane, keep);   // right arm
   chain_up<13, 6, CL>(P, D, S, target, E0, V0, ball, bc, sel, selfw, IA0, pA0, lds, lane, keep);   // right leg
-  // (d) root: I0^A a0 = -p0^A
+  // (d) root: I0^A a0 = -p0^A; urdfAsset.fixBaseLink (BEZ_FLAG_FIX_BASE): the torso is welded to the world, a0 = 0
   SV a0 = solve_spd6(IA0, svzero() - pA0);
+  if (P.flags & BEZ_FLAG_FIX_BASE) a0 = svzero();
   // (e) pass 3 + joint integration + contact forces
   V3 fl = mk(0, 0, 0);
   {

@@ -415,7 +415,10 @@ int launch_step(BezSim* s, const float* actions, hipStream_t stream, bool obs_on
   // observation noise and keep the action-noise snapshot
   const bool dr = has_dr(s) || s->cleats || s->dr_on;
   if constexpr (SIM && PRE == POST) {
-    if (s->kernel != 2) {
+    // urdfAsset.fixBaseLink (BEZ_FLAG_FIX_BASE): a test / debugging configuration of the reference (kick_env.py:287) -- served by the
+    // one-env-per-lane kernel, which carries the "root acceleration = 0" branch; in the 8-role-wave kernel that branch costs the default
+    // configuration 0.8 % (26.56 -> 26.78 us, same box: six more spilled VGPRs in a kernel at its 256-register ceiling)
+    if (s->kernel != 2 && !(s->cfg.flags & BEZ_FLAG_FIX_BASE)) {
       bez::launch_step_ws8(P, PRE, dr, s->cleats, stream);
       hipError_t e = hipGetLastError();
       if (e != hipSuccess) return fail(s, -2, "step_kernel_ws launch", e);

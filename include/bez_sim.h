@@ -82,6 +82,12 @@ extern "C" {
                                             nothing on the bez_kick path touches the ground with them before its fall reset): libbez_sim.so \
                                             refuses it with rc -5 */
 
+#define BEZ_FLAG_FIX_BASE 4096u /* urdfAsset.fixBaseLink: True (kick_env.py:287, bez_kick.yaml:83): the torso is welded to the world -- its spatial \
+                                   acceleration is zero instead of the 6 x 6 root solve's, its twist stays zero, the pose stays where reset put it; \
+                                   joints, contacts and the ball are unchanged.  (The reference's per-DOF sweep, test/test_kick_env.py:142-186, \
+                                   notes "better when fixBaseLink = True".)  A test configuration: stepped by the one-env-per-lane kernel \
+                                   (3.3 x 10^7 env-steps/s at 4096 envs), not by the 8-role-wave kernel of the default path. */
+
 #define BEZ_FLAG_LEAN_STEP 128u /* bez_sim_step / bez_sim_step_many keep only what the rollout reads (state, obs, reward, reset / progress / \
                                    timeout, DOF targets): the stores of the NET_CONTACT_FORCE rows, FEET and PREV_LIN_VEL -- 308 B of the \
                                    912 B an env-step writes -- are skipped, and those three tensors then hold the values of the last call \

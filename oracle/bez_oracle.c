@@ -659,6 +659,7 @@ static void dynamics(const BezSimConfig* c, const Env* e, real h, int mode, cons
   M6 I0 = IA[0];
   SV a0 = sv_scale(sv_add(pA[0], pS[0]), -1);
   chol6_solve(&I0, &a0, 1);
+  if (c->flags & BEZ_FLAG_FIX_BASE) memset(&a0, 0, sizeof(a0)); /* urdfAsset.fixBaseLink (kick_env.py:287): the torso is welded to the world */
   out->a0 = a0;
   /* pass 3 */
   SV acc[NL];

@@ -101,7 +101,7 @@ def test_product_does_not_import_oracle():
                 assert "bez_oracle" not in txt and "import oracle" not in txt and "from oracle" not in txt, os.path.join(dp, f)
 
 
-@pytest.mark.parametrize("path,value", [(("env", "urdfAsset", "fixBaseLink"), True), (("env", "urdfAsset", "disable_gravity"), True),
+@pytest.mark.parametrize("path,value", [(("env", "urdfAsset", "disable_gravity"), True),
                                         (("env", "urdfAsset", "angular_damping"), 0.05), (("env", "urdfAsset", "linear_damping"), 0.1),
                                         (("env", "plane", "restitution"), 0.3), (("env", "plane", "staticFriction"), 0.5),
                                         (("env", "controlFrequencyInv"), 0)])
@@ -134,3 +134,14 @@ def test_per_env_uniform_is_the_oracles_philox_and_shard_invariant():
             assert whole[g, k] == np.float32(w >> 8) * np.float32(1.0 / 16777216.0)
     assert np.array_equal(per_env_uniform(seed, range(100, 228), tag, 19), whole[100:228])
     assert 0.0 <= whole.min() and whole.max() < 1.0 and abs(whole.mean() - 0.5) < 0.02
+
+
+def test_fix_base_link_translates_to_its_flag():
+    """urdfAsset.fixBaseLink (kick_env.py:287, bez_kick.yaml:83) is modelled: BEZ_FLAG_FIX_BASE, the header's value."""
+    from bez_isaacgym_amd.utils.config import load_config
+    cfg = load_config(["task=bez_kick", "num_envs=8", "headless=True"])["task"]
+    assert not abi.config_from_task_cfg(cfg).flags & abi.FLAG_FIX_BASE
+    cfg["env"]["urdfAsset"]["fixBaseLink"] = True
+    assert abi.config_from_task_cfg(cfg).flags & abi.FLAG_FIX_BASE
+    hdr = open(os.path.join(ROOT, "include", "bez_sim.h")).read()
+    assert int(re.search(r"#define BEZ_FLAG_FIX_BASE (\d+)u", hdr).group(1)) == abi.FLAG_FIX_BASE

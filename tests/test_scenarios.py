@@ -105,3 +105,30 @@ def test_separating_axis_test_of_the_pair_log():
     Rx = quat_to_mat(qx)
     d = sep([0, 0, 0], I, [1.0, 0.05, 0.05], [0, 0.0, 0.4], Rx, [0.05, 1.0, 0.05])
     assert d == pytest.approx(0.4 / np.sqrt(2.0) - 0.05 * np.sqrt(2.0) - 0.05, abs=1e-9)
+
+
+def check_fixed_base_sweep(rows, root_before, root_after):
+    """The reference's form of the sweep ("better when fixBaseLink = True", test/test_kick_env.py:142-186): gravity on, the torso welded one
+    metre above the plane.  The torso does not move by a bit; every actuated DOF reaches both limits under its limb's weight and returns,
+    with the same two exceptions as the floating sweep (head joints never commanded, a hip rolling inward meets the other leg)."""
+    assert np.array_equal(root_before, root_after)
+    for r in rows:
+        assert r["finite"], r
+        if r["dof"] < 2:
+            assert r["miss_default"] < 1e-3 and r["miss_lower"] > 1.5, r
+        elif r["name"].endswith("leg_motor_1"):
+            assert 0.2 < r["miss_lower"] < 0.5 and r["miss_upper"] < 0.06 and r["miss_default"] < 0.06, r
+        else:
+            assert r["miss_lower"] < 0.06 and r["miss_upper"] < 0.06 and r["miss_default"] < 0.06, r
+
+
+def test_dof_sweep_with_a_fixed_base_oracle(model):
+    n = 2
+    cfg = abi.default_config(n, seed=3)
+    cfg.flags |= abi.FLAG_FIX_BASE
+    sim = make_backend("oracle", cfg)
+    sim.step(np.zeros((n, 18), np.float32))
+    rows = dof_sweep(sim, n, model, dofs=range(18))
+    root = sim.root_states.reshape(n, -1, 13)[:, 0].copy()
+    expect = np.zeros(13, np.float32); expect[2] = 1.0; expect[6] = 1.0     # where dof_sweep placed it
+    check_fixed_base_sweep(rows, np.tile(expect, (n, 1)), root)
