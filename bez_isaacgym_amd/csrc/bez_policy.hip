@@ -17,6 +17,7 @@
 #include <hip/hip_fp16.h>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <cstdlib>
 #include <cstring>
 
 #include <type_traits>
@@ -68,8 +69,8 @@ struct PolicyArgs {
 };
 #ifdef BEZ_PF_STAMPS
 #define PF_STAMP(k) do { if (a.stamps && blockIdx.x == 0 && threadIdx.x == 0) a.stamps[k] = __builtin_amdgcn_s_memtime(); } while (0)
-__device__ unsigned long long* g_pf_wave_stamps = nullptr;   // (layer tag, wave, phase) stamps of workgroup 0: entries [tag * 32 + wave * 4 + phase]
-#define PF_WSTAMP(tag, wave, ph) do { if (g_pf_wave_stamps && blockIdx.x == 0 && (threadIdx.x & 63) == 0) g_pf_wave_stamps[(tag) * 32 + (wave) * 4 + (ph)] = __builtin_amdgcn_s_memtime(); } while (0)
+__device__ unsigned long long* g_pf_wave_stamps = nullptr;   // (layer tag, wave, phase) stamps of workgroup 0: entries [tag * 64 + wave * 4 + phase]
+#define PF_WSTAMP(tag, wave, ph) do { if (g_pf_wave_stamps && blockIdx.x == 0 && (threadIdx.x & 63) == 0) g_pf_wave_stamps[(tag) * 64 + (wave) * 4 + (ph)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define PF_STAMP(k) do { } while (0)
 #define PF_WSTAMP(tag, wave, ph) do { } while (0)
@@ -305,11 +306,28 @@ __device__ __forceinline__ void store_row_groups(const f32x16& acc, _Float16 (*d
 }
 
 // dst[:, 0:Npad] = act(src[:, 0:K] W^T + b) for the 64 rows of the workgroup; this wave takes column blocks wave, wave + PF_WAVES, ...
-template <bool ELU, bool PK, int LDS, int LDD>
+template <bool ELU, bool PK, bool ONEHALF = false, int LDS, int LDD>
 __device__ __forceinline__ void layer(const _Float16 (*src)[LDS], _Float16 (*dst)[LDD], const _Float16* W, const _Float16* B, int in, int out, int wave,
                                       int lane, int tag = 0, int nw = PF_WAVES) {   // nw: waves of the workgroup (8, or 16 in the 4096-row forward kernels)
   const int r = lane & 31, h = lane >> 5;
   const int nblk = (out + 31) >> 5, npad = (out + 15) & ~15;  // (a narrow tile only covers the width padded to 16 columns)
+  if constexpr (PK && ONEHALF) {
+    // a 32-row tile (the forward-only / rollout kernels of <= 8192 rows): one MFMA chain per column block, the blocks dealt over the waves
+    const int ksteps = (in + 15) >> 4;
+    dispatch_ksteps(ksteps, [&](auto RP) {
+      for (int nb = wave; nb < nblk; nb += nw) {
+        const int cb = nb * 32 + 4 * h;
+        const Bias16 bias = load_bias16(B, cb, out);
+        f32x16 acc;
+        if (nb == wave) PF_WSTAMP(tag, wave, 0);
+        gemm_packed<LDS, true, 1, decltype(RP)::value>(src, W + (size_t)nb * ksteps * 512, ksteps, r, h, 0, &acc, &bias);
+        if (nb == wave) PF_WSTAMP(tag, wave, 1);
+        store_row_groups<ELU>(acc, dst, r, cb, npad);
+        if (nb == wave) PF_WSTAMP(tag, wave, 2);
+      }
+    });
+    return;
+  }
   if constexpr (PK) {
     const int ksteps = (in + 15) >> 4;
     // One 32-row half of a column block per wave where a layer has <= 4 column blocks (the 100-wide one: 4): half or more of the eight waves
@@ -393,13 +411,16 @@ __device__ __forceinline__ void heads(const PolicyArgs& a, const _Float16 (*src)
   }
 }
 
+__device__ __forceinline__ float head_bias(const PolicyArgs& a, int r) {
+  return r < a.num_actions ? (float)a.b_mu[r] : (r == a.num_actions ? (float)a.b_val[0] : 0.f);
+}
 template <bool ROLL, int LD>
 __device__ __forceinline__ void heads_half(const PolicyArgs& a, const _Float16 (*src)[LD], int in, float* tile, int64_t row0, int nrow, int lane, int half) {
   const int r = lane & 31, h = lane >> 5, A = a.num_actions, ksteps = (in + 15) >> 4;
   dispatch_ksteps(ksteps, [&](auto RP) {
     f32x16 acc;
     gemm_packed<LD, false, 1, decltype(RP)::value>(src, a.w_mu, ksteps, r, h, half, &acc);
-    const float bias = r < A ? (float)a.b_mu[r] : (r == A ? (float)a.b_val[0] : 0.f);
+    const float bias = head_bias(a, r);
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const int row = 32 * half + (i & 3) + 8 * (i >> 2) + 4 * h;
@@ -422,11 +443,15 @@ __device__ __forceinline__ void heads_half(const PolicyArgs& a, const _Float16 (
 // layer of 54-400-200-100 is then ONE round of units (13 column blocks; 14, 8 and 2 (block, row half) units) instead of two rounds of
 // double work on 8 waves; the kernel is a chain of per-layer latencies, and this halves the two longest links.
 constexpr int PF_FWD_WAVES = 16;
-template <int MODE, int LD0, int LD1, bool PK>
+template <int MODE, int LD0, int LD1, bool PK, int ROWS = PF_ROWS>
 __global__ __launch_bounds__(MODE == 2 ? PF_WAVES * 64 : PF_FWD_WAVES * 64, (MODE != 2 || (LD0 + LD1) * PF_ROWS * 2 <= 80 * 1024) ? 4 : 2) void policy_forward_kernel(PolicyArgs a) {
   constexpr bool ROLL = MODE == 1, TRAIN = MODE == 2;
-  __shared__ __attribute__((aligned(16))) _Float16 t0[PF_ROWS][LD0];
-  __shared__ __attribute__((aligned(16))) _Float16 t1[PF_ROWS][LD1];
+  // (32-row tiles for the TRAINING forward, 1024 workgroups at three per CU: 35.5-36.3 us against 31.3 -- every workgroup streams the whole weight
+  // set, and the stream doubles)
+  static_assert(ROWS == PF_ROWS || (ROWS == 32 && PK && MODE != 2), "32-row tiles: fragment-major weights, forward-only / rollout kernels");
+  constexpr bool ONEHALF = ROWS == 32;
+  __shared__ __attribute__((aligned(16))) _Float16 t0[ROWS][LD0];
+  __shared__ __attribute__((aligned(16))) _Float16 t1[ROWS][LD1];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   constexpr int nw = MODE == 2 ? PF_WAVES : PF_FWD_WAVES, nt = nw * 64;   // (= blockDim.x: the launches below)
   if (ROLL && a.dr_on && blockIdx.x == gridDim.x - 1) {
@@ -438,14 +463,14 @@ __global__ __launch_bounds__(MODE == 2 ? PF_WAVES * 64 : PF_FWD_WAVES * 64, (MOD
     bez::dr::dr_step(a.dr, scratch + 1, cap, scratch);
     return;
   }
-  const int64_t row0 = (int64_t)blockIdx.x * PF_ROWS;
-  const int nrow = (int)((a.n - row0) < (int64_t)PF_ROWS ? (a.n - row0) : (int64_t)PF_ROWS);
+  const int64_t row0 = (int64_t)blockIdx.x * ROWS;
+  const int nrow = (int)((a.n - row0) < (int64_t)ROWS ? (a.n - row0) : (int64_t)ROWS);
   PF_STAMP(0);
   // ROLL with the env's action noise (BezPpoActionNoise): the samples do not depend on the forward pass, so they are drawn HERE, in the
   // shadow of the observation loads: one Philox block + Box-Muller pair = four samples per thread (the block's 64 x A / 4 quads on its first
   // threads), parked in LDS until the epilogue (this mode's tiles leave 54 KB free).  Every element used to recompute its whole quad:
   // 4 x the generator work, +1.3 us on the launch.  (row0 * A is a multiple of 4: a workgroup's block starts on a quad.)
-  __shared__ float nzs[ROLL ? PF_ROWS * 32 : 1];
+  __shared__ float nzs[ROLL ? ROWS * 32 : 1];
   if (ROLL && a.an.snap_dev) {
     const bez::DrSnap sn = *static_cast<const bez::DrSnap*>(a.an.snap_dev);
     const unsigned long long frame = (unsigned long long)sn.frame_hi << 32 | sn.frame_lo;
@@ -465,7 +490,7 @@ __global__ __launch_bounds__(MODE == 2 ? PF_WAVES * 64 : PF_FWD_WAVES * 64, (MOD
     float mk = 0.f, sk = 1.f;
     if (a.mean && kin) { mk = (float)a.mean[k]; sk = sqrtf((float)a.var[k] + a.eps); }
 #pragma unroll 4
-    for (int rr = wave; rr < PF_ROWS; rr += nw) {
+    for (int rr = wave; rr < ROWS; rr += nw) {
       float v = 0.f;
       if (rr < nrow && kin) {
         v = a.obs[(row0 + rr) * a.d_in + k];
@@ -480,76 +505,23 @@ __global__ __launch_bounds__(MODE == 2 ? PF_WAVES * 64 : PF_FWD_WAVES * 64, (MOD
   }
   __syncthreads();
   PF_STAMP(1);
-  if (TRAIN) store_tile(t0, a.x0_out, row0, nrow, a.d_in, tid, nw);
-  int in = a.d_in;
-  for (int L = 0; L < a.nhid; L += 2) {
-    layer<true, PK>(t0, t1, a.w[L], a.b[L], in, a.width[L], wave, lane, L, nw);
-    PF_STAMP(2 + 2 * L);
-    // the next layer reads K padded to 16: columns width..pad16(width) were written as elu(0 + 0) = 0 by the padded column block
-    __syncthreads();
-    PF_STAMP(3 + 2 * L);
-    in = a.width[L];
-    if (TRAIN) store_tile(t1, a.act_out[L], row0, nrow, in, tid, nw);  // (moving these stores behind the next layer's product changed nothing: 31.5 -> 31.3 us)
-    if (L + 1 < a.nhid) {
-      layer<true, PK>(t1, t0, a.w[L + 1], a.b[L + 1], in, a.width[L + 1], wave, lane, L + 1, nw);
-      PF_STAMP(4 + 2 * L);
-      __syncthreads();
-      PF_STAMP(5 + 2 * L);
-      in = a.width[L + 1];
-      if (TRAIN) store_tile(t0, a.act_out[L + 1], row0, nrow, in, tid, nw);
-    }
-  }
-  const bool in_t1 = (a.nhid & 1) != 0;  // where the last hidden activations are; the other tile is free
-  float* tile = in_t1 ? reinterpret_cast<float*>(&t0[0][0]) : reinterpret_cast<float*>(&t1[0][0]);
-  if constexpr (PK) {
-    if (wave < 2) {   // two waves, one 32-row half each
-      if (in_t1) heads_half<ROLL>(a, t1, in, tile, row0, nrow, lane, wave);
-      else heads_half<ROLL>(a, t0, in, tile, row0, nrow, lane, wave);
-    }
-  } else if (wave == 0) {
-    if (in_t1) heads<ROLL, PK>(a, t1, in, tile, row0, nrow, lane);
-    else heads<ROLL, PK>(a, t0, in, tile, row0, nrow, lane);
-  }
-  PF_STAMP(14);
-  if (ROLL) {
-    // sampling, neglogp, clamp, rollout-buffer rows: one thread per (env, action), the per-env sum through the same LDS tile
-    __syncthreads();
+  __shared__ float ls_s[1];   // ROLL: the sum of log sigma (one number for every row)
+  if (ROLL && wave == nw - 1) {
+    // The last wave (idle in the layers of 54-400-200-100: 13, 7 and 4 column blocks) does what does not depend on the forward pass, in its shadow:
+    // the sum of log sigma in the reference's order, and the bookkeeping of the env step BEFORE this one.  (Both used to follow the heads: three
+    // dependent rounds of load latency at the end of every workgroup.)
     const int A = a.num_actions;
-    float* zz = tile + PF_ROWS * 33;  // (64, 32) squared standardised actions
-    static_assert(4 * PF_WAVES * 64 >= PF_ROWS * 31, "four elements per thread cover the block (at the smallest workgroup)");
-#pragma unroll
-    for (int it = 0; it < 4; ++it) {
-      const int idx = tid + it * nt;
-      if (idx >= nrow * A) break;
-      const int rr = idx / A, j = idx - rr * A;
-      const float m = tile[rr * 33 + j];
-      const float l = a.logstd[j], sg = expf(l), z = a.noise[(row0 + rr) * A + j];
-      const float x = fmaf(sg, z, m);
-      const int64_t o = (row0 + rr) * A + j;
-      float xe = fminf(fmaxf(x, -1.0f), 1.0f);   // what rl_games hands to env.step
-      if (a.an.snap_dev) xe = xe + nzs[idx];
-      const int64_t om = (row0 + rr) * a.ld_act + j;   // (the rollout rows may be strided: written straight into the env-major dataset)
-      a.mb_mu[om] = m; a.act[om] = x; a.act_env[o] = xe; a.sigma[om] = sg;
-      const float q = (x - m) / sg;  // as the reference computes it from the stored action
-      zz[rr * 32 + j] = q * q;
-    }
-    __syncthreads();
-    if (tid < nrow) {
-      float acc = 0.f, ls = 0.f;
-      for (int j = 0; j < A; ++j) { acc += zz[tid * 32 + j]; ls += a.logstd[j]; }
-      a.neglogp[(row0 + tid) * a.ld_one] = 0.5f * acc + 0.5f * 1.8378770664093453f * (float)A + ls;
-      float v = tile[tid * 33 + A];
-      if (a.vmean) v = sqrtf((float)a.vvar[0] + a.veps) * fminf(fmaxf(v, -5.0f), 5.0f) + (float)a.vmean[0];
-      a.mb_val[row0 + tid] = v;
-      if (!a.post.rew) a.mb_dones[row0 + tid] = a.dones[row0 + tid];
-    }
-    if (a.post.rew && tid < 64) {
-      // the env step BEFORE this one, as ppo_rollout_post_kernel (csrc/bez_ppo.hip): shaped reward with the time-out bootstrap on the value
-      // THAT step's policy launch stored, done flags as floats (also this step's rollout row), episode return / length, statistics.
-      // The env's reward / reset / time-out buffers still hold that step's results: the next env step runs behind this launch.
+    const float lj = lane < A ? a.logstd[lane] : 0.f;
+    float ls = 0.f;
+    for (int j = 0; j < A; ++j) ls += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, lj), j));
+    if (lane == 0) ls_s[0] = ls;
+    if (a.post.rew) {
+      // as ppo_rollout_post_kernel (csrc/bez_ppo.hip): shaped reward with the time-out bootstrap on the value THAT step's policy launch stored,
+      // done flags as floats (also this step's rollout row), episode return / length, statistics.  The env's reward / reset / time-out buffers
+      // still hold that step's results: the next env step runs behind this launch.
       const BezPpoRolloutPost& q = a.post;
-      const bool ok = tid < nrow;
-      const int64_t i = row0 + (ok ? tid : 0);
+      const bool ok = lane < nrow;
+      const int64_t i = row0 + (ok ? lane : 0);
       double c = 0.0, r = 0.0, l = 0.0;
       if (ok) {
         const float rw = q.rew[i];
@@ -565,8 +537,93 @@ __global__ __launch_bounds__(MODE == 2 ? PF_WAVES * 64 : PF_FWD_WAVES * 64, (MOD
       }
 #pragma unroll
       for (int o = 32; o > 0; o >>= 1) { c += __shfl_xor(c, o, 64); r += __shfl_xor(r, o, 64); l += __shfl_xor(l, o, 64); }
-      if (tid == 0 && c != 0.0) { atomicAdd(&q.ep_stats[0], c); atomicAdd(&q.ep_stats[1], r); atomicAdd(&q.ep_stats[2], l); }
+      if (lane == 0 && c != 0.0) { atomicAdd(&q.ep_stats[0], c); atomicAdd(&q.ep_stats[1], r); atomicAdd(&q.ep_stats[2], l); }
     }
+  }
+  if (TRAIN) store_tile(t0, a.x0_out, row0, nrow, a.d_in, tid, nw);
+  int in = a.d_in;
+  for (int L = 0; L < a.nhid; L += 2) {
+    layer<true, PK, ONEHALF>(t0, t1, a.w[L], a.b[L], in, a.width[L], wave, lane, L, nw);
+    PF_STAMP(2 + 2 * L);
+    // the next layer reads K padded to 16: columns width..pad16(width) were written as elu(0 + 0) = 0 by the padded column block
+    __syncthreads();
+    PF_STAMP(3 + 2 * L);
+    in = a.width[L];
+    if (TRAIN) store_tile(t1, a.act_out[L], row0, nrow, in, tid, nw);  // (moving these stores behind the next layer's product changed nothing: 31.5 -> 31.3 us)
+    if (L + 1 < a.nhid) {
+      layer<true, PK, ONEHALF>(t1, t0, a.w[L + 1], a.b[L + 1], in, a.width[L + 1], wave, lane, L + 1, nw);
+      PF_STAMP(4 + 2 * L);
+      __syncthreads();
+      PF_STAMP(5 + 2 * L);
+      in = a.width[L + 1];
+      if (TRAIN) store_tile(t0, a.act_out[L + 1], row0, nrow, in, tid, nw);
+    }
+  }
+  const bool in_t1 = (a.nhid & 1) != 0;  // where the last hidden activations are; the other tile is free
+  float* tile = in_t1 ? reinterpret_cast<float*>(&t0[0][0]) : reinterpret_cast<float*>(&t1[0][0]);
+  // ROLL: the sampling pass's operands are requested here, in front of the heads (one (env, action) element per thread and pass)
+  constexpr int NIT = ROLL ? (ROWS * 31 + nt - 1) / nt : 1;
+  [[maybe_unused]] float ez[NIT], el[NIT];
+  if (ROLL) {
+    const int A = a.num_actions;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int idx = tid + it * nt;
+      ez[it] = el[it] = 0.f;
+      if (idx < nrow * A) { ez[it] = a.noise[row0 * A + idx]; el[it] = a.logstd[idx % A]; }
+    }
+  }
+  if constexpr (PK) {
+    if (wave < (ONEHALF ? 1 : 2)) {   // two waves, one 32-row half each (a 32-row tile: one)
+      if (in_t1) heads_half<ROLL>(a, t1, in, tile, row0, nrow, lane, wave);
+      else heads_half<ROLL>(a, t0, in, tile, row0, nrow, lane, wave);
+    }
+  } else if (wave == 0) {
+    if (in_t1) heads<ROLL, PK>(a, t1, in, tile, row0, nrow, lane);
+    else heads<ROLL, PK>(a, t0, in, tile, row0, nrow, lane);
+  }
+  PF_STAMP(14);
+  if (ROLL) {
+    // sampling, neglogp, clamp, rollout-buffer rows: one thread per (env, action), the per-env sum through the same LDS tile
+    __syncthreads();
+    const int A = a.num_actions;
+    float* zz = tile + ROWS * 33;  // (rows, 36) squared standardised actions: 16-byte rows a bank group apart (stride 32 was a 32-way bank conflict per read)
+    static_assert(sizeof(float) * ROWS * (33 + 36) <= sizeof(_Float16) * ROWS * (LD0 < LD1 ? LD0 : LD1), "the free tile holds both");
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int idx = tid + it * nt;
+      if (idx >= nrow * A) break;
+      const int rr = idx / A, j = idx - rr * A;
+      const float m = tile[rr * 33 + j];
+      const float l = el[it], sg = expf(l), z = ez[it];
+      const float x = fmaf(sg, z, m);
+      const int64_t o = (row0 + rr) * A + j;
+      float xe = fminf(fmaxf(x, -1.0f), 1.0f);   // what rl_games hands to env.step
+      if (a.an.snap_dev) xe = xe + nzs[idx];
+      const int64_t om = (row0 + rr) * a.ld_act + j;   // (the rollout rows may be strided: written straight into the env-major dataset)
+      a.mb_mu[om] = m; a.act[om] = x; a.act_env[o] = xe; a.sigma[om] = sg;
+      const float q = (x - m) / sg;  // as the reference computes it from the stored action
+      zz[rr * 36 + j] = q * q;
+    }
+    __syncthreads();
+    PF_STAMP(13);
+    if (tid < nrow) {
+      float acc = 0.f;   // (the additions in the order j = 0, 1, ...: what the separate rollout kernel computes)
+      const float4* z4 = reinterpret_cast<const float4*>(zz + tid * 36);
+      for (int j = 0; j < A; j += 4) {
+        const float4 v = z4[j >> 2];
+        acc += v.x;
+        if (j + 1 < A) acc += v.y;
+        if (j + 2 < A) acc += v.z;
+        if (j + 3 < A) acc += v.w;
+      }
+      a.neglogp[(row0 + tid) * a.ld_one] = 0.5f * acc + 0.5f * 1.8378770664093453f * (float)A + ls_s[0];
+      float v = tile[tid * 33 + A];
+      if (a.vmean) v = sqrtf((float)a.vvar[0] + a.veps) * fminf(fmaxf(v, -5.0f), 5.0f) + (float)a.vmean[0];
+      a.mb_val[row0 + tid] = v;
+      if (!a.post.rew) a.mb_dones[row0 + tid] = a.dones[row0 + tid];
+    }
+    PF_STAMP(12);
   }
   PF_STAMP(15);
 }
@@ -824,7 +881,7 @@ __global__ void scatter_f16_kernel(const _Float16* __restrict__ src, const int32
 
 #ifdef BEZ_PF_STAMPS
 static unsigned long long* g_pf_stamps = nullptr;  // diagnostic build: device buffer of 16 stamps (tools/policy_stamp_probe.py)
-extern "C" void bez_ppo_policy_debug_stamps(unsigned long long* dev) {   // 16 phase stamps, then (layer, wave, phase) stamps: 16 + 32 * PF_MAXL entries
+extern "C" void bez_ppo_policy_debug_stamps(unsigned long long* dev) {   // 16 phase stamps, then (layer, wave, phase) stamps: 16 + 64 * PF_MAXL entries
   g_pf_stamps = dev;
   unsigned long long* w = dev ? dev + 16 : nullptr;
   (void)hipMemcpyToSymbol(HIP_SYMBOL(g_pf_wave_stamps), &w, sizeof(w));
@@ -860,6 +917,13 @@ static int fill_args(PolicyArgs& a, const float* obs_dev, int64_t n, int32_t num
   return 0;
 }
 
+// Forward-only / rollout launches of at most 8192 rows (<= 128 tiles of 64 on 256 CUs) run 32-row tiles: twice the workgroups, every
+// column block one MFMA chain.  BEZ_PF_ROWS=64 (read once) keeps the 64-row tiles for A/B runs.
+static bool small_batch(int64_t n) {
+  static const bool off = [] { const char* e = std::getenv("BEZ_PF_ROWS"); return e && std::atoi(e) == 64; }();
+  return !off && n <= 8192;
+}
+
 extern "C" int bez_ppo_policy_forward(const float* obs_dev, int64_t n, int32_t num_obs, const double* obs_mean_dev, const double* obs_var_dev, float obs_eps,
                                       int32_t num_hidden, const void* const* hidden_w_f16_dev, const void* const* hidden_b_f16_dev, const int32_t* hidden_width,
                                       const void* mu_w_f16_dev, const void* mu_b_f16_dev, int32_t num_actions, const void* value_w_f16_dev,
@@ -868,7 +932,8 @@ extern "C" int bez_ppo_policy_forward(const float* obs_dev, int64_t n, int32_t n
   if (!mu_dev || !value_dev || fill_args(a, obs_dev, n, num_obs, obs_mean_dev, obs_var_dev, obs_eps, num_hidden, hidden_w_f16_dev, hidden_b_f16_dev, hidden_width,
                                          mu_w_f16_dev, mu_b_f16_dev, num_actions, value_w_f16_dev, value_b_f16_dev)) return -1;
   a.mu = mu_dev; a.value = value_dev; a.packed = weights_packed;
-  if (weights_packed) hipLaunchKernelGGL((policy_forward_kernel<0, PF_LD, PF_LD, true>), dim3((unsigned)((n + PF_ROWS - 1) / PF_ROWS)), dim3(PF_FWD_WAVES * 64), 0, (hipStream_t)stream, a);
+  if (weights_packed && small_batch(n)) hipLaunchKernelGGL((policy_forward_kernel<0, PF_LD, PF_LD, true, 32>), dim3((unsigned)((n + 31) / 32)), dim3(PF_FWD_WAVES * 64), 0, (hipStream_t)stream, a);
+  else if (weights_packed) hipLaunchKernelGGL((policy_forward_kernel<0, PF_LD, PF_LD, true>), dim3((unsigned)((n + PF_ROWS - 1) / PF_ROWS)), dim3(PF_FWD_WAVES * 64), 0, (hipStream_t)stream, a);
   else hipLaunchKernelGGL((policy_forward_kernel<0, PF_LD, PF_LD, false>), dim3((unsigned)((n + PF_ROWS - 1) / PF_ROWS)), dim3(PF_FWD_WAVES * 64), 0, (hipStream_t)stream, a);
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
@@ -899,8 +964,11 @@ extern "C" int bez_ppo_policy_rollout_step(const float* obs_dev, int64_t n, int3
   }
   static_assert(sizeof(bez::dr::DrArgs) <= BEZ_DR_STEP_BYTES, "BezPpoDrStep blob of the C ABI too small");
   if (dr_step) { std::memcpy(&a.dr, dr_step, sizeof(a.dr)); a.dr_on = 1; if (a.dr.n <= 0 || !a.dr.st || a.dr.first) return -1; }
-  const unsigned grid = (unsigned)((n + PF_ROWS - 1) / PF_ROWS) + (dr_step ? 1u : 0u);   // + the randomisation workgroup
-  if (weights_packed) hipLaunchKernelGGL((policy_forward_kernel<1, PF_LD, PF_LD, true>), dim3(grid), dim3(PF_FWD_WAVES * 64), 0, (hipStream_t)stream, a);
+  const bool small = weights_packed && small_batch(n);
+  const int rows = small ? 32 : PF_ROWS;
+  const unsigned grid = (unsigned)((n + rows - 1) / rows) + (dr_step ? 1u : 0u);   // + the randomisation workgroup
+  if (small) hipLaunchKernelGGL((policy_forward_kernel<1, PF_LD, PF_LD, true, 32>), dim3(grid), dim3(PF_FWD_WAVES * 64), 0, (hipStream_t)stream, a);
+  else if (weights_packed) hipLaunchKernelGGL((policy_forward_kernel<1, PF_LD, PF_LD, true>), dim3(grid), dim3(PF_FWD_WAVES * 64), 0, (hipStream_t)stream, a);
   else hipLaunchKernelGGL((policy_forward_kernel<1, PF_LD, PF_LD, false>), dim3(grid), dim3(PF_FWD_WAVES * 64), 0, (hipStream_t)stream, a);
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }

@@ -277,11 +277,18 @@ __global__ void wgrad_reduce_kernel(const Args* __restrict__ Ap, int accumulate)
 // output element has exactly one writer, so with accumulate == 0 the launch WRITES the whole flat gradient (weights, biases, log-sigma)
 // and the statistics: the caller needs no clear in front of the step.
 constexpr int RA_MAXL = 8;
+// the bias-gradient blocks of the launch: 256 threads as RA_BROWS row lanes x RA_BCOLS columns.  512 per-workgroup partials (32768 rows) on 4 row
+// lanes were 128 dependent-latency loads per thread, 16 rounds of 8 in flight -- the longest workgroups of the launch by far.
+#ifndef BEZ_RA_BCOLS
+#define BEZ_RA_BCOLS 16
+#endif
+constexpr int RA_BCOLS = BEZ_RA_BCOLS, RA_BROWS = 256 / RA_BCOLS;
+static_assert(RA_BROWS % 4 == 0 && RA_BROWS * RA_BCOLS == 256, "row lanes in fours");
 struct BiasReduce { const float* partial; int prow, ptotal, nhid, num_actions, nwg; int poff[RA_MAXL]; float* bgrad[RA_MAXL]; float* bmu; float* bv; };
 struct LossReduce { const float* scratch; int A; unsigned int nblocks; float* grad_logstd; float* stats; };
 __global__ __launch_bounds__(256) void grad_reduce_all_kernel(const Args* __restrict__ Ap, int accumulate, int wx, int nwb, BiasReduce B, int nbb, LossReduce Ls,
                                                               float* __restrict__ normpart) {
-  __shared__ float sh[4][64];
+  __shared__ float sh[RA_BROWS][RA_BCOLS];
   __shared__ float nrm[2][4];
   const int b = blockIdx.x, tid = threadIdx.x;
   float mine = 0.f;      // the gradient element this thread wrote (0: none), for the block's share of the squared gradient norm
@@ -295,7 +302,7 @@ __global__ __launch_bounds__(256) void grad_reduce_all_kernel(const Args* __rest
       const float* p = A.partial + P.partial_off + i;
       float s = accumulate ? *d : 0.f;
       int k = 0;
-      for (; k + 8 <= P.splits; k += 8) {   // eight loads in flight, added in their fixed order
+      for (; k + 8 <= P.splits; k += 8) {   // eight loads in flight, added in their fixed order (16 / 32 in flight: no faster)
         float v[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) v[u] = p[(long long)(k + u) * n];
@@ -306,19 +313,21 @@ __global__ __launch_bounds__(256) void grad_reduce_all_kernel(const Args* __rest
       *d = s;
       mine = s;
     }
-  } else if (b < nwb + nbb) {   // bias gradients: 4 row lanes x 64 columns; a row lane sums every 4th workgroup's partial
-    const int l = tid & 63, rl = tid >> 6;
-    const int c = (b - nwb) * 64 + l;
+  } else if (b < nwb + nbb) {   // bias gradients: RA_BROWS row lanes x RA_BCOLS columns; a row lane sums every RA_BROWS-th workgroup's partial
+    const int l = tid % RA_BCOLS, rl = tid / RA_BCOLS;
+    const int c = (b - nwb) * RA_BCOLS + l;
     const int ncol = B.ptotal + B.num_actions + 1;
     float s = 0.f;
     if (c < ncol) {
 #pragma unroll 8
-      for (int w = rl; w < B.nwg; w += 4) s += B.partial[(size_t)w * B.prow + c];
+      for (int w = rl; w < B.nwg; w += RA_BROWS) s += B.partial[(size_t)w * B.prow + c];
     }
     sh[rl][l] = s;
     __syncthreads();
     if (rl == 0 && c < ncol) {
-      float t = (sh[0][l] + sh[1][l]) + (sh[2][l] + sh[3][l]);
+      float t = 0.f;
+#pragma unroll
+      for (int q = 0; q < RA_BROWS; q += 4) t += (sh[q][l] + sh[q + 1][l]) + (sh[q + 2][l] + sh[q + 3][l]);
       float* d;
       if (c >= B.ptotal) { const int k = c - B.ptotal; d = k < B.num_actions ? &B.bmu[k] : &B.bv[0]; }
       else {
@@ -475,7 +484,7 @@ static int reduce_all_geometry(const Args* H, int32_t num_hidden, const int32_t*
   if (!H || num_hidden <= 0 || num_hidden > RA_MAXL || !hidden_width || num_actions <= 0 || num_actions > 31) return -1;
   int tot = 0;
   for (int i = 0; i < num_hidden; ++i) tot += hidden_width[i];
-  *wx = (H->max_block + 255) / 256; *nwb = *wx * H->nparts; *nbb = (tot + num_actions + 1 + 63) / 64; *nlb = num_actions + 5;
+  *wx = (H->max_block + 255) / 256; *nwb = *wx * H->nparts; *nbb = (tot + num_actions + 1 + RA_BCOLS - 1) / RA_BCOLS; *nlb = num_actions + 5;
   return 0;
 }
 /* workgroups of bez_ppo_grad_reduce_all for this plan / network = pairs of floats it writes to norm_parts_dev */

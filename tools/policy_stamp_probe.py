@@ -20,7 +20,7 @@ mu_w, mu_b = (torch.randn(a, 100, device=dev) / 10).half().contiguous(), torch.z
 v_w, v_b = (torch.randn(1, 100, device=dev) / 10).half().contiguous(), torch.zeros(1, device=dev).half()
 obs = torch.randn(n, d, device=dev)
 mu, val = torch.empty(n, a, device=dev), torch.empty(n, 1, device=dev)
-stamps = torch.zeros(16 + 32 * 6, dtype=torch.int64, device=dev)
+stamps = torch.zeros(16 + 64 * 6, dtype=torch.int64, device=dev)
 lib.bez_ppo_policy_debug_stamps(C.c_void_p(stamps.data_ptr()))
 hw = (C.c_void_p * 3)(*[w.data_ptr() for w, _ in hid]); hb = (C.c_void_p * 3)(*[b.data_ptr() for _, b in hid]); wd = (C.c_int32 * 3)(*units)
 vp = C.c_void_p
@@ -43,6 +43,24 @@ if PACKED:  # fragment-major copies (the layout of include/bez_sim.h, weights_pa
     def run():
         return lib.bez_ppo_policy_forward(vp(obs.data_ptr()), n, d, None, None, 0.0, 3, C.cast(hw, vp), C.cast(hb, vp), C.cast(wd, vp), vp(heads_pk.data_ptr()),
                                           vp(mu_b.data_ptr()), a, vp(v_w.data_ptr()), vp(v_b.data_ptr()), vp(mu.data_ptr()), vp(val.data_ptr()), 1, None)
+if os.environ.get("ROLL"):   # the rollout-step form of the launch (sampling epilogue + the previous step's bookkeeping), contiguous rows
+    assert PACKED
+    f = lambda *sh: torch.zeros(*sh, device=dev)
+    logstd, noise, dones = f(a), torch.randn(n, a, device=dev), f(n)
+    mb_obs, mb_dones, mb_mu, mb_val, act, act_env, nlp, sig = f(n, d), f(n), f(n, a), f(n), f(n, a), f(n, a), f(n), f(n, a)
+    class Post(C.Structure):
+        _fields_ = [("rew", vp), ("reset", vp), ("timeouts", vp), ("prev_values", vp), ("reward_scale", C.c_float), ("gamma", C.c_float), ("bootstrap", C.c_int32),
+                    ("shaped", vp), ("dones_f", vp), ("cur_rew", vp), ("cur_len", vp), ("ep_stats", vp)]
+    keep = [f(n), torch.zeros(n, dtype=torch.int64, device=dev), torch.zeros(n, dtype=torch.int64, device=dev), f(n), f(n), f(n), f(n), f(n),
+            torch.zeros(3, dtype=torch.float64, device=dev)]
+    post = Post(keep[0].data_ptr(), keep[1].data_ptr(), keep[2].data_ptr(), keep[3].data_ptr(), 0.01, 0.99, 1, keep[4].data_ptr(), keep[5].data_ptr(),
+                keep[6].data_ptr(), keep[7].data_ptr(), keep[8].data_ptr())
+    P = lambda t: vp(t.data_ptr())
+    def run():
+        return lib.bez_ppo_policy_rollout_step(P(obs), C.c_int64(n), C.c_int32(d), None, None, C.c_float(0.0), C.c_int32(3), C.cast(hw, vp), C.cast(hb, vp), C.cast(wd, vp),
+                                               P(heads_pk), P(mu_b), C.c_int32(a), P(v_w), P(v_b), P(logstd), P(noise), P(dones), None, None, C.c_float(0.0),
+                                               P(mb_obs), P(mb_dones), P(mb_mu), P(mb_val), P(act), P(act_env), P(nlp), P(sig), C.c_int32(1),
+                                               C.byref(post) if os.environ["ROLL"] == "2" else None, None, None, None, None)
 for _ in range(20):
     assert run() == 0
 torch.cuda.synchronize()
@@ -53,13 +71,13 @@ for _ in range(200):
 e1.record(); torch.cuda.synchronize()
 print("kernel %.2f us per launch (n = %d, weights %s)" % (e0.elapsed_time(e1) * 1e3 / 200, n, "fragment-major" if PACKED else "row-major"))
 s = stamps.cpu().numpy()
-names = {0: "entry", 1: "obs staged + sync", 2: "layer 0 done (wave 0)", 3: "after sync", 4: "layer 1 done", 5: "after sync", 6: "layer 2 done", 7: "after sync", 14: "heads done", 15: "end"}
-for k in sorted(names):
+names = {0: "entry", 1: "obs staged + sync", 2: "layer 0 done (wave 0)", 3: "after sync", 4: "layer 1 done", 5: "after sync", 6: "layer 2 done", 7: "after sync", 13: "epilogue: sampled + sync", 12: "epilogue: per-row done", 14: "heads done", 15: "end"}
+for k in sorted(names, key=lambda k: s[k]):
     if s[k]:
         print("%-24s %8d" % (names[k], s[k] - s[0]))
 print("per wave (relative to entry): layer, wave: product start / product done / epilogue done [/ second block done]")
 for L in range(3):
-    for w in range(8):
-        v = s[16 + L * 32 + w * 4: 16 + L * 32 + w * 4 + 4]
+    for w in range(16):
+        v = s[16 + L * 64 + w * 4: 16 + L * 64 + w * 4 + 4]
         if v[0]:
             print("  L%d w%d  %s" % (L, w, "  ".join("%7d" % (x - s[0]) if x else "      -" for x in v)))
