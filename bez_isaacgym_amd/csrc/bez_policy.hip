@@ -417,10 +417,10 @@ __device__ __forceinline__ float head_bias(const PolicyArgs& a, int r) {
 template <bool ROLL, int LD>
 __device__ __forceinline__ void heads_half(const PolicyArgs& a, const _Float16 (*src)[LD], int in, float* tile, int64_t row0, int nrow, int lane, int half) {
   const int r = lane & 31, h = lane >> 5, A = a.num_actions, ksteps = (in + 15) >> 4;
+  const float bias = head_bias(a, r);   // requested ahead of the weight stream (behind the product it was a round trip of its own)
   dispatch_ksteps(ksteps, [&](auto RP) {
     f32x16 acc;
     gemm_packed<LD, false, 1, decltype(RP)::value>(src, a.w_mu, ksteps, r, h, half, &acc);
-    const float bias = head_bias(a, r);
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const int row = 32 * half + (i & 3) + 8 * (i >> 2) + 4 * h;
@@ -506,6 +506,7 @@ __global__ __launch_bounds__(MODE == 2 ? PF_WAVES * 64 : PF_FWD_WAVES * 64, (MOD
   __syncthreads();
   PF_STAMP(1);
   __shared__ float ls_s[1];   // ROLL: the sum of log sigma (one number for every row)
+  [[maybe_unused]] double ep_c = 0.0, ep_r = 0.0, ep_l = 0.0;   // wave nw - 1: this lane's share of the finished episodes' count / return / length
   if (ROLL && wave == nw - 1) {
     // The last wave (idle in the layers of 54-400-200-100: 13, 7 and 4 column blocks) does what does not depend on the forward pass, in its shadow:
     // the sum of log sigma in the reference's order, and the bookkeeping of the env step BEFORE this one.  (Both used to follow the heads: three
@@ -518,7 +519,8 @@ __global__ __launch_bounds__(MODE == 2 ? PF_WAVES * 64 : PF_FWD_WAVES * 64, (MOD
     if (a.post.rew) {
       // as ppo_rollout_post_kernel (csrc/bez_ppo.hip): shaped reward with the time-out bootstrap on the value THAT step's policy launch stored,
       // done flags as floats (also this step's rollout row), episode return / length, statistics.  The env's reward / reset / time-out buffers
-      // still hold that step's results: the next env step runs behind this launch.
+      // still hold that step's results: the next env step runs behind this launch.  (The three fp64 butterflies and the atomics follow behind
+      // the FIRST layer's barrier, in the window of the second layer: all of it here held that barrier up by 1.3 k cycles.)
       const BezPpoRolloutPost& q = a.post;
       const bool ok = lane < nrow;
       const int64_t i = row0 + (ok ? lane : 0);
@@ -535,11 +537,15 @@ __global__ __launch_bounds__(MODE == 2 ? PF_WAVES * 64 : PF_FWD_WAVES * 64, (MOD
         c = d; r = cr * d; l = cl * d;
         q.cur_rew[i] = cr * (1.0f - d); q.cur_len[i] = cl * (1.0f - d);
       }
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) { c += __shfl_xor(c, o, 64); r += __shfl_xor(r, o, 64); l += __shfl_xor(l, o, 64); }
-      if (lane == 0 && c != 0.0) { atomicAdd(&q.ep_stats[0], c); atomicAdd(&q.ep_stats[1], r); atomicAdd(&q.ep_stats[2], l); }
+      ep_c = c; ep_r = r; ep_l = l;
     }
   }
+  auto episode_sums = [&]() {   // (wave nw - 1, behind the first layer's barrier)
+    double c = ep_c, r = ep_r, l = ep_l;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { c += __shfl_xor(c, o, 64); r += __shfl_xor(r, o, 64); l += __shfl_xor(l, o, 64); }
+    if (lane == 0 && c != 0.0) { atomicAdd(&a.post.ep_stats[0], c); atomicAdd(&a.post.ep_stats[1], r); atomicAdd(&a.post.ep_stats[2], l); }
+  };
   if (TRAIN) store_tile(t0, a.x0_out, row0, nrow, a.d_in, tid, nw);
   int in = a.d_in;
   for (int L = 0; L < a.nhid; L += 2) {
@@ -548,6 +554,7 @@ __global__ __launch_bounds__(MODE == 2 ? PF_WAVES * 64 : PF_FWD_WAVES * 64, (MOD
     // the next layer reads K padded to 16: columns width..pad16(width) were written as elu(0 + 0) = 0 by the padded column block
     __syncthreads();
     PF_STAMP(3 + 2 * L);
+    if (ROLL && L == 0 && wave == nw - 1 && a.post.rew) episode_sums();
     in = a.width[L];
     if (TRAIN) store_tile(t1, a.act_out[L], row0, nrow, in, tid, nw);  // (moving these stores behind the next layer's product changed nothing: 31.5 -> 31.3 us)
     if (L + 1 < a.nhid) {
