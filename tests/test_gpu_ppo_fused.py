@@ -160,14 +160,18 @@ def test_policy_forward_kernel_against_an_fp32_reference_with_a_derived_bound(n,
         assert float(diff.mean()) < 5e-4, float(diff.mean())   # and on average far inside it: most elements see no rounding flip at all
 
 
-@pytest.mark.parametrize("n,normalize_value", [(4096, True), (333, False)])
-def test_policy_rollout_step_equals_forward_then_rollout_pre(n, normalize_value):
+@pytest.mark.parametrize("n,normalize_value,units", [
+    (4096, True, (400, 400, 200, 100)), (333, False, (400, 400, 200, 100)),
+    # the yaml's three hidden layers (the last activations end in the OTHER tile) at the edges of the 32-row tiling: one row, a tile minus / plus
+    # one row, the largest launch on 32-row tiles and the first on 64-row tiles (csrc/bez_policy.hip small_batch)
+    (1, True, (400, 200, 100)), (31, False, (400, 200, 100)), (33, True, (400, 200, 100)), (8192, False, (400, 200, 100)), (8193, True, (400, 200, 100))])
+def test_policy_rollout_step_equals_forward_then_rollout_pre(n, normalize_value, units):
     """bez_ppo_policy_rollout_step = bez_ppo_policy_forward + bez_ppo_rollout_pre in one launch: same mu / value / action /
     clamp / sigma / obs / dones rows bit for bit; neglogp differs only by the order of an 18-term fp32 sum."""
     from bez_isaacgym_amd.ppo import fused as F
     from bez_isaacgym_amd.ppo.a2c_continuous import RunningMeanStd
     torch.manual_seed(21)
-    d, units, a = 54, (400, 400, 200, 100), 18
+    d, a = 54, 18
     dims = [d] + list(units)
     hidden = [((torch.randn(dims[i + 1], dims[i], device=DEV) / dims[i] ** 0.5).half().contiguous(), (torch.randn(dims[i + 1], device=DEV) * 0.1).half())
               for i in range(len(units))]
@@ -200,7 +204,9 @@ def test_policy_rollout_step_equals_forward_then_rollout_pre(n, normalize_value)
             np.testing.assert_allclose(got[k].cpu(), want[k].cpu(), rtol=2e-6, atol=1e-5)
         else:
             np.testing.assert_array_equal(got[k].cpu().numpy(), want[k].cpu().numpy(), err_msg=k)
-    assert float(got["env_act"].abs().max()) <= 1.0 and float((got["act"].abs() > 1.0).float().mean()) > 0.01  # the clamp did something
+    assert float(got["env_act"].abs().max()) <= 1.0
+    if n >= 333:
+        assert float((got["act"].abs() > 1.0).float().mean()) > 0.01  # the clamp did something
 
 
 def _torch_loss(mu, logstd, value, mb, e, critic_coef, entropy_coef, bounds_coef, clip_value):
