@@ -219,7 +219,7 @@ def ppo_leg(args, rank, local_rank, world, n):
     venv = RLGPUEnv("rlgpu", n, env_creator=get_rlgames_env_creator(task, "bez_kick", dev, dev, 0, True))
     params = cfg["train"]["params"]
     params["config"].update(save_frequency=0, save_best_after=10 ** 9)
-    for k in ("dr_prelaunch", "fold_action_noise", "fold_rollout_post", "fused_dataset_prep", "fused_loss_backward", "dp_capture_collectives", "dp_grid_norm"):   # A/B switches of the rollout loop (default: all on)
+    for k in ("dr_prelaunch", "fold_action_noise", "fold_rollout_post", "fused_dataset_prep", "fused_loss_backward", "dp_capture_collectives", "dp_grid_norm", "dp_eager_update"):   # A/B switches of the rollout loop (default: all on)
         if os.environ.get("BEZ_PPO_" + k.upper()) is not None:
             params["config"][k] = os.environ["BEZ_PPO_" + k.upper()] == "1"
     params["config"]["minibatch_size"] = min(int(params["config"]["minibatch_size"]), n * int(params["config"]["horizon_length"]))

@@ -1309,6 +1309,8 @@ class A2CAgent:
 
     def run_update(self):
         if self.use_graphs and self._segmented and self._eager_epochs >= self.graph_warmup_epochs:
+            if self.cfg.get("dp_eager_update", False):   # A/B: the update's ~120 launches eagerly instead of S + 1 graph segments (the rollout stays a graph)
+                return self._update_impl()
             return self._update_segmented()
         if not self.use_graphs or self._eager_epochs < self.graph_warmup_epochs:
             self._update_impl()
