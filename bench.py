@@ -219,7 +219,7 @@ def ppo_leg(args, rank, local_rank, world, n):
     venv = RLGPUEnv("rlgpu", n, env_creator=get_rlgames_env_creator(task, "bez_kick", dev, dev, 0, True))
     params = cfg["train"]["params"]
     params["config"].update(save_frequency=0, save_best_after=10 ** 9)
-    for k in ("dr_prelaunch", "fold_action_noise", "fold_rollout_post", "fused_dataset_prep", "fused_loss_backward", "dp_capture_collectives", "dp_grid_norm", "dp_eager_update"):   # A/B switches of the rollout loop (default: all on)
+    for k in ("dr_prelaunch", "fold_action_noise", "fold_rollout_post", "fused_dataset_prep", "fused_loss_backward", "dp_capture_collectives", "dp_grid_norm", "dp_eager_update", "pipeline_epochs"):   # A/B switches of the rollout loop (default: all on)
         if os.environ.get("BEZ_PPO_" + k.upper()) is not None:
             params["config"][k] = os.environ["BEZ_PPO_" + k.upper()] == "1"
     params["config"]["minibatch_size"] = min(int(params["config"]["minibatch_size"]), n * int(params["config"]["horizon_length"]))
@@ -232,9 +232,17 @@ def ppo_leg(args, rank, local_rank, world, n):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     play = 0.0
+    pending = None   # epochs pipelined as A2CAgent.train() runs them: epoch k's report is read while epoch k + 1 is queued
     for _ in range(args.ppo_epochs):
-        st = agent.train_epoch()
-        play += st["play_time"]
+        ticket = agent.train_epoch_launch() if agent.cfg.get("pipeline_epochs", True) else None
+        if ticket is None:
+            play += agent.train_epoch()["play_time"]
+            continue
+        if pending is not None:
+            play += agent.train_epoch_finish(pending)["play_time"]
+        pending = ticket
+    if pending is not None:
+        play += agent.train_epoch_finish(pending)["play_time"]
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if world > 1:

@@ -1323,11 +1323,12 @@ class A2CAgent:
         else:
             self._g_update.replay()
 
-    def _drain_episode_stats(self, host=None):
+    def _drain_episode_stats(self, host=None, zero=True):
         """Finished-episode count / return / length sums of this epoch's rollout (host = the values already read back with the epoch
-        report; None: one device->host read of its own)."""
+        report; None: one device->host read of its own).  zero False: the caller has cleared the device sums already (pipelined epochs)."""
         cnt, rsum, lsum = self.ep_stats.tolist() if host is None else host
-        self.ep_stats.zero_()
+        if zero:
+            self.ep_stats.zero_()
         if cnt > 0:
             self._ep_hist.append((cnt, rsum, lsum))
             while len(self._ep_hist) > 1 and sum(c for c, _, _ in self._ep_hist[1:]) >= self.games_to_track:
@@ -1376,6 +1377,65 @@ class A2CAgent:
         return dict(play_time=t_play, update_time=t_total - t_play, total_time=t_total, kl=sum(kls) / len(kls),
                     a_loss=a_l, c_loss=c_l, lr=self.last_lr)
 
+    # ---- pipelined epochs: the host reads epoch k's report while epoch k + 1 is already queued.  train_epoch() ends in the epoch's one
+    # device-to-host copy and only then launches the next rollout: between the two the GPU waits for the host (wake-up from the copy, the
+    # report, the next epoch's fills / noise / graph launch) -- ~120 us of a 3.9 ms epoch in the kernel trace.  Here the report goes to a pinned
+    # buffer behind the epoch's kernels (two slots), the device sums are cleared in stream order, and the caller collects the report one epoch late.
+    def train_epoch_launch(self):
+        """Queues one epoch (rollout + update + the copy of its report) and returns a ticket for train_epoch_finish(); None where the epoch
+        report is not packed (CPU, unfused paths): the caller then uses train_epoch()."""
+        packed = self._report is not None and self.mb is not None and self.ep_stats.data_ptr() == self._report.data_ptr()
+        if not packed or self.device.type != "cuda":
+            return None
+        pipe = getattr(self, "_pipe", None)
+        if pipe is None:
+            pipe = self._pipe = [dict(ev=[torch.cuda.Event(enable_timing=True) for _ in range(3)], done=torch.cuda.Event(),
+                                      host=torch.zeros(self._report.numel(), dtype=self._report.dtype).pin_memory(), busy=False) for _ in range(2)]
+            self._pipe_next = 0
+        slot = self._pipe_next
+        st = pipe[slot]
+        assert not st["busy"], "train_epoch_finish() the ticket of two epochs ago first"
+        self._pipe_next = 1 - slot
+        st["t0"] = time.perf_counter()
+        ev = st["ev"]
+        ev[0].record()
+        self.play_steps()
+        ev[1].record()
+        self.run_update()
+        ev[2].record()
+        st["host"].copy_(self._report, non_blocking=True)
+        self.ep_stats.zero_()            # (stream order: behind the copy, in front of the next rollout's first count)
+        st["done"].record()
+        st["busy"] = True
+        self._eager_epochs += 1
+        self.epoch_num += 1
+        self.frame += self.batch_size * self.world
+        st["epoch"], st["frame"] = self.epoch_num, self.frame
+        self._weights_sig = self._weights_signature()
+        return slot
+
+    def train_epoch_finish(self, ticket):
+        """Waits for the epoch of `ticket` and returns what train_epoch() returns for it (+ "epoch", "frame"); total_time is the wall time since
+        the previous report (or since the epoch's launch, for the first)."""
+        st = self._pipe[ticket]
+        assert st["busy"]
+        st["done"].synchronize()
+        st["busy"] = False
+        rep = st["host"]
+        f32 = rep.view(torch.float32)
+        self.last_lr = float(f32[8])
+        kls = f32[12:12 + self.mini_epochs].tolist()
+        a_l, c_l = (f32[10:12] / (self.mini_epochs * self.num_minibatches)).tolist()
+        self._drain_episode_stats(rep[0:3].tolist(), zero=False)
+        now = time.perf_counter()
+        t_total = now - max(st["t0"], getattr(self, "_pipe_last_report", 0.0))
+        self._pipe_last_report = now
+        ev = st["ev"]
+        dev_play, dev_upd = ev[0].elapsed_time(ev[1]) * 1e-3, ev[1].elapsed_time(ev[2]) * 1e-3
+        t_play = t_total * dev_play / max(dev_play + dev_upd, 1e-9)
+        return dict(play_time=t_play, update_time=t_total - t_play, total_time=t_total, kl=sum(kls) / len(kls), a_loss=a_l, c_loss=c_l,
+                    lr=self.last_lr, epoch=st["epoch"], frame=st["frame"])
+
     def release_env(self):
         """Hands the env back to other consumers: lean stepping off, so env.net_contact_forces / feet / prev_lin_vel are
         current again after its next step (the agent switched them off for its rollouts)."""
@@ -1400,24 +1460,43 @@ class A2CAgent:
         self.obs = self.env_reset()
         max_epochs = max_epochs or self.max_epochs
         total_time = 0.0
-        while self.epoch_num < max_epochs:
-            st = self.train_epoch()
+        won = False
+
+        def report(st):   # one epoch's report: log line, observer, checkpoints, the stop rule
+            nonlocal total_time, won
             total_time += st["total_time"]
+            epoch, frame = st.get("epoch", self.epoch_num), st.get("frame", self.frame)
             mean_rew = sum(self.game_rewards) / len(self.game_rewards) if self.game_rewards else float("nan")
             if self.rank == 0:
                 fps = self.batch_size * self.world / st["total_time"]
                 log("epoch %d frames %d fps total %.0f (step %.0f) kl %.5f lr %.2e a_loss %.4f c_loss %.4f mean_reward %.3f" % (
-                    self.epoch_num, self.frame, fps, self.batch_size * self.world / st["play_time"], st["kl"], st["lr"],
+                    epoch, frame, fps, self.batch_size * self.world / st["play_time"], st["kl"], st["lr"],
                     st["a_loss"], st["c_loss"], mean_rew))
                 if self.writer is not None:
-                    self.writer.add(dict(epoch=self.epoch_num, frame=self.frame, time=total_time, fps=fps, mean_reward=mean_rew, **st))
-                if self.save_frequency and self.epoch_num % self.save_frequency == 0:
-                    self.save(os.path.join("runs", str(self.name), "nn", "last_%s_ep_%d.pth" % (self.name, self.epoch_num)))
-                if self.game_rewards and mean_rew > self.last_mean_rewards and self.epoch_num >= self.save_best_after:
+                    self.writer.add(dict(st, epoch=epoch, frame=frame, time=total_time, fps=fps, mean_reward=mean_rew))
+                if self.save_frequency and epoch % self.save_frequency == 0:
+                    self.save(os.path.join("runs", str(self.name), "nn", "last_%s_ep_%d.pth" % (self.name, epoch)))
+                if self.game_rewards and mean_rew > self.last_mean_rewards and epoch >= self.save_best_after:
+                    # (pipelined epochs: the weights saved are those behind the epoch in flight, one update further than the report that chose them)
                     self.last_mean_rewards = mean_rew
                     self.save(os.path.join("runs", str(self.name), "nn", "%s.pth" % self.name))
             if self.game_rewards and mean_rew > self.score_to_win:
-                break
+                won = True
+        pending = None
+        pipelined = bool(self.cfg.get("pipeline_epochs", True))
+        while self.epoch_num < max_epochs and not won:
+            ticket = self.train_epoch_launch() if pipelined else None
+            if ticket is None:
+                report(self.train_epoch())
+                continue
+            if pending is not None:
+                report(self.train_epoch_finish(pending))    # the epoch BEFORE the one just queued
+            pending = ticket
+            if self.save_frequency and self.epoch_num % self.save_frequency == 0:   # a periodic checkpoint holds exactly its epoch's weights
+                report(self.train_epoch_finish(pending))
+                pending = None
+        if pending is not None:
+            report(self.train_epoch_finish(pending))
         return self.last_mean_rewards, self.epoch_num
 
     # ------------------------------------------------------------------ checkpoints (rl_games key layout)

@@ -358,3 +358,52 @@ def test_fixed_base_hip_equals_oracle_and_the_torso_does_not_move(model):
     rows = dof_sweep(sim, n2, model)
     expect = np.zeros(13, np.float32); expect[2] = 1.0; expect[6] = 1.0
     check_fixed_base_sweep(rows, np.tile(expect, (n2, 1)), sim.root_states.reshape(n2, -1, 13)[:, 0])
+
+
+@pytest.mark.gpu
+def test_pipelined_epochs_train_to_the_same_bits_and_report_the_same_numbers():
+    """A2CAgent.train() reads epoch k's report while epoch k + 1 is queued (train_epoch_launch / train_epoch_finish): the same kernels in the
+    same stream order as train_epoch() one epoch at a time -- same weights, Adam moments and normaliser bit for bit through eager, capturing and
+    replayed epochs, and the same per-epoch report (KL, losses, learning rate, finished-episode sums cleared in stream order, not a report late)."""
+    import torch
+    from tests.test_gpu_round2 import _agent
+    n_ep = 7
+    reports = {}
+    states = {}
+    for mode in ("one_at_a_time", "pipelined"):
+        torch.manual_seed(5)
+        ag = _agent(512, 4096)
+        ag.obs = ag.env_reset()
+        reps, hist = [], []
+        if mode == "one_at_a_time":
+            for _ in range(n_ep):
+                reps.append(ag.train_epoch())
+                hist.append(list(ag._ep_hist[-1]) if ag._ep_hist else None)
+        else:
+            pending = None
+            for _ in range(n_ep):
+                t = ag.train_epoch_launch()
+                if t is None:      # the first epoch (the rollout buffers do not exist yet): one at a time, as A2CAgent.train() runs it
+                    assert pending is None and not reps
+                    reps.append(dict(ag.train_epoch(), epoch=ag.epoch_num, frame=ag.frame)); hist.append(list(ag._ep_hist[-1]) if ag._ep_hist else None)
+                    continue
+                if pending is not None:
+                    reps.append(ag.train_epoch_finish(pending)); hist.append(list(ag._ep_hist[-1]) if ag._ep_hist else None)
+                pending = t
+            reps.append(ag.train_epoch_finish(pending)); hist.append(list(ag._ep_hist[-1]) if ag._ep_hist else None)
+            assert [r["epoch"] for r in reps] == list(range(1, n_ep + 1)) and reps[-1]["frame"] == ag.frame
+        assert ag.use_graphs and ag._g_update is not None      # the later epochs were replays
+        torch.cuda.synchronize()
+        reports[mode] = [(r["kl"], r["a_loss"], r["c_loss"], r["lr"]) for r in reps], hist
+        states[mode] = ([p.detach().clone() for p in ag.model.parameters()], ag._mflat.clone(), ag._vflat.clone(),
+                        ag.running_mean_std.running_mean.clone(), float(ag.ep_stats.sum()))
+        ag.release_env()
+        del ag
+    assert reports["one_at_a_time"][0] == reports["pipelined"][0]
+    for a, b in zip(reports["one_at_a_time"][1], reports["pipelined"][1]):     # finished-episode sums: fp64 atomics, order-dependent in the last bits
+        assert (a is None) == (b is None)
+        if a is not None:
+            np.testing.assert_allclose(a, b, rtol=1e-12)
+    sa, sb = states["one_at_a_time"], states["pipelined"]
+    assert all(torch.equal(x, y) for x, y in zip(sa[0], sb[0])) and torch.equal(sa[1], sb[1]) and torch.equal(sa[2], sb[2]) and torch.equal(sa[3], sb[3])
+    assert sa[4] == sb[4] == 0.0     # both leave the device sums cleared
