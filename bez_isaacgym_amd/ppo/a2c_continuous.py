@@ -577,7 +577,8 @@ class A2CAgent:
                 self._packed_stale = False
         cur = self.obs  # step 0 reads the agent's copy; later steps read the env's own observation buffer (no per-step copy)
         vrms = self.value_mean_std if self.normalize_value else None
-        fx["noise"].normal_()  # the whole horizon's action noise in one launch
+        if not torch.cuda.is_current_stream_capturing():
+            fx["noise"].normal_()  # the whole horizon's action noise in one launch (replayed rollouts: drawn by play_steps in front of the replay)
         boot = self.value_bootstrap
         pending = None  # rollout_post arguments of the env step whose bookkeeping has not run yet
         fold = self._policy_fwd is not None and self.cfg.get("fold_rollout_post", True)
@@ -849,6 +850,7 @@ class A2CAgent:
                 self._g_rollout = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(self._g_rollout, pool=self._graph_pool()):
                     self._rollout_steps_fused()
+            self._draw_rollout_noise()
             self._g_rollout.replay()  # (capture only records: the freshly captured graph is replayed like any later one)
             self._rollout_impl(steps_done=True)
         elif not self.use_graphs or self._eager_epochs < self.graph_warmup_epochs:
@@ -858,10 +860,19 @@ class A2CAgent:
             self._g_rollout = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self._g_rollout, pool=self._graph_pool()):
                 self._rollout_impl()
+            self._draw_rollout_noise()
             self._g_rollout.replay()  # capture only records: the epoch that captures still has to run its rollout
         else:
+            self._draw_rollout_noise()
             self._g_rollout.replay()
         return self.dataset
+
+    def _draw_rollout_noise(self):
+        """The horizon's action noise, drawn eagerly in front of a rollout-graph replay: a graph that uses torch's generator makes every replay
+        fill the generator's seed / offset tensors first (two launches, ~9 us of the epoch); drawn outside, the captured rollout has no generator use."""
+        fx = getattr(self, "_fx", None)
+        if self.fused and fx is not None and "noise" in fx:
+            fx["noise"].normal_()
 
     def _graph_pool(self):
         if self._pool is None:
@@ -1250,9 +1261,18 @@ class A2CAgent:
         mb["_i"] = i  # row of the epoch's precomputed observation moments
         return mb
 
+    def _zero_update_sums(self):
+        acc = getattr(self, "_upd_sums", None)
+        if acc is None and self._report is not None and self.loss_acc.data_ptr() + 8 == self.kl_acc.data_ptr():
+            acc = self._upd_sums = self._report.view(torch.float32)[10:12 + self.mini_epochs]   # loss_acc | kl_acc: neighbours in the epoch report, one fill
+        if acc is not None:
+            acc.zero_()
+        else:
+            self.kl_acc.zero_(); self.loss_acc.zero_()
+
     def _update_impl(self):
         """mini_epochs x num_minibatches optimiser steps + the adaptive LR rule, all on the device."""
-        self.kl_acc.zero_(); self.loss_acc.zero_()
+        self._zero_update_sums()
         self._rms_preapplied = False
         last = self.mini_epochs * self.num_minibatches - 1
         for ep in range(self.mini_epochs):
@@ -1286,7 +1306,7 @@ class A2CAgent:
             self._rms_preapplied = False
             self._seg = seg
         seg = self._seg
-        self.kl_acc.zero_(); self.loss_acc.zero_()
+        self._zero_update_sums()
         seg["kl"].zero_()
         steps = self.mini_epochs * nm
 
