@@ -61,6 +61,15 @@ if os.environ.get("ROLL"):   # the rollout-step form of the launch (sampling epi
                                                P(heads_pk), P(mu_b), C.c_int32(a), P(v_w), P(v_b), P(logstd), P(noise), P(dones), None, None, C.c_float(0.0),
                                                P(mb_obs), P(mb_dones), P(mb_mu), P(mb_val), P(act), P(act_env), P(nlp), P(sig), C.c_int32(1),
                                                C.byref(post) if os.environ["ROLL"] == "2" else None, None, None, None, None)
+if os.environ.get("TRAIN"):   # the training forward (activations kept for the backward pass): 8 waves per 64-row tile, two workgroups per CU
+    assert PACKED
+    x0 = torch.empty(n, d, device=dev, dtype=torch.float16)
+    acts = [torch.empty(n, u, device=dev, dtype=torch.float16) for u in units]
+    ao = (C.c_void_p * 3)(*[t.data_ptr() for t in acts])
+    def run():
+        return lib.bez_ppo_policy_forward_train(vp(obs.data_ptr()), C.c_int64(n), C.c_int32(d), None, None, C.c_float(0.0), C.c_int32(3), C.cast(hw, vp), C.cast(hb, vp),
+                                                C.cast(wd, vp), vp(heads_pk.data_ptr()), vp(mu_b.data_ptr()), C.c_int32(a), vp(v_w.data_ptr()), vp(v_b.data_ptr()),
+                                                vp(x0.data_ptr()), C.cast(ao, vp), vp(mu.data_ptr()), vp(val.data_ptr()), C.c_int32(1), None)
 for _ in range(20):
     assert run() == 0
 torch.cuda.synchronize()
