@@ -20,6 +20,7 @@
 
 #include <cstdint>
 #include <atomic>
+#include <cstdlib>
 #include <cstring>
 
 #include "../../include/bez_sim.h"
@@ -436,7 +437,10 @@ int bez_ppo_wgrad_plan(const void* const* dy_f16_dev, const void* const* x_f16_d
   if (lds_bytes > 160 * 1024) return -3;
   // K-splits per block in proportion to its stream, ~250 workgroups in all (one round on 256 CUs), within the caller's scratch
   const int nstage = (int)(rows / KT);
-  const int target_wgs = 250;
+  // 254: with the rounding below 255 workgroups for bez_kickPPO.yaml's five layers -- every workgroup fewer is ~0.2 us more for the others (248 / 250 /
+  // 255 workgroups: 41.1 / 40.2-40.6 / 39.7-39.8 us on one box, tools/wgrad_target_ab.sh); a 257th would be a second round: trimmed below
+  static const int target_wgs = [] { const char* e = std::getenv("BEZ_WGRAD_TARGET_WGS"); const int v = e ? std::atoi(e) : 0; return v > 0 ? v : 254; }();   // (A/B knob)
+  constexpr int max_wgs = 256;   // one workgroup per CU, ONE round
   long long used = 0;
   int wg = 0, max_block = 0;
   for (int i = 0; i < np; ++i) {
@@ -446,6 +450,20 @@ int bez_ppo_wgrad_plan(const void* const* dy_f16_dev, const void* const* x_f16_d
     if (sp > nstage) sp = nstage;
     if (sp > nsplit) sp = nsplit;   // the caller's scratch holds nsplit images of every gradient
     P.splits = (int)sp; P.wg_begin = wg; P.partial_off = used;
+    wg += P.splits;
+    used += (long long)P.splits * P.gcols * P.xcols;
+    if (P.gcols * P.xcols > max_block) max_block = P.gcols * P.xcols;
+  }
+  while (wg > max_wgs) {   // the roundings added up to more than one round: take the split back where a workgroup has the fewest stages to gain
+    int k = -1;
+    for (int i = 0; i < np; ++i) if (A.part[i].splits > 1 && (k < 0 || A.part[i].splits > A.part[k].splits)) k = i;
+    if (k < 0) break;
+    --A.part[k].splits; --wg;
+  }
+  used = 0; wg = 0; max_block = 0;
+  for (int i = 0; i < np; ++i) {
+    Part& P = A.part[i];
+    P.wg_begin = wg; P.partial_off = used;
     wg += P.splits;
     used += (long long)P.splits * P.gcols * P.xcols;
     if (P.gcols * P.xcols > max_block) max_block = P.gcols * P.xcols;

@@ -292,7 +292,7 @@ class WgradMfma:
     """dW_L (+)= dY_L^T X_L for all Linear layers of the MLP in ONE split-K MFMA launch + one deterministic reduction
     (csrc/bez_wgrad.hip).  The work is laid out once per set of tensors (bez_ppo_wgrad_plan), the plan copied to the device once;
     `ok` is False when the kernel does not take the shapes (the caller then keeps its GEMM path)."""
-    NSPLIT = int(__import__("os").environ.get("BEZ_WGRAD_NSPLIT", "32"))   # images of every gradient the scratch holds = the most K-splits a block may get
+    NSPLIT = int(__import__("os").environ.get("BEZ_WGRAD_NSPLIT", "40"))   # images of every gradient the scratch holds = the most K-splits a block may get
     PLAN_BYTES = 3072
 
     def __init__(self, dys, xs, grads):
