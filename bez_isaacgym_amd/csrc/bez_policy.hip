@@ -506,46 +506,64 @@ __global__ __launch_bounds__(MODE == 2 ? PF_WAVES * 64 : PF_FWD_WAVES * 64, (MOD
   __syncthreads();
   PF_STAMP(1);
   __shared__ float ls_s[1];   // ROLL: the sum of log sigma (one number for every row)
-  [[maybe_unused]] double ep_c = 0.0, ep_r = 0.0, ep_l = 0.0;   // wave nw - 1: this lane's share of the finished episodes' count / return / length
-  if (ROLL && wave == nw - 1) {
-    // The last wave (idle in the layers of 54-400-200-100: 13, 7 and 4 column blocks) does what does not depend on the forward pass, in its shadow:
-    // the sum of log sigma in the reference's order, and the bookkeeping of the env step BEFORE this one.  (Both used to follow the heads: three
-    // dependent rounds of load latency at the end of every workgroup.)
+  [[maybe_unused]] double ep_c = 0.0, ep_r = 0.0, ep_l = 0.0;   // the bookkeeping wave: this lane's share of the finished episodes' count / return / length
+  // What does not depend on the forward pass runs on the two last waves, which the layers of 54-400-200-100 leave idle (13, 7 and 4 column blocks on
+  // 16 waves), in their shadow (it used to follow the heads: three dependent rounds of load latency at the end of every workgroup): the sum of log
+  // sigma in the reference's order on wave 14; on wave 15 the bookkeeping of the env step BEFORE this one, in two parts -- loads, shaping, stores behind
+  // the staging barrier; the three fp64 butterflies and the episode sums behind the first layer's barrier (all of it in the first window held that
+  // barrier up by 1.3 k cycles).
+  auto log_sigma_sum = [&]() {
     const int A = a.num_actions;
     const float lj = lane < A ? a.logstd[lane] : 0.f;
     float ls = 0.f;
     for (int j = 0; j < A; ++j) ls += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, lj), j));
     if (lane == 0) ls_s[0] = ls;
-    if (a.post.rew) {
-      // as ppo_rollout_post_kernel (csrc/bez_ppo.hip): shaped reward with the time-out bootstrap on the value THAT step's policy launch stored,
-      // done flags as floats (also this step's rollout row), episode return / length, statistics.  The env's reward / reset / time-out buffers
-      // still hold that step's results: the next env step runs behind this launch.  (The three fp64 butterflies and the atomics follow behind
-      // the FIRST layer's barrier, in the window of the second layer: all of it here held that barrier up by 1.3 k cycles.)
-      const BezPpoRolloutPost& q = a.post;
-      const bool ok = lane < nrow;
-      const int64_t i = row0 + (ok ? lane : 0);
-      double c = 0.0, r = 0.0, l = 0.0;
-      if (ok) {
-        const float rw = q.rew[i];
-        float sh = rw * q.reward_scale;
-        if (q.bootstrap) sh += q.gamma * q.prev_values[i] * (float)q.timeouts[i];
-        q.shaped[i] = sh;
-        const float d = (float)q.reset[i];
-        q.dones_f[i] = d;
-        a.mb_dones[i] = d;
-        const float cr = q.cur_rew[i] + rw, cl = q.cur_len[i] + 1.0f;
-        c = d; r = cr * d; l = cl * d;
-        q.cur_rew[i] = cr * (1.0f - d); q.cur_len[i] = cl * (1.0f - d);
-      }
-      ep_c = c; ep_r = r; ep_l = l;
+  };
+  auto bookkeeping = [&]() {
+    // as ppo_rollout_post_kernel (csrc/bez_ppo.hip): shaped reward with the time-out bootstrap on the value THAT step's policy launch stored,
+    // done flags as floats (also this step's rollout row), episode return / length.  The env's reward / reset / time-out buffers still hold that
+    // step's results: the next env step runs behind this launch.
+    const BezPpoRolloutPost& q = a.post;
+    const bool ok = lane < nrow;
+    const int64_t i = row0 + (ok ? lane : 0);
+    double c = 0.0, r = 0.0, l = 0.0;
+    if (ok) {
+      const float rw = q.rew[i];
+      float sh = rw * q.reward_scale;
+      if (q.bootstrap) sh += q.gamma * q.prev_values[i] * (float)q.timeouts[i];
+      q.shaped[i] = sh;
+      const float d = (float)q.reset[i];
+      q.dones_f[i] = d;
+      a.mb_dones[i] = d;
+      const float cr = q.cur_rew[i] + rw, cl = q.cur_len[i] + 1.0f;
+      c = d; r = cr * d; l = cl * d;
+      q.cur_rew[i] = cr * (1.0f - d); q.cur_len[i] = cl * (1.0f - d);
     }
-  }
-  auto episode_sums = [&]() {   // (wave nw - 1, behind the first layer's barrier)
+    ep_c = c; ep_r = r; ep_l = l;
+  };
+  auto episode_sums = [&]() {
     double c = ep_c, r = ep_r, l = ep_l;
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { c += __shfl_xor(c, o, 64); r += __shfl_xor(r, o, 64); l += __shfl_xor(l, o, 64); }
-    if (lane == 0 && c != 0.0) { atomicAdd(&a.post.ep_stats[0], c); atomicAdd(&a.post.ep_stats[1], r); atomicAdd(&a.post.ep_stats[2], l); }
+    for (int o = (ROWS < 64 ? ROWS : 64) / 2; o > 0; o >>= 1) { c += __shfl_xor(c, o, 64); r += __shfl_xor(r, o, 64); l += __shfl_xor(l, o, 64); }   // (lanes >= ROWS hold zeros)
+    if (lane == 0 && c != 0.0) {
+      if (a.post.ep_parts) {   // this workgroup's own slot: a plain read-modify-write (launches are stream-ordered, nobody else touches it)
+        double* p = a.post.ep_parts + 4 * (size_t)blockIdx.x;
+        p[0] += c; p[1] += r; p[2] += l;
+      } else {
+        atomicAdd(&a.post.ep_stats[0], c); atomicAdd(&a.post.ep_stats[1], r); atomicAdd(&a.post.ep_stats[2], l);
+      }
+    }
   };
+  // window w = behind the barrier of layer w - 1 (0: behind the staging barrier); with one hidden layer both parts run in window 1 at the latest
+  auto shadow_work = [&](int w) {
+    if (!ROLL) return;
+    if (w == 0 && wave == nw - 2) log_sigma_sum();
+    if (a.post.rew && wave == nw - 1) {
+      if (w == 0) bookkeeping();
+      if (w == 1) episode_sums();
+    }
+  };
+  shadow_work(0);
   if (TRAIN) store_tile(t0, a.x0_out, row0, nrow, a.d_in, tid, nw);
   int in = a.d_in;
   for (int L = 0; L < a.nhid; L += 2) {
@@ -554,7 +572,7 @@ __global__ __launch_bounds__(MODE == 2 ? PF_WAVES * 64 : PF_FWD_WAVES * 64, (MOD
     // the next layer reads K padded to 16: columns width..pad16(width) were written as elu(0 + 0) = 0 by the padded column block
     __syncthreads();
     PF_STAMP(3 + 2 * L);
-    if (ROLL && L == 0 && wave == nw - 1 && a.post.rew) episode_sums();
+    shadow_work(L + 1);
     in = a.width[L];
     if (TRAIN) store_tile(t1, a.act_out[L], row0, nrow, in, tid, nw);  // (moving these stores behind the next layer's product changed nothing: 31.5 -> 31.3 us)
     if (L + 1 < a.nhid) {

@@ -165,9 +165,21 @@ __global__ __launch_bounds__(PPO_TB) void ppo_rollout_pre_kernel(const IN* __res
 __global__ __launch_bounds__(PPO_TB) void ppo_rollout_post_kernel(const float* __restrict__ rew, const int64_t* __restrict__ dones, const int64_t* __restrict__ timeouts,
                                                                   const float* __restrict__ values, int64_t N, float reward_scale, float gamma, int bootstrap,
                                                                   float* __restrict__ shaped, float* __restrict__ dones_f, float* __restrict__ cur_rew,
-                                                                  float* __restrict__ cur_len, double* __restrict__ ep_stats) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+                                                                  float* __restrict__ cur_len, double* __restrict__ ep_stats, double* __restrict__ ep_parts,
+                                                                  int nslots) {
   double c = 0.0, r = 0.0, l = 0.0;
+  if (ep_parts && blockIdx.x == gridDim.x - 1) {
+    // one extra workgroup (bez_ppo_rollout_post_fold): the per-workgroup slots the policy launches of this rollout filled (BezPpoRolloutPost.ep_parts)
+    // are added to ep_stats and cleared
+    for (int s = (int)threadIdx.x; s < nslots; s += (int)blockDim.x) {
+      c += ep_parts[4 * s]; r += ep_parts[4 * s + 1]; l += ep_parts[4 * s + 2];
+      ep_parts[4 * s] = 0.0; ep_parts[4 * s + 1] = 0.0; ep_parts[4 * s + 2] = 0.0;
+    }
+    c = wave_sum(c); r = wave_sum(r); l = wave_sum(l);
+    if ((threadIdx.x & 63) == 0 && c != 0.0) { atomicAdd(&ep_stats[0], c); atomicAdd(&ep_stats[1], r); atomicAdd(&ep_stats[2], l); }
+    return;
+  }
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < N) {
     const float rw = rew[i];
     float s = rw * reward_scale;
@@ -861,7 +873,16 @@ int bez_ppo_rollout_post(const float* rew_dev, const int64_t* dones_dev, const i
                          double* ep_stats_dev, void* stream) {
   if (!rew_dev || !dones_dev || !timeouts_dev || !values_dev || !shaped_dev || !dones_f_dev || !cur_rew_dev || !cur_len_dev || !ep_stats_dev || n <= 0) return -1;
   hipLaunchKernelGGL(ppo_rollout_post_kernel, dim3(nblk(n)), dim3(PPO_TB), 0, (hipStream_t)stream, rew_dev, dones_dev, timeouts_dev, values_dev, n, reward_scale,
-                     gamma, (int)value_bootstrap, shaped_dev, dones_f_dev, cur_rew_dev, cur_len_dev, ep_stats_dev);
+                     gamma, (int)value_bootstrap, shaped_dev, dones_f_dev, cur_rew_dev, cur_len_dev, ep_stats_dev, (double*)nullptr, 0);
+  return launch_ok();
+}
+int bez_ppo_rollout_post_fold(const float* rew_dev, const int64_t* dones_dev, const int64_t* timeouts_dev, const float* values_dev, int64_t n, float reward_scale,
+                              float gamma, int32_t value_bootstrap, float* shaped_dev, float* dones_f_dev, float* cur_rew_dev, float* cur_len_dev,
+                              double* ep_stats_dev, double* ep_parts_dev, int32_t nslots, void* stream) {
+  if (!rew_dev || !dones_dev || !timeouts_dev || !values_dev || !shaped_dev || !dones_f_dev || !cur_rew_dev || !cur_len_dev || !ep_stats_dev || n <= 0 ||
+      !ep_parts_dev || nslots <= 0) return -1;
+  hipLaunchKernelGGL(ppo_rollout_post_kernel, dim3(nblk(n) + 1), dim3(PPO_TB), 0, (hipStream_t)stream, rew_dev, dones_dev, timeouts_dev, values_dev, n, reward_scale,
+                     gamma, (int)value_bootstrap, shaped_dev, dones_f_dev, cur_rew_dev, cur_len_dev, ep_stats_dev, ep_parts_dev, (int)nslots);
   return launch_ok();
 }
 int bez_ppo_loss(const float* mu_dev, const float* logstd_dev, const float* value_dev, const float* actions_dev, const float* old_logp_dev,

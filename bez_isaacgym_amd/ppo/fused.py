@@ -16,6 +16,7 @@ _SIGS = {
     "bez_ppo_rms_normalize": [_vp, _i64, _i32, _vp, _vp, _f, _vp, _i32, _vp],
     "bez_ppo_sample": [_vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp],
     "bez_ppo_rollout_post": [_vp, _vp, _vp, _vp, _i64, _f, _f, _i32, _vp, _vp, _vp, _vp, _vp, _vp],
+    "bez_ppo_rollout_post_fold": [_vp, _vp, _vp, _vp, _i64, _f, _f, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp],
     "bez_ppo_loss": [_vp] * 10 + [_i64, _i32, _f, _f, _f, _f, _i32] + [_vp] * 7,
     "bez_ppo_rollout_pre": [_vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _f, _i64, _i32, _i32] + [_vp] * 9,
     "bez_ppo_policy_forward": [_vp, _i64, _i32, _vp, _vp, _f, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _vp],
@@ -41,7 +42,7 @@ _SIGS = {
     "bez_ppo_grad_norm_parts": [_vp, _i64, _vp, _i32, _vp],
 }
 _lib = None
-PPO_ABI_VERSION = 7   # BEZ_PPO_ABI_VERSION (include/bez_sim.h)
+PPO_ABI_VERSION = 8   # BEZ_PPO_ABI_VERSION (include/bez_sim.h)
 
 
 def lib():
@@ -138,18 +139,40 @@ class RolloutPost(C.Structure):
     """BezPpoRolloutPost (include/bez_sim.h): the arguments of rollout_post() for the launch that carries them (PolicyForward.rollout_step)"""
     _fields_ = [("rew", C.c_void_p), ("reset", C.c_void_p), ("timeouts", C.c_void_p), ("prev_values", C.c_void_p), ("reward_scale", C.c_float),
                 ("gamma", C.c_float), ("bootstrap", C.c_int32), ("shaped", C.c_void_p), ("dones_f", C.c_void_p), ("cur_rew", C.c_void_p),
-                ("cur_len", C.c_void_p), ("ep_stats", C.c_void_p)]
+                ("cur_len", C.c_void_p), ("ep_stats", C.c_void_p), ("ep_parts", C.c_void_p)]
+
+    @staticmethod
+    def parts_numel(n):
+        """doubles of the per-workgroup slots (ep_parts) for launches of up to n rows: 4 per workgroup, the smallest tile has 32 rows"""
+        return 4 * ((n + 31) // 32 + 1)
 
     @classmethod
-    def of(cls, rew, dones, timeouts, values, reward_scale, gamma, bootstrap, shaped, dones_f, cur_rew, cur_len, ep_stats):
+    def of(cls, rew, dones, timeouts, values, reward_scale, gamma, bootstrap, shaped, dones_f, cur_rew, cur_len, ep_stats, ep_parts=None):
+        """ep_parts (fp64, parts_numel(n) zero-initialised elements): the launch adds each workgroup's finished-episode sums to that workgroup's own
+        slot instead of adding to ep_stats with atomics; the caller folds the slots into ep_stats (fold_episode_parts) once per rollout."""
         n = rew.numel()
         assert dones.numel() == timeouts.numel() == values.numel() == shaped.numel() == dones_f.numel() == cur_rew.numel() == cur_len.numel() == n
+        if ep_parts is not None:
+            assert ep_parts.dtype == torch.float64 and ep_parts.is_contiguous() and ep_parts.numel() >= cls.parts_numel(n)
         return cls(_p(rew).value, _p(dones, torch.int64).value, _p(timeouts, torch.int64).value, _p(values).value, float(reward_scale), float(gamma),
-                   1 if bootstrap else 0, _p(shaped).value, _p(dones_f).value, _p(cur_rew).value, _p(cur_len).value, _p(ep_stats, torch.float64).value)
+                   1 if bootstrap else 0, _p(shaped).value, _p(dones_f).value, _p(cur_rew).value, _p(cur_len).value, _p(ep_stats, torch.float64).value,
+                   None if ep_parts is None else _p(ep_parts, torch.float64).value)
 
 
-def rollout_post(rew, dones, timeouts, values, reward_scale, gamma, bootstrap, shaped, dones_f, cur_rew, cur_len, ep_stats):
+def fold_episode_parts(ep_stats, ep_parts):
+    """ep_stats[0:3] += the per-workgroup slots' column sums (fixed order), slots cleared: once per rollout, behind its last policy launch"""
+    ep_stats.add_(ep_parts.view(-1, 4)[:, :3].sum(0))
+    ep_parts.zero_()
+
+
+def rollout_post(rew, dones, timeouts, values, reward_scale, gamma, bootstrap, shaped, dones_f, cur_rew, cur_len, ep_stats, ep_parts=None):
+    """ep_parts: the slots RolloutPost.of(ep_parts=) launches filled -- one extra workgroup of this launch adds them to ep_stats and clears them"""
     n = rew.numel()
+    if ep_parts is not None:
+        _chk(lib().bez_ppo_rollout_post_fold(_p(rew), _p(dones, torch.int64), _p(timeouts, torch.int64), _p(values), n, float(reward_scale), float(gamma),
+                                             1 if bootstrap else 0, _p(shaped), _p(dones_f), _p(cur_rew), _p(cur_len), _p(ep_stats, torch.float64),
+                                             _p(ep_parts, torch.float64), ep_parts.numel() // 4, _stream(rew)), "bez_ppo_rollout_post_fold")
+        return
     _chk(lib().bez_ppo_rollout_post(_p(rew), _p(dones, torch.int64), _p(timeouts, torch.int64), _p(values), n, float(reward_scale), float(gamma),
                                     1 if bootstrap else 0, _p(shaped), _p(dones_f), _p(cur_rew), _p(cur_len), _p(ep_stats, torch.float64), _stream(rew)),
          "bez_ppo_rollout_post")

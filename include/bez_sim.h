@@ -324,7 +324,7 @@ int bez_sim_time_steps(BezSim* sim, const float* actions_dev, int32_t n_steps, v
 
 /* The signatures below change between rounds (round 3: scratch buffers of the fixed-order reductions, plan / run split of the weight
  * gradients, the optimiser tail's bookkeeping): a binding checks this number once after dlopen. */
-#define BEZ_PPO_ABI_VERSION 7
+#define BEZ_PPO_ABI_VERSION 8
 int32_t bez_ppo_abi_version(void);
 
 /* RunningMeanStd (normalize_input / normalize_value, bez_kickPPO.yaml:51-52): moments[0:D] = column sums, [D:2D] = sums of
@@ -353,6 +353,11 @@ int bez_ppo_rollout_pre(const void* mu_dev, const void* value_dev, int32_t input
 int bez_ppo_rollout_post(const float* rew_dev, const int64_t* dones_dev, const int64_t* timeouts_dev, const float* values_dev, int64_t n,
                          float reward_scale, float gamma, int32_t value_bootstrap, float* shaped_dev, float* dones_f_dev,
                          float* cur_rew_dev, float* cur_len_dev, double* ep_stats_dev, void* stream);
+/* ABI 8: the same launch with ONE EXTRA workgroup that adds the nslots per-workgroup slots of BezPpoRolloutPost.ep_parts (4 doubles each) to
+ * ep_stats and clears them -- the last bookkeeping launch of a rollout whose policy launches filled the slots. */
+int bez_ppo_rollout_post_fold(const float* rew_dev, const int64_t* dones_dev, const int64_t* timeouts_dev, const float* values_dev, int64_t n,
+                              float reward_scale, float gamma, int32_t value_bootstrap, float* shaped_dev, float* dones_f_dev, float* cur_rew_dev,
+                              float* cur_len_dev, double* ep_stats_dev, double* ep_parts_dev, int32_t nslots, void* stream);
 /* PPO minibatch loss (clipped surrogate, clipped value loss, entropy, bounds loss) AND its gradient w.r.t. the network
  * outputs mu (B,A), value (B) and the log-std parameter (A), multiplied by *loss_scale_dev (GradScaler; NULL = 1).
  * stats_dev[5] = sums of a_loss, c_loss, b_loss, KL(current || old), entropy over the minibatch.
@@ -387,6 +392,10 @@ typedef struct BezPpoRolloutPost {
   const float* rew; const int64_t* reset; const int64_t* timeouts; const float* prev_values;
   float reward_scale, gamma; int32_t bootstrap;
   float* shaped; float* dones_f; float* cur_rew; float* cur_len; double* ep_stats;
+  /* ABI 8 (NULL = the launch adds to ep_stats with atomics, as before): 4 doubles per workgroup of the launch (ceil(n / 32) of them at most), each
+   * workgroup ADDS its finished episodes' (count, return sum, length sum) to its own slot -- no atomics: 128-256 workgroups adding to one cache line
+   * cost the launch 1.7-3.2 us.  The caller adds the slots to ep_stats and clears them once per rollout. */
+  double* ep_parts;
 } BezPpoRolloutPost;
 /* action_noise (NULL = none; ABI 4): the env's action-noise lambda of the domain randomisation inside this launch -- env_actions_dev receives
  * clamp(a, -1, 1) + noise, bit for bit what bez_sim_add_dr_noise(which = 1) would add to the clamped actions (the three fields are what

@@ -137,6 +137,9 @@ def test_rollout_bookkeeping_inside_the_policy_launch_changes_nothing():
     assert torch.equal(a.dones, b.dones) and torch.equal(a.current_rewards, b.current_rewards) and torch.equal(a.current_lengths, b.current_lengths)
     np.testing.assert_allclose(a.ep_stats.cpu().numpy(), b.ep_stats.cpu().numpy(), rtol=1e-12)   # fp64 atomics: order-dependent in the last bits
     assert float(a.ep_stats[0]) > 0   # episodes did end (random initial policy falls within the horizon)
+    # round 5: b's policy launches add their finished-episode sums to per-workgroup slots (BezPpoRolloutPost.ep_parts, no atomics); the rollout's
+    # last bookkeeping launch folded them into ep_stats (compared above) and left them cleared
+    assert getattr(a, "_ep_parts", None) is not None and float(b._ep_parts.abs().sum()) == 0.0
 
 
 @pytest.mark.parametrize("fast", [{}, {"dr_prelaunch": True}])

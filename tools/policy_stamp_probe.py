@@ -50,11 +50,11 @@ if os.environ.get("ROLL"):   # the rollout-step form of the launch (sampling epi
     mb_obs, mb_dones, mb_mu, mb_val, act, act_env, nlp, sig = f(n, d), f(n), f(n, a), f(n), f(n, a), f(n, a), f(n), f(n, a)
     class Post(C.Structure):
         _fields_ = [("rew", vp), ("reset", vp), ("timeouts", vp), ("prev_values", vp), ("reward_scale", C.c_float), ("gamma", C.c_float), ("bootstrap", C.c_int32),
-                    ("shaped", vp), ("dones_f", vp), ("cur_rew", vp), ("cur_len", vp), ("ep_stats", vp)]
+                    ("shaped", vp), ("dones_f", vp), ("cur_rew", vp), ("cur_len", vp), ("ep_stats", vp), ("ep_parts", vp)]
     keep = [f(n), torch.zeros(n, dtype=torch.int64, device=dev), torch.zeros(n, dtype=torch.int64, device=dev), f(n), f(n), f(n), f(n), f(n),
             torch.zeros(3, dtype=torch.float64, device=dev)]
     post = Post(keep[0].data_ptr(), keep[1].data_ptr(), keep[2].data_ptr(), keep[3].data_ptr(), 0.01, 0.99, 1, keep[4].data_ptr(), keep[5].data_ptr(),
-                keep[6].data_ptr(), keep[7].data_ptr(), keep[8].data_ptr())
+                keep[6].data_ptr(), keep[7].data_ptr(), keep[8].data_ptr(), None)
     P = lambda t: vp(t.data_ptr())
     def run():
         return lib.bez_ppo_policy_rollout_step(P(obs), C.c_int64(n), C.c_int32(d), None, None, C.c_float(0.0), C.c_int32(3), C.cast(hw, vp), C.cast(hb, vp), C.cast(wd, vp),
