@@ -135,7 +135,7 @@ def dr_config_from_params(dr_params):
 # Contact / limit model constants of this build (no reference counterpart; DESIGN.md "Physics model")
 CONTACT_DEFAULTS = dict(contact_kn=2.0e4, contact_cn=20.0, contact_ct=1.0e3, contact_veps=0.01,
                         limit_k=200.0, limit_d=2.0, jfric_veps=0.1, ball_ang_damping=0.5,
-                        self_kn=3000.0, self_cn=5.0, ball_kn=0.0, ball_cn=0.0)
+                        self_kn=2.0e4, self_cn=5.0, ball_kn=0.0, ball_cn=0.0)
 
 
 def default_config(num_envs=4096, seed=42, env_id_offset=0):

@@ -455,7 +455,7 @@ int bez_sim_default_config(BezSimConfig* c, int32_t num_envs) {
   c->goal[0] = (float)BEZ_DEFAULT_GOAL[0]; c->goal[1] = (float)BEZ_DEFAULT_GOAL[1];
   c->contact_kn = 2.0e4f; c->contact_cn = 20.0f; c->contact_ct = 1.0e3f; c->contact_veps = 0.01f;
   c->limit_k = 200.0f; c->limit_d = 2.0f; c->jfric_veps = 0.1f; c->ball_ang_damping = 0.5f;
-  c->self_kn = 3000.0f; c->self_cn = 5.0f;
+  c->self_kn = 2.0e4f; c->self_cn = 5.0f;
   c->ball_kn = 0.0f; c->ball_cn = 0.0f;
   c->flags = BEZ_FLAG_IMU_PREV_ALIAS;
   c->seed = 42;

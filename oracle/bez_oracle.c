@@ -347,9 +347,11 @@ static int ground_contact(const BezSimConfig* c, real ckn, real ccn, real mu, re
 
 /* ---- leg <-> leg self-collision (kick_env.py:365-366: create_actor(..., collision_filter 0) enables it).
  * Each leg box is a capsule (bez_model_gen.h: BEZ_CAP_*); every left x right pair of BEZ_CPAIR is tested by the
- * closest points of the two segments.  A penetrating pair is one EXPLICIT spring-damper + regularised Coulomb point
- * contact with equal and opposite forces on the two links (momentum is conserved exactly).  Explicit because a
- * contact between two links of the same tree closes a kinematic loop that the ABA recursion cannot fold in. */
+ * closest points of the two segments.  A penetrating pair is a spring-damper + regularised Coulomb point contact with
+ * equal and opposite forces on the two links (momentum is conserved exactly).  A contact between two links of the same
+ * tree closes a kinematic loop that the ABA recursion cannot fold in, so the pairs' forces are evaluated from the state
+ * at the start of the substep -- lambda0 = k (depth - h u_n) - c u_n, the spring at the gap the CURRENT closing speed
+ * leads to -- and then scaled by ONE factor per env that stands for the implicit part (self_contact_scale below). */
 static void segment_closest(V3 p1, V3 q1, V3 p2, V3 q2, V3* c1, V3* c2) {
   V3 d1 = v3sub(q1, p1), d2 = v3sub(q2, p2), r = v3sub(p1, p2);
   real a = v3dot(d1, d1), e = v3dot(d2, d2), f = v3dot(d2, r);
@@ -364,7 +366,8 @@ static void segment_closest(V3 p1, V3 q1, V3 p2, V3 q2, V3* c1, V3* c2) {
   *c1 = v3add(p1, v3scale(d1, s));
   *c2 = v3add(p2, v3scale(d2, t));
 }
-static void self_collision(const BezSimConfig* c, real mu, const Kin* k, const SV* V, SV* pS, real cf[][3], int with_fric) {
+static void self_collision(const BezSimConfig* c, real hs, real mu, const Kin* k, const SV* V, SV* pS, real cf[][3], int with_fric) {
+  /* hs = the substep the spring looks ahead by (0: the round-5 explicit law, kept for the oracle-only solver families) */
   for (int pr = 0; pr < BEZ_NCPAIR; ++pr) {
     const int ia = BEZ_CPAIR[pr][0], ib = BEZ_CPAIR[pr][1];
     const int la = BEZ_CAP_LINK[ia], lb = BEZ_CAP_LINK[ib];
@@ -384,7 +387,7 @@ static void self_collision(const BezSimConfig* c, real mu, const Kin* k, const S
     V3 va = v3add(sv_lin(V[la]), v3cross(sv_ang(V[la]), x)), vb = v3add(sv_lin(V[lb]), v3cross(sv_ang(V[lb]), x));
     V3 u = v3sub(va, vb);
     real un = v3dot(u, n);
-    real fmag = (real)c->self_kn * depth - (real)c->self_cn * un;
+    real fmag = (real)c->self_kn * depth - (hs * (real)c->self_kn + (real)c->self_cn) * un;
     if (!(fmag > 0)) continue;
     V3 ut = v3sub(u, v3scale(n, un));
     real vt = sqrt(v3dot(ut, ut));
@@ -397,6 +400,36 @@ static void self_collision(const BezSimConfig* c, real mu, const Kin* k, const S
     V3 fr = with_fric ? f : fn;
     for (int i = 0; i < 3; ++i) { cf[m_link_body(c, la)][i] += fr.v[i]; cf[m_link_body(c, lb)][i] -= fr.v[i]; }
   }
+}
+
+/* The implicit part of the leg <-> leg contact (round 6).  The wrench pair of a contact between two links of the same tree does no work
+ * on the torso: it is exactly the joint torques tau_d = J_d lambda on the joints between the two links (J_d = d gap / d q_d).  An implicit
+ * spring-damper would be lambda = lambda0 - K (gap acceleration), K = h^2 k + h c, the gap acceleration being that of the solved step --
+ * which pass 2 cannot know.  What IS known once pass 2 has run, per joint: g_d = 1/D_d, the held-parent acceleration qdd_hp_d the
+ * saturation and speed-limit predictors use, and tau_d = S_d . (sum of the contact wrenches W_l on the links of joint d's subtree).  With
+ * every pair force scaled by the SAME s (equal and opposite pairs stay equal and opposite: momentum is conserved whatever s is), the
+ * lambda0-weighted implicit equation  s F2 = F2 - K (A_M + s A_S)  has the joint-space-diagonal estimates
+ *     A_M = sum_d tau_d qdd_hp_d            (how fast the gap would close with the contact switched off),
+ *     A_S = sum_d tau_d^2 g_d               (how fast the contact's own force opens it; F2 = sum of the pairs' |force|^2),
+ * and  s = (F2 - K A_M) / (F2 + BEZ_SELF_IMPLICIT K A_S),  clamped to [0, 8].  Exact for one pair acting on joints that do not recoil on
+ * each other; BEZ_SELF_IMPLICIT = 2 covers the recoil the diagonal leaves out (J M^-1 J^T against its diagonal part).  The scale is known
+ * BEFORE the root solve, so the scaled wrenches enter as the exact linear correction of pass 2's bias recursion they always were. */
+#define BEZ_SELF_IMPLICIT 2.0
+static real self_contact_scale(const BezSimConfig* c, real h, const SV* S, const SV* W, const real* g, const real* qdd_hp) {
+  SV Wsub[NL]; memcpy(Wsub, W, sizeof(Wsub));
+  real AM = 0, AS = 0, F2 = 0;
+  for (int l = NL - 1; l >= 1; --l) {
+    real t = sv_dot(S[l], Wsub[l]);
+    AS += t * t * g[l]; AM += t * qdd_hp[l];
+    Wsub[BEZ_LINK_PARENT[l]] = sv_add(Wsub[BEZ_LINK_PARENT[l]], Wsub[l]);
+    F2 += (real)0.5 * (W[l].v[3] * W[l].v[3] + W[l].v[4] * W[l].v[4] + W[l].v[5] * W[l].v[5]); /* each pair's force sits on two links */
+  }
+  if (!(F2 > 0)) return 0;
+  const real K = h * h * (real)c->self_kn + h * (real)c->self_cn;
+  real sc = (F2 - K * AM) / (F2 + (real)BEZ_SELF_IMPLICIT * K * AS);
+  if (!(sc > 0)) sc = 0;
+  if (sc > 8) sc = 8;
+  return sc;
 }
 
 /* ---- same-leg calf <-> foot-plate contact (BEZ_FLAG_ANKLE_STOP; kick_env.py:365-366: collision_filter 0 collides every non-adjacent
@@ -472,16 +505,18 @@ static void aba_pass1(const BezSimConfig* c, const Env* e, Pass1* P) {
 /* One evaluation of the build's dynamics model for one env at substep size h.
  * `mode` 0 = full model; 1 = bare ABA (no PD / friction / limits / contact / armature: used by the
  * known-answer tests, with tau_in as the applied joint torques). */
-static void dynamics(const BezSimConfig* c, const Env* e, real h, int mode, const real* tau_in, Dyn* out) {
+/* force_lock != NULL: the speed-limit locks are given (+1 / -1 / 0 per joint) instead of predicted: the active-set reference (dynamics) */
+static void dynamics_x(const BezSimConfig* c, const Env* e, real h, int mode, const real* tau_in, Dyn* out, const int* force_lock) {
   Pass1 P1;
   aba_pass1(c, e, &P1);
   const Kin k = P1.k;
   const int nb = m_nb(c); /* row of the ball */
   V3 g = v3(e->gravity[0], e->gravity[1], e->gravity[2]);
   SV *V = P1.V, *S = P1.S, *cb = P1.cb, *pA = P1.pA;
-  SV pS[NL]; /* explicit leg<->leg contact wrenches, propagated next to pA: the drive-saturation predictor below does not see them */
+  SV pS[NL]; /* leg<->leg contact wrenches (as bias forces), propagated next to pA: the predictors below do not see them */
+  SV Wself[NL]; real cfs[NBMAX][3]; /* the same as wrenches ON the links, and the contact-force rows they report: both scaled by self_contact_scale */
   M6* IA = P1.IA;
-  memset(pS, 0, sizeof(pS));
+  memset(pS, 0, sizeof(pS)); memset(Wself, 0, sizeof(Wself)); memset(cfs, 0, sizeof(cfs));
   memset(out->contact_force, 0, sizeof(out->contact_force));
 
   /* contacts (implicit spring-dampers folded into IA / pA) */
@@ -511,7 +546,8 @@ static void dynamics(const BezSimConfig* c, const Env* e, real h, int mode, cons
       }
     }
     if (!(c->flags & BEZ_FLAG_NO_SELF_COLLISION)) {
-      self_collision(c, mu, &k, V, pS, out->contact_force, (c->flags & BEZ_FLAG_CF_WITH_FRICTION) != 0);
+      self_collision(c, h, mu, &k, V, pS, cfs, (c->flags & BEZ_FLAG_CF_WITH_FRICTION) != 0);
+      for (int l = 0; l < NL; ++l) Wself[l] = sv_scale(pS[l], -1);
     }
     /* ball */
     real R = (real)BEZ_BALL_RADIUS, mb = (real)BEZ_BALL_MASS, Ib = (real)BEZ_BALL_INERTIA;
@@ -614,13 +650,22 @@ static void dynamics(const BezSimConfig* c, const Env* e, real h, int mode, cons
       stop_tau[AS.lf[i]] += AS.Jf[i] * AS.lam0[i]; stop_k[AS.lf[i]] += kimp * AS.Jf[i] * AS.Jf[i];
     }
   }
-  /* pass 2: articulated inertias, leaves -> root */
-  SV U[NL]; real Dinv[NL], u[NL];
+  /* pass 2: articulated inertias, leaves -> root.  Per joint the recursion keeps g = 1/D and w = (tau - S.pA)/D; pass 3 forms
+   * qdd = w - g U.(a_parent + c).  A joint on its speed limit (kick_env.py:327: velocity 2 pi rad/s) is the same recursion with
+   * g = 0 and w = the acceleration that puts its rate ON the limit at the end of the substep: a prescribed-rate joint, whose
+   * reaction reaches the parent through pA like any other joint force.  (Round 5 clamped the rate after the step instead, which
+   * took the link's momentum without reacting on anything.)  Which joints: those whose held-parent predictor -- the one the
+   * drive saturation uses -- sees the rate beyond the limit.  The predictor can miss (the parent's own acceleration decides as
+   * often as the joint's torque does): such a joint exceeds the limit for one substep and is caught by the next;
+   * tools/vlimit_probe.py has the rates, `dynamics` below the exact reference. */
+  SV U[NL]; real gj[NL], wj[NL], wS[NL], qdd_hp[NL];
   for (int l = NL - 1; l >= 1; --l) {
     int p = BEZ_LINK_PARENT[l], d = l - 1;
     U[l] = m6mulv(&IA[l], S[l]);
     real J = sv_dot(S[l], U[l]);
     real tau, D;
+    int lock = 0; real qdd_fix = 0;
+    const real Ucb = sv_dot(U[l], cb[l]);
     if (mode == 0) {
       J += (real)c->armature;
       real kp = (real)c->kp * e->kp_scale[d], kdm = (real)c->kd * e->kd_scale[d];
@@ -634,30 +679,40 @@ static void dynamics(const BezSimConfig* c, const Env* e, real h, int mode, cons
       else if (e->q[d] > hi) { tau_l0 = (real)c->limit_k * (hi - e->q[d] - h * e->qd[d]) - (real)c->limit_d * e->qd[d]; k_l = h * h * (real)c->limit_k + h * (real)c->limit_d; }
       tau_l0 += stop_tau[l]; k_l += stop_k[l];
       /* effort-limit predictor: joint acceleration with the parent held (a_parent = 0) */
-      real bias = sv_dot(S[l], pA[l]) + sv_dot(U[l], cb[l]);
+      real bias = sv_dot(S[l], pA[l]) + Ucb;
       real qdd_est = (tau_pd0 + tau_f0 + tau_l0 - bias) / (J + k_pd + k_f + k_l);
       real tau_drive = tau_pd0 - k_pd * qdd_est;
       real eff = (real)c->effort;
       if (tau_drive > eff) { tau = eff + tau_f0 + tau_l0; D = J + k_f + k_l; }
       else if (tau_drive < -eff) { tau = -eff + tau_f0 + tau_l0; D = J + k_f + k_l; }
       else { tau = tau_pd0 + tau_f0 + tau_l0; D = J + k_pd + k_f + k_l; }
+      /* speed-limit predictor, the same kind: the rate the joint would have at the end of the substep with the parent held */
+      real vl = (real)c->vel_limit, v_pred = e->qd[d] + h * (tau - bias) / D;
+      if (force_lock) { lock = force_lock[d] != 0; if (lock) qdd_fix = ((force_lock[d] > 0 ? vl : -vl) - e->qd[d]) / h; }
+      else if (v_pred > vl) { lock = 1; qdd_fix = (vl - e->qd[d]) / h; }
+      else if (v_pred < -vl) { lock = 1; qdd_fix = (-vl - e->qd[d]) / h; }
     } else {
       tau = tau_in ? tau_in[d] : 0;
       D = J;
     }
-    Dinv[l] = 1 / D;
-    real u_main = tau - sv_dot(S[l], pA[l]), du = -sv_dot(S[l], pS[l]);
-    u[l] = u_main + du;
+    const real u_main = tau - sv_dot(S[l], pA[l]), du = -sv_dot(S[l], pS[l]);
+    if (lock) { gj[l] = 0; wj[l] = qdd_fix; qdd_hp[l] = qdd_fix; }
+    else { gj[l] = 1 / D; wj[l] = u_main * gj[l]; qdd_hp[l] = (u_main - Ucb) * gj[l]; }
+    wS[l] = du * gj[l];
     M6 Ia = IA[l];
-    for (int i = 0; i < 6; ++i) for (int j = 0; j < 6; ++j) Ia.m[i][j] -= U[l].v[i] * U[l].v[j] * Dinv[l];
-    SV pa = sv_add(pA[l], sv_add(m6mulv(&Ia, cb[l]), sv_scale(U[l], u_main * Dinv[l])));
+    for (int i = 0; i < 6; ++i) for (int j = 0; j < 6; ++j) Ia.m[i][j] -= U[l].v[i] * U[l].v[j] * gj[l];
+    SV pa = sv_add(pA[l], sv_add(m6mulv(&Ia, cb[l]), sv_scale(U[l], wj[l])));
     for (int i = 0; i < 6; ++i) for (int j = 0; j < 6; ++j) IA[p].m[i][j] += Ia.m[i][j];
     pA[p] = sv_add(pA[p], pa);
-    pS[p] = sv_add(pS[p], sv_add(pS[l], sv_scale(U[l], du * Dinv[l])));
+    pS[p] = sv_add(pS[p], sv_add(pS[l], sv_scale(U[l], wS[l])));
   }
+  /* the leg<->leg forces' common scale, then their (linear) share of the joint accelerations and of the torso's bias */
+  const real sc = mode == 0 ? self_contact_scale(c, h, S, Wself, gj, qdd_hp) : 0;
+  for (int l = 1; l < NL; ++l) wj[l] += sc * wS[l];
+  for (int b = 0; b < NBMAX; ++b) for (int i = 0; i < 3; ++i) out->contact_force[b][i] += sc * cfs[b][i];
   /* root */
   M6 I0 = IA[0];
-  SV a0 = sv_scale(sv_add(pA[0], pS[0]), -1);
+  SV a0 = sv_scale(sv_add(pA[0], sv_scale(pS[0], sc)), -1);
   chol6_solve(&I0, &a0, 1);
   if (c->flags & BEZ_FLAG_FIX_BASE) memset(&a0, 0, sizeof(a0)); /* urdfAsset.fixBaseLink (kick_env.py:287): the torso is welded to the world */
   out->a0 = a0;
@@ -667,7 +722,7 @@ static void dynamics(const BezSimConfig* c, const Env* e, real h, int mode, cons
   for (int l = 1; l < NL; ++l) {
     int p = BEZ_LINK_PARENT[l];
     SV ap = sv_add(acc[p], cb[l]);
-    real qdd = (u[l] - sv_dot(U[l], ap)) * Dinv[l];
+    real qdd = wj[l] - gj[l] * sv_dot(U[l], ap);
     out->qdd[l - 1] = qdd;
     acc[l] = sv_add(ap, sv_scale(S[l], qdd));
   }
@@ -718,6 +773,24 @@ static void dynamics(const BezSimConfig* c, const Env* e, real h, int mode, cons
       }
       out->contact_force[nb][2] += bhit.fn0 - bhit.kn * ap.v[2];
     }
+  }
+}
+
+/* One evaluation of the model.  tune[22] = n > 0 (ORACLE ONLY; libbez_sim.so refuses every non-zero tune[] entry): the speed-limit locks
+ * are found by an active-set iteration of up to n passes (a joint that ends beyond the limit is locked and the dynamics re-evaluated;
+ * locks are only added) instead of by the predictor -- the reference the predictor's misses are measured against. */
+static void dynamics(const BezSimConfig* c, const Env* e, real h, int mode, const real* tau_in, Dyn* out) {
+  const int npass = (int)c->tune[22];
+  if (mode != 0 || npass <= 0) { dynamics_x(c, e, h, mode, tau_in, out, NULL); return; }
+  int lock[ND]; memset(lock, 0, sizeof(lock));
+  for (int it = 0; it < npass; ++it) {
+    dynamics_x(c, e, h, mode, tau_in, out, lock);
+    int changed = 0;
+    for (int d = 0; d < ND; ++d) {
+      real v = e->qd[d] + h * out->qdd[d], vl = (real)c->vel_limit;
+      if (!lock[d]) { if (v > vl * (1 + (real)1e-9)) { lock[d] = 1; changed = 1; } else if (v < -vl * (1 + (real)1e-9)) { lock[d] = -1; changed = 1; } }
+    }
+    if (!changed) break;
   }
 }
 
@@ -800,7 +873,7 @@ static void dynamics_hard(const BezSimConfig* c, const Env* e, real h, DynH* out
   /* explicit leg <-> leg penalty contact, as in the compliant model */
   SV pS[NL]; memset(pS, 0, sizeof(pS));
   if (!(c->flags & BEZ_FLAG_NO_SELF_COLLISION))
-    self_collision(c, mu, k, V, pS, out->contact_force, (c->flags & BEZ_FLAG_CF_WITH_FRICTION) != 0);
+    self_collision(c, 0, mu, k, V, pS, out->contact_force, (c->flags & BEZ_FLAG_CF_WITH_FRICTION) != 0);
 
   /* ---- contact detection */
   HContact C[HC_MAXC]; int nc = 0;
@@ -1084,12 +1157,10 @@ static void substep(const BezSimConfig* c, Env* e, real h, int first, real wgt) 
   if (c->flags & BEZ_FLAG_HARD_CONTACT) { substep_hard(c, e, h, first, wgt); return; }
   Dyn d;
   dynamics(c, e, h, 0, NULL, &d);
-  /* joints: semi-implicit Euler + velocity clamp (kick_env.py:327 velocity limit) */
+  /* joints: semi-implicit Euler.  The speed limit (kick_env.py:327) is inside the dynamics (a prescribed-rate joint in pass 2):
+   * no rate is edited here */
   for (int j = 0; j < ND; ++j) {
     real v = e->qd[j] + h * d.qdd[j];
-    real vl = (real)c->vel_limit;
-    if (v > vl) v = vl;
-    if (v < -vl) v = -vl;
     e->qd[j] = v;
     e->q[j] += h * v;
   }

@@ -117,3 +117,103 @@ def dof_sweep(sim, n, model, speed=3.0, hold=25, dofs=range(18)):
         out.append(dict(dof=int(d), name=JOINT_ORDER[d], miss_lower=float(miss_lo.max()), miss_upper=float(miss_hi.max()),
                         miss_default=float(back.max()), finite=bool(np.isfinite(q).all())))
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# round 6: the two defects of the round-5 model (missing 2) as a scenario with numbers
+def body_momenta(sim, n, model):
+    """Linear momentum and angular momentum about the centre of mass of every env's robot, from the Isaac-visible rigid-body rows
+    (origin velocity, spin) and the URDF masses / inertias -- independent of the step's own articulated-body quantities."""
+    links = model["links"]
+    mass = np.array([L["mass"] for L in links]); com = np.array([L["com"] for L in links]); body = np.array([L["body"] for L in links])
+    inertia = np.array([[[L["inertia"][0], L["inertia"][3], L["inertia"][4]], [L["inertia"][3], L["inertia"][1], L["inertia"][5]],
+                         [L["inertia"][4], L["inertia"][5], L["inertia"][2]]] for L in links])
+    rb = sim.rigid_body_states.reshape(n, -1, 13).astype(np.float64)[:, body]
+    q = rb[..., 3:7]
+    x, y, z, w = q[..., 0], q[..., 1], q[..., 2], q[..., 3]
+    R = np.stack([np.stack([1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)], -1),
+                  np.stack([2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)], -1),
+                  np.stack([2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)], -1)], -2)
+    rc = np.einsum("nlij,lj->nli", R, com)
+    pc = rb[..., 0:3] + rc
+    vc = rb[..., 7:10] + np.cross(rb[..., 10:13], rc)
+    p = (mass[None, :, None] * vc).sum(1)
+    cm = (mass[None, :, None] * pc).sum(1) / mass.sum()
+    Iw = np.einsum("nlij,ljk,nlmk->nlim", R, inertia, R)
+    L = (np.cross(pc - cm[:, None], mass[None, :, None] * vc) + np.einsum("nlij,nlj->nli", Iw, rb[..., 10:13])).sum(1)
+    return p, L
+
+
+def _seg_closest(p1, q1, p2, q2):
+    """closest points of two segments, batched (Ericson 5.1.9; the oracle's `segment_closest`)"""
+    d1, d2, r = q1 - p1, q2 - p2, p1 - p2
+    a = (d1 * d1).sum(-1); e = (d2 * d2).sum(-1); f = (d2 * r).sum(-1); c = (d1 * r).sum(-1); b = (d1 * d2).sum(-1)
+    den = a * e - b * b
+    s = np.clip(np.where(den > 1e-12, (b * f - c * e) / np.maximum(den, 1e-30), 0.0), 0, 1)
+    t = (b * s + f) / e
+    s = np.where(t < 0, np.clip(-c / a, 0, 1), np.where(t > 1, np.clip((b - c) / a, 0, 1), s))
+    t = np.clip(t, 0, 1)
+    return p1 + d1 * s[..., None], p2 + d2 * t[..., None]
+
+
+def capsule_penetration(sim, n, model):
+    """Deepest overlap (m, >= 0) over the model's left x right leg capsule pairs per env, from the rigid-body rows."""
+    rb = sim.rigid_body_states.reshape(n, -1, 13).astype(np.float64)
+    links, caps = model["links"], model["capsules"]
+    q = rb[..., 3:7]
+    x, y, z, w = q[..., 0], q[..., 1], q[..., 2], q[..., 3]
+    R = np.stack([np.stack([1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)], -1),
+                  np.stack([2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)], -1),
+                  np.stack([2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)], -1)], -2)
+    ends = []
+    for c in caps:
+        b = links[c["link"]]["body"]
+        ends.append((rb[:, b, 0:3] + np.einsum("nij,j->ni", R[:, b], np.asarray(c["p0"])),
+                     rb[:, b, 0:3] + np.einsum("nij,j->ni", R[:, b], np.asarray(c["p1"])), c["r"]))
+    deepest = np.zeros(n)
+    for ia, ib in model["capsule_pairs"]:
+        ca, cb = _seg_closest(ends[ia][0], ends[ia][1], ends[ib][0], ends[ib][1])
+        deepest = np.maximum(deepest, ends[ia][2] + ends[ib][2] - np.linalg.norm(ca - cb, axis=-1))
+    return deepest
+
+
+def leg_press(sim, n, model, steps=90, rng=None):
+    """Free-floating robot in zero gravity (cfg.gravity = 0 before creating `sim`), the ball parked away.  Both hip-roll drives are
+    commanded 0.6 rad INWARD -- past where the legs meet, so the saturated drives press the legs together for the whole run -- while hip
+    pitch, knee and ankle targets of both legs jump by +-1.2 rad every 5 control steps, which puts those joints on the 2 pi rad/s speed
+    limit.  Every force of the scenario is internal: linear and angular momentum must stay what they were.  Returns the largest drift
+    of both over the run (absolute, SI), the deepest capsule overlap after the first contact transient, and how many joint samples sat
+    on the speed limit."""
+    rng = rng or np.random.default_rng(5)
+    dflt = np.asarray(model["dof_default"], np.float64)
+    lo, hi = np.asarray(model["dof_lower"], np.float64), np.asarray(model["dof_upper"], np.float64)
+    rs = sim.root_states.reshape(n, -1, 13).copy()
+    rs[:, 0, :] = 0; rs[:, 0, 2] = 1.0; rs[:, 0, 6] = 1.0
+    if rs.shape[1] > 1:
+        rs[:, 1, :] = 0; rs[:, 1, 0:3] = (0.0, 3.0, 0.08); rs[:, 1, 6] = 1.0
+    sim.set_root_states(rs.reshape(-1, 13))
+    ds = np.zeros((n, 18, 2), np.float32); ds[:, :, 0] = dflt
+    sim.set_dof_state(ds.reshape(-1, 2))
+    sim.pre_physics(np.zeros((n, 18), np.float32)); sim.simulate()
+    p0, L0 = body_momenta(sim, n, model)
+    vlim = float(sim.cfg.vel_limit)
+    dp = np.zeros(n); dL = np.zeros(n); pen = np.zeros(n); on_limit = 0; over_limit = 0.0
+    swing = np.zeros((n, 18))
+    for k in range(steps):
+        if k % 5 == 0:
+            swing[:] = 0
+            for d in (6, 7, 8, 14, 15, 16):
+                swing[:, d] = rng.choice([-1.2, 1.2], n)
+        cmd = np.tile(dflt, (n, 1)) + swing
+        cmd[:, 5] = dflt[5] - 0.6; cmd[:, 13] = dflt[13] - 0.6      # both hip-roll axes count inward as negative (the sweep: 0.34 rad short of -0.785)
+        cmd = np.clip(cmd, lo, hi)
+        sim.pre_physics((cmd - dflt).astype(np.float32)); sim.simulate()
+        p, L = body_momenta(sim, n, model)
+        dp = np.maximum(dp, np.abs(p - p0).max(1)); dL = np.maximum(dL, np.abs(L - L0).max(1))
+        qd = np.abs(sim.dof_state.reshape(n, 18, 2)[:, :, 1].astype(np.float64))
+        on_limit += int((qd > 0.97 * vlim).sum()); over_limit = max(over_limit, float(qd.max() / vlim))
+        if k >= 10:
+            pen = np.maximum(pen, capsule_penetration(sim, n, model))
+    q = sim.dof_state.reshape(n, 18, 2)[:, :, 0]
+    return dict(dp=float(dp.max()), dL=float(dL.max()), penetration=float(pen.max()), on_limit=on_limit, over_limit=over_limit,
+                finite=bool(np.isfinite(q).all()), hip_roll=[float(q[:, 5].min()), float(q[:, 13].min())])

@@ -59,14 +59,18 @@ def test_all_ground_shapes_let_the_back_getup_roll_over_oracle():
 
 def check_dof_sweep(rows):
     """Every actuated DOF reaches both limits and returns (zero gravity, floating base) -- except where the model says it cannot:
-    the head joints never receive an action (kick_env.py:414) and a hip rolling INWARD meets the other leg (collision_filter 0,
-    kick_env.py:365-366) 0.34 rad short of its -0.785 rad limit."""
+    the head joints never receive an action (kick_env.py:414), a hip rolling INWARD meets the other leg (collision_filter 0,
+    kick_env.py:365-366: the foot plates, 8 mm apart in the default pose, touch first) 0.6 rad short of its -0.785 rad limit, and a hip
+    yawing to its lower limit swings the hip box into the other leg 0.1 rad short of -1.309.  (Round 5's 3000 N/m explicit spring let
+    the saturated drive push 2 cm into the other leg: its hip roll stopped 0.34 rad short, at the thighs.)"""
     for r in rows:
         assert r["finite"], r
         if r["dof"] < 2:
             assert r["miss_default"] < 1e-3 and r["miss_lower"] > 1.5, r       # did not move
         elif r["name"].endswith("leg_motor_1"):
-            assert 0.2 < r["miss_lower"] < 0.5 and r["miss_upper"] < 0.05 and r["miss_default"] < 0.05, r
+            assert 0.5 < r["miss_lower"] < 0.72 and r["miss_upper"] < 0.05 and r["miss_default"] < 0.05, r
+        elif r["name"].endswith("leg_motor_0"):
+            assert 0.03 < r["miss_lower"] < 0.2 and r["miss_upper"] < 0.05 and r["miss_default"] < 0.05, r
         else:
             assert r["miss_lower"] < 0.05 and r["miss_upper"] < 0.05 and r["miss_default"] < 0.05, r
 
@@ -110,14 +114,16 @@ def test_separating_axis_test_of_the_pair_log():
 def check_fixed_base_sweep(rows, root_before, root_after):
     """The reference's form of the sweep ("better when fixBaseLink = True", test/test_kick_env.py:142-186): gravity on, the torso welded one
     metre above the plane.  The torso does not move by a bit; every actuated DOF reaches both limits under its limb's weight and returns,
-    with the same two exceptions as the floating sweep (head joints never commanded, a hip rolling inward meets the other leg)."""
+    with the same exceptions as the floating sweep (head joints never commanded, a hip rolling inward or yawing to its lower limit meets the other leg)."""
     assert np.array_equal(root_before, root_after)
     for r in rows:
         assert r["finite"], r
         if r["dof"] < 2:
             assert r["miss_default"] < 1e-3 and r["miss_lower"] > 1.5, r
         elif r["name"].endswith("leg_motor_1"):
-            assert 0.2 < r["miss_lower"] < 0.5 and r["miss_upper"] < 0.06 and r["miss_default"] < 0.06, r
+            assert 0.5 < r["miss_lower"] < 0.72 and r["miss_upper"] < 0.06 and r["miss_default"] < 0.06, r
+        elif r["name"].endswith("leg_motor_0"):
+            assert 0.03 < r["miss_lower"] < 0.2 and r["miss_upper"] < 0.06 and r["miss_default"] < 0.06, r
         else:
             assert r["miss_lower"] < 0.06 and r["miss_upper"] < 0.06 and r["miss_default"] < 0.06, r
 

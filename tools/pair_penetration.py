@@ -65,6 +65,8 @@ def main():
     ap.add_argument("--flags", type=int, default=None)
     ap.add_argument("--stochastic", action="store_true")
     ap.add_argument("--out", default=None)
+    ap.add_argument("--set", nargs="*", default=[], help="BezSimConfig overrides, key=value")
+    ap.add_argument("--modelled-only", action="store_true")
     a = ap.parse_args()
     from oracle.bez_oracle import Oracle
     from s2s_cpu import NumpyPolicy
@@ -86,6 +88,8 @@ def main():
     cfg = abi.default_config(n, seed=1)
     if a.flags is not None:
         cfg.flags = a.flags
+    for kv in a.set:
+        k, v = kv.split("="); setattr(cfg, k, float(v))
     o = Oracle(cfg)
     pol = NumpyPolicy()
     rng = np.random.default_rng(1)
@@ -123,7 +127,7 @@ def main():
     print("policy %s, %d envs x %d steps (first episodes only), asset %s, flags %s" % (a.policy, n, a.steps, a.asset, a.flags))
     print("%-18s %-18s %-9s %11s %11s %9s %10s" % ("body a", "body b", "modelled", "penetrating", "within 2cm", "deepest", "median sep"))
     for r in rows:
-        if r["within_2cm"] > 0.0 or r["modelled"]:
+        if (r["within_2cm"] > 0.0 and not a.modelled_only) or r["modelled"]:
             print("%-18s %-18s %-9s %10.1f%% %10.1f%% %8.1f mm %8.1f mm" % (r["a"], r["b"], "yes" if r["modelled"] else "NO", 100 * r["penetrating"],
                                                                   100 * r["within_2cm"], 1e3 * r["deepest"], 1e3 * r["median_sep"]))
     never = [r for r in rows if r["within_2cm"] == 0.0 and not r["modelled"]]
