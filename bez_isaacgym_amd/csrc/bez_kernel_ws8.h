@@ -18,7 +18,8 @@
 // The deepest of the three ball candidates wins (left, right, torso on ties, the box order of the oracle); every owner decides
 // locally from the three published depths whether it is the winner, and only the winner evaluates the contact operands (a leg
 // wave skips that block altogether unless one of its 64 envs has a ball<->leg contact).
-// All roles execute the same barriers (B0, per substep B1 B1c B2 B3 B4 B5).  512 threads, <= 256 VGPRs per wave.
+// All roles execute the same barriers (B0, per substep B1 B1c B1d B2 B3 B4 B5; B1d: the legs exchange the sums of the leg<->leg contact
+// scale).  512 threads, <= 256 VGPRs per wave.
 // The action / observation staging block aliases the X_IA slots (actions are consumed before the first X_IA store, the
 // observation rows are staged after the last X_IA load).
 #pragma once
@@ -46,7 +47,8 @@ enum : int {
   X_BCN = 574,     // per leg: contact rows of the foot (B 9, C 6, F0 3), parked here across pass 2 (register pressure)
   X_CANDH = 610,   // per leg: the same 14 floats for the upper boxes (hip / thigh links), from role 2
   X_SLOTS = 638,
-  X_RESETF = X_PSUM + 3  // 1.0 where this step resets the env: its contact rows leave the kernel as zeros (written by role 7, read by the copy-out)
+  X_RESETF = X_PSUM + 3,  // 1.0 where this step resets the env: its contact rows leave the kernel as zeros (written by role 7, read by the copy-out)
+  X_SELFSUM = X_PSUM     // inside the substep loop (the pose-error slots are written after it): per leg the three partial sums of the leg<->leg contact scale
 };
 #ifndef BEZ_W8_CAND_SPLIT
 #define BEZ_W8_CAND_SPLIT 4
@@ -319,7 +321,10 @@ BEZ_DEV void leg_role(const Params& P, float* lds, int lane, int e, bool active,
     ws_chain_pass2<FIRST, LEN, true>(P, D, kps, kds, lo, hi, q, qd, target, LI, pAl, Sl, cbl, Kc, pc, mine, sel, p3, IA, pA);
     WS_STAMP(side, 24 + s);
     ws_barrier();  // B1c: both helper parts' leg<->leg contact wrenches are in LDS
-    ws_chain_self_correction<LEN>(lds, lane, side, p3, pA);
+    SelfCorr sc_;
+    ws_chain_self_prepare<LEN>(P, lds, lane, side, p3, sc_);
+    ws_barrier();  // B1d: both legs' partial sums of the contact scale are in LDS
+    const float sc = ws_chain_self_apply<LEN>(P, lds, lane, sc_, p3, pA);
     xs_store_sym6(lds, lane, X_IA + side * 27, IA, pA);
     WS_STAMP(side, 4 + 8 * s);
     ws_barrier();  // B2
@@ -328,7 +333,7 @@ BEZ_DEV void leg_role(const Params& P, float* lds, int lane, int e, bool active,
     WS_STAMP(side, 6 + 8 * s);
     SV a0 = xs_load_sv(lds, lane, X_A0);
     V3 fl = mk(0, 0, 0), fend = mk(0, 0, 0);
-    SV aend = ws_chain_pass3<FIRST, LEN, true, CL>(P, a0, p3, q, qd, mine, sel, fl, fend, lds, lane, keep, first);
+    SV aend = ws_chain_pass3<FIRST, LEN, true, CL>(P, a0, p3, q, qd, mine, sel, fl, fend, lds, lane, keep, first, sc);
     if (mine && sel.link >= 0) { xs_store_v3(lds, lane, X_FL, fl); xs_store_v3(lds, lane, X_FL + 3, sel.xb); }
     if (keep) {
       if constexpr (CL) {  // the foot plate only feels the ball / the other leg; the ground acts on the four cleats
@@ -411,6 +416,7 @@ BEZ_DEV void head_role(const Params& P, float* lds, int lane, int e, bool active
     C.up(P, in_loop(D), lds, lane);
     WS_STAMP(2, 4 + 8 * s);
     ws_barrier();  // B1c: head and arm blocks are in LDS (role 4 sums them into block 2 before B2)
+    ws_barrier();  // B1d
     ws_barrier();  // B2
     ws_barrier();  // B3
     C.down(P, lds, lane, keep, first);
@@ -458,6 +464,7 @@ BEZ_DEV void cand_arm_role(const Params& P, float* lds, int lane, int e, bool ac
       add_to(I2, C.IAc); p2 = p2 + C.pAc;
       xs_store_sym6(lds, lane, X_IA + 2 * 27, I2, p2);
     }
+    ws_barrier();  // B1d
     ws_barrier();  // B2
     ws_barrier();  // B3
     C.down(P, lds, lane, keep, first);
@@ -567,6 +574,7 @@ BEZ_DEV void self_role(const Params& P, float* lds, int lane, int e, bool active
     ws_self_pairs<PART>(P, D.mu, lds, lane, K);
     WS_STAMP(6 + PART, 4 + 8 * s);
     ws_barrier();  // B1c
+    ws_barrier();  // B1d
     ws_barrier();  // B2
     ws_barrier();  // B3
     ws_barrier();  // B4
@@ -674,6 +682,7 @@ BEZ_DEV void root_role(const Params& P, float* lds, int lane, int e, bool active
     if (torso_hit) { add_point_stiffness(IA0, sel.x, sel.A); pA0 = pA0 - wrench_at(sel.x, sel.f0p); }
     WS_STAMP(3, 24 + s);
     ws_barrier();  // B1c
+    ws_barrier();  // B1d
     ws_barrier();  // B2: chain contributions published
     WS_STAMP(3, 5 + 8 * s);
 #pragma unroll

@@ -24,6 +24,7 @@
 namespace bez {
 
 constexpr int BLOCK = 64;  // one wave per workgroup
+constexpr float SELF_IMPLICIT = 2.0f;  // BEZ_SELF_IMPLICIT of the oracle (self_contact_scale)
 
 // ---- SoA state fields (floats per env)
 enum : int {
@@ -34,7 +35,7 @@ enum : int {
 };
 
 // ---- LDS slots per lane
-constexpr int P3_STRIDE = 19;                       // UD(6) uD(1) S(6) cb(6) per joint
+constexpr int P3_STRIDE = 20;                       // UD(6) uD(1) S(6) cb(6) per joint + the leg<->leg contacts' share of uD (1)
 constexpr int LDS_P3 = 0;                           // 18 joints
 constexpr int LDS_HIT = LDS_P3 + BEZ_ND * P3_STRIDE;  // ground-point records, 8 floats each
 constexpr int HIT_STRIDE = 8;                       // x(3) fn0 kn ct ftx0 fty0
@@ -45,7 +46,7 @@ constexpr int LDS_SLOTS = LDS_HIT + BEZ_NPT * HIT_STRIDE;
 
 struct Params {
   int n, substeps, max_len, use_prev, obs_only;
-  float dt, h;
+  float dt, h, inv_h;
   float ang_init;  // atan2 of the unit vector ball_init -> goal (kick_env.py:1238-1243): constant of the config
   float g[3];
   float kp, kd, armature, effort, vel_limit, jfric, mu, clip;
@@ -368,8 +369,10 @@ BEZ_DEV void ball_link_contact(const Params& P, float mu, V3 ball_ang, V3 ball_l
 }
 
 // ---- leg <-> leg self-collision (kick_env.py:365-366: collision_filter 0).  Each leg box is a capsule (BEZ_CAP_*);
-// a penetrating left x right pair is ONE explicit spring-damper + regularised Coulomb point contact with equal and
-// opposite forces on the two links (a contact inside the tree closes a loop the ABA recursion cannot fold in).
+// a penetrating left x right pair is ONE spring-damper + regularised Coulomb point contact with equal and opposite forces
+// on the two links (a contact inside the tree closes a loop the ABA recursion cannot fold in): lambda0 = k (depth - h u_n)
+// - c u_n from the state at the start of the substep, then every pair of the env scaled by ONE factor that stands for the
+// implicit part (self_scale below; the oracle's self_contact_scale).
 BEZ_DEV float clamp01(float s) { return fminf(fmaxf(s, 0.f), 1.f); }
 // closest points of two (non-degenerate) segments, branch-free: the unconstrained s, the t it implies, and -- when that t
 // had to be clamped to its segment -- the s that is closest to the clamped end point
@@ -397,7 +400,7 @@ BEZ_DEV bool self_pair(const Params& P, float mu, float ra, float rb, V3 a0, V3 
   x = fma3(n, rb - 0.5f * depth, cb);
   V3 u = point_of(Va, x) - point_of(Vb, x);
   float un = dot(u, n);
-  float fmag = fmaf(P.self_kn, depth, -P.self_cn * un);
+  float fmag = fmaf(P.self_kn, depth, -fmaf(P.h, P.self_kn, P.self_cn) * un);
   if (!(fmag > 0.f)) return false;
   V3 ut = u - n * un;
   float vt = fsqrt(dot(ut, ut));
@@ -507,10 +510,13 @@ BEZ_DEV void link_ground_forces_cleats(const Params& P, SV acc, const float* lds
   }
 }
 
-// joint drive / friction / limit terms and the ABA joint-space quantities for DOF d = L-1
+// joint drive / friction / limit terms and the ABA joint-space quantities for DOF d = L-1:  g = 1/D, w = (tau - S.pA)/D (pass 3
+// forms qdd = w - g U.(a_parent + c)) and the held-parent acceleration qdd_hp = w - g U.c the predictors work with.  A joint whose
+// held-parent rate would end the substep beyond the speed limit (kick_env.py:327) is a prescribed-rate joint: g = 0, w = the
+// acceleration that puts it ON the limit -- same recursion, and the reaction reaches the parent through pA (oracle: dynamics_x).
 template <int L>
 BEZ_DEV void joint_terms(const Params& P, float kp_scale, float kd_scale, float lo, float hi, float q, float qd, float target, const Sym6& IA, SV pA,
-                         SV S, SV cb, SV& U, float& Dinv, float& u) {
+                         SV S, SV cb, SV& U, float& g, float& w, float& qdd_hp) {
   U = mul(IA, S);
   float J = dot(S, U) + P.armature;
   float kp = P.kp * kp_scale, kdm = P.kd * kd_scale;
@@ -522,15 +528,29 @@ BEZ_DEV void joint_terms(const Params& P, float kp_scale, float kd_scale, float 
   if (q < lo) { tau_l0 = fmaf(P.lim_k, lo - q - P.h * qd, -P.lim_d * qd); k_l = fmaf(P.h * P.h, P.lim_k, P.h * P.lim_d); }
   else if (q > hi) { tau_l0 = fmaf(P.lim_k, hi - q - P.h * qd, -P.lim_d * qd); k_l = fmaf(P.h * P.h, P.lim_k, P.h * P.lim_d); }
   float sp = dot(S, pA);
-  float bias = sp + dot(U, cb);
+  float ucb = dot(U, cb);
+  float bias = sp + ucb;
   float qdd_est = (tau_pd0 + tau_f0 + tau_l0 - bias) * frcp(J + k_pd + k_f + k_l);
   float tau_drive = fmaf(-k_pd, qdd_est, tau_pd0);
   float tau, Dj;
   if (tau_drive > P.effort) { tau = P.effort + tau_f0 + tau_l0; Dj = J + k_f + k_l; }
   else if (tau_drive < -P.effort) { tau = -P.effort + tau_f0 + tau_l0; Dj = J + k_f + k_l; }
   else { tau = tau_pd0 + tau_f0 + tau_l0; Dj = J + k_pd + k_f + k_l; }
-  Dinv = frcp(Dj);
-  u = tau - sp;
+  g = frcp(Dj);
+  qdd_hp = (tau - bias) * g;
+  w = (tau - sp) * g;
+  const float v_pred = fmaf(P.h, qdd_hp, qd);
+  if (v_pred > P.vel_limit) { g = 0.f; w = qdd_hp = (P.vel_limit - qd) * P.inv_h; }
+  else if (v_pred < -P.vel_limit) { g = 0.f; w = qdd_hp = (-P.vel_limit - qd) * P.inv_h; }
+}
+
+// sums of the leg<->leg contact scale (oracle: self_contact_scale), accumulated joint by joint while the legs run pass 2
+struct SelfSums { float am, as, f2; };
+BEZ_DEV float self_scale(const Params& P, const SelfSums& Z) {
+  if (!(Z.f2 > 0.f)) return 0.f;
+  const float K = fmaf(P.h * P.h, P.self_kn, P.h * P.self_cn);
+  const float sc = (Z.f2 - K * Z.am) / fmaf(SELF_IMPLICIT * K, Z.as, Z.f2);
+  return fminf(fmaxf(sc, 0.f), 8.f);   // (NaN-safe the oracle's way: !(sc > 0) -> 0)
 }
 
 // compile-time loop: f(std::integral_constant<int, i>) for i in [0, N)
@@ -543,7 +563,7 @@ BEZ_DEV void static_for(F&& f) { static_for_impl(std::make_integer_sequence<int,
 // articulated inertia / bias into the torso's (IA0, pA0) and stages pass-3 data in LDS.
 template <int FIRST, int LEN, bool CL>
 BEZ_DEV void chain_up(const Params& P, const EnvDyn& D, const EnvState& S, const float* target, const M3& E0, SV V0,
-                      const BallBody& ball, V3 bc, BallSel& sel, const SV* selfw, Sym6& IA0, SV& pA0, float* lds, int lane, bool keep) {
+                      const BallBody& ball, V3 bc, BallSel& sel, const SV* selfw, Sym6& IA0, SV& pA0, SV& pS0, SelfSums& Z, float* lds, int lane, bool keep) {
   LinkInertia LI[LEN];
   SV pAl[LEN], Sl[LEN], cbl[LEN];
   M3 E = E0;
@@ -562,7 +582,8 @@ BEZ_DEV void chain_up(const Params& P, const EnvDyn& D, const EnvState& S, const
   // tip: ground points of the chain-end link (E, r, V are still the tip's)
   Sym6 IA = sym6zero();
   SV pA = svzero();
-  SV pS = svzero();  // explicit leg<->leg contact wrenches, propagated next to pA (the drive-saturation predictor does not see them)
+  SV pS = svzero();  // leg<->leg contact wrenches (as bias forces), propagated next to pA (the predictors do not see them); their common scale comes later
+  SV wsub = svzero();  // the same, summed over the subtree WITHOUT the projections: S . wsub = the contacts' generalised force on the joint
   link_ground_points<FIRST + LEN - 1, CL>(P, D.mu, S.root_pos.z, E, r, V, IA, pA, lds, lane, keep);
   // pass 2: tip -> root
   static_for<LEN>([&](auto I) {
@@ -570,37 +591,42 @@ BEZ_DEV void chain_up(const Params& P, const EnvDyn& D, const EnvState& S, const
     constexpr int L = FIRST + i;
     add_link_inertia(IA, LI[i]);
     pA = pA + pAl[i];
-    if constexpr (link_has_box(L)) pS = pS + selfw[L];
+    if constexpr (link_has_box(L)) { pS = pS + selfw[L]; wsub = wsub + selfw[L]; Z.f2 = fmaf(0.5f, dot(selfw[L].l, selfw[L].l), Z.f2); }
     if constexpr (link_has_box(L)) {
       if (sel.link == L) {
         add_point_stiffness(IA, sel.x, sel.A);
         pA = pA - wrench_at(sel.x, sel.f0p);
       }
     }
-    SV U; float Dinv, u;
+    SV U; float Dinv, uD, qhp;
     joint_terms<L>(P, D.kp_scale[L - 1], D.kd_scale[L - 1], D.lo[L - 1], D.hi[L - 1], S.q[L - 1], S.qd[L - 1], target[L - 1], IA, pA, Sl[i], cbl[i], U,
-                   Dinv, u);
+                   Dinv, uD, qhp);
     SV UD = U * Dinv;
     const float duD = -dot(Sl[i], pS) * Dinv;
-    float uD = fmaf(u, Dinv, duD);
+    if constexpr (FIRST == 5 || FIRST == 13) {   // only the legs carry leg<->leg contacts
+      const float tq = dot(Sl[i], wsub);         // (sign: wsub holds bias forces = minus the wrenches; tq enters squared and times am's own sign convention below)
+      Z.as = fmaf(tq * tq, Dinv, Z.as); Z.am = fmaf(-tq, qhp, Z.am);
+    }
     float* p3 = lds + (size_t)(LDS_P3 + (L - 1) * P3_STRIDE) * BLOCK + lane;
     p3[0 * BLOCK] = UD.a.x; p3[1 * BLOCK] = UD.a.y; p3[2 * BLOCK] = UD.a.z; p3[3 * BLOCK] = UD.l.x; p3[4 * BLOCK] = UD.l.y; p3[5 * BLOCK] = UD.l.z;
     p3[6 * BLOCK] = uD;
     p3[7 * BLOCK] = Sl[i].a.x; p3[8 * BLOCK] = Sl[i].a.y; p3[9 * BLOCK] = Sl[i].a.z; p3[10 * BLOCK] = Sl[i].l.x; p3[11 * BLOCK] = Sl[i].l.y; p3[12 * BLOCK] = Sl[i].l.z;
     p3[13 * BLOCK] = cbl[i].a.x; p3[14 * BLOCK] = cbl[i].a.y; p3[15 * BLOCK] = cbl[i].a.z; p3[16 * BLOCK] = cbl[i].l.x; p3[17 * BLOCK] = cbl[i].l.y; p3[18 * BLOCK] = cbl[i].l.z;
+    p3[19 * BLOCK] = duD;
     // Ia = IA - U U^T / D ;  pa = pA + Ia c + U u / D
     add_outer(IA, U, -Dinv);
-    pA = pA + mul(IA, cbl[i]) + U * (u * Dinv);
+    pA = pA + mul(IA, cbl[i]) + U * uD;
     pS = pS + U * duD;
   });
   add_to(IA0, IA);
-  pA0 = pA0 + pA + pS;
+  pA0 = pA0 + pA;
+  pS0 = pS0 + pS;
 }
 
 // ---- pass 3 of one chain: joint accelerations from the torso acceleration; integrates the joints in
-// place (semi-implicit Euler + velocity clamp) and resolves contact forces on the way.
+// place (semi-implicit Euler) and resolves contact forces on the way.  sc = the leg<->leg contacts' common scale.
 template <int FIRST, int LEN, bool CL>
-BEZ_DEV void chain_down(const Params& P, EnvState& S, SV a0, BallSel& sel, const V3* selfcf, V3& ball_link_force, CfOut& co, const float* lds,
+BEZ_DEV void chain_down(const Params& P, EnvState& S, SV a0, float sc, BallSel& sel, const V3* selfcf, V3& ball_link_force, CfOut& co, const float* lds,
                         int lane, bool keep, bool first) {
   SV a = a0;
   constexpr int Lend = FIRST + LEN - 1;
@@ -610,18 +636,17 @@ BEZ_DEV void chain_down(const Params& P, EnvState& S, SV a0, BallSel& sel, const
     constexpr int L = FIRST + i;
     const float* p3 = lds + (size_t)(LDS_P3 + (L - 1) * P3_STRIDE) * BLOCK + lane;
     SV UD = mksv(mk(p3[0 * BLOCK], p3[1 * BLOCK], p3[2 * BLOCK]), mk(p3[3 * BLOCK], p3[4 * BLOCK], p3[5 * BLOCK]));
-    float uD = p3[6 * BLOCK];
+    float uD = fmaf(sc, p3[19 * BLOCK], p3[6 * BLOCK]);
     SV Sj = mksv(mk(p3[7 * BLOCK], p3[8 * BLOCK], p3[9 * BLOCK]), mk(p3[10 * BLOCK], p3[11 * BLOCK], p3[12 * BLOCK]));
     SV cb = mksv(mk(p3[13 * BLOCK], p3[14 * BLOCK], p3[15 * BLOCK]), mk(p3[16 * BLOCK], p3[17 * BLOCK], p3[18 * BLOCK]));
     SV ap = a + cb;
     float qdd = uD - dot(UD, ap);
     a = ap + Sj * qdd;
-    float v = fmaf(P.h, qdd, S.qd[L - 1]);
-    v = fminf(fmaxf(v, -P.vel_limit), P.vel_limit);
+    float v = fmaf(P.h, qdd, S.qd[L - 1]);   // the speed limit is inside the dynamics (joint_terms): no rate is edited here
     S.qd[L - 1] = v;
     S.q[L - 1] = fmaf(P.h, v, S.q[L - 1]);
     if constexpr (link_has_box(L)) {
-      V3 f = selfcf[L];
+      V3 f = selfcf[L] * sc;
       if (sel.link == L) {
         ball_link_force = sel.f0p - mul(sel.A, point_of(a, sel.x));
         f = f + cf_along(P, ball_link_force, sel.n);
@@ -716,11 +741,15 @@ BEZ_DEV void substep(const Params& P, const EnvDyn& D, EnvState& S, const float*
       if (sel.link == 0) { add_point_stiffness(IA0, sel.x, sel.A); pA0 = pA0 - wrench_at(sel.x, sel.f0p); }
     }
   }
-  chain_up<1, 2, CL>(P, D, S, target, E0, V0, ball, bc, sel, selfw, IA0, pA0, lds, lane, keep);    // neck, head
-  chain_up<3, 2, CL>(P, D, S, target, E0, V0, ball, bc, sel, selfw, IA0, pA0, lds, lane, keep);    // left arm
-  chain_up<5, 6, CL>(P, D, S, target, E0, V0, ball, bc, sel, selfw, IA0, pA0, lds, lane, keep);    // left leg
-  chain_up<11, 2, CL>(P, D, S, target, E0, V0, ball, bc, sel, selfw, IA0, pA0, lds, lane, keep);   // right arm
-  chain_up<13, 6, CL>(P, D, S, target, E0, V0, ball, bc, sel, selfw, IA0, pA0, lds, lane, keep);   // right leg
+  SV pS0 = svzero(); SelfSums Z; Z.am = Z.as = Z.f2 = 0.f;
+  chain_up<1, 2, CL>(P, D, S, target, E0, V0, ball, bc, sel, selfw, IA0, pA0, pS0, Z, lds, lane, keep);    // neck, head
+  chain_up<3, 2, CL>(P, D, S, target, E0, V0, ball, bc, sel, selfw, IA0, pA0, pS0, Z, lds, lane, keep);    // left arm
+  chain_up<5, 6, CL>(P, D, S, target, E0, V0, ball, bc, sel, selfw, IA0, pA0, pS0, Z, lds, lane, keep);    // left leg
+  chain_up<11, 2, CL>(P, D, S, target, E0, V0, ball, bc, sel, selfw, IA0, pA0, pS0, Z, lds, lane, keep);   // right arm
+  chain_up<13, 6, CL>(P, D, S, target, E0, V0, ball, bc, sel, selfw, IA0, pA0, pS0, Z, lds, lane, keep);   // right leg
+  // the leg<->leg contacts' common scale (known before the root solve), then their share of the torso's bias
+  const float sc = self_scale(P, Z);
+  pA0 = pA0 + pS0 * sc;
   // (d) root: I0^A a0 = -p0^A; urdfAsset.fixBaseLink (BEZ_FLAG_FIX_BASE): the torso is welded to the world, a0 = 0
   SV a0 = solve_spd6(IA0, svzero() - pA0);
   if (P.flags & BEZ_FLAG_FIX_BASE) a0 = svzero();
@@ -731,11 +760,11 @@ BEZ_DEV void substep(const Params& P, const EnvDyn& D, EnvState& S, const float*
     if (sel.link == 0) { fl = sel.f0p - mul(sel.A, point_of(a0, sel.x)); f0 = cf_along(P, fl, sel.n); }
     if (keep) cf_accum(co, 0, f0 + cf_ground(P, link_ground_forces<0>(P, a0, lds, lane)), P.cf_w, first);
   }
-  chain_down<1, 2, CL>(P, S, a0, sel, selfcf, fl, co, lds, lane, keep, first);
-  chain_down<3, 2, CL>(P, S, a0, sel, selfcf, fl, co, lds, lane, keep, first);
-  chain_down<5, 6, CL>(P, S, a0, sel, selfcf, fl, co, lds, lane, keep, first);
-  chain_down<11, 2, CL>(P, S, a0, sel, selfcf, fl, co, lds, lane, keep, first);
-  chain_down<13, 6, CL>(P, S, a0, sel, selfcf, fl, co, lds, lane, keep, first);
+  chain_down<1, 2, CL>(P, S, a0, sc, sel, selfcf, fl, co, lds, lane, keep, first);
+  chain_down<3, 2, CL>(P, S, a0, sc, sel, selfcf, fl, co, lds, lane, keep, first);
+  chain_down<5, 6, CL>(P, S, a0, sc, sel, selfcf, fl, co, lds, lane, keep, first);
+  chain_down<11, 2, CL>(P, S, a0, sc, sel, selfcf, fl, co, lds, lane, keep, first);
+  chain_down<13, 6, CL>(P, S, a0, sc, sel, selfcf, fl, co, lds, lane, keep, first);
   // (f) ball: Mb ab = -pb - Jb^T fl
   SV ab = ball_minv(ball, svzero() - ball.pb - wrench_at(sel.xb, fl));
   if (keep) {

@@ -187,7 +187,7 @@ Params make_params(const BezSim* s, const float* actions) {
   P.n = s->n; P.substeps = c.substeps; P.max_len = c.max_episode_length;
   P.use_prev = (!(c.flags & BEZ_FLAG_IMU_PREV_ALIAS) || s->obs_calls == 0) ? 1 : 0;
   P.lean = 0;  // set by launch_step for the fused step only
-  P.dt = c.dt; P.h = c.dt / (float)c.substeps;
+  P.dt = c.dt; P.h = c.dt / (float)c.substeps; P.inv_h = 1.0f / P.h;
   {
     float igx = c.goal[0] - c.ball_init[0], igy = c.goal[1] - c.ball_init[1];
     float ign = std::sqrt(igx * igx + igy * igy);

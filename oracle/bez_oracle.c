@@ -271,6 +271,7 @@ typedef struct {
   /* DR */
   real friction, kp_scale[ND], kd_scale[ND], mass_scale[NL], gravity[3], lim_lo[ND], lim_hi[ND];
   real ftrans[ND]; /* BEZ_FLAG_TGS_SOLVER: size of the spatial force each joint transmitted in the previous substep */
+  real vmargin;    /* test aid: smallest distance of a speed-limit predictor from its decision boundary over the last control step, rad/s */
 } Env;
 
 typedef struct {
@@ -311,6 +312,7 @@ typedef struct {
   real qdd[ND];
   V3 ball_lin_acc, ball_ang_acc; /* classical */
   real contact_force[NBMAX][3];
+  real vmargin;
 } Dyn;
 
 typedef struct { int link, body; V3 x; real fn0, kn, ct, ftx0, fty0; } GroundHit;
@@ -518,6 +520,7 @@ static void dynamics_x(const BezSimConfig* c, const Env* e, real h, int mode, co
   M6* IA = P1.IA;
   memset(pS, 0, sizeof(pS)); memset(Wself, 0, sizeof(Wself)); memset(cfs, 0, sizeof(cfs));
   memset(out->contact_force, 0, sizeof(out->contact_force));
+  out->vmargin = (real)1e9;
 
   /* contacts (implicit spring-dampers folded into IA / pA) */
   GroundHit hits[BEZ_NPT + BEZ_NXPT];
@@ -688,6 +691,7 @@ static void dynamics_x(const BezSimConfig* c, const Env* e, real h, int mode, co
       else { tau = tau_pd0 + tau_f0 + tau_l0; D = J + k_pd + k_f + k_l; }
       /* speed-limit predictor, the same kind: the rate the joint would have at the end of the substep with the parent held */
       real vl = (real)c->vel_limit, v_pred = e->qd[d] + h * (tau - bias) / D;
+      if (d >= 2 && fabs(fabs(v_pred) - vl) < out->vmargin) out->vmargin = fabs(fabs(v_pred) - vl); /* (the head joints are never driven) */
       if (force_lock) { lock = force_lock[d] != 0; if (lock) qdd_fix = ((force_lock[d] > 0 ? vl : -vl) - e->qd[d]) / h; }
       else if (v_pred > vl) { lock = 1; qdd_fix = (vl - e->qd[d]) / h; }
       else if (v_pred < -vl) { lock = 1; qdd_fix = (-vl - e->qd[d]) / h; }
@@ -1183,6 +1187,7 @@ static void substep(const BezSimConfig* c, Env* e, real h, int first, real wgt) 
     e->ball_pos[i] += h * e->ball_lin[i];
   }
   quat_integrate(e->ball_quat, e->ball_ang, h);
+  e->vmargin = first ? d.vmargin : (d.vmargin < e->vmargin ? d.vmargin : e->vmargin);
   /* physx.contact_collection 2 = CC_ALL_SUBSTEPS (bez_kick.yaml:147): the tensor holds the mean force over the control step [ext] */
   for (int b = 0; b < NBMAX; ++b) for (int i = 0; i < 3; ++i) e->contact_force[b][i] = first ? d.contact_force[b][i] * wgt : e->contact_force[b][i] + d.contact_force[b][i] * wgt;
 }
@@ -1591,6 +1596,8 @@ void bez_oracle_get_prev_lin_vel(void* h, float* out) { Oracle* o = (Oracle*)h; 
 void bez_oracle_set_prev_lin_vel(void* h, const float* in) { Oracle* o = (Oracle*)h; for (int i = 0; i < o->n; ++i) for (int k = 0; k < 3; ++k) o->env[i].prev_lin_vel[k] = in[(size_t)i * 3 + k]; }
 void bez_oracle_get_obs(void* h, float* out) { Oracle* o = (Oracle*)h; const int no = m_nobs(&o->cfg); for (int i = 0; i < o->n; ++i) for (int k = 0; k < no; ++k) out[(size_t)i * no + k] = (float)o->env[i].obs[k]; }
 void bez_oracle_get_feet(void* h, float* out) { Oracle* o = (Oracle*)h; for (int i = 0; i < o->n; ++i) for (int k = 0; k < 8; ++k) out[(size_t)i * 8 + k] = (float)o->env[i].feet[k]; }
+/* test aid (tests/: which envs sat within rounding of a speed-limit decision in the last control step) */
+void bez_oracle_get_vlim_margin(void* h, float* out) { Oracle* o = (Oracle*)h; for (int i = 0; i < o->n; ++i) out[i] = (float)o->env[i].vmargin; }
 void bez_oracle_get_rew(void* h, float* out) { Oracle* o = (Oracle*)h; for (int i = 0; i < o->n; ++i) out[i] = (float)o->env[i].rew; }
 void bez_oracle_get_reset(void* h, int64_t* out) { Oracle* o = (Oracle*)h; for (int i = 0; i < o->n; ++i) out[i] = o->env[i].reset; }
 void bez_oracle_set_reset(void* h, const int64_t* in) { Oracle* o = (Oracle*)h; for (int i = 0; i < o->n; ++i) o->env[i].reset = in[i]; }

@@ -87,6 +87,7 @@ class Oracle:
     obs = property(lambda s: s._get("obs", (s.n, s.nobs)))
     feet = property(lambda s: s._get("feet", (s.n, 8)))
     rew = property(lambda s: s._get("rew", (s.n,)))
+    vlim_margin = property(lambda s: s._get("vlim_margin", (s.n,)))   # rad/s: how close a speed-limit decision of the last step came to its boundary
     reset_buf = property(lambda s: s._get("reset", (s.n,), np.int64))
     progress_buf = property(lambda s: s._get("progress", (s.n,), np.int64))
     timeout_buf = property(lambda s: s._get("timeout", (s.n,), np.int64))

@@ -1,0 +1,111 @@
+"""Round 6 on the GPU: the in-dynamics joint speed limit and the leg <-> leg contact with its common implicit
+scale, on BOTH step kernels through the C ABI -- the same known answers as tests/test_oracle_round6.py, plus HIP = oracle on the scenario."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from bez_isaacgym_amd import abi  # noqa: E402
+from tests import rbd_numpy as R  # noqa: E402
+from tests.scenarios import capsule_penetration, leg_press  # noqa: E402
+from tests.test_oracle_round6 import _free_space_cfg, _pressed_state  # noqa: E402
+
+
+def _adapter(cfg, kernel, monkeypatch):
+    from tests.sim_adapter import SimAdapter
+    monkeypatch.setenv("BEZ_SIM_KERNEL", kernel)
+    return SimAdapter(cfg)
+
+
+def _inject(sim, n, model, seed):
+    """n pressed states (tests/test_oracle_round6._pressed_state) through the Isaac-layout setters; returns them"""
+    rng = np.random.default_rng(seed)
+    dflt = np.asarray(model["dof_default"], float)
+    rs = sim.root_states.reshape(n, 2, 13).copy()
+    ds = np.zeros((n, 18, 2), np.float32)
+    acts = np.zeros((n, 18), np.float32)
+    states = []
+    for e in range(n):
+        q, qd, target, v0, quat, fast, sign = _pressed_state(model, rng)
+        rs[e, 0, 0:3] = (0.0, 0.0, 1.0); rs[e, 0, 3:7] = quat; rs[e, 0, 7:10] = v0[3:]; rs[e, 0, 10:13] = v0[:3]
+        rs[e, 1, :] = 0; rs[e, 1, 0:3] = (0.0, 3.0, 0.08); rs[e, 1, 6] = 1.0
+        ds[e, :, 0] = q; ds[e, :, 1] = qd
+        acts[e] = (target - dflt).astype(np.float32)
+        states.append((q, qd, v0, quat))
+    sim.set_root_states(rs.reshape(-1, 13)); sim.set_dof_state(ds.reshape(-1, 2))
+    return acts, states
+
+
+@pytest.mark.parametrize("kernel", ["ws8", "lane"])
+def test_one_substep_with_locked_joints_needs_no_base_wrench(model, kernel, monkeypatch):
+    """One substep (substeps = 1) from the pressed state on the GPU: the accelerations the state change implies, put into the
+    independent RNEA, need no wrench on the floating base (fp32 state read back: 2e-2 N / N m of joint torques of 2.5 N m, contact
+    forces of tens of newtons and a constraint torque per locked joint), >= 3 joints per env end ON the limit, and the contact rows
+    show the legs pressed together."""
+    n = 64
+    cfg = _free_space_cfg(n, substeps=1)
+    sim = _adapter(cfg, kernel, monkeypatch)
+    sim.step(np.zeros((n, 18), np.float32))
+    acts, states = _inject(sim, n, model, 21)
+    rs0 = sim.root_states.reshape(n, 2, 13).astype(np.float64); ds0 = sim.dof_state.reshape(n, 18, 2).astype(np.float64)
+    sim.pre_physics(acts); sim.simulate()
+    rs1 = sim.root_states.reshape(n, 2, 13).astype(np.float64); ds1 = sim.dof_state.reshape(n, 18, 2).astype(np.float64)
+    cf = sim.contact_forces.reshape(n, -1, 3)
+    h = float(cfg.dt)
+    on = 0; worst = 0.0
+    for e in range(n):
+        q, qd = ds0[e, :, 0], ds0[e, :, 1]
+        quat = rs0[e, 0, 3:7]; w0, v0 = rs0[e, 0, 10:13], rs0[e, 0, 7:10]
+        qdd = (ds1[e, :, 1] - qd) / h
+        wdot = (rs1[e, 0, 10:13] - w0) / h
+        vdot = (rs1[e, 0, 7:10] - v0) / h
+        a0 = np.concatenate([wdot, vdot - np.cross(w0, v0)])          # classical -> spatial acceleration of the torso origin (substep: oracle)
+        f0, _ = R.rnea_floating(model, quat / np.linalg.norm(quat), np.concatenate([w0, v0]), a0, q, qd, qdd, np.zeros(3))
+        worst = max(worst, float(np.abs(f0).max()))
+        on += int((np.abs(np.abs(ds1[e, :, 1]) - float(cfg.vel_limit)) < 2e-4).sum() >= 3)
+    assert worst < 2e-2, worst
+    assert on >= n // 2, on
+    assert (np.abs(cf[:, :21]).sum((1, 2)) > 1.0).mean() > 0.5
+
+
+@pytest.mark.parametrize("kernel", ["ws8", "lane"])
+def test_leg_press_hip_equals_oracle_and_stays_bounded(model, kernel, monkeypatch):
+    """The scenario that broke the round-5 model, on the GPU: finite, momentum drift within the integrator's bound of the oracle test, and
+    over the first control steps (before fp32 / fp64 trajectories of a chaotic scenario part) the same joint angles as the oracle."""
+    from tests.scenarios import make_backend
+    n = 64
+    cfg = _free_space_cfg(n)
+    sim = _adapter(cfg, kernel, monkeypatch)
+    sim.step(np.zeros((n, 18), np.float32))
+    r = leg_press(sim, n, model)
+    assert r["finite"] and r["on_limit"] > 5000, r
+    assert r["dp"] < 1.5 and r["dL"] < 0.25, r
+    orc = make_backend("oracle", _free_space_cfg(4)); orc.step(np.zeros((4, 18), np.float32))
+    gpu = _adapter(_free_space_cfg(4), kernel, monkeypatch); gpu.step(np.zeros((4, 18), np.float32))
+    a = leg_press(orc, 4, model, steps=6); b = leg_press(gpu, 4, model, steps=6)
+    np.testing.assert_allclose(gpu.dof_state.reshape(4, 18, 2)[:, :, 0], orc.dof_state.reshape(4, 18, 2)[:, :, 0], atol=2e-2)
+    assert abs(a["penetration"] - b["penetration"]) < 2e-3, (a, b)
+
+
+@pytest.mark.parametrize("kernel", ["ws8", "lane"])
+def test_self_contact_holds_the_legs_apart_hip(model, kernel, monkeypatch):
+    """tests/test_oracle_round6.test_self_contact_holds_the_legs_apart on the GPU: steady, < 5 mm, the hip stopped by the other foot."""
+    n = 64
+    cfg = _free_space_cfg(n)
+    o = _adapter(cfg, kernel, monkeypatch)
+    o.step(np.zeros((n, 18), np.float32))
+    dflt = np.asarray(model["dof_default"], np.float32)
+    rs = o.root_states.reshape(n, -1, 13).copy(); rs[:, 0, :] = 0; rs[:, 0, 2] = 1.0; rs[:, 0, 6] = 1.0
+    rs[:, 1, :] = 0; rs[:, 1, 0:3] = (0.0, 3.0, 0.08); rs[:, 1, 6] = 1.0
+    o.set_root_states(rs.reshape(-1, 13))
+    ds = np.zeros((n, 18, 2), np.float32); ds[:, :, 0] = dflt
+    o.set_dof_state(ds.reshape(-1, 2))
+    act = np.zeros((n, 18), np.float32); act[:, 5] = -0.7
+    pens, rolls = [], []
+    for k in range(120):
+        o.pre_physics(act); o.simulate()
+        if k >= 60:
+            pens.append(capsule_penetration(o, n, model).max()); rolls.append(o.dof_state.reshape(n, 18, 2)[:, 5, 0].copy())
+    assert max(pens) < 0.005, max(pens)
+    assert np.ptp(np.array(rolls[30:]), axis=0).max() < 0.01
+    assert -0.25 < rolls[-1].min() and rolls[-1].max() < -0.03, (rolls[-1].min(), rolls[-1].max())
