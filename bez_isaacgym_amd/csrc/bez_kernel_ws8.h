@@ -18,8 +18,7 @@
 // The deepest of the three ball candidates wins (left, right, torso on ties, the box order of the oracle); every owner decides
 // locally from the three published depths whether it is the winner, and only the winner evaluates the contact operands (a leg
 // wave skips that block altogether unless one of its 64 envs has a ball<->leg contact).
-// All roles execute the same barriers (B0, per substep B1 B1c B1d B2 B3 B4 B5; B1d: the legs exchange the sums of the leg<->leg contact
-// scale).  512 threads, <= 256 VGPRs per wave.
+// All roles execute the same barriers (B0, per substep B1 B1c B2 B3 B4 B5).  512 threads, <= 256 VGPRs per wave.
 // The action / observation staging block aliases the X_IA slots (actions are consumed before the first X_IA store, the
 // observation rows are staged after the last X_IA load).
 #pragma once
@@ -39,6 +38,8 @@ enum : int {
   X_PSUM = 34,     // per chain-owning role (0,1,2,4,5): sum of (default - q)^2 over its joints; slot 3 (no chain): X_RESETF
   X_CAND = 40,     // per leg: depth, link, n(3), P(3), V(6) of its deepest ball/box candidate among the lower boxes (roles 4 / 5) = 14 x 2
   X_TORSO = 68,    // depth of the torso-box candidate (role 3)
+  X_SELFF2 = 69,   // per helper part: sum of |force|^2 over its active leg<->leg pairs (2)
+  X_PAIRSEQ = 71,  // lanes 0 / 1 of this slot: the two leg waves' sequence words (ws_pair_publish); 72..80 unused
   X_LEGQ = 81,     // per leg: q(6) qd(6) at the start of the substep (read by the helper roles)
   X_SELF = 105,    // 2 helper parts x [per leg box link (left 5, right 5): bias wrench (6) + reported force (3)] = 2 x 90
   X_CF = 285,      // net contact force rows, up to BEZ_NBE_MAX = 30 bodies (mean over substeps)
@@ -48,7 +49,7 @@ enum : int {
   X_CANDH = 610,   // per leg: the same 14 floats for the upper boxes (hip / thigh links), from role 2
   X_SLOTS = 638,
   X_RESETF = X_PSUM + 3,  // 1.0 where this step resets the env: its contact rows leave the kernel as zeros (written by role 7, read by the copy-out)
-  X_SELFSUM = X_PSUM     // inside the substep loop (the pose-error slots are written after it): per leg the three partial sums of the leg<->leg contact scale
+  X_SELFSUM = X_PSUM     // inside the substep loop (the pose-error slots are written after it): per leg the two joint sums of the leg<->leg contact scale
 };
 #ifndef BEZ_W8_CAND_SPLIT
 #define BEZ_W8_CAND_SPLIT 4
@@ -319,13 +320,15 @@ BEZ_DEV void leg_role(const Params& P, float* lds, int lane, int e, bool active,
     P3 p3[LEN];
     Sym6 IA = sym6zero(); SV pA = svzero();
     ws_chain_pass2<FIRST, LEN, true>(P, D, kps, kds, lo, hi, q, qd, target, LI, pAl, Sl, cbl, Kc, pc, mine, sel, p3, IA, pA);
+    {  // the chain's articulated inertia goes to its X_IA block NOW (free since B1: the staged actions are consumed): 21 registers
+       // less across the barrier and the correction below; the bias follows once the leg<->leg share is in it
+      const float* f = (const float*)&IA;
+#pragma unroll
+      for (int i = 0; i < 21; ++i) XS(X_IA + side * 27 + i) = f[i];
+    }
     WS_STAMP(side, 24 + s);
     ws_barrier();  // B1c: both helper parts' leg<->leg contact wrenches are in LDS
-    SelfCorr sc_;
-    ws_chain_self_prepare<LEN>(P, lds, lane, side, p3, sc_);
-    ws_barrier();  // B1d: both legs' partial sums of the contact scale are in LDS
-    const float sc = ws_chain_self_apply<LEN>(P, lds, lane, sc_, p3, pA);
-    xs_store_sym6(lds, lane, X_IA + side * 27, IA, pA);
+    const float sc = ws_chain_self_correction<LEN>(P, lds, lane, side, s + 1, p3, pA);   // (stores the bias part of the chain's X_IA block)
     WS_STAMP(side, 4 + 8 * s);
     ws_barrier();  // B2
     WS_STAMP(side, 5 + 8 * s);
@@ -416,7 +419,6 @@ BEZ_DEV void head_role(const Params& P, float* lds, int lane, int e, bool active
     C.up(P, in_loop(D), lds, lane);
     WS_STAMP(2, 4 + 8 * s);
     ws_barrier();  // B1c: head and arm blocks are in LDS (role 4 sums them into block 2 before B2)
-    ws_barrier();  // B1d
     ws_barrier();  // B2
     ws_barrier();  // B3
     C.down(P, lds, lane, keep, first);
@@ -464,7 +466,6 @@ BEZ_DEV void cand_arm_role(const Params& P, float* lds, int lane, int e, bool ac
       add_to(I2, C.IAc); p2 = p2 + C.pAc;
       xs_store_sym6(lds, lane, X_IA + 2 * 27, I2, p2);
     }
-    ws_barrier();  // B1d
     ws_barrier();  // B2
     ws_barrier();  // B3
     C.down(P, lds, lane, keep, first);
@@ -574,7 +575,6 @@ BEZ_DEV void self_role(const Params& P, float* lds, int lane, int e, bool active
     ws_self_pairs<PART>(P, D.mu, lds, lane, K);
     WS_STAMP(6 + PART, 4 + 8 * s);
     ws_barrier();  // B1c
-    ws_barrier();  // B1d
     ws_barrier();  // B2
     ws_barrier();  // B3
     ws_barrier();  // B4
@@ -682,7 +682,6 @@ BEZ_DEV void root_role(const Params& P, float* lds, int lane, int e, bool active
     if (torso_hit) { add_point_stiffness(IA0, sel.x, sel.A); pA0 = pA0 - wrench_at(sel.x, sel.f0p); }
     WS_STAMP(3, 24 + s);
     ws_barrier();  // B1c
-    ws_barrier();  // B1d
     ws_barrier();  // B2: chain contributions published
     WS_STAMP(3, 5 + 8 * s);
 #pragma unroll
@@ -783,6 +782,7 @@ __global__ __launch_bounds__(WS_BLOCK) void step_kernel_ws8(Params P) {
     const float* src = P.actions + (size_t)env0 * BEZ_ND;
     for (int i = tid; i < nloc * BEZ_ND; i += WS_BLOCK) act[(i / BEZ_ND) * WS_ACT_STRIDE + (i % BEZ_ND)] = src[i];
   }
+  if (tid < 2) reinterpret_cast<int*>(lds + X_PAIRSEQ * WS_ENVS)[tid] = 0;   // (published before B0)
   // contact-force rows start from zero: bodies nothing touches are never accumulated into
   constexpr int NROW = (nb_of<CL>() + 1) * 3;  // contact-force rows of this asset (robot bodies + ball)
   for (int i = tid; i < NROW * WS_ENVS; i += WS_BLOCK) lds[X_CF * WS_ENVS + i] = 0.f;

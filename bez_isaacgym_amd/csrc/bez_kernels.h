@@ -537,11 +537,15 @@ BEZ_DEV void joint_terms(const Params& P, float kp_scale, float kd_scale, float 
   else if (tau_drive < -P.effort) { tau = -P.effort + tau_f0 + tau_l0; Dj = J + k_f + k_l; }
   else { tau = tau_pd0 + tau_f0 + tau_l0; Dj = J + k_pd + k_f + k_l; }
   g = frcp(Dj);
-  qdd_hp = (tau - bias) * g;
   w = (tau - sp) * g;
-  const float v_pred = fmaf(P.h, qdd_hp, qd);
-  if (v_pred > P.vel_limit) { g = 0.f; w = qdd_hp = (P.vel_limit - qd) * P.inv_h; }
-  else if (v_pred < -P.vel_limit) { g = 0.f; w = qdd_hp = (-P.vel_limit - qd) * P.inv_h; }
+  qdd_hp = fmaf(-ucb, g, w);
+#ifndef BEZ_AB_NO_VLIM
+  // v_pred = qd + h qdd_hp beyond +-vel_limit  <=>  qdd_hp outside [alo, ahi], the accelerations that reach the limits in one substep
+  const float ahi = (P.vel_limit - qd) * P.inv_h, alo = (-P.vel_limit - qd) * P.inv_h;
+  const float fix = fminf(fmaxf(qdd_hp, alo), ahi);
+  const bool lock = fix != qdd_hp;
+  w = lock ? fix : w; g = lock ? 0.f : g; qdd_hp = fix;
+#endif
 }
 
 // sums of the leg<->leg contact scale (oracle: self_contact_scale), accumulated joint by joint while the legs run pass 2
@@ -549,7 +553,7 @@ struct SelfSums { float am, as, f2; };
 BEZ_DEV float self_scale(const Params& P, const SelfSums& Z) {
   if (!(Z.f2 > 0.f)) return 0.f;
   const float K = fmaf(P.h * P.h, P.self_kn, P.h * P.self_cn);
-  const float sc = (Z.f2 - K * Z.am) / fmaf(SELF_IMPLICIT * K, Z.as, Z.f2);
+  const float sc = fmaf(-K, Z.am, Z.f2) * frcp(fmaf(SELF_IMPLICIT * K, Z.as, Z.f2));
   return fminf(fmaxf(sc, 0.f), 8.f);   // (NaN-safe the oracle's way: !(sc > 0) -> 0)
 }
 
@@ -591,7 +595,7 @@ BEZ_DEV void chain_up(const Params& P, const EnvDyn& D, const EnvState& S, const
     constexpr int L = FIRST + i;
     add_link_inertia(IA, LI[i]);
     pA = pA + pAl[i];
-    if constexpr (link_has_box(L)) { pS = pS + selfw[L]; wsub = wsub + selfw[L]; Z.f2 = fmaf(0.5f, dot(selfw[L].l, selfw[L].l), Z.f2); }
+    if constexpr (link_has_box(L)) { pS = pS + selfw[L]; wsub = wsub + selfw[L]; }
     if constexpr (link_has_box(L)) {
       if (sel.link == L) {
         add_point_stiffness(IA, sel.x, sel.A);
@@ -710,7 +714,7 @@ BEZ_DEV void substep(const Params& P, const EnvDyn& D, EnvState& S, const float*
     });
     test_torso_box(P, E0, mk(0, 0, 0), bc, sel);
   }
-  SV selfw[BEZ_NL]; V3 selfcf[BEZ_NL];
+  SV selfw[BEZ_NL]; V3 selfcf[BEZ_NL]; float selff2 = 0.f;   // per-link bias wrenches / reported forces of the leg<->leg pairs, and the sum of their |force|^2
 #pragma unroll
   for (int l = 0; l < BEZ_NL; ++l) { selfw[l] = svzero(); selfcf[l] = mk(0, 0, 0); }
   if (!(P.flags & BEZ_FLAG_NO_SELF_COLLISION)) {
@@ -720,7 +724,7 @@ BEZ_DEV void substep(const Params& P, const EnvDyn& D, EnvState& S, const float*
       V3 x, f, fn;
       if (self_pair(P, D.mu, (float)BEZ_CAP_R[ia], (float)BEZ_CAP_R[ib], cap0[ia], cap1[ia], cap0[ib], cap1[ib], capV[ia], capV[ib], x, f, fn)) {
         SV w = wrench_at(x, f);
-        selfw[la] = selfw[la] - w; selfw[lb] = selfw[lb] + w;
+        selfw[la] = selfw[la] - w; selfw[lb] = selfw[lb] + w; selff2 = fmaf(f.x, f.x, fmaf(f.y, f.y, fmaf(f.z, f.z, selff2)));
         V3 fr = (P.flags & BEZ_FLAG_CF_WITH_FRICTION) ? f : fn;
         selfcf[la] = selfcf[la] + fr; selfcf[lb] = selfcf[lb] - fr;
       }
@@ -741,7 +745,7 @@ BEZ_DEV void substep(const Params& P, const EnvDyn& D, EnvState& S, const float*
       if (sel.link == 0) { add_point_stiffness(IA0, sel.x, sel.A); pA0 = pA0 - wrench_at(sel.x, sel.f0p); }
     }
   }
-  SV pS0 = svzero(); SelfSums Z; Z.am = Z.as = Z.f2 = 0.f;
+  SV pS0 = svzero(); SelfSums Z; Z.am = Z.as = 0.f; Z.f2 = selff2;
   chain_up<1, 2, CL>(P, D, S, target, E0, V0, ball, bc, sel, selfw, IA0, pA0, pS0, Z, lds, lane, keep);    // neck, head
   chain_up<3, 2, CL>(P, D, S, target, E0, V0, ball, bc, sel, selfw, IA0, pA0, pS0, Z, lds, lane, keep);    // left arm
   chain_up<5, 6, CL>(P, D, S, target, E0, V0, ball, bc, sel, selfw, IA0, pA0, pS0, Z, lds, lane, keep);    // left leg

@@ -368,7 +368,7 @@ static void segment_closest(V3 p1, V3 q1, V3 p2, V3 q2, V3* c1, V3* c2) {
   *c1 = v3add(p1, v3scale(d1, s));
   *c2 = v3add(p2, v3scale(d2, t));
 }
-static void self_collision(const BezSimConfig* c, real hs, real mu, const Kin* k, const SV* V, SV* pS, real cf[][3], int with_fric) {
+static void self_collision(const BezSimConfig* c, real hs, real mu, const Kin* k, const SV* V, SV* pS, real cf[][3], int with_fric, real* f2) {
   /* hs = the substep the spring looks ahead by (0: the round-5 explicit law, kept for the oracle-only solver families) */
   for (int pr = 0; pr < BEZ_NCPAIR; ++pr) {
     const int ia = BEZ_CPAIR[pr][0], ib = BEZ_CPAIR[pr][1];
@@ -399,6 +399,7 @@ static void self_collision(const BezSimConfig* c, real hs, real mu, const Kin* k
     V3 f = v3add(fn, v3scale(ut, -ct));                                   /* force on link la; -f on link lb */
     pS[la] = sv_add(pS[la], sv_scale(wrench_at(x, f), -1));
     pS[lb] = sv_add(pS[lb], wrench_at(x, f));
+    if (f2) *f2 += v3dot(f, f);
     V3 fr = with_fric ? f : fn;
     for (int i = 0; i < 3; ++i) { cf[m_link_body(c, la)][i] += fr.v[i]; cf[m_link_body(c, lb)][i] -= fr.v[i]; }
   }
@@ -417,14 +418,13 @@ static void self_collision(const BezSimConfig* c, real hs, real mu, const Kin* k
  * each other; BEZ_SELF_IMPLICIT = 2 covers the recoil the diagonal leaves out (J M^-1 J^T against its diagonal part).  The scale is known
  * BEFORE the root solve, so the scaled wrenches enter as the exact linear correction of pass 2's bias recursion they always were. */
 #define BEZ_SELF_IMPLICIT 2.0
-static real self_contact_scale(const BezSimConfig* c, real h, const SV* S, const SV* W, const real* g, const real* qdd_hp) {
+static real self_contact_scale(const BezSimConfig* c, real h, const SV* S, const SV* W, real F2, const real* g, const real* qdd_hp) {
   SV Wsub[NL]; memcpy(Wsub, W, sizeof(Wsub));
-  real AM = 0, AS = 0, F2 = 0;
+  real AM = 0, AS = 0;
   for (int l = NL - 1; l >= 1; --l) {
     real t = sv_dot(S[l], Wsub[l]);
     AS += t * t * g[l]; AM += t * qdd_hp[l];
     Wsub[BEZ_LINK_PARENT[l]] = sv_add(Wsub[BEZ_LINK_PARENT[l]], Wsub[l]);
-    F2 += (real)0.5 * (W[l].v[3] * W[l].v[3] + W[l].v[4] * W[l].v[4] + W[l].v[5] * W[l].v[5]); /* each pair's force sits on two links */
   }
   if (!(F2 > 0)) return 0;
   const real K = h * h * (real)c->self_kn + h * (real)c->self_cn;
@@ -516,6 +516,7 @@ static void dynamics_x(const BezSimConfig* c, const Env* e, real h, int mode, co
   V3 g = v3(e->gravity[0], e->gravity[1], e->gravity[2]);
   SV *V = P1.V, *S = P1.S, *cb = P1.cb, *pA = P1.pA;
   SV pS[NL]; /* leg<->leg contact wrenches (as bias forces), propagated next to pA: the predictors below do not see them */
+  real F2self = 0; /* sum over the pairs of |force|^2 */
   SV Wself[NL]; real cfs[NBMAX][3]; /* the same as wrenches ON the links, and the contact-force rows they report: both scaled by self_contact_scale */
   M6* IA = P1.IA;
   memset(pS, 0, sizeof(pS)); memset(Wself, 0, sizeof(Wself)); memset(cfs, 0, sizeof(cfs));
@@ -549,7 +550,7 @@ static void dynamics_x(const BezSimConfig* c, const Env* e, real h, int mode, co
       }
     }
     if (!(c->flags & BEZ_FLAG_NO_SELF_COLLISION)) {
-      self_collision(c, h, mu, &k, V, pS, cfs, (c->flags & BEZ_FLAG_CF_WITH_FRICTION) != 0);
+      self_collision(c, h, mu, &k, V, pS, cfs, (c->flags & BEZ_FLAG_CF_WITH_FRICTION) != 0, &F2self);
       for (int l = 0; l < NL; ++l) Wself[l] = sv_scale(pS[l], -1);
     }
     /* ball */
@@ -711,7 +712,7 @@ static void dynamics_x(const BezSimConfig* c, const Env* e, real h, int mode, co
     pS[p] = sv_add(pS[p], sv_add(pS[l], sv_scale(U[l], wS[l])));
   }
   /* the leg<->leg forces' common scale, then their (linear) share of the joint accelerations and of the torso's bias */
-  const real sc = mode == 0 ? self_contact_scale(c, h, S, Wself, gj, qdd_hp) : 0;
+  const real sc = mode == 0 ? self_contact_scale(c, h, S, Wself, F2self, gj, qdd_hp) : 0;
   for (int l = 1; l < NL; ++l) wj[l] += sc * wS[l];
   for (int b = 0; b < NBMAX; ++b) for (int i = 0; i < 3; ++i) out->contact_force[b][i] += sc * cfs[b][i];
   /* root */
@@ -877,7 +878,7 @@ static void dynamics_hard(const BezSimConfig* c, const Env* e, real h, DynH* out
   /* explicit leg <-> leg penalty contact, as in the compliant model */
   SV pS[NL]; memset(pS, 0, sizeof(pS));
   if (!(c->flags & BEZ_FLAG_NO_SELF_COLLISION))
-    self_collision(c, 0, mu, k, V, pS, out->contact_force, (c->flags & BEZ_FLAG_CF_WITH_FRICTION) != 0);
+    self_collision(c, 0, mu, k, V, pS, out->contact_force, (c->flags & BEZ_FLAG_CF_WITH_FRICTION) != 0, NULL);
 
   /* ---- contact detection */
   HContact C[HC_MAXC]; int nc = 0;
