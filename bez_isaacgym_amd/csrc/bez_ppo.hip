@@ -1055,6 +1055,33 @@ int bez_ppo_grad_norm_parts(const float* grads_dev, int64_t n, float* parts_dev,
   return rc ? rc : (int)g;
 }
 
+static unsigned adam_grid(int64_t n) {
+  unsigned g = (unsigned)((n + 2 * ADAM_TB - 1) / (2 * ADAM_TB));
+  if (g < 8) g = 8;
+  if (g > 256) g = 256;
+  return g;
+}
+// workgroups of adam_fused_kernel that fit on the current device at the same time (queried once per device)
+static int adam_resident_capacity(int* out) {
+  static int cached[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return -1;
+  if (cached[dev] == 0) {
+    int per_cu = 0, cus = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, adam_fused_kernel, ADAM_TB, 0) != hipSuccess) return -1;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return -1;
+    cached[dev] = per_cu * cus > 0 ? per_cu * cus : -1;
+  }
+  *out = cached[dev] > 0 ? cached[dev] : 0;
+  return 0;
+}
+int bez_ppo_adam_grid_capacity(int64_t n, int32_t* resident_workgroups, int32_t* launch_workgroups) {
+  if (n <= 0 || !resident_workgroups || !launch_workgroups) return -1;
+  int cap = 0;
+  if (adam_resident_capacity(&cap) != 0) return -2;
+  *resident_workgroups = cap; *launch_workgroups = (int32_t)adam_grid(n);
+  return 0;
+}
 int bez_ppo_adam_step(float* params_dev, const float* grads_dev, float* exp_avg_dev, float* exp_avg_sq_dev, int64_t n, float* steps_dev,
                       int32_t nsteps, float* lr_dev, float beta1, float beta2, float eps, float weight_decay, float max_norm, float* scale_dev,
                       int32_t* growth_tracker_dev, float growth_factor, float backoff_factor, int32_t growth_interval, float* work_dev,
@@ -1083,9 +1110,11 @@ int bez_ppo_adam_step(float* params_dev, const float* grads_dev, float* exp_avg_
     ex.rms_mom = extra->rms_moments_dev; ex.rms_d = extra->rms_cols; ex.rms_mean = extra->rms_mean_dev; ex.rms_var = extra->rms_var_dev; ex.rms_count = extra->rms_count_dev;
   }
   // one slice of <= 2 elements per thread keeps the update short; at least 8 workgroups so that every XCD has one
-  unsigned g = (unsigned)((n + 2 * ADAM_TB - 1) / (2 * ADAM_TB));
-  if (g < 8) g = 8;
-  if (g > 256) g = 256;
+  const unsigned g = adam_grid(n);
+  if (ex.gridnorm) {   // the in-launch norm is a grid barrier: every workgroup of the launch has to be resident at once (round-5 advisor finding)
+    int cap = 0;
+    if (adam_resident_capacity(&cap) != 0 || (int)g > cap) return -6;
+  }
   hipLaunchKernelGGL(adam_fused_kernel, dim3(g), dim3(ADAM_TB), 0, st, params_dev, grads_dev, exp_avg_dev, exp_avg_sq_dev, n, steps_dev, (int)nsteps, lr_dev,
                      beta1, beta2, eps, weight_decay, max_norm, scale_dev, growth_tracker_dev, growth_factor, backoff_factor, growth_interval,
                      reinterpret_cast<unsigned int*>(work_dev), (__half*)params_f16_dev, tail, ex);

@@ -33,6 +33,15 @@ import torch.nn as nn
 _MEASURE_NO_COLLECTIVE = os.environ.get("BEZ_PPO_MEASURE_NO_COLLECTIVE") == "1"
 
 
+def _skip_collective_for_measurement():
+    """the knob is honoured on a 1-rank group only: dropped on real ranks it would let the replicas diverge without an error (round-5 advisor finding)"""
+    if not _MEASURE_NO_COLLECTIVE:
+        return False
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        raise RuntimeError("BEZ_PPO_MEASURE_NO_COLLECTIVE=1 is a 1-rank measurement knob; unset it for a %d-rank job" % dist.get_world_size())
+    return True
+
+
 def _dist_on():
     # BEZ_PPO_FORCE_DIST=1 (tests): treat a 1-rank process group as data parallel, so the real RCCL calls run on a 1-GPU box
     return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or os.environ.get("BEZ_PPO_FORCE_DIST") == "1")
@@ -479,7 +488,7 @@ class A2CAgent:
                     # ... and the input-gradient chain of the minibatch backward pass as one kernel on transposed copies
                     if (hflat is not None and c.get("fused_policy_backward", True) and all(32 <= w.shape[0] <= 416 and w.shape[0] % 2 == 0 for w, _ in wb[:nh])):
                         self._policy_bwd = F.PolicyBackward(hflat, layout, act_dim, self._packed)
-        if self._segmented and not self.fused:
+        if (self._segmented or world > 1 or _dist_on()) and not self.fused:   # (also with dp_capture_collectives: the plain torch path is never captured across ranks)
             self.use_graphs = False  # the plain torch path has collectives in the middle of autograd-heavy code: eager only
         self._seg = None  # segmented graphs of the data-parallel update
         if _dist_on():  # identical replicas (hvd.broadcast_parameters equivalent)
@@ -1163,7 +1172,9 @@ class A2CAgent:
                 # ... and the norm of the all-reduced buffer is formed INSIDE the optimiser launch: every workgroup sums its own slice, the
                 # workgroups meet at a counter (`dp_grid_norm`, default).  Off: one small launch re-forms the shares (bez_ppo_grad_norm_parts).
                 # (Every workgroup reading the whole gradient instead costs the launch 18 us against 9.)
-                if self.cfg.get("dp_grid_norm", True):
+                if getattr(self, "_grid_fits", None) is None:   # (host query, once: can every workgroup of the launch be resident at the same time?)
+                    self._grid_fits = bool(self._F.adam_grid_fits(self._nparam))
+                if self.cfg.get("dp_grid_norm", True) and self._grid_fits:
                     gridn = getattr(self, "_grid_norm", None)
                     if gridn is None:
                         assert not torch.cuda.is_current_stream_capturing()
@@ -1327,7 +1338,7 @@ class A2CAgent:
                 seg["cb"][s_ % nm].replay()
                 if s_ % nm == 0:
                     close_mini_epoch(s_ // nm - 1)
-            if _dist_on() and not _MEASURE_NO_COLLECTIVE:
+            if _dist_on() and not _skip_collective_for_measurement():
                 dist.all_reduce(self._flat)
         seg["c"].replay()
         close_mini_epoch(self.mini_epochs - 1)

@@ -40,9 +40,10 @@ _SIGS = {
     "bez_ppo_grad_reduce_all": [_vp, _vp, _vp, _i64, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i32, _vp, _vp],
     "bez_ppo_grad_reduce_blocks": [_vp, _i32, _vp, _i32],
     "bez_ppo_grad_norm_parts": [_vp, _i64, _vp, _i32, _vp],
+    "bez_ppo_adam_grid_capacity": [_i64, _vp, _vp],
 }
 _lib = None
-PPO_ABI_VERSION = 8   # BEZ_PPO_ABI_VERSION (include/bez_sim.h)
+PPO_ABI_VERSION = 9   # BEZ_PPO_ABI_VERSION (include/bez_sim.h)
 
 
 def lib():
@@ -220,6 +221,16 @@ def loss_scratch(b, a, device):
 
 ADAM_WORK_FLOATS = 258   # BEZ_PPO_ADAM_WORK_FLOATS
 ADAM_GRIDNORM_FLOATS = 516   # BEZ_PPO_ADAM_GRIDNORM_FLOATS
+
+
+def adam_grid_fits(n):
+    """True when every workgroup of the optimiser launch for n parameters is resident at once on the current device -- the condition of the
+    in-launch gradient norm (AdamExtra.grid_norm_dev: the workgroups meet at a counter); bez_ppo_adam_step refuses the launch (-6) otherwise."""
+    cap, g = C.c_int32(0), C.c_int32(0)
+    rc = lib().bez_ppo_adam_grid_capacity(int(n), C.addressof(cap), C.addressof(g))
+    if rc != 0:
+        raise RuntimeError("bez_ppo_adam_grid_capacity failed (%d)" % rc)
+    return g.value <= cap.value
 
 
 def adam_step(params, grads, exp_avg, exp_avg_sq, steps, lr, betas, eps, weight_decay, max_norm, scale, growth_tracker, growth_factor,

@@ -324,7 +324,7 @@ int bez_sim_time_steps(BezSim* sim, const float* actions_dev, int32_t n_steps, v
 
 /* The signatures below change between rounds (round 3: scratch buffers of the fixed-order reductions, plan / run split of the weight
  * gradients, the optimiser tail's bookkeeping): a binding checks this number once after dlopen. */
-#define BEZ_PPO_ABI_VERSION 8
+#define BEZ_PPO_ABI_VERSION 9
 int32_t bez_ppo_abi_version(void);
 
 /* RunningMeanStd (normalize_input / normalize_value, bez_kickPPO.yaml:51-52): moments[0:D] = column sums, [D:2D] = sums of
@@ -588,6 +588,11 @@ typedef struct BezPpoAdamExtra {
 int bez_ppo_grad_norm_parts(const float* grads_dev, int64_t n, float* parts_dev, int32_t parts, void* stream);
 #define BEZ_PPO_ADAM_WORK_FLOATS 258
 #define BEZ_PPO_ADAM_GRIDNORM_FLOATS 516
+/* How many workgroups of bez_ppo_adam_step's launch can be resident on the current device at once (occupancy x compute units), and how
+ * many the launch uses for n parameters.  With BezPpoAdamExtra.grid_norm_dev the launch's workgroups meet at a counter: that is only safe
+ * when all of them are co-resident (a CU-masked or partitioned device, a smaller part, two ranks on one GPU can break the assumption) --
+ * bez_ppo_adam_step then returns -6 instead of launching, and the caller falls back to bez_ppo_grad_norm_parts (PPO ABI 9). */
+int bez_ppo_adam_grid_capacity(int64_t n, int32_t* resident_workgroups, int32_t* launch_workgroups);
 int bez_ppo_adam_step(float* params_dev, const float* grads_dev, float* exp_avg_dev, float* exp_avg_sq_dev, int64_t n, float* steps_dev,
                       int32_t nsteps, float* lr_dev, float beta1, float beta2, float eps, float weight_decay, float max_norm, float* scale_dev,
                       int32_t* growth_tracker_dev, float growth_factor, float backoff_factor, int32_t growth_interval, float* work_dev,

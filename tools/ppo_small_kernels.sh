@@ -3,7 +3,7 @@
 set -e
 export TMPDIR=/tmp
 rm -rf gpurun_out/small
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/small -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --ppo-epochs 10 > gpurun_out/small.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/small -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-dp-path --ppo-epochs 10 > gpurun_out/small.log 2>&1
 export SMALL_EPOCHS=$(python3 -c "import json; d=json.loads(open('gpurun_out/small.log').read().strip().splitlines()[-1]); print(d['ppo']['epochs'] + 4)")
 python3 - <<'PY'
 import csv, glob
