@@ -25,7 +25,6 @@ namespace bez {
 
 constexpr int BLOCK = 64;  // one wave per workgroup
 constexpr float SELF_IMPLICIT = 2.0f;  // BEZ_SELF_IMPLICIT of the oracle (self_contact_scale)
-constexpr float SELF_CONTACT_OFFSET = 0.02f;  // BEZ_SELF_CONTACT_OFFSET of the oracle (self_collision)
 
 // ---- SoA state fields (floats per env)
 enum : int {
@@ -395,10 +394,7 @@ BEZ_DEV bool self_pair(const Params& P, float mu, float ra, float rb, V3 a0, V3 
   segment_closest(a0, a1, b0, b1, ca, cb);
   V3 dl = ca - cb;
   float d2 = dot(dl, dl), rs = ra + rb;
-  // physx.contact_offset (bez_kick.yaml:139): a pair inside the 2 cm shell is tested with the look-ahead law below, which is positive
-  // only if the current closing speed takes the capsules into each other by the end of the substep (depth < 0 = a gap)
-  constexpr float shell = SELF_CONTACT_OFFSET;
-  if (!(d2 < (rs + shell) * (rs + shell)) || !(d2 > 1e-12f)) return false;
+  if (!(d2 < rs * rs) || !(d2 > 1e-12f)) return false;
   float idist = frsq(d2), depth = rs - d2 * idist;
   V3 n = dl * idist;
   x = fma3(n, rb - 0.5f * depth, cb);

@@ -368,10 +368,9 @@ static void segment_closest(V3 p1, V3 q1, V3 p2, V3 q2, V3* c1, V3* c2) {
   *c1 = v3add(p1, v3scale(d1, s));
   *c2 = v3add(p2, v3scale(d2, t));
 }
-/* physx.contact_offset (bez_kick.yaml:139): PhysX generates a contact 2 cm before the shapes touch and its solver keeps the gap from going
- * negative within the step; here a pair inside that shell is tested with the same look-ahead law, which is positive only if the current
- * closing speed would take the capsules into each other by the end of the substep -- the braking starts before the overlap does */
-#define BEZ_SELF_CONTACT_OFFSET 0.02
+/* (Tried in round 6 and removed: testing the pairs inside physx.contact_offset, bez_kick.yaml:139, 2 cm before the capsules touch, with the same
+ * look-ahead law -- box penetration along the reference policy's rollouts 25.8 -> 24.1 mm, but default-yaml training over eight seeds fell from
+ * 26 / 34 / 1 / 23 / 32 / 37 / 32 / 21 to 35 / 3 / 9 / 1 / 17 / 2 / 21 / 18: profiles/r06_seed_table_contact_offset.txt.) */
 static void self_collision(const BezSimConfig* c, real hs, real mu, const Kin* k, const SV* V, SV* pS, real cf[][3], int with_fric, real* f2) {
   /* hs = the substep the spring looks ahead by (0: the round-5 explicit law, kept for the oracle-only solver families) */
   for (int pr = 0; pr < BEZ_NCPAIR; ++pr) {
@@ -386,9 +385,8 @@ static void self_collision(const BezSimConfig* c, real hs, real mu, const Kin* k
     V3 dl = v3sub(ca, cb);
     real d2 = v3dot(dl, dl);
     real rs = (real)BEZ_CAP_R[ia] + (real)BEZ_CAP_R[ib] + ((c->flags & BEZ_FLAG_HARD_CONTACT) ? 2 * (real)c->tune[6] : 0); /* EXPERIMENT: shape rest offsets */
-    const real shell = hs > 0 ? (real)BEZ_SELF_CONTACT_OFFSET : 0;
-    if (!(d2 < (rs + shell) * (rs + shell)) || !(d2 > (real)1e-12)) continue;
-    real dist = sqrt(d2), depth = rs - dist; /* < 0: a gap the pair may close within this substep (fmag > 0 below decides) */
+    if (!(d2 < rs * rs) || !(d2 > (real)1e-12)) continue;
+    real dist = sqrt(d2), depth = rs - dist;
     V3 n = v3scale(dl, 1 / dist);                                         /* from capsule b towards capsule a */
     V3 x = v3add(cb, v3scale(n, (real)BEZ_CAP_R[ib] - (real)0.5 * depth)); /* mid-point of the overlap, rel. O */
     V3 va = v3add(sv_lin(V[la]), v3cross(sv_ang(V[la]), x)), vb = v3add(sv_lin(V[lb]), v3cross(sv_ang(V[lb]), x));
