@@ -42,6 +42,18 @@ def _skip_collective_for_measurement():
     return True
 
 
+def _make_all_reduce(cfg, device):
+    """The in-place sum over the ranks the data-parallel paths call.  With an RCCL process group on a GPU: a communicator of the package's own,
+    whose ncclAllReduce is enqueued on the TRAINING stream (ppo/rccl_direct.py; `dp_direct_rccl: False` keeps torch.distributed) -- the
+    all-reduce between two graph replays is then stream-ordered, without torch.distributed's two cross-stream event waits.  Otherwise
+    (gloo on CPU, the world-2 tests): torch.distributed."""
+    from . import rccl_direct
+    if cfg.get("dp_direct_rccl", True) and rccl_direct.available(device):
+        comm = rccl_direct.RcclComm(device)
+        return (lambda t: comm.all_reduce_(t)), comm
+    return (lambda t: dist.all_reduce(t)), None
+
+
 def _dist_on():
     # BEZ_PPO_FORCE_DIST=1 (tests): treat a 1-rank process group as data parallel, so the real RCCL calls run on a 1-GPU box
     return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or os.environ.get("BEZ_PPO_FORCE_DIST") == "1")
@@ -337,6 +349,12 @@ class A2CAgent:
         # path's two replays per epoch, collectives included.  torch.distributed supports capturing NCCL / RCCL work; exercised here on a
         # 1-rank group only (a 1-GPU box cannot hold two RCCL ranks), hence off by default
         self._segmented = bool((world > 1 or _dist_on()) and not c.get("dp_capture_collectives", False))
+        self.collective_sizes = []   # element count of every data-parallel sum this agent issued (tests: `steps + 2` per epoch), whatever the transport
+        if _dist_on():
+            fn, self._rccl = _make_all_reduce(c, self.device)
+            self._all_reduce = lambda t: (self.collective_sizes.append(int(t.numel())), fn(t))[1]
+        else:
+            self._all_reduce, self._rccl = (lambda t: t), None
         self.num_actors = int(c["num_actors"])
         self.horizon = int(c["horizon_length"])
         self.gamma, self.tau = float(c["gamma"]), float(c["tau"])
@@ -462,7 +480,7 @@ class A2CAgent:
         if self.fused:
             from . import fused as F
             self._F = F
-            red = (lambda t: dist.all_reduce(t)) if _dist_on() else None
+            red = self._all_reduce if _dist_on() else None
             self._f_obs_rms = F.FusedRunningMeanStd(self.running_mean_std, red) if self.normalize_input else None
             self._f_val_rms = F.FusedRunningMeanStd(self.value_mean_std, red) if self.normalize_value else None
             self.half_path = bool(self.mixed_precision and self.normalize_input and c.get("half_path", True))
@@ -755,10 +773,10 @@ class A2CAgent:
                 st = self._adv_pack
                 done = prep(1)
                 if done:
-                    dist.all_reduce(self._mom_pack)
+                    self._all_reduce(self._mom_pack)
                     prep(2, st)
                     st[3:6] = self.ep_stats
-                    dist.all_reduce(st)
+                    self._all_reduce(st)
                     self.ep_stats.copy_(st[3:6])
                     prep(4, st)
             if done:
@@ -782,7 +800,7 @@ class A2CAgent:
         elif self.normalize_value:
             self._val_mom.copy_(self.value_mean_std.moments(values)); self._ret_mom.copy_(self.value_mean_std.moments(returns))
         if _dist_on():
-            dist.all_reduce(self._mom_pack)
+            self._all_reduce(self._mom_pack)
         if fused_v:
             # RunningMeanStd.forward in train mode, twice (values, then returns): update -> normalise, two launches each
             fx, vr = self._fx, self._f_val_rms
@@ -799,7 +817,7 @@ class A2CAgent:
                 # episode statistics ride along (every rank then reports the job's mean reward, not its shard's)
                 st = self._adv_pack
                 st[0] = adv.sum(); st[1] = (adv * adv).sum(); st[2] = float(adv.numel()); st[3:6] = self.ep_stats
-                dist.all_reduce(st)
+                self._all_reduce(st)
                 self.ep_stats.copy_(st[3:6])
                 mean = st[0] / st[2]
                 std = torch.sqrt(((st[1] / st[2] - mean * mean) * st[2] / (st[2] - 1)).clamp_min(0))
@@ -976,7 +994,7 @@ class A2CAgent:
             self._flat_grad[off:off + p.numel()].copy_(p.grad.reshape(-1))
             off += p.numel()
         self._flat_grad[n] = kl
-        dist.all_reduce(self._flat_grad)
+        self._all_reduce(self._flat_grad)
         self._flat_grad.div_(dist.get_world_size())
         off = 0
         for p in params:
@@ -1216,7 +1234,7 @@ class A2CAgent:
         if _dist_on():
             # ONE all-reduce of the flat STILL-SCALED gradient + KL (124 238 fp32 = 497 KB, latency-bound on xGMI): an fp16
             # overflow on any rank reaches every rank, so unscale_ records the same found_inf everywhere (as DDP does)
-            dist.all_reduce(self._flat)
+            self._all_reduce(self._flat)
         self._phase_c(kl_out, loss_out, next_i)
 
     def calc_gradients(self, mb, kl_out, loss_out, next_i=None):
@@ -1339,7 +1357,7 @@ class A2CAgent:
                 if s_ % nm == 0:
                     close_mini_epoch(s_ // nm - 1)
             if _dist_on() and not _skip_collective_for_measurement():
-                dist.all_reduce(self._flat)
+                self._all_reduce(self._flat)
         seg["c"].replay()
         close_mini_epoch(self.mini_epochs - 1)
 

@@ -596,12 +596,23 @@ st = [a.train_epoch() for _ in range(5)]
 assert a._seg is not None and a._g_rollout is not None
 assert all(np.isfinite([s["kl"], s["a_loss"], s["c_loss"]]).all() for s in st), st
 assert all(torch.isfinite(p).all() for p in a.model.parameters())
-calls, real = [], dist.all_reduce
-dist.all_reduce = lambda t, *ar, **k: (calls.append(int(t.numel())), real(t, *ar, **k))[1]
+assert a._rccl is not None and a._rccl.world == 1          # the package's own communicator: ncclAllReduce on the training stream (ppo/rccl_direct.py)
+seen, real = [], dist.all_reduce
+dist.all_reduce = lambda t, *ar, **k: (seen.append(int(t.numel())), real(t, *ar, **k))[1]
+del a.collective_sizes[:]; n0 = a._rccl.calls
 a.train_epoch()
 dist.all_reduce = real
+calls = list(a.collective_sizes)
 steps = a.mini_epochs * a.num_minibatches
 assert len(calls) == steps + 2 and calls[2:] == [a._flat.numel()] * steps, calls   # SURVEY.md 5.8: ONE collective per optimiser step (+ 2 per epoch)
+assert a._rccl.calls - n0 == steps + 2 and not seen, (a._rccl.calls - n0, seen)   # ... every one of them through the direct communicator, none through torch.distributed
+# the direct all-reduce really sums on the stream it is given: a side stream's buffer, stream-ordered behind a fill
+side = torch.cuda.Stream()
+with torch.cuda.stream(side):
+    buf = torch.full((1000,), 3.0, device="cuda")
+    a._rccl.all_reduce_(buf)
+side.synchronize()
+assert float(buf.sum()) == 3000.0
 dist.destroy_process_group()
 print("DP_OK", st[-1]["kl"])
 ''' % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), __import__("tests.conftest", fromlist=["free_port"]).free_port())

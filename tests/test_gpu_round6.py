@@ -143,6 +143,7 @@ def test_in_launch_gradient_norm_on_a_capped_grid_and_its_residency_guard():
     p_ref, m_ref = step(False)
     for _ in range(2):
         p_g, m_g = step(True)
-        torch.testing.assert_close(p_g, p_ref, rtol=0, atol=2e-9); torch.testing.assert_close(m_g, m_ref, rtol=1e-6, atol=1e-9)
+        # (the two norms add 1.5 M squares in different fixed orders: the clip coefficient may differ in its last bit, an ulp in 0.1 % of the elements)
+        torch.testing.assert_close(p_g, p_ref, rtol=3e-7, atol=2e-9); torch.testing.assert_close(m_g, m_ref, rtol=1e-6, atol=1e-9)
         assert int(grid_buf[512:513].view(torch.int32)) == 0
     assert not torch.equal(p_ref, p0)
