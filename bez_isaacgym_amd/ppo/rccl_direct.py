@@ -73,7 +73,8 @@ class RcclComm:
         if self.rank == 0:
             _chk(lib.ncclGetUniqueId(C.byref(uid)), "ncclGetUniqueId")
         # the id travels through the process group that already exists (as a byte tensor on this rank's GPU: the nccl backend moves GPU tensors)
-        t = torch.frombuffer(bytearray(bytes(uid.internal) if self.rank == 0 else bytes(NCCL_UNIQUE_ID_BYTES)), dtype=torch.uint8).to(self.device)
+        # (C.string_at on the struct: reading the c_char array FIELD would stop at the id's first zero byte)
+        t = torch.frombuffer(bytearray(C.string_at(C.addressof(uid), NCCL_UNIQUE_ID_BYTES) if self.rank == 0 else bytes(NCCL_UNIQUE_ID_BYTES)), dtype=torch.uint8).to(self.device)
         dist.broadcast(t, src=0)
         raw = bytes(t.cpu().numpy().tobytes())
         C.memmove(C.addressof(uid), raw, NCCL_UNIQUE_ID_BYTES)
