@@ -188,16 +188,37 @@ def ppo_roofline(agent, samples_per_s, num_envs):
     path = os.path.join(ROOT, "profiles", "%s_ppo_kernel_stats.csv" % tag) if tag else None
     if path and os.path.exists(path):
         mb = float(agent.minibatch_size)
-        flops = {"policy_forward_kernel<2": ("training forward", 2.0 * macs * mb), "policy_backward_kernel": ("loss + input-gradient chain", 2.0 * bwd_macs * mb),
-                 "wgrad_kernel": ("weight gradients (split-K)", 2.0 * macs * mb), "policy_forward_kernel<1": ("rollout forward", 2.0 * macs * float(agent.num_actors))}
+        # unique operand bytes per row of a launch (what has to cross HBM / Infinity Cache at least once; weights are < 0.3 MB and stay in L2):
+        # hidden widths h, input width d_in, action width A.  fp16 activations, fp32 observations / loss operands / outputs.
+        mats = [p for n_, p in net.named_parameters() if p.dim() == 2]
+        nh = len(mats) - 2                                  # actor_mlp layers, then the mu and value heads
+        d_in = int(mats[0].shape[1]); hid = [int(mats[i].shape[0]) for i in range(nh)]; A = int(mats[nh].shape[0])
+        sh = float(sum(hid))
+        row_bytes = {
+            "policy_forward_kernel<2": 4.0 * d_in + 2.0 * (d_in + sh) + 4.0 * (A + 1),                  # obs in; x0 + every ELU output kept for the backward pass; mu, value out
+            "policy_backward_kernel": 2.0 * sh + 4.0 * 4.0 * A + 2.0 * (sh + A + 1) + 4.0 * 4,           # ELU outputs in; old mu / sigma / action / neglogp blocks; gz of every layer + head gradients out
+            "wgrad_kernel": 2.0 * (sh + A + 1) + 2.0 * (d_in + sh),                                      # dY of every layer + X of every layer, each read once
+            "policy_forward_kernel<1": 4.0 * d_in + 4.0 * (3 * A + 3),                                   # obs in; action, mu, sigma, value, neglogp rows out
+        }
+        flops = {"policy_forward_kernel<2": ("training forward", 2.0 * macs * mb, mb), "policy_backward_kernel": ("loss + input-gradient chain", 2.0 * bwd_macs * mb, mb),
+                 "wgrad_kernel": ("weight gradients (split-K)", 2.0 * macs * mb, mb), "policy_forward_kernel<1": ("rollout forward", 2.0 * macs * float(agent.num_actors), float(agent.num_actors))}
+        ridge = MFMA_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9)      # flop per byte at which the two roofs meet (312)
         rows = []
         for r in csv.DictReader(open(path)):
-            for key, (what, fl) in flops.items():
+            for key, (what, fl, nrow) in flops.items():
                 if key in r["Name"]:
                     us = float(r["AverageNs"]) * 1e-3
+                    by = row_bytes[key] * nrow
+                    inten = fl / by
+                    gbs = by / (us * 1e-6) / 1e9
                     rows.append({"kernel": what, "avg_us": us, "gflop_per_launch": fl / 1e9, "tflops": fl / (us * 1e-6) / 1e12,
-                                 "frac": fl / (us * 1e-6) / 1e12 / MFMA_PEAK_TFLOPS, "calls": int(r["Calls"])})
+                                 "frac": fl / (us * 1e-6) / 1e12 / MFMA_PEAK_TFLOPS, "calls": int(r["Calls"]),
+                                 "unique_mbytes_per_launch": by / 1e6, "flop_per_byte": inten, "bound": "hbm" if inten < ridge else "mfma",
+                                 "hbm_gbs": gbs, "hbm_frac": gbs / HBM_PEAK_GBS})
         out["kernels"] = rows
+        out["ridge_flop_per_byte"] = ridge
+        out["bound_note"] = ("every PPO kernel sits far below the %.0f flop/B ridge (84 - 140 flop/B): the roof that bounds it is HBM, hbm_frac is the honest figure; "
+                             "the MFMA fractions are kept beside it" % ridge)
         out["kernels_source"] = "profiles/%s_ppo_kernel_stats.csv (rocprofv3 --kernel-trace --stats of this build: source hash matches profiles/%s_pmc_traffic.json)" % (tag, tag)
     return out
 
