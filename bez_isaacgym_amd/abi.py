@@ -25,8 +25,8 @@ FLAG_HARD_CONTACT = 64
 FLAG_LEAN_STEP = 128
 FLAG_OBS_NOISE_IN_STEP = 256
 FLAG_TGS_SOLVER = 512
-FLAG_ANKLE_STOP = 1024          # oracle only (this round's experiment; include/bez_sim.h)
-FLAG_ALL_GROUND_SHAPES = 2048   # oracle only
+FLAG_ANKLE_STOP = 1024          # scenario harness: calf <-> foot-plate contact (one-env-per-lane kernel, stl asset without cleats)
+FLAG_ALL_GROUND_SHAPES = 2048   # scenario harness: ground contact at every collision shape's corners (same)
 FLAG_FIX_BASE = 4096            # urdfAsset.fixBaseLink: the torso welded to the world
 TASK_KICK, TASK_WALK, TASK_ORIENT = 0, 1, 2
 TASK_IDS = {"bez_kick": TASK_KICK, "bez_walk": TASK_WALK, "bez_orient": TASK_ORIENT}

@@ -18,6 +18,7 @@
 
 #include "../../include/bez_sim.h"
 #include "bez_model_gen.h"
+#include "bez_shapes_gen.h"
 #include "bez_spatial.h"
 #include "bez_dr_noise.h"
 
@@ -39,7 +40,11 @@ constexpr int P3_STRIDE = 20;                       // UD(6) uD(1) S(6) cb(6) pe
 constexpr int LDS_P3 = 0;                           // 18 joints
 constexpr int LDS_HIT = LDS_P3 + BEZ_ND * P3_STRIDE;  // ground-point records, 8 floats each
 constexpr int HIT_STRIDE = 8;                       // x(3) fn0 kn ct ftx0 fty0
-constexpr int LDS_SLOTS = LDS_HIT + BEZ_NPT * HIT_STRIDE;
+constexpr int LDS_STOP = LDS_HIT + BEZ_NPT * HIT_STRIDE;   // BEZ_FLAG_ANKLE_STOP: per leg 4 corner records (Ja, Jf, lam0) + the foot's normal (3)
+constexpr int STOP_STRIDE = 15;
+constexpr int LDS_SLOTS = LDS_STOP + 2 * STOP_STRIDE;
+static_assert(LDS_SLOTS * BLOCK * 4 <= 160 * 1024, "LDS budget of the one-env-per-lane kernel");
+constexpr float STOP_KN = 2.0e5f, STOP_CN = 1.0e3f;   // calf <-> foot-plate contact (oracle: m_stop_kn / m_stop_cn defaults)
 
 // (DrState, the device-resident state of the domain randomisation: bez_dr_noise.h)
 // (DrSnap, the action-noise snapshot the step kernels keep: bez_dr_noise.h)
@@ -85,6 +90,7 @@ struct Params {
   const float4* dr_pack;     // (N,18) {kp scale, kd scale, lower, upper} = dr_kp / dr_kd / dr_lower / dr_upper in one 16-byte load per joint, or null
   const float* dr_lower;     // (N,18)   or null: physical joint limits (targets keep the model's, kick_env.py:393-400)
   const float* dr_upper;     // (N,18)   or null
+  float* xhit;               // != null: BEZ_FLAG_ALL_GROUND_SHAPES -- scratch for the BEZ_NXPT extra ground-point records, [(point * 8 + k) * n + env]
   unsigned long long* stamps; // diagnostic builds only (-DBEZ_WS_STAMPS): s_memtime per role / phase of workgroup 0
 };
 // the goal an env reset by this launch receives (bez_walk / bez_orient)
@@ -510,13 +516,69 @@ BEZ_DEV void link_ground_forces_cleats(const Params& P, SV acc, const float* lds
   }
 }
 
+// ---- BEZ_FLAG_ALL_GROUND_SHAPES (one-env-per-lane kernel only: the scenario harness): ground contact at the corners of every collision
+// shape of soccerbot_stl.urdf (bez_shapes_gen.h).  118 records do not fit LDS beside the pass-3 operands: they live in a global scratch
+// buffer (coalesced: [(point * 8 + k) * n + env]).  Pass 1 has the link frames: evaluate and store; pass 2 folds a link's records into its
+// articulated inertia / bias; pass 3 resolves the forces into the body rows.
+BEZ_DEV void xhit_store(const Params& P, int e, int idx, const Hit& h) {
+  float* p = P.xhit + (size_t)(idx * 8) * P.n + e;
+  const size_t n = (size_t)P.n;
+  p[0] = h.x.x; p[n] = h.x.y; p[2 * n] = h.x.z; p[3 * n] = h.fn0; p[4 * n] = h.kn; p[5 * n] = h.ct; p[6 * n] = h.ftx0; p[7 * n] = h.fty0;
+}
+BEZ_DEV Hit xhit_load(const Params& P, int e, int idx) {
+  const float* p = P.xhit + (size_t)(idx * 8) * P.n + e;
+  const size_t n = (size_t)P.n;
+  Hit h; h.x = mk(p[0], p[n], p[2 * n]); h.fn0 = p[3 * n]; h.kn = p[4 * n]; h.ct = p[5 * n]; h.ftx0 = p[6 * n]; h.fty0 = p[7 * n];
+  return h;
+}
+template <int L>
+BEZ_DEV void link_xpoints_eval(const Params& P, int e, float mu, float root_z, const M3& E, V3 r, SV V) {
+#pragma unroll
+  for (int i = 0; i < BEZ_NXPT; ++i) {
+    if (BEZ_XPT_LINK[i] == L) {
+      V3 x = r + mul(E, mk((float)BEZ_XPT_POS[i][0], (float)BEZ_XPT_POS[i][1], (float)BEZ_XPT_POS[i][2]));
+      Sym6 dI = sym6zero(); SV dp = svzero();
+      xhit_store(P, e, i, ground_contact(P, P.kn, P.cn, mu, x, root_z + x.z, V, dI, dp));
+    }
+  }
+}
+template <int L>
+BEZ_DEV void link_xpoints_fold(const Params& P, int e, Sym6& IA, SV& pA) {
+#pragma unroll
+  for (int i = 0; i < BEZ_NXPT; ++i) {
+    if (BEZ_XPT_LINK[i] == L) {
+      const Hit h = xhit_load(P, e, i);
+      if (h.kn > 0.f) {
+        add_point_stiffness_diag(IA, h.x, P.h * h.ct, h.kn);
+        pA = pA - wrench_at(h.x, mk(h.ftx0, h.fty0, h.fn0));
+      }
+    }
+  }
+}
+template <int L>
+BEZ_DEV V3 link_xpoints_force(const Params& P, int e, SV acc) {   // the sum over the link's extra points: they all report into the link's own body row
+  V3 f = mk(0, 0, 0);
+#pragma unroll
+  for (int i = 0; i < BEZ_NXPT; ++i) {
+    if (BEZ_XPT_LINK[i] == L) {
+      const Hit h = xhit_load(P, e, i);
+      if (h.kn > 0.f) f = f + cf_ground(P, hit_force(P, h, acc));
+    }
+  }
+  return f;
+}
+BEZ_DEV constexpr bool link_has_xpoints(int l) {
+  for (int i = 0; i < BEZ_NXPT; ++i) if (BEZ_XPT_LINK[i] == l) return true;
+  return false;
+}
+
 // joint drive / friction / limit terms and the ABA joint-space quantities for DOF d = L-1:  g = 1/D, w = (tau - S.pA)/D (pass 3
 // forms qdd = w - g U.(a_parent + c)) and the held-parent acceleration qdd_hp = w - g U.c the predictors work with.  A joint whose
 // held-parent rate would end the substep beyond the speed limit (kick_env.py:327) is a prescribed-rate joint: g = 0, w = the
 // acceleration that puts it ON the limit -- same recursion, and the reaction reaches the parent through pA (oracle: dynamics_x).
 template <int L>
 BEZ_DEV void joint_terms(const Params& P, float kp_scale, float kd_scale, float lo, float hi, float q, float qd, float target, const Sym6& IA, SV pA,
-                         SV S, SV cb, SV& U, float& g, float& w, float& qdd_hp) {
+                         SV S, SV cb, SV& U, float& g, float& w, float& qdd_hp, float stop_tau = 0.f, float stop_k = 0.f) {
   U = mul(IA, S);
   float J = dot(S, U) + P.armature;
   float kp = P.kp * kp_scale, kdm = P.kd * kd_scale;
@@ -527,6 +589,7 @@ BEZ_DEV void joint_terms(const Params& P, float kp_scale, float kd_scale, float 
   float k_l = 0.f, tau_l0 = 0.f;
   if (q < lo) { tau_l0 = fmaf(P.lim_k, lo - q - P.h * qd, -P.lim_d * qd); k_l = fmaf(P.h * P.h, P.lim_k, P.h * P.lim_d); }
   else if (q > hi) { tau_l0 = fmaf(P.lim_k, hi - q - P.h * qd, -P.lim_d * qd); k_l = fmaf(P.h * P.h, P.lim_k, P.h * P.lim_d); }
+  tau_l0 += stop_tau; k_l += stop_k;   // BEZ_FLAG_ANKLE_STOP: the calf <-> foot-plate contact as a coupled limit of the two ankle joints (0 otherwise)
   float sp = dot(S, pA);
   float ucb = dot(U, cb);
   float bias = sp + ucb;
@@ -567,8 +630,10 @@ BEZ_DEV void static_for(F&& f) { static_for_impl(std::make_integer_sequence<int,
 // articulated inertia / bias into the torso's (IA0, pA0) and stages pass-3 data in LDS.
 template <int FIRST, int LEN, bool CL>
 BEZ_DEV void chain_up(const Params& P, const EnvDyn& D, const EnvState& S, const float* target, const M3& E0, SV V0,
-                      const BallBody& ball, V3 bc, BallSel& sel, const SV* selfw, Sym6& IA0, SV& pA0, SV& pS0, SelfSums& Z, float* lds, int lane, bool keep) {
+                      const BallBody& ball, V3 bc, BallSel& sel, const SV* selfw, Sym6& IA0, SV& pA0, SV& pS0, SelfSums& Z, float* lds, int lane, bool keep, int e) {
   LinkInertia LI[LEN];
+  constexpr bool LEG = (FIRST == 5 || FIRST == 13);
+  M3 Ecalf = E0; V3 rcalf = mk(0, 0, 0);   // BEZ_FLAG_ANKLE_STOP: the calf's frame, kept from pass 1 (legs only)
   SV pAl[LEN], Sl[LEN], cbl[LEN];
   M3 E = E0;
   V3 r = mk(0, 0, 0);
@@ -582,7 +647,44 @@ BEZ_DEV void chain_up(const Params& P, const EnvDyn& D, const EnvState& S, const
     if constexpr (link_has_box(L)) {
       if (sel.link == L) ball_link_contact(P, D.mu, S.ball_ang, S.ball_lin, ball, bc, V, sel);
     }
+    if constexpr (!CL && link_has_xpoints(L)) { if (P.xhit) link_xpoints_eval<L>(P, e, D.mu, S.root_pos.z, E, r, V); }
+    if constexpr (LEG && i == 3) { Ecalf = E; rcalf = r; }
   });
+  // BEZ_FLAG_ANKLE_STOP (oracle: ankle_stop): the bottom corners of the calf box against the top face of the foot plate of the same leg.
+  // The gap depends on the ankle-pitch and foot-roll angles alone, so the contact is the joint-space force tau_d = J_d lambda on those two
+  // joints, lambda = -k (g + h g') - c g' - (h^2 k + h c) sum J_e qdd_e: the own-joint part goes into each joint's D, the cross term is dropped.
+  float stop_tau[2] = {0.f, 0.f}, stop_k[2] = {0.f, 0.f};   // [0] ankle pitch (link FIRST+4), [1] foot roll (link FIRST+5)
+  if constexpr (LEG && !CL) {
+    if (P.flags & BEZ_FLAG_ANKLE_STOP) {
+      constexpr int side = FIRST == 5 ? 0 : 1, bcf = 2 + 5 * side, bff = 4 + 5 * side;
+      static_assert(BEZ_BOX_LINK[bcf] == FIRST + 3 && BEZ_BOX_LINK[bff] == FIRST + 5, "calf / foot boxes of this leg");
+      const float ztop = (float)(BEZ_BOX_CENTER[bff][2] + BEZ_BOX_HALF[bff][2]);
+      const V3 nf = col(E, 2);   // (E, r are the foot's after pass 1)
+      const float kimp = fmaf(P.h * P.h, STOP_KN, P.h * STOP_CN);
+      float* rec = lds + (size_t)(LDS_STOP + side * STOP_STRIDE) * BLOCK + lane;
+      int k = 0;
+#pragma unroll
+      for (int cx = -1; cx <= 1; cx += 2) {
+#pragma unroll
+        for (int cy = -1; cy <= 1; cy += 2) {
+          const V3 pl = mk((float)(BEZ_BOX_CENTER[bcf][0] + cx * BEZ_BOX_HALF[bcf][0]), (float)(BEZ_BOX_CENTER[bcf][1] + cy * BEZ_BOX_HALF[bcf][1]),
+                           (float)(BEZ_BOX_CENTER[bcf][2] - BEZ_BOX_HALF[bcf][2]));
+          const V3 x = rcalf + mul(Ecalf, pl);
+          const float g = dot(nf, x - r) - ztop;
+          const float Ja = -dot(nf, point_of(Sl[4], x)), Jf = -dot(nf, point_of(Sl[5], x));
+          const float gd = fmaf(Ja, S.qd[FIRST + 3], Jf * S.qd[FIRST + 4]);   // dof indices: link - 1
+          float lam0 = -STOP_KN * fmaf(P.h, gd, g) - STOP_CN * gd;
+          const bool on = (g < 0.f) && (lam0 > 0.f);
+          lam0 = on ? lam0 : 0.f;
+          stop_tau[0] = fmaf(Ja, lam0, stop_tau[0]); stop_tau[1] = fmaf(Jf, lam0, stop_tau[1]);
+          if (on) { stop_k[0] = fmaf(kimp * Ja, Ja, stop_k[0]); stop_k[1] = fmaf(kimp * Jf, Jf, stop_k[1]); }
+          rec[(3 * k + 0) * BLOCK] = Ja; rec[(3 * k + 1) * BLOCK] = Jf; rec[(3 * k + 2) * BLOCK] = lam0;
+          ++k;
+        }
+      }
+      rec[12 * BLOCK] = nf.x; rec[13 * BLOCK] = nf.y; rec[14 * BLOCK] = nf.z;
+    }
+  }
   // tip: ground points of the chain-end link (E, r, V are still the tip's)
   Sym6 IA = sym6zero();
   SV pA = svzero();
@@ -602,9 +704,10 @@ BEZ_DEV void chain_up(const Params& P, const EnvDyn& D, const EnvState& S, const
         pA = pA - wrench_at(sel.x, sel.f0p);
       }
     }
+    if constexpr (!CL && link_has_xpoints(L)) { if (P.xhit) link_xpoints_fold<L>(P, e, IA, pA); }
     SV U; float Dinv, uD, qhp;
     joint_terms<L>(P, D.kp_scale[L - 1], D.kd_scale[L - 1], D.lo[L - 1], D.hi[L - 1], S.q[L - 1], S.qd[L - 1], target[L - 1], IA, pA, Sl[i], cbl[i], U,
-                   Dinv, uD, qhp);
+                   Dinv, uD, qhp, (LEG && i >= 4) ? stop_tau[i >= 4 ? i - 4 : 0] : 0.f, (LEG && i >= 4) ? stop_k[i >= 4 ? i - 4 : 0] : 0.f);
     SV UD = U * Dinv;
     const float duD = -dot(Sl[i], pS) * Dinv;
     if constexpr (FIRST == 5 || FIRST == 13) {   // only the legs carry leg<->leg contacts
@@ -631,9 +734,12 @@ BEZ_DEV void chain_up(const Params& P, const EnvDyn& D, const EnvState& S, const
 // place (semi-implicit Euler) and resolves contact forces on the way.  sc = the leg<->leg contacts' common scale.
 template <int FIRST, int LEN, bool CL>
 BEZ_DEV void chain_down(const Params& P, EnvState& S, SV a0, float sc, BallSel& sel, const V3* selfcf, V3& ball_link_force, CfOut& co, const float* lds,
-                        int lane, bool keep, bool first) {
+                        int lane, bool keep, bool first, int e) {
   SV a = a0;
   constexpr int Lend = FIRST + LEN - 1;
+  constexpr bool LEG = (FIRST == 5 || FIRST == 13);
+  float qdd_ankle = 0.f;   // BEZ_FLAG_ANKLE_STOP: the ankle-pitch acceleration, needed with the foot roll's for the contact force
+  V3 fstop = mk(0, 0, 0);  // ... and the force on the calf (the foot receives the opposite)
   V3 fend = mk(0, 0, 0);  // ball force on the chain-end link (a foot), if it is the selected box
   static_for<LEN>([&](auto I) {
     constexpr int i = decltype(I)::value;
@@ -649,8 +755,10 @@ BEZ_DEV void chain_down(const Params& P, EnvState& S, SV a0, float sc, BallSel& 
     float v = fmaf(P.h, qdd, S.qd[L - 1]);   // the speed limit is inside the dynamics (joint_terms): no rate is edited here
     S.qd[L - 1] = v;
     S.q[L - 1] = fmaf(P.h, v, S.q[L - 1]);
+    V3 fx = mk(0, 0, 0);   // BEZ_FLAG_ALL_GROUND_SHAPES: this link's extra ground points
+    if constexpr (!CL && link_has_xpoints(L)) { if (P.xhit) fx = link_xpoints_force<L>(P, e, a); }
     if constexpr (link_has_box(L)) {
-      V3 f = selfcf[L] * sc;
+      V3 f = selfcf[L] * sc + fx;
       if (sel.link == L) {
         ball_link_force = sel.f0p - mul(sel.A, point_of(a, sel.x));
         f = f + cf_along(P, ball_link_force, sel.n);
@@ -659,8 +767,37 @@ BEZ_DEV void chain_down(const Params& P, EnvState& S, SV a0, float sc, BallSel& 
         if constexpr (L == Lend) fend = f;
         else cf_accum(co, link_body<CL>(L), f, P.cf_w, first);
       }
+    } else if constexpr (!CL && link_has_xpoints(L)) {
+      if (keep && P.xhit) {
+        if constexpr (L == Lend) fend = fx;                                  // head / forearms: joins the chain-end guard points below
+        else cf_accum(co, link_body<CL>(L), fx, P.cf_w, first);              // neck: a row nothing else writes
+      }
+    }
+    if constexpr (LEG && !CL) {   // BEZ_FLAG_ANKLE_STOP: lambda = lam0 - (h^2 k + h c) (Ja qdd_ankle + Jf qdd_foot) per corner, +lambda n on the calf, -lambda n on the foot
+      if constexpr (i == 4) qdd_ankle = qdd;
+      if constexpr (i == 5) {
+        if (P.flags & BEZ_FLAG_ANKLE_STOP) {
+          const float* rec = lds + (size_t)(LDS_STOP + (FIRST == 5 ? 0 : 1) * STOP_STRIDE) * BLOCK + lane;
+          const float kimp = fmaf(P.h * P.h, STOP_KN, P.h * STOP_CN);
+          float lam = 0.f;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const float l0 = rec[(3 * k + 2) * BLOCK];
+            const float lk = l0 - kimp * fmaf(rec[(3 * k) * BLOCK], qdd_ankle, rec[(3 * k + 1) * BLOCK] * qdd);
+            lam += (l0 > 0.f && lk > 0.f) ? lk : 0.f;
+          }
+          fstop = mk(rec[12 * BLOCK], rec[13 * BLOCK], rec[14 * BLOCK]) * lam;
+        }
+      }
     }
   });
+  if constexpr (LEG && !CL) {
+    if (keep && (P.flags & BEZ_FLAG_ANKLE_STOP)) {   // the calf's row was stored / accumulated above (first substep: stored): add; the foot's share joins fend
+      float* pc = co.base + (size_t)(link_body<CL>(FIRST + 3) * 3) * co.n;
+      pc[0] = fmaf(fstop.x, P.cf_w, pc[0]); pc[(size_t)co.n] = fmaf(fstop.y, P.cf_w, pc[(size_t)co.n]); pc[(size_t)2 * co.n] = fmaf(fstop.z, P.cf_w, pc[(size_t)2 * co.n]);
+      fend = fend - fstop;
+    }
+  }
   if (keep) {
     constexpr bool foot = (Lend == BEZ_LFOOT_LINK || Lend == BEZ_RFOOT_LINK);
     if constexpr (CL && foot) {  // the foot plate itself only feels the ball / the other leg; the ground acts on the cleats
@@ -690,7 +827,7 @@ BEZ_DEV void quat_integrate(float q[4], V3 w, float h) {
 // ---- one substep of the articulated-body dynamics for this lane's env.  When `keep` the net contact force per body of
 // this substep is accumulated (`first`: it starts the mean): foot rows in `co`, all other rows in HBM.
 template <bool CL>
-BEZ_DEV void substep(const Params& P, const EnvDyn& D, EnvState& S, const float* target, CfOut& co, float* lds, int lane, bool keep, bool first) {
+BEZ_DEV void substep(const Params& P, const EnvDyn& D, EnvState& S, const float* target, CfOut& co, float* lds, int lane, bool keep, bool first, int e) {
   const M3 E0 = quat_to_mat(S.rq[0], S.rq[1], S.rq[2], S.rq[3]);
   const SV V0 = mksv(S.root_ang, S.root_lin);
   const V3 bc = S.ball_pos - S.root_pos;  // ball centre rel. O
@@ -746,11 +883,11 @@ BEZ_DEV void substep(const Params& P, const EnvDyn& D, EnvState& S, const float*
     }
   }
   SV pS0 = svzero(); SelfSums Z; Z.am = Z.as = 0.f; Z.f2 = selff2;
-  chain_up<1, 2, CL>(P, D, S, target, E0, V0, ball, bc, sel, selfw, IA0, pA0, pS0, Z, lds, lane, keep);    // neck, head
-  chain_up<3, 2, CL>(P, D, S, target, E0, V0, ball, bc, sel, selfw, IA0, pA0, pS0, Z, lds, lane, keep);    // left arm
-  chain_up<5, 6, CL>(P, D, S, target, E0, V0, ball, bc, sel, selfw, IA0, pA0, pS0, Z, lds, lane, keep);    // left leg
-  chain_up<11, 2, CL>(P, D, S, target, E0, V0, ball, bc, sel, selfw, IA0, pA0, pS0, Z, lds, lane, keep);   // right arm
-  chain_up<13, 6, CL>(P, D, S, target, E0, V0, ball, bc, sel, selfw, IA0, pA0, pS0, Z, lds, lane, keep);   // right leg
+  chain_up<1, 2, CL>(P, D, S, target, E0, V0, ball, bc, sel, selfw, IA0, pA0, pS0, Z, lds, lane, keep, e);    // neck, head
+  chain_up<3, 2, CL>(P, D, S, target, E0, V0, ball, bc, sel, selfw, IA0, pA0, pS0, Z, lds, lane, keep, e);    // left arm
+  chain_up<5, 6, CL>(P, D, S, target, E0, V0, ball, bc, sel, selfw, IA0, pA0, pS0, Z, lds, lane, keep, e);    // left leg
+  chain_up<11, 2, CL>(P, D, S, target, E0, V0, ball, bc, sel, selfw, IA0, pA0, pS0, Z, lds, lane, keep, e);   // right arm
+  chain_up<13, 6, CL>(P, D, S, target, E0, V0, ball, bc, sel, selfw, IA0, pA0, pS0, Z, lds, lane, keep, e);   // right leg
   // the leg<->leg contacts' common scale (known before the root solve), then their share of the torso's bias
   const float sc = self_scale(P, Z);
   pA0 = pA0 + pS0 * sc;
@@ -764,11 +901,11 @@ BEZ_DEV void substep(const Params& P, const EnvDyn& D, EnvState& S, const float*
     if (sel.link == 0) { fl = sel.f0p - mul(sel.A, point_of(a0, sel.x)); f0 = cf_along(P, fl, sel.n); }
     if (keep) cf_accum(co, 0, f0 + cf_ground(P, link_ground_forces<0>(P, a0, lds, lane)), P.cf_w, first);
   }
-  chain_down<1, 2, CL>(P, S, a0, sc, sel, selfcf, fl, co, lds, lane, keep, first);
-  chain_down<3, 2, CL>(P, S, a0, sc, sel, selfcf, fl, co, lds, lane, keep, first);
-  chain_down<5, 6, CL>(P, S, a0, sc, sel, selfcf, fl, co, lds, lane, keep, first);
-  chain_down<11, 2, CL>(P, S, a0, sc, sel, selfcf, fl, co, lds, lane, keep, first);
-  chain_down<13, 6, CL>(P, S, a0, sc, sel, selfcf, fl, co, lds, lane, keep, first);
+  chain_down<1, 2, CL>(P, S, a0, sc, sel, selfcf, fl, co, lds, lane, keep, first, e);
+  chain_down<3, 2, CL>(P, S, a0, sc, sel, selfcf, fl, co, lds, lane, keep, first, e);
+  chain_down<5, 6, CL>(P, S, a0, sc, sel, selfcf, fl, co, lds, lane, keep, first, e);
+  chain_down<11, 2, CL>(P, S, a0, sc, sel, selfcf, fl, co, lds, lane, keep, first, e);
+  chain_down<13, 6, CL>(P, S, a0, sc, sel, selfcf, fl, co, lds, lane, keep, first, e);
   // (f) ball: Mb ab = -pb - Jb^T fl
   SV ab = ball_minv(ball, svzero() - ball.pb - wrench_at(sel.xb, fl));
   if (keep) {
@@ -1065,7 +1202,7 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(Params P) {
     const bool last_only = (P.flags & BEZ_FLAG_CF_LAST_SUBSTEP) != 0;
     for (int s = 0; s < P.substeps; ++s) {
       const bool last = (s == P.substeps - 1);
-      substep<CL>(P, D, S, target, co, lds, lane, last_only ? last : true, last_only ? true : (s == 0));
+      substep<CL>(P, D, S, target, co, lds, lane, last_only ? last : true, last_only ? true : (s == 0), e);
     }
   } else if (POST && !CL) {
     co.lf = mk(co.base[(size_t)(BEZ_LFOOT_BODY * 3 + 0) * n], co.base[(size_t)(BEZ_LFOOT_BODY * 3 + 1) * n], co.base[(size_t)(BEZ_LFOOT_BODY * 3 + 2) * n]);

@@ -71,6 +71,7 @@ struct BezSim {
   unsigned long long* post_calls_dev = nullptr;  // device-resident call counter keying that draw (HIP-graph replay safe)
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   unsigned long long* stamps = nullptr;  // diagnostic builds only
+  float* xhit = nullptr;                 // BEZ_FLAG_ALL_GROUND_SHAPES: records of the extra ground points (BEZ_NXPT x 8 floats per env)
 };
 
 namespace {
@@ -213,6 +214,7 @@ Params make_params(const BezSim* s, const float* actions) {
   P.dr_lower = s->dr[BEZ_PARAM_DOF_LOWER]; P.dr_upper = s->dr[BEZ_PARAM_DOF_UPPER];
   P.dr_pack = s->dr_pack; P.dr_gravity_uniform = (s->dr[BEZ_PARAM_GRAVITY] && s->gravity_uniform) ? 1 : 0;
   P.stamps = s->stamps;
+  P.xhit = (c.flags & BEZ_FLAG_ALL_GROUND_SHAPES) ? s->xhit : nullptr;
   return P;
 }
 bool has_dr(const BezSim* s) {
@@ -418,7 +420,8 @@ int launch_step(BezSim* s, const float* actions, hipStream_t stream, bool obs_on
     // urdfAsset.fixBaseLink (BEZ_FLAG_FIX_BASE): a test / debugging configuration of the reference (kick_env.py:287) -- served by the
     // one-env-per-lane kernel, which carries the "root acceleration = 0" branch; in the 8-role-wave kernel that branch costs the default
     // configuration 0.8 % (26.56 -> 26.78 us, same box: six more spilled VGPRs in a kernel at its 256-register ceiling)
-    if (s->kernel != 2 && !(s->cfg.flags & BEZ_FLAG_FIX_BASE)) {
+    // (the same holds for the scenario harness's contact variants, BEZ_FLAG_ALL_GROUND_SHAPES / BEZ_FLAG_ANKLE_STOP: one-env-per-lane kernel only)
+    if (s->kernel != 2 && !(s->cfg.flags & (BEZ_FLAG_FIX_BASE | BEZ_FLAG_ALL_GROUND_SHAPES | BEZ_FLAG_ANKLE_STOP))) {
       bez::launch_step_ws8(P, PRE, dr, s->cleats, stream);
       hipError_t e = hipGetLastError();
       if (e != hipSuccess) return fail(s, -2, "step_kernel_ws launch", e);
@@ -471,8 +474,9 @@ const char* bez_sim_last_error(const BezSim* sim) { return sim ? sim->err.c_str(
 static const char* oracle_only(uint32_t flags, const float* tune) {
   if (flags & BEZ_FLAG_HARD_CONTACT) return "BEZ_FLAG_HARD_CONTACT: rigid contact exists only in the CPU oracle; libbez_sim.so has no kernel for it";
   if (flags & BEZ_FLAG_TGS_SOLVER) return "BEZ_FLAG_TGS_SOLVER: the TGS-shaped solver exists only in the CPU oracle; libbez_sim.so has no kernel for it";
-  if (flags & BEZ_FLAG_ANKLE_STOP) return "BEZ_FLAG_ANKLE_STOP: the calf <-> foot-plate contact exists only in the CPU oracle; libbez_sim.so has no kernel for it";
-  if (flags & BEZ_FLAG_ALL_GROUND_SHAPES) return "BEZ_FLAG_ALL_GROUND_SHAPES: ground contact at every shape's corners exists only in the CPU oracle; libbez_sim.so has no kernel for it";
+  // (round 6: the scenario harness's two contact variants run on the one-env-per-lane kernel -- for the asset they are defined for)
+  if ((flags & (BEZ_FLAG_ANKLE_STOP | BEZ_FLAG_ALL_GROUND_SHAPES)) && (flags & (BEZ_FLAG_CLEATS | BEZ_FLAG_BOX_ASSET)))
+    return "BEZ_FLAG_ANKLE_STOP / BEZ_FLAG_ALL_GROUND_SHAPES are defined for soccerbot_stl.urdf without cleats only (as in the CPU oracle); this asset has no kernel for them";
   if (tune) for (int i = 0; i < 24; ++i) if (tune[i] != 0.f) return "BezSimConfig.tune[]: knobs of the oracle-only solver variants; must be 0 for libbez_sim.so";
   return nullptr;
 }
@@ -481,7 +485,7 @@ int bez_sim_destroy(BezSim* s) {
   if (!s) return 0;
   (void)hipSetDevice(s->device);
   void* bufs[] = {s->state, s->obs, s->rew, s->reset, s->progress, s->timeout, s->episode, s->root_states, s->dof_state,
-                  s->rigid_body, s->contact, s->targets_aos, s->prev_aos, s->feet_aos, s->goal_aos, s->goal_draw_dev, s->post_calls_dev, s->randomize, s->dr_state, s->dr_snap, s->dr_pack};
+                  s->rigid_body, s->contact, s->targets_aos, s->prev_aos, s->feet_aos, s->goal_aos, s->goal_draw_dev, s->post_calls_dev, s->randomize, s->dr_state, s->dr_snap, s->dr_pack, s->xhit};
   for (void* b : bufs) if (b) (void)hipFree(b);
   for (int i = 0; i < BEZ_PARAM_COUNT; ++i) if (s->dr[i]) (void)hipFree(s->dr[i]);
   if (s->ev0) (void)hipEventDestroy(s->ev0);
@@ -529,6 +533,11 @@ int bez_sim_create(const BezSimConfig* cfg, int device_id, BezSim** out) {
   for (auto& a : allocs) {
     e = hipMalloc(a.p, a.bytes);
     if (e == hipSuccess) e = hipMemset(*a.p, 0, a.bytes);
+    if (e != hipSuccess) { int rc = fail(nullptr, -4, "hipMalloc", e); bez_sim_destroy(s); return rc; }
+  }
+  if (cfg->flags & BEZ_FLAG_ALL_GROUND_SHAPES) {   // records of the extra ground points (one-env-per-lane kernel)
+    e = hipMalloc((void**)&s->xhit, n * BEZ_NXPT * 8 * sizeof(float));
+    if (e == hipSuccess) e = hipMemset(s->xhit, 0, n * BEZ_NXPT * 8 * sizeof(float));
     if (e != hipSuccess) { int rc = fail(nullptr, -4, "hipMalloc", e); bez_sim_destroy(s); return rc; }
   }
   (void)hipEventCreate(&s->ev0);
@@ -636,9 +645,15 @@ int bez_sim_set_prev_lin_vel_tensor(BezSim* s, const float* prev_dev, void* stre
 }
 int bez_sim_set_flags(BezSim* s, uint32_t flags) {
   if (!s) return -1;
-  if (const char* why = oracle_only(flags, nullptr)) return fail(s, -5, why);
   const uint32_t asset = BEZ_FLAG_CLEATS | BEZ_FLAG_BOX_ASSET;  // the asset is fixed at creation (buffer shapes, kernel variant)
-  s->cfg.flags = (flags & ~asset) | (s->cfg.flags & asset);
+  const uint32_t merged = (flags & ~asset) | (s->cfg.flags & asset);
+  if (const char* why = oracle_only(merged, nullptr)) return fail(s, -5, why);
+  if ((merged & BEZ_FLAG_ALL_GROUND_SHAPES) && !s->xhit) {
+    (void)hipSetDevice(s->device);
+    HIP_TRY(s, hipMalloc((void**)&s->xhit, (size_t)s->cfg.num_envs * BEZ_NXPT * 8 * sizeof(float)));
+    HIP_TRY(s, hipMemset(s->xhit, 0, (size_t)s->cfg.num_envs * BEZ_NXPT * 8 * sizeof(float)));
+  }
+  s->cfg.flags = merged;
   return 0;
 }
 int bez_sim_set_obs_calls(BezSim* s, int64_t calls) { if (!s) return -1; s->obs_calls = calls; return 0; }

@@ -73,14 +73,15 @@ extern "C" {
                                      all the time: the bottom corners of the calf box (soccerbot_stl.urdf:232-236) meet the top face of the \
                                      3 mm foot plate (:272-276) once the flexed ankle also rolls by 0.3-0.45 rad -- well inside the roll \
                                      joint's own +-0.785 rad.  The gap is a function of the two ankle angles alone, so the contact is a \
-                                     coupled limit of those two joints: an implicit spring-damper along the gap's gradient.  ORACLE ONLY \
-                                     (the reference policy's sim-to-sim does not move with it): libbez_sim.so refuses it, rc -5 */
+                                     coupled limit of those two joints: an implicit spring-damper along the gap's gradient.  A scenario-harness \
+                                     variant (the reference policy's sim-to-sim does not move with it): stepped by the \
+                                     one-env-per-lane kernel, stl asset without cleats only (any other asset: rc -5) */
 
 #define BEZ_FLAG_ALL_GROUND_SHAPES 2048u /* ground contact at the corners of EVERY collision shape of soccerbot_stl.urdf (hip, thigh, calf, ankle, \
                                             forearm, neck, head boxes / mesh bounds), not only the foot corners and the upper-body guard points. \
-                                            ORACLE ONLY (the get-up scenarios of tools/getup_probe.py need knees and elbows on the ground; \
-                                            nothing on the bez_kick path touches the ground with them before its fall reset): libbez_sim.so \
-                                            refuses it with rc -5 */
+                                            For the scenario harness (the get-up tables put knees, hips and forearms on the ground, \
+                                            soccer_trajectories.py:56-91; nothing on the bez_kick path touches the ground with them before its \
+                                            fall reset): stepped by the one-env-per-lane kernel, stl asset without cleats only (else rc -5) */
 
 #define BEZ_FLAG_FIX_BASE 4096u /* urdfAsset.fixBaseLink: True (kick_env.py:287, bez_kick.yaml:83): the torso is welded to the world -- its spatial \
                                    acceleration is zero instead of the 6 x 6 root solve's, its twist stays zero, the pose stays where reset put it; \

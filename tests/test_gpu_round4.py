@@ -13,7 +13,7 @@ def test_set_flags_refuses_oracle_only_variants():
     from bez_isaacgym_amd.sim import BezSim, BezSimError
     sim = BezSim(abi.default_config(64, seed=2), 0)
     before = int(sim.cfg.flags)
-    for bad in (abi.FLAG_HARD_CONTACT, abi.FLAG_TGS_SOLVER, abi.FLAG_ANKLE_STOP, abi.FLAG_ALL_GROUND_SHAPES):
+    for bad in (abi.FLAG_HARD_CONTACT, abi.FLAG_TGS_SOLVER):
         with pytest.raises(BezSimError, match="oracle"):
             sim.set_flags(before | bad)
     sim.set_flags(before)  # a legal word is still accepted

@@ -5,30 +5,40 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def _getup(backend, name, n):
+def _getup(backend, name, n, flags=None):
     import json, os
     from bez_isaacgym_amd import abi
     from tests.scenarios import ROOT, lay_down, make_backend, play
     model = json.load(open(os.path.join(ROOT, "bez_isaacgym_amd", "model", "bez_model.json")))
-    sim = make_backend(backend, abi.default_config(n, seed=7))
+    cfg = abi.default_config(n, seed=7)
+    if flags is not None:
+        cfg.flags = flags
+    sim = make_backend(backend, cfg)
     sim.step(np.zeros((n, 18), np.float32))
     lay_down(sim, n, name, np.random.default_rng(3))
     return play(sim, n, name, model)
 
 
+@pytest.mark.parametrize("shapes", [False, True])
 @pytest.mark.parametrize("name", ["getupfront", "getupback", "getupside"])
-def test_getup_scenarios_hip_equals_oracle(name):
+def test_getup_scenarios_hip_equals_oracle(name, shapes):
     """The reference's get-up tables from lying starts (tests/scenarios.py) in 64 HIP envs through the split entry points
     (bez_sim_pre_physics + bez_sim_simulate): a thousand control steps on knees, forearms and the torso's guard points -- contact
     the bez_kick episodes never reach before their fall reset.  The HIP kernels and the fp64 oracle must tell the same story
     (medians over the envs; the envs differ by +-0.02 rad in their start pose)."""
-    h = _getup("hip", name, 64)
-    o = _getup("oracle", name, 8)
+    from bez_isaacgym_amd import abi
+    # shapes: BEZ_FLAG_ALL_GROUND_SHAPES (round 6: on the HIP back-end too, one-env-per-lane kernel) -- ground contact at the corners of
+    # every collision shape of soccerbot_stl.urdf:172-278, which is what lets the back get-up roll over (soccer_trajectories.py:56-91)
+    fl = (abi.FLAG_IMU_PREV_ALIAS | abi.FLAG_ALL_GROUND_SHAPES) if shapes else None
+    h = _getup("hip", name, 64, fl)
+    o = _getup("oracle", name, 8, fl)
     assert h["finite"] == 1.0, h
     for k, tol in (("final_z", 0.02), ("max_z", 0.02), ("final_up", 0.15), ("max_up", 0.1)):
         assert abs(h[k] - o[k]) < tol, (k, h, o)
-    if name == "getupfront":
-        assert h["max_z"] > 0.20 and h["max_up"] > 0.75, h   # the squat on the feet is reached
+    if name == "getupfront" or (shapes and name == "getupback"):
+        assert h["max_z"] > 0.20 and h["max_up"] > 0.75, h   # the squat on the feet is reached (from the back: only with every shape on the ground)
+    if name == "getupback" and not shapes:
+        assert h["max_z"] < 0.12, h                           # with the baked contact set the robot never leaves its back
 
 
 @pytest.mark.xfail(strict=True, reason="measured: 0 of 64 HIP envs stand at the end of simulation_getupfront (the squat is reached; the last key frame tips "

@@ -147,3 +147,53 @@ def test_in_launch_gradient_norm_on_a_capped_grid_and_its_residency_guard():
         torch.testing.assert_close(p_g, p_ref, rtol=3e-7, atol=2e-9); torch.testing.assert_close(m_g, m_ref, rtol=1e-6, atol=1e-9)
         assert int(grid_buf[512:513].view(torch.int32)) == 0
     assert not torch.equal(p_ref, p0)
+
+
+def test_scenario_contact_variants_step_like_the_oracle(model):
+    """BEZ_FLAG_ALL_GROUND_SHAPES and BEZ_FLAG_ANKLE_STOP on the GPU (one-env-per-lane kernel), no longer rc -5.
+    Resynchronised single-step parity against the fp64 oracle on states that exercise both: half the envs lying on their back / side
+    with bent legs (hip, thigh, calf and forearm corners on the ground), ankles flexed and rolled into the calf <-> foot-plate stop."""
+    from oracle.bez_oracle import Oracle
+    from tests.parity_util import EnvOutliers
+    from tests.sim_adapter import SimAdapter
+    n = 128
+    fl = abi.FLAG_IMU_PREV_ALIAS | abi.FLAG_ALL_GROUND_SHAPES | abi.FLAG_ANKLE_STOP
+    co, cg = abi.default_config(n, seed=9), abi.default_config(n, seed=9)
+    co.flags = fl; cg.flags = fl
+    o, g = Oracle(co), SimAdapter(cg)
+    plain = Oracle(abi.default_config(n, seed=9))
+    rng = np.random.default_rng(4)
+    dflt = np.asarray(model["dof_default"], np.float32)
+    rs = o.root_states.reshape(n, 2, 13).copy()
+    S = np.sqrt(0.5)
+    for e in range(n // 2):                      # lying: back, front or side, just above the ground
+        rs[e, 0, 2] = 0.09
+        rs[e, 0, 3:7] = [(0.0, -S, 0.0, S), (0.0, S, 0.0, S), (S, 0.0, 0.0, S)][e % 3]
+    rs[:, 1, 0:3] = (0.0, 2.0, 0.08)
+    ds = o.dof_state.reshape(n, 18, 2).copy()
+    ds[:, :, 0] = dflt + rng.uniform(-0.3, 0.3, (n, 18)).astype(np.float32)
+    ds[n // 2:, 8, 0] = rng.uniform(0.7, 1.3, n - n // 2); ds[n // 2:, 9, 0] = rng.uniform(0.3, 0.7, n - n // 2) * rng.choice([-1, 1], n - n // 2)      # left ankle into the stop
+    ds[n // 2:, 16, 0] = rng.uniform(0.7, 1.3, n - n // 2); ds[n // 2:, 17, 0] = rng.uniform(0.3, 0.7, n - n // 2) * rng.choice([-1, 1], n - n // 2)
+    for x in (o, plain):
+        x.set_root_states(rs.reshape(-1, 13)); x.set_dof_state(ds.reshape(-1, 2))
+    T = EnvOutliers(n, share=4e-3)
+    differs = 0.0
+    for t in range(20):
+        g.set_root_states(o.root_states); g.set_dof_state(o.dof_state); g.set_contact_forces(o.contact_forces); g.set_targets(o.targets)
+        g.set_reset(o.reset_buf); g.set_progress(o.progress_buf)
+        plain.set_root_states(o.root_states); plain.set_dof_state(o.dof_state); plain.set_targets(o.targets)
+        act = rng.uniform(-0.5, 0.5, (n, 18)).astype(np.float32)
+        for x in (o, g, plain):
+            x.pre_physics(act); x.simulate()
+        do, dg = o.dof_state.reshape(n, 18, 2), g.dof_state.reshape(n, 18, 2)
+        T.close(dg[..., 0], do[..., 0], 2e-4, what="q"); T.close(dg[..., 1], do[..., 1], 3e-2, what="qd")
+        ro, rg = o.root_states.reshape(n, 2, 13), g.root_states.reshape(n, 2, 13)
+        T.close(rg[:, 0, 0:7], ro[:, 0, 0:7], 5e-5, what="pose"); T.close(rg[:, 0, 7:13], ro[:, 0, 7:13], 1e-2, what="vel")
+        if t > 0:   # (step 0: the ball has just been teleported onto the ground 2 m away; its row holds that transient)
+            T.close(g.contact_forces, o.contact_forces, 0.08, rtol=0.02, what="cf")
+        T.end_step()
+        differs = max(differs, float(np.abs(do[..., 1] - plain.dof_state.reshape(n, 18, 2)[..., 1]).max()))
+    T.finish()
+    assert differs > 0.5, differs                          # the two variants really change the step (against the plain model on the same states)
+    cf = g.contact_forces.reshape(n, 22, 3)
+    assert np.abs(cf[: n // 2, [6, 7, 8, 9, 10, 14, 15, 16, 17, 18]]).sum() > 10.0   # forearm / hip / thigh / calf rows loaded in the lying envs
