@@ -274,15 +274,6 @@ BEZ_DEV void leg_role(const Params& P, float* lds, int lane, int e, bool active,
   ws_barrier();  // B0: actions staged, root/ball and the leg joint state published
   WS_STAMP(side, 1);
   load_targets<FIRST, LEN, PRE, false>(P, lds, lane, e, target);
-#ifdef BEZ_W8_TARGET_RELOAD
-  // the six position targets are only read once per substep (pass 2): they go to their state rows NOW (where the epilogue would store them
-  // anyway) and are re-fetched inside the loop next to their use instead of living in registers through passes 1-3 (the leg roles sit at the
-  // 256-VGPR ceiling).  The store and the loads are this lane's own addresses: program order holds.
-  if (PRE && active) {
-#pragma unroll
-    for (int i = 0; i < LEN; ++i) P.state[(size_t)(F_TARGET + FIRST - 1 + i) * P.n + e] = target[i];
-  }
-#endif
   for (int s = 0; s < P.substeps; ++s) {
     const bool keep = last_only ? (s == P.substeps - 1) : true;
     const bool first = last_only ? true : (s == 0);
@@ -327,22 +318,8 @@ BEZ_DEV void leg_role(const Params& P, float* lds, int lane, int e, bool active,
     } else {
       sel.link = -1;
     }
-#ifndef BEZ_W8_NO_Q_RELOAD
-    // the leg's joint state lives in its X_LEGQ slots between the passes (published there for the helper roles anyway): re-read here, the
-    // twelve registers are free across the barrier and the phase behind it
-#pragma unroll
-    for (int i = 0; i < LEN; ++i) { q[i] = XS(X_LEGQ + side * 12 + i); qd[i] = XS(X_LEGQ + side * 12 + 6 + i); }
-#endif
     P3 p3[LEN];
     Sym6 IA = sym6zero(); SV pA = svzero();
-#ifdef BEZ_W8_TARGET_RELOAD
-    {   // (requested right behind B1; the foot joint's terms, which need target[5] first, come ~400 instructions later)
-      int ei = e;
-      asm volatile("" : "+v"(ei));
-#pragma unroll
-      for (int i = 0; i < LEN; ++i) target[i] = P.state[(size_t)(F_TARGET + FIRST - 1 + i) * P.n + ei];
-    }
-#endif
     ws_chain_pass2<FIRST, LEN, true>(P, D, kps, kds, lo, hi, q, qd, target, LI, pAl, Sl, cbl, Kc, pc, mine, sel, p3, IA, pA);
     {  // the chain's articulated inertia goes to its X_IA block NOW (free since B1: the staged actions are consumed): 21 registers
        // less across the barrier and the correction below; the bias follows once the leg<->leg share is in it
@@ -358,12 +335,10 @@ BEZ_DEV void leg_role(const Params& P, float* lds, int lane, int e, bool active,
     WS_STAMP(side, 5 + 8 * s);
     ws_barrier();  // B3: torso acceleration published
     WS_STAMP(side, 6 + 8 * s);
-#ifndef BEZ_W8_NO_Q_RELOAD
-    // the leg's joint state lives in its X_LEGQ slots between the passes (published there for the helper roles anyway): re-read here, the
-    // twelve registers are free across the barrier and the phase behind it
+    // the leg's joint state is re-read from its X_LEGQ slots (published there for the helper roles anyway): the twelve registers are free
+    // across pass 2's tail, the correction and the root solve -- the leg role then compiles without spilled VGPRs (tools/role_resources.sh)
 #pragma unroll
     for (int i = 0; i < LEN; ++i) { q[i] = XS(X_LEGQ + side * 12 + i); qd[i] = XS(X_LEGQ + side * 12 + 6 + i); }
-#endif
     SV a0 = xs_load_sv(lds, lane, X_A0);
     V3 fl = mk(0, 0, 0), fend = mk(0, 0, 0);
     SV aend = ws_chain_pass3<FIRST, LEN, true, CL>(P, a0, p3, q, qd, mine, sel, fl, fend, lds, lane, keep, first, sc);
@@ -385,12 +360,6 @@ BEZ_DEV void leg_role(const Params& P, float* lds, int lane, int e, bool active,
     WS_STAMP(side, 8 + 8 * s);
   }
   // joint-side post-physics in the window of the root's last ball update (needs nothing the ball publishes)
-#ifndef BEZ_W8_NO_Q_RELOAD
-  // the leg's joint state lives in its X_LEGQ slots between the passes (published there for the helper roles anyway): re-read here, the
-  // twelve registers are free across the barrier and the phase behind it
-#pragma unroll
-  for (int i = 0; i < LEN; ++i) { q[i] = XS(X_LEGQ + side * 12 + i); qd[i] = XS(X_LEGQ + side * 12 + 6 + i); }
-#endif
   ws_chain_epilogue<(FIRST == 5 ? 0 : 1), POST>(P, lds, lane, e, active, do_reset, episode, q, qd, target);
   WS_STAMP(side, 21);
   ws_barrier();  // B5 of the last substep = the last barrier: contact rows, staged observation rows and pose-error sums complete

@@ -602,13 +602,11 @@ BEZ_DEV void joint_terms(const Params& P, float kp_scale, float kd_scale, float 
   g = frcp(Dj);
   w = (tau - sp) * g;
   qdd_hp = fmaf(-ucb, g, w);
-#ifndef BEZ_AB_NO_VLIM
   // v_pred = qd + h qdd_hp beyond +-vel_limit  <=>  qdd_hp outside [alo, ahi], the accelerations that reach the limits in one substep
   const float ahi = (P.vel_limit - qd) * P.inv_h, alo = (-P.vel_limit - qd) * P.inv_h;
   const float fix = fminf(fmaxf(qdd_hp, alo), ahi);
   const bool lock = fix != qdd_hp;
   w = lock ? fix : w; g = lock ? 0.f : g; qdd_hp = fix;
-#endif
 }
 
 // sums of the leg<->leg contact scale (oracle: self_contact_scale), accumulated joint by joint while the legs run pass 2
