@@ -24,11 +24,27 @@
 #pragma once
 #include "bez_kernels.h"
 
+// BEZ_WS_SUB (bez_step_ws8q.hip defines it as 4): lanes per env.  1 = the production kernel above (namespace w8).  4 = the lane-group
+// form (namespace w8q): lane l works on env l / 4 of a 16-env workgroup (256 workgroups at 4096 envs: every CU of the chip), the four
+// lanes of a quad split the 6 x 6 work of the legs' recursion between them (quad_perm DPP) and run whatever is not split redundantly --
+// the LDS slot of a lane stays its own (stride WS_LANES), so a quad's four copies are private and the roles' hand-overs are unchanged.
+#ifndef BEZ_WS_SUB
+#define BEZ_WS_SUB 1
+#endif
 namespace bez {
+#if BEZ_WS_SUB == 1
 namespace w8 {
+#else
+namespace w8q {
+#endif
 
 constexpr int WS_BLOCK = 512;
-constexpr int WS_ENVS = 64;
+constexpr int WS_SUB = BEZ_WS_SUB;        // lanes per env
+constexpr int WS_LANES = 64;              // lanes per wave = stride of an LDS slot
+constexpr int WS_ENVS = WS_LANES / WS_SUB;  // envs per workgroup
+static_assert(WS_SUB == 1 || WS_SUB == 4, "one lane or one quad per env");
+constexpr int WS_SUB_SHIFT = WS_SUB == 4 ? 2 : 0, WS_ENV_SHIFT = 6 - WS_SUB_SHIFT;
+BEZ_DEV constexpr int ws_env_of(int lane) { return lane >> WS_SUB_SHIFT; }   // workgroup-local env of a lane
 
 enum : int {
   X_ROOT = 0,      // pos3 quat4 lin3 ang3
@@ -70,7 +86,7 @@ template <bool CL> BEZ_DEV constexpr int cand_lo_end() { return CL ? 6 : 5; }
 constexpr int X_CANDF = X_HIT;
 constexpr int X_STAGE = X_IA;  // staging aliases the chain blocks (see the header comment)
 constexpr int WS_ACT_STRIDE = 19;
-constexpr int WS_LDS_FLOATS = X_SLOTS * WS_ENVS;
+constexpr int WS_LDS_FLOATS = X_SLOTS * WS_LANES;
 static_assert(WS_LDS_FLOATS * 4 <= 160 * 1024, "LDS budget");
 static_assert(5 * 27 >= 54 && 5 * 27 >= WS_ACT_STRIDE, "staging fits the aliased block");
 
@@ -240,7 +256,7 @@ BEZ_DEV void load_joint_params(const Params& P, int e, float* kps, float* kds, f
 template <int FIRST, int NJ, bool PRE, bool HEAD>
 BEZ_DEV void load_targets(const Params& P, const float* lds, int lane, int e, float* target) {
   if (PRE) {
-    const float* act = lds + X_STAGE * WS_ENVS + lane * WS_ACT_STRIDE;
+    const float* act = lds + X_STAGE * WS_LANES + ws_env_of(lane) * WS_ACT_STRIDE;
 #pragma unroll
     for (int i = 0; i < NJ; ++i) {
       constexpr int d0 = FIRST - 1;
@@ -517,7 +533,7 @@ BEZ_DEV void post_imu_orn(const Params& P, float* lds, int lane, int e, bool act
   }
   float tail[8];
   obs_imu_orn(P, root_pos, rq, lin, ang, prev, goal_x, goal_y, tail);
-  float* obs_row = lds + X_STAGE * WS_ENVS + lane * P.nobs;
+  float* obs_row = lds + X_STAGE * WS_LANES + ws_env_of(lane) * P.nobs;
 #pragma unroll
   for (int i = 0; i < 8; ++i) obs_row[36 + i] = tail[i];
   if (active && !P.lean) {
@@ -547,7 +563,7 @@ BEZ_DEV void post_feet(const Params& P, float* lds, int lane, int e, bool active
   }
   float feet[8], tail[18];
   obs_feet(P, co, CL ? cleats : nullptr, feet, tail);
-  float* obs_row = lds + X_STAGE * WS_ENVS + lane * P.nobs;
+  float* obs_row = lds + X_STAGE * WS_LANES + ws_env_of(lane) * P.nobs;
 #pragma unroll
   for (int i = 8; i < 18; ++i) if (36 + i < P.nobs) obs_row[36 + i] = tail[i];
   if (!CL) {  // the no-cleats feet logic filters the two foot rows in place (kick_env.py:987-990)
@@ -778,19 +794,20 @@ __global__ __launch_bounds__(WS_BLOCK) void step_kernel_ws8(Params P) {
   const int role = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int env0 = blockIdx.x * WS_ENVS;
   const int nloc = min(WS_ENVS, P.n - env0);
-  const bool active = lane < nloc;
-  const int e = env0 + (active ? lane : 0);  // inactive lanes shadow env0 (loads only; every global store is guarded)
+  const bool valid = ws_env_of(lane) < nloc;
+  const int e = env0 + (valid ? ws_env_of(lane) : 0);  // inactive lanes shadow env0 (loads only; every global store is guarded)
+  const bool active = valid && ((lane & (WS_SUB - 1)) == 0);   // the lane that stores its env's results (a quad's lanes hold the same ones)
   WS_STAMP(role, 22);
   if (PRE) {
     // coalesced stage of this workgroup's contiguous (nloc,18) action block, transposed to [lane][19]
-    float* act = lds + X_STAGE * WS_ENVS;
+    float* act = lds + X_STAGE * WS_LANES;
     const float* src = P.actions + (size_t)env0 * BEZ_ND;
     for (int i = tid; i < nloc * BEZ_ND; i += WS_BLOCK) act[(i / BEZ_ND) * WS_ACT_STRIDE + (i % BEZ_ND)] = src[i];
   }
-  if (tid < 2) reinterpret_cast<int*>(lds + X_PAIRSEQ * WS_ENVS)[tid] = 0;   // (published before B0)
+  if (tid < 2) reinterpret_cast<int*>(lds + X_PAIRSEQ * WS_LANES)[tid] = 0;   // (published before B0)
   // contact-force rows start from zero: bodies nothing touches are never accumulated into
   constexpr int NROW = (nb_of<CL>() + 1) * 3;  // contact-force rows of this asset (robot bodies + ball)
-  for (int i = tid; i < NROW * WS_ENVS; i += WS_BLOCK) lds[X_CF * WS_ENVS + i] = 0.f;
+  for (int i = tid; i < NROW * WS_LANES; i += WS_BLOCK) lds[X_CF * WS_LANES + i] = 0.f;
   WS_STAMP(role, 18);
 #ifdef BEZ_AB_ONLY_ROLE   // offline diagnostics (tools/role_resources.sh): the register / spill figures of ONE role's code; never launched
   if (BEZ_AB_ONLY_ROLE == 0) leg_role<5, PRE, POST, DR, CL>(P, lds, lane, e, active, 0);
@@ -820,10 +837,10 @@ __global__ __launch_bounds__(WS_BLOCK) void step_kernel_ws8(Params P) {
       // net contact force: SoA rows of 64 consecutive envs each -> coalesced
       float* dst = P.state + (size_t)F_CF * P.n + env0;
       static_assert(NT % WS_ENVS == 0, "a copy-out thread stays on one env lane");
-      const bool zero = POST && lds[X_RESETF * WS_ENVS + (ctid & 63)] != 0.f;  // env reset by this step: no contact forces
+      const bool zero = POST && lds[X_RESETF * WS_LANES + ((ctid & (WS_ENVS - 1)) << WS_SUB_SHIFT)] != 0.f;  // env reset by this step: no contact forces
       for (int i = ctid; i < NROW * WS_ENVS; i += NT) {
-        const int k = i >> 6, l = i & 63;
-        if (l < nloc) dst[(size_t)k * P.n + l] = zero ? 0.f : lds[(X_CF + k) * WS_ENVS + l];
+        const int k = i >> WS_ENV_SHIFT, l = i & (WS_ENVS - 1);
+        if (l < nloc) dst[(size_t)k * P.n + l] = zero ? 0.f : lds[(X_CF + k) * WS_LANES + (l << WS_SUB_SHIFT)];
       }
     }
     if (DR && POST && P.dr_snap && blockIdx.x == 0 && ctid == 0) {   // the next step's action-noise parameters: a copy (bez_kernels.h DrSnap)
@@ -832,13 +849,13 @@ __global__ __launch_bounds__(WS_BLOCK) void step_kernel_ws8(Params P) {
     }
     if (POST) {
       // the staged rows are the contiguous (nloc,nobs) image of this workgroup's slice of obs_buf: 16-byte copy-out
-      const float4* rows = reinterpret_cast<const float4*>(lds + X_STAGE * WS_ENVS);
+      const float4* rows = reinterpret_cast<const float4*>(lds + X_STAGE * WS_LANES);
       float4* dst = reinterpret_cast<float4*>(P.obs + (size_t)env0 * P.nobs);  // 64 * nobs * 4 B per workgroup: 16-B aligned for 54 and 52
       const int nvec = (nloc * P.nobs) >> 2;
       if (DR && P.obs_noise) {
         // the observation noise of the domain randomisation rides on the copy-out (one Philox block per 16-byte vector, spread over
         // the seven copying waves) instead of a launch of its own behind the step: the same bits as bez_sim_add_dr_noise would add
-        const long long q0 = ((long long)env0 * P.nobs) >> 2;   // env0 is a multiple of 64: the workgroup's block starts on a vector
+        const long long q0 = ((long long)env0 * P.nobs) >> 2;   // env0 is a multiple of 16: the workgroup's block starts on a vector
         const float mean = P.dr_state->noise[0], sd = P.dr_state->noise[1];
         const unsigned long long frame = P.dr_state->frame;
         for (int i = ctid; i < nvec; i += NT) {
@@ -849,10 +866,10 @@ __global__ __launch_bounds__(WS_BLOCK) void step_kernel_ws8(Params P) {
           dst[i] = v;
         }
         for (int i = (nvec << 2) + ctid; i < nloc * P.nobs; i += NT)
-          P.obs[(size_t)env0 * P.nobs + i] = obs_with_noise(P, (long long)env0 * P.nobs + i, lds[X_STAGE * WS_ENVS + i]);
+          P.obs[(size_t)env0 * P.nobs + i] = obs_with_noise(P, (long long)env0 * P.nobs + i, lds[X_STAGE * WS_LANES + i]);
       } else {
         for (int i = ctid; i < nvec; i += NT) dst[i] = rows[i];
-        for (int i = (nvec << 2) + ctid; i < nloc * P.nobs; i += NT) P.obs[(size_t)env0 * P.nobs + i] = lds[X_STAGE * WS_ENVS + i];
+        for (int i = (nvec << 2) + ctid; i < nloc * P.nobs; i += NT) P.obs[(size_t)env0 * P.nobs + i] = lds[X_STAGE * WS_LANES + i];
       }
     }
   }
@@ -860,5 +877,5 @@ __global__ __launch_bounds__(WS_BLOCK) void step_kernel_ws8(Params P) {
 }
 
 #undef XS
-}  // namespace w8
+}  // namespace w8 / w8q
 }  // namespace bez

@@ -83,11 +83,11 @@ def test_ws_kernel_post_physics_pinned_against_lane_kernel(task, asset):
     assert resets + (a.progress_buf < 30).sum() > 0  # resets really happened inside the window
 
 
-@pytest.mark.parametrize("other", ["lane"])
+@pytest.mark.parametrize("other", ["lane", "ws8q"])
 @pytest.mark.parametrize("variant", ["kick", "kick_cleats", "walk", "kick_box", "orient", "orient_cleats", "walk_box"])
 def test_fused_step_kernels_agree(other, variant, monkeypatch):
-    """The two implementations of the fused control step -- 8 role waves (default) and one env per lane (BEZ_SIM_KERNEL=lane) --
-    compute the same physics in a different order.  From an identical state, with the same actions, resynchronised every step:
+    """The implementations of the fused control step -- 8 role waves (default), the same with four lanes per env (BEZ_SIM_KERNEL=ws8q,
+    16-env workgroups) and one env per lane (BEZ_SIM_KERNEL=lane) -- compute the same physics in a different order.  From an identical state, with the same actions, resynchronised every step:
     integers exact, fp32 quantities to a few ulp of their scale.  N is not a multiple of the 64-env workgroup."""
     from tests.sim_adapter import SimAdapter
     from tests.test_tasks import make_cfg
