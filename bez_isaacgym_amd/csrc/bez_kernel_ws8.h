@@ -98,6 +98,9 @@ BEZ_DEV constexpr bool self_part_owns(int part, int ia, int) { return (part == 0
 BEZ_DEV constexpr int self_fk_depth(int part, int side) { return (part == 0 && side == 0) ? 4 : 6; }
 
 #include "bez_ws_common.inc"
+#if BEZ_WS_SUB == 4
+#include "bez_ws_quad.inc"
+#endif
 
 BEZ_DEV void xs_load_sym6(const float* lds, int lane, int slot, Sym6& I, SV& p) {
   float* f = (float*)&I;
@@ -334,6 +337,21 @@ BEZ_DEV void leg_role(const Params& P, float* lds, int lane, int e, bool active,
     } else {
       sel.link = -1;
     }
+#if BEZ_WS_SUB == 4
+    // lane-group form (bez_ws_quad.inc): the quad's lanes hold one 3 x 3 block of the articulated inertia each
+    const Quad Q = quad_of(lane);
+    P3q p3[LEN];
+    V3 pA;
+    {
+      Blk M;
+      wq_chain_pass2<FIRST, LEN>(P, Q, kps, kds, lo, hi, q, qd, target, LI, pAl, Sl, cbl, Kc, pc, mine, sel, p3, M, pA);
+#pragma unroll
+      for (int i = 0; i < 9; ++i) XS(X_IA + side * 27 + i) = M.m[i];   // the block, in the quad's layout (wq_add_leg_block)
+    }
+    WS_STAMP(side, 24 + s);
+    ws_barrier();  // B1c: both helper parts' leg<->leg contact wrenches are in LDS
+    const float sc = wq_chain_self_correction<LEN>(P, Q, lds, lane, side, s + 1, p3, pA, X_IA + side * 27 + 9);
+#else
     P3 p3[LEN];
     Sym6 IA = sym6zero(); SV pA = svzero();
     ws_chain_pass2<FIRST, LEN, true>(P, D, kps, kds, lo, hi, q, qd, target, LI, pAl, Sl, cbl, Kc, pc, mine, sel, p3, IA, pA);
@@ -346,6 +364,7 @@ BEZ_DEV void leg_role(const Params& P, float* lds, int lane, int e, bool active,
     WS_STAMP(side, 24 + s);
     ws_barrier();  // B1c: both helper parts' leg<->leg contact wrenches are in LDS
     const float sc = ws_chain_self_correction<LEN>(P, lds, lane, side, s + 1, p3, pA);   // (stores the bias part of the chain's X_IA block)
+#endif
     WS_STAMP(side, 4 + 8 * s);
     ws_barrier();  // B2
     WS_STAMP(side, 5 + 8 * s);
@@ -355,9 +374,13 @@ BEZ_DEV void leg_role(const Params& P, float* lds, int lane, int e, bool active,
     // across pass 2's tail, the correction and the root solve -- the leg role then compiles without spilled VGPRs (tools/role_resources.sh)
 #pragma unroll
     for (int i = 0; i < LEN; ++i) { q[i] = XS(X_LEGQ + side * 12 + i); qd[i] = XS(X_LEGQ + side * 12 + 6 + i); }
-    SV a0 = xs_load_sv(lds, lane, X_A0);
     V3 fl = mk(0, 0, 0), fend = mk(0, 0, 0);
+#if BEZ_WS_SUB == 4
+    SV aend = wq_chain_pass3<FIRST, LEN, CL>(P, Q, p3, q, qd, mine, sel, fl, fend, lds, lane, keep, first, sc);
+#else
+    SV a0 = xs_load_sv(lds, lane, X_A0);
     SV aend = ws_chain_pass3<FIRST, LEN, true, CL>(P, a0, p3, q, qd, mine, sel, fl, fend, lds, lane, keep, first, sc);
+#endif
     if (mine && sel.link >= 0) { xs_store_v3(lds, lane, X_FL, fl); xs_store_v3(lds, lane, X_FL + 3, sel.xb); }
     if (keep) {
       if constexpr (CL) {  // the foot plate only feels the ball / the other leg; the ground acts on the four cleats
@@ -705,8 +728,13 @@ BEZ_DEV void root_role(const Params& P, float* lds, int lane, int e, bool active
     ws_barrier();  // B1c
     ws_barrier();  // B2: chain contributions published
     WS_STAMP(3, 5 + 8 * s);
+#if BEZ_WS_SUB == 4
+    wq_add_leg_block(lds, lane, X_IA, IA0, pA0); wq_add_leg_block(lds, lane, X_IA + 27, IA0, pA0);   // the legs' blocks, gathered from the quad's columns
+    xs_add_sym6(lds, lane, X_IA + 2 * 27, IA0, pA0);                                                   // head + arms, summed by role 4
+#else
 #pragma unroll
     for (int k = 0; k < 3; ++k) xs_add_sym6(lds, lane, X_IA + k * 27, IA0, pA0);  // legs + (head + arms, summed by role 4)
+#endif
     SV a0 = solve_spd6(IA0, svzero() - pA0);
     xs_store_sv(lds, lane, X_A0, a0);
     WS_STAMP(3, 4 + 8 * s);

@@ -609,6 +609,36 @@ BEZ_DEV void joint_terms(const Params& P, float kp_scale, float kd_scale, float 
   w = lock ? fix : w; g = lock ? 0.f : g; qdd_hp = fix;
 }
 
+// The scalar part of joint_terms for the lane-group kernel (bez_step_ws8q.hip), which forms Jraw = S.(IA S), sp = S.pA and
+// ucb = (IA S).cb across a quad of lanes; the same arithmetic in the same order as above.
+template <int L>
+BEZ_DEV void joint_scalar(const Params& P, float kp_scale, float kd_scale, float lo, float hi, float q, float qd, float target, float Jraw, float sp, float ucb,
+                          float& g, float& w, float& qdd_hp) {
+  float J = Jraw + P.armature;
+  float kp = P.kp * kp_scale, kdm = P.kd * kd_scale;
+  float tau_pd0 = fmaf(kp, target - q - P.h * qd, -kdm * qd);
+  float k_pd = fmaf(P.h * P.h, kp, P.h * kdm);
+  float cf = P.jfric * frcp(fmaxf(fabsf(qd), P.jf_veps));
+  float k_f = P.h * cf, tau_f0 = -cf * qd;
+  float k_l = 0.f, tau_l0 = 0.f;
+  if (q < lo) { tau_l0 = fmaf(P.lim_k, lo - q - P.h * qd, -P.lim_d * qd); k_l = fmaf(P.h * P.h, P.lim_k, P.h * P.lim_d); }
+  else if (q > hi) { tau_l0 = fmaf(P.lim_k, hi - q - P.h * qd, -P.lim_d * qd); k_l = fmaf(P.h * P.h, P.lim_k, P.h * P.lim_d); }
+  float bias = sp + ucb;
+  float qdd_est = (tau_pd0 + tau_f0 + tau_l0 - bias) * frcp(J + k_pd + k_f + k_l);
+  float tau_drive = fmaf(-k_pd, qdd_est, tau_pd0);
+  float tau, Dj;
+  if (tau_drive > P.effort) { tau = P.effort + tau_f0 + tau_l0; Dj = J + k_f + k_l; }
+  else if (tau_drive < -P.effort) { tau = -P.effort + tau_f0 + tau_l0; Dj = J + k_f + k_l; }
+  else { tau = tau_pd0 + tau_f0 + tau_l0; Dj = J + k_pd + k_f + k_l; }
+  g = frcp(Dj);
+  w = (tau - sp) * g;
+  qdd_hp = fmaf(-ucb, g, w);
+  const float ahi = (P.vel_limit - qd) * P.inv_h, alo = (-P.vel_limit - qd) * P.inv_h;
+  const float fix = fminf(fmaxf(qdd_hp, alo), ahi);
+  const bool lock = fix != qdd_hp;
+  w = lock ? fix : w; g = lock ? 0.f : g; qdd_hp = fix;
+}
+
 // sums of the leg<->leg contact scale (oracle: self_contact_scale), accumulated joint by joint while the legs run pass 2
 struct SelfSums { float am, as, f2; };
 BEZ_DEV float self_scale(const Params& P, const SelfSums& Z) {

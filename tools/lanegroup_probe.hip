@@ -326,6 +326,82 @@ __global__ __launch_bounds__(64) void chain_lane_group(Inputs in, float* __restr
   if (threadIdx.x == 0) cycles[blockIdx.x] = t1 - t0;
 }
 
+// ------------------------------------------------------------------------------------------------ mapping D (round 6)
+// Four lanes per env, no MFMA: the 6x6 as 2x2 blocks of 3x3, lane (r, c) = quad lane 2r + c holds block (r, c) in full (9 registers)
+// and the row half r of pA.  U_r = sum_c M_rc S_c is one quad_perm [1,0,3,2] add per component, the two scalars S.U and S.pA one
+// quad_perm [2,3,0,1] add each, the column half of U for the rank-1 update comes from the other row pair (quad_perm [2,3,0,1]).
+// DPP only -- no LDS round trip (mapping B's ds_swizzle), no MFMA pipeline hop (mapping C).
+__device__ __forceinline__ float qp_flip_c(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true)); }
+__device__ __forceinline__ float qp_flip_r(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true)); }
+constexpr int NQ = 9 + 3 + 3 + 3 + 3 + 1;   // floats per (joint, lane): its block of LI, pAl_r, S_c, S_r, cb_c, tau
+__global__ __launch_bounds__(64) void chain_quad(Inputs in, float* __restrict__ out, unsigned long long* __restrict__ cycles, int reps) {
+  __shared__ float sh[NJ][NQ][64];
+  const int lane = threadIdx.x, sub = lane & 3, r = sub >> 1, c = sub & 1;
+  const int e = blockIdx.x * 16 + (lane >> 2), ee = e < in.n ? e : 0;
+  for (int j = 0; j < NJ; ++j) {
+    const size_t b = (size_t)j * in.n + ee;
+    for (int i = 0; i < 3; ++i) {
+      for (int k = 0; k < 3; ++k) sh[j][i * 3 + k][lane] = in.LI[b * 36 + (3 * r + i) * 6 + 3 * c + k];
+      sh[j][9 + i][lane] = in.pAl[b * 6 + 3 * r + i];
+      sh[j][12 + i][lane] = in.S[b * 6 + 3 * c + i];
+      sh[j][15 + i][lane] = in.S[b * 6 + 3 * r + i];
+      sh[j][18 + i][lane] = in.cb[b * 6 + 3 * c + i];
+    }
+    sh[j][21][lane] = in.tau[b];
+  }
+  __syncthreads();
+  const bool diag = r == c;
+  float M[9], pA[3];
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  for (int rep = 0; rep < reps; ++rep) {
+#pragma unroll
+    for (int k = 0; k < 9; ++k) M[k] = 0.f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) pA[k] = 0.f;
+#pragma unroll
+    for (int j = NJ - 1; j >= 0; --j) {
+      float Sc[3], Sr[3], cbc[3];
+#pragma unroll
+      for (int k = 0; k < 9; ++k) M[k] += sh[j][k][lane];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { pA[k] += sh[j][9 + k][lane]; Sc[k] = sh[j][12 + k][lane]; Sr[k] = sh[j][15 + k][lane]; cbc[k] = sh[j][18 + k][lane]; }
+      float u[3];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) { const float s = fmaf(M[3 * i], Sc[0], fmaf(M[3 * i + 1], Sc[1], M[3 * i + 2] * Sc[2])); u[i] = s + qp_flip_c(s); }
+      float d = fmaf(Sr[0], u[0], fmaf(Sr[1], u[1], Sr[2] * u[2])), sp = fmaf(Sr[0], pA[0], fmaf(Sr[1], pA[1], Sr[2] * pA[2]));
+      d += qp_flip_r(d); sp += qp_flip_r(sp);
+      const float Dinv = __builtin_amdgcn_rcpf(d + in.arm), uD = (sh[j][21][lane] - sp) * Dinv;
+      float uc[3];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) { const float o = qp_flip_r(u[i]); uc[i] = diag ? u[i] : o; }
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        const float k = -u[i] * Dinv;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) M[3 * i + q] = fmaf(k, uc[q], M[3 * i + q]);
+      }
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        const float s = fmaf(M[3 * i], cbc[0], fmaf(M[3 * i + 1], cbc[1], M[3 * i + 2] * cbc[2]));
+        pA[i] += fmaf(u[i], uD, s + qp_flip_c(s));
+      }
+    }
+    asm volatile("" : "+v"(pA[0]));
+  }
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  float tot = 0.f;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) tot += M[k];
+  tot += qp_flip_c(tot); tot += qp_flip_r(tot);
+  if (e >= in.n) return;
+  if (c == 0) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) out[(size_t)e * 7 + 3 * r + i] = pA[i];
+  }
+  if (sub == 0) out[(size_t)e * 7 + 6] = tot;
+  if (threadIdx.x == 0) cycles[blockIdx.x] = t1 - t0;
+}
+
 // ------------------------------------------------------------------------------------------------ mapping C (round 5; north_star: "MFMA only if
 // the batched 6x6 spatial-inertia products prove worth it in rocprof")
 // FOUR lanes per env, sixteen envs per wave, the matrix padded to 8 x 8 as 2 x 2 blocks of 4 x 4: lane q of an env's group holds COLUMNS q and 4 + q
@@ -547,7 +623,8 @@ extern "C" int probe_joint_work(int mode, const float* links, int n, float* out,
 extern "C" int probe_run(int mapping, const float* LI, const float* pAl, const float* S, const float* cb, const float* tau, int n, float arm, float* out,
                          unsigned long long* cycles, int reps, void* stream) {
   Inputs in{LI, pAl, S, cb, tau, n, arm};
-  if (mapping == 4) hipLaunchKernelGGL(chain_mfma4, dim3((n + 15) / 16), dim3(64), 0, (hipStream_t)stream, in, out, cycles, reps);
+  if (mapping == 5) hipLaunchKernelGGL(chain_quad, dim3((n + 15) / 16), dim3(64), 0, (hipStream_t)stream, in, out, cycles, reps);
+  else if (mapping == 4) hipLaunchKernelGGL(chain_mfma4, dim3((n + 15) / 16), dim3(64), 0, (hipStream_t)stream, in, out, cycles, reps);
   else if (mapping == 3) hipLaunchKernelGGL(chain_one_lane_colpairs, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, in, out, cycles, reps);
   else if (mapping == 2) hipLaunchKernelGGL(chain_one_lane_packed, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, in, out, cycles, reps);
   else if (mapping == 0) hipLaunchKernelGGL(chain_one_lane, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, in, out, cycles, reps);

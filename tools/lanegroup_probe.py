@@ -36,7 +36,7 @@ arm = 1e-3
 
 def run(mapping, reps):
     out = torch.zeros(n, 7, device=dev)
-    nwg = (n + 7) // 8 if mapping == 1 else ((n + 15) // 16 if mapping == 4 else (n + 63) // 64)
+    nwg = (n + 7) // 8 if mapping == 1 else ((n + 15) // 16 if mapping in (4, 5) else (n + 63) // 64)
     cyc = torch.zeros(nwg, dtype=torch.int64, device=dev)
     args = (mapping, vp(LI.data_ptr()), vp(pAl.data_ptr()), vp(S.data_ptr()), vp(cb.data_ptr()), vp(tau.data_ptr()), n, arm, vp(out.data_ptr()), vp(cyc.data_ptr()), reps, None)
     for _ in range(3):
@@ -68,7 +68,8 @@ res = {}
 for mapping, name in ((0, "A  one lane per env (symmetric 6x6 in 21 registers)"), (1, "B  eight lanes per env (row per lane, DPP sums, ds_swizzle broadcasts)"),
                       (2, "A2 one lane per env, packed fp32 (full 6x6 as 18 register pairs, v_pk_fma_f32)"),
                       (3, "A3 one lane per env, column pairs + op_sel broadcasts (no moves, no horizontal adds)"),
-                      (4, "C  four lanes per env, 8x8 as 2x2 blocks of 4x4, rank-1 update on v_mfma_f32_4x4x1_16B_f32")):
+                      (4, "C  four lanes per env, 8x8 as 2x2 blocks of 4x4, rank-1 update on v_mfma_f32_4x4x1_16B_f32"),
+                      (5, "D  four lanes per env, 2x2 blocks of 3x3, quad_perm DPP only")):
     out, cyc, us = run(mapping, REPS)
     err = float((out.double() - want).abs().max() / want.abs().max())
     res[mapping] = (cyc, us)
@@ -85,6 +86,9 @@ print("column pairs with op_sel broadcasts: %.0f -> %.0f cycles per chain = x%.2
 c4 = np.median(res[4][0])
 print("MFMA rank-1 update, four lanes per env: %.0f -> %.0f cycles per chain = x%.2f; waves needed for 64 envs: 1 -> 4; chip-level %.1f -> %.1f us per %d chains" % (
     a, c4, a / c4, res[0][1], res[4][1], REPS))
+c5 = np.median(res[5][0])
+print("quad blocks with quad_perm DPP, four lanes per env: %.0f -> %.0f cycles per chain = x%.2f; waves needed for 64 envs: 1 -> 4; chip-level %.1f -> %.1f us per %d chains" % (
+    a, c5, a / c5, res[0][1], res[5][1], REPS))
 
 # ---- the per-(env, joint) work of pass 2 that is NOT the recursion: one lane per env over six joints vs one lane per (env, joint)
 lib.probe_joint_work.argtypes = [C.c_int, vp, C.c_int, vp, vp, C.c_int, vp]

@@ -63,3 +63,25 @@ for r in range(ROUNDS):
         e1.record(); torch.cuda.synchronize()
         res[k].append(e0.elapsed_time(e1) * 1e3 / STEPS)
 for k in res: print("%-12s %s  mean %.3f us" % (k, " ".join("%.3f" % x for x in res[k]), float(np.mean(res[k]))), flush=True)
+
+# the other kernel variants: cleats asset (per-env parameter loads compiled in), walk task
+for label, kw in (("cleats", dict(cleats=True)), ("walk", dict(task="bez_walk")), ("box", dict(box=True))):
+    sims = []
+    for kern in ("ws8", "ws8q"):
+        os.environ["BEZ_SIM_KERNEL"] = kern
+        cfg = make_cfg(N, seed=5, **kw); cfg.flags |= abi.FLAG_LEAN_STEP
+        h = C.c_void_p()
+        assert L.bez_sim_create(C.byref(cfg), 0, C.byref(h)) == 0
+        sims.append(("%s %s" % (kern, label), h))
+    os.environ.pop("BEZ_SIM_KERNEL", None)
+    res = {k: [] for k, _ in sims}
+    for r in range(ROUNDS):
+        for k, h in sims:
+            for t in range(100): L.bez_sim_step(h, C.c_void_p(acts[t % 64].data_ptr()), None)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for t in range(STEPS): L.bez_sim_step(h, C.c_void_p(acts[t % 64].data_ptr()), None)
+            e1.record(); torch.cuda.synchronize()
+            res[k].append(e0.elapsed_time(e1) * 1e3 / STEPS)
+    for k in res: print("%-14s %s  mean %.3f us" % (k, " ".join("%.3f" % x for x in res[k]), float(np.mean(res[k]))), flush=True)
