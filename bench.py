@@ -548,11 +548,14 @@ def main():
                        "lean_vs_full_what": "HIP event pairs over 4 x 100-step blocks each, interleaved, after the timed region (device time; the headline ms_per_step is wall clock)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "valu_frac": None if valu is None else valu["frac"], "valu": valu,
-                         "kernel": "bez::w8::step_kernel_ws8<true,true,false,false> (fused control step, default asset, 8 role waves per 64 envs)", "kernel_ms": kernel_ms,
+                         "kernel": {"ws8": "bez::w8::step_kernel_ws8<true,true,false,false> (fused control step, default asset, 8 role waves per 64 envs; BEZ_SIM_KERNEL=ws8)",
+                                    "lane": "bez::step_kernel<true,true,true,false,false> (one env per lane; BEZ_SIM_KERNEL=lane)"}.get(os.environ.get("BEZ_SIM_KERNEL", ""),
+                                    "bez::w8q::step_kernel_ws8<true,true,false,false> (fused control step, default asset, 8 role waves per 16 envs, four lanes per env)"),
+                         "kernel_ms": kernel_ms,
                          "algorithmic_bytes_per_launch": ALGO_BYTES_PER_ENV_STEP * n,
                          "traffic_unit": "bytes per launch (rocprofv3 FETCH_SIZE: instruction stream x1 + data x2, + WRITE_SIZE; source: profiles/%s)" % traffic_src
                                          if traffic is not None else "no committed PMC profile matches this build's source hash",
-                         "note": "N=4096 is latency-bound (64 workgroups x 8 role waves on 256 CUs, serial ABA chains): see DESIGN.md"},
+                         "note": "N=4096 is latency-bound (256 workgroups x 8 role waves, serial ABA chains; the instruction stream of a leg role sets the time): see DESIGN.md"},
         }
         if ppo is not None:
             out["ppo"] = ppo

@@ -94,7 +94,7 @@ def test_fused_step_kernels_agree(other, variant, monkeypatch):
     n = 200
     task = "bez_walk" if variant.startswith("walk") else ("bez_orient" if variant.startswith("orient") else "bez_kick")
     kw = dict(seed=31, task=task, cleats=variant.endswith("_cleats"), box=variant.endswith("_box"))
-    monkeypatch.delenv("BEZ_SIM_KERNEL", raising=False)
+    monkeypatch.setenv("BEZ_SIM_KERNEL", "ws8")
     a = SimAdapter(make_cfg(n, **kw))
     monkeypatch.setenv("BEZ_SIM_KERNEL", other)  # read once, at bez_sim_create
     b = SimAdapter(make_cfg(n, **kw))

@@ -156,7 +156,7 @@ def test_dr_noise_kernel_statistics_and_schedule():
     assert not torch.equal(a, c) and abs(float((a * c).mean())) < 2e-5
 
 
-@pytest.mark.parametrize("kernel,n", [("ws8", 4096), ("ws8", 200), ("lane", 256)])
+@pytest.mark.parametrize("kernel,n", [("ws8", 4096), ("ws8", 200), ("ws8q", 200), ("lane", 256)])
 def test_observation_noise_inside_the_step_equals_the_separate_launch(kernel, n, monkeypatch):
     """BEZ_FLAG_OBS_NOISE_IN_STEP: the post-physics part writes the noisy observations itself (the noise rides on the kernel's
     copy-out).  Two simulators with the same seed and randomisation, one with the flag, one adding the noise with
@@ -221,7 +221,7 @@ def test_lean_step_changes_nothing_the_rollout_reads():
     assert a.obs[:, 44:52].max() == 1.0 and a.obs[:, 44:52].min() == -1.0
 
 
-@pytest.mark.parametrize("kernel", ["ws8", "lane"])
+@pytest.mark.parametrize("kernel", ["ws8", "ws8q", "lane"])
 def test_free_flight_momentum_at_full_size(model, kernel, monkeypatch):
     """A size-independent property at BASELINE's full size (4096 envs) on the production kernel: in free flight (robot dropped from
     5 m, the ball parked far away) drives, joint friction and joint limits are INTERNAL forces -- whatever the 18 targets do, the

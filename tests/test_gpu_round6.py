@@ -36,7 +36,7 @@ def _inject(sim, n, model, seed):
     return acts, states
 
 
-@pytest.mark.parametrize("kernel", ["ws8", "lane"])
+@pytest.mark.parametrize("kernel", ["ws8", "ws8q", "lane"])
 def test_one_substep_with_locked_joints_needs_no_base_wrench(model, kernel, monkeypatch):
     """One substep (substeps = 1) from the pressed state on the GPU: the accelerations the state change implies, put into the
     independent RNEA, need no wrench on the floating base (fp32 state read back: 2e-2 N / N m of joint torques of 2.5 N m, contact
@@ -68,7 +68,7 @@ def test_one_substep_with_locked_joints_needs_no_base_wrench(model, kernel, monk
     assert (np.abs(cf[:, :21]).sum((1, 2)) > 1.0).mean() > 0.5
 
 
-@pytest.mark.parametrize("kernel", ["ws8", "lane"])
+@pytest.mark.parametrize("kernel", ["ws8", "ws8q", "lane"])
 def test_leg_press_hip_equals_oracle_and_stays_bounded(model, kernel, monkeypatch):
     """The scenario that broke the round-5 model, on the GPU: finite, momentum drift within the integrator's bound of the oracle test, and
     over the first control steps (before fp32 / fp64 trajectories of a chaotic scenario part) the same joint angles as the oracle."""
@@ -87,7 +87,7 @@ def test_leg_press_hip_equals_oracle_and_stays_bounded(model, kernel, monkeypatc
     assert abs(a["penetration"] - b["penetration"]) < 2e-3, (a, b)
 
 
-@pytest.mark.parametrize("kernel", ["ws8", "lane"])
+@pytest.mark.parametrize("kernel", ["ws8", "ws8q", "lane"])
 def test_self_contact_holds_the_legs_apart_hip(model, kernel, monkeypatch):
     """tests/test_oracle_round6.test_self_contact_holds_the_legs_apart on the GPU: steady, < 5 mm, the hip stopped by the other foot."""
     n = 64

@@ -38,11 +38,11 @@ def counter_mean(directory, counter, kernel_substr):
     return {"mean": sum(v) / len(v), "min": min(v), "max": max(v), "dispatches": len(v)}
 
 
-def kernel_code_bytes(kernel_mangled):
+def kernel_code_bytes(kernel_mangled, unit="bez_step_ws8.hip"):
     """codeLenInByte of one kernel: device-only assembly of its translation unit with the build's own flags."""
     import tempfile
     from bez_isaacgym_amd.build import _flags
-    src = os.path.join(ROOT, "bez_isaacgym_amd", "csrc", "bez_step_ws8.hip")
+    src = os.path.join(ROOT, "bez_isaacgym_amd", "csrc", unit)
     with tempfile.TemporaryDirectory() as d:
         out = os.path.join(d, "ws.s")
         flags = [f for f in _flags() if f != "-fPIC"]
@@ -59,15 +59,16 @@ def kernel_code_bytes(kernel_mangled):
 
 
 def size_sweep(directory, counter):
-    """mean counter value (KiB) per launch of the step kernel, by number of envs (grid size / 512 threads x 64 envs)."""
+    """mean counter value (KiB) per launch of the step kernel, by number of envs (grid size / 512 threads x the kernel's envs per workgroup)."""
     f = _one(os.path.join(directory, "**", "*counter_collection.csv"))
     if not f:
         return None
     acc = {}
     for row in csv.DictReader(open(f)):
         if row["Counter_Name"] == counter and KERNEL in row["Kernel_Name"]:
-            acc.setdefault(int(row["Grid_Size"]) // 512 * 64, {}).setdefault(row["Dispatch_Id"], 0.0)
-            acc[int(row["Grid_Size"]) // 512 * 64][row["Dispatch_Id"]] += float(row["Counter_Value"])
+            n = int(row["Grid_Size"]) // 512 * (16 if "w8q" in row["Kernel_Name"] else 64)   # envs per workgroup: 64 (ws8) / 16 (ws8q, four lanes per env)
+            acc.setdefault(n, {}).setdefault(row["Dispatch_Id"], 0.0)
+            acc[n][row["Dispatch_Id"]] += float(row["Counter_Value"])
     return {n: (lambda v: sum(v) / len(v))(list(d.values())[4:]) for n, d in sorted(acc.items())}
 
 
@@ -135,7 +136,9 @@ def main():
         per_env_raw = (sw_r[16384] - sw_r[4096]) * 1024 / (16384 - 4096)
         fixed_raw = (sw_r[4096] * 1024 - 4096 * per_env_raw) / 8
         mangled = kernel_name.split("(")[0] if kernel_name else None
-        code = kernel_code_bytes("_ZN3bez2w815step_kernel_ws8ILb1ELb1ELb0ELb0EEEvNS_6ParamsE")
+        quad = bool(kernel_name) and "w8q" in kernel_name
+        code = (kernel_code_bytes("_ZN3bez3w8q15step_kernel_ws8ILb1ELb1ELb0ELb0EEEvNS_6ParamsE", "bez_step_ws8q.hip") if quad
+                else kernel_code_bytes("_ZN3bez2w815step_kernel_ws8ILb1ELb1ELb0ELb0EEEvNS_6ParamsE"))
         att = {"FETCH_SIZE_KiB_by_num_envs": sw_r, "WRITE_SIZE_KiB_by_num_envs": sw_w,
                "fit": "raw FETCH_SIZE bytes = 8 XCDs x fixed + num_envs x per_env (from the 4096 and 16384 points)",
                "fixed_bytes_per_xcd_raw": fixed_raw, "kernel_codeLenInByte": code,

@@ -11,7 +11,7 @@ from bez_isaacgym_amd import abi
 
 
 def pair(n, **kw):
-    os.environ.pop("BEZ_SIM_KERNEL", None)
+    os.environ["BEZ_SIM_KERNEL"] = "ws8"
     a = SimAdapter(make_cfg(n, **kw))
     os.environ["BEZ_SIM_KERNEL"] = "ws8q"
     b = SimAdapter(make_cfg(n, **kw))
