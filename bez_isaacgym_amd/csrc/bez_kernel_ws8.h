@@ -24,10 +24,12 @@
 #pragma once
 #include "bez_kernels.h"
 
-// BEZ_WS_SUB (bez_step_ws8q.hip defines it as 4): lanes per env.  1 = the production kernel above (namespace w8).  4 = the lane-group
-// form (namespace w8q): lane l works on env l / 4 of a 16-env workgroup (256 workgroups at 4096 envs: every CU of the chip), the four
-// lanes of a quad split the 6 x 6 work of the legs' recursion between them (quad_perm DPP) and run whatever is not split redundantly --
-// the LDS slot of a lane stays its own (stride WS_LANES), so a quad's four copies are private and the roles' hand-overs are unchanged.
+// BEZ_WS_SUB: lanes per env.  1 (bez_step_ws8.hip, namespace w8): lane l of every role wave works on env l of a 64-env workgroup.
+// 4 (bez_step_ws8q.hip, namespace w8q; the default for the default asset without per-env parameters, bez_sim.hip kernel_from_env):
+// lane l works on env l / 4 of a 16-env workgroup -- 256 workgroups at 4096 envs, every CU of the chip -- and the four lanes of a
+// quad split the 6 x 6 work of the legs' passes between them (bez_ws_quad.inc: 2 x 2 blocks of 3 x 3, quad_perm DPP); whatever is
+// not split runs redundantly in the quad's lanes, whose LDS columns stay private (slot stride WS_LANES), so the roles' hand-overs
+// are the same in both forms.
 #ifndef BEZ_WS_SUB
 #define BEZ_WS_SUB 1
 #endif
