@@ -86,6 +86,9 @@ template <bool CL> BEZ_DEV constexpr int cand_lo_end() { return CL ? 6 : 5; }
 // The default asset has no cleat records: its kernels use the X_HIT slots for a third partial ball candidate per leg (the foot
 // box, tested by the leg role itself: 2 x 14 floats).
 constexpr int X_CANDF = X_HIT;
+// ... and, in the lane-group form, for the link packages the arm roles hand to the legs (bez_ws_quad.inc: 2 x 16 slots behind the candidates)
+constexpr int X_PKG = X_HIT + 28;
+static_assert(X_PKG + 32 <= X_HIT + 64, "packages fit the cleat records' slots");
 constexpr int X_STAGE = X_IA;  // staging aliases the chain blocks (see the header comment)
 constexpr int WS_ACT_STRIDE = 19;
 constexpr int WS_LDS_FLOATS = X_SLOTS * WS_LANES;
@@ -346,7 +349,7 @@ BEZ_DEV void leg_role(const Params& P, float* lds, int lane, int e, bool active,
     V3 pA;
     {
       Blk M;
-      wq_chain_pass2<FIRST, LEN>(P, Q, kps, kds, lo, hi, q, qd, target, LI, pAl, Sl, cbl, Kc, pc, mine, sel, p3, M, pA);
+      wq_chain_pass2<FIRST, LEN, (!CL && !DR)>(P, Q, lds, lane, side, s + 1, kps, kds, lo, hi, q, qd, target, LI, pAl, Sl, cbl, Kc, pc, mine, sel, p3, M, pA);
 #pragma unroll
       for (int i = 0; i < 9; ++i) XS(X_IA + side * 27 + i) = M.m[i];   // the block, in the quad's layout (wq_add_leg_block)
     }
@@ -502,6 +505,9 @@ BEZ_DEV void cand_arm_role(const Params& P, float* lds, int lane, int e, bool ac
     }
     WS_STAMP(ROLE, 2 + 8 * s);
     ws_barrier();  // B1
+#if BEZ_WS_SUB == 4
+    if constexpr (!CL && !DR) wq_produce_packages<LEG_FIRST>(P, in_loop(D).g, lds, lane, side, s + 1);   // the hip links' packages of this side's leg
+#endif
     C.up(P, in_loop(D), lds, lane);
     WS_STAMP(ROLE, 4 + 8 * s);
     ws_barrier();  // B1c: head and arm blocks are in LDS
@@ -613,7 +619,11 @@ BEZ_DEV void self_role(const Params& P, float* lds, int lane, int e, bool active
     {  // kinematics of both legs: one third in, meet the other roles at B5 of the previous substep (this role does not read the ball)
       const M3 E0 = quat_to_mat(XS(X_ROOT + 3), XS(X_ROOT + 4), XS(X_ROOT + 5), XS(X_ROOT + 6));
       const SV V0 = mksv(xs_load_v3(lds, lane, X_ROOT + 10), xs_load_v3(lds, lane, X_ROOT + 7));
+#if BEZ_WS_SUB == 4
+      ws_self_fk<PART, BEZ_W8_SELF_BAR, ((!CL && !DR) ? 1 - PART : -1)>(lds, lane, E0, V0, K, s > 0, quirk_rz<CL>(P.flags), in_loop(D).g);   // + the other leg's ankle / foot packages
+#else
       ws_self_fk<PART, BEZ_W8_SELF_BAR>(lds, lane, E0, V0, K, s > 0, quirk_rz<CL>(P.flags));
+#endif
       ws_self_pin<PART>(K);
     }
     WS_STAMP(6 + PART, 2 + 8 * s);
@@ -834,7 +844,7 @@ __global__ __launch_bounds__(WS_BLOCK) void step_kernel_ws8(Params P) {
     const float* src = P.actions + (size_t)env0 * BEZ_ND;
     for (int i = tid; i < nloc * BEZ_ND; i += WS_BLOCK) act[(i / BEZ_ND) * WS_ACT_STRIDE + (i % BEZ_ND)] = src[i];
   }
-  if (tid < 2) reinterpret_cast<int*>(lds + X_PAIRSEQ * WS_LANES)[tid] = 0;   // (published before B0)
+  if (tid < (WS_SUB == 4 ? 4 : 2)) reinterpret_cast<int*>(lds + X_PAIRSEQ * WS_LANES)[tid] = 0;   // (published before B0; words 2 / 3: the package hand-over of the lane-group form)
   // contact-force rows start from zero: bodies nothing touches are never accumulated into
   constexpr int NROW = (nb_of<CL>() + 1) * 3;  // contact-force rows of this asset (robot bodies + ball)
   for (int i = tid; i < NROW * WS_LANES; i += WS_BLOCK) lds[X_CF * WS_LANES + i] = 0.f;
