@@ -57,7 +57,8 @@ enum : int {
   X_CAND = 40,     // per leg: depth, link, n(3), P(3), V(6) of its deepest ball/box candidate among the lower boxes (roles 4 / 5) = 14 x 2
   X_TORSO = 68,    // depth of the torso-box candidate (role 3)
   X_SELFF2 = 69,   // per helper part: sum of |force|^2 over its active leg<->leg pairs (2)
-  X_PAIRSEQ = 71,  // lanes 0 / 1 of this slot: the two leg waves' sequence words (ws_pair_publish); 72..80 unused
+  X_PAIRSEQ = 71,  // lanes 0 / 1 of this slot: the two leg waves' sequence words (ws_pair_publish); lanes 2 / 3: the package hand-over of the lane-group form
+  X_SPARE = 72,    // 72..80 unused (lane-group form: the torso's contact rows across the root solve, 72..76)
   X_LEGQ = 81,     // per leg: q(6) qd(6) at the start of the substep (read by the helper roles)
   X_SELF = 105,    // 2 helper parts x [per leg box link (left 5, right 5): bias wrench (6) + reported force (3)] = 2 x 90
   X_CF = 285,      // net contact force rows, up to BEZ_NBE_MAX = 30 bodies (mean over substeps)
@@ -512,11 +513,17 @@ BEZ_DEV void cand_arm_role(const Params& P, float* lds, int lane, int e, bool ac
     WS_STAMP(ROLE, 4 + 8 * s);
     ws_barrier();  // B1c: head and arm blocks are in LDS
     if (ROLE == 4) {
+#if BEZ_WS_SUB == 4
+      // (lane-group form: the root role reads the three inertia parts itself, behind B1c; only the biases are summed here)
+      const SV p2 = (xs_load_sv(lds, lane, X_IA + 2 * 27 + 21) + xs_load_sv(lds, lane, X_IA + 4 * 27 + 21)) + C.pAc;
+      xs_store_sv(lds, lane, X_IA + 2 * 27 + 21, p2);
+#else
       Sym6 I2; SV p2;
       xs_load_sym6(lds, lane, X_IA + 2 * 27, I2, p2);
       xs_add_sym6(lds, lane, X_IA + 4 * 27, I2, p2);
       add_to(I2, C.IAc); p2 = p2 + C.pAc;
       xs_store_sym6(lds, lane, X_IA + 2 * 27, I2, p2);
+#endif
     }
     ws_barrier();  // B2
     ws_barrier();  // B3
@@ -658,7 +665,11 @@ BEZ_DEV void root_role(const Params& P, float* lds, int lane, int e, bool active
   V3 ball_ang = mk(ld(F_BALL_ANG), ld(F_BALL_ANG + 1), ld(F_BALL_ANG + 2));
   // bookkeeping inputs of the post-physics, fetched now so that their latency hides behind the physics
   int64_t progress = 0, reset = 0;
+#if BEZ_WS_SUB == 4
+  // (lane-group form: fetched during the last substep instead -- four registers less across the physics, the kernel's last spilled value)
+#else
   if (POST) { progress = P.progress[e]; reset = P.reset[e]; }
+#endif
   const ChainDyn D = load_chain_dyn<DR>(P, e);
   float ms0 = 1.f;
   if (DR) { if (P.dr_mass) ms0 = P.dr_mass[(size_t)e * BEZ_NL]; }
@@ -672,9 +683,9 @@ BEZ_DEV void root_role(const Params& P, float* lds, int lane, int e, bool active
     xs_store_v3(lds, lane, X_BALL, ball_pos); xs_store_v3(lds, lane, X_BALL + 3, ball_lin); xs_store_v3(lds, lane, X_BALL + 6, ball_ang);
   };
   publish_root(); publish_ball();
-  WS_STAMP(3, 0);
+  WS_STAMP_ROOT_N(0, 3, 0);
   ws_barrier();  // B0
-  WS_STAMP(3, 1);
+  WS_STAMP_ROOT_N(1, 3, 1);
   // The ball is integrated one barrier late: its update needs the ball<->link force of pass 3 (published at B4), but only the
   // box tests of the NEXT substep need its result -- so the update runs at the top of the next iteration (and once after the
   // loop), beside the other roles' forward kinematics, and B5 sits in the middle of their pass-1 window.
@@ -702,7 +713,7 @@ BEZ_DEV void root_role(const Params& P, float* lds, int lane, int e, bool active
     if (s > 0) {
       ball_update(last_only ? false : true, last_only ? true : (s == 1));  // the previous substep's flags
       ws_barrier();  // B5 of the previous substep
-      WS_STAMP(3, 9 + 8 * (s - 1));
+      WS_STAMP_ROOT_N(2, 3, 9 + 8 * (s - 1));
     }
     const M3 E0 = quat_to_mat(rq[0], rq[1], rq[2], rq[3]);
     const SV V0 = mksv(root_ang, root_lin);
@@ -714,9 +725,9 @@ BEZ_DEV void root_role(const Params& P, float* lds, int lane, int e, bool active
     test_torso_box(P, E0, mk(0, 0, 0), bc, sel);
     XS(X_TORSO) = sel.depth;
     if (sel.link == 0) ball_link_contact(P, D.mu, ball_ang, ball_lin, ball, bc, V0, sel);
-    WS_STAMP(3, 2 + 8 * s);
+    WS_STAMP_ROOT_N(3, 3, 2 + 8 * s);
     ws_barrier();  // B1: all candidates are in LDS
-    WS_STAMP(3, 3 + 8 * s);
+    WS_STAMP_ROOT_N(4, 3, 3 + 8 * s);
     const CandDepths cd = load_cand_depths<CL>(lds, lane);
     const int winner = cand_winner(cd);
     torso_hit = (winner == 2) && (sel.link == 0);
@@ -732,27 +743,56 @@ BEZ_DEV void root_role(const Params& P, float* lds, int lane, int e, bool active
     link_inertia<0, CL>(ms0, D.g, E0, mk(0, 0, 0), V0, I0, pA0);
     Sym6 Kc = sym6zero(); SV pc = svzero();
     ws_ground_points<0, CL>(P, D.mu, root_pos.z, E0, mk(0, 0, 0), V0, Kc, pc);
+#if BEZ_WS_SUB == 4
+    {  // the torso's contact rows are only needed behind B3: parked in the spare slots 72..76 (word k in column k % 4 of the quad) so that they
+       // do not hold 18 registers across the factorisation below
+      const BodyContact b = body_contact_of(Kc, pc);
+      const float* f = (const float*)&b;
+      float* col = lds + (lane & ~3);
+#pragma unroll
+      for (int k = 0; k < 18; ++k) col[(X_SPARE + k / 4) * WS_LANES + (k & 3)] = f[k];
+    }
+#else
     BodyContact bc0 = body_contact_of(Kc, pc);
+#endif
     add_link_inertia(IA0, I0);
     add_to(IA0, Kc); pA0 = pA0 + pc;
     if (torso_hit) { add_point_stiffness(IA0, sel.x, sel.A); pA0 = pA0 - wrench_at(sel.x, sel.f0p); }
-    WS_STAMP(3, 24 + s);
+    WS_STAMP_ROOT_N(5, 3, 24 + s);
     ws_barrier();  // B1c
-    ws_barrier();  // B2: chain contributions published
-    WS_STAMP(3, 5 + 8 * s);
 #if BEZ_WS_SUB == 4
-    wq_add_leg_block(lds, lane, X_IA, IA0, pA0); wq_add_leg_block(lds, lane, X_IA + 27, IA0, pA0);   // the legs' blocks, gathered from the quad's columns
-    xs_add_sym6(lds, lane, X_IA + 2 * 27, IA0, pA0);                                                   // head + arms, summed by role 4
+    // every chain's articulated inertia is in LDS (the legs store theirs right behind pass 2; the leg<->leg correction that runs now
+    // changes the biases only): sum and FACTORISE while the legs are busy, so that only the two substitutions sit between B2 and B3
+    wq_add_leg_inertia(lds, lane, X_IA, IA0); wq_add_leg_inertia(lds, lane, X_IA + 27, IA0);   // gathered from the quad's columns
+#pragma unroll
+    for (int k = 2; k < 5; ++k) xs_add_inertia(lds, lane, X_IA + k * 27, IA0);                 // head, left arm, right arm (role 4 sums their biases only)
+    const Ldl6 F = ldl6_factor(IA0);
+    ws_barrier();  // B2: the biases are published
+    WS_STAMP_ROOT_N(6, 3, 5 + 8 * s);
+    wq_add_leg_bias(lds, lane, X_IA, pA0); wq_add_leg_bias(lds, lane, X_IA + 27, pA0);
+    pA0 = pA0 + xs_load_sv(lds, lane, X_IA + 2 * 27 + 21);
+    SV a0 = ldl6_solve(F, svzero() - pA0);
 #else
+    ws_barrier();  // B2: chain contributions published
+    WS_STAMP_ROOT_N(7, 3, 5 + 8 * s);
 #pragma unroll
     for (int k = 0; k < 3; ++k) xs_add_sym6(lds, lane, X_IA + k * 27, IA0, pA0);  // legs + (head + arms, summed by role 4)
-#endif
     SV a0 = solve_spd6(IA0, svzero() - pA0);
+#endif
     xs_store_sv(lds, lane, X_A0, a0);
-    WS_STAMP(3, 4 + 8 * s);
+    WS_STAMP_ROOT_N(8, 3, 4 + 8 * s);
     ws_barrier();  // B3
-    WS_STAMP(3, 6 + 8 * s);
+    WS_STAMP_ROOT_N(9, 3, 6 + 8 * s);
     fl_t = mk(0, 0, 0);
+#if BEZ_WS_SUB == 4
+    BodyContact bc0;
+    {
+      float* f = (float*)&bc0;
+      const float* col = lds + (lane & ~3);
+#pragma unroll
+      for (int k = 0; k < 18; ++k) f[k] = col[(X_SPARE + k / 4) * WS_LANES + (k & 3)];
+    }
+#endif
     if (torso_hit) fl_t = sel.f0p - mul(sel.A, point_of(a0, sel.x));
     if (keep) ws_cf_acc(lds, lane, 0, cf_along(P, fl_t, sel.n) + cf_ground(P, body_contact_force(bc0, a0)), P.cf_w, first);
     V3 vdot = a0.l + cross(root_ang, root_lin);
@@ -761,9 +801,12 @@ BEZ_DEV void root_role(const Params& P, float* lds, int lane, int e, bool active
     root_pos = fma3(root_lin, P.h, root_pos);
     quat_integrate(rq, root_ang, P.h);
     publish_root();  // the chains' next pass 1 starts right after B4
-    WS_STAMP(3, 7 + 8 * s);
+#if BEZ_WS_SUB == 4
+    if (POST && s == P.substeps - 1) { progress = P.progress[e]; reset = P.reset[e]; }
+#endif
+    WS_STAMP_ROOT_N(10, 3, 7 + 8 * s);
     ws_barrier();  // B4: ball<->link force published
-    WS_STAMP(3, 8 + 8 * s);
+    WS_STAMP_ROOT_N(11, 3, 8 + 8 * s);
   }
   {
     const bool keep_l = true, first_l = last_only ? true : (P.substeps == 1);
@@ -804,9 +847,9 @@ BEZ_DEV void root_role(const Params& P, float* lds, int lane, int e, bool active
     sv(F_BALL_LIN, ball_lin.x); sv(F_BALL_LIN + 1, ball_lin.y); sv(F_BALL_LIN + 2, ball_lin.z);
     sv(F_BALL_ANG, ball_ang.x); sv(F_BALL_ANG + 1, ball_ang.y); sv(F_BALL_ANG + 2, ball_ang.z);
   }
-  WS_STAMP(3, 19);
+  WS_STAMP_ROOT_N(12, 3, 19);
   ws_barrier();  // B5 of the last substep = the last barrier
-  WS_STAMP(3, 9 + 8 * (P.substeps - 1));
+  WS_STAMP_ROOT_N(13, 3, 9 + 8 * (P.substeps - 1));
   // The chain roles key their reset draw with P.episode[e] / P.reset[e], loaded before B4 and CONSUMED (hence waited for) before
   // this barrier; ws_barrier() itself does not wait for outstanding global loads (vmcnt), so the two words are only rewritten here,
   // behind the last barrier -- no reliance on the memory pipeline serving another wave's earlier load before this store.
@@ -822,7 +865,7 @@ BEZ_DEV void root_role(const Params& P, float* lds, int lane, int e, bool active
     reward_of(P, root_pos, rq, root_lin, root_ang, ball_pos, ball_lin, pn, orn, rew, reset, progress, goal_x, goal_y);
     if (active) { P.rew[e] = rew; P.reset[e] = reset; P.progress[e] = progress; P.timeout[e] = timeout; }
   }
-  WS_STAMP(3, 21);
+  WS_STAMP_ROOT_N(14, 3, 21);
 }
 
 // ---- the kernel.  grid = ceil(N / 64) workgroups of 512 threads.
@@ -872,7 +915,13 @@ __global__ __launch_bounds__(WS_BLOCK) void step_kernel_ws8(Params P) {
   // LDS.  The seven other waves copy them out while the root role is still busy with the reward.
   if (role != 3) {
     constexpr int NT = WS_BLOCK - 64;
+#if BEZ_WS_SUB == 4
+    // the thread index is formed again here (role is a scalar; the lane from mbcnt): carried from the kernel's head it is live across the
+    // root role's 256 registers and was the kernel's one spilled value -- with it gone the kernel needs no scratch memory at all
+    const int ctid = (role - (role > 3 ? 1 : 0)) * 64 + (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+#else
     const int ctid = tid - (role > 3 ? 64 : 0);
+#endif
     if (!P.lean) {
       // net contact force: SoA rows of 64 consecutive envs each -> coalesced
       float* dst = P.state + (size_t)F_CF * P.n + env0;
