@@ -36,7 +36,7 @@ struct BezSim {
   int64_t obs_calls = 0;  // compute_observations passes so far (quirk Q1: only the first sees prev = zeros)
   uint64_t post_calls = 0, reset_calls = 0;  // keys of the shared goal draw (bez_walk / bez_orient)
   bool cleats = false, has_ball = true;
-  int kernel = 0;  // fused-step kernel: 0 = chosen per launch (kernel_from_env), 1 = 8 role waves (bez_kernel_ws8.h), 3 = the same with four lanes per env (bez_step_ws8q.hip), 2 = one env per lane (bez_kernels.h)
+  int kernel = 0;  // fused-step kernel: 0 / 3 = 8 role waves, four lanes per env (bez_step_ws8q.hip, the default), 1 = 8 role waves, one lane per env (bez_kernel_ws8.h), 2 = one env per lane (bez_kernels.h)
   int nb = BEZ_NB, nbe = BEZ_NBE, nobs = BEZ_NUM_OBS, nact = 2;  // robot bodies, exported body rows, obs width, actors per env
   std::string err;
   // sim-owned device memory
@@ -368,12 +368,10 @@ __global__ void set_target_indexed_kernel(float* __restrict__ st, const float* _
   st[(size_t)(F_TARGET + j) * n + e] = src[(size_t)e * BEZ_ND + j];
 }
 
-// Kernel choice for launches that include the physics, fixed per sim at bez_sim_create from BEZ_SIM_KERNEL: "ws8" = the
-// 8-role-wave kernel (bez_kernel_ws8.h), "ws8q" = its lane-group form (four lanes per env, bez_step_ws8q.hip), "lane" = the
-// one-env-per-lane reference kernel (bez_kernels.h).  Unset: the faster of the two role-wave forms for the variant that is launched --
-// ws8q for the default asset without per-env parameters (26.99 against 27.57 us per step at 4096 envs, same box), ws8 for the variants
-// that carry the per-env parameter loads (cleats asset, domain randomisation: the lane-group form spills there, 34.8 against 32.8 us).
-// The two are held against each other by tests/test_gpu_round2.py.
+// Kernel choice for launches that include the physics, fixed per sim at bez_sim_create from BEZ_SIM_KERNEL: "ws8q" = the 8-role-wave
+// kernel in its lane-group form (four lanes per env, 16-env workgroups: bez_step_ws8q.hip) -- the default: 23.6 against 27.6 us per step
+// at 4096 envs for the default asset, level with the one-lane form for the cleats asset (32.7 / 32.8) and 1 % ahead on the randomised
+// PPO epoch; "ws8" = the one-lane form (bez_kernel_ws8.h, 64-env workgroups), "lane" = the one-env-per-lane reference kernel (bez_kernels.h).
 int kernel_from_env() {
   const char* v = std::getenv("BEZ_SIM_KERNEL");
   if (!v) return 0;
@@ -425,7 +423,7 @@ int launch_step(BezSim* s, const float* actions, hipStream_t stream, bool obs_on
     // configuration 0.8 % (26.56 -> 26.78 us, same box: six more spilled VGPRs in a kernel at its 256-register ceiling)
     // (the same holds for the scenario harness's contact variants, BEZ_FLAG_ALL_GROUND_SHAPES / BEZ_FLAG_ANKLE_STOP: one-env-per-lane kernel only)
     if (s->kernel != 2 && !(s->cfg.flags & (BEZ_FLAG_FIX_BASE | BEZ_FLAG_ALL_GROUND_SHAPES | BEZ_FLAG_ANKLE_STOP))) {
-      if (s->kernel == 3 || (s->kernel == 0 && !dr && !s->cleats)) bez::launch_step_ws8q(P, PRE, dr, s->cleats, stream);
+      if (s->kernel != 1) bez::launch_step_ws8q(P, PRE, dr, s->cleats, stream);
       else bez::launch_step_ws8(P, PRE, dr, s->cleats, stream);
       hipError_t e = hipGetLastError();
       if (e != hipSuccess) return fail(s, -2, "step_kernel_ws launch", e);
