@@ -36,7 +36,8 @@ struct BezSim {
   int64_t obs_calls = 0;  // compute_observations passes so far (quirk Q1: only the first sees prev = zeros)
   uint64_t post_calls = 0, reset_calls = 0;  // keys of the shared goal draw (bez_walk / bez_orient)
   bool cleats = false, has_ball = true;
-  int kernel = 0;  // fused-step kernel: 0 / 3 = 8 role waves, four lanes per env (bez_step_ws8q.hip, the default), 1 = 8 role waves, one lane per env (bez_kernel_ws8.h), 2 = one env per lane (bez_kernels.h)
+  int kernel = 0;  // fused-step kernel: 0 = by size (below), 3 = 8 role waves, four lanes per env (bez_step_ws8q.hip), 1 = 8 role waves, one lane per env (bez_kernel_ws8.h), 2 = one env per lane (bez_kernels.h)
+  int quad_max_envs = 4096;  // 16 envs x the device's CUs: up to here the lane-group form runs in one round of workgroups
   int nb = BEZ_NB, nbe = BEZ_NBE, nobs = BEZ_NUM_OBS, nact = 2;  // robot bodies, exported body rows, obs width, actors per env
   std::string err;
   // sim-owned device memory
@@ -369,9 +370,11 @@ __global__ void set_target_indexed_kernel(float* __restrict__ st, const float* _
 }
 
 // Kernel choice for launches that include the physics, fixed per sim at bez_sim_create from BEZ_SIM_KERNEL: "ws8q" = the 8-role-wave
-// kernel in its lane-group form (four lanes per env, 16-env workgroups: bez_step_ws8q.hip) -- the default: 23.6 against 27.6 us per step
-// at 4096 envs for the default asset, level with the one-lane form for the cleats asset (32.7 / 32.8) and 1 % ahead on the randomised
-// PPO epoch; "ws8" = the one-lane form (bez_kernel_ws8.h, 64-env workgroups), "lane" = the one-env-per-lane reference kernel (bez_kernels.h).
+// kernel in its lane-group form (four lanes per env, 16-env workgroups: bez_step_ws8q.hip), "ws8" = the one-lane form (bez_kernel_ws8.h,
+// 64-env workgroups), "lane" = the one-env-per-lane reference kernel (bez_kernels.h).  Unset: by size -- the lane-group form while its
+// workgroups fit the chip in one round (num_envs <= 16 x CUs = 4096 on MI355X: 23.6 against 27.6 us per step at 4096 envs, level for
+// the cleats asset, 1 % ahead on the randomised PPO epoch), the one-lane form beyond (8192 envs: 27.9 us against 44.9, the lane-group
+// form's second round; profiles/r06_ws_scale.txt).
 int kernel_from_env() {
   const char* v = std::getenv("BEZ_SIM_KERNEL");
   if (!v) return 0;
@@ -423,7 +426,7 @@ int launch_step(BezSim* s, const float* actions, hipStream_t stream, bool obs_on
     // configuration 0.8 % (26.56 -> 26.78 us, same box: six more spilled VGPRs in a kernel at its 256-register ceiling)
     // (the same holds for the scenario harness's contact variants, BEZ_FLAG_ALL_GROUND_SHAPES / BEZ_FLAG_ANKLE_STOP: one-env-per-lane kernel only)
     if (s->kernel != 2 && !(s->cfg.flags & (BEZ_FLAG_FIX_BASE | BEZ_FLAG_ALL_GROUND_SHAPES | BEZ_FLAG_ANKLE_STOP))) {
-      if (s->kernel != 1) bez::launch_step_ws8q(P, PRE, dr, s->cleats, stream);
+      if (s->kernel == 3 || (s->kernel == 0 && s->n <= s->quad_max_envs)) bez::launch_step_ws8q(P, PRE, dr, s->cleats, stream);
       else bez::launch_step_ws8(P, PRE, dr, s->cleats, stream);
       hipError_t e = hipGetLastError();
       if (e != hipSuccess) return fail(s, -2, "step_kernel_ws launch", e);
@@ -515,6 +518,10 @@ int bez_sim_create(const BezSimConfig* cfg, int device_id, BezSim** out) {
   if (cfg->task < BEZ_TASK_KICK || cfg->task > BEZ_TASK_ORIENT) { delete s; return fail(nullptr, -1, "bez_sim_create: unknown task"); }
   s->cleats = (cfg->flags & BEZ_FLAG_CLEATS) != 0;
   s->kernel = kernel_from_env();
+  {
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_id) == hipSuccess && cus > 0) s->quad_max_envs = 16 * cus;
+  }
   s->has_ball = cfg->task == BEZ_TASK_KICK;                    // walk_env.py / orient_env.py create no ball actor
   s->nb = s->cleats ? BEZ_NB_CL : BEZ_NB;
   s->nbe = s->nb + (s->has_ball ? 1 : 0);

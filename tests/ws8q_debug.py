@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""where ws8q and ws8 part: per step, the envs whose joint rates differ by more than 0.05 rad/s (resynchronised every step)"""
+"""where ws8q and ws8 part: per step, the envs whose joint rates differ by more than 0.05 rad/s (resynchronised every step), and what the
+fp64 oracle says about them (its joint rates, the margin of its closest speed-limit decision).  A diagnostic beside the parity tests
+(it uses the oracle, hence its place under tests/):   python tests/ws8q_debug.py"""
 import os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import numpy as np
