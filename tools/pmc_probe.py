@@ -3,6 +3,7 @@
 FETCH_SIZE (instruction fetch of a ~300 KB kernel into each XCD's L2, kernel arguments) separates from the per-env part.
   rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d OUT -- python3 tools/pmc_probe.py"""
 import os, sys
+os.environ.setdefault("BEZ_SIM_KERNEL", "ws8q")   # one kernel at every size (unset, the library switches to the one-lane form above 16 x CUs envs)
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import torch
 from bez_isaacgym_amd import abi
