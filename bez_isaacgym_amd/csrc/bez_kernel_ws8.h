@@ -837,7 +837,13 @@ BEZ_DEV void root_role(const Params& P, float* lds, int lane, int e, bool active
     }
   }
   if (active) {
+#if BEZ_WS_SUB == 4
+    int es = e;
+    asm volatile("" : "+v"(es));   // the store addresses are formed HERE: hoisted to the kernel's head (where the same fields are loaded) they were 22 spilled VGPRs
+    auto sv = [&](int f, float v) { st[(size_t)f * n + es] = v; };
+#else
     auto sv = [&](int f, float v) { st[(size_t)f * n + e] = v; };
+#endif
     sv(F_ROOT_POS, root_pos.x); sv(F_ROOT_POS + 1, root_pos.y); sv(F_ROOT_POS + 2, root_pos.z);
 #pragma unroll
     for (int i = 0; i < 4; ++i) { sv(F_ROOT_QUAT + i, rq[i]); sv(F_BALL_QUAT + i, bq[i]); }
