@@ -59,7 +59,11 @@ struct Args {
   Part part[MAX_PARTS];
   int nparts, nstage_total;                 // stages of KT rows in the whole reduction
   float* partial;
-  int wg_total, max_block, lds_bytes, pad;  // launch geometry (read by bez_ppo_wgrad_run on the host copy)
+  int wg_total, max_block, lds_bytes, grid; // launch geometry (read by bez_ppo_wgrad_run on the host copy); grid = workgroups launched (>= wg_total)
+  // XCD-aware placement (round 6): workgroup id -> (part, split).  The hardware deals workgroup ids round-robin over the 8 XCDs (id % 8), each
+  // with its own L2; the blocks of one layer re-read each other's operand columns (1.6 x the unique bytes), so the workgroups of a layer
+  // that stream the SAME rows at the same time are given ids of one XCD -- the second reader of a slice hits that XCD's L2.  0xff = no work.
+  unsigned char map_part[256], map_split[256];
 };
 static_assert(sizeof(Args) <= BEZ_PPO_WGRAD_PLAN_BYTES, "plan buffer of the C ABI too small");
 
@@ -229,10 +233,10 @@ __device__ __forceinline__ void wgrad_body(const Args& A, const Part& P, int spl
 __global__ void __launch_bounds__(WG_THREADS) wgrad_kernel(const Args* __restrict__ Ap) {
   extern __shared__ __attribute__((aligned(16))) _Float16 lds[];
   const Args& A = *Ap;
-  int pi = 0;
-  for (int i = 1; i < A.nparts; ++i) if ((int)blockIdx.x >= A.part[i].wg_begin) pi = i;   // (scalar: <= 24 entries)
+  const int pi = A.map_part[blockIdx.x];
+  if (pi == 0xff) return;   // (an id the placement left empty)
   const Part& P = A.part[pi];
-  const int split = (int)blockIdx.x - P.wg_begin;
+  const int split = A.map_split[blockIdx.x];
   const int tpw = (P.nt + WG_WAVES / P.mt - 1) / (WG_WAVES / P.mt);   // tile columns per wave of this block
   const int variant = (tpw <= 1 ? 0 : (tpw <= 4 ? 2 : 3)) * 16 + (P.gu == 8 ? 0 : (P.gu == 4 ? 1 : (P.gu == 2 ? 2 : 3))) * 4 + (P.xu == 8 ? 0 : (P.xu == 4 ? 1 : 2));
   // every (tiles per wave, dY unit, X unit) combination is its own straight-line instantiation
@@ -398,6 +402,7 @@ int bez_ppo_wgrad_plan(const void* const* dy_f16_dev, const void* const* x_f16_d
   int np = 0;
   size_t lds_bytes = 0;
   long long weight[MAX_PARTS], total_weight = 0, budget = 0;
+  int layer_of[MAX_PARTS];
   // fixed part of a stage (barrier, load latency) in column equivalents: measured, 32768 rows of bez_kickPPO.yaml's five layers:
   // 0 -> 61 us (the heads' few workgroups run 46 short stages each while the wide blocks finish 13), 64 -> 48, 128 -> 46, 512 -> 46
   const int stage_cost = 128;
@@ -428,6 +433,7 @@ int bez_ppo_wgrad_plan(const void* const* dy_f16_dev, const void* const* x_f16_d
         P.dst = dw_dev[L]; P.dst_ld = I;
         const size_t need = 2 * (size_t)KT * (P.gs + P.xs) * sizeof(_Float16) + WG_THREADS * 16;   // two LDS buffers + a scrap slot per thread
         if (need > lds_bytes) lds_bytes = need;
+        layer_of[np] = L;
         weight[np] = P.gcols + P.xcols + stage_cost;               // time of one stage of this block: columns streamed + a fixed part (barrier, load latency)
         total_weight += weight[np];
         ++np;
@@ -471,6 +477,33 @@ int bez_ppo_wgrad_plan(const void* const* dy_f16_dev, const void* const* x_f16_d
   if (used > budget) return -3;
   A.nparts = np; A.nstage_total = nstage; A.partial = partial_dev;
   A.wg_total = wg; A.max_block = max_block; A.lds_bytes = (int)lds_bytes;
+  {  // placement: per layer the workgroups in the order of the rows they start at (ties: by block), four consecutive ones to one XCD
+    struct W { int part, split; long long start; };
+    W order[256];
+    int n = 0;
+    for (int L = 0; L < nlayers; ++L) {
+      const int first = n;
+      for (int i = 0; i < np; ++i) if (layer_of[i] == L)
+        for (int k = 0; k < A.part[i].splits; ++k) order[n++] = W{i, k, (long long)k * nstage / A.part[i].splits};
+      for (int a = first + 1; a < n; ++a) {   // insertion sort (<= 256 entries): by first stage, then block
+        const W w = order[a];
+        int b = a - 1;
+        while (b >= first && (order[b].start > w.start || (order[b].start == w.start && order[b].part > w.part))) { order[b + 1] = order[b]; --b; }
+        order[b + 1] = w;
+      }
+    }
+    static const int xcd_aware = [] { const char* e = std::getenv("BEZ_WGRAD_XCD"); const int v = e ? std::atoi(e) : 4; return (v == 0 || v == 1 || v == 2 || v == 4 || v == 8 || v == 16 || v == 32) ? v : 4; }();   // (A/B knob: consecutive workgroups per XCD; 0 = ids in plan order)
+    std::memset(A.map_part, 0xff, sizeof(A.map_part)); std::memset(A.map_split, 0, sizeof(A.map_split));
+    int grid = 0;
+    for (int l = 0; l < n; ++l) {
+      int id = l;
+      if (xcd_aware) { const int G = xcd_aware, g = l / G, q = l % G, x = g % 8, slot = (g / 8) * G + q; id = slot * 8 + x; }   // G consecutive ones to one XCD
+      if (id >= 256) return -3;
+      A.map_part[id] = (unsigned char)order[l].part; A.map_split[id] = (unsigned char)order[l].split;
+      if (id + 1 > grid) grid = id + 1;
+    }
+    A.grid = grid;
+  }
   std::memset(plan_host, 0, BEZ_PPO_WGRAD_PLAN_BYTES);
   std::memcpy(plan_host, &A, sizeof(A));
   return 0;
@@ -492,7 +525,7 @@ int bez_ppo_wgrad_run(const void* plan_host, const void* plan_dev, int32_t accum
     if (hipFuncSetAttribute((const void*)wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return -2;
     attr_devices.fetch_or(bit, std::memory_order_release);
   }
-  hipLaunchKernelGGL(wgrad_kernel, dim3(H->wg_total), dim3(WG_THREADS), (size_t)H->lds_bytes, stream, D);
+  hipLaunchKernelGGL(wgrad_kernel, dim3(H->grid), dim3(WG_THREADS), (size_t)H->lds_bytes, stream, D);
   if (accumulate != 2)  // 2: the partial images only -- bez_ppo_grad_reduce_all adds them together with the step's other reductions
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((H->max_block + 255) / 256, H->nparts), dim3(256), 0, stream, D, (int)accumulate);
   return hipGetLastError() == hipSuccess ? 0 : -2;
