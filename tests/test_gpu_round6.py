@@ -197,3 +197,38 @@ def test_scenario_contact_variants_step_like_the_oracle(model):
     assert differs > 0.5, differs                          # the two variants really change the step (against the plain model on the same states)
     cf = g.contact_forces.reshape(n, 22, 3)
     assert np.abs(cf[: n // 2, [6, 7, 8, 9, 10, 14, 15, 16, 17, 18]]).sum() > 10.0   # forearm / hip / thigh / calf rows loaded in the lying envs
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("substeps", [1, 3, 4])
+def test_lane_group_kernel_at_other_substep_counts(substeps, monkeypatch):
+    """The lane-group kernel's hand-overs are ordered by sequence words that count substeps (leg <-> leg sums, link packages): the default
+    yaml runs 2; 1, 3 and 4 substeps step like the one-lane kernel too (resynchronised every step, the usual bars and outlier bookkeeping)."""
+    from tests.parity_util import EnvOutliers
+    from tests.test_tasks import make_cfg
+    n = 120
+
+    def cfg():
+        c = make_cfg(n, seed=17)
+        c.substeps = substeps
+        return c
+    a = _adapter(cfg(), "ws8", monkeypatch)
+    b = _adapter(cfg(), "ws8q", monkeypatch)
+    rng = np.random.default_rng(5)
+    T = EnvOutliers(n)
+    for t in range(25):
+        b.set_root_states(a.root_states); b.set_dof_state(a.dof_state); b.set_contact_forces(a.contact_forces)
+        b.set_targets(a.targets); b.set_reset(a.reset_buf); b.set_progress(a.progress_buf); b.set_prev_lin_vel(a.prev_lin_vel)
+        act = rng.uniform(-1, 1, (n, 18)).astype(np.float32)
+        a.step(act); b.step(act)
+        np.testing.assert_array_equal(b.progress_buf, a.progress_buf)
+        ra, rb = a.root_states, b.root_states
+        assert np.isfinite(rb).all()
+        T.close(rb[..., 0:7], ra[..., 0:7], 2e-5, what="pose")
+        T.close(rb[..., 7:13], ra[..., 7:13], 4e-3, what="vel")
+        da, db = a.dof_state.reshape(n, 18, 2), b.dof_state.reshape(n, 18, 2)
+        T.close(db[..., 0], da[..., 0], 1e-4, what="q")
+        T.close(db[..., 1], da[..., 1], 1.5e-2, what="qd")
+        T.close(b.contact_forces, a.contact_forces, 2.5e-2, rtol=4e-3, what="cf")
+        T.end_step()
+    T.finish()
